@@ -1,0 +1,223 @@
+"""CPU tests: pin the oracle (oracle/amm_oracle.c) against the reference's own known-answer
+energies (tests/golden/goldens.json, literals cited from /root/reference/tests) and check its
+analytic forces against central differences of its energies.  Tolerance vs the reference literals:
+rel 1e-6 (the reference's own pytest.approx default); observed agreement is 1e-12 or better except
+G3 (7e-9, ill-conditioned b = 19) and G8 (4.6e-8, PME vs exact Ewald)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+REL = 1e-6
+
+
+def near(adj, rc, rs, **kw):
+    return O.desc(O.ADJ[adj], rc=kw.pop('actual', rc), rc0=rc, rs0=rs, **kw)
+
+
+@pytest.mark.parametrize('gid,adj', [('G1', None), ('G2', 'shift'), ('G3', 'force-switch')])
+def test_near_goldens(spcfw, goldens, gid, adj):
+    c = spcfw
+    e, f, npairs = O.pair_eval(near(adj, 1.0, 0.95), c['positions'], c['box'], c['charge'], c['sigma'],
+                               c['epsilon'], c['exc_pairs'])
+    assert npairs == 314034                      # non-excluded pairs < 1.0 nm
+    assert e == pytest.approx(goldens[gid]['value'], rel=REL)
+    assert abs(f.sum(0)).max() < 1e-8            # Newton's third law
+
+
+@pytest.mark.parametrize('gid,degree', [('G4', 1), ('G5', 2)])
+def test_damped_goldens(spcfw, goldens, gid, degree):
+    c = spcfw
+    d = O.desc(O.DAMPED, rc=1.0, rswitch=0.95, alpha=2.9, degree=degree)
+    e, _, _ = O.pair_eval(d, c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'],
+                          want_forces=False)
+    assert e == pytest.approx(goldens[gid]['value'], rel=1e-12)
+
+
+def test_respa_near_golden_G6(spcfw, goldens):
+    c = spcfw
+    e, _, npairs = O.pair_eval(near('force-switch', 0.7, 0.5), c['positions'], c['box'], c['charge'],
+                               c['sigma'], c['epsilon'], c['exc_pairs'], want_forces=False)
+    assert npairs == 106161
+    assert e == pytest.approx(goldens['G6']['value'], rel=1e-11)
+    # group 31 = -step(rc0-r)*(near): same magnitude, opposite sign (tests/test_systems.py:145)
+    em, _, _ = O.pair_eval(near('force-switch', 0.7, 0.5, sign=-1.0, flags=O.GUARD_RC0), c['positions'], c['box'],
+                           c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'], want_forces=False)
+    assert em == pytest.approx(-goldens['G6']['value'], rel=1e-11)
+
+
+def test_ewald_direct_golden_G7_and_reciprocal_G8(spcfw, goldens):
+    c = spcfw
+    alpha = np.sqrt(-np.log(2 * 5e-4)) / 1.0       # OpenMM: alpha = sqrt(-ln(2 tol))/rc
+    d = O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, alpha=alpha, flags=O.COULOMB_EWALD | O.SWITCH)
+    e_dir, _, _ = O.pair_eval(d, c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'],
+                              want_forces=False)
+    e_exc, _ = O.ewald_exclusion(c['exc_pairs'], c['positions'], c['box'], c['charge'], alpha, want_forces=False)
+    e_disp = O.dispersion_correction(c['sigma'], c['epsilon'], c['box'], 1.0, 0.9)
+    assert e_dir + e_exc + e_disp == pytest.approx(goldens['G7']['value'], rel=1e-10)
+    e_rec, _ = O.ewald_reciprocal(c['positions'], c['box'], c['charge'], alpha, 14)
+    assert e_rec == pytest.approx(goldens['G8']['value'], rel=REL)
+
+
+def test_bonded_goldens(spcfw, heaq, goldens):
+    c = spcfw
+    eb, _ = O.harmonic_bonds(c['bonds'], c['bond_r0'], c['bond_k'], c['positions'], c['box'], want_forces=False)
+    ea, _ = O.harmonic_angles(c['angles'], c['angle_theta0'], c['angle_k'], c['positions'], c['box'], want_forces=False)
+    assert eb == pytest.approx(goldens['G_bonds']['value'], rel=REL)
+    assert ea == pytest.approx(goldens['G_angles']['value'], rel=REL)
+    ex, _ = O.ljc_bonds(c['exc_pairs'], c['exc_chargeprod'], c['exc_sigma'], c['exc_epsilon'], c['positions'],
+                        c['box'], want_forces=False)
+    assert ex == goldens['G_exc0']['value']
+    h = heaq
+    eb, _ = O.harmonic_bonds(h['bonds'], h['bond_r0'], h['bond_k'], h['positions'], h['box'], want_forces=False)
+    ea, _ = O.harmonic_angles(h['angles'], h['angle_theta0'], h['angle_k'], h['positions'], h['box'], want_forces=False)
+    et, _ = O.periodic_torsions(h['torsions'], h['torsion_n'], h['torsion_phase'], h['torsion_k'], h['positions'],
+                                h['box'], want_forces=False)
+    assert eb == pytest.approx(goldens['G_heaq_bonds']['value'], rel=REL)
+    assert ea == pytest.approx(goldens['G_heaq_angles']['value'], rel=REL)
+    assert et == pytest.approx(goldens['G_heaq_torsions']['value'], rel=REL)
+
+
+def solvation_respa_inputs(h, lambda_coul):
+    """What SolvationSystem (systems.py:261-313) + RESPASystem (systems.py:62-82) hand to the near force
+    and to the exceptions CustomBondForce for the HEAQ case (solute = residue 'aaa')."""
+    solute = np.where(h['resname'] == 'aaa')[0]
+    q = h['charge'].copy(); s = h['sigma'].copy(); e = h['epsilon'].copy()
+    q[solute] *= lambda_coul     # charge offset: 0 + lambda_coul*q  (systems.py:303,311)
+    s[solute] = 0.0; e[solute] = 0.0
+    have = {(int(a), int(b)) for a, b in h['exc_pairs']}
+    pairs = [tuple(p) for p in h['exc_pairs']]
+    qq = list(h['exc_chargeprod']); sg = list(h['exc_sigma']); ep = list(h['exc_epsilon'])
+    for i, j in itertools.combinations([int(a) for a in solute], 2):
+        if (i, j) not in have:
+            pairs.append((i, j)); qq.append(h['charge'][i] * h['charge'][j])
+            sg.append(0.5 * (h['sigma'][i] + h['sigma'][j])); ep.append(np.sqrt(h['epsilon'][i] * h['epsilon'][j]))
+    return q, s, e, np.array(pairs, dtype=np.int32), np.array(qq), np.array(sg), np.array(ep)
+
+
+def test_solvation_respa_goldens_G9_G10(heaq, goldens):
+    h = heaq
+    q, s, e, pairs, qq, sg, ep = solvation_respa_inputs(h, 0.5)
+    en, _, _ = O.pair_eval(near('force-switch', 0.7, 0.5), h['positions'], h['box'], q, s, e, pairs, want_forces=False)
+    assert en == pytest.approx(goldens['G9']['value'], rel=1e-10)
+    ex, _ = O.ljc_bonds(pairs, qq, sg, ep, h['positions'], h['box'], periodic=True, want_forces=False)
+    assert ex == pytest.approx(goldens['G10']['value'], rel=REL)
+
+
+def test_exceptions_plus_bonded_golden_G11(emim, goldens):
+    c = emim
+    e = O.ljc_bonds(c['exc_pairs'], c['exc_chargeprod'], c['exc_sigma'], c['exc_epsilon'], c['positions'], c['box'],
+                    periodic=True, want_forces=False)[0]
+    e += O.harmonic_bonds(c['bonds'], c['bond_r0'], c['bond_k'], c['positions'], c['box'], want_forces=False)[0]
+    e += O.harmonic_angles(c['angles'], c['angle_theta0'], c['angle_k'], c['positions'], c['box'], want_forces=False)[0]
+    e += O.periodic_torsions(c['torsions'], c['torsion_n'], c['torsion_phase'], c['torsion_k'], c['positions'],
+                             c['box'], want_forces=False)[0]
+    assert e == pytest.approx(goldens['G11']['value'], rel=REL)
+
+
+DESCS = {
+    'near-none': near(None, 0.7, 0.5), 'near-shift': near('shift', 0.7, 0.5),
+    'near-fswitch': near('force-switch', 0.7, 0.5),
+    'near-fswitch-guarded-neg': near('force-switch', 0.7, 0.5, sign=-1.0, flags=O.GUARD_RC0, actual=1.0),
+    'damped-1': O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1),
+    'damped-2': O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=2),
+    'ewald': O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, alpha=2.6, flags=O.COULOMB_EWALD | O.SWITCH),
+    'rf': O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, flags=O.COULOMB_RF | O.SWITCH,
+                 krf=(78.3 - 1) / (2 * 78.3 + 1), crf=3 * 78.3 / (2 * 78.3 + 1)),
+    'plain': O.desc(O.NONBONDED, rc=1.0),
+}
+
+
+@pytest.mark.parametrize('name', sorted(DESCS))
+def test_pair_kernel_force_is_minus_gradient(name):
+    """-dE/dr by central differences, incl. the force-switch identity V' = S V'_LJC (forces.py:628)."""
+    d = DESCS[name]
+    qq, sig, eps = -0.35, 0.3166, 0.65
+    rmax = min(d.rc, d.rc0 if (d.flags & O.GUARD_RC0) else d.rc)
+    for r in np.linspace(0.28, rmax - 1e-3, 57):
+        h = 1e-6
+        ep, _ = O.pair_kernel(d, (r + h) ** 2, qq, sig, eps)
+        em, _ = O.pair_kernel(d, (r - h) ** 2, qq, sig, eps)
+        _, fr = O.pair_kernel(d, r * r, qq, sig, eps)
+        fd = -(ep - em) / (2 * h)
+        assert fr * r == pytest.approx(fd, rel=1e-5, abs=2e-5), (name, r)
+
+
+def test_near_continuity_at_cutoff():
+    for adj in (None, 'shift', 'force-switch'):
+        d = near(adj, 0.7, 0.5)
+        e, fr = O.pair_kernel(d, (0.7 - 1e-9) ** 2, -0.35, 0.3166, 0.65)
+        assert abs(e) < 1e-6 and abs(fr) < 1e-5
+
+
+def _fd_forces(fn, pos, idxs, h=1e-6):
+    out = []
+    for (i, k) in idxs:
+        p = pos.copy(); p[i, k] += h; ep = fn(p)
+        p[i, k] -= 2 * h; em = fn(p)
+        out.append(-(ep - em) / (2 * h))
+    return np.array(out)
+
+
+def test_bonded_forces_fd(heaq):
+    h = heaq
+    pos = h['positions']
+    idxs = [(0, 0), (6, 1), (17, 2), (19, 0), (32, 1), (35, 2)]
+    for fn in (
+        lambda p, wf=False: O.harmonic_bonds(h['bonds'], h['bond_r0'], h['bond_k'], p, h['box'], want_forces=wf),
+        lambda p, wf=False: O.harmonic_angles(h['angles'], h['angle_theta0'], h['angle_k'], p, h['box'], want_forces=wf),
+        lambda p, wf=False: O.periodic_torsions(h['torsions'], h['torsion_n'], h['torsion_phase'], h['torsion_k'], p,
+                                                h['box'], want_forces=wf),
+        lambda p, wf=False: O.ljc_bonds(h['exc_pairs'], h['exc_chargeprod'], h['exc_sigma'], h['exc_epsilon'], p,
+                                        h['box'], want_forces=wf),
+    ):
+        f = fn(pos, True)[1]
+        fd = _fd_forces(lambda p: fn(p)[0], pos, idxs)
+        an = np.array([f[i, k] for i, k in idxs])
+        assert an == pytest.approx(fd, rel=1e-5, abs=1e-4)
+        assert abs(f.sum(0)).max() < 1e-7
+
+
+def test_pair_forces_fd_and_cells_match_n2(spcfw):
+    c = spcfw
+    args = (c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])
+    d = near('force-switch', 0.7, 0.5)
+    e1, f1, n1 = O.pair_eval(d, *args)
+    e2, f2, n2 = O.pair_eval(d, *args, use_cells=True)
+    assert n1 == n2
+    assert e2 == pytest.approx(e1, rel=1e-12)
+    assert np.abs(f2 - f1).max() < 1e-9 * np.abs(f1).max()
+    idxs = [(0, 0), (1, 1), (700, 2)]
+    fd = _fd_forces(lambda p: O.pair_eval(d, p, *args[1:], want_forces=False)[0], c['positions'], idxs)
+    assert np.array([f1[i, k] for i, k in idxs]) == pytest.approx(fd, rel=1e-5, abs=1e-3)
+
+
+def test_ewald_exclusion_and_reciprocal_forces_fd(spcfw):
+    c = spcfw
+    n = 96
+    pos, q, box = c['positions'][:n].copy(), c['charge'][:n], c['box']
+    pairs = c['exc_pairs'][:n]
+    idxs = [(0, 0), (4, 1), (50, 2)]
+    f = O.ewald_exclusion(pairs, pos, box, q, 2.6)[1]
+    fd = _fd_forces(lambda p: O.ewald_exclusion(pairs, p, box, q, 2.6, want_forces=False)[0], pos, idxs)
+    assert np.array([f[i, k] for i, k in idxs]) == pytest.approx(fd, rel=1e-5, abs=1e-4)
+    f = O.ewald_reciprocal(pos, box, q, 2.6, 6, want_forces=True)[1]
+    fd = _fd_forces(lambda p: O.ewald_reciprocal(p, box, q, 2.6, 6)[0], pos, idxs)
+    assert np.array([f[i, k] for i, k in idxs]) == pytest.approx(fd, rel=1e-5, abs=1e-4)
+
+
+def test_step_primitives():
+    rng = np.random.default_rng(1)
+    n = 10
+    x = rng.normal(size=(n, 3)); v = rng.normal(size=(n, 3)); f = rng.normal(size=(n, 3)); g = rng.normal(size=(n, 3))
+    m = rng.uniform(1, 16, size=n)
+    v0 = v.copy(); x0 = x.copy()
+    O.kick(v, f, m, 0.25)
+    assert np.array_equal(v, v0 + 0.25 * f / m[:, None])
+    O.kick(v, f, m, 0.5, fsub=g)
+    assert np.array_equal(v, (v0 + 0.25 * f / m[:, None]) + 0.5 * (f - g) / m[:, None])
+    O.move(x, v, 0.125)
+    assert np.array_equal(x, x0 + 0.125 * v)
+    assert O.mvv(v, m) == pytest.approx((m[:, None] * v * v).sum(), rel=1e-14)
