@@ -1,0 +1,243 @@
+"""ctypes binding of include/atomsmm_hip.h (libatomsmm_hip.so, gfx950).
+
+There is NO CPU fallback: if the shared library is missing or no HIP device is visible, every entry
+point raises.  Device memory, streams and collectives come from torch (plumbing only).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libatomsmm_hip.so')
+
+NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED = range(5)
+GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH = 1, 2, 4, 8
+BOND_HARMONIC, ANGLE_HARMONIC, BOND_LJC, BOND_NEAR, TORSION_PERIODIC, BOND_EWALD_EXCL = range(6)
+OP_EVAL, OP_KICK, OP_MOVE, OP_COPY = 1, 2, 3, 4
+KC = 138.935456   # forces.py:407
+ARITY = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 3, BOND_LJC: 2, BOND_NEAR: 2, TORSION_PERIODIC: 4, BOND_EWALD_EXCL: 2}
+NPAR = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 2, BOND_LJC: 3, BOND_NEAR: 3, TORSION_PERIODIC: 3, BOND_EWALD_EXCL: 1}
+
+EXPORTS = [
+    'amm_abi_version', 'amm_last_error', 'amm_create', 'amm_destroy', 'amm_set_stream', 'amm_set_slice',
+    'amm_synchronize', 'amm_check', 'amm_pair_create', 'amm_pair_set_params', 'amm_bonded_create',
+    'amm_bonded_add_terms', 'amm_bonded_finalize', 'amm_bonded_set_sliced', 'amm_force_eval', 'amm_kick',
+    'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
+    'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
+]
+
+
+class PairDesc(C.Structure):
+    _fields_ = [('family', C.c_int32), ('flags', C.c_int32), ('degree', C.c_int32), ('pad_', C.c_int32),
+                ('sign', C.c_double), ('rc', C.c_double), ('rswitch', C.c_double), ('rc0', C.c_double),
+                ('rs0', C.c_double), ('alpha', C.c_double), ('Kc', C.c_double), ('krf', C.c_double),
+                ('crf', C.c_double)]
+
+
+class Op(C.Structure):
+    _fields_ = [('op', C.c_int32), ('a', C.c_int32), ('b', C.c_int32), ('c', C.c_int32), ('coef', C.c_double)]
+
+
+class PairStats(C.Structure):
+    _fields_ = [('n_builds', C.c_int64), ('n_evals', C.c_int64), ('n_list_pairs', C.c_int64),
+                ('n_slice_atoms', C.c_int64), ('capacity', C.c_int32), ('max_neighbors', C.c_int32),
+                ('lanes_per_atom', C.c_int32), ('n_cells', C.c_int32), ('rlist', C.c_double)]
+
+
+def pair_desc(family, rc, rc0=0.0, rs0=0.0, rswitch=0.0, alpha=0.0, degree=1, flags=0, sign=1.0, Kc=KC,
+              krf=0.0, crf=0.0):
+    return PairDesc(int(family), int(flags), int(degree), 0, float(sign), float(rc), float(rswitch), float(rc0),
+                    float(rs0), float(alpha), float(Kc), float(krf), float(crf))
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib():
+    """Load libatomsmm_hip.so; raises HipError when it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError('libatomsmm_hip.so not found at %s: build it with `python -m atomsmm_amd.build` '
+                           '(hipcc --offload-arch=gfx950). The HIP path has no CPU fallback.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        L.amm_abi_version.restype = C.c_int
+        L.amm_last_error.restype = C.c_char_p
+        L.amm_create.argtypes = [C.c_int32, dp, C.c_int32, vp, C.POINTER(vp)]
+        L.amm_destroy.argtypes = [vp]
+        L.amm_set_stream.argtypes = [vp, vp]
+        L.amm_set_slice.argtypes = [vp, C.c_int32, C.c_int32]
+        L.amm_synchronize.argtypes = [vp]
+        L.amm_check.argtypes = [vp]
+        L.amm_pair_create.argtypes = [vp, C.POINTER(PairDesc), dp, dp, dp, ip, C.c_int32, C.c_double, ip]
+        L.amm_pair_set_params.argtypes = [vp, C.c_int32, dp, dp, dp]
+        L.amm_bonded_create.argtypes = [vp, ip]
+        L.amm_bonded_add_terms.argtypes = [vp, C.c_int32, C.c_int32, ip, dp, C.c_int32, C.c_int32, C.POINTER(PairDesc)]
+        L.amm_bonded_finalize.argtypes = [vp, C.c_int32]
+        L.amm_bonded_set_sliced.argtypes = [vp, C.c_int32, C.c_int32]
+        L.amm_force_eval.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
+        L.amm_kick.argtypes = [vp, vp, vp, vp, vp, C.c_double]
+        L.amm_move.argtypes = [vp, vp, vp, C.c_double]
+        L.amm_copy.argtypes = [vp, vp, vp]
+        L.amm_mvv.argtypes = [vp, vp, vp, vp]
+        L.amm_bind_state.argtypes = [vp, vp, vp, vp]
+        L.amm_bind_buffer.argtypes = [vp, C.c_int32, vp]
+        L.amm_group_define.argtypes = [vp, C.c_int32, C.c_int32, ip, C.c_int32]
+        L.amm_run_ops.argtypes = [vp, C.POINTER(Op), C.c_int32, C.c_int32]
+        L.amm_pair_get_stats.argtypes = [vp, C.c_int32, C.POINTER(PairStats)]
+        L.amm_profile_enable.argtypes = [vp, C.c_int32]
+        L.amm_profile_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), dp]
+        for name in EXPORTS:
+            if name not in ('amm_last_error',):
+                getattr(L, name).restype = C.c_int
+        L.amm_last_error.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HipError(lib().amm_last_error().decode())
+
+
+def _hd(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _hi(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (fp64, contiguous, on the GPU) or None."""
+    if t is None:
+        return None
+    import torch
+    assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), \
+        'expected a contiguous float64 CUDA/HIP tensor'
+    return C.c_void_p(t.data_ptr())
+
+
+class HipContext:
+    """Thin object wrapper over the C-ABI; all tensors are torch float64 tensors on the context's device."""
+
+    def __init__(self, n_atoms, box, device=0, stream=None, rank=0, world=1):
+        import torch
+        if not torch.cuda.is_available():
+            raise HipError('no HIP device visible to torch: the HIP path has no CPU fallback')
+        L = lib()
+        self.n = int(n_atoms)
+        self.device = int(device)
+        self.torch_device = torch.device('cuda', self.device)
+        torch.cuda.set_device(self.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.torch_device).cuda_stream
+        b, bp = _hd(np.asarray(box, dtype=np.float64).reshape(3))
+        h = C.c_void_p()
+        _chk(L.amm_create(self.n, bp, self.device, C.c_void_p(stream), C.byref(h)))
+        self.h = h
+        self.rank, self.world = rank, world
+        if world > 1:
+            _chk(L.amm_set_slice(self.h, rank, world))
+        self._keep = []
+
+    def close(self):
+        if getattr(self, 'h', None):
+            lib().amm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- forces
+    def pair_create(self, desc, q, sigma, eps, excl_pairs=None, skin=-1.0):
+        q_, qp = _hd(q); s_, sp = _hd(sigma); e_, ep = _hd(eps)
+        assert len(q_) == len(s_) == len(e_) == self.n
+        ex = np.zeros((0, 2), np.int32) if excl_pairs is None else np.asarray(excl_pairs, dtype=np.int32).reshape(-1, 2)
+        ex_, exp_ = _hi(ex)
+        fid = C.c_int32(-1)
+        _chk(lib().amm_pair_create(self.h, C.byref(desc), qp, sp, ep, exp_, len(ex_), float(skin), C.byref(fid)))
+        return fid.value
+
+    def pair_set_params(self, fid, q, sigma, eps):
+        q_, qp = _hd(q); s_, sp = _hd(sigma); e_, ep = _hd(eps)
+        _chk(lib().amm_pair_set_params(self.h, fid, qp, sp, ep))
+
+    def bonded_create(self):
+        fid = C.c_int32(-1)
+        _chk(lib().amm_bonded_create(self.h, C.byref(fid)))
+        return fid.value
+
+    def bonded_add_terms(self, fid, kind, idx, params, periodic=False, desc=None):
+        idx_, ip = _hi(np.asarray(idx).reshape(-1, ARITY[kind]))
+        par_, pp = _hd(np.asarray(params, dtype=np.float64).reshape(-1, NPAR[kind]))
+        assert len(idx_) == len(par_)
+        _chk(lib().amm_bonded_add_terms(self.h, fid, kind, ip, pp, len(idx_), int(bool(periodic)),
+                                        C.byref(desc) if desc is not None else None))
+
+    def bonded_finalize(self, fid, sliced=False):
+        _chk(lib().amm_bonded_finalize(self.h, fid))
+        if sliced:
+            _chk(lib().amm_bonded_set_sliced(self.h, fid, 1))
+
+    def force_eval(self, fid, pos, force, accumulate=False, energy=None):
+        _chk(lib().amm_force_eval(self.h, fid, _ptr(pos), _ptr(force), int(bool(accumulate)), _ptr(energy)))
+
+    # ---- step primitives
+    def kick(self, v, f, mass, coef, fsub=None):
+        _chk(lib().amm_kick(self.h, _ptr(v), _ptr(f), _ptr(fsub), _ptr(mass), float(coef)))
+
+    def move(self, x, v, coef):
+        _chk(lib().amm_move(self.h, _ptr(x), _ptr(v), float(coef)))
+
+    def copy(self, dst, src):
+        _chk(lib().amm_copy(self.h, _ptr(dst), _ptr(src)))
+
+    def mvv(self, v, mass, out):
+        _chk(lib().amm_mvv(self.h, _ptr(v), _ptr(mass), _ptr(out)))
+
+    def bind_state(self, x, v, mass):
+        self._keep += [x, v, mass]
+        _chk(lib().amm_bind_state(self.h, _ptr(x), _ptr(v), _ptr(mass)))
+
+    def bind_buffer(self, slot, buf):
+        self._keep.append(buf)
+        _chk(lib().amm_bind_buffer(self.h, slot, _ptr(buf)))
+
+    def group_define(self, group, slot, force_ids):
+        ids, p = _hi(np.asarray(force_ids, dtype=np.int32).reshape(-1))
+        _chk(lib().amm_group_define(self.h, group, slot, p, len(ids)))
+
+    def run_ops(self, ops, repeat=1):
+        arr = (Op * len(ops))(*ops)
+        _chk(lib().amm_run_ops(self.h, arr, len(ops), int(repeat)))
+
+    def synchronize(self):
+        _chk(lib().amm_synchronize(self.h))
+
+    def check(self):
+        _chk(lib().amm_check(self.h))
+
+    def pair_stats(self, fid):
+        st = PairStats()
+        _chk(lib().amm_pair_get_stats(self.h, fid, C.byref(st)))
+        return {name: getattr(st, name) for name, _ in PairStats._fields_}
+
+    def profile_enable(self, on=True):
+        _chk(lib().amm_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self, fid):
+        n = C.c_int64(); ms = C.c_double()
+        _chk(lib().amm_profile_read(self.h, fid, C.byref(n), C.byref(ms)))
+        return n.value, ms.value

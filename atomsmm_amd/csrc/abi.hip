@@ -1,0 +1,441 @@
+// atomsmm_amd/csrc/abi.hip -- extern "C" entry points declared in include/atomsmm_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "amm_ctx.h"
+
+int amm_pair_setup_grid(amm_ctx *ctx, PairForce *pf);
+int amm_bonded_arity(int kind);
+int amm_bonded_npar(int kind);
+
+static thread_local std::string g_error;
+void amm_set_error(const std::string &msg) { g_error = msg; }
+
+static PairForce *get_pair(amm_ctx *ctx, int id) {
+    if (!ctx || id < 0 || id >= (int)ctx->forces.size() || ctx->forces[id].type != 1) {
+        amm_set_error("invalid pair force id");
+        return nullptr;
+    }
+    return ctx->forces[id].pair;
+}
+static BondedSet *get_bonded(amm_ctx *ctx, int id) {
+    if (!ctx || id < 0 || id >= (int)ctx->forces.size() || ctx->forces[id].type != 2) {
+        amm_set_error("invalid bonded force id");
+        return nullptr;
+    }
+    return ctx->forces[id].bonded;
+}
+
+template <typename T>
+static int upload(T **dst, const T *src, size_t n) {
+    AMM_HIP(hipMalloc(dst, sizeof(T) * std::max<size_t>(n, 1)));
+    if (n) AMM_HIP(hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" {
+
+int amm_abi_version(void) { return AMM_ABI_VERSION; }
+const char *amm_last_error(void) { return g_error.c_str(); }
+
+int amm_create(int32_t n_atoms, const double h_box[3], int32_t device, void *stream, amm_ctx **out) {
+    if (!out || n_atoms <= 0 || !h_box) {
+        amm_set_error("amm_create: bad arguments");
+        return 1;
+    }
+    for (int k = 0; k < 3; ++k)
+        if (!(h_box[k] > 0.0)) {
+            amm_set_error("amm_create: box edges must be positive (orthorhombic periodic box)");
+            return 1;
+        }
+    int ndev = 0;
+    AMM_HIP(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) {
+        amm_set_error("amm_create: no HIP device visible (the HIP path has no CPU fallback)");
+        return 1;
+    }
+    AMM_HIP(hipSetDevice(device));
+    amm_ctx *ctx = new amm_ctx();
+    ctx->n = n_atoms;
+    ctx->device = device;
+    ctx->stream = (hipStream_t)stream;
+    for (int k = 0; k < 3; ++k) {
+        ctx->box.L[k] = h_box[k];
+        ctx->box.invL[k] = 1.0 / h_box[k];
+    }
+    AMM_HIP(hipMalloc(&ctx->d_scratch, sizeof(double) * ((n_atoms + 255) / 256 + 8)));
+    *out = ctx;
+    return 0;
+}
+
+int amm_destroy(amm_ctx *ctx) {
+    if (!ctx) return 0;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &f : ctx->forces) {
+        if (f.pair) {
+            amm_pair_free(f.pair);
+            delete f.pair;
+        }
+        if (f.bonded) {
+            amm_bonded_free(f.bonded);
+            delete f.bonded;
+        }
+    }
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    delete ctx;
+    return 0;
+}
+
+int amm_set_stream(amm_ctx *ctx, void *stream) {
+    ctx->stream = (hipStream_t)stream;
+    return 0;
+}
+
+int amm_set_slice(amm_ctx *ctx, int32_t rank, int32_t world) {
+    if (world < 1 || rank < 0 || rank >= world) {
+        amm_set_error("amm_set_slice: need 0 <= rank < world");
+        return 1;
+    }
+    for (auto &f : ctx->forces)
+        if (f.pair && f.pair->built) {
+            amm_set_error("amm_set_slice must be called before the first force evaluation");
+            return 1;
+        }
+    ctx->rank = rank;
+    ctx->world = world;
+    return 0;
+}
+
+int amm_synchronize(amm_ctx *ctx) {
+    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int amm_check(amm_ctx *ctx) {
+    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t id = 0; id < ctx->forces.size(); ++id) {
+        PairForce *pf = ctx->forces[id].pair;
+        if (!pf || !pf->built) continue;
+        int flags[4];
+        AMM_HIP(hipMemcpy(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        if (flags[1]) {
+            amm_set_error("neighbour list overflow in pair force " + std::to_string(id) + ": " + std::to_string(flags[2]) +
+                          " neighbours > capacity " + std::to_string(pf->cap) +
+                          "; forces since the last rebuild are incomplete");
+            return 2;
+        }
+    }
+    return 0;
+}
+
+int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, const double *h_sigma,
+                    const double *h_eps, const int32_t *h_excl, int32_t n_excl, double skin, int32_t *force_id) {
+    if (!ctx || !desc || !h_q || !h_sigma || !h_eps || !force_id) {
+        amm_set_error("amm_pair_create: null argument");
+        return 1;
+    }
+    if (desc->family < AMM_NEAR_NONE || desc->family > AMM_NONBONDED) {
+        amm_set_error("amm_pair_create: unknown family");
+        return 1;
+    }
+    if (!(desc->rc > 0.0)) {
+        amm_set_error("amm_pair_create: cutoff must be positive");
+        return 1;
+    }
+    PairForce *pf = new PairForce();
+    pf->desc = *desc;
+    pf->n = ctx->n;
+    if (amm_pair_build_consts(*desc, pf->pc)) {
+        delete pf;
+        return 1;
+    }
+    const int n = ctx->n;
+    double Lmin = std::min(ctx->box.L[0], std::min(ctx->box.L[1], ctx->box.L[2]));
+    if (skin < 0) skin = 0.1;
+    skin = std::min(skin, std::max(0.0, 0.5 * Lmin - desc->rc) * 0.999);
+    pf->skin = skin;
+    pf->rlist = desc->rc + skin;
+    if (amm_pair_setup_grid(ctx, pf)) {
+        delete pf;
+        return 1;
+    }
+    // exclusions -> symmetric CSR in original atom indices
+    std::vector<int> ptr(n + 1, 0);
+    for (int e = 0; e < n_excl; ++e) {
+        int i = h_excl[2 * e], j = h_excl[2 * e + 1];
+        if (i < 0 || j < 0 || i >= n || j >= n) {
+            amm_set_error("amm_pair_create: exclusion index out of range");
+            delete pf;
+            return 1;
+        }
+        if (i == j) continue;
+        ptr[i + 1]++;
+        ptr[j + 1]++;
+    }
+    for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+    std::vector<int> idx(ptr[n]), fill(ptr.begin(), ptr.end() - 1);
+    for (int e = 0; e < n_excl; ++e) {
+        int i = h_excl[2 * e], j = h_excl[2 * e + 1];
+        if (i == j) continue;
+        idx[fill[i]++] = j;
+        idx[fill[j]++] = i;
+    }
+    if (upload(&pf->d_excl_ptr, ptr.data(), ptr.size()) || upload(&pf->d_excl_idx, idx.data(), idx.size())) return 1;
+    AMM_HIP(hipMalloc(&pf->d_q, sizeof(double) * n));
+    AMM_HIP(hipMalloc(&pf->d_hsig, sizeof(double) * n));
+    AMM_HIP(hipMalloc(&pf->d_seps2, sizeof(double) * n));
+    const int nc = pf->grid.ncell;
+    AMM_HIP(hipMalloc(&pf->d_cell_of, sizeof(int) * n));
+    AMM_HIP(hipMalloc(&pf->d_cell_count, sizeof(int) * (nc + 1)));
+    AMM_HIP(hipMemset(pf->d_cell_count, 0, sizeof(int) * (nc + 1)));
+    AMM_HIP(hipMalloc(&pf->d_cell_start, sizeof(int) * (nc + 1)));
+    AMM_HIP(hipMalloc(&pf->d_cell_fill, sizeof(int) * (nc + 1)));
+    AMM_HIP(hipMalloc(&pf->d_perm_tmp, sizeof(int) * n));
+    AMM_HIP(hipMalloc(&pf->d_perm, sizeof(int) * n));
+    AMM_HIP(hipMalloc(&pf->d_posq_s, sizeof(double4) * n));
+    AMM_HIP(hipMalloc(&pf->d_lj_s, sizeof(double2) * n));
+    AMM_HIP(hipMalloc(&pf->d_xref, sizeof(double) * 3 * n));
+    AMM_HIP(hipMalloc(&pf->d_flags, sizeof(int) * 4));
+    AMM_HIP(hipMemset(pf->d_flags, 0, sizeof(int) * 4));
+    AMM_HIP(hipMalloc(&pf->d_counters, sizeof(unsigned long long) * 2));
+    AMM_HIP(hipMemset(pf->d_counters, 0, sizeof(unsigned long long) * 2));
+    ForceObj fo;
+    fo.type = 1;
+    fo.pair = pf;
+    ctx->forces.push_back(fo);
+    *force_id = (int)ctx->forces.size() - 1;
+    return amm_pair_set_params(ctx, *force_id, h_q, h_sigma, h_eps);
+}
+
+int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const double *h_sigma, const double *h_eps) {
+    PairForce *pf = get_pair(ctx, force_id);
+    if (!pf) return 1;
+    const int n = pf->n;
+    std::vector<double> hs(n), se(n);
+    for (int i = 0; i < n; ++i) {
+        if (h_eps[i] < 0.0) {
+            amm_set_error("amm_pair_set_params: negative epsilon");
+            return 1;
+        }
+        hs[i] = 0.5 * h_sigma[i];          // sigma = 0.5*(sigma1+sigma2)       forces.py:256
+        se[i] = 2.0 * std::sqrt(h_eps[i]); // 4*epsilon = 4*sqrt(eps1*eps2)     forces.py:257
+    }
+    // ordered after any kernels already queued on the stream
+    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    AMM_HIP(hipMemcpy(pf->d_q, h_q, sizeof(double) * n, hipMemcpyHostToDevice));
+    AMM_HIP(hipMemcpy(pf->d_hsig, hs.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    AMM_HIP(hipMemcpy(pf->d_seps2, se.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int amm_bonded_create(amm_ctx *ctx, int32_t *force_id) {
+    BondedSet *bs = new BondedSet();
+    std::memset(&bs->near_pc, 0, sizeof(bs->near_pc));
+    ForceObj fo;
+    fo.type = 2;
+    fo.bonded = bs;
+    ctx->forces.push_back(fo);
+    *force_id = (int)ctx->forces.size() - 1;
+    return 0;
+}
+
+int amm_bonded_add_terms(amm_ctx *ctx, int32_t force_id, int32_t kind, const int32_t *h_idx, const double *h_params,
+                         int32_t n_terms, int32_t periodic, const amm_pair_desc *desc) {
+    BondedSet *bs = get_bonded(ctx, force_id);
+    if (!bs) return 1;
+    if (bs->finalized) {
+        amm_set_error("amm_bonded_add_terms after finalize");
+        return 1;
+    }
+    if (kind < 0 || kind > 5) {
+        amm_set_error("amm_bonded_add_terms: unknown kind");
+        return 1;
+    }
+    if (!bs->h_idx[kind].empty() && bs->periodic[kind] != periodic) {
+        amm_set_error("amm_bonded_add_terms: mixed periodic flags within one kind");
+        return 1;
+    }
+    const int ar = amm_bonded_arity(kind), np = amm_bonded_npar(kind);
+    if (kind == AMM_BOND_NEAR) {
+        if (!desc) {
+            amm_set_error("AMM_BOND_NEAR needs a pair descriptor");
+            return 1;
+        }
+        if (bs->has_near && std::memcmp(&bs->near_desc, desc, sizeof(*desc)) != 0) {
+            amm_set_error("one bonded set supports a single near-exception descriptor");
+            return 1;
+        }
+        bs->has_near = true;
+        bs->near_desc = *desc;
+        if (amm_pair_build_consts(*desc, bs->near_pc)) return 1;
+    }
+    double scale = 1.0;
+    if (kind == AMM_BOND_EWALD_EXCL) {
+        if (!desc) {
+            amm_set_error("AMM_BOND_EWALD_EXCL needs a descriptor carrying alpha and Kc");
+            return 1;
+        }
+        bs->ewald_alpha = desc->alpha;
+        bs->ewald_Kc = desc->Kc;
+        scale = desc->Kc;
+    }
+    if (kind == AMM_BOND_LJC && desc) bs->ljc_Kc = desc->Kc;
+    bs->periodic[kind] = periodic;
+    bs->h_idx[kind].insert(bs->h_idx[kind].end(), h_idx, h_idx + (size_t)n_terms * ar);
+    for (size_t k = 0; k < (size_t)n_terms * np; ++k) bs->h_par[kind].push_back(h_params[k] * scale);
+    return 0;
+}
+
+int amm_bonded_finalize(amm_ctx *ctx, int32_t force_id) {
+    BondedSet *bs = get_bonded(ctx, force_id);
+    if (!bs) return 1;
+    return amm_bonded_finalize_impl(ctx, bs);
+}
+
+int amm_bonded_set_sliced(amm_ctx *ctx, int32_t force_id, int32_t on) {
+    BondedSet *bs = get_bonded(ctx, force_id);
+    if (!bs) return 1;
+    bs->sliced = on != 0;
+    return 0;
+}
+
+int amm_force_eval(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_force, int32_t accumulate,
+                   double *d_energy) {
+    if (!ctx || force_id < 0 || force_id >= (int)ctx->forces.size() || !d_pos || !d_force) {
+        amm_set_error("amm_force_eval: bad arguments");
+        return 1;
+    }
+    ForceObj &f = ctx->forces[force_id];
+    if (f.type == 1) return amm_pair_eval_impl(ctx, f.pair, d_pos, d_force, accumulate, d_energy);
+    return amm_bonded_eval_impl(ctx, f.bonded, d_pos, d_force, accumulate, d_energy);
+}
+
+int amm_kick(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_fsub, const double *d_mass, double coef) {
+    return amm_kick_impl(ctx, d_v, d_f, d_fsub, d_mass, coef);
+}
+int amm_move(amm_ctx *ctx, double *d_x, const double *d_v, double coef) { return amm_move_impl(ctx, d_x, d_v, coef); }
+int amm_copy(amm_ctx *ctx, double *d_dst, const double *d_src) { return amm_copy_impl(ctx, d_dst, d_src); }
+int amm_mvv(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out) { return amm_mvv_impl(ctx, d_v, d_m, d_out); }
+
+int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass) {
+    ctx->d_x = d_x;
+    ctx->d_v = d_v;
+    ctx->d_mass = d_mass;
+    return 0;
+}
+int amm_bind_buffer(amm_ctx *ctx, int32_t slot, double *d_buf) {
+    if (slot < 0 || slot >= AMM_MAX_SLOTS) {
+        amm_set_error("amm_bind_buffer: slot out of range");
+        return 1;
+    }
+    ctx->slots[slot] = d_buf;
+    return 0;
+}
+int amm_group_define(amm_ctx *ctx, int32_t group, int32_t slot, const int32_t *force_ids, int32_t n_forces) {
+    if (group < 0 || group >= AMM_MAX_GROUPS || slot < 0 || slot >= AMM_MAX_SLOTS) {
+        amm_set_error("amm_group_define: group/slot out of range");
+        return 1;
+    }
+    ctx->groups[group].slot = slot;
+    ctx->groups[group].forces.assign(force_ids, force_ids + n_forces);
+    return 0;
+}
+
+int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) {
+    if (!ctx->d_x || !ctx->d_v || !ctx->d_mass) {
+        amm_set_error("amm_run_ops: state not bound (amm_bind_state)");
+        return 1;
+    }
+    for (int rep = 0; rep < repeat; ++rep)
+        for (int k = 0; k < n_ops; ++k) {
+            const amm_op &op = ops[k];
+            switch (op.op) {
+            case AMM_OP_EVAL: {
+                if (op.a < 0 || op.a >= AMM_MAX_GROUPS || ctx->groups[op.a].slot < 0) {
+                    amm_set_error("amm_run_ops: EVAL of an undefined group");
+                    return 1;
+                }
+                GroupDef &g = ctx->groups[op.a];
+                double *buf = ctx->slots[g.slot];
+                if (!buf) {
+                    amm_set_error("amm_run_ops: group buffer not bound");
+                    return 1;
+                }
+                if (g.forces.empty()) AMM_HIP(hipMemsetAsync(buf, 0, sizeof(double) * 3 * (size_t)ctx->n, ctx->stream));
+                for (size_t j = 0; j < g.forces.size(); ++j)
+                    if (amm_force_eval(ctx, g.forces[j], ctx->d_x, buf, j > 0, nullptr)) return 1;
+            } break;
+            case AMM_OP_KICK: {
+                double *fa = (op.a >= 0 && op.a < AMM_MAX_SLOTS) ? ctx->slots[op.a] : nullptr;
+                double *fb = (op.b >= 0 && op.b < AMM_MAX_SLOTS) ? ctx->slots[op.b] : nullptr;
+                if (!fa || (op.b >= 0 && !fb)) {
+                    amm_set_error("amm_run_ops: KICK buffer not bound");
+                    return 1;
+                }
+                if (amm_kick_impl(ctx, ctx->d_v, fa, fb, ctx->d_mass, op.coef)) return 1;
+            } break;
+            case AMM_OP_MOVE:
+                if (amm_move_impl(ctx, ctx->d_x, ctx->d_v, op.coef)) return 1;
+                break;
+            case AMM_OP_COPY: {
+                double *dst = (op.a >= 0 && op.a < AMM_MAX_SLOTS) ? ctx->slots[op.a] : nullptr;
+                double *src = (op.b >= 0 && op.b < AMM_MAX_SLOTS) ? ctx->slots[op.b] : nullptr;
+                if (!dst || !src) {
+                    amm_set_error("amm_run_ops: COPY buffer not bound");
+                    return 1;
+                }
+                if (amm_copy_impl(ctx, dst, src)) return 1;
+            } break;
+            default: amm_set_error("amm_run_ops: unknown op"); return 1;
+            }
+        }
+    return 0;
+}
+
+int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
+    PairForce *pf = get_pair(ctx, force_id);
+    if (!pf || !out) return 1;
+    std::memset(out, 0, sizeof(*out));
+    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    out->n_evals = pf->n_evals;
+    out->capacity = pf->cap;
+    out->lanes_per_atom = pf->lpa;
+    out->n_cells = pf->grid.ncell;
+    out->rlist = pf->rlist;
+    out->n_slice_atoms = pf->s_end - pf->s_begin;
+    if (pf->built) {
+        int flags[4];
+        unsigned long long cnt[2];
+        AMM_HIP(hipMemcpy(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        AMM_HIP(hipMemcpy(cnt, pf->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+        out->n_builds = (int64_t)cnt[0];
+        out->n_list_pairs = (int64_t)cnt[1];
+        out->max_neighbors = flags[2];
+    }
+    return 0;
+}
+
+int amm_profile_enable(amm_ctx *ctx, int32_t on) {
+    ctx->profile = on != 0;
+    return 0;
+}
+
+int amm_profile_read(amm_ctx *ctx, int32_t force_id, int64_t *n_launches, double *total_ms) {
+    PairForce *pf = get_pair(ctx, force_id);
+    if (!pf) return 1;
+    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (size_t k = 0; k + 1 < pf->ev_used; k += 2) {
+        float ms = 0.f;
+        AMM_HIP(hipEventElapsedTime(&ms, pf->ev[k], pf->ev[k + 1]));
+        tot += ms;
+    }
+    if (n_launches) *n_launches = (int64_t)(pf->ev_used / 2);
+    if (total_ms) *total_ms = tot;
+    pf->ev_used = 0;
+    return 0;
+}
+
+}  // extern "C"

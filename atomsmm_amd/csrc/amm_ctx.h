@@ -1,0 +1,137 @@
+// atomsmm_amd/csrc/amm_ctx.h -- internal structures of libatomsmm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/atomsmm_hip.h"
+
+#define AMM_WAVE 64
+#define AMM_MAX_SLOTS 16
+#define AMM_MAX_GROUPS 32
+
+void amm_set_error(const std::string &msg);
+#define AMM_HIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            amm_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                    \
+            return 1;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+// Constants of one pair force, precomputed on the host and passed to kernels by value.
+struct PairConsts {
+    int family, flags, degree, cmode;   // cmode: 0 plain coulomb, 1 ewald(erfc), 2 reaction field
+    double sign, rc2, rc0, rs0, inv_dr0, rswitch, rc;
+    double alpha, two_alpha_over_sqrtpi, Kc, krf, crf;
+    double inv_rc0, inv_rc0_2;          // shift / force-switch constants
+    double b, f12c, f6c, f1c;           // force-switch (forces.py:559-563)
+    double sw_den, inv_sw_dr;           // DAMPED: rc^d - rs^d ; NONBONDED: 1/(rc - rswitch)
+};
+
+struct Box {
+    double L[3], invL[3];
+};
+
+struct CellGrid {
+    int nc[3];
+    int nstencil[3];   // number of unique neighbour offsets per axis (3, 2 or 1)
+    int ncell;
+    double cw[3], inv_cw[3];
+};
+
+struct PairForce {
+    amm_pair_desc desc;
+    PairConsts pc;
+    int n = 0;
+    double skin = 0, rlist = 0;
+    // per-atom parameters, original order: q, sigma/2, 2*sqrt(eps)
+    double *d_q = nullptr, *d_hsig = nullptr, *d_seps2 = nullptr;
+    int *d_excl_ptr = nullptr, *d_excl_idx = nullptr;
+    CellGrid grid;
+    int *d_cell_of = nullptr, *d_cell_count = nullptr, *d_cell_start = nullptr, *d_cell_fill = nullptr;
+    int *d_perm_tmp = nullptr, *d_perm = nullptr;
+    double4 *d_posq_s = nullptr;   // sorted: wrapped x,y,z and charge
+    double2 *d_lj_s = nullptr;     // sorted: sigma/2, 2*sqrt(eps)
+    double *d_xref = nullptr;      // positions at the last list build (original order)
+    int s_begin = 0, s_end = 0;    // sorted-slot range owned by this rank
+    int cap = 0;
+    int *d_nl = nullptr, *d_nnb = nullptr;
+    int *d_flags = nullptr;        // [0] need_rebuild [1] overflow [2] max_nb [3] scratch
+    unsigned long long *d_counters = nullptr;  // [0] builds [1] list pairs
+    int lpa = 8;                   // lanes per i-atom in the traversal kernel
+    int lpb = 16;                  // lanes per i-atom in the list-build kernel
+    double *d_epart = nullptr;
+    int n_epart = 0;
+    bool built = false;
+    int64_t n_evals = 0;
+    // profiling
+    std::vector<hipEvent_t> ev;    // pairs (start, stop)
+    size_t ev_used = 0;
+};
+
+struct BondedSet {
+    // host staging
+    std::vector<int32_t> h_idx[6];
+    std::vector<double> h_par[6];
+    int periodic[6] = {0, 0, 0, 0, 0, 0};
+    bool has_near = false;
+    amm_pair_desc near_desc;
+    PairConsts near_pc;
+    double ewald_alpha = 0, ewald_Kc = 0;
+    double ljc_Kc = 138.935456;
+    bool sliced = false;           // world > 1: compute only this rank's rows (group is all-reduced by the host)
+    bool finalized = false;
+    // device: term arrays per kind, CSR per atom of (kind, term, role)
+    int32_t *d_idx[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *d_par[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n_terms[6] = {0, 0, 0, 0, 0, 0};
+    int *d_ref_ptr = nullptr;      // [n+1]
+    uint32_t *d_ref = nullptr;     // kind<<28 | role<<26 | term
+    double *d_epart = nullptr;
+    int n_epart = 0;
+};
+
+struct ForceObj {
+    int type = 0;   // 1 pair, 2 bonded
+    PairForce *pair = nullptr;
+    BondedSet *bonded = nullptr;
+};
+
+struct GroupDef {
+    int slot = -1;
+    std::vector<int> forces;
+};
+
+struct amm_ctx {
+    int n = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Box box;
+    int rank = 0, world = 1;
+    std::vector<ForceObj> forces;
+    double *d_x = nullptr, *d_v = nullptr;
+    const double *d_mass = nullptr;
+    double *slots[AMM_MAX_SLOTS] = {nullptr};
+    GroupDef groups[AMM_MAX_GROUPS];
+    bool profile = false;
+    double *d_scratch = nullptr;   // small scratch (reductions)
+};
+
+// implemented in pair.hip / cells.hip / bonded.hip / integrate.hip
+int amm_pair_build_consts(const amm_pair_desc &d, PairConsts &pc);
+int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate,
+                       double *d_energy);
+int amm_pair_free(PairForce *pf);
+int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate,
+                         double *d_energy);
+int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
+int amm_bonded_free(BondedSet *bs);
+int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_fsub, const double *d_mass, double coef);
+int amm_move_impl(amm_ctx *ctx, double *d_x, const double *d_v, double coef);
+int amm_copy_impl(amm_ctx *ctx, double *d_dst, const double *d_src);
+int amm_mvv_impl(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out);
+int amm_reduce_add(amm_ctx *ctx, const double *d_part, int n, double scale, double *d_out);

@@ -1,0 +1,270 @@
+// atomsmm_amd/csrc/bonded.hip -- bond-list forces of one force group, owner-computes (gfx950, fp64).
+//
+// Takes over OpenMM's CustomBondForce / HarmonicBondForce / HarmonicAngleForce / PeriodicTorsionForce
+// evaluation for the objects the reference builds or keeps in group 0 (forces.py:326-407, 673-680;
+// systems.py:113-119) and the exclusion term of the group-2 NonbondedForce (forces.py:181-183).
+// One thread per atom walks a CSR of (kind, term, role) references and recomputes each term's force
+// on ITS atom: no atomics, so the summation order -- and therefore every bit of the result -- is the
+// same on every launch and on every rank (ranks integrate all atoms redundantly and must stay in
+// lock-step).  In RESPA this kernel runs n0*n1*n2 times per outer step: it is latency-, not flop-bound.
+#include <algorithm>
+#include <cmath>
+
+#include "amm_ctx.h"
+#include "pair_math.h"
+
+struct BondedArgs {
+    int n, row_begin, row_end;
+    const int *ref_ptr;
+    const uint32_t *ref;
+    const int32_t *idx[6];
+    const double *par[6];
+    int periodic[6];
+    const double *pos;
+    double *force;
+    double *epart;
+    int accumulate, want_energy;
+    Box box;
+    PairConsts near_pc;
+    double ewald_alpha, ewald_tasp;
+    double Kc_ljc;
+};
+
+__device__ __forceinline__ void delta3(const double *pos, int a, int b, const Box &box, int periodic, double *d) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double v = pos[3 * a + k] - pos[3 * b + k];
+        if (periodic) v = amm_min_image(v, box.L[k], box.invL[k]);
+        d[k] = v;
+    }
+}
+__device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ void __launch_bounds__(256) k_bonded(BondedArgs A) {
+    const int i = A.row_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    double f[3] = {0.0, 0.0, 0.0};
+    double esum = 0.0;
+    if (i < A.row_end) {
+        const int rb = A.ref_ptr[i], re = A.ref_ptr[i + 1];
+        for (int r = rb; r < re; ++r) {
+            const uint32_t ref = A.ref[r];
+            const int kind = ref >> 28, role = (ref >> 26) & 3, t = ref & 0x3ffffff;
+            switch (kind) {
+            case AMM_BOND_HARMONIC: {
+                const int32_t *ix = A.idx[kind] + 2 * t;
+                const double *p = A.par[kind] + 2 * t;
+                const int other = ix[1 - role];
+                double d[3];
+                delta3(A.pos, i, other, A.box, A.periodic[kind], d);
+                const double rr = sqrt(dot3(d, d));
+                const double dr = rr - p[0];
+                const double fr = -p[1] * dr / rr;
+                f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
+                if (role == 0) esum += 0.5 * p[1] * dr * dr;
+            } break;
+            case AMM_ANGLE_HARMONIC: {
+                const int32_t *ix = A.idx[kind] + 3 * t;
+                const double *p = A.par[kind] + 2 * t;
+                double d1[3], d2[3];
+                delta3(A.pos, ix[0], ix[1], A.box, A.periodic[kind], d1);
+                delta3(A.pos, ix[2], ix[1], A.box, A.periodic[kind], d2);
+                const double r1 = sqrt(dot3(d1, d1)), r2 = sqrt(dot3(d2, d2));
+                double c = dot3(d1, d2) / (r1 * r2);
+                c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+                const double th = acos(c), dth = th - p[0];
+                double s = sqrt(1.0 - c * c);
+                if (s < 1e-12) s = 1e-12;
+                const double g = p[1] * dth / s;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const double fi = g * (d2[x] / r2 - c * d1[x] / r1) / r1;
+                    const double fk = g * (d1[x] / r1 - c * d2[x] / r2) / r2;
+                    f[x] += role == 0 ? fi : (role == 2 ? fk : -(fi + fk));
+                }
+                if (role == 0) esum += 0.5 * p[1] * dth * dth;
+            } break;
+            case AMM_BOND_LJC:
+            case AMM_BOND_NEAR: {
+                const int32_t *ix = A.idx[kind] + 2 * t;
+                const double *p = A.par[kind] + 3 * t;
+                const int other = ix[1 - role];
+                double d[3];
+                delta3(A.pos, i, other, A.box, A.periodic[kind], d);
+                const double r2 = dot3(d, d);
+                double e, fr;
+                if (kind == AMM_BOND_LJC) {   // forces.py:406
+                    const double rinv2 = 1.0 / r2, rinv = sqrt(rinv2);
+                    const double s2 = p[1] * p[1] * rinv2, x6 = s2 * s2 * s2;
+                    e = 4.0 * p[2] * x6 * (x6 - 1.0) + A.Kc_ljc * p[0] * rinv;
+                    fr = (4.0 * p[2] * (12.0 * x6 * x6 - 6.0 * x6) + A.Kc_ljc * p[0] * rinv) * rinv2;
+                } else {
+                    amm_pair_math_rt(A.near_pc, r2, A.near_pc.Kc * p[0], p[1], 4.0 * p[2], e, fr);
+                }
+                f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
+                if (role == 0) esum += e;
+            } break;
+            case AMM_BOND_EWALD_EXCL: {
+                const int32_t *ix = A.idx[kind] + 2 * t;
+                const double qq = A.par[kind][t];
+                const int other = ix[1 - role];
+                double d[3];
+                delta3(A.pos, i, other, A.box, 1, d);
+                const double r2 = dot3(d, d), rr = sqrt(r2), ar = A.ewald_alpha * rr;
+                const double er = erf(ar);
+                // E = -qq erf(ar)/r ;  -dE/dr = qq [ tasp exp(-a^2 r^2)/r - erf(ar)/r^2 ]
+                const double fr = qq * (A.ewald_tasp * exp(-ar * ar) / rr - er / r2) / rr;
+                f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
+                if (role == 0) esum += -qq * er / rr;
+            } break;
+            case AMM_TORSION_PERIODIC: {
+                const int32_t *ix = A.idx[kind] + 4 * t;
+                const double *p = A.par[kind] + 3 * t;
+                double F[3], G[3], H[3], Av[3], Bv[3], BA[3];
+                delta3(A.pos, ix[0], ix[1], A.box, A.periodic[kind], F);
+                delta3(A.pos, ix[1], ix[2], A.box, A.periodic[kind], G);
+                delta3(A.pos, ix[3], ix[2], A.box, A.periodic[kind], H);
+                cross3(F, G, Av);
+                cross3(H, G, Bv);
+                cross3(Bv, Av, BA);
+                const double Gn = sqrt(dot3(G, G));
+                const double phi = atan2(dot3(BA, G) / Gn, dot3(Av, Bv));
+                const double nper = p[0];
+                const double dEdphi = -p[2] * nper * sin(nper * phi - p[1]);
+                const double A2 = dot3(Av, Av), B2 = dot3(Bv, Bv), FG = dot3(F, G), HG = dot3(H, G);
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const double gi = -Gn / A2 * Av[x], gl = Gn / B2 * Bv[x];
+                    const double gj = Gn / A2 * Av[x] + FG / (A2 * Gn) * Av[x] - HG / (B2 * Gn) * Bv[x];
+                    const double gk = -Gn / B2 * Bv[x] - FG / (A2 * Gn) * Av[x] + HG / (B2 * Gn) * Bv[x];
+                    const double g = role == 0 ? gi : (role == 1 ? gj : (role == 2 ? gk : gl));
+                    f[x] -= dEdphi * g;
+                }
+                if (role == 0) esum += p[2] * (1.0 + cos(nper * phi - p[1]));
+            } break;
+            default: break;
+            }
+        }
+        if (A.accumulate) {
+            A.force[3 * i] += f[0]; A.force[3 * i + 1] += f[1]; A.force[3 * i + 2] += f[2];
+        } else {
+            A.force[3 * i] = f[0]; A.force[3 * i + 1] = f[1]; A.force[3 * i + 2] = f[2];
+        }
+    }
+    if (A.want_energy) {
+        __shared__ double red[4];
+        for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = esum;
+        __syncthreads();
+        if (threadIdx.x == 0) A.epart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+static const int kArity[6] = {2, 3, 2, 2, 4, 2};
+static const int kNpar[6] = {2, 2, 3, 3, 3, 1};
+
+int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
+    const int n = ctx->n;
+    std::vector<int> cnt(n + 1, 0);
+    for (int kind = 0; kind < 6; ++kind) {
+        const int nt = (int)bs->h_idx[kind].size() / kArity[kind];
+        bs->n_terms[kind] = nt;
+        for (int t = 0; t < nt; ++t)
+            for (int r = 0; r < kArity[kind]; ++r) {
+                int a = bs->h_idx[kind][t * kArity[kind] + r];
+                if (a < 0 || a >= n) {
+                    amm_set_error("bonded term references an atom index out of range");
+                    return 1;
+                }
+                cnt[a + 1]++;
+            }
+        if (nt >= (1 << 26)) {
+            amm_set_error("too many bonded terms of one kind");
+            return 1;
+        }
+    }
+    for (int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+    std::vector<uint32_t> ref(cnt[n]);
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+    for (int kind = 0; kind < 6; ++kind)
+        for (int t = 0; t < bs->n_terms[kind]; ++t)
+            for (int r = 0; r < kArity[kind]; ++r) {
+                int a = bs->h_idx[kind][t * kArity[kind] + r];
+                ref[fill[a]++] = ((uint32_t)kind << 28) | ((uint32_t)r << 26) | (uint32_t)t;
+            }
+    AMM_HIP(hipMalloc(&bs->d_ref_ptr, sizeof(int) * (n + 1)));
+    AMM_HIP(hipMemcpy(bs->d_ref_ptr, cnt.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+    AMM_HIP(hipMalloc(&bs->d_ref, sizeof(uint32_t) * std::max<size_t>(ref.size(), 1)));
+    if (!ref.empty()) AMM_HIP(hipMemcpy(bs->d_ref, ref.data(), sizeof(uint32_t) * ref.size(), hipMemcpyHostToDevice));
+    for (int kind = 0; kind < 6; ++kind) {
+        if (bs->n_terms[kind] == 0) continue;
+        AMM_HIP(hipMalloc(&bs->d_idx[kind], sizeof(int32_t) * bs->h_idx[kind].size()));
+        AMM_HIP(hipMemcpy(bs->d_idx[kind], bs->h_idx[kind].data(), sizeof(int32_t) * bs->h_idx[kind].size(), hipMemcpyHostToDevice));
+        AMM_HIP(hipMalloc(&bs->d_par[kind], sizeof(double) * bs->h_par[kind].size()));
+        AMM_HIP(hipMemcpy(bs->d_par[kind], bs->h_par[kind].data(), sizeof(double) * bs->h_par[kind].size(), hipMemcpyHostToDevice));
+    }
+    bs->n_epart = (n + 255) / 256;
+    AMM_HIP(hipMalloc(&bs->d_epart, sizeof(double) * bs->n_epart));
+    bs->finalized = true;
+    return 0;
+}
+
+int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate,
+                         double *d_energy) {
+    if (!bs->finalized) {
+        amm_set_error("bonded set evaluated before amm_bonded_finalize");
+        return 1;
+    }
+    const int n = ctx->n;
+    BondedArgs A;
+    A.n = n;
+    A.row_begin = 0;
+    A.row_end = n;
+    if (bs->sliced && ctx->world > 1) {
+        const int per = (n + ctx->world - 1) / ctx->world;
+        A.row_begin = std::min(n, ctx->rank * per);
+        A.row_end = std::min(n, A.row_begin + per);
+        if (!accumulate) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, ctx->stream));
+    }
+    A.ref_ptr = bs->d_ref_ptr;
+    A.ref = bs->d_ref;
+    for (int k = 0; k < 6; ++k) {
+        A.idx[k] = bs->d_idx[k];
+        A.par[k] = bs->d_par[k];
+        A.periodic[k] = bs->periodic[k];
+    }
+    A.pos = d_pos;
+    A.force = d_force;
+    A.epart = bs->d_epart;
+    A.accumulate = accumulate;
+    A.want_energy = d_energy != nullptr;
+    A.box = ctx->box;
+    A.near_pc = bs->near_pc;
+    A.ewald_alpha = bs->ewald_alpha;
+    A.ewald_tasp = bs->ewald_alpha * 1.1283791670955125739;
+    A.Kc_ljc = bs->ljc_Kc;
+    const int rows = A.row_end - A.row_begin;
+    const int nblk = std::max(1, (rows + 255) / 256);
+    hipLaunchKernelGGL(k_bonded, dim3(nblk), dim3(256), 0, ctx->stream, A);
+    AMM_HIP(hipGetLastError());
+    if (d_energy) return amm_reduce_add(ctx, bs->d_epart, nblk, 1.0, d_energy);
+    return 0;
+}
+
+int amm_bonded_free(BondedSet *bs) {
+    for (int k = 0; k < 6; ++k) {
+        if (bs->d_idx[k]) (void)hipFree(bs->d_idx[k]);
+        if (bs->d_par[k]) (void)hipFree(bs->d_par[k]);
+    }
+    if (bs->d_ref_ptr) (void)hipFree(bs->d_ref_ptr);
+    if (bs->d_ref) (void)hipFree(bs->d_ref);
+    if (bs->d_epart) (void)hipFree(bs->d_epart);
+    return 0;
+}
+
+int amm_bonded_arity(int kind) { return kArity[kind]; }
+int amm_bonded_npar(int kind) { return kNpar[kind]; }

@@ -1,0 +1,60 @@
+// atomsmm_amd/csrc/integrate.hip -- per-DOF step-program primitives (gfx950, fp64).
+//
+// The reference's propagators emit CustomIntegrator per-DOF assignments (propagators.py:249 move,
+// :271 kick; integrators.py:113 mvv sum); OpenMM's VM evaluates them operation by operation in fp64.
+// These kernels do the same arithmetic in the same order, with contraction into FMA disabled
+// (explicit __dmul_rn/__dadd_rn/__ddiv_rn), so a kick/move here is BIT-IDENTICAL to the oracle's.
+// Pure streaming: 3N doubles, 16-byte accesses where the layout allows.
+#include "amm_ctx.h"
+
+// v <- v + (coef)*(f - fsub)/m      propagators.py:271 with force expression `f`, `(_f2_-f1)`, ...
+__global__ void k_kick(int n3, double *__restrict__ v, const double *__restrict__ f, const double *__restrict__ fsub,
+                       const double *__restrict__ mass, double coef) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    double ff = f[t];
+    if (fsub) ff = __dsub_rn(ff, fsub[t]);
+    v[t] = __dadd_rn(v[t], __ddiv_rn(__dmul_rn(coef, ff), mass[t / 3]));
+}
+
+// x <- x + (coef)*v                propagators.py:249
+__global__ void k_move(int n3, double *__restrict__ x, const double *__restrict__ v, double coef) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    x[t] = __dadd_rn(x[t], __dmul_rn(coef, v[t]));
+}
+
+__global__ void k_mvv(int n, const double *__restrict__ v, const double *__restrict__ m, double *part) {
+    __shared__ double red[4];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double s = 0.0;
+    if (i < n) s = m[i] * (v[3 * i] * v[3 * i] + v[3 * i + 1] * v[3 * i + 1] + v[3 * i + 2] * v[3 * i + 2]);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_fsub, const double *d_mass, double coef) {
+    const int n3 = 3 * ctx->n;
+    hipLaunchKernelGGL(k_kick, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_v, d_f, d_fsub, d_mass, coef);
+    AMM_HIP(hipGetLastError());
+    return 0;
+}
+int amm_move_impl(amm_ctx *ctx, double *d_x, const double *d_v, double coef) {
+    const int n3 = 3 * ctx->n;
+    hipLaunchKernelGGL(k_move, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_x, d_v, coef);
+    AMM_HIP(hipGetLastError());
+    return 0;
+}
+int amm_copy_impl(amm_ctx *ctx, double *d_dst, const double *d_src) {
+    AMM_HIP(hipMemcpyAsync(d_dst, d_src, sizeof(double) * 3 * (size_t)ctx->n, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+int amm_mvv_impl(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out) {
+    const int nblk = (ctx->n + 255) / 256;
+    hipLaunchKernelGGL(k_mvv, dim3(nblk), dim3(256), 0, ctx->stream, ctx->n, d_v, d_m, ctx->d_scratch);
+    AMM_HIP(hipGetLastError());
+    AMM_HIP(hipMemsetAsync(d_out, 0, sizeof(double), ctx->stream));
+    return amm_reduce_add(ctx, ctx->d_scratch, nblk, 1.0, d_out);
+}

@@ -1,0 +1,142 @@
+// atomsmm_amd/csrc/pair_math.h -- per-pair energy / force of the AtomsMM pair families (device, fp64).
+//
+// Every family returns e = sign*E(r) and fr = sign*(-dE/dr)/r for mixed parameters
+//   qq  = Kc*q_i*q_j,  sig = (sigma_i+sigma_j)/2,  eps4 = 4*sqrt(eps_i*eps_j)
+// following the energy strings of the reference (file:line in /root/reference/src/atomsmm):
+//   NEAR_NONE     forces.py:542-543   S*(4 eps ((s/r)^12-(s/r)^6) + Kc qq/r), S = 1+step(r-rs0) u^3 (15u-6u^2-10)
+//   NEAR_SHIFT    forces.py:545-548   S*(V(r)-V(rc0)) term-wise
+//   NEAR_FSWITCH  forces.py:550-563   force-switched potential; V'(r) = S(u) V'_LJC(r) (forces.py:628)
+//   DAMPED        forces.py:448-455   SW*(LJ + erfc(alpha r) Kc qq/r), u = (r^d-rs^d)/(rc^d-rs^d)
+//   NONBONDED     forces.py:134-190   S_b*LJ + Coulomb {plain | erfc | reaction field}
+#pragma once
+#include "amm_ctx.h"
+
+__device__ __forceinline__ double amm_sw_S(double u) { return 1.0 + u * u * u * (15.0 * u - 6.0 * u * u - 10.0); }
+__device__ __forceinline__ double amm_sw_dS(double u) {
+    double w = u * (1.0 - u);
+    return -30.0 * w * w;
+}
+__device__ __forceinline__ double amm_powi(double x, int n) {
+    double r = 1.0;
+    for (int k = 0; k < n; ++k) r *= x;
+    return r;
+}
+
+template <int FAM, int CMODE, bool GUARD, bool EN>
+__device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, double qq, double sig, double eps4,
+                                              double &e, double &fr) {
+    const double rinv = 1.0 / sqrt(r2);
+    const double r = r2 * rinv;
+    const double rinv2 = rinv * rinv;
+    e = 0.0;
+    fr = 0.0;
+    if (GUARD) {
+        if (!(c.rc0 - r >= 0.0)) return;   // step(rc0 - r), forces.py:661,714
+    }
+    const double s2 = sig * sig * rinv2;
+    const double s6 = s2 * s2 * s2;
+    const double s12 = s6 * s6;
+    const double dlj_r = eps4 * (12.0 * s12 - 6.0 * s6) * rinv2;   // (-dV_LJ/dr)/r
+    const double coul = qq * rinv;
+    const double dcoul_r = coul * rinv2;                            // (-d(qq/r)/dr)/r
+    if (FAM == AMM_NEAR_NONE || FAM == AMM_NEAR_SHIFT || FAM == AMM_NEAR_FSWITCH) {
+        const double du = r - c.rs0;
+        const double u = (du >= 0.0) ? du * c.inv_dr0 : 0.0;
+        const double S = amm_sw_S(u);
+        if (FAM == AMM_NEAR_FSWITCH) {
+            fr = S * (dlj_r + dcoul_r);
+            if (EN) {
+                double f12 = 1.0, f6 = 1.0, f1 = 1.0;
+                if (du >= 0.0) {
+                    const double b = c.b, b2 = b * b, b3 = b2 * b;
+                    const double R = u / b + 1.0;
+                    const double u2 = u * u, u3 = u2 * u, u4 = u3 * u, u5 = u4 * u;
+                    const double R2 = R * R, R3 = R2 * R, R6 = R3 * R3, R12 = R6 * R6;
+                    f12 = 1.0 + ((6 * b2 - 21 * b + 28) * (b3 * (R12 - 1) - 12 * b2 * u - 66 * b * u2 - 220 * u3) / 462 +
+                                 45 * (7 - 2 * b) * u4 / 14 - 72 * u5 / 7);
+                    f6 = 1.0 + ((6 * b2 - 3 * b + 1) * (b3 * (R6 - 1) - 6 * b2 * u - 15 * b * u2 - 20 * u3) +
+                                45 * (1 - 2 * b) * u4 - 36 * u5);
+                    f1 = 1.0 + (5 * (b + 1) * (b + 1) * (6 * b3 * R * log(R) - 6 * b2 * u - 3 * b * u2 + u3) +
+                                u4 * (3 * u - 5 * b - 10) / 2);
+                }
+                const double sc2 = sig * sig * c.inv_rc0_2, sc6 = sc2 * sc2 * sc2, sc12 = sc6 * sc6;
+                e = eps4 * (f12 * s12 - f6 * s6) + qq * f1 * rinv -
+                    (eps4 * (c.f12c * sc12 - c.f6c * sc6) + qq * c.f1c * c.inv_rc0);
+            }
+        } else {
+            double V;
+            if (FAM == AMM_NEAR_SHIFT) {
+                const double sc2 = sig * sig * c.inv_rc0_2, sc6 = sc2 * sc2 * sc2, sc12 = sc6 * sc6;
+                V = eps4 * (s12 - s6 - (sc12 - sc6)) + qq * (rinv - c.inv_rc0);
+            } else {
+                V = eps4 * (s12 - s6) + coul;
+            }
+            const double dSdr = amm_sw_dS(u) * c.inv_dr0;
+            fr = S * (dlj_r + dcoul_r) - dSdr * V * rinv;
+            if (EN) e = S * V;
+        }
+    } else if (FAM == AMM_DAMPED) {
+        const double ar = c.alpha * r;
+        const double ec = erfc(ar);
+        const double ex = exp(-ar * ar);
+        const double V = eps4 * (s12 - s6) + ec * coul;
+        const double mdV_r = dlj_r + ec * dcoul_r + coul * c.two_alpha_over_sqrtpi * ex * rinv;
+        double S = 1.0, dSdr = 0.0;
+        if (r - c.rswitch >= 0.0) {
+            const int d = c.degree;
+            const double rd1 = amm_powi(r, d - 1);
+            const double u = (rd1 * r - amm_powi(c.rswitch, d)) / c.sw_den;
+            S = amm_sw_S(u);
+            dSdr = amm_sw_dS(u) * d * rd1 / c.sw_den;
+        }
+        fr = S * mdV_r - dSdr * V * rinv;
+        if (EN) e = S * V;
+    } else {   // AMM_NONBONDED
+        double S = 1.0, dSdr = 0.0;
+        if ((c.flags & AMM_SWITCH) && r > c.rswitch) {
+            const double t = (r - c.rswitch) * c.inv_sw_dr;
+            S = amm_sw_S(t);
+            dSdr = amm_sw_dS(t) * c.inv_sw_dr;
+        }
+        const double lj = eps4 * (s12 - s6);
+        fr = S * dlj_r - dSdr * lj * rinv;
+        if (EN) e = S * lj;
+        if (CMODE == 1) {
+            const double ar = c.alpha * r;
+            const double ec = erfc(ar);
+            const double ex = exp(-ar * ar);
+            fr += ec * dcoul_r + coul * c.two_alpha_over_sqrtpi * ex * rinv;
+            if (EN) e += ec * coul;
+        } else if (CMODE == 2) {
+            fr += qq * (rinv2 * rinv - 2.0 * c.krf);
+            if (EN) e += qq * (rinv + c.krf * r2 - c.crf);
+        } else {
+            fr += dcoul_r;
+            if (EN) e += coul;
+        }
+    }
+    fr *= c.sign;
+    if (EN) e *= c.sign;
+}
+
+// Runtime-dispatched variant for the bond-list kernels (not hot: O(#exceptions)).
+__device__ __forceinline__ void amm_pair_math_rt(const PairConsts &c, double r2, double qq, double sig, double eps4,
+                                                 double &e, double &fr) {
+    const bool g = (c.flags & AMM_GUARD_RC0) != 0;
+    switch (c.family) {
+    case AMM_NEAR_NONE:
+        if (g) amm_pair_math<AMM_NEAR_NONE, 0, true, true>(c, r2, qq, sig, eps4, e, fr);
+        else amm_pair_math<AMM_NEAR_NONE, 0, false, true>(c, r2, qq, sig, eps4, e, fr);
+        break;
+    case AMM_NEAR_SHIFT:
+        if (g) amm_pair_math<AMM_NEAR_SHIFT, 0, true, true>(c, r2, qq, sig, eps4, e, fr);
+        else amm_pair_math<AMM_NEAR_SHIFT, 0, false, true>(c, r2, qq, sig, eps4, e, fr);
+        break;
+    default:
+        if (g) amm_pair_math<AMM_NEAR_FSWITCH, 0, true, true>(c, r2, qq, sig, eps4, e, fr);
+        else amm_pair_math<AMM_NEAR_FSWITCH, 0, false, true>(c, r2, qq, sig, eps4, e, fr);
+        break;
+    }
+}
+
+__device__ __forceinline__ double amm_min_image(double d, double L, double invL) { return d - L * rint(d * invL); }

@@ -1,0 +1,157 @@
+/*
+ * include/atomsmm_hip.h -- C-ABI of libatomsmm_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE hot path of AtomsMM: the RESPA-split nonbonded pair forces and the
+ * multiple-timescale propagator inner loop.  AtomsMM has no FFI of its own: it subclasses OpenMM's
+ * SWIG classes and OpenMM's C++ does the arithmetic.  Each entry point below
+ * therefore names the OpenMM call *as made by the reference* (file:line in /root/reference) whose
+ * work it takes over.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - return 0 = OK; non-zero = error, message via amm_last_error().
+ *   - `h_` pointers are HOST memory (copied during the call, caller keeps ownership);
+ *     `d_` pointers are DEVICE memory owned by the caller (e.g. torch tensors), fp64, C-contiguous;
+ *     per-atom vectors are AoS [n_atoms][3].
+ *   - units: nm, ps, dalton, kJ/mol, elementary charge (OpenMM's unit system).
+ *   - all work is enqueued on the context's HIP stream; nothing synchronises unless stated.
+ *   - one context per process per GPU; not thread-safe.
+ *   - atom decomposition: amm_set_slice(rank, world) makes pair forces compute only the atoms of
+ *     this rank's slice (rows of other atoms are written as 0), so that an all-reduce(sum) over
+ *     ranks (RCCL, done by the host through torch.distributed) yields the full force.
+ */
+#ifndef ATOMSMM_HIP_H
+#define ATOMSMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMM_ABI_VERSION 1
+
+/* ---- pair-energy families -------------------------------------------------------------------- */
+enum {
+    AMM_NEAR_NONE = 0,      /* S(u) V_LJC                      NearForce._expressions forces.py:541-543 */
+    AMM_NEAR_SHIFT = 1,     /* S(u) (V_LJC(r) - V_LJC(rc0))    forces.py:544-548                        */
+    AMM_NEAR_FSWITCH = 2,   /* force-switched LJC              forces.py:549-563 (V' = S V'_LJC, :628)  */
+    AMM_DAMPED = 3,         /* DampedSmoothedForce             forces.py:448-455                        */
+    AMM_NONBONDED = 4       /* _AtomsMM_NonbondedForce direct space  forces.py:134-190, 723             */
+};
+enum {
+    AMM_GUARD_RC0 = 1,      /* energy *= step(rc0 - r)         forces.py:661, 714 ; systems.py:73      */
+    AMM_COULOMB_EWALD = 2,  /* NONBONDED: Kc qq erfc(alpha r)/r                                         */
+    AMM_COULOMB_RF = 4,     /* NONBONDED: reaction field (parity unpinned)              */
+    AMM_SWITCH = 8          /* NONBONDED: OpenMM built-in switch on the LJ term                         */
+};
+
+typedef struct {
+    int32_t family;
+    int32_t flags;
+    int32_t degree;   /* DAMPED: u = (r^d - rs^d)/(rc^d - rs^d); d = 1 is OpenMM's built-in switch */
+    int32_t pad_;
+    double sign;      /* +1 / -1 (subtract=True forces.py:662; discount forces.py:714)            */
+    double rc;        /* cutoff actually used: pairs with r >= rc skipped                          */
+    double rswitch;   /* DAMPED / NONBONDED switch start                                           */
+    double rc0, rs0;  /* near-force cutoff / switch start                                          */
+    double alpha;     /* erfc damping, 1/nm                                                        */
+    double Kc;        /* 138.935456  forces.py:407                                                 */
+    double krf, crf;  /* reaction field constants                                                  */
+} amm_pair_desc;
+
+/* ---- bonded term kinds (owner-computes, no atomics) ------------------------------------------ */
+enum {
+    AMM_BOND_HARMONIC = 0,   /* idx[2], params (r0, k)            OpenMM HarmonicBondForce (group 0)       */
+    AMM_ANGLE_HARMONIC = 1,  /* idx[3], params (theta0, k)        OpenMM HarmonicAngleForce                */
+    AMM_BOND_LJC = 2,        /* idx[2], params (qq, sigma, eps)   NonbondedExceptionsForce forces.py:400-407 */
+    AMM_BOND_NEAR = 3,       /* idx[2], params (qq, sigma, eps)   NearExceptionForce forces.py:673-680     */
+    AMM_TORSION_PERIODIC = 4,/* idx[4], params (n, phase, k)      OpenMM PeriodicTorsionForce              */
+    AMM_BOND_EWALD_EXCL = 5  /* idx[2], params (qi*qj)            -Kc qi qj erf(alpha r)/r, NonbondedForce exclusion term */
+};
+
+/* ---- step-program ops (one flat, unrolled outer step; built by the host from the step program
+ *      that RespaPropagator.addSteps emits, propagators.py:933-973) ------------------------------ */
+enum {
+    AMM_OP_EVAL = 1,   /* a = group: buffer[group_slot(a)] <- sum of the group's forces at current x */
+    AMM_OP_KICK = 2,   /* v <- v + coef*(buf[a] - buf[b])/m   (b = -1: no subtraction)  propagators.py:271 */
+    AMM_OP_MOVE = 3,   /* x <- x + coef*v                                                propagators.py:249 */
+    AMM_OP_COPY = 4    /* buf[a] <- buf[b]                          integrators.py:139-144 (`_f2_ <- f2`)    */
+};
+typedef struct {
+    int32_t op, a, b, c;
+    double coef;
+} amm_op;
+
+typedef struct amm_ctx amm_ctx;
+
+int amm_abi_version(void);
+const char *amm_last_error(void);
+
+/* Context.__init__ / Context.setPeriodicBoxVectors  (utils.py:153-155 builds the Simulation/Context).
+ * stream: hipStream_t as void* (NULL = default stream). */
+int amm_create(int32_t n_atoms, const double h_box[3], int32_t device, void *stream, amm_ctx **out);
+int amm_destroy(amm_ctx *ctx);
+int amm_set_stream(amm_ctx *ctx, void *stream);
+int amm_set_slice(amm_ctx *ctx, int32_t rank, int32_t world);
+int amm_synchronize(amm_ctx *ctx);
+/* Raises pending device-side errors (neighbour-list overflow, NaN guard): returns non-zero + message. Synchronises. */
+int amm_check(amm_ctx *ctx);
+
+/* CustomNonbondedForce(energy) + addParticle + addExclusion  (forces.py:225, 299-312; systems.py:97-111).
+ * h_excl: E pairs (i,j) -- every exception of the source NonbondedForce becomes an exclusion.
+ * skin: Verlet buffer (nm) for the cell-list-built neighbour list; <0 = default. */
+int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, const double *h_sigma,
+                    const double *h_eps, const int32_t *h_excl, int32_t n_excl, double skin,
+                    int32_t *force_id);
+/* setParticleParameters + updateParametersInContext / Context.setParameter for offset parameters
+ * (forces.py:247-258, 292-309: charge+lambda*chargeScale ...). Effective values are passed. */
+int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const double *h_sigma,
+                        const double *h_eps);
+
+/* CustomBondForce / HarmonicBondForce / HarmonicAngleForce term lists of one force group. */
+int amm_bonded_create(amm_ctx *ctx, int32_t *force_id);
+int amm_bonded_add_terms(amm_ctx *ctx, int32_t force_id, int32_t kind, const int32_t *h_idx,
+                         const double *h_params, int32_t n_terms, int32_t periodic,
+                         const amm_pair_desc *desc_or_null);
+int amm_bonded_finalize(amm_ctx *ctx, int32_t force_id);
+/* world > 1: evaluate only this rank's block of atoms (use for bonded sets living in an all-reduced group). */
+int amm_bonded_set_sliced(amm_ctx *ctx, int32_t force_id, int32_t on);
+
+/* Context.getState(getForces=True, getEnergy=True, groups=...)  (utils.py:159-164).
+ * d_force [n][3]: overwritten (accumulate=0) or added to; d_energy: *d_energy += E (skipped if NULL). */
+int amm_force_eval(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_force,
+                   int32_t accumulate, double *d_energy);
+
+/* CustomIntegrator per-DOF steps as the reference emits them (propagators.py:249, 271; integrators.py:113). */
+int amm_kick(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_fsub, const double *d_mass, double coef);
+int amm_move(amm_ctx *ctx, double *d_x, const double *d_v, double coef);
+int amm_copy(amm_ctx *ctx, double *d_dst, const double *d_src);
+int amm_mvv(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out); /* addComputeSum('mvv','m*v*v') */
+
+/* CustomIntegrator.step(n)  (integrators.py:153-163): bind state buffers, define groups, run ops. */
+int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass);
+int amm_bind_buffer(amm_ctx *ctx, int32_t slot, double *d_buf);              /* per-DOF buffers f0.., _f2_, fm1 */
+int amm_group_define(amm_ctx *ctx, int32_t group, int32_t slot, const int32_t *force_ids, int32_t n_forces);
+int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+typedef struct {
+    int64_t n_builds;       /* neighbour-list (re)builds so far                       */
+    int64_t n_evals;        /* force evaluations so far                               */
+    int64_t n_list_pairs;   /* directed pairs currently in the list (this slice)      */
+    int64_t n_slice_atoms;  /* atoms owned by this rank's slice                       */
+    int32_t capacity;       /* neighbour slots per atom                               */
+    int32_t max_neighbors;  /* longest list                                           */
+    int32_t lanes_per_atom; /* lanes of a wavefront that share one i-atom             */
+    int32_t n_cells;
+    double rlist;
+} amm_pair_stats;
+int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
+/* HIP-event timing of the dominant kernel (pair traversal) on the context stream. */
+int amm_profile_enable(amm_ctx *ctx, int32_t on);
+int amm_profile_read(amm_ctx *ctx, int32_t force_id, int64_t *n_launches, double *total_ms); /* synchronises, resets */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

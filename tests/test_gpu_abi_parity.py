@@ -1,0 +1,360 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP kernels called through the C-ABI
+(include/atomsmm_hip.h via atomsmm_amd.backend) against the CPU oracle on the same inputs, and
+against the reference's golden literals.
+
+Stated fp64 tolerances: energies rel 1e-10 vs the oracle (1e-8 for the
+ill-conditioned force-switch energy at b = 19), forces 1e-9*max|F| vs the oracle, energies rel 1e-6
+vs the reference literals (the reference's own tolerance); kick/move: bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+from oracle import oracle as O  # noqa: E402  (checker only)
+
+
+def _backend():
+    from atomsmm_amd import backend as B
+    return B
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device='cuda')
+
+
+def hip_pair(B, ctx, d, c, skin=-1.0, q=None, s=None, e=None, excl=None):
+    q = c['charge'] if q is None else q
+    s = c['sigma'] if s is None else s
+    e = c['epsilon'] if e is None else e
+    excl = c['exc_pairs'] if excl is None else excl
+    desc = B.pair_desc(d.family, d.rc, rc0=d.rc0, rs0=d.rs0, rswitch=d.rswitch, alpha=d.alpha, degree=d.degree,
+                       flags=d.flags, sign=d.sign, Kc=d.Kc, krf=d.krf, crf=d.crf)
+    return ctx.pair_create(desc, q, s, e, excl, skin=skin)
+
+
+def eval_force(ctx, fid, pos_t, n):
+    f = torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda')
+    en = torch.zeros(1, dtype=torch.float64, device='cuda')
+    ctx.force_eval(fid, pos_t, f, accumulate=False, energy=en)
+    ctx.check()
+    return en.item(), f.cpu().numpy()
+
+
+def near(adj, rc, rs, **kw):
+    return O.desc(O.ADJ[adj], rc=kw.pop('actual', rc), rc0=rc, rs0=rs, **kw)
+
+
+CASES = {
+    'G1-near-none': (near(None, 1.0, 0.95), 'G1', 1e-10),
+    'G2-near-shift': (near('shift', 1.0, 0.95), 'G2', 1e-10),
+    'G3-near-fswitch-b19': (near('force-switch', 1.0, 0.95), 'G3', 1e-7),
+    'G4-damped-1': (O.desc(O.DAMPED, rc=1.0, rswitch=0.95, alpha=2.9, degree=1), 'G4', 1e-10),
+    'G5-damped-2': (O.desc(O.DAMPED, rc=1.0, rswitch=0.95, alpha=2.9, degree=2), 'G5', 1e-10),
+    'G6-respa-near': (near('force-switch', 0.7, 0.5), 'G6', 1e-10),
+    'G6-respa-minus-near': (near('force-switch', 0.7, 0.5, sign=-1.0, flags=O.GUARD_RC0), None, 1e-10),
+    'discount-at-outer-cutoff': (near('force-switch', 0.7, 0.5, sign=-1.0, flags=O.GUARD_RC0, actual=1.0), None, 1e-10),
+    'near-none-respa': (near(None, 0.7, 0.5), None, 1e-10),
+    'near-shift-respa': (near('shift', 0.7, 0.5), None, 1e-10),
+    'ewald-direct': (O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, alpha=2.628260884878466,
+                            flags=O.COULOMB_EWALD | O.SWITCH), None, 1e-10),
+    'reaction-field': (O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, flags=O.COULOMB_RF | O.SWITCH,
+                              krf=(78.3 - 1) / (2 * 78.3 + 1), crf=3 * 78.3 / (2 * 78.3 + 1)), None, 1e-10),
+    'plain-cutoff': (O.desc(O.NONBONDED, rc=1.0), None, 1e-10),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_pair_families_vs_oracle_and_goldens(spcfw, goldens, name):
+    B = _backend()
+    d, gid, etol = CASES[name]
+    c = spcfw
+    n = len(c['positions'])
+    e_ref, f_ref, _ = O.pair_eval(d, c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])
+    ctx = B.HipContext(n, c['box'])
+    fid = hip_pair(B, ctx, d, c)
+    e, f = eval_force(ctx, fid, dev(c['positions']), n)
+    assert e == pytest.approx(e_ref, rel=etol)
+    assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    if gid:
+        assert e == pytest.approx(goldens[gid]['value'], rel=1e-6)
+    # force-only launch (no energy) gives the same forces bit for bit
+    f2 = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+    ctx.force_eval(fid, dev(c['positions']), f2)
+    if d.family != O.NEAR_FSWITCH:
+        assert np.abs(f2.cpu().numpy() - f).max() <= 1e-12 * np.abs(f).max()
+    else:
+        assert np.array_equal(f2.cpu().numpy(), f)
+    ctx.close()
+
+
+def test_ewald_direct_golden_G7(spcfw, goldens):
+    """Group-2 NonbondedForce direct space = pair(erfc, switched LJ) + exclusion erf term + dispersion constant."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    alpha = np.sqrt(-np.log(2 * 5e-4)) / 1.0
+    ctx = B.HipContext(n, c['box'])
+    d = O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, alpha=alpha, flags=O.COULOMB_EWALD | O.SWITCH)
+    fid = hip_pair(B, ctx, d, c)
+    bid = ctx.bonded_create()
+    qq = c['charge'][c['exc_pairs'][:, 0]] * c['charge'][c['exc_pairs'][:, 1]]
+    ctx.bonded_add_terms(bid, B.BOND_EWALD_EXCL, c['exc_pairs'], qq, periodic=True,
+                         desc=B.pair_desc(B.NONBONDED, 1.0, alpha=alpha))
+    ctx.bonded_finalize(bid)
+    pos = dev(c['positions'])
+    e1, f1 = eval_force(ctx, fid, pos, n)
+    e2, f2 = eval_force(ctx, bid, pos, n)
+    e_exc, f_exc = O.ewald_exclusion(c['exc_pairs'], c['positions'], c['box'], c['charge'], alpha)
+    assert e2 == pytest.approx(e_exc, rel=1e-11)
+    assert np.abs(f2 - f_exc).max() <= 1e-9 * np.abs(f_exc).max()
+    e_disp = O.dispersion_correction(c['sigma'], c['epsilon'], c['box'], 1.0, 0.9)   # constant, host side
+    assert e1 + e2 + e_disp == pytest.approx(goldens['G7']['value'], rel=1e-6)
+    ctx.close()
+
+
+def test_bonded_terms_vs_oracle(heaq, goldens):
+    B = _backend()
+    h = heaq
+    n = len(h['positions'])
+    ctx = B.HipContext(n, h['box'])
+    pos = dev(h['positions'])
+    sets = {
+        'bonds': (B.BOND_HARMONIC, h['bonds'], np.stack([h['bond_r0'], h['bond_k']], 1), False,
+                  O.harmonic_bonds(h['bonds'], h['bond_r0'], h['bond_k'], h['positions'], h['box']), 'G_heaq_bonds'),
+        'angles': (B.ANGLE_HARMONIC, h['angles'], np.stack([h['angle_theta0'], h['angle_k']], 1), False,
+                   O.harmonic_angles(h['angles'], h['angle_theta0'], h['angle_k'], h['positions'], h['box']),
+                   'G_heaq_angles'),
+        'torsions': (B.TORSION_PERIODIC, h['torsions'],
+                     np.stack([h['torsion_n'].astype(float), h['torsion_phase'], h['torsion_k']], 1), False,
+                     O.periodic_torsions(h['torsions'], h['torsion_n'], h['torsion_phase'], h['torsion_k'],
+                                         h['positions'], h['box']), 'G_heaq_torsions'),
+        'ljc': (B.BOND_LJC, h['exc_pairs'], np.stack([h['exc_chargeprod'], h['exc_sigma'], h['exc_epsilon']], 1), True,
+                O.ljc_bonds(h['exc_pairs'], h['exc_chargeprod'], h['exc_sigma'], h['exc_epsilon'], h['positions'],
+                            h['box'], periodic=True), None),
+    }
+    ftot_ref = np.zeros((n, 3))
+    allid = ctx.bonded_create()
+    for name, (kind, idx, par, periodic, (e_ref, f_ref), gid) in sets.items():
+        bid = ctx.bonded_create()
+        ctx.bonded_add_terms(bid, kind, idx, par, periodic=periodic)
+        ctx.bonded_finalize(bid)
+        ctx.bonded_add_terms(allid, kind, idx, par, periodic=periodic)
+        e, f = eval_force(ctx, bid, pos, n)
+        assert e == pytest.approx(e_ref, rel=1e-11, abs=1e-10), name
+        assert np.abs(f - f_ref).max() <= 1e-10 * max(1.0, np.abs(f_ref).max()), name
+        if gid:
+            assert e == pytest.approx(goldens[gid]['value'], rel=1e-6)
+        ftot_ref += f_ref
+    ctx.bonded_finalize(allid)
+    _, f = eval_force(ctx, allid, pos, n)
+    assert np.abs(f - ftot_ref).max() <= 1e-10 * np.abs(ftot_ref).max()
+    # near-guarded exception bonds (NearExceptionForce, forces.py:673-680)
+    d = near('force-switch', 0.7, 0.5, flags=O.GUARD_RC0)
+    e_ref, f_ref = O.near_bonds(d, h['exc_pairs'], h['exc_chargeprod'], h['exc_sigma'], h['exc_epsilon'],
+                                h['positions'], h['box'], periodic=True)
+    bid = ctx.bonded_create()
+    ctx.bonded_add_terms(bid, B.BOND_NEAR, h['exc_pairs'],
+                         np.stack([h['exc_chargeprod'], h['exc_sigma'], h['exc_epsilon']], 1), periodic=True,
+                         desc=B.pair_desc(B.NEAR_FSWITCH, 0.7, rc0=0.7, rs0=0.5, flags=B.GUARD_RC0))
+    ctx.bonded_finalize(bid)
+    e, f = eval_force(ctx, bid, pos, n)
+    assert e == pytest.approx(e_ref, rel=1e-10)
+    assert np.abs(f - f_ref).max() <= 1e-10 * np.abs(f_ref).max()
+    ctx.close()
+
+
+def test_solvation_respa_golden_G9(heaq, goldens):
+    from helpers import solvation_respa_inputs
+    B = _backend()
+    h = heaq
+    n = len(h['positions'])
+    q, s, e, pairs, _, _, _ = solvation_respa_inputs(h, 0.5)
+    ctx = B.HipContext(n, h['box'])
+    d = near('force-switch', 0.7, 0.5)
+    fid = hip_pair(B, ctx, d, h, q=h['charge'], s=s, e=e, excl=pairs)
+    ctx.pair_set_params(fid, q, s, e)       # lambda_coul = 0.5 applied as a parameter update
+    en, _ = eval_force(ctx, fid, dev(h['positions']), n)
+    assert en == pytest.approx(goldens['G9']['value'], rel=1e-6)
+    ctx.close()
+
+
+def test_kick_move_bit_exact():
+    B = _backend()
+    rng = np.random.default_rng(7)
+    n = 1000
+    x = rng.normal(size=(n, 3)); v = rng.normal(size=(n, 3)); f = rng.normal(size=(n, 3)) * 100
+    g = rng.normal(size=(n, 3)) * 100
+    m = rng.uniform(1, 16, size=n)
+    ctx = B.HipContext(n, [3.0, 3.0, 3.0])
+    xd, vd, fd, gd, md = dev(x), dev(v), dev(f), dev(g), dev(m)
+    ctx.kick(vd, fd, md, 0.0625 * 0.004)
+    O.kick(v, f, m, 0.0625 * 0.004)
+    ctx.kick(vd, fd, md, 0.5 * 0.004, fsub=gd)
+    O.kick(v, f, m, 0.5 * 0.004, fsub=g)
+    ctx.move(xd, vd, 0.125 * 0.004)
+    O.move(x, v, 0.125 * 0.004)
+    ctx.synchronize()
+    assert np.array_equal(vd.cpu().numpy(), v)
+    assert np.array_equal(xd.cpu().numpy(), x)
+    out = torch.zeros(1, dtype=torch.float64, device='cuda')
+    ctx.mvv(vd, md, out)
+    assert out.item() == pytest.approx(O.mvv(v, m), rel=1e-13)
+    ctx.close()
+
+
+def test_neighbour_list_rebuild_and_reuse(spcfw):
+    """Positions drift: the Verlet list is reused while max displacement < skin/2 and rebuilt after;
+    forces match the oracle at every stage."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    d = near('force-switch', 0.7, 0.5)
+    ctx = B.HipContext(n, c['box'])
+    fid = hip_pair(B, ctx, d, c, skin=0.1)
+    rng = np.random.default_rng(3)
+    pos = c['positions'].copy()
+    builds = []
+    for step in range(6):
+        e_ref, f_ref, _ = O.pair_eval(d, pos, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])
+        e, f = eval_force(ctx, fid, dev(pos), n)
+        assert e == pytest.approx(e_ref, rel=1e-10)
+        assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+        builds.append(ctx.pair_stats(fid)['n_builds'])
+        pos = pos + rng.normal(scale=0.012, size=pos.shape)     # random walk, ~0.02 nm per step
+    assert builds[0] == 1 and builds[1] == 1          # reused
+    assert builds[-1] > 1                              # rebuilt once the skin was consumed
+    # a big jump (atoms leave the box) forces a rebuild and wrapping
+    pos = pos + np.array([3.1, -2.7, 5.0])
+    e_ref, f_ref, _ = O.pair_eval(d, pos, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])
+    e, f = eval_force(ctx, fid, dev(pos), n)
+    assert e == pytest.approx(e_ref, rel=1e-10)
+    assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    ctx.close()
+
+
+def test_atom_decomposition_slices_sum_to_full(spcfw):
+    """amm_set_slice: two 'ranks' (two contexts on one GPU) each compute their i-slice; the sum of the
+    two buffers (what the RCCL all-reduce does) equals the single-rank forces bit for bit."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    d = near('force-switch', 0.7, 0.5)
+    pos = dev(c['positions'])
+    ctx = B.HipContext(n, c['box'])
+    e_full, f_full = eval_force(ctx, hip_pair(B, ctx, d, c), pos, n)
+    parts, es = [], []
+    for r in range(2):
+        cr = B.HipContext(n, c['box'], rank=r, world=2)
+        e, f = eval_force(cr, hip_pair(B, cr, d, c), pos, n)
+        parts.append(f); es.append(e)
+        assert cr.pair_stats(0)['n_slice_atoms'] == n // 2
+        cr.close()
+    assert np.array_equal(parts[0] + parts[1], f_full)
+    assert ((parts[0] != 0).any(1) & (parts[1] != 0).any(1)).sum() == 0      # disjoint rows
+    assert es[0] + es[1] == pytest.approx(e_full, rel=1e-12)
+    ctx.close()
+
+
+def lj_fluid(ncell, seed=20240521):
+    """C2-style synthetic LJ fluid: simple-cubic lattice + jitter, rho*sigma^3 = 0.8."""
+    rng = np.random.default_rng(seed)
+    sigma, eps = 0.34, 0.996
+    a = sigma / 0.8 ** (1 / 3)
+    g = np.arange(ncell)
+    pos = np.stack(np.meshgrid(g, g, g, indexing='ij'), -1).reshape(-1, 3) * a
+    pos = pos + rng.normal(scale=0.05 * sigma, size=pos.shape)
+    n = len(pos)
+    return pos, np.full(3, ncell * a), np.zeros(n), np.full(n, sigma), np.full(n, eps)
+
+
+@pytest.mark.parametrize('adj', [None, 'shift', 'force-switch'])
+def test_lj_fluid_vs_oracle_cells(adj):
+    B = _backend()
+    pos, box, q, s, e = lj_fluid(16)      # 4096 atoms (the 32k config C2 runs in bench/test_gpu_full)
+    n = len(pos)
+    d = near(adj, 0.85, 0.765)
+    e_ref, f_ref, npairs = O.pair_eval(d, pos, box, q, s, e, None, use_cells=True)
+    ctx = B.HipContext(n, box)
+    desc = B.pair_desc(d.family, d.rc, rc0=d.rc0, rs0=d.rs0)
+    fid = ctx.pair_create(desc, q, s, e, None)
+    en, f = eval_force(ctx, fid, dev(pos), n)
+    assert en == pytest.approx(e_ref, rel=1e-10)
+    assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    st = ctx.pair_stats(fid)
+    assert st['n_list_pairs'] >= 2 * npairs
+    ctx.close()
+
+
+def test_respa_ops_vs_oracle_trajectory(spcfw, goldens):
+    """RespaPropagator([4,2,1]) op list on flexible q-SPC-FW for 2 outer steps:
+    groups 0 = bonds+angles, 1 = near force-switch(0.7,0.5), 2 = DampedSmoothed(2.9,1.0,0.9); the GPU
+    trajectory matches the same program driven on the oracle (positions to 1e-11 nm)."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    dt = 0.004
+    rng = np.random.default_rng(11)
+    x = c['positions'].copy()
+    m = c['mass'].copy()
+    v = rng.normal(size=(n, 3)) * np.sqrt(2.494 / m)[:, None]
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+
+    def f0(p):
+        return (O.harmonic_bonds(c['bonds'], c['bond_r0'], c['bond_k'], p, c['box'])[1] +
+                O.harmonic_angles(c['angles'], c['angle_theta0'], c['angle_k'], p, c['box'])[1])
+
+    def f1(p):
+        return O.pair_eval(dn, p, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
+
+    def f2(p):
+        return O.pair_eval(dd, p, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
+
+    # --- oracle-driven program (exact op order of SURVEY.md 3.2)
+    xo, vo = x.copy(), v.copy()
+    nsteps = 2
+    for _ in range(nsteps):
+        F2 = f2(xo); F1 = f1(xo)
+        O.kick(vo, F2, m, 0.5 * dt, fsub=F1)
+        for _n1 in range(2):
+            O.kick(vo, F1, m, 0.25 * dt)
+            F0 = f0(xo)
+            for _n0 in range(4):
+                O.kick(vo, F0, m, 0.0625 * dt)
+                O.move(xo, vo, 0.125 * dt)
+                F0 = f0(xo)
+                O.kick(vo, F0, m, 0.0625 * dt)
+            F1 = f1(xo)
+            O.kick(vo, F1, m, 0.25 * dt)
+        F2 = f2(xo)
+        O.kick(vo, F2, m, 0.5 * dt, fsub=F1)
+    # --- HIP
+    ctx = B.HipContext(n, c['box'])
+    bid = ctx.bonded_create()
+    ctx.bonded_add_terms(bid, B.BOND_HARMONIC, c['bonds'], np.stack([c['bond_r0'], c['bond_k']], 1))
+    ctx.bonded_add_terms(bid, B.ANGLE_HARMONIC, c['angles'], np.stack([c['angle_theta0'], c['angle_k']], 1))
+    ctx.bonded_finalize(bid)
+    nid = hip_pair(B, ctx, dn, c)
+    did = hip_pair(B, ctx, dd, c)
+    xd, vd, md = dev(x), dev(v), dev(m)
+    bufs = [torch.zeros((n, 3), dtype=torch.float64, device='cuda') for _ in range(4)]
+    ctx.bind_state(xd, vd, md)
+    for k, b in enumerate(bufs):
+        ctx.bind_buffer(k, b)
+    ctx.group_define(0, 0, [bid]); ctx.group_define(1, 1, [nid]); ctx.group_define(2, 2, [did])
+    E, K, M, CP = B.OP_EVAL, B.OP_KICK, B.OP_MOVE, B.OP_COPY
+    ops = [B.Op(E, 2, 0, 0, 0.0), B.Op(E, 1, 0, 0, 0.0), B.Op(CP, 3, 2, 0, 0.0), B.Op(K, 3, 1, 0, 0.5 * dt)]
+    for _n1 in range(2):
+        ops += [B.Op(K, 1, -1, 0, 0.25 * dt), B.Op(E, 0, 0, 0, 0.0)]
+        for _n0 in range(4):
+            ops += [B.Op(K, 0, -1, 0, 0.0625 * dt), B.Op(M, 0, 0, 0, 0.125 * dt), B.Op(E, 0, 0, 0, 0.0),
+                    B.Op(K, 0, -1, 0, 0.0625 * dt)]
+        ops += [B.Op(E, 1, 0, 0, 0.0), B.Op(K, 1, -1, 0, 0.25 * dt)]
+    ops += [B.Op(E, 2, 0, 0, 0.0), B.Op(CP, 3, 2, 0, 0.0), B.Op(K, 3, 1, 0, 0.5 * dt)]
+    ctx.run_ops(ops, repeat=nsteps)
+    ctx.check()
+    assert np.abs(xd.cpu().numpy() - xo).max() < 1e-11
+    assert np.abs(vd.cpu().numpy() - vo).max() < 1e-9
+    ctx.close()
