@@ -14,7 +14,9 @@ LIB_PATH = os.path.join(HERE, 'libatomsmm_hip.so')
 NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED = range(5)
 GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH = 1, 2, 4, 8
 BOND_HARMONIC, ANGLE_HARMONIC, BOND_LJC, BOND_NEAR, TORSION_PERIODIC, BOND_EWALD_EXCL = range(6)
-OP_EVAL, OP_KICK, OP_MOVE, OP_COPY = 1, 2, 3, 4
+OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE = 1, 2, 3, 4, 5
+MAX_SLOTS, SLOT_X, SLOT_V = 64, 62, 63
+GROUP_ALL = 32   # pseudo-group of the force symbol `f` (all groups)
 KC = 138.935456   # forces.py:407
 ARITY = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 3, BOND_LJC: 2, BOND_NEAR: 2, TORSION_PERIODIC: 4, BOND_EWALD_EXCL: 2}
 NPAR = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 2, BOND_LJC: 3, BOND_NEAR: 3, TORSION_PERIODIC: 3, BOND_EWALD_EXCL: 1}
@@ -82,7 +84,7 @@ def lib():
         L.amm_bonded_finalize.argtypes = [vp, C.c_int32]
         L.amm_bonded_set_sliced.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_force_eval.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
-        L.amm_kick.argtypes = [vp, vp, vp, vp, vp, C.c_double]
+        L.amm_kick.argtypes = [vp, vp, vp, vp, C.c_int32, vp, C.c_double]
         L.amm_move.argtypes = [vp, vp, vp, C.c_double]
         L.amm_copy.argtypes = [vp, vp, vp]
         L.amm_mvv.argtypes = [vp, vp, vp, vp]
@@ -195,8 +197,9 @@ class HipContext:
         _chk(lib().amm_force_eval(self.h, fid, _ptr(pos), _ptr(force), int(bool(accumulate)), _ptr(energy)))
 
     # ---- step primitives
-    def kick(self, v, f, mass, coef, fsub=None):
-        _chk(lib().amm_kick(self.h, _ptr(v), _ptr(f), _ptr(fsub), _ptr(mass), float(coef)))
+    def kick(self, v, f, mass, coef, fsub=None, fadd=None):
+        second = fsub if fsub is not None else fadd
+        _chk(lib().amm_kick(self.h, _ptr(v), _ptr(f), _ptr(second), int(fadd is not None), _ptr(mass), float(coef)))
 
     def move(self, x, v, coef):
         _chk(lib().amm_move(self.h, _ptr(x), _ptr(v), float(coef)))

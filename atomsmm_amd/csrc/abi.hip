@@ -312,8 +312,8 @@ int amm_force_eval(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *
     return amm_bonded_eval_impl(ctx, f.bonded, d_pos, d_force, accumulate, d_energy);
 }
 
-int amm_kick(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_fsub, const double *d_mass, double coef) {
-    return amm_kick_impl(ctx, d_v, d_f, d_fsub, d_mass, coef);
+int amm_kick(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int32_t plus, const double *d_mass, double coef) {
+    return amm_kick_impl(ctx, d_v, d_f, d_f2, plus, d_mass, coef);
 }
 int amm_move(amm_ctx *ctx, double *d_x, const double *d_v, double coef) { return amm_move_impl(ctx, d_x, d_v, coef); }
 int amm_copy(amm_ctx *ctx, double *d_dst, const double *d_src) { return amm_copy_impl(ctx, d_dst, d_src); }
@@ -323,6 +323,8 @@ int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass)
     ctx->d_x = d_x;
     ctx->d_v = d_v;
     ctx->d_mass = d_mass;
+    ctx->slots[AMM_SLOT_X] = d_x;
+    ctx->slots[AMM_SLOT_V] = d_v;
     return 0;
 }
 int amm_bind_buffer(amm_ctx *ctx, int32_t slot, double *d_buf) {
@@ -374,7 +376,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     amm_set_error("amm_run_ops: KICK buffer not bound");
                     return 1;
                 }
-                if (amm_kick_impl(ctx, ctx->d_v, fa, fb, ctx->d_mass, op.coef)) return 1;
+                if (amm_kick_impl(ctx, ctx->d_v, fa, fb, op.c, ctx->d_mass, op.coef)) return 1;
             } break;
             case AMM_OP_MOVE:
                 if (amm_move_impl(ctx, ctx->d_x, ctx->d_v, op.coef)) return 1;
@@ -387,6 +389,16 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     return 1;
                 }
                 if (amm_copy_impl(ctx, dst, src)) return 1;
+            } break;
+            case AMM_OP_COMBINE: {
+                double *dst = (op.a >= 0 && op.a < AMM_MAX_SLOTS) ? ctx->slots[op.a] : nullptr;
+                double *sa = (op.b >= 0 && op.b < AMM_MAX_SLOTS) ? ctx->slots[op.b] : nullptr;
+                double *sb = (op.c >= 0 && op.c < AMM_MAX_SLOTS) ? ctx->slots[op.c] : nullptr;
+                if (!dst || !sa || !sb) {
+                    amm_set_error("amm_run_ops: COMBINE buffer not bound");
+                    return 1;
+                }
+                if (amm_combine_impl(ctx, dst, sa, sb, op.coef)) return 1;
             } break;
             default: amm_set_error("amm_run_ops: unknown op"); return 1;
             }

@@ -9,8 +9,7 @@
 #include "../../include/atomsmm_hip.h"
 
 #define AMM_WAVE 64
-#define AMM_MAX_SLOTS 16
-#define AMM_MAX_GROUPS 32
+#define AMM_MAX_GROUPS 33   // 0..31 = OpenMM force groups, 32 = all forces (`f`)
 
 void amm_set_error(const std::string &msg);
 #define AMM_HIP(call)                                                                            \
@@ -130,7 +129,8 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
                          double *d_energy);
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
 int amm_bonded_free(BondedSet *bs);
-int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_fsub, const double *d_mass, double coef);
+int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef);
+int amm_combine_impl(amm_ctx *ctx, double *d_dst, const double *d_a, const double *d_b, double coef);
 int amm_move_impl(amm_ctx *ctx, double *d_x, const double *d_v, double coef);
 int amm_copy_impl(amm_ctx *ctx, double *d_dst, const double *d_src);
 int amm_mvv_impl(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out);

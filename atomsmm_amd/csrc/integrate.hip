@@ -3,25 +3,40 @@
 // The reference's propagators emit CustomIntegrator per-DOF assignments (propagators.py:249 move,
 // :271 kick; integrators.py:113 mvv sum); OpenMM's VM evaluates them operation by operation in fp64.
 // These kernels do the same arithmetic in the same order, with contraction into FMA disabled
-// (explicit __dmul_rn/__dadd_rn/__ddiv_rn), so a kick/move here is BIT-IDENTICAL to the oracle's.
+// (#pragma clang fp contract(off) below), so a kick/move here is BIT-IDENTICAL to the oracle's.
 // Pure streaming: 3N doubles, 16-byte accesses where the layout allows.
 #include "amm_ctx.h"
 
+// hipcc contracts a*b+c into FMA by default (and __dmul_rn/__dadd_rn are plain * and + in HIP):
+// switch contraction off for this file so that mul and add round separately, as in OpenMM's VM.
+#pragma clang fp contract(off)
+
 // v <- v + (coef)*(f - fsub)/m      propagators.py:271 with force expression `f`, `(_f2_-f1)`, ...
-__global__ void k_kick(int n3, double *__restrict__ v, const double *__restrict__ f, const double *__restrict__ fsub,
-                       const double *__restrict__ mass, double coef) {
+__global__ void k_kick(int n3, double *__restrict__ v, const double *__restrict__ f, const double *__restrict__ f2,
+                       int plus, const double *__restrict__ mass, double coef) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n3) return;
     double ff = f[t];
-    if (fsub) ff = __dsub_rn(ff, fsub[t]);
-    v[t] = __dadd_rn(v[t], __ddiv_rn(__dmul_rn(coef, ff), mass[t / 3]));
+    if (f2) ff = plus ? ff + f2[t] : ff - f2[t];
+    const double num = coef * ff;
+    const double dv = num / mass[t / 3];
+    v[t] = v[t] + dv;
 }
 
 // x <- x + (coef)*v                propagators.py:249
 __global__ void k_move(int n3, double *__restrict__ x, const double *__restrict__ v, double coef) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n3) return;
-    x[t] = __dadd_rn(x[t], __dmul_rn(coef, v[t]));
+    const double dx = coef * v[t];
+    x[t] = x[t] + dx;
+}
+
+// dst <- a + coef*b   (`fm2 <- f2-f1`, propagators.py:951)
+__global__ void k_combine(int n3, double *__restrict__ dst, const double *__restrict__ a, const double *__restrict__ b, double coef) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    const double sb = coef * b[t];
+    dst[t] = a[t] + sb;
 }
 
 __global__ void k_mvv(int n, const double *__restrict__ v, const double *__restrict__ m, double *part) {
@@ -35,15 +50,21 @@ __global__ void k_mvv(int n, const double *__restrict__ v, const double *__restr
     if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_fsub, const double *d_mass, double coef) {
+int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef) {
     const int n3 = 3 * ctx->n;
-    hipLaunchKernelGGL(k_kick, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_v, d_f, d_fsub, d_mass, coef);
+    hipLaunchKernelGGL(k_kick, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_v, d_f, d_f2, plus, d_mass, coef);
     AMM_HIP(hipGetLastError());
     return 0;
 }
 int amm_move_impl(amm_ctx *ctx, double *d_x, const double *d_v, double coef) {
     const int n3 = 3 * ctx->n;
     hipLaunchKernelGGL(k_move, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_x, d_v, coef);
+    AMM_HIP(hipGetLastError());
+    return 0;
+}
+int amm_combine_impl(amm_ctx *ctx, double *d_dst, const double *d_a, const double *d_b, double coef) {
+    const int n3 = 3 * ctx->n;
+    hipLaunchKernelGGL(k_combine, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_dst, d_a, d_b, coef);
     AMM_HIP(hipGetLastError());
     return 0;
 }

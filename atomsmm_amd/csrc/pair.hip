@@ -446,7 +446,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
     AMM_HIP(hipStreamSynchronize(ctx->stream));
     int maxnb = flags[2];
-    pf->cap = ((int)(maxnb * 1.25) + 16 + 15) / 16 * 16;
+    pf->cap = ((int)(maxnb * 1.5) + 32 + 15) / 16 * 16;   // head-room for density fluctuations between rebuilds
     AMM_HIP(hipMalloc(&pf->d_nl, sizeof(int) * (size_t)std::max(nslice, 1) * pf->cap));
     if (build_chain(ctx, pf, d_pos, 1, false)) return 1;
     pf->built = true;

@@ -1,0 +1,683 @@
+"""Host engine behind `openmm.Context`: turns a System + integrator *description* into calls of the
+HIP library (include/atomsmm_hip.h) and takes over what OpenMM's C++ does for the reference
+(SURVEY.md section 3.3): per-group force/energy evaluation (`getState(groups=...)`) and execution of
+the CustomIntegrator step program (`integrator.step(n)`).
+
+Design (MI355X-first, not OpenMM's):
+  * every Force object becomes backend objects once, at Context creation -- a pair force (cell list ->
+    Verlet list -> lanes-per-atom traversal) or bond-list terms (owner-computes CSR);
+  * the step program is *unrolled on the host* into a flat op list (EVAL group / KICK / MOVE / COPY)
+    with one force cache per group: a group is re-evaluated only if positions changed since its last
+    evaluation.  For RespaPropagator([4,2,1]) that is 1/2/8 evaluations of groups 2/1/0 per outer step
+    instead of the 2/4/10 OpenMM's single-buffer VM performs, with identical arithmetic;
+  * the op list of a steady-state step is cached and replayed by `amm_run_ops` with no Python in the loop;
+  * atom decomposition: with torch.distributed initialised (one process per GPU) every rank integrates all
+    atoms redundantly, computes pair forces for its slice of the cell-sorted order and all-reduces the
+    per-group force buffer over RCCL.
+
+There is no CPU path: creating a Context without the built HIP library or without a GPU raises.
+"""
+import math
+import re
+
+import numpy as np
+
+from . import backend as B
+from . import openmm as mm
+from .forces import describe_energy
+from .utils import InputError
+
+_FAMILY = {'near-none': B.NEAR_NONE, 'near-shift': B.NEAR_SHIFT, 'near-force-switch': B.NEAR_FSWITCH,
+           'damped': B.DAMPED}
+_SAFE_FUNCS = {name: getattr(math, name) for name in ('sqrt', 'exp', 'log', 'sin', 'cos', 'tan', 'erf', 'erfc', 'floor', 'ceil')}
+_SAFE_FUNCS.update(step=lambda x: 1.0 if x >= 0 else 0.0, delta=lambda x: 1.0 if x == 0 else 0.0,
+                   select=lambda c, a, b: a if c != 0 else b, min=min, max=max, abs=abs)
+ALLREDUCE = 'allreduce'
+_context_factory = B.HipContext   # the only backend; tests of the host logic substitute a call recorder
+
+
+def dispersion_correction(sigma, eps, box, rc, rswitch=None):
+    """Long-range LJ correction of OpenMM's NonbondedForce, with the switching-function term
+    (SURVEY.md Appendix B.6): (2 pi N^2/V) <int_rc^inf V r^2 dr + int_rs^rc (1-S) V r^2 dr> over type pairs."""
+    classes = {}
+    for s, e in zip(sigma, eps):
+        classes[(s, e)] = classes.get((s, e), 0) + 1
+    keys = list(classes)
+    n = float(len(sigma))
+    total = 0.0
+    for a in range(len(keys)):
+        for b in range(a, len(keys)):
+            e = math.sqrt(keys[a][1] * keys[b][1])
+            if e == 0.0:
+                continue
+            s = 0.5 * (keys[a][0] + keys[b][0])
+            s6 = s ** 6
+            s12 = s6 * s6
+            w = 0.5 * classes[keys[a]] * (classes[keys[a]] + 1) if a == b else float(classes[keys[a]]) * classes[keys[b]]
+            term = 4 * e * (s12 / (9 * rc ** 9) - s6 / (3 * rc ** 3))
+            if rswitch is not None:
+                r = np.linspace(rswitch, rc, 2001)
+                t = (r - rswitch) / (rc - rswitch)
+                S = 1 + t ** 3 * (15 * t - 6 * t * t - 10)
+                g = (1 - S) * 4 * e * (s12 / r ** 12 - s6 / r ** 6) * r * r
+                h = r[1] - r[0]
+                term += h / 3 * (g[0] + g[-1] + 4 * g[1:-1:2].sum() + 2 * g[2:-1:2].sum())
+            total += w * term
+    total /= 0.5 * n * (n + 1)
+    return 2 * math.pi * n * n * total / (box[0] * box[1] * box[2])
+
+
+class _Entry:
+    """One System force translated to backend objects."""
+
+    def __init__(self, force, group):
+        self.force = force
+        self.group = group
+        self.pair_ids = []          # backend pair forces (sliced across ranks)
+        self.bonded_id = None       # backend bonded set holding this force's bond-list terms
+        self.terms = []             # (kind, idx, params, periodic, desc) for group-level merging
+        self.constant = 0.0         # energy-only constant (dispersion correction)
+        self.recip_group = None
+        self.recip = None
+        self.update = None          # callable(parameters) refreshing lambda-dependent parameters
+
+
+class Engine:
+    def __init__(self, system, integrator, properties):
+        import torch
+        self.torch = torch
+        self.system = system
+        self.integrator = integrator
+        n = system.getNumParticles()
+        if n == 0:
+            raise mm.OpenMMException('System has no particles')
+        try:
+            vecs = system._box
+        except AttributeError:
+            vecs = None
+        if vecs is None:
+            raise InputError('the HIP path needs a periodic orthorhombic box: call System.setDefaultPeriodicBoxVectors')
+        for i in range(3):
+            for j in range(3):
+                if i != j and abs(vecs[i][j]) > 1e-12:
+                    raise InputError('only orthorhombic periodic boxes are supported by the HIP path')
+        self.box = np.array([vecs[0][0], vecs[1][1], vecs[2][2]], dtype=np.float64)
+        self.rank, self.world = 0, 1
+        dist = torch.distributed
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        device = int(properties.get('DeviceIndex', torch.cuda.current_device() if torch.cuda.is_available() else 0))
+        self.ctx = _context_factory(n, self.box, device=device, rank=self.rank, world=self.world)
+        self.n = n
+        dev = self.ctx.torch_device
+        f64 = torch.float64
+        self.x = torch.zeros((n, 3), dtype=f64, device=dev)
+        self.v = torch.zeros((n, 3), dtype=f64, device=dev)
+        self.mass = torch.as_tensor(np.array(system._masses, dtype=np.float64), device=dev)
+        self.time = 0.0
+        self.parameters = {}
+        self.entries = []
+        self.skin = float(properties.get('Skin', -1.0))
+        for force in system.getForces():
+            self._translate(force)
+        self._slots = {}
+        self._buffers = {}
+        self._group_defs = {}
+        self._valid = {}
+        self._programs = {}
+        self._energy = torch.zeros(1, dtype=f64, device=dev)
+        self._fwork = torch.zeros((n, 3), dtype=f64, device=dev)
+        self._fwork2 = torch.zeros((n, 3), dtype=f64, device=dev)
+        self.ctx.bind_state(self.x, self.v, self.mass)
+        if system.getNumConstraints() > 0:
+            raise NotImplementedError('distance constraints are outside this round\'s scope (SURVEY.md 8f-3)')
+        if isinstance(integrator, mm.CustomIntegrator):
+            integrator._n_hint = n
+
+    # ------------------------------------------------------------------------------- translation
+    def _register_globals(self, force):
+        if hasattr(force, 'getNumGlobalParameters'):
+            for i in range(force.getNumGlobalParameters()):
+                self.parameters.setdefault(force.getGlobalParameterName(i), force.getGlobalParameterDefaultValue(i))
+
+    def _translate(self, force):
+        self._register_globals(force)
+        if isinstance(force, mm.CMMotionRemover):
+            return
+        entry = _Entry(force, force.getForceGroup())
+        if isinstance(force, mm.NonbondedForce):
+            self._translate_nonbonded(force, entry)
+        elif isinstance(force, mm.CustomNonbondedForce):
+            self._translate_custom_nonbonded(force, entry)
+        elif isinstance(force, mm.CustomBondForce):
+            self._translate_custom_bond(force, entry)
+        elif isinstance(force, mm.HarmonicBondForce):
+            b = np.array([[r[0], r[1]] for r in force._bonds], dtype=np.int32).reshape(-1, 2)
+            p = np.array([[r[2], r[3]] for r in force._bonds], dtype=np.float64).reshape(-1, 2)
+            entry.terms.append((B.BOND_HARMONIC, b, p, force.usesPeriodicBoundaryConditions(), None))
+        elif isinstance(force, mm.HarmonicAngleForce):
+            a = np.array([r[:3] for r in force._angles], dtype=np.int32).reshape(-1, 3)
+            p = np.array([r[3:] for r in force._angles], dtype=np.float64).reshape(-1, 2)
+            entry.terms.append((B.ANGLE_HARMONIC, a, p, force.usesPeriodicBoundaryConditions(), None))
+        elif isinstance(force, mm.PeriodicTorsionForce):
+            t = np.array([r[:4] for r in force._torsions], dtype=np.int32).reshape(-1, 4)
+            p = np.array([[r[4], r[5], r[6]] for r in force._torsions], dtype=np.float64).reshape(-1, 3)
+            entry.terms.append((B.TORSION_PERIODIC, t, p, force.usesPeriodicBoundaryConditions(), None))
+        else:
+            raise InputError('force type {} is not supported by the HIP path'.format(force.__class__.__name__))
+        self._finish_entry(entry)
+        self.entries.append(entry)
+
+    def _finish_entry(self, entry):
+        if entry.terms:
+            entry.bonded_id = self._make_bonded(entry.terms, sliced=False)
+
+    def _make_bonded(self, terms, sliced):
+        bid = self.ctx.bonded_create()
+        for kind, idx, par, periodic, desc in terms:
+            if len(idx):
+                self.ctx.bonded_add_terms(bid, kind, idx, par, periodic=periodic, desc=desc)
+        self.ctx.bonded_finalize(bid, sliced=sliced)
+        return bid
+
+    @staticmethod
+    def _effective(base, scales, names, parameters):
+        """base (n,3) + sum_p lambda_p * scales[p] (n,3): parameter offsets (forces.py:247-258)."""
+        out = base.copy()
+        for k, name in enumerate(names):
+            out += parameters[name] * scales[k]
+        return out
+
+    def _translate_nonbonded(self, nb, entry):
+        method = nb.getNonbondedMethod()
+        if method not in (nb.CutoffPeriodic, nb.Ewald, nb.PME):
+            raise InputError('the HIP path evaluates periodic NonbondedForces only (CutoffPeriodic, Ewald, PME)')
+        rc = nb._cutoff
+        n = self.n
+        base = np.array(nb._particles, dtype=np.float64).reshape(n, 3)
+        names = []
+        for rec in nb._particle_offsets:
+            if rec[0] not in names:
+                names.append(rec[0])
+        scales = np.zeros((len(names), n, 3))
+        for name, idx, qs, ss, es in nb._particle_offsets:
+            scales[names.index(name), idx] = [qs, ss, es]
+        exc = np.array([[r[0], r[1]] for r in nb._exceptions], dtype=np.int32).reshape(-1, 2)
+        exc_base = np.array([r[2:] for r in nb._exceptions], dtype=np.float64).reshape(-1, 3)
+        enames = []
+        for rec in nb._exception_offsets:
+            if rec[0] not in enames:
+                enames.append(rec[0])
+        escales = np.zeros((len(enames), len(exc), 3))
+        for name, idx, qs, ss, es in nb._exception_offsets:
+            escales[enames.index(name), idx] = [qs, ss, es]
+        flags = B.SWITCH if nb._use_switch else 0
+        alpha = krf = crf = 0.0
+        ewald = method in (nb.Ewald, nb.PME)
+        if ewald:
+            alpha = nb._pme[0] if nb._pme[0] > 0 else math.sqrt(-math.log(2 * nb._ewald_tol)) / rc
+            flags |= B.COULOMB_EWALD
+        else:
+            eps_rf = nb._rf_dielectric
+            krf = (eps_rf - 1) / ((2 * eps_rf + 1) * rc ** 3)
+            crf = 3 * eps_rf / ((2 * eps_rf + 1) * rc)
+            flags |= B.COULOMB_RF
+        desc = B.pair_desc(B.NONBONDED, rc, rswitch=nb._switch if nb._use_switch else 0.0, alpha=alpha, flags=flags,
+                           krf=krf, crf=crf)
+        eff = self._effective(base, scales, names, self.parameters)
+        pid = self.ctx.pair_create(desc, eff[:, 0], eff[:, 1], eff[:, 2], exc, skin=self.skin)
+        entry.pair_ids.append(pid)
+        entry.alpha = alpha
+        entry.ewald = ewald
+        if ewald:
+            entry.recip_group = nb._recip_group if nb._recip_group >= 0 else nb.getForceGroup()
+
+        def bonded_terms(parameters):
+            q = self._effective(base, scales, names, parameters)[:, 0]
+            terms = []
+            ep = self._effective(exc_base, escales, enames, parameters) if len(exc) else exc_base
+            keep = (ep[:, 0] != 0.0) | (ep[:, 2] != 0.0) if len(exc) else np.zeros(0, bool)
+            if keep.any():
+                terms.append((B.BOND_LJC, exc[keep], ep[keep], True, B.pair_desc(B.NONBONDED, rc)))
+            if ewald and len(exc):
+                terms.append((B.BOND_EWALD_EXCL, exc, (q[exc[:, 0]] * q[exc[:, 1]]).reshape(-1, 1), True,
+                              B.pair_desc(B.NONBONDED, rc, alpha=alpha)))
+            return terms
+
+        def constant(parameters):
+            if not nb._dispersion:
+                return 0.0
+            p = self._effective(base, scales, names, parameters)
+            return dispersion_correction(p[:, 1], p[:, 2], self.box, rc, nb._switch if nb._use_switch else None)
+
+        entry.terms = bonded_terms(self.parameters)
+        entry.constant = constant(self.parameters)
+        lam = set(names) | set(enames)
+        if lam:
+            def update(parameters, changed):
+                if not (lam & changed):
+                    return False
+                p = self._effective(base, scales, names, parameters)
+                self.ctx.pair_set_params(pid, p[:, 0], p[:, 1], p[:, 2])
+                entry.terms = bonded_terms(parameters)
+                entry.bonded_id = self._make_bonded(entry.terms, sliced=False) if entry.terms else None
+                entry.constant = constant(parameters)
+                return True
+            entry.update = update
+
+    def _descriptor_of(self, force):
+        desc = getattr(force, '_amm', None)
+        if desc is None:
+            globs = {force.getGlobalParameterName(i): force.getGlobalParameterDefaultValue(i)
+                     for i in range(force.getNumGlobalParameters())}
+            desc = describe_energy(force.getEnergyFunction(), globs)
+        if desc is None:
+            raise InputError('energy expression not recognised by the HIP path (supported: the AtomsMM near / '
+                             'damped-smoothed / exception families): ' + force.getEnergyFunction().split(';')[0])
+        return desc
+
+    def _pair_desc_from(self, d, rc, builtin_switch=None):
+        family = d['family']
+        flags = B.GUARD_RC0 if d.get('guard') else 0
+        if family == 'damped':
+            degree = int(d.get('degree', 1))
+            rswitch = builtin_switch if (degree == 1 and builtin_switch is not None) else d['rswitch']
+            return B.pair_desc(B.DAMPED, rc, rswitch=rswitch, alpha=d['alpha'], degree=degree, sign=d.get('sign', 1.0),
+                               Kc=d.get('Kc', B.KC))
+        rc0, rs0 = d.get('rc0'), d.get('rs0')
+        if rc0 is None or rs0 is None:
+            raise InputError('near force without rc0/rs0')
+        return B.pair_desc(_FAMILY[family], rc, rc0=rc0, rs0=rs0, flags=flags, sign=d.get('sign', 1.0), Kc=d.get('Kc', B.KC))
+
+    def _translate_custom_nonbonded(self, force, entry):
+        d = dict(self._descriptor_of(force))
+        if d['family'] == 'ljc':
+            raise InputError('the LJC exception expression belongs in a CustomBondForce')
+        if force.getNonbondedMethod() != force.CutoffPeriodic:
+            raise InputError('the HIP path evaluates CutoffPeriodic CustomNonbondedForces only')
+        if force.getNumInteractionGroups() > 0:
+            raise NotImplementedError('interaction groups are outside the HIP hot path (alchemical features)')
+        if force.getUseLongRangeCorrection():
+            raise NotImplementedError('long-range correction of CustomNonbondedForce is not implemented')
+        rc = force._cutoff
+        for key in ('rc0', 'rs0', 'alpha', 'rswitch', 'Kc'):
+            if d.get(key) is None and key in self.parameters:
+                d[key] = self.parameters[key]
+        builtin = force._switch if force.getUseSwitchingFunction() else None
+        if builtin is not None and d['family'] != 'damped':
+            raise NotImplementedError('built-in switching function on a near force')
+        desc = self._pair_desc_from(d, rc, builtin)
+        n = self.n
+        if force.getNumParticles() != n:
+            raise mm.OpenMMException('CustomNonbondedForce must have exactly as many particles as the System')
+        allp = np.array(force._particles, dtype=np.float64).reshape(n, -1)
+        names = list(getattr(force, '_offset_parameters', []))
+        base = allp[:, :3]
+        scales = np.stack([allp[:, 3 * (k + 1):3 * (k + 2)] for k in range(len(names))]) if names else np.zeros((0, n, 3))
+        eff = self._effective(base, scales, names, self.parameters)
+        excl = np.array(force._exclusions, dtype=np.int32).reshape(-1, 2)
+        pid = self.ctx.pair_create(desc, eff[:, 0], eff[:, 1], eff[:, 2], excl, skin=self.skin)
+        entry.pair_ids.append(pid)
+        if names:
+            lam = set(names)
+
+            def update(parameters, changed):
+                if not (lam & changed):
+                    return False
+                p = self._effective(base, scales, names, parameters)
+                self.ctx.pair_set_params(pid, p[:, 0], p[:, 1], p[:, 2])
+                return True
+            entry.update = update
+
+    def _translate_custom_bond(self, force, entry):
+        d = dict(self._descriptor_of(force))
+        nb_ = force.getNumBonds()
+        idx = np.array([[b[0], b[1]] for b in force._bonds], dtype=np.int32).reshape(-1, 2)
+        allp = np.array([b[2] for b in force._bonds], dtype=np.float64).reshape(nb_, -1)
+        names = list(getattr(force, '_offset_parameters', []))
+        base = allp[:, :3]
+        scales = np.stack([allp[:, 3 * (k + 1):3 * (k + 2)] for k in range(len(names))]) if names else np.zeros((0, nb_, 3))
+        periodic = force.usesPeriodicBoundaryConditions()
+        if d['family'] == 'ljc':
+            kind, desc = B.BOND_LJC, B.pair_desc(B.NONBONDED, 1.0, Kc=d.get('Kc', B.KC))
+        else:
+            for key in ('rc0', 'rs0', 'Kc'):
+                if d.get(key) is None and key in self.parameters:
+                    d[key] = self.parameters[key]
+            kind, desc = B.BOND_NEAR, self._pair_desc_from(d, d['rc0'])
+
+        def terms(parameters):
+            return [(kind, idx, self._effective(base, scales, names, parameters), periodic, desc)]
+
+        entry.terms = terms(self.parameters)
+        if names:
+            lam = set(names)
+
+            def update(parameters, changed):
+                if not (lam & changed):
+                    return False
+                entry.terms = terms(parameters)
+                entry.bonded_id = self._make_bonded(entry.terms, sliced=False)
+                return True
+            entry.update = update
+
+    # ------------------------------------------------------------------------------- state
+    def _invalidate_forces(self):
+        for g in self._valid:
+            self._valid[g] = False
+
+    def set_positions(self, arr):
+        self.x.copy_(self.torch.as_tensor(arr, device=self.x.device))
+        self._invalidate_forces()
+
+    def set_velocities(self, arr):
+        self.v.copy_(self.torch.as_tensor(arr, device=self.v.device))
+
+    def set_parameter(self, name, value):
+        if name not in self.parameters:
+            raise mm.OpenMMException('Called setParameter() with invalid parameter name: ' + name)
+        if self.parameters[name] == value:
+            return
+        self.parameters[name] = value
+        changed = {name}
+        dirty = False
+        for entry in self.entries:
+            if entry.update is not None and entry.update(self.parameters, changed):
+                dirty = True
+        if dirty:
+            self._group_defs.clear()
+            self._programs.clear()
+            self._invalidate_forces()
+
+    def get_parameter(self, name):
+        return self.parameters[name]
+
+    def invalidate_program(self):
+        self._programs.clear()
+
+    def reinitialize(self, preserveState=False):
+        raise NotImplementedError('Context.reinitialize: create a new Context instead')
+
+    # per-DOF variables live in named device buffers
+    def _buffer(self, name):
+        if name not in self._buffers:
+            t = self.torch.zeros((self.n, 3), dtype=self.torch.float64, device=self.x.device)
+            integ = self.integrator
+            if isinstance(integ, mm.CustomIntegrator) and name in integ._pnames:
+                t.fill_(integ._pvalues[integ._pnames.index(name)])
+            self._buffers[name] = t
+        return self._buffers[name]
+
+    def fill_per_dof(self, name, value):
+        self._buffer(name).fill_(value)
+
+    def get_per_dof(self, name):
+        return [mm.Vec3(*row) for row in self._buffer(name).cpu().numpy().tolist()]
+
+    def set_per_dof(self, name, values):
+        arr = np.array([list(v) for v in values], dtype=np.float64).reshape(self.n, 3)
+        self._buffer(name).copy_(self.torch.as_tensor(arr, device=self.x.device))
+
+    # ------------------------------------------------------------------------------- getState
+    def _allreduce(self, tensor):
+        if self.world > 1:
+            self.torch.distributed.all_reduce(tensor)
+
+    def get_state(self, want_pos, want_vel, want_forces, want_energy, mask):
+        torch = self.torch
+        energy = forces = None
+        if want_forces or want_energy:
+            for entry in self.entries:
+                if entry.recip_group is not None and mask & (1 << entry.recip_group):
+                    raise NotImplementedError(
+                        'Ewald/PME reciprocal space is not implemented in this round (SURVEY.md 8f-1): exclude group '
+                        '%d, or use a DampedSmoothedForce / CutoffPeriodic outer force' % entry.recip_group)
+            e_pair = self._energy.zero_() if want_energy else None
+            fp = self._fwork.zero_()
+            fb = self._fwork2.zero_()
+            e_bond = torch.zeros(1, dtype=torch.float64, device=self.x.device) if want_energy else None
+            const = 0.0
+            for entry in self.entries:
+                if mask & (1 << entry.group):
+                    for pid in entry.pair_ids:
+                        self.ctx.force_eval(pid, self.x, fp, accumulate=True, energy=e_pair)
+                    if entry.bonded_id is not None:
+                        self.ctx.force_eval(entry.bonded_id, self.x, fb, accumulate=True, energy=e_bond)
+                    const += entry.constant
+            self.ctx.check()
+            if self.world > 1:
+                self._allreduce(fp)
+                if want_energy:
+                    self._allreduce(e_pair)
+            if want_forces:
+                forces = (fp + fb).cpu().numpy()
+            if want_energy:
+                energy = e_pair.item() + e_bond.item() + const
+        kinetic = None
+        if want_energy:
+            out = torch.zeros(1, dtype=torch.float64, device=self.x.device)
+            self.ctx.mvv(self.v, self.mass, out)
+            kinetic = 0.5 * out.item()
+        pos = self.x.cpu().numpy() if want_pos else None
+        vel = self.v.cpu().numpy() if want_vel else None
+        box = [(self.box[0], 0, 0), (0, self.box[1], 0), (0, 0, self.box[2])]
+        return mm.State(energy, kinetic, forces, pos, vel, box, self.time)
+
+    # ------------------------------------------------------------------------------- step programs
+    def _slot(self, name):
+        """Slot index of a named per-DOF buffer ('f3' = force of group 3, other names = per-DOF variables)."""
+        if name == 'x':
+            return B.SLOT_X
+        if name == 'v':
+            return B.SLOT_V
+        if name not in self._slots:
+            slot = len(self._slots)
+            if slot >= B.SLOT_X:
+                raise NotImplementedError('too many per-DOF buffers')
+            self._slots[name] = slot
+            self.ctx.bind_buffer(slot, self._buffer(name))
+        return self._slots[name]
+
+    def _define_group(self, g):
+        """Backend group g = pair forces + one merged bonded set of all bond-list terms in the group."""
+        if g in self._group_defs:
+            return self._group_defs[g]
+        members = [e for e in self.entries if (e.group == g if g != 'all' else True)]
+        for e in members:
+            if e.recip_group is not None and (g == 'all' or e.recip_group == g):
+                raise NotImplementedError('Ewald/PME reciprocal space is not implemented in this round (SURVEY.md 8f-1); '
+                                          'use a DampedSmoothedForce or CutoffPeriodic outer force for group %s' % g)
+        pair_ids = [pid for e in members for pid in e.pair_ids]
+        terms = [t for e in members for t in e.terms]
+        reduced = self.world > 1 and bool(pair_ids)
+        ids = list(pair_ids)
+        if terms:
+            ids.append(self._make_bonded(terms, sliced=reduced))
+        index = B.GROUP_ALL if g == 'all' else int(g)
+        slot = self._slot('f' if g == 'all' else 'f{}'.format(g))
+        self.ctx.group_define(index, slot, ids)
+        self._group_defs[g] = (index, slot, reduced)
+        return self._group_defs[g]
+
+    def _eval(self, expr, env):
+        return float(eval(expr.replace('^', '**'), {'__builtins__': {}}, env))
+
+    def _compile(self):
+        """Unroll one outer step of the CustomIntegrator program into backend ops (host-side control flow)."""
+        integ = self.integrator
+        steps = integ._steps
+        C = mm.CustomIntegrator
+        # block structure
+        match, stack = {}, []
+        for pc, (kind, _, _) in enumerate(steps):
+            if kind in (C.IfBlock, C.WhileBlock):
+                stack.append(pc)
+            elif kind == C.EndBlock:
+                begin = stack.pop()
+                match[begin], match[pc] = pc, begin
+        env = dict(_SAFE_FUNCS)
+        env.update(self.parameters)
+        env.update(zip(integ._gnames, integ._gvalues))
+        env['dt'] = integ._dt
+        valid = dict(self._valid)
+        ops = []
+        pc = 0
+        guard = 0
+        while pc < len(steps):
+            guard += 1
+            if guard > 2_000_000:
+                raise RuntimeError('step program does not terminate')
+            kind, target, expr = steps[pc]
+            if kind == C.ComputeGlobal:
+                value = self._eval(expr, env)
+                if target in self.parameters and target not in integ._gnames:
+                    if value != self.parameters[target]:
+                        raise NotImplementedError('step programs that change Context parameters (%s) are not supported' % target)
+                env[target] = value
+            elif kind == C.ComputePerDof:
+                self._emit_per_dof(target, expr, env, ops, valid)
+            elif kind == C.ComputeSum:
+                raise NotImplementedError('ComputeSum steps (thermostat propagators) are outside this round\'s scope')
+            elif kind in (C.ConstrainPositions, C.ConstrainVelocities, C.UpdateContextState):
+                pass    # no constraints in the System (checked at Context creation): identity
+            elif kind in (C.IfBlock, C.WhileBlock):
+                if not self._condition(expr, env):
+                    pc = match[pc]
+            elif kind == C.EndBlock:
+                if steps[match[pc]][0] == C.WhileBlock:
+                    pc = match[pc] - 1
+            pc += 1
+        finals = {name: env[name] for name in integ._gnames}
+        return ops, valid, finals
+
+    def _condition(self, expr, env):
+        m = re.match(r'^(.*?)(<=|>=|!=|=|<|>)(.*)$', expr)
+        if not m:
+            raise NotImplementedError('unsupported block condition: ' + expr)
+        a, op, b = self._eval(m.group(1), env), m.group(2), self._eval(m.group(3), env)
+        return {'<': a < b, '>': a > b, '<=': a <= b, '>=': a >= b, '=': a == b, '!=': a != b}[op]
+
+    @staticmethod
+    def _split_leading_group(text):
+        """'(A)*rest' -> ('A', 'rest') with balanced parentheses."""
+        if not text.startswith('('):
+            return None
+        depth = 0
+        for k, ch in enumerate(text):
+            depth += ch == '('
+            depth -= ch == ')'
+            if depth == 0:
+                if text[k + 1:k + 2] != '*':
+                    return None
+                return text[1:k], text[k + 2:]
+        return None
+
+    def _force_ref(self, name, ops, valid):
+        """Slot of a force symbol / per-DOF buffer; emits the EVAL (and all-reduce marker) when stale."""
+        m = re.fullmatch(r'f([0-9]*)', name)
+        if m:
+            g = 'all' if m.group(1) == '' else int(m.group(1))
+            index, slot, reduced = self._define_group(g)
+            if not valid.get(g, False):
+                ops.append(B.Op(B.OP_EVAL, index, 0, 0, 0.0))
+                if reduced:
+                    ops.append((ALLREDUCE, slot))
+                valid[g] = True
+            return slot
+        integ = self.integrator
+        if name not in integ._pnames and name not in ('x', 'v'):
+            raise NotImplementedError('unknown per-DOF symbol in step program: ' + name)
+        return self._slot(name)
+
+    def _emit_per_dof(self, target, expr, env, ops, valid):
+        text = expr.replace(' ', '')
+        if ';' in text:
+            raise NotImplementedError('per-DOF expressions with auxiliary definitions are outside this round\'s scope: ' + expr)
+        # kick: v <- v + (coef)*FORCE/m
+        if target == 'v' and text.startswith('v+') and text.endswith('/m'):
+            parts = self._split_leading_group(text[2:-2])
+            if parts:
+                coef = self._eval(parts[0], env)
+                terms = self._signed_terms(parts[1])
+                if terms and len(terms) <= 2 and terms[0][0] == 1:
+                    a = self._force_ref(terms[0][1], ops, valid)
+                    b, plus = -1, 0
+                    if len(terms) == 2:
+                        b = self._force_ref(terms[1][1], ops, valid)
+                        plus = 1 if terms[1][0] == 1 else 0
+                    ops.append(B.Op(B.OP_KICK, a, b, plus, coef))
+                    return
+        # move: x <- x + (coef)*v
+        if target == 'x' and text.startswith('x+') and text.endswith('*v'):
+            parts = self._split_leading_group(text[2:])
+            if parts and parts[1] == 'v':
+                ops.append(B.Op(B.OP_MOVE, 0, 0, 0, self._eval(parts[0], env)))
+                for g in valid:
+                    valid[g] = False
+                return
+        # copies / differences of buffers: `_f2_ <- f2`, `fm1 <- f1`, `fm2 <- f2-f1`, `x0 <- x`
+        if target not in ('x', 'v'):
+            terms = self._signed_terms(text)
+            if terms and terms[0][0] == 1 and len(terms) <= 2:
+                src = self._force_ref(terms[0][1], ops, valid)
+                dst = self._slot(target)
+                if len(terms) == 1:
+                    ops.append(B.Op(B.OP_COPY, dst, src, 0, 0.0))
+                else:
+                    second = self._force_ref(terms[1][1], ops, valid)
+                    ops.append(B.Op(B.OP_COMBINE, dst, src, second, float(terms[1][0])))
+                return
+        raise NotImplementedError('per-DOF computation outside the RESPA hot path: {} <- {}'.format(target, expr))
+
+    @staticmethod
+    def _signed_terms(text):
+        """'(f0+fm1)' -> [(1,'f0'), (1,'fm1')]; None if not a signed sum of identifiers."""
+        while text.startswith('(') and text.endswith(')'):
+            text = text[1:-1]
+        if not re.fullmatch(r'[A-Za-z_][A-Za-z_0-9]*([+-][A-Za-z_][A-Za-z_0-9]*)*', text):
+            return None
+        return [(-1 if s == '-' else 1, name) for s, name in re.findall(r'([+-]?)([A-Za-z_][A-Za-z_0-9]*)', text)]
+
+    def _run(self, ops, repeat):
+        if self.world == 1:
+            self.ctx.run_ops([op for op in ops if not isinstance(op, tuple)], repeat)
+            return
+        segments, current = [], []
+        for op in ops:
+            if isinstance(op, tuple):
+                segments.append((current, op[1]))
+                current = []
+            else:
+                current.append(op)
+        inv = {slot: name for name, slot in self._slots.items()}
+        for _ in range(repeat):
+            for seg, slot in segments:
+                if seg:
+                    self.ctx.run_ops(seg, 1)
+                self.torch.distributed.all_reduce(self._buffers[inv[slot]])
+            if current:
+                self.ctx.run_ops(current, 1)
+
+    def step(self, n):
+        integ = self.integrator
+        if not isinstance(integ, mm.CustomIntegrator):
+            raise NotImplementedError('only CustomIntegrator step programs run on the HIP path')
+        remaining = int(n)
+        while remaining > 0:
+            key = tuple(sorted((str(g), ok) for g, ok in self._valid.items()))
+            if key not in self._programs:
+                self._programs[key] = self._compile()
+            ops, valid_after, finals = self._programs[key]
+            after_key = tuple(sorted((str(g), ok) for g, ok in valid_after.items()))
+            count = remaining if after_key == key else 1
+            self._run(ops, count)
+            self._valid = dict(valid_after)
+            for name, value in finals.items():
+                integ._gvalues[integ._gnames.index(name)] = value
+            remaining -= count
+            self.time += count * integ._dt
+        self.ctx.check()
+
+    # measurement helpers (bench / tests)
+    def pair_force_ids(self, group):
+        return [pid for e in self.entries if e.group == group for pid in e.pair_ids]

@@ -1,0 +1,286 @@
+"""Step-program builders with the class names and signatures of `atomsmm.propagators`
+(reference: src/atomsmm/propagators.py), restricted to the hot path: the move / boost primitives,
+the composition schemes and the RESPA multiple-timescale propagators.
+
+A propagator does no arithmetic.  `addSteps(integrator, fraction, force)` appends CustomIntegrator
+computations ("v <- v + (0.0625*dt)*(f0)/m" ...) to an integrator object; `atomsmm_amd.engine`
+later unrolls that program into kick / move / copy / force-group-evaluation ops for the HIP library
+(include/atomsmm_hip.h, amm_run_ops).  The emitted text is identical to the reference's
+(tests/golden/goldens.json -> programs), which is the cheapest parity check there is.
+
+Thermostat, 'regulated' and 'limited-speed' propagators (reference :276-827, :1045-2172) are out of
+scope of this round (per-DOF elementwise math, no pair work: SURVEY.md section 8f-2).
+"""
+from .utils import InputError
+
+
+class Propagator:
+    """Base class: global / per-DOF variable tables and `integrator(stepSize)` (propagators.py:24-75)."""
+
+    def __init__(self):
+        self.globalVariables = dict()
+        self.perDofVariables = dict()
+
+    def addVariables(self, integrator):
+        for name, value in self.globalVariables.items():
+            integrator.addGlobalVariable(name, value)
+        for name, value in self.perDofVariables.items():
+            integrator.addPerDofVariable(name, value)
+
+    def absorbVariables(self, propagator):
+        for table, label in ((propagator.globalVariables, 'Global'), (propagator.perDofVariables, 'Per-dof')):
+            mine = self.globalVariables if label == 'Global' else self.perDofVariables
+            for key, value in table.items():
+                if key in mine and value != mine[key]:
+                    raise InputError('{} variable inconsistency in merged propagators'.format(label))
+        self.globalVariables.update(propagator.globalVariables)
+        self.perDofVariables.update(propagator.perDofVariables)
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        pass
+
+    def integrator(self, stepSize):
+        """An `_AtomsMM_Integrator` that carries out this propagator over `stepSize`."""
+        from .integrators import _AtomsMM_Integrator
+        integrator = _AtomsMM_Integrator(stepSize)
+        self.addVariables(integrator)
+        self.addSteps(integrator)
+        return integrator
+
+
+class ChainedPropagator(Propagator):
+    """C = A B ...: the listed propagators one after another (propagators.py:78-114)."""
+
+    def __init__(self, propagators):
+        super().__init__()
+        self.propagators = propagators
+        for propagator in propagators:
+            self.absorbVariables(propagator)
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        for propagator in self.propagators:
+            propagator.addSteps(integrator, fraction, force)
+
+
+class SplitPropagator(Propagator):
+    """A over dt as n applications of A over dt/n, emitted as a while-block on the global `nSplit`
+    (propagators.py:117-149; like the reference, the `force` argument is not forwarded when n > 1)."""
+
+    def __init__(self, A, n):
+        super().__init__()
+        self.A = A
+        self.absorbVariables(A)
+        self.n = n
+        self.globalVariables['nSplit'] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        if self.n == 1:
+            self.A.addSteps(integrator, fraction, force)
+            return
+        integrator.addComputeGlobal('nSplit', '0')
+        integrator.beginWhileBlock('nSplit < {}'.format(self.n))
+        self.A.addSteps(integrator, fraction / self.n)
+        integrator.addComputeGlobal('nSplit', 'nSplit + 1')
+        integrator.endBlock()
+
+
+class TrotterSuzukiPropagator(Propagator):
+    """C = B^(1/2) A B^(1/2)  (propagators.py:152-187)."""
+
+    def __init__(self, A, B):
+        super().__init__()
+        self.A = A
+        self.B = B
+        self.absorbVariables(A)
+        self.absorbVariables(B)
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        self.B.addSteps(integrator, 0.5 * fraction, force)
+        self.A.addSteps(integrator, fraction, force)
+        self.B.addSteps(integrator, 0.5 * fraction, force)
+
+
+class SuzukiYoshidaPropagator(Propagator):
+    """High-order symmetric factorisation with nsy in {1, 3, 7, 15} weights (propagators.py:190-226)."""
+
+    _HALF_WEIGHTS = {
+        15: [0.9148442462, 0.2536933366, -1.4448522369, -0.1582406354, 1.9381391376, -1.960610233, 0.1027998494],
+        7: [0.784513610477560, 0.235573213359357, -1.17767998417887],
+        3: [1.3512071919596578],
+        1: [],
+    }
+
+    def __init__(self, A, nsy=3):
+        super().__init__()
+        if nsy not in self._HALF_WEIGHTS:
+            raise InputError('SuzukiYoshidaPropagator accepts nsy = 1, 3, 7, or 15 only')
+        self.A = A
+        self.nsy = nsy
+        self.absorbVariables(A)
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        half = self._HALF_WEIGHTS[self.nsy]
+        for w in half + [1 - 2 * sum(half)] + half[::-1]:
+            self.A.addSteps(integrator, fraction * w)
+
+
+class TranslationPropagator(Propagator):
+    """x <- x + (fraction*dt)*v ; the constrained variant saves x0, constrains positions and rebuilds
+    v from the displacement (propagators.py:229-252)."""
+
+    def __init__(self, constrained=True):
+        super().__init__()
+        self.constrained = constrained
+        if constrained:
+            self.perDofVariables['x0'] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        if self.constrained:
+            integrator.addComputePerDof('x0', 'x')
+        integrator.addComputePerDof('x', 'x + ({}*dt)*v'.format(fraction))
+        if self.constrained:
+            integrator.addConstrainPositions()
+            integrator.addComputePerDof('v', '(x - x0)/({}*dt)'.format(fraction))
+
+
+class VelocityBoostPropagator(Propagator):
+    """v <- v + (fraction*dt)*force/m (+ velocity constraints)  (propagators.py:255-273)."""
+
+    def __init__(self, constrained=True):
+        super().__init__()
+        self.constrained = constrained
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        integrator.addComputePerDof('v', 'v + ({}*dt)*{}/m'.format(fraction, force))
+        if self.constrained:
+            integrator.addConstrainVelocities()
+
+
+class RespaPropagator(Propagator):
+    """rRESPA with N force groups; group 0 in the innermost loop (propagators.py:830-973).
+
+    loops[k] = iterations of level k per iteration of level k+1.  Level k kicks with force expression
+    f0, f1, f2-f1, f3-f2, ... (the near force is *subtracted inside the integrator*).  Optional
+    `core` (between two half moves) and `shell` {level: propagator} baths; keyword flags
+    has_memory (default False, as in the reference's code), use_respa_switch, blitz.
+    """
+
+    def __init__(self, loops, move=None, boost=None, core=None, shell=None, **kwargs):
+        super().__init__()
+        self.loops = loops
+        self.N = len(loops)
+        self.move = move if move is not None else TranslationPropagator(constrained=False)
+        self.boost = boost if boost is not None else VelocityBoostPropagator(constrained=False)
+        self.core = core
+        if shell is None:
+            self.shell = dict()
+        elif set(shell.keys()).issubset(range(self.N)):
+            self.shell = shell
+        else:
+            raise InputError('invalid key(s) in RespaPropagator \'shell\' argument')
+        for member in [self.move, self.boost, self.core] + list(self.shell.values()):
+            if member is not None:
+                self.absorbVariables(member)
+        for level, n in enumerate(loops):
+            if n > 1:
+                self.globalVariables['n{}RESPA'.format(level)] = 0
+        self.expr = ['f{}'.format(level) for level in range(self.N)]
+        for level in range(2, self.N):
+            self.expr[level] += '-f{}'.format(level - 1)
+        self.force = list(self.expr)
+        self._has_memory = kwargs.pop('has_memory', False)
+        if self._has_memory:
+            for level in range(1, self.N):
+                self.perDofVariables['fm{}'.format(level)] = 0.0
+                self.force[0] += '+fm{}'.format(level)
+                self.force[level] += '-fm{}'.format(level)
+        self.force = ['({})'.format(f) for f in self.force]
+        self._use_respa_switch = kwargs.pop('use_respa_switch', False)
+        self._blitz = kwargs.pop('blitz', False)
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        if self._use_respa_switch:
+            integrator.addComputeGlobal('respa_switch', '1')
+        self._addSubsteps(integrator, self.N - 1, fraction)
+        if self._use_respa_switch:
+            integrator.addComputeGlobal('respa_switch', '0')
+
+    def _internalSplitting(self, integrator, timescale, fraction, shell):
+        remembered = self._has_memory and timescale > 0
+        if self._blitz:
+            if remembered:
+                integrator.addComputePerDof('F{}'.format(timescale), 'f{}'.format(timescale))
+            else:
+                self.boost.addSteps(integrator, fraction, self.force[timescale])
+            self._addSubsteps(integrator, timescale - 1, fraction)
+            return
+        if shell:
+            shell.addSteps(integrator, 0.5 * fraction, self.force[timescale])
+        if remembered:
+            integrator.addComputePerDof('fm{}'.format(timescale), self.expr[timescale])
+        else:
+            self.boost.addSteps(integrator, 0.5 * fraction, self.force[timescale])
+        self._addSubsteps(integrator, timescale - 1, fraction)
+        self.boost.addSteps(integrator, 0.5 * fraction, self.force[timescale])
+        if shell:
+            shell.addSteps(integrator, 0.5 * fraction, self.force[timescale])
+
+    def _addSubsteps(self, integrator, timescale, fraction):
+        if timescale < 0:
+            if self.core is None:
+                self.move.addSteps(integrator, fraction)
+            else:
+                self.move.addSteps(integrator, 0.5 * fraction)
+                self.core.addSteps(integrator, fraction)
+                self.move.addSteps(integrator, 0.5 * fraction)
+            return
+        n = self.loops[timescale]
+        counter = 'n{}RESPA'.format(timescale)
+        if n > 1:
+            integrator.addComputeGlobal(counter, '0')
+            integrator.beginWhileBlock('{} < {}'.format(counter, n))
+        self._internalSplitting(integrator, timescale, fraction / n, self.shell.get(timescale, None))
+        if n > 1:
+            integrator.addComputeGlobal(counter, '{} + 1'.format(counter))
+            integrator.endBlock()
+
+
+class MultipleTimeScalePropagator(RespaPropagator):
+    """RESPA with a bath placed by `scheme` in {middle, blitz, xi-respa, xo-respa, side}; the bath may be
+    factorised by `nres` (SplitPropagator) and `nsy` (Suzuki-Yoshida)  (propagators.py:976-1042)."""
+
+    def __init__(self, loops, move=None, boost=None, bath=None, **kwargs):
+        scheme = kwargs.pop('scheme', 'middle')
+        location = kwargs.pop('location', 0)
+        nres = kwargs.pop('nres', 1)
+        nsy = kwargs.pop('nsy', 1)
+        if nres > 1:
+            bath = SplitPropagator(bath, nres)
+        if nsy > 1:
+            bath = SuzukiYoshidaPropagator(bath, nsy)
+        if scheme == 'middle':
+            super().__init__(loops, move=move, boost=boost, core=bath, **kwargs)
+        elif scheme == 'blitz':
+            super().__init__(loops, move=move, boost=boost, core=bath, blitz=True, **kwargs)
+        elif scheme in ('xi-respa', 'xo-respa', 'side'):
+            level = {'side': location, 'xi-respa': 0, 'xo-respa': len(loops) - 1}[scheme]
+            super().__init__(loops, move=move, boost=boost, shell={level: bath}, **kwargs)
+        else:
+            raise InputError('wrong value of scheme parameter')
+
+
+class VelocityVerletPropagator(Propagator):
+    """Velocity Verlet with constraints (propagators.py:1108-1133)."""
+
+    def __init__(self):
+        super().__init__()
+        self.perDofVariables['x0'] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        Dt = '; Dt=%s*dt' % fraction
+        integrator.addComputePerDof('v', 'v+0.5*Dt*f/m' + Dt)
+        integrator.addComputePerDof('x0', 'x')
+        integrator.addComputePerDof('x', 'x+Dt*v' + Dt)
+        integrator.addConstrainPositions()
+        integrator.addComputePerDof('v', '(x-x0)/Dt+0.5*Dt*f/m' + Dt)
+        integrator.addConstrainVelocities()

@@ -73,9 +73,11 @@ enum {
  *      that RespaPropagator.addSteps emits, propagators.py:933-973) ------------------------------ */
 enum {
     AMM_OP_EVAL = 1,   /* a = group: buffer[group_slot(a)] <- sum of the group's forces at current x */
-    AMM_OP_KICK = 2,   /* v <- v + coef*(buf[a] - buf[b])/m   (b = -1: no subtraction)  propagators.py:271 */
+    AMM_OP_KICK = 2,   /* v <- v + coef*(buf[a] -/+ buf[b])/m  (b = -1: single buffer; c = 1: plus)  propagators.py:271,
+                          force expressions (f0), (f2-f1), (f0+fm1) ... of propagators.py:917-928 */
     AMM_OP_MOVE = 3,   /* x <- x + coef*v                                                propagators.py:249 */
-    AMM_OP_COPY = 4    /* buf[a] <- buf[b]                          integrators.py:139-144 (`_f2_ <- f2`)    */
+    AMM_OP_COPY = 4,   /* buf[a] <- buf[b]                          integrators.py:139-144 (`_f2_ <- f2`)    */
+    AMM_OP_COMBINE = 5 /* buf[a] <- buf[b] + coef*buf[c]            propagators.py:951 (`fm2 <- f2-f1`)       */
 };
 typedef struct {
     int32_t op, a, b, c;
@@ -123,13 +125,16 @@ int amm_force_eval(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *
                    int32_t accumulate, double *d_energy);
 
 /* CustomIntegrator per-DOF steps as the reference emits them (propagators.py:249, 271; integrators.py:113). */
-int amm_kick(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_fsub, const double *d_mass, double coef);
+int amm_kick(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int32_t plus, const double *d_mass, double coef);
 int amm_move(amm_ctx *ctx, double *d_x, const double *d_v, double coef);
 int amm_copy(amm_ctx *ctx, double *d_dst, const double *d_src);
 int amm_mvv(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out); /* addComputeSum('mvv','m*v*v') */
 
 /* CustomIntegrator.step(n)  (integrators.py:153-163): bind state buffers, define groups, run ops. */
 int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass);
+#define AMM_MAX_SLOTS 64
+#define AMM_SLOT_X 62   /* positions and velocities are addressable as buffers too (`x0 <- x`) */
+#define AMM_SLOT_V 63
 int amm_bind_buffer(amm_ctx *ctx, int32_t slot, double *d_buf);              /* per-DOF buffers f0.., _f2_, fm1 */
 int amm_group_define(amm_ctx *ctx, int32_t group, int32_t slot, const int32_t *force_ids, int32_t n_forces);
 int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat);

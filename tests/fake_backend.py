@@ -1,0 +1,67 @@
+"""Call recorder standing in for atomsmm_amd.backend.HipContext in CPU tests of the HOST logic
+(program unrolling, force translation, group definitions).  It computes nothing."""
+import torch
+
+
+class RecordingContext:
+    def __init__(self, n_atoms, box, device=0, stream=None, rank=0, world=1):
+        self.n, self.box, self.rank, self.world = n_atoms, box, rank, world
+        self.torch_device = torch.device('cpu')
+        self.calls = []
+        self.pairs = []
+        self.bonded = []
+        self.groups = {}
+        self.runs = []
+        self._next = 0
+
+    def _new(self):
+        self._next += 1
+        return self._next - 1
+
+    def pair_create(self, desc, q, sigma, eps, excl_pairs=None, skin=-1.0):
+        fid = self._new()
+        self.pairs.append(dict(id=fid, family=desc.family, flags=desc.flags, sign=desc.sign, rc=desc.rc, rc0=desc.rc0,
+                               rs0=desc.rs0, alpha=desc.alpha, rswitch=desc.rswitch, degree=desc.degree,
+                               q=q.copy(), sigma=sigma.copy(), eps=eps.copy(), n_excl=0 if excl_pairs is None else len(excl_pairs)))
+        return fid
+
+    def pair_set_params(self, fid, q, sigma, eps):
+        self.calls.append(('pair_set_params', fid, q.copy(), sigma.copy(), eps.copy()))
+
+    def bonded_create(self):
+        fid = self._new()
+        self.bonded.append(dict(id=fid, terms=[], sliced=False))
+        return fid
+
+    def bonded_add_terms(self, fid, kind, idx, params, periodic=False, desc=None):
+        [b for b in self.bonded if b['id'] == fid][0]['terms'].append((kind, len(idx), bool(periodic)))
+
+    def bonded_finalize(self, fid, sliced=False):
+        [b for b in self.bonded if b['id'] == fid][0]['sliced'] = sliced
+
+    def bind_state(self, x, v, mass):
+        pass
+
+    def bind_buffer(self, slot, buf):
+        self.calls.append(('bind_buffer', slot))
+
+    def group_define(self, group, slot, force_ids):
+        self.groups[group] = (slot, list(force_ids))
+
+    def run_ops(self, ops, repeat=1):
+        self.runs.append(([(o.op, o.a, o.b, o.c, o.coef) for o in ops], repeat))
+
+    def force_eval(self, fid, pos, force, accumulate=False, energy=None):
+        self.calls.append(('force_eval', fid, accumulate))
+
+    def mvv(self, v, mass, out):
+        pass
+
+    def check(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass

@@ -1,0 +1,373 @@
+"""CPU tests of the host side: the AtomsMM-shaped API (names, strings, step programs, errors) and the
+engine's translation / program unrolling, with a call recorder in place of the HIP library."""
+import copy
+import re
+
+import numpy as np
+import pytest
+
+import atomsmm_amd as atomsmm
+from atomsmm_amd import backend as B
+from atomsmm_amd import engine as E
+from atomsmm_amd import forces as F
+from atomsmm_amd import openmm, unit
+from atomsmm_amd.openmm import app
+from atomsmm_amd.testing import system_from_arrays
+from fake_backend import RecordingContext
+
+
+@pytest.fixture()
+def recorder(monkeypatch):
+    made = []
+
+    def factory(*a, **k):
+        made.append(RecordingContext(*a, **k))
+        return made[-1]
+    monkeypatch.setattr(E, '_context_factory', factory)
+    return made
+
+
+# ------------------------------------------------------------------------------------ step programs
+def test_respa_program_text_matches_reference_capture(goldens):
+    integ = atomsmm.RespaPropagator([4, 2, 1]).integrator(4 * unit.femtoseconds)
+    g = goldens['programs']['respa_4_2_1']
+    assert integ.pretty_steps() == g['steps']
+    assert [integ.getPerDofVariableName(i) for i in range(integ.getNumPerDofVariables())] == g['per_dof']
+    assert [integ.getGlobalVariableName(i) for i in range(integ.getNumGlobalVariables())] == g['globals']
+    assert 'Computation steps:' in repr(integ) and '   8:       v <- v + (0.0625*dt)*(f0)/m' in repr(integ)
+
+
+def test_constrained_respa_program_matches_reference_capture(goldens):
+    nve = atomsmm.RespaPropagator([4, 1], boost=atomsmm.VelocityBoostPropagator(constrained=True),
+                                  move=atomsmm.TranslationPropagator(constrained=True))
+    integ = atomsmm.GlobalThermostatIntegrator(1 * unit.femtoseconds, nve)
+    assert integ.pretty_steps() == goldens['programs']['respa_4_1_constrained']['steps']
+
+
+def test_memory_respa_program_matches_reference_capture(goldens):
+    integ = atomsmm.RespaPropagator([2, 1], has_memory=True).integrator(1 * unit.femtoseconds)
+    assert integ.pretty_steps() == goldens['programs']['respa_2_1_memory']['steps']
+
+
+def test_respa_switch_and_loop_of_one():
+    integ = atomsmm.RespaPropagator([1, 1], use_respa_switch=True).integrator(1 * unit.femtoseconds)
+    steps = integ.pretty_steps()
+    assert steps[0] == 'respa_switch <- 1' and steps[-1] == 'respa_switch <- 0'
+    assert not any('while' in s for s in steps)          # loop counts of 1 emit no counter (propagators.py:960-967)
+    assert steps.count('allow forces to update the context state') == 1
+
+
+def test_composition_propagators():
+    kick, move = atomsmm.VelocityBoostPropagator(constrained=False), atomsmm.TranslationPropagator(constrained=False)
+    ts = atomsmm.TrotterSuzukiPropagator(move, kick).integrator(2 * unit.femtoseconds)
+    assert ts.pretty_steps()[1:] == ['v <- v + (0.5*dt)*f/m', 'x <- x + (1.0*dt)*v', 'v <- v + (0.5*dt)*f/m']
+    sp = atomsmm.SplitPropagator(move, 3).integrator(1 * unit.femtoseconds)
+    assert sp.pretty_steps() == ['nSplit <- 0', 'while (nSplit < 3):', '   x <- x + (0.3333333333333333*dt)*v',
+                                 '   nSplit <- nSplit + 1', 'end']
+    sy = atomsmm.SuzukiYoshidaPropagator(move, 3).integrator(1 * unit.femtoseconds)
+    w = 1.3512071919596578
+    assert sy.pretty_steps() == ['x <- x + ({}*dt)*v'.format(c) for c in (w, 1 - 2 * w, w)]
+    with pytest.raises(atomsmm.InputError):
+        atomsmm.SuzukiYoshidaPropagator(move, 5)
+    with pytest.raises(atomsmm.InputError):
+        atomsmm.RespaPropagator([2, 1], shell={5: kick})
+    from atomsmm_amd.propagators import Propagator
+    a, b = Propagator(), Propagator()
+    a.globalVariables['k'] = 1
+    b.globalVariables['k'] = 2
+    with pytest.raises(atomsmm.InputError):
+        atomsmm.ChainedPropagator([a, b])
+
+
+def test_mts_schemes():
+    bath = atomsmm.VelocityBoostPropagator(constrained=False)     # any propagator serves as a stand-in bath
+    mid = atomsmm.MultipleTimeScaleIntegrator(2 * unit.femtoseconds, [2, 1], bath=bath, scheme='middle').pretty_steps()
+    assert '   x <- x + (0.25*dt)*v' in mid                      # move split x, bath, x (propagators.py:970-973)
+    xo = atomsmm.MultipleTimeScaleIntegrator(2 * unit.femtoseconds, [2, 1], bath=bath, scheme='xo-respa').pretty_steps()
+    assert xo[1] == 'v <- v + (0.5*dt)*(f1)/m' and xo[2] == 'v <- v + (0.5*dt)*(f1)/m'
+    with pytest.raises(atomsmm.InputError):
+        atomsmm.MultipleTimeScaleIntegrator(2 * unit.femtoseconds, [2, 1], scheme='nope')
+    with pytest.raises(atomsmm.InputError):
+        atomsmm.RespaPropagator([2]).integrator(1 * unit.femtoseconds).addComputeGlobal('mvv', '1')
+
+
+# ------------------------------------------------------------------------------------ energy strings
+def test_energy_strings_match_reference_captures():
+    """SURVEY.md Appendix C.5."""
+    rc, rs = 7 * unit.angstroms, 5 * unit.angstroms
+    lines = repr(atomsmm.NearNonbondedForce(rc, rs, None)).split('\n')
+    assert lines == ['S*(4*epsilon*((sigma/r)^12-(sigma/r)^6) + Kc*chargeprod/r)',
+                     'S = 1 + step(r - rs0)*u^3*(15*u - 6*u^2 - 10)', 'u=(r-rs0)/(rc0-rs0)']
+    lines = repr(atomsmm.NearNonbondedForce(rc, rs, 'shift')).split('\n')
+    assert lines[0] == ('S*(4*epsilon*((sigma/r)^12-(sigma/r)^6-((sigma/rc0)^12-(sigma/rc0)^6))'
+                        '+Kc*chargeprod*(1/r-1/rc0))')
+    fs = atomsmm.NearNonbondedForce(rc, rs, 'force-switch')
+    lines = repr(fs).split('\n')
+    assert lines[0] == ('4*epsilon*(f12*(sigma/r)^12-f6*(sigma/r)^6) + Kc*chargeprod*f1/r-(4*epsilon*'
+                        '(f12c*(sigma/rc0)^12-f6c*(sigma/rc0)^6) + Kc*chargeprod*f1c/rc0)')
+    assert lines[4] == 'R=u/b+1' and lines[5] == 'b=2.5' and lines[-1] == 'u=(r-rs0)/(rc0-rs0)'
+    consts = {l.split('=')[0]: float(l.split('=')[1]) for l in lines[5:9]}
+    assert consts['f12c'] == pytest.approx(8.685770457212126, rel=1e-14)
+    assert consts['f6c'] == pytest.approx(2.744, rel=1e-14)
+    assert consts['f1c'] == pytest.approx(1.171339712719476, rel=1e-12)
+    assert fs.getGlobalParameters() == {'Kc': 138.935456, 'rc0': pytest.approx(0.7), 'rs0': pytest.approx(0.5)}
+    assert repr(atomsmm.NearNonbondedForce(10 * unit.angstroms, 9.5 * unit.angstroms, 'force-switch')).split('\n')[5] == 'b=19.0'
+    d1 = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9.5 * unit.angstroms)
+    assert d1.getEnergyFunction() == '4*epsilon*((sigma/r)^12 - (sigma/r)^6) + erfc(alpha*r)*Kc*chargeprod/r'
+    assert d1.getUseSwitchingFunction() and d1.getSwitchingDistance() / unit.nanometer == pytest.approx(0.95)
+    assert not d1.getUseLongRangeCorrection()
+    d2 = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9.5 * unit.angstroms, degree=2)
+    assert repr(d2).split('\n') == ['S*(4*epsilon*((sigma/r)^12 - (sigma/r)^6) + erfc(alpha*r)*Kc*chargeprod/r)',
+                                    'S = 1 + step(r - rswitch)*u^3*(15*u - 6*u^2 - 10)',
+                                    'u = (r^d - rswitch^d)/(rcut^d - rswitch^d)', 'd=2']
+    assert not d2.getUseSwitchingFunction()
+    assert atomsmm.NonbondedExceptionsForce().getEnergyFunction() == '4*epsilon*x*(x-1) + Kc*chargeprod/r; x=(sigma/r)^6'
+    sub = atomsmm.NearNonbondedForce(rc, rs, None, subtract=True, actual_cutoff=10 * unit.angstroms)
+    assert sub.getEnergyFunction().startswith('-(step(rc0-r)*(S*(')
+    assert sub.getCutoffDistance() / unit.nanometer == pytest.approx(1.0)
+    exp = F.nearForceExpressions(rc, rs, 'force-switch')
+    assert exp[-3:] == ['rs0=0.5', 'rc0={}'.format(unit.md_value(rc)), 'Kc=138.935456']
+
+
+def test_input_errors():
+    with pytest.raises(atomsmm.InputError):
+        atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 10 * unit.angstroms)
+    with pytest.raises(atomsmm.InputError):
+        atomsmm.NearNonbondedForce(10 * unit.angstroms, 9 * unit.angstroms, 'bogus')
+    with pytest.raises(atomsmm.InputError):
+        atomsmm.FarNonbondedForce(atomsmm.NonbondedExceptionsForce(), 10 * unit.angstroms)
+    assert str(atomsmm.InputError('x')) == '\033[1;31mx\033[0m'
+
+
+@pytest.mark.parametrize('adj', [None, 'shift', 'force-switch'])
+def test_describe_energy_recognises_reference_strings(adj):
+    rc, rs = 7 * unit.angstroms, 5 * unit.angstroms
+    near = atomsmm.NearNonbondedForce(rc, rs, adj)
+    d = F.describe_energy(near.getEnergyFunction(), near.getGlobalParameters())
+    assert d['family'] == near._amm['family'] and d['sign'] == 1.0 and not d['guard']
+    assert d['rc0'] == pytest.approx(0.7) and d['rs0'] == pytest.approx(0.5)
+    far = atomsmm.FarNonbondedForce(near, 10 * unit.angstroms, 9 * unit.angstroms)
+    dd = F.describe_energy(far[1].getEnergyFunction(), far[1].getGlobalParameters())
+    assert dd['family'] == d['family'] and dd['sign'] == -1.0 and dd['guard']
+    assert far[1]._amm['sign'] == -1.0 and far[1]._amm['guard']
+    respa_strings = ';'.join(F.nearForceExpressions(rc, rs, adj))
+    dr = F.describe_energy(respa_strings)
+    assert dr['family'] == d['family'] and dr['rc0'] == pytest.approx(0.7) and dr['Kc'] == 138.935456
+    minus = respa_strings.split(';')
+    minus[0] = '-step(rc0-r)*({})'.format(minus[0])
+    dm = F.describe_energy(';'.join(minus))
+    assert dm['sign'] == -1.0 and dm['guard']
+    assert F.describe_energy('k*r^2') is None
+
+
+# ------------------------------------------------------------------------------------ systems / forces plumbing
+def water_system(spcfw, **kw):
+    return system_from_arrays(spcfw, **kw)
+
+
+def test_import_from_and_compound_force(spcfw):
+    system = water_system(spcfw, nonbondedMethod='PME', flexible=False)
+    n_forces = system.getNumForces()
+    nb = atomsmm.hijackForce(system, atomsmm.findNonbondedForce(system))
+    assert system.getNumForces() == n_forces - 1
+    near = atomsmm.NearNonbondedForce(7 * unit.angstroms, 6.5 * unit.angstroms, 'shift')
+    assert near.importFrom(nb).addTo(system) is near
+    assert near.getNumParticles() == 1536 and near.getNumExclusions() == 1536
+    assert near.getNonbondedMethod() == openmm.CustomNonbondedForce.CutoffPeriodic
+    assert near.getEnergyFunction().endswith(';chargeprod = (charge1)*(charge2);sigma = 0.5*(sigma1+sigma2);'
+                                             'epsilon = sqrt((epsilon1)*(epsilon2))')
+    far = atomsmm.FarNonbondedForce(near, 10 * unit.angstroms, 9.5 * unit.angstroms).setForceGroup(2)
+    assert isinstance(far, atomsmm.FarNonbondedForce) and far.getForceGroup() == 2
+    far.importFrom(nb).addTo(system)
+    total, discount = far[0], far[1]
+    assert [f for f in far] == [total, discount]
+    assert total.getNonbondedMethod() == openmm.NonbondedForce.PME and total.getNumExceptions() == 1536
+    assert all(total.getExceptionParameters(i)[2] / unit.elementary_charge ** 2 == 0 for i in range(5))
+    assert discount.getCutoffDistance() / unit.nanometer == pytest.approx(1.0)
+    assert system.getNumForces() == n_forces + 2
+    far.enableExceptions()
+    assert len(far.forces) == 3 and far[2].getForceGroup() == 2
+    assert atomsmm.countDegreesOfFreedom(system) == 3 * 1536 - 3
+
+
+def test_respa_system_groups(spcfw):
+    system = water_system(spcfw, nonbondedMethod='PME', switch=0.9)
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    assert system.getNumForces() == 3                       # input untouched (deep copy, systems.py:63)
+    groups = [(f.__class__.__name__, f.getForceGroup()) for f in respa.getForces()]
+    assert groups == [('HarmonicBondForce', 0), ('HarmonicAngleForce', 0), ('NonbondedForce', 2),
+                      ('_AtomsMM_CustomNonbondedForce', 1), ('_AtomsMM_CustomNonbondedForce', 31),
+                      ('_AtomsMM_CustomBondForce', 0)]
+    nb = respa.getForce(2)
+    assert nb.getReciprocalSpaceForceGroup() == 2
+    near, minus, exc = respa.getForce(3), respa.getForce(4), respa.getForce(5)
+    assert near._amm['family'] == 'near-force-switch' and minus._amm['sign'] == -1.0 and minus._amm['guard']
+    assert minus.getEnergyFunction().startswith('-step(rc0-r)*(4*epsilon*(f12*')
+    assert exc.getNumBonds() == 1536 and exc.getEnergyFunction().startswith('4*epsilon*x*(x-1) + Kc*chargeprod/r;x=(sigma/r)^6')
+    # fastExceptions extracted (zeroed) the exceptions of the NonbondedForce (forces.py:387-388)
+    i, j, qq, s, e = nb.getExceptionParameters(0)
+    assert (qq / qq.unit, s / s.unit, e / e.unit) == (0.0, 1.0, 0.0)
+    slow = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms, fastExceptions=False)
+    assert [f.getForceGroup() for f in slow.getForces()] == [0, 0, 2, 1, 31, 1, 31]
+
+
+def test_unit_module():
+    a = 10 * unit.angstroms
+    assert a.value_in_unit(unit.nanometers) == pytest.approx(1.0) and a / a.unit == 10
+    assert (0.29 / unit.angstroms).value_in_unit(unit.nanometer ** -1) == pytest.approx(2.9)
+    assert 9.5 * unit.angstroms < a and a >= 1.0 * unit.nanometer
+    assert (4 * unit.femtoseconds)._md() == pytest.approx(0.004)
+    assert (atomsmm.utils.kB * 300 * unit.kelvin)._md() == pytest.approx(2.494338785445972)
+    with pytest.raises(TypeError):
+        a + 1.0
+    with pytest.raises(TypeError):
+        a.value_in_unit(unit.picosecond)
+
+
+# ------------------------------------------------------------------------------------ engine (host logic, recorder)
+def respa_context(spcfw, recorder, loops=(4, 2, 1), outer='damped'):
+    system = water_system(spcfw, nonbondedMethod='CutoffPeriodic')
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    if outer == 'damped':       # composition recipe of SURVEY.md 8d C1
+        nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+        f = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9 * unit.angstroms).importFrom(nb)
+        f.setForceGroup(2)
+        f.addTo(respa)
+    integ = atomsmm.RespaPropagator(list(loops)).integrator(4 * unit.femtoseconds)
+    sim = app.Simulation(app.Topology(), respa, integ, openmm.Platform.getPlatformByName('HIP'))
+    sim.context.setPositions(spcfw['positions'] * unit.nanometers)
+    return sim, recorder[-1]
+
+
+def test_engine_translation(spcfw, recorder):
+    sim, rec = respa_context(spcfw, recorder)
+    fams = sorted((p['family'], p['sign'], p['rc'], bool(p['flags'] & B.GUARD_RC0)) for p in rec.pairs)
+    assert fams == [(B.NEAR_FSWITCH, -1.0, pytest.approx(0.7), True), (B.NEAR_FSWITCH, 1.0, pytest.approx(0.7), False),
+                    (B.DAMPED, 1.0, pytest.approx(1.0), False)]
+    damped = [p for p in rec.pairs if p['family'] == B.DAMPED][0]
+    assert damped['alpha'] == pytest.approx(2.9) and damped['rswitch'] == pytest.approx(0.9) and damped['degree'] == 1
+    assert damped['n_excl'] == 1536 and damped['q'][1] == pytest.approx(-0.84)
+    kinds = sorted(t[0] for b in rec.bonded for t in b['terms'])
+    assert kinds == [B.BOND_HARMONIC, B.ANGLE_HARMONIC, B.BOND_LJC]
+
+
+def test_engine_unrolls_respa_with_force_caches(spcfw, recorder):
+    sim, rec = respa_context(spcfw, recorder)
+    sim.step(5)
+    assert len(rec.runs) == 2 and rec.runs[0][1] == 1 and rec.runs[1][1] == 4   # first step, then steady state x4
+    first, steady = rec.runs[0][0], rec.runs[1][0]
+    g = {grp: slot for grp, (slot, ids) in rec.groups.items()}
+
+    def evals(ops):
+        return [o[1] for o in ops if o[0] == B.OP_EVAL]
+    # steady state: 1 / 2 / 8 evaluations of groups 2 / 1 / 0, first step one more of f2 and f1
+    assert sorted(evals(steady)) == [0] * 8 + [1] * 2 + [2]
+    assert sorted(evals(first)) == [0] * 9 + [1] * 3 + [2] * 2
+    kicks = [o for o in steady if o[0] == B.OP_KICK]
+    moves = [o for o in steady if o[0] == B.OP_MOVE]
+    assert len(kicks) == 2 + 4 + 16 and len(moves) == 8
+    assert moves[0][4] == pytest.approx(0.125 * 0.004)
+    assert kicks[0][1] != g[2] and kicks[0][2] == g[1] and kicks[0][3] == 0 and kicks[0][4] == pytest.approx(0.5 * 0.004)
+    assert [o for o in steady if o[0] == B.OP_COPY][0][2] == g[2]              # `_f2_ <- f2`
+    # group 0 = one merged bonded set (bonds + angles + exceptions), groups 1/2 = one pair force each
+    assert len(rec.groups[0][1]) == 1 and len(rec.groups[1][1]) == 1 and len(rec.groups[2][1]) == 1
+    integ = sim.integrator
+    assert integ.getGlobalVariableByName('n0RESPA') == 4 and integ.getGlobalVariableByName('n1RESPA') == 2
+    assert integ.getGlobalVariableByName('NDOF') == 3 * 1536
+    # new positions invalidate the caches: next step is a 'first' step again
+    sim.context.setPositions(spcfw['positions'] * unit.nanometers)
+    sim.step(1)
+    assert sorted(evals(rec.runs[-1][0])) == [0] * 9 + [1] * 3 + [2] * 2
+
+
+def test_engine_memory_program_and_unsupported_steps(spcfw, recorder):
+    system = water_system(spcfw, nonbondedMethod='CutoffPeriodic')
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    nb = respa.getForce(atomsmm.findNonbondedForce(respa))
+    nb.setForceGroup(1)            # two time scales: 0 bonded, 1 everything else... keep near in 1 as well
+    integ = atomsmm.RespaPropagator([2, 1], has_memory=True).integrator(1 * unit.femtoseconds)
+    ctx = openmm.Context(respa, integ)
+    ctx.setPositions(spcfw['positions'])
+    integ.step(1)
+    ops = recorder[-1].runs[0][0]
+    assert [o[0] for o in ops if o[0] in (B.OP_COPY, B.OP_KICK)][0] == B.OP_COPY            # fm1 <- f1
+    plus = [o for o in ops if o[0] == B.OP_KICK and o[3] == 1]
+    assert len(plus) == 4                                                                    # (f0+fm1) kicks
+    assert [o for o in ops if o[0] == B.OP_KICK][-1][3] == 0                                 # (f1-fm1)
+    # constrained propagators are accepted on constraint-free systems only up to what the HIP path implements
+    nve = atomsmm.RespaPropagator([2, 1], move=atomsmm.TranslationPropagator(constrained=True))
+    integ2 = atomsmm.GlobalThermostatIntegrator(1 * unit.femtoseconds, nve)
+    ctx2 = openmm.Context(respa, integ2)
+    ctx2.setPositions(spcfw['positions'])
+    with pytest.raises(NotImplementedError):
+        integ2.step(1)                                                                      # v <- (x - x0)/(c*dt)
+
+
+def test_engine_rejects_what_it_cannot_run(spcfw, recorder):
+    system = water_system(spcfw, nonbondedMethod='PME')
+    integ = atomsmm.RespaPropagator([2, 2, 1]).integrator(1 * unit.femtoseconds)
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    ctx = openmm.Context(respa, integ)
+    ctx.setPositions(spcfw['positions'])
+    with pytest.raises(NotImplementedError, match='reciprocal'):
+        integ.step(1)
+    with pytest.raises(NotImplementedError, match='reciprocal'):
+        ctx.getState(getEnergy=True)
+    custom = openmm.CustomNonbondedForce('k*r^2')
+    custom.setNonbondedMethod(custom.CutoffPeriodic)
+    for _ in range(1536):
+        custom.addParticle([])
+    bad = copy.deepcopy(system)
+    bad.addForce(custom)
+    with pytest.raises(atomsmm.InputError, match='not recognised'):
+        openmm.Context(bad, openmm.VerletIntegrator(0.0))
+    nobox = openmm.System()
+    nobox.addParticle(1.0)
+    with pytest.raises(atomsmm.InputError):
+        openmm.Context(nobox, openmm.VerletIntegrator(0.0))
+    with pytest.raises(openmm.OpenMMException):
+        openmm.VerletIntegrator(0.0).step(1)
+
+
+def test_parameter_offsets_update_backend(heaq, recorder):
+    """SolvationSystem-style charge offsets (systems.py:303-311): q_eff = q + lambda_coul*chargeScale."""
+    system = system_from_arrays(heaq, nonbondedMethod='CutoffPeriodic')
+    nb = system.getForce(atomsmm.findNonbondedForce(system))
+    solute = np.where(heaq['resname'] == 'aaa')[0]
+    nb.addGlobalParameter('lambda_coul', 1.0)
+    for i in solute:
+        q, s, e = nb.getParticleParameters(int(i))
+        nb.setParticleParameters(int(i), 0.0, 0.0, 0.0)
+        nb.addParticleParameterOffset('lambda_coul', int(i), q, 0.0, 0.0)
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    near = respa.getForce(respa.getNumForces() - 3)
+    assert 'charge1+lambda_coul*chargeScale_lambda_coul1' in near.getEnergyFunction()
+    assert near.getNumPerParticleParameters() == 6 and near.getGlobalParameters()['lambda_coul'] == 1.0
+    ctx = openmm.Context(respa, openmm.VerletIntegrator(0.0))
+    rec = recorder[-1]
+    i0 = int(solute[0])
+    assert rec.pairs[1]['q'][i0] == pytest.approx(heaq['charge'][i0])
+    ctx.setParameter('lambda_coul', 0.5)
+    updates = [c for c in rec.calls if c[0] == 'pair_set_params']
+    assert len(updates) == 3 and all(u[2][i0] == pytest.approx(0.5 * heaq['charge'][i0]) for u in updates)
+    assert ctx.getParameter('lambda_coul') == 0.5
+    with pytest.raises(openmm.OpenMMException):
+        ctx.setParameter('nope', 1.0)
+
+
+def test_distributed_markers(spcfw, recorder, monkeypatch):
+    """world = 2: EVAL of a group holding a pair force is followed by an all-reduce of its buffer; group 0
+    (bond lists only, computed redundantly) is not reduced; bond lists sharing a reduced group are sliced."""
+    import torch.distributed as dist
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_world_size', lambda *a: 2)
+    monkeypatch.setattr(dist, 'get_rank', lambda *a: 1)
+    reduced = []
+    monkeypatch.setattr(dist, 'all_reduce', lambda t, *a, **k: reduced.append(t.data_ptr()))
+    sim, rec = respa_context(spcfw, recorder)
+    assert rec.rank == 1 and rec.world == 2
+    sim.step(2)
+    eng = sim.context._engine
+    f1, f2 = eng._buffers['f1'].data_ptr(), eng._buffers['f2'].data_ptr()
+    assert reduced == [f2, f1, f1, f1, f2] + [f1, f1, f2]
+    assert all(not b['sliced'] for b in rec.bonded)            # group 0 holds no pair force -> redundant, unsliced
