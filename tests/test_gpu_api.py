@@ -77,8 +77,9 @@ def test_RESPASystem_split_energies(spcfw, goldens):
     system, positions, topology = create_system(spcfw, nonbondedMethod='CutoffPeriodic', switch=0.9)
     respa_system = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
     components = atomsmm.splitPotentialEnergy(respa_system, topology, positions)
-    assert set(components) == {'HarmonicBondForce', 'HarmonicAngleForce', 'Real-Space', 'CustomNonbondedForce',
-                               'CustomNonbondedForce(1)', 'CustomBondForce', 'Total'}
+    assert set(components) == {'HarmonicBondForce', 'HarmonicAngleForce', 'Real-Space', 'Reciprocal-Space',
+                               'CustomNonbondedForce', 'CustomNonbondedForce(1)', 'CustomBondForce', 'Total'}
+    assert components['Reciprocal-Space']._value == 0.0      # CutoffPeriodic: no reciprocal-space term
     value = {k: v / v.unit for k, v in components.items()}
     assert value['HarmonicBondForce'] == pytest.approx(goldens['G_bonds']['value'])
     assert value['HarmonicAngleForce'] == pytest.approx(goldens['G_angles']['value'])
@@ -244,7 +245,7 @@ def test_time_reversibility_and_energy_conservation(spcfw):
     context.setVelocitiesToTemperature(300 * unit.kelvin, 7)
 
     def total():
-        s = context.getState(getEnergy=True, groups={0, 1, 2})
+        s = context.getState(getEnergy=True)      # all groups: 31 (-near) cancels 1, leaving E0 + E2 = the Hamiltonian
         return s.getPotentialEnergy()._value + s.getKineticEnergy()._value
     e0 = total()
     integrator.step(50)
