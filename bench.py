@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json): ns/day of a ~100k-atom flexible TIP3P box
+under RESPA (near/far split + multiple-timescale inner loop) on N MI355X, plus the near-nonbonded
+kernel's roofline figure and a CPU baseline timed in the same run.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload: 32 768 flexible TIP3P waters (98 304 atoms, L = 9.94 nm) built by
+atomsmm_amd.testing.tip3p_box (seeded, synthetic); RESPASystem(rcutIn = 0.7 nm, rswitchIn = 0.5 nm,
+'force-switch'); outer force DampedSmoothedForce(alpha = 2.9/nm, 1.0 nm, 0.9 nm) in group 2;
+RespaPropagator([4,2,1]), outer step 4 fs (0.5 / 2 / 4 fs).  Everything goes through the AtomsMM-shaped API
+(atomsmm_amd as atomsmm) and therefore through the C-ABI of libatomsmm_hip.so.  One "step" = one outer
+RESPA step = 1 far + 2 near + 8 bonded evaluations, 22 kicks, 8 moves.  The lattice start is relaxed
+before timing (velocity rescaling to 300 K, untimed) so that neighbour-list rebuild frequency is that of
+liquid water.  Inputs are resident in HBM when the timed region starts.
+
+N > 1: one process per GPU; every rank integrates all atoms, evaluates pair forces for its slice of the
+cell-sorted atom order and all-reduces the per-group force buffer (RCCL).  Strong scaling (fixed box).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
+FP64_VECTOR_PEAK_TF = 78.6     # public datasheet value; not in the container's guide
+BYTES_PER_ATOM = 72            # fp64: read x,y,z + q,sigma,eps, write Fx,Fy,Fz
+FLOP_PER_PAIR_NEAR = 60        # force-switch near, force only
+KB = 0.0083144626181532
+
+
+def build_simulation(nside, loops, dt_fs):
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import openmm, unit
+    from atomsmm_amd.openmm import app
+    from atomsmm_amd.testing import system_from_arrays, tip3p_box
+    case = tip3p_box(nside)
+    system = system_from_arrays(case, nonbondedMethod='CutoffPeriodic', cutoff=1.0, switch=0.9)
+    respa = atomsmm.RESPASystem(system, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
+    nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+    outer = atomsmm.DampedSmoothedForce(2.9 / unit.nanometers, 1.0 * unit.nanometers, 0.9 * unit.nanometers)
+    outer.importFrom(nb)
+    outer.setForceGroup(2)
+    outer.addTo(respa)
+    integrator = atomsmm.RespaPropagator(list(loops)).integrator(dt_fs * unit.femtoseconds)
+    simulation = app.Simulation(app.Topology(len(case['positions'])), respa, integrator,
+                                openmm.Platform.getPlatformByName('HIP'))
+    simulation.context.setPositions(case['positions'] * unit.nanometers)
+    simulation.context.setVelocities(case['velocities'])
+    return simulation, case
+
+
+def temperature(engine, torch):
+    out = torch.zeros(1, dtype=torch.float64, device=engine.x.device)
+    engine.ctx.mvv(engine.v, engine.mass, out)
+    return out.item() / (3 * engine.n * KB)
+
+
+def relax(simulation, torch, target=300.0, max_steps=1500, block=10, log=None):
+    """Untimed: take the synthetic lattice start to liquid-like water at ~300 K by rescaling velocities."""
+    eng = simulation.context._engine
+    calm = 0
+    done = 0
+    while done < max_steps:
+        simulation.step(block)
+        done += block
+        T = temperature(eng, torch)
+        if log:
+            log('relax step %d: T = %.1f K' % (done, T))
+        eng.v.mul_((target / T) ** 0.5)
+        calm = calm + 1 if T < 1.04 * target else 0
+        if calm >= 5:
+            break
+    return done
+
+
+def cpu_baseline(nside, loops, dt_fs, sample_steps=3):
+    """Oracle (CPU restatement, OpenMP cell-list, fp64) on this host's cores: same system, same step program."""
+    from atomsmm_amd.testing import tip3p_box
+    from oracle import oracle as O
+    from oracle import respa_cpu
+    case = tip3p_box(nside)
+    sec, sim = respa_cpu.time_respa(case, warmup=1, steps=sample_steps, loops=tuple(loops), dt=dt_fs * 1e-3)
+    return {'value': round(dt_fs * 1e-6 * 86400.0 / sec, 4), 'unit': 'ns/day', 'cores': int(O.num_threads()), 'kind': 'port',
+            'sample': '%d outer RESPA steps (after 1 warm-up) of the same %d-atom workload, %.2f s/step; CPU restatement '
+                      '(oracle/amm_oracle.c), not OpenMM' % (sample_steps, len(case['positions']), sec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--nside', type=int, default=32, help='waters per box edge (32 -> 98 304 atoms)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-relax', action='store_true')
+    ap.add_argument('--verbose', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    if args.gpus != world and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+
+    def log(msg):
+        if args.verbose and rank == 0:
+            print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+    loops, dt_fs = (4, 2, 1), 4.0
+    t_setup = time.perf_counter()
+    simulation, case = build_simulation(args.nside, loops, dt_fs)
+    eng = simulation.context._engine
+    n = eng.n
+    log('system built in %.1f s: %d atoms' % (time.perf_counter() - t_setup, n))
+    relaxed = 0 if args.no_relax else relax(simulation, torch, log=log)
+    log('relaxed for %d steps, T = %.1f K' % (relaxed, temperature(eng, torch)))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    simulation.step(args.warmup)
+    near_id = eng.pair_force_ids(1)[0]
+    far_id = eng.pair_force_ids(2)[0]
+    st0 = {fid: eng.ctx.pair_stats(fid) for fid in (near_id, far_id)}
+    eng.ctx.profile_enable(True)       # HIP events around each pair-traversal launch, on the launch stream
+    fence()
+    t0 = time.perf_counter()
+    simulation.step(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    n_near, ms_near = eng.ctx.profile_read(near_id)
+    n_far, ms_far = eng.ctx.profile_read(far_id)
+    eng.ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    st1 = {fid: eng.ctx.pair_stats(fid) for fid in (near_id, far_id)}
+    T_end = temperature(eng, torch)
+    ms_per_step = elapsed / args.steps * 1e3
+    ns_day = dt_fs * 1e-6 * 86400.0 / (elapsed / args.steps)
+
+    if rank == 0:
+        t_near = ms_near / max(n_near, 1) * 1e-3          # s per launch (this rank's slice)
+        atoms_per_launch = st1[near_id]['n_slice_atoms']
+        alg_bytes = BYTES_PER_ATOM * atoms_per_launch
+        achieved = alg_bytes / t_near / 1e9
+        # directed in-cutoff pairs ~ list pairs * (rc/rlist)^3 ; algorithmic pairs counted once per (i,j)
+        near_stats = st1[near_id]
+        pairs_once = 0.5 * near_stats['n_list_pairs'] * (0.7 / near_stats['rlist']) ** 3
+        fp64_tf = FLOP_PER_PAIR_NEAR * pairs_once / t_near / 1e12
+        result = {
+            'metric': 'ns/day on 100k-atom TIP3P RESPA box; near-nonbonded HBM GB/s vs 8 TB/s peak',
+            'value': round(ns_day, 3), 'unit': 'ns/day', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'C3: %d-atom flexible TIP3P box (L = %.3f nm), RESPASystem(0.7, 0.5, force-switch) + '
+                                   'DampedSmoothedForce(2.9/nm, 1.0, 0.9) outer force, RespaPropagator([4,2,1]), 4 fs outer step'
+                                   % (n, case['box'][0]),
+                       'atoms': n, 'loops': list(loops), 'outer_step_fs': dt_fs, 'relax_steps': relaxed,
+                       'parallelism': 'atom-decomposition x%d, all-reduce of group force buffers' % world if world > 1 else 'single GPU',
+                       'temperature_K_end': round(T_end, 1)},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': None,
+                         'kernel': 'k_pair_nlist<NEAR_FSWITCH> (group-1 near force, force only)',
+                         'avg_launch_us': round(t_near * 1e6, 2), 'launches': n_near,
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'note': 'FP64-VALU/latency bound, not HBM bound (SURVEY.md 8d): %.2f TFLOP/s fp64 = %.3f of %.1f TF vector peak '
+                                 'at 60 flop per in-cutoff pair' % (fp64_tf, fp64_tf / FP64_VECTOR_PEAK_TF, FP64_VECTOR_PEAK_TF)},
+            'detail': {'near_kernel_us': round(t_near * 1e6, 2), 'far_kernel_us': round(ms_far / max(n_far, 1) * 1e3, 2),
+                       'near_launches': n_near, 'far_launches': n_far,
+                       'near_list_builds_in_timed_region': st1[near_id]['n_builds'] - st0[near_id]['n_builds'],
+                       'far_list_builds_in_timed_region': st1[far_id]['n_builds'] - st0[far_id]['n_builds'],
+                       'near_lanes_per_atom': near_stats['lanes_per_atom'], 'near_rlist_nm': near_stats['rlist'],
+                       'near_list_pairs': near_stats['n_list_pairs'], 'fp64_tflops_near': round(fp64_tf, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result['cpu_baseline'] = cpu_baseline(args.nside, loops, dt_fs)
+            except Exception as exc:   # the baseline is a reported figure, never a reason to lose the GPU result
+                result['cpu_baseline'] = {'value': None, 'unit': 'ns/day', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

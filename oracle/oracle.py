@@ -97,15 +97,16 @@ def exclusion_csr(n, pairs):
     return ptr, both[:, 1].astype(np.int32)
 
 
-def pair_eval(d, pos, box, q, sigma, eps, excl_pairs=None, want_forces=True, use_cells=False):
+def pair_eval(d, pos, box, q, sigma, eps, excl_pairs=None, want_forces=True, use_cells=False, csr=None):
+    """csr = exclusion_csr(n, pairs) may be passed instead of excl_pairs to avoid rebuilding it per call."""
     n = len(pos)
     pos_, pp = _d(pos)
     box_, bp = _d(box)
     q_, qp = _d(q)
     s_, sp = _d(sigma)
     e_, ep = _d(eps)
-    if excl_pairs is not None and len(excl_pairs):
-        ptr, idx = exclusion_csr(n, excl_pairs)
+    if csr is not None or (excl_pairs is not None and len(excl_pairs)):
+        ptr, idx = csr if csr is not None else exclusion_csr(n, excl_pairs)
         ptr_, ptrp = _i(ptr)
         idx_, idxp = _i(idx)
     else:
