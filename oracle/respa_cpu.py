@@ -34,7 +34,8 @@ class RespaCPU:
                              O.harmonic_angles(c['angles'], c['angle_theta0'], c['angle_k'], self.x, c['box'])[1])
             else:
                 d = self.dn if g == 1 else self.dd
-                self.F[g] = O.pair_eval(d, self.x, c['box'], c['charge'], c['sigma'], c['epsilon'], use_cells=True,
+                cells = min(c['box']) / d.rc >= 3.0       # the 27-cell stencil needs >= 3 cells per axis
+                self.F[g] = O.pair_eval(d, self.x, c['box'], c['charge'], c['sigma'], c['epsilon'], use_cells=cells,
                                         csr=self.csr)[1]
         return self.F[g]
 
