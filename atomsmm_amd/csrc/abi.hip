@@ -157,6 +157,7 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     skin = std::min(skin, std::max(0.0, 0.5 * Lmin - desc->rc) * 0.999);
     pf->skin = skin;
     pf->rlist = desc->rc + skin;
+    pf->rlist_build = pf->rlist + 2e-4;   // fp32 build: positions carry ~1e-6 nm rounding, superset is harmless
     if (amm_pair_setup_grid(ctx, pf)) {
         delete pf;
         return 1;
@@ -194,8 +195,10 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     AMM_HIP(hipMalloc(&pf->d_cell_fill, sizeof(int) * (nc + 1)));
     AMM_HIP(hipMalloc(&pf->d_perm_tmp, sizeof(int) * n));
     AMM_HIP(hipMalloc(&pf->d_perm, sizeof(int) * n));
+    AMM_HIP(hipMalloc(&pf->d_inv_perm, sizeof(int) * n));
     AMM_HIP(hipMalloc(&pf->d_posq_s, sizeof(double4) * n));
     AMM_HIP(hipMalloc(&pf->d_lj_s, sizeof(double2) * n));
+    AMM_HIP(hipMalloc(&pf->d_pos4f_s, sizeof(float4) * n));
     AMM_HIP(hipMalloc(&pf->d_xref, sizeof(double) * 3 * n));
     AMM_HIP(hipMalloc(&pf->d_flags, sizeof(int) * 4));
     AMM_HIP(hipMemset(pf->d_flags, 0, sizeof(int) * 4));

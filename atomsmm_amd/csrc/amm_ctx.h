@@ -37,7 +37,8 @@ struct Box {
 
 struct CellGrid {
     int nc[3];
-    int nstencil[3];   // number of unique neighbour offsets per axis (3, 2 or 1)
+    int nstencil[3];   // number of unique neighbour cells visited per axis (2h+1, or all nc cells)
+    int h[3];          // stencil half-width in cells
     int ncell;
     double cw[3], inv_cw[3];
 };
@@ -47,22 +48,25 @@ struct PairForce {
     PairConsts pc;
     int n = 0;
     double skin = 0, rlist = 0;
+    double rlist_build = 0;        // rlist + fp32 safety margin used by the list build
     // per-atom parameters, original order: q, sigma/2, 2*sqrt(eps)
     double *d_q = nullptr, *d_hsig = nullptr, *d_seps2 = nullptr;
     int *d_excl_ptr = nullptr, *d_excl_idx = nullptr;
     CellGrid grid;
     int *d_cell_of = nullptr, *d_cell_count = nullptr, *d_cell_start = nullptr, *d_cell_fill = nullptr;
-    int *d_perm_tmp = nullptr, *d_perm = nullptr;
+    int *d_perm_tmp = nullptr, *d_perm = nullptr, *d_inv_perm = nullptr;
     double4 *d_posq_s = nullptr;   // sorted: wrapped x,y,z and charge
     double2 *d_lj_s = nullptr;     // sorted: sigma/2, 2*sqrt(eps)
+    float4 *d_pos4f_s = nullptr;   // sorted fp32 positions at the last list build
     double *d_xref = nullptr;      // positions at the last list build (original order)
     int s_begin = 0, s_end = 0;    // sorted-slot range owned by this rank
     int cap = 0;
     int *d_nl = nullptr, *d_nnb = nullptr;
     int *d_flags = nullptr;        // [0] need_rebuild [1] overflow [2] max_nb [3] scratch
     unsigned long long *d_counters = nullptr;  // [0] builds [1] list pairs
+    unsigned long long *d_blockstats = nullptr; // per build-kernel block: (sum, max) of list lengths
     int lpa = 8;                   // lanes per i-atom in the traversal kernel
-    int lpb = 16;                  // lanes per i-atom in the list-build kernel
+    int parts = 1;                 // wavefronts per cell in the list-build kernel
     double *d_epart = nullptr;
     int n_epart = 0;
     bool built = false;

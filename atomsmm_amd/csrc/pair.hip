@@ -89,8 +89,8 @@ __global__ void k_cell_assign(int n, const double *__restrict__ pos, Box box, Ce
         double x = pos[3 * i + k];
         xref[3 * i + k] = x;
         double w = wrap1(x, box.L[k], box.invL[k]);
-        int ck = (int)(w * g.inv_cw[k]);
-        c[k] = ck >= g.nc[k] ? g.nc[k] - 1 : ck;
+        int ck = (w == w) ? (int)(w * g.inv_cw[k]) : 0;      // NaN-safe: a blown-up trajectory must not index out of range
+        c[k] = ck >= g.nc[k] ? g.nc[k] - 1 : (ck < 0 ? 0 : ck);
     }
     int cell = (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
     cell_of[i] = cell;
@@ -98,7 +98,8 @@ __global__ void k_cell_assign(int n, const double *__restrict__ pos, Box box, Ce
 }
 
 // single block: exclusive scan of count[0..ncell) -> start[0..ncell], fill <- start, count <- 0
-__global__ void k_cell_scan(int ncell, int *count, int *start, int *fill, const int *flags, int force) {
+__global__ void k_cell_scan(int ncell, int *count, int *start, int *fill, const int *flags, int *flags_rw,
+                            unsigned long long *counters, int force) {
     if (!force && !flags[0]) return;
     __shared__ int part[1024];
     __shared__ int carry;
@@ -126,7 +127,9 @@ __global__ void k_cell_scan(int ncell, int *count, int *start, int *fill, const 
         if (t == 1023) carry += part[1023];
         __syncthreads();
     }
-    if (t == 0) start[ncell] = carry;
+    if (t == 0) {
+        start[ncell] = carry;
+    }
 }
 
 __global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, int *perm_tmp, const int *flags, int force) {
@@ -170,100 +173,219 @@ __global__ void k_gather_sorted(int n, const int *__restrict__ perm, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// neighbour-list build: `lpb` lanes per i-atom sweep the candidate cells; ordered (ballot) compaction
-template <bool COUNT_ONLY>
-__global__ void k_build_nlist(int s_begin, int s_end, int lpb_shift, const int *__restrict__ perm,
-                              const int *__restrict__ cell_of, const int *__restrict__ cell_start,
-                              const double *__restrict__ pos, Box box, CellGrid g, double rlist2,
-                              const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
-                              int *nnb, int *flags, unsigned long long *counters, int force) {
+// fp32 copy of the sorted, wrapped positions: the list build only has to find a SUPERSET of the pairs
+// within rlist (the traversal re-tests r^2 < rc^2 in fp64), so it runs on the fp32 pipe with a margin.
+__global__ void k_gather_f32(int n, const int *__restrict__ perm, const double *__restrict__ pos, Box box,
+                             float4 *pos4f_s, int *inv_perm, const int *flags, int force) {
     if (!force && !flags[0]) return;
-    const int lpb = 1 << lpb_shift;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int a = tid >> lpb_shift;
-    const int sub = tid & (lpb - 1);
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    int i = perm[s];
+    float4 p;
+    p.x = (float)wrap1(pos[3 * i], box.L[0], box.invL[0]);
+    p.y = (float)wrap1(pos[3 * i + 1], box.L[1], box.invL[1]);
+    p.z = (float)wrap1(pos[3 * i + 2], box.L[2], box.invL[2]);
+    p.w = 0.f;
+    pos4f_s[s] = p;
+    inv_perm[i] = s;
+}
+
+struct BoxF {
+    float L[3], invL[3];
+};
+
+// neighbour-list build: one wavefront per (cell, part).  All i-atoms of a cell share the same candidate
+// rows (cells are x-fastest, so the 2h+1 x-neighbours of a (y,z) row are one or two contiguous runs of the
+// sorted arrays): the wave loads a chunk of up to 128 candidates ONCE into registers (coalesced float4
+// loads), shifts it by the periodic image of its run, and tests it against up to AMM_BATCH i-atoms whose
+// coordinates sit one-per-lane and are broadcast with v_readlane.  Range bookkeeping is wave-uniform (scalar
+// registers).  Ordered ballot compaction keeps the list order -- and hence the force summation order --
+// deterministic.  Exclusions are looked up (in sorted-slot space, via inv_perm) only for the rare chunks that
+// overlap the slot range [exlo, exhi] spanned by the atom and its excluded partners.
+#define AMM_BCHUNK 128
+#define AMM_BATCH 8
+
+template <bool COUNT_ONLY, bool RINT>
+__global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int parts, const int *__restrict__ perm,
+                              const int *__restrict__ inv_perm, const int *__restrict__ cell_start,
+                              const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2,
+                              const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
+                              int *nnb, int *flags, unsigned long long *blockstats, int force) {
+    if (!force && !flags[0]) return;
     const int lane = threadIdx.x & 63;
-    const int gbase = lane & ~(lpb - 1);              // first lane of my group inside the wavefront
-    const unsigned long long gmask = (lpb == 64 ? ~0ull : ((1ull << lpb) - 1ull)) << gbase;
-    const int s = s_begin + a;
-    const bool valid = s < s_end;
-    int i = 0, ci = 0;
-    double xi = 0, yi = 0, zi = 0;
-    if (valid) {
-        i = perm[s];
-        ci = cell_of[i];
-        xi = wrap1(pos[3 * i], box.L[0], box.invL[0]);
-        yi = wrap1(pos[3 * i + 1], box.L[1], box.invL[1]);
-        zi = wrap1(pos[3 * i + 2], box.L[2], box.invL[2]);
-    }
-    const int cx = ci % g.nc[0], cy = (ci / g.nc[0]) % g.nc[1], cz = ci / (g.nc[0] * g.nc[1]);
-    const int eb = valid ? excl_ptr[i] : 0, ee = valid ? excl_ptr[i + 1] : 0;
-    int count = 0;
-    // wave-uniform trip counts: every lane walks the same stencil; ranges differ per group
-    for (int oz = 0; oz < g.nstencil[2]; ++oz)
-        for (int oy = 0; oy < g.nstencil[1]; ++oy)
-            for (int ox = 0; ox < g.nstencil[0]; ++ox) {
-                // offsets: 3 -> {-1,0,1}; 2 -> {0,1}; 1 -> {0}
-                int dx = g.nstencil[0] == 3 ? ox - 1 : ox, dy = g.nstencil[1] == 3 ? oy - 1 : oy,
-                    dz = g.nstencil[2] == 3 ? oz - 1 : oz;
-                int nx = cx + dx, ny = cy + dy, nz = cz + dz;
-                nx = nx < 0 ? nx + g.nc[0] : (nx >= g.nc[0] ? nx - g.nc[0] : nx);
-                ny = ny < 0 ? ny + g.nc[1] : (ny >= g.nc[1] ? ny - g.nc[1] : ny);
-                nz = nz < 0 ? nz + g.nc[2] : (nz >= g.nc[2] ? nz - g.nc[2] : nz);
-                int c2 = (nz * g.nc[1] + ny) * g.nc[0] + nx;
-                int jb = valid ? cell_start[c2] : 0, je = valid ? cell_start[c2 + 1] : 0;
-                // all lanes of the wavefront must take part in every ballot: iterate to the wave-wide maximum
-                int len = je - jb;
-                int maxlen = len;
-                for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
-                for (int base = 0; base < maxlen; base += lpb) {
-                    int js = jb + base + sub;
-                    bool pass = false;
-                    if (valid && base + sub < len) {
-                        int j = perm[js];
-                        double ddx = amm_min_image(xi - wrap1(pos[3 * j], box.L[0], box.invL[0]), box.L[0], box.invL[0]);
-                        double ddy = amm_min_image(yi - wrap1(pos[3 * j + 1], box.L[1], box.invL[1]), box.L[1], box.invL[1]);
-                        double ddz = amm_min_image(zi - wrap1(pos[3 * j + 2], box.L[2], box.invL[2]), box.L[2], box.invL[2]);
-                        double r2 = ddx * ddx + ddy * ddy + ddz * ddz;
-                        pass = (r2 < rlist2) && (j != i);
-                        if (pass) {
-                            for (int k = eb; k < ee; ++k)
-                                if (excl_idx[k] == j) pass = false;
-                        }
-                    }
-                    unsigned long long bal = __ballot(pass) & gmask;
-                    if (pass) {
-                        int pos_in = count + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (!COUNT_ONLY) {
-                            if (pos_in < cap) nl[(size_t)a * cap + pos_in] = js;
-                        }
-                    }
-                    count += __popcll(bal);
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int c = wave / parts, part = wave - c * parts;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const float FAR = 1.0e9f;
+    unsigned long long wsum = 0;
+    int wmax = 0;
+    if (c < g.ncell) {
+        const int ib = max(__builtin_amdgcn_readfirstlane(cell_start[c]), s_begin);
+        const int ie = min(__builtin_amdgcn_readfirstlane(cell_start[c + 1]), s_end);
+        const int ncx = g.nc[0], ncy = g.nc[1], ncz = g.nc[2];
+        const int cx = c % ncx, cy = (c / ncx) % ncy, cz = c / (ncx * ncy);
+        // x runs: [xa0,xa1] and [xb0,xb1] (second may be empty) with their periodic image (-1, 0, +1)
+        int xa0, xa1, xb0 = 0, xb1 = -1, xsa = 0, xsb = 0;
+        if (ncx < 2 * g.h[0] + 1) {       // stencil would wrap onto itself: visit every cell once (RINT build)
+            xa0 = 0; xa1 = ncx - 1;
+        } else {
+            const int x0 = cx - g.h[0], x1 = cx + g.h[0];
+            if (x0 < 0) { xa0 = x0 + ncx; xa1 = ncx - 1; xb0 = 0; xb1 = x1; xsa = -1; }
+            else if (x1 >= ncx) { xa0 = x0; xa1 = ncx - 1; xb0 = 0; xb1 = x1 - ncx; xsb = 1; }
+            else { xa0 = x0; xa1 = x1; }
+        }
+        for (int tb = ib + part * AMM_BATCH; tb < ie; tb += parts * AMM_BATCH) {
+            const int nt = min(AMM_BATCH, ie - tb);
+            float4 my = make_float4(0.f, 0.f, 0.f, 0.f);
+            int exlo = 0x7fffffff, exhi = -1;             // slot range of {self, excluded partners}
+            if (lane < nt) {
+                my = pos4f_s[tb + lane];
+                const int i = perm[tb + lane];
+                exlo = exhi = tb + lane;
+                for (int k = excl_ptr[i]; k < excl_ptr[i + 1]; ++k) {
+                    const int es = inv_perm[excl_idx[k]];
+                    exlo = min(exlo, es);
+                    exhi = max(exhi, es);
                 }
             }
-    if (valid && sub == 0) {
-        if (!COUNT_ONLY) {
-            nnb[a] = count < cap ? count : cap;
-            if (count > cap) flags[1] = 1;
-            atomicAdd(&counters[1], (unsigned long long)count);
+            int count = 0;                                 // lane t: list length of i-atom tb+t
+            for (int oz = 0; oz < g.nstencil[2]; ++oz) {
+                int nz = ncz < 2 * g.h[2] + 1 ? oz : cz - g.h[2] + oz;
+                const float sz = nz < 0 ? -box.L[2] : (nz >= ncz ? box.L[2] : 0.f);
+                nz = nz < 0 ? nz + ncz : (nz >= ncz ? nz - ncz : nz);
+                for (int oy = 0; oy < g.nstencil[1]; ++oy) {
+                    int ny = ncy < 2 * g.h[1] + 1 ? oy : cy - g.h[1] + oy;
+                    const float sy = ny < 0 ? -box.L[1] : (ny >= ncy ? box.L[1] : 0.f);
+                    ny = ny < 0 ? ny + ncy : (ny >= ncy ? ny - ncy : ny);
+                    const int row = (nz * ncy + ny) * ncx;
+                    for (int seg = 0; seg < 2; ++seg) {
+                        const int c0 = seg == 0 ? xa0 : xb0, c1 = seg == 0 ? xa1 : xb1;
+                        if (c1 < c0) continue;
+                        const float sx = (float)(seg == 0 ? xsa : xsb) * box.L[0];
+                        const int rb = __builtin_amdgcn_readfirstlane(cell_start[row + c0]);
+                        const int re = __builtin_amdgcn_readfirstlane(cell_start[row + c1 + 1]);
+                        for (int jb = rb; jb < re; jb += AMM_BCHUNK) {
+                            const int len = min(AMM_BCHUNK, re - jb);
+                            float4 cand[2];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int idx = u * 64 + lane;
+                                const bool in = idx < len;
+                                float4 q = pos4f_s[jb + (in ? idx : 0)];
+                                if (RINT) {
+                                    q.w = in ? 1.f : 0.f;
+                                } else {                 // image shift; lanes beyond the run are parked far away
+                                    q.x = in ? q.x + sx : FAR;
+                                    q.y = in ? q.y + sy : FAR;
+                                    q.z = in ? q.z + sz : FAR;
+                                }
+                                cand[u] = q;
+                            }
+                            for (int t = 0; t < nt; ++t) {
+                                const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.x), t));
+                                const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.y), t));
+                                const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.z), t));
+                                const int lo = __builtin_amdgcn_readlane(exlo, t), hi = __builtin_amdgcn_readlane(exhi, t);
+                                const bool special = (lo < jb + len) && (hi >= jb);     // wave-uniform, rare
+                                int cnt = __builtin_amdgcn_readlane(count, t);
+                                int *row_out = nl + (size_t)(tb + t - s_begin) * cap;
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    if (u * 64 >= len) continue;                        // wave-uniform
+                                    const int js = jb + u * 64 + lane;
+                                    float dx = px - cand[u].x, dy = py - cand[u].y, dz = pz - cand[u].z;
+                                    if (RINT) {
+                                        dx -= box.L[0] * rintf(dx * box.invL[0]);
+                                        dy -= box.L[1] * rintf(dy * box.invL[1]);
+                                        dz -= box.L[2] * rintf(dz * box.invL[2]);
+                                    }
+                                    const float r2 = dx * dx + dy * dy + dz * dz;
+                                    bool pass = r2 < rlist2;
+                                    if (RINT) pass = pass && (cand[u].w != 0.f);
+                                    if (special && pass) {
+                                        const int st = tb + t;
+                                        if (js == st) pass = false;
+                                        const int i = perm[st];
+                                        for (int k = excl_ptr[i]; k < excl_ptr[i + 1]; ++k)
+                                            if (inv_perm[excl_idx[k]] == js) pass = false;
+                                    }
+                                    const unsigned long long bal = __ballot(pass);
+                                    if (pass && !COUNT_ONLY) {
+                                        const int pos_in = cnt + __popcll(bal & below);
+                                        if (pos_in < cap) row_out[pos_in] = js;
+                                    }
+                                    cnt += __popcll(bal);
+                                }
+                                count = (lane == t) ? cnt : count;
+                            }
+                        }
+                    }
+                }
+            }
+            if (lane < nt) {
+                if (!COUNT_ONLY) {
+                    nnb[tb + lane - s_begin] = count < cap ? count : cap;
+                    if (count > cap) flags[1] = 1;
+                }
+                wsum += (unsigned long long)count;
+                wmax = max(wmax, count);
+            }
         }
-        atomicMax(&flags[2], count);
+    }
+    // per-block (sum, max) of the list lengths -> blockstats; k_finish_build reduces them.  (One same-address
+    // atomic per atom serialises at L2: ~0.5 ms for 98k atoms -- measured -- so no atomics here.)
+    for (int off = 32; off > 0; off >>= 1) {
+        wsum += __shfl_xor(wsum, off);
+        wmax = max(wmax, __shfl_xor(wmax, off));
+    }
+    __shared__ unsigned long long s_sum[4];
+    __shared__ int s_max[4];
+    if (lane == 0) {
+        s_sum[threadIdx.x >> 6] = wsum;
+        s_max[threadIdx.x >> 6] = wmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blockstats[2 * blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        blockstats[2 * blockIdx.x + 1] = (unsigned long long)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
     }
 }
 
-__global__ void k_finish_build(int *flags, unsigned long long *counters, int force) {
+// single block: reduce the per-block list statistics, clear the rebuild request, count the build
+__global__ void k_finish_build(int *flags, unsigned long long *counters, const unsigned long long *blockstats,
+                               int nblocks, int count_only, int force) {
     if (!force && !flags[0]) return;
-    flags[0] = 0;
-    counters[0] += 1;
-}
-__global__ void k_begin_build(int *flags, unsigned long long *counters, int force) {
-    if (!force && !flags[0]) return;
-    flags[2] = 0;
-    counters[1] = 0;
+    __shared__ unsigned long long sh_sum[256];
+    __shared__ unsigned long long sh_max[256];
+    unsigned long long sum = 0, mx = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        sum += blockstats[2 * b];
+        mx = max(mx, blockstats[2 * b + 1]);
+    }
+    sh_sum[threadIdx.x] = sum;
+    sh_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            sh_sum[threadIdx.x] += sh_sum[threadIdx.x + off];
+            sh_max[threadIdx.x] = max(sh_max[threadIdx.x], sh_max[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        flags[2] = (int)sh_max[0];
+        counters[1] = sh_sum[0];
+        if (!count_only) {
+            flags[0] = 0;
+            counters[0] += 1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2/K3: pair traversal.  lpa lanes per i-atom; wavefront-shuffle reduction of the partial forces.
+// K2/K3: pair traversal.  lpa lanes per i-atom stride through the atom's neighbour row, four entries
+// per trip with all loads issued up front (index -> position/charge -> sigma/eps gathers are the latency
+// chain; four independent chains per lane hide it), branch-free arithmetic, wavefront-shuffle reduction.
 struct PairArgs {
     int s_begin, s_end, lpa_shift, cap;
     const int *perm;
@@ -276,6 +398,8 @@ struct PairArgs {
     int accumulate;
     Box box;
 };
+
+#define AMM_UNROLL 4
 
 template <int FAM, int CMODE, bool GUARD, bool EN>
 __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
@@ -292,21 +416,39 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
         const double qi = c.Kc * pi.w;
         const int nn = A.nnb[a];
         const int *row = A.nl + (size_t)a * A.cap;
-        for (int k = sub; k < nn; k += lpa) {
-            const int js = row[k];
-            const double4 pj = A.posq_s[js];
-            const double2 lj = A.lj_s[js];
-            double dx = amm_min_image(pi.x - pj.x, A.box.L[0], A.box.invL[0]);
-            double dy = amm_min_image(pi.y - pj.y, A.box.L[1], A.box.invL[1]);
-            double dz = amm_min_image(pi.z - pj.z, A.box.L[2], A.box.invL[2]);
-            double r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 < c.rc2) {
+        const double guard2 = GUARD ? c.rc0 * c.rc0 : 0.0;
+        for (int k0 = sub; k0 < nn; k0 += AMM_UNROLL * lpa) {
+            int js[AMM_UNROLL];
+            bool ok[AMM_UNROLL];
+#pragma unroll
+            for (int u = 0; u < AMM_UNROLL; ++u) {
+                const int k = k0 + u * lpa;
+                ok[u] = k < nn;
+                js[u] = ok[u] ? row[k] : s;
+            }
+            double4 pj[AMM_UNROLL];
+            double2 lj[AMM_UNROLL];
+#pragma unroll
+            for (int u = 0; u < AMM_UNROLL; ++u) {
+                pj[u] = A.posq_s[js[u]];
+                lj[u] = A.lj_s[js[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < AMM_UNROLL; ++u) {
+                const double dx = amm_min_image(pi.x - pj[u].x, A.box.L[0], A.box.invL[0]);
+                const double dy = amm_min_image(pi.y - pj[u].y, A.box.L[1], A.box.invL[1]);
+                const double dz = amm_min_image(pi.z - pj[u].z, A.box.L[2], A.box.invL[2]);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                bool pass = ok[u] && (r2 < c.rc2);
+                if (GUARD) pass = pass && (r2 <= guard2);          // step(rc0 - r)
+                const double r2s = pass ? r2 : 1.0;
                 double e, fr;
-                amm_pair_math<FAM, CMODE, GUARD, EN>(c, r2, qi * pj.w, li.x + lj.x, li.y * lj.y, e, fr);
+                amm_pair_math<FAM, CMODE, false, EN>(c, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, e, fr);
+                fr = pass ? fr : 0.0;
                 fx += fr * dx;
                 fy += fr * dy;
                 fz += fr * dz;
-                if (EN) esum += e;
+                if (EN) esum += pass ? e : 0.0;
             }
         }
     }
@@ -385,10 +527,13 @@ static int setup_grid(amm_ctx *ctx, PairForce *pf) {
             amm_set_error("pair cutoff exceeds half the box edge (minimum image needs rc <= L/2)");
             return 1;
         }
-        int nc = (int)floor(L / pf->rlist);
+        // cell edge >= rlist/2  ->  neighbours within +-2 cells; fewer than 5 cells: visit every cell once
+        int nc = (int)floor(L / (0.5 * pf->rlist_build));
         if (nc < 1) nc = 1;
+        if (nc > 512) nc = 512;
         g.nc[k] = nc;
-        g.nstencil[k] = nc >= 3 ? 3 : nc;
+        g.h[k] = 2;
+        g.nstencil[k] = nc >= 5 ? 5 : nc;
         g.cw[k] = L / nc;
         g.inv_cw[k] = nc / L;
         g.ncell *= nc;
@@ -400,28 +545,39 @@ static int build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int for
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
-    hipLaunchKernelGGL(k_begin_build, dim3(1), dim3(1), 0, st, pf->d_flags, pf->d_counters, force);
     hipLaunchKernelGGL(k_cell_assign, dim3(nb), dim3(256), 0, st, n, d_pos, ctx->box, pf->grid, pf->d_cell_of,
                        pf->d_cell_count, pf->d_xref, pf->d_flags, force);
     hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, pf->grid.ncell, pf->d_cell_count, pf->d_cell_start,
-                       pf->d_cell_fill, pf->d_flags, force);
+                       pf->d_cell_fill, pf->d_flags, pf->d_flags, pf->d_counters, force);
     hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, st, n, pf->d_cell_of, pf->d_cell_fill, pf->d_perm_tmp,
                        pf->d_flags, force);
     hipLaunchKernelGGL(k_cell_sort, dim3((pf->grid.ncell * 64 + 255) / 256), dim3(256), 0, st, pf->grid.ncell,
                        pf->d_cell_start, pf->d_perm_tmp, pf->d_perm, pf->d_flags, force);
-    const int nslice = pf->s_end - pf->s_begin;
-    const int lpb_shift = ilog2(pf->lpb);
-    const long threads = (long)nslice << lpb_shift;
+    hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, st, n, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s,
+                       pf->d_inv_perm, pf->d_flags, force);
+    const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
-    if (count_only)
-        hipLaunchKernelGGL((k_build_nlist<true>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, lpb_shift, pf->d_perm,
-                           pf->d_cell_of, pf->d_cell_start, d_pos, ctx->box, pf->grid, pf->rlist * pf->rlist,
-                           pf->d_excl_ptr, pf->d_excl_idx, pf->cap, pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, force);
-    else
-        hipLaunchKernelGGL((k_build_nlist<false>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, lpb_shift, pf->d_perm,
-                           pf->d_cell_of, pf->d_cell_start, d_pos, ctx->box, pf->grid, pf->rlist * pf->rlist,
-                           pf->d_excl_ptr, pf->d_excl_idx, pf->cap, pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, force);
-    if (!count_only) hipLaunchKernelGGL(k_finish_build, dim3(1), dim3(1), 0, st, pf->d_flags, pf->d_counters, force);
+    BoxF bf;
+    for (int k = 0; k < 3; ++k) {
+        bf.L[k] = (float)ctx->box.L[k];
+        bf.invL[k] = (float)ctx->box.invL[k];
+    }
+    const float rl2 = (float)(pf->rlist_build * pf->rlist_build);
+    const bool use_rint = pf->grid.nc[0] < 5 || pf->grid.nc[1] < 5 || pf->grid.nc[2] < 5;
+#define AMM_LAUNCH_BUILD(CO, RI)                                                                                       \
+    hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
+                       pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, pf->d_excl_ptr,              \
+                       pf->d_excl_idx, pf->cap, pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_blockstats, force)
+    if (count_only) {
+        if (use_rint) AMM_LAUNCH_BUILD(true, true);
+        else AMM_LAUNCH_BUILD(true, false);
+    } else {
+        if (use_rint) AMM_LAUNCH_BUILD(false, true);
+        else AMM_LAUNCH_BUILD(false, false);
+    }
+#undef AMM_LAUNCH_BUILD
+    hipLaunchKernelGGL(k_finish_build, dim3(1), dim3(256), 0, st, pf->d_flags, pf->d_counters, pf->d_blockstats, (int)grid.x,
+                       count_only ? 1 : 0, force);
     AMM_HIP(hipGetLastError());
     return 0;
 }
@@ -438,7 +594,14 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     int lpa = 1;
     while (lpa < 64 && (long)nslice * lpa < 64L * 1024 * 8) lpa <<= 1;
     pf->lpa = lpa;
-    pf->lpb = 16;
+    {
+        // waves per cell: enough that a cell's atoms are covered by about one batch per wave
+        const double per_cell = (double)n / pf->grid.ncell;
+        pf->parts = std::max(1, std::min(8, (int)std::ceil(per_cell / AMM_BATCH)));
+        const long threads = (long)pf->grid.ncell * pf->parts * 64;
+        const size_t nblk = (size_t)((threads + 255) / 256);
+        AMM_HIP(hipMalloc(&pf->d_blockstats, sizeof(unsigned long long) * 2 * nblk));
+    }
     // pass 1: count only -> capacity
     pf->cap = 0;
     if (build_chain(ctx, pf, d_pos, 1, true)) return 1;
@@ -532,7 +695,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
 int amm_pair_free(PairForce *pf) {
     void *ptrs[] = {pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_excl_ptr, pf->d_excl_idx, pf->d_cell_of, pf->d_cell_count,
                     pf->d_cell_start, pf->d_cell_fill, pf->d_perm_tmp, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
-                    pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart};
+                    pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);
