@@ -23,7 +23,7 @@ NPAR = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 2, BOND_LJC: 3, BOND_NEAR: 3, TORSION_
 
 EXPORTS = [
     'amm_abi_version', 'amm_last_error', 'amm_create', 'amm_destroy', 'amm_set_stream', 'amm_set_slice',
-    'amm_synchronize', 'amm_check', 'amm_pair_create', 'amm_pair_set_params', 'amm_bonded_create',
+    'amm_synchronize', 'amm_check', 'amm_pair_create', 'amm_pair_set_params', 'amm_pair_share_list', 'amm_bonded_create',
     'amm_bonded_add_terms', 'amm_bonded_finalize', 'amm_bonded_set_sliced', 'amm_force_eval', 'amm_kick',
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
@@ -44,7 +44,8 @@ class Op(C.Structure):
 class PairStats(C.Structure):
     _fields_ = [('n_builds', C.c_int64), ('n_evals', C.c_int64), ('n_list_pairs', C.c_int64),
                 ('n_slice_atoms', C.c_int64), ('capacity', C.c_int32), ('max_neighbors', C.c_int32),
-                ('lanes_per_atom', C.c_int32), ('n_cells', C.c_int32), ('rlist', C.c_double)]
+                ('lanes_per_atom', C.c_int32), ('n_cells', C.c_int32), ('rlist', C.c_double),
+                ('shares_list', C.c_int32), ('pad_', C.c_int32)]
 
 
 def pair_desc(family, rc, rc0=0.0, rs0=0.0, rswitch=0.0, alpha=0.0, degree=1, flags=0, sign=1.0, Kc=KC,
@@ -79,6 +80,7 @@ def lib():
         L.amm_check.argtypes = [vp]
         L.amm_pair_create.argtypes = [vp, C.POINTER(PairDesc), dp, dp, dp, ip, C.c_int32, C.c_double, ip]
         L.amm_pair_set_params.argtypes = [vp, C.c_int32, dp, dp, dp]
+        L.amm_pair_share_list.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_bonded_create.argtypes = [vp, ip]
         L.amm_bonded_add_terms.argtypes = [vp, C.c_int32, C.c_int32, ip, dp, C.c_int32, C.c_int32, C.POINTER(PairDesc)]
         L.amm_bonded_finalize.argtypes = [vp, C.c_int32]
@@ -171,6 +173,9 @@ class HipContext:
         fid = C.c_int32(-1)
         _chk(lib().amm_pair_create(self.h, C.byref(desc), qp, sp, ep, exp_, len(ex_), float(skin), C.byref(fid)))
         return fid.value
+
+    def pair_share_list(self, fid, host_fid):
+        _chk(lib().amm_pair_share_list(self.h, fid, host_fid))
 
     def pair_set_params(self, fid, q, sigma, eps):
         q_, qp = _hd(q); s_, sp = _hd(sigma); e_, ep = _hd(eps)

@@ -202,14 +202,61 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     AMM_HIP(hipMalloc(&pf->d_xref, sizeof(double) * 3 * n));
     AMM_HIP(hipMalloc(&pf->d_flags, sizeof(int) * 4));
     AMM_HIP(hipMemset(pf->d_flags, 0, sizeof(int) * 4));
-    AMM_HIP(hipMalloc(&pf->d_counters, sizeof(unsigned long long) * 2));
-    AMM_HIP(hipMemset(pf->d_counters, 0, sizeof(unsigned long long) * 2));
+    AMM_HIP(hipMalloc(&pf->d_counters, sizeof(unsigned long long) * 4));
+    AMM_HIP(hipMemset(pf->d_counters, 0, sizeof(unsigned long long) * 4));
     ForceObj fo;
     fo.type = 1;
     fo.pair = pf;
     ctx->forces.push_back(fo);
     *force_id = (int)ctx->forces.size() - 1;
     return amm_pair_set_params(ctx, *force_id, h_q, h_sigma, h_eps);
+}
+
+int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id) {
+    PairForce *g = get_pair(ctx, force_id), *h = get_pair(ctx, host_id);
+    if (!g || !h) return 1;
+    if (g == h || h->host || g->host || g->rnear_build > 0) {
+        amm_set_error("amm_pair_share_list: invalid host/guest combination");
+        return 1;
+    }
+    if (g->built || h->built) {
+        amm_set_error("amm_pair_share_list must be called before the first force evaluation");
+        return 1;
+    }
+    if (g->rlist_build > h->rlist_build) {
+        amm_set_error("amm_pair_share_list: the guest's list radius exceeds the host's");
+        return 1;
+    }
+    if (h->rnear_build > 0 && h->rnear_build != g->rlist_build) {
+        amm_set_error("amm_pair_share_list: the host already serves a guest with a different list radius");
+        return 1;
+    }
+    // identical exclusion sets are required: compare the CSR arrays
+    const int n = ctx->n;
+    std::vector<int> pa(n + 1), pb(n + 1);
+    AMM_HIP(hipMemcpy(pa.data(), g->d_excl_ptr, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
+    AMM_HIP(hipMemcpy(pb.data(), h->d_excl_ptr, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
+    bool same = pa == pb;
+    if (same && pa[n] > 0) {
+        std::vector<int> ia(pa[n]), ib(pa[n]);
+        AMM_HIP(hipMemcpy(ia.data(), g->d_excl_idx, sizeof(int) * pa[n], hipMemcpyDeviceToHost));
+        AMM_HIP(hipMemcpy(ib.data(), h->d_excl_idx, sizeof(int) * pa[n], hipMemcpyDeviceToHost));
+        for (int i = 0; i < n && same; ++i) {
+            std::sort(ia.begin() + pa[i], ia.begin() + pa[i + 1]);
+            std::sort(ib.begin() + pa[i], ib.begin() + pa[i + 1]);
+        }
+        same = ia == ib;
+    }
+    if (!same) {
+        amm_set_error("amm_pair_share_list: exclusion lists differ");
+        return 1;
+    }
+    // the guest's skin must be consumed no later than the host's: same displacement trigger
+    g->skin = std::min(g->skin, h->skin);
+    h->skin = g->skin;
+    h->rnear_build = g->rlist_build;
+    g->host = h;
+    return 0;
 }
 
 int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const double *h_sigma, const double *h_eps) {
@@ -415,18 +462,20 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     std::memset(out, 0, sizeof(*out));
     AMM_HIP(hipStreamSynchronize(ctx->stream));
     out->n_evals = pf->n_evals;
-    out->capacity = pf->cap;
-    out->lanes_per_atom = pf->lpa;
-    out->n_cells = pf->grid.ncell;
+    PairForce *L = pf->host ? pf->host : pf;
+    out->capacity = L->cap;
+    out->lanes_per_atom = L->lpa;
+    out->n_cells = L->grid.ncell;
     out->rlist = pf->rlist;
-    out->n_slice_atoms = pf->s_end - pf->s_begin;
-    if (pf->built) {
+    out->n_slice_atoms = L->s_end - L->s_begin;
+    out->shares_list = pf->host ? 1 : 0;
+    if (L->built) {
         int flags[4];
-        unsigned long long cnt[2];
-        AMM_HIP(hipMemcpy(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
-        AMM_HIP(hipMemcpy(cnt, pf->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+        unsigned long long cnt[4];
+        AMM_HIP(hipMemcpy(flags, L->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        AMM_HIP(hipMemcpy(cnt, L->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
         out->n_builds = (int64_t)cnt[0];
-        out->n_list_pairs = (int64_t)cnt[1];
+        out->n_list_pairs = (int64_t)(pf->host ? cnt[2] : cnt[1]);   // a guest walks the front parts only
         out->max_neighbors = flags[2];
     }
     return 0;

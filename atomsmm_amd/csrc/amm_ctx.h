@@ -61,9 +61,11 @@ struct PairForce {
     double *d_xref = nullptr;      // positions at the last list build (original order)
     int s_begin = 0, s_end = 0;    // sorted-slot range owned by this rank
     int cap = 0;
-    int *d_nl = nullptr, *d_nnb = nullptr;
+    int *d_nl = nullptr, *d_nnb = nullptr, *d_nnb_near = nullptr;
+    PairForce *host = nullptr;     // owner of the neighbour list this force traverses (nullptr: its own)
+    double rnear_build = 0;        // list radius of the guest force sharing this list (front part of each row)
     int *d_flags = nullptr;        // [0] need_rebuild [1] overflow [2] max_nb [3] scratch
-    unsigned long long *d_counters = nullptr;  // [0] builds [1] list pairs
+    unsigned long long *d_counters = nullptr;  // [0] builds [1] list pairs [2] pairs in the front (near) parts
     unsigned long long *d_blockstats = nullptr; // per build-kernel block: (sum, max) of list lengths
     int lpa = 8;                   // lanes per i-atom in the traversal kernel
     int parts = 1;                 // wavefronts per cell in the list-build kernel

@@ -208,16 +208,16 @@ struct BoxF {
 template <bool COUNT_ONLY, bool RINT>
 __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int parts, const int *__restrict__ perm,
                               const int *__restrict__ inv_perm, const int *__restrict__ cell_start,
-                              const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2,
+                              const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2, float rnear2,
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
-                              int *nnb, int *flags, unsigned long long *blockstats, int force) {
+                              int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats, int force) {
     if (!force && !flags[0]) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int c = wave / parts, part = wave - c * parts;
     const unsigned long long below = (1ull << lane) - 1ull;
     const float FAR = 1.0e9f;
-    unsigned long long wsum = 0;
+    unsigned long long wsum = 0, wnear = 0;
     int wmax = 0;
     if (c < g.ncell) {
         const int ib = max(__builtin_amdgcn_readfirstlane(cell_start[c]), s_begin);
@@ -248,7 +248,9 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                     exhi = max(exhi, es);
                 }
             }
-            int count = 0;                                 // lane t: list length of i-atom tb+t
+            // lane t: list lengths of i-atom tb+t.  Row layout: entries with r < rnear fill the row from the front,
+            // the others from the back, so a shorter-ranged force sharing this list walks only the front part.
+            int count = 0, countf = 0;
             for (int oz = 0; oz < g.nstencil[2]; ++oz) {
                 int nz = ncz < 2 * g.h[2] + 1 ? oz : cz - g.h[2] + oz;
                 const float sz = nz < 0 ? -box.L[2] : (nz >= ncz ? box.L[2] : 0.f);
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                                 const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.z), t));
                                 const int lo = __builtin_amdgcn_readlane(exlo, t), hi = __builtin_amdgcn_readlane(exhi, t);
                                 const bool special = (lo < jb + len) && (hi >= jb);     // wave-uniform, rare
-                                int cnt = __builtin_amdgcn_readlane(count, t);
+                                int cnt = __builtin_amdgcn_readlane(count, t), cntf = __builtin_amdgcn_readlane(countf, t);
                                 int *row_out = nl + (size_t)(tb + t - s_begin) * cap;
 #pragma unroll
                                 for (int u = 0; u < 2; ++u) {
@@ -309,26 +311,34 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                                         for (int k = excl_ptr[i]; k < excl_ptr[i + 1]; ++k)
                                             if (inv_perm[excl_idx[k]] == js) pass = false;
                                     }
-                                    const unsigned long long bal = __ballot(pass);
+                                    const bool nearp = pass && (r2 < rnear2);
+                                    const unsigned long long bal = __ballot(nearp), balf = __ballot(pass && !nearp);
                                     if (pass && !COUNT_ONLY) {
-                                        const int pos_in = cnt + __popcll(bal & below);
-                                        if (pos_in < cap) row_out[pos_in] = js;
+                                        const int pos_in = nearp ? cnt + __popcll(bal & below)
+                                                                 : cap - 1 - (cntf + __popcll(balf & below));
+                                        if (cnt + cntf + __popcll(bal) + __popcll(balf) <= cap) row_out[pos_in] = js;
                                     }
                                     cnt += __popcll(bal);
+                                    cntf += __popcll(balf);
                                 }
                                 count = (lane == t) ? cnt : count;
+                                countf = (lane == t) ? cntf : countf;
                             }
                         }
                     }
                 }
             }
             if (lane < nt) {
+                const int total = count + countf;
                 if (!COUNT_ONLY) {
-                    nnb[tb + lane - s_begin] = count < cap ? count : cap;
-                    if (count > cap) flags[1] = 1;
+                    const bool over = total > cap;      // rows that overflow are flagged; amm_check() raises
+                    nnb[tb + lane - s_begin] = over ? 0 : total;
+                    nnb_near[tb + lane - s_begin] = over ? 0 : count;
+                    if (over) flags[1] = 1;
                 }
-                wsum += (unsigned long long)count;
-                wmax = max(wmax, count);
+                wsum += (unsigned long long)total;
+                wnear += (unsigned long long)count;
+                wmax = max(wmax, total);
             }
         }
     }
@@ -336,18 +346,21 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
     // atomic per atom serialises at L2: ~0.5 ms for 98k atoms -- measured -- so no atomics here.)
     for (int off = 32; off > 0; off >>= 1) {
         wsum += __shfl_xor(wsum, off);
+        wnear += __shfl_xor(wnear, off);
         wmax = max(wmax, __shfl_xor(wmax, off));
     }
-    __shared__ unsigned long long s_sum[4];
+    __shared__ unsigned long long s_sum[4], s_near[4];
     __shared__ int s_max[4];
     if (lane == 0) {
         s_sum[threadIdx.x >> 6] = wsum;
+        s_near[threadIdx.x >> 6] = wnear;
         s_max[threadIdx.x >> 6] = wmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        blockstats[2 * blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-        blockstats[2 * blockIdx.x + 1] = (unsigned long long)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        blockstats[3 * blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        blockstats[3 * blockIdx.x + 1] = (unsigned long long)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        blockstats[3 * blockIdx.x + 2] = s_near[0] + s_near[1] + s_near[2] + s_near[3];
     }
 }
 
@@ -357,17 +370,21 @@ __global__ void k_finish_build(int *flags, unsigned long long *counters, const u
     if (!force && !flags[0]) return;
     __shared__ unsigned long long sh_sum[256];
     __shared__ unsigned long long sh_max[256];
-    unsigned long long sum = 0, mx = 0;
+    __shared__ unsigned long long sh_near[256];
+    unsigned long long sum = 0, mx = 0, nr = 0;
     for (int b = threadIdx.x; b < nblocks; b += 256) {
-        sum += blockstats[2 * b];
-        mx = max(mx, blockstats[2 * b + 1]);
+        sum += blockstats[3 * b];
+        mx = max(mx, blockstats[3 * b + 1]);
+        nr += blockstats[3 * b + 2];
     }
     sh_sum[threadIdx.x] = sum;
     sh_max[threadIdx.x] = mx;
+    sh_near[threadIdx.x] = nr;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if (threadIdx.x < off) {
             sh_sum[threadIdx.x] += sh_sum[threadIdx.x + off];
+            sh_near[threadIdx.x] += sh_near[threadIdx.x + off];
             sh_max[threadIdx.x] = max(sh_max[threadIdx.x], sh_max[threadIdx.x + off]);
         }
         __syncthreads();
@@ -375,6 +392,7 @@ __global__ void k_finish_build(int *flags, unsigned long long *counters, const u
     if (threadIdx.x == 0) {
         flags[2] = (int)sh_max[0];
         counters[1] = sh_sum[0];
+        counters[2] = sh_near[0];
         if (!count_only) {
             flags[0] = 0;
             counters[0] += 1;
@@ -390,7 +408,8 @@ struct PairArgs {
     int s_begin, s_end, lpa_shift, cap;
     const int *perm;
     const int *nl;
-    const int *nnb;
+    const int *nnb;        // entries at the front of the row
+    const int *nnb_total;  // if non-null: total entries; those beyond nnb[a] are stored from the back of the row
     const double4 *posq_s;
     const double2 *lj_s;
     double *force;     // original order [n][3]
@@ -414,8 +433,10 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
         const double4 pi = A.posq_s[s];
         const double2 li = A.lj_s[s];
         const double qi = c.Kc * pi.w;
-        const int nn = A.nnb[a];
+        const int nfront = A.nnb[a];
+        const int nn = A.nnb_total ? A.nnb_total[a] : nfront;
         const int *row = A.nl + (size_t)a * A.cap;
+        const int back = A.cap - 1 + nfront;
         const double guard2 = GUARD ? c.rc0 * c.rc0 : 0.0;
         for (int k0 = sub; k0 < nn; k0 += AMM_UNROLL * lpa) {
             int js[AMM_UNROLL];
@@ -424,7 +445,7 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
             for (int u = 0; u < AMM_UNROLL; ++u) {
                 const int k = k0 + u * lpa;
                 ok[u] = k < nn;
-                js[u] = ok[u] ? row[k] : s;
+                js[u] = ok[u] ? row[k < nfront ? k : back - k] : s;
             }
             double4 pj[AMM_UNROLL];
             double2 lj[AMM_UNROLL];
@@ -563,11 +584,12 @@ static int build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int for
         bf.invL[k] = (float)ctx->box.invL[k];
     }
     const float rl2 = (float)(pf->rlist_build * pf->rlist_build);
+    const float rn2 = pf->rnear_build > 0 ? (float)(pf->rnear_build * pf->rnear_build) : 3.0e38f;
     const bool use_rint = pf->grid.nc[0] < 5 || pf->grid.nc[1] < 5 || pf->grid.nc[2] < 5;
 #define AMM_LAUNCH_BUILD(CO, RI)                                                                                       \
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
-                       pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, pf->d_excl_ptr,              \
-                       pf->d_excl_idx, pf->cap, pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_blockstats, force)
+                       pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
+                       pf->d_excl_idx, pf->cap, pf->d_nl, pf->d_nnb, pf->d_nnb_near, pf->d_flags, pf->d_blockstats, force)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
         else AMM_LAUNCH_BUILD(true, false);
@@ -590,6 +612,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     pf->s_end = std::min(n, pf->s_begin + per);
     const int nslice = pf->s_end - pf->s_begin;
     AMM_HIP(hipMalloc(&pf->d_nnb, sizeof(int) * std::max(nslice, 1)));
+    AMM_HIP(hipMalloc(&pf->d_nnb_near, sizeof(int) * std::max(nslice, 1)));
     // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding
     int lpa = 1;
     while (lpa < 64 && (long)nslice * lpa < 64L * 1024 * 8) lpa <<= 1;
@@ -600,7 +623,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         pf->parts = std::max(1, std::min(8, (int)std::ceil(per_cell / AMM_BATCH)));
         const long threads = (long)pf->grid.ncell * pf->parts * 64;
         const size_t nblk = (size_t)((threads + 255) / 256);
-        AMM_HIP(hipMalloc(&pf->d_blockstats, sizeof(unsigned long long) * 2 * nblk));
+        AMM_HIP(hipMalloc(&pf->d_blockstats, sizeof(unsigned long long) * 3 * nblk));
     }
     // pass 1: count only -> capacity
     pf->cap = 0;
@@ -621,15 +644,21 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
-    if (!pf->built) {
-        if (first_build(ctx, pf, d_pos)) return 1;
+    // the neighbour list may belong to another, longer-ranged pair force (amm_pair_share_list)
+    PairForce *L = pf->host ? pf->host : pf;
+    if (!L->built) {
+        if (first_build(ctx, L, d_pos)) return 1;
     } else {
-        const double thr = 0.5 * pf->skin;
-        hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, pf->d_xref, thr * thr, pf->d_flags);
-        if (build_chain(ctx, pf, d_pos, 0, false)) return 1;
+        const double thr = 0.5 * L->skin;
+        hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, L->d_xref, thr * thr, L->d_flags);
+        if (build_chain(ctx, L, d_pos, 0, false)) return 1;
     }
-    hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, n, pf->d_perm, d_pos, pf->d_q, pf->d_hsig,
+    hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, n, L->d_perm, d_pos, pf->d_q, pf->d_hsig,
                        pf->d_seps2, ctx->box, pf->d_posq_s, pf->d_lj_s);
+    pf->s_begin = L->s_begin;
+    pf->s_end = L->s_end;
+    pf->lpa = L->lpa;
+    pf->cap = L->cap;
     const int nslice = pf->s_end - pf->s_begin;
     if (!accumulate && ctx->world > 1) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, st));
     if (nslice > 0) {
@@ -638,9 +667,10 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         A.s_end = pf->s_end;
         A.lpa_shift = ilog2(pf->lpa);
         A.cap = pf->cap;
-        A.perm = pf->d_perm;
-        A.nl = pf->d_nl;
-        A.nnb = pf->d_nnb;
+        A.perm = L->d_perm;
+        A.nl = L->d_nl;
+        A.nnb = L->d_nnb_near;
+        A.nnb_total = (pf == L && L->rnear_build > 0) ? L->d_nnb : nullptr;
         A.posq_s = pf->d_posq_s;
         A.lj_s = pf->d_lj_s;
         A.force = d_force;
@@ -695,7 +725,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
 int amm_pair_free(PairForce *pf) {
     void *ptrs[] = {pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_excl_ptr, pf->d_excl_idx, pf->d_cell_of, pf->d_cell_count,
                     pf->d_cell_start, pf->d_cell_fill, pf->d_perm_tmp, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
-                    pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm};
+                    pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);

@@ -118,8 +118,10 @@ class Engine:
         self.parameters = {}
         self.entries = []
         self.skin = float(properties.get('Skin', -1.0))
+        self._pair_info = {}
         for force in system.getForces():
             self._translate(force)
+        self._share_lists()
         self._slots = {}
         self._buffers = {}
         self._group_defs = {}
@@ -167,6 +169,31 @@ class Engine:
             raise InputError('force type {} is not supported by the HIP path'.format(force.__class__.__name__))
         self._finish_entry(entry)
         self.entries.append(entry)
+
+    def _pair_create(self, desc, q, sigma, eps, excl):
+        pid = self.ctx.pair_create(desc, q, sigma, eps, excl, skin=self.skin)
+        key = np.sort(np.sort(np.asarray(excl, dtype=np.int64).reshape(-1, 2), axis=1), axis=0).tobytes()
+        self._pair_info[pid] = (float(desc.rc), key)
+        return pid
+
+    def _share_lists(self):
+        """RESPASystem leaves a short-ranged copy (group 1, and its negative in group 31) and the full force over the
+        same particles and exclusions: the shorter-ranged ones traverse the front part of the longest-ranged force's
+        neighbour rows instead of building lists of their own (amm_pair_share_list)."""
+        by_key = {}
+        for pid, (rc, key) in self._pair_info.items():
+            by_key.setdefault(key, []).append((rc, pid))
+        self.shared = {}
+        for members in by_key.values():
+            members.sort(reverse=True)
+            host_rc, host = members[0]
+            for rc, pid in members[1:]:
+                if rc < host_rc:
+                    try:
+                        self.ctx.pair_share_list(pid, host)
+                        self.shared[pid] = host
+                    except B.HipError:
+                        pass          # incompatible radius with an earlier guest: keeps its own list
 
     def _finish_entry(self, entry):
         if entry.terms:
@@ -225,7 +252,7 @@ class Engine:
         desc = B.pair_desc(B.NONBONDED, rc, rswitch=nb._switch if nb._use_switch else 0.0, alpha=alpha, flags=flags,
                            krf=krf, crf=crf)
         eff = self._effective(base, scales, names, self.parameters)
-        pid = self.ctx.pair_create(desc, eff[:, 0], eff[:, 1], eff[:, 2], exc, skin=self.skin)
+        pid = self._pair_create(desc, eff[:, 0], eff[:, 1], eff[:, 2], exc)
         entry.pair_ids.append(pid)
         entry.alpha = alpha
         entry.ewald = ewald
@@ -316,7 +343,7 @@ class Engine:
         scales = np.stack([allp[:, 3 * (k + 1):3 * (k + 2)] for k in range(len(names))]) if names else np.zeros((0, n, 3))
         eff = self._effective(base, scales, names, self.parameters)
         excl = np.array(force._exclusions, dtype=np.int32).reshape(-1, 2)
-        pid = self.ctx.pair_create(desc, eff[:, 0], eff[:, 1], eff[:, 2], excl, skin=self.skin)
+        pid = self._pair_create(desc, eff[:, 0], eff[:, 1], eff[:, 2], excl)
         entry.pair_ids.append(pid)
         if names:
             lam = set(names)

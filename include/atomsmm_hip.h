@@ -109,6 +109,10 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
  * (forces.py:247-258, 292-309: charge+lambda*chargeScale ...). Effective values are passed. */
 int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const double *h_sigma,
                         const double *h_eps);
+/* RESPASystem puts a short-ranged copy (group 1, rcutIn) and the full force (group 2) over the SAME particles and
+ * exclusions (systems.py:71-77): let `force_id` traverse the front part of `host_id`'s neighbour rows instead of
+ * building its own list.  Call before the first evaluation; exclusions must be identical. */
+int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id);
 
 /* CustomBondForce / HarmonicBondForce / HarmonicAngleForce term lists of one force group. */
 int amm_bonded_create(amm_ctx *ctx, int32_t *force_id);
@@ -150,6 +154,8 @@ typedef struct {
     int32_t lanes_per_atom; /* lanes of a wavefront that share one i-atom             */
     int32_t n_cells;
     double rlist;
+    int32_t shares_list;    /* 1 if this force traverses another force's list */
+    int32_t pad_;
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
 /* HIP-event timing of the dominant kernel (pair traversal) on the context stream. */

@@ -25,6 +25,9 @@ class RecordingContext:
                                q=q.copy(), sigma=sigma.copy(), eps=eps.copy(), n_excl=0 if excl_pairs is None else len(excl_pairs)))
         return fid
 
+    def pair_share_list(self, fid, host_fid):
+        self.calls.append(('pair_share_list', fid, host_fid))
+
     def pair_set_params(self, fid, q, sigma, eps):
         self.calls.append(('pair_set_params', fid, q.copy(), sigma.copy(), eps.copy()))
 

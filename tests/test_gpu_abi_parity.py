@@ -257,6 +257,35 @@ def test_atom_decomposition_slices_sum_to_full(spcfw):
     ctx.close()
 
 
+def test_shared_neighbour_list(spcfw):
+    """amm_pair_share_list: the near force (rc 0.7) traverses the front part of the damped force's (rc 1.0) rows;
+    both reproduce the oracle, also after drifting positions force a rebuild of the shared list."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+    ctx = B.HipContext(n, c['box'])
+    far_id = hip_pair(B, ctx, dd, c, skin=0.1)
+    near_id = hip_pair(B, ctx, dn, c, skin=0.1)
+    ctx.pair_share_list(near_id, far_id)
+    with pytest.raises(B.HipError):
+        ctx.pair_share_list(far_id, near_id)
+    rng = np.random.default_rng(5)
+    pos = c['positions'].copy()
+    for step in range(5):
+        for fid, d in ((near_id, dn), (far_id, dd)) if step % 2 == 0 else ((far_id, dd), (near_id, dn)):
+            e_ref, f_ref, _ = O.pair_eval(d, pos, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])
+            e, f = eval_force(ctx, fid, dev(pos), n)
+            assert e == pytest.approx(e_ref, rel=1e-10)
+            assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+        pos = pos + rng.normal(scale=0.015, size=pos.shape)
+    sn, sf = ctx.pair_stats(near_id), ctx.pair_stats(far_id)
+    assert sn['shares_list'] == 1 and sf['shares_list'] == 0
+    assert sn['n_builds'] == sf['n_builds'] > 1 and sn['capacity'] == sf['capacity']
+    ctx.close()
+
+
 def lj_fluid(ncell, seed=20240521):
     """C2-style synthetic LJ fluid: simple-cubic lattice + jitter, rho*sigma^3 = 0.8."""
     rng = np.random.default_rng(seed)

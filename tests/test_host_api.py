@@ -249,6 +249,9 @@ def test_engine_translation(spcfw, recorder):
     assert damped['n_excl'] == 1536 and damped['q'][1] == pytest.approx(-0.84)
     kinds = sorted(t[0] for b in rec.bonded for t in b['terms'])
     assert kinds == [B.BOND_HARMONIC, B.ANGLE_HARMONIC, B.BOND_LJC]
+    # both near copies (groups 1 and 31) traverse the damped force's neighbour list
+    shares = [c for c in rec.calls if c[0] == 'pair_share_list']
+    assert len(shares) == 2 and {c[2] for c in shares} == {damped['id']}
 
 
 def test_engine_unrolls_respa_with_force_caches(spcfw, recorder):
