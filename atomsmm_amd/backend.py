@@ -26,6 +26,7 @@ EXPORTS = [
     'amm_synchronize', 'amm_check', 'amm_pair_create', 'amm_pair_set_params', 'amm_pair_share_list', 'amm_bonded_create',
     'amm_bonded_add_terms', 'amm_bonded_finalize', 'amm_bonded_set_sliced', 'amm_force_eval', 'amm_kick',
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
+    'amm_set_fuse_inner',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
 ]
 
@@ -94,6 +95,7 @@ def lib():
         L.amm_bind_buffer.argtypes = [vp, C.c_int32, vp]
         L.amm_group_define.argtypes = [vp, C.c_int32, C.c_int32, ip, C.c_int32]
         L.amm_run_ops.argtypes = [vp, C.POINTER(Op), C.c_int32, C.c_int32]
+        L.amm_set_fuse_inner.argtypes = [vp, C.c_int32]
         L.amm_pair_get_stats.argtypes = [vp, C.c_int32, C.POINTER(PairStats)]
         L.amm_profile_enable.argtypes = [vp, C.c_int32]
         L.amm_profile_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), dp]
@@ -230,6 +232,9 @@ class HipContext:
     def run_ops(self, ops, repeat=1):
         arr = (Op * len(ops))(*ops)
         _chk(lib().amm_run_ops(self.h, arr, len(ops), int(repeat)))
+
+    def set_fuse_inner(self, on=True):
+        _chk(lib().amm_set_fuse_inner(self.h, int(bool(on))))
 
     def synchronize(self):
         _chk(lib().amm_synchronize(self.h))

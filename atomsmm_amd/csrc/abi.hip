@@ -84,6 +84,9 @@ int amm_destroy(amm_ctx *ctx) {
         }
     }
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->alt_x) (void)hipFree(ctx->alt_x);
+    if (ctx->alt_v) (void)hipFree(ctx->alt_v);
+    if (ctx->alt_f) (void)hipFree(ctx->alt_f);
     delete ctx;
     return 0;
 }
@@ -400,9 +403,46 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
         amm_set_error("amm_run_ops: state not bound (amm_bind_state)");
         return 1;
     }
+    // user-visible buffers; the fused inner iteration ping-pongs between them and library-owned partners
+    double *const user_x = ctx->d_x, *const user_v = ctx->d_v;
+    int f0_slot = -1;
+    double *user_f0 = nullptr;
+    bool swapped = false;
     for (int rep = 0; rep < repeat; ++rep)
         for (int k = 0; k < n_ops; ++k) {
             const amm_op &op = ops[k];
+            // fused inner RESPA iteration: KICK(c1, fg) ; MOVE(d) ; EVAL(g) ; KICK(c2, fg) with g = one bond-list set
+            if (ctx->fuse_inner && op.op == AMM_OP_KICK && op.b < 0 && k + 3 < n_ops && ops[k + 1].op == AMM_OP_MOVE &&
+                ops[k + 2].op == AMM_OP_EVAL && ops[k + 3].op == AMM_OP_KICK && ops[k + 3].b < 0 && ops[k + 3].a == op.a &&
+                ops[k + 2].a >= 0 && ops[k + 2].a < AMM_MAX_GROUPS) {
+                GroupDef &g = ctx->groups[ops[k + 2].a];
+                if (g.slot == op.a && g.forces.size() == 1 && ctx->forces[g.forces[0]].type == 2 &&
+                    !(ctx->forces[g.forces[0]].bonded->sliced && ctx->world > 1) && (f0_slot < 0 || f0_slot == g.slot)) {
+                    BondedSet *bs = ctx->forces[g.forces[0]].bonded;
+                    if (!ctx->alt_x) {
+                        const size_t bytes = sizeof(double) * 3 * (size_t)ctx->n;
+                        AMM_HIP(hipMalloc(&ctx->alt_x, bytes));
+                        AMM_HIP(hipMalloc(&ctx->alt_v, bytes));
+                        AMM_HIP(hipMalloc(&ctx->alt_f, bytes));
+                    }
+                    if (f0_slot < 0) {
+                        f0_slot = g.slot;
+                        user_f0 = ctx->slots[f0_slot];
+                    }
+                    double *xi = ctx->d_x, *vi = ctx->d_v, *fi = ctx->slots[f0_slot];
+                    double *xo = swapped ? user_x : ctx->alt_x, *vo = swapped ? user_v : ctx->alt_v,
+                           *fo = swapped ? user_f0 : ctx->alt_f;
+                    if (amm_fused_inner_impl(ctx, bs, xi, vi, fi, xo, vo, fo, op.coef, ops[k + 1].coef, ops[k + 3].coef)) return 1;
+                    ctx->d_x = xo;
+                    ctx->d_v = vo;
+                    ctx->slots[f0_slot] = fo;
+                    ctx->slots[AMM_SLOT_X] = xo;
+                    ctx->slots[AMM_SLOT_V] = vo;
+                    swapped = !swapped;
+                    k += 3;
+                    continue;
+                }
+            }
             switch (op.op) {
             case AMM_OP_EVAL: {
                 if (op.a < 0 || op.a >= AMM_MAX_GROUPS || ctx->groups[op.a].slot < 0) {
@@ -453,6 +493,19 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
             default: amm_set_error("amm_run_ops: unknown op"); return 1;
             }
         }
+    if (swapped) {   // odd number of fused iterations: bring the state back into the caller's buffers
+        const size_t bytes = sizeof(double) * 3 * (size_t)ctx->n;
+        AMM_HIP(hipMemcpyAsync(user_x, ctx->d_x, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        AMM_HIP(hipMemcpyAsync(user_v, ctx->d_v, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        AMM_HIP(hipMemcpyAsync(user_f0, ctx->slots[f0_slot], bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (f0_slot >= 0) {
+        ctx->d_x = user_x;
+        ctx->d_v = user_v;
+        ctx->slots[f0_slot] = user_f0;
+        ctx->slots[AMM_SLOT_X] = user_x;
+        ctx->slots[AMM_SLOT_V] = user_v;
+    }
     return 0;
 }
 
@@ -478,6 +531,11 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
         out->n_list_pairs = (int64_t)(pf->host ? cnt[2] : cnt[1]);   // a guest walks the front parts only
         out->max_neighbors = flags[2];
     }
+    return 0;
+}
+
+int amm_set_fuse_inner(amm_ctx *ctx, int32_t on) {
+    ctx->fuse_inner = on != 0;
     return 0;
 }
 

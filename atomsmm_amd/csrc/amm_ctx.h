@@ -29,6 +29,7 @@ struct PairConsts {
     double inv_rc0, inv_rc0_2;          // shift / force-switch constants
     double b, f12c, f6c, f1c;           // force-switch (forces.py:559-563)
     double sw_den, inv_sw_dr;           // DAMPED: rc^d - rs^d ; NONBONDED: 1/(rc - rswitch)
+    double inv_sw_den, rswitch_d;       // DAMPED: 1/(rc^d - rs^d), rs^d
 };
 
 struct Box {
@@ -124,6 +125,9 @@ struct amm_ctx {
     GroupDef groups[AMM_MAX_GROUPS];
     bool profile = false;
     double *d_scratch = nullptr;   // small scratch (reductions)
+    // ping-pong partners of x, v and the group-0 force buffer for the fused inner RESPA iteration
+    double *alt_x = nullptr, *alt_v = nullptr, *alt_f = nullptr;
+    bool fuse_inner = true;
 };
 
 // implemented in pair.hip / cells.hip / bonded.hip / integrate.hip
@@ -135,6 +139,8 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
                          double *d_energy);
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
 int amm_bonded_free(BondedSet *bs);
+int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const double *v_in, const double *f_in,
+                         double *x_out, double *v_out, double *f_out, double c1, double d, double c2);
 int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef);
 int amm_combine_impl(amm_ctx *ctx, double *d_dst, const double *d_a, const double *d_b, double coef);
 int amm_move_impl(amm_ctx *ctx, double *d_x, const double *d_v, double coef);

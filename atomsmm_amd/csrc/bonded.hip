@@ -30,10 +30,33 @@ struct BondedArgs {
     double Kc_ljc;
 };
 
-__device__ __forceinline__ void delta3(const double *pos, int a, int b, const Box &box, int periodic, double *d) {
+// position accessors: plain array, or "state advanced by kick+move" (fused inner RESPA iteration)
+struct PosPlain {
+    const double *pos;
+    __device__ __forceinline__ double get(int a, int k) const { return pos[3 * a + k]; }
+};
+struct PosAdvanced {
+    // x_new = x + d*(v + (c1*f)/m): exactly the arithmetic (and rounding sequence) of k_kick followed by k_move
+    const double *x, *v, *f, *m;
+    double c1, d;
+    __device__ __forceinline__ double vel(int a, int k) const {
+#pragma clang fp contract(off)
+        const double num = c1 * f[3 * a + k];
+        const double dv = num / m[a];
+        return v[3 * a + k] + dv;
+    }
+    __device__ __forceinline__ double get(int a, int k) const {
+#pragma clang fp contract(off)
+        const double dx = d * vel(a, k);
+        return x[3 * a + k] + dx;
+    }
+};
+
+template <class P>
+__device__ __forceinline__ void delta3(const P &pos, int a, int b, const Box &box, int periodic, double *d) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        double v = pos[3 * a + k] - pos[3 * b + k];
+        double v = pos.get(a, k) - pos.get(b, k);
         if (periodic) v = amm_min_image(v, box.L[k], box.invL[k]);
         d[k] = v;
     }
@@ -45,110 +68,117 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// force on atom i (and, for role-0 references, the energy) of every bond-list term that contains it
+template <class P>
+__device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, int i, double *f, double &esum) {
+    const int rb = A.ref_ptr[i], re = A.ref_ptr[i + 1];
+    for (int r = rb; r < re; ++r) {
+        const uint32_t ref = A.ref[r];
+        const int kind = ref >> 28, role = (ref >> 26) & 3, t = ref & 0x3ffffff;
+        switch (kind) {
+        case AMM_BOND_HARMONIC: {
+            const int32_t *ix = A.idx[kind] + 2 * t;
+            const double *p = A.par[kind] + 2 * t;
+            const int other = ix[1 - role];
+            double d[3];
+            delta3(pos, i, other, A.box, A.periodic[kind], d);
+            const double rr = sqrt(dot3(d, d));
+            const double dr = rr - p[0];
+            const double fr = -p[1] * dr / rr;
+            f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
+            if (role == 0) esum += 0.5 * p[1] * dr * dr;
+        } break;
+        case AMM_ANGLE_HARMONIC: {
+            const int32_t *ix = A.idx[kind] + 3 * t;
+            const double *p = A.par[kind] + 2 * t;
+            double d1[3], d2[3];
+            delta3(pos, ix[0], ix[1], A.box, A.periodic[kind], d1);
+            delta3(pos, ix[2], ix[1], A.box, A.periodic[kind], d2);
+            const double r1 = sqrt(dot3(d1, d1)), r2 = sqrt(dot3(d2, d2));
+            double c = dot3(d1, d2) / (r1 * r2);
+            c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+            const double th = acos(c), dth = th - p[0];
+            double sn = sqrt(1.0 - c * c);
+            if (sn < 1e-12) sn = 1e-12;
+            const double g = p[1] * dth / sn;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const double fi = g * (d2[x] / r2 - c * d1[x] / r1) / r1;
+                const double fk = g * (d1[x] / r1 - c * d2[x] / r2) / r2;
+                f[x] += role == 0 ? fi : (role == 2 ? fk : -(fi + fk));
+            }
+            if (role == 0) esum += 0.5 * p[1] * dth * dth;
+        } break;
+        case AMM_BOND_LJC:
+        case AMM_BOND_NEAR: {
+            const int32_t *ix = A.idx[kind] + 2 * t;
+            const double *p = A.par[kind] + 3 * t;
+            const int other = ix[1 - role];
+            double d[3];
+            delta3(pos, i, other, A.box, A.periodic[kind], d);
+            const double r2 = dot3(d, d);
+            double e, fr;
+            if (kind == AMM_BOND_LJC) {   // forces.py:406
+                const double rinv2 = 1.0 / r2, rinv = sqrt(rinv2);
+                const double s2 = p[1] * p[1] * rinv2, x6 = s2 * s2 * s2;
+                e = 4.0 * p[2] * x6 * (x6 - 1.0) + A.Kc_ljc * p[0] * rinv;
+                fr = (4.0 * p[2] * (12.0 * x6 * x6 - 6.0 * x6) + A.Kc_ljc * p[0] * rinv) * rinv2;
+            } else {
+                amm_pair_math_rt(A.near_pc, r2, A.near_pc.Kc * p[0], p[1], 4.0 * p[2], e, fr);
+            }
+            f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
+            if (role == 0) esum += e;
+        } break;
+        case AMM_BOND_EWALD_EXCL: {
+            const int32_t *ix = A.idx[kind] + 2 * t;
+            const double qq = A.par[kind][t];
+            const int other = ix[1 - role];
+            double d[3];
+            delta3(pos, i, other, A.box, 1, d);
+            const double r2 = dot3(d, d), rr = sqrt(r2), ar = A.ewald_alpha * rr;
+            const double er = erf(ar);
+            // E = -qq erf(ar)/r ;  -dE/dr = qq [ tasp exp(-a^2 r^2)/r - erf(ar)/r^2 ]
+            const double fr = qq * (A.ewald_tasp * exp(-ar * ar) / rr - er / r2) / rr;
+            f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
+            if (role == 0) esum += -qq * er / rr;
+        } break;
+        case AMM_TORSION_PERIODIC: {
+            const int32_t *ix = A.idx[kind] + 4 * t;
+            const double *p = A.par[kind] + 3 * t;
+            double F[3], G[3], H[3], Av[3], Bv[3], BA[3];
+            delta3(pos, ix[0], ix[1], A.box, A.periodic[kind], F);
+            delta3(pos, ix[1], ix[2], A.box, A.periodic[kind], G);
+            delta3(pos, ix[3], ix[2], A.box, A.periodic[kind], H);
+            cross3(F, G, Av);
+            cross3(H, G, Bv);
+            cross3(Bv, Av, BA);
+            const double Gn = sqrt(dot3(G, G));
+            const double phi = atan2(dot3(BA, G) / Gn, dot3(Av, Bv));
+            const double nper = p[0];
+            const double dEdphi = -p[2] * nper * sin(nper * phi - p[1]);
+            const double A2 = dot3(Av, Av), B2 = dot3(Bv, Bv), FG = dot3(F, G), HG = dot3(H, G);
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const double gi = -Gn / A2 * Av[x], gl = Gn / B2 * Bv[x];
+                const double gj = Gn / A2 * Av[x] + FG / (A2 * Gn) * Av[x] - HG / (B2 * Gn) * Bv[x];
+                const double gk = -Gn / B2 * Bv[x] - FG / (A2 * Gn) * Av[x] + HG / (B2 * Gn) * Bv[x];
+                const double g = role == 0 ? gi : (role == 1 ? gj : (role == 2 ? gk : gl));
+                f[x] -= dEdphi * g;
+            }
+            if (role == 0) esum += p[2] * (1.0 + cos(nper * phi - p[1]));
+        } break;
+        default: break;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_bonded(BondedArgs A) {
     const int i = A.row_begin + blockIdx.x * blockDim.x + threadIdx.x;
     double f[3] = {0.0, 0.0, 0.0};
     double esum = 0.0;
     if (i < A.row_end) {
-        const int rb = A.ref_ptr[i], re = A.ref_ptr[i + 1];
-        for (int r = rb; r < re; ++r) {
-            const uint32_t ref = A.ref[r];
-            const int kind = ref >> 28, role = (ref >> 26) & 3, t = ref & 0x3ffffff;
-            switch (kind) {
-            case AMM_BOND_HARMONIC: {
-                const int32_t *ix = A.idx[kind] + 2 * t;
-                const double *p = A.par[kind] + 2 * t;
-                const int other = ix[1 - role];
-                double d[3];
-                delta3(A.pos, i, other, A.box, A.periodic[kind], d);
-                const double rr = sqrt(dot3(d, d));
-                const double dr = rr - p[0];
-                const double fr = -p[1] * dr / rr;
-                f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
-                if (role == 0) esum += 0.5 * p[1] * dr * dr;
-            } break;
-            case AMM_ANGLE_HARMONIC: {
-                const int32_t *ix = A.idx[kind] + 3 * t;
-                const double *p = A.par[kind] + 2 * t;
-                double d1[3], d2[3];
-                delta3(A.pos, ix[0], ix[1], A.box, A.periodic[kind], d1);
-                delta3(A.pos, ix[2], ix[1], A.box, A.periodic[kind], d2);
-                const double r1 = sqrt(dot3(d1, d1)), r2 = sqrt(dot3(d2, d2));
-                double c = dot3(d1, d2) / (r1 * r2);
-                c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
-                const double th = acos(c), dth = th - p[0];
-                double s = sqrt(1.0 - c * c);
-                if (s < 1e-12) s = 1e-12;
-                const double g = p[1] * dth / s;
-#pragma unroll
-                for (int x = 0; x < 3; ++x) {
-                    const double fi = g * (d2[x] / r2 - c * d1[x] / r1) / r1;
-                    const double fk = g * (d1[x] / r1 - c * d2[x] / r2) / r2;
-                    f[x] += role == 0 ? fi : (role == 2 ? fk : -(fi + fk));
-                }
-                if (role == 0) esum += 0.5 * p[1] * dth * dth;
-            } break;
-            case AMM_BOND_LJC:
-            case AMM_BOND_NEAR: {
-                const int32_t *ix = A.idx[kind] + 2 * t;
-                const double *p = A.par[kind] + 3 * t;
-                const int other = ix[1 - role];
-                double d[3];
-                delta3(A.pos, i, other, A.box, A.periodic[kind], d);
-                const double r2 = dot3(d, d);
-                double e, fr;
-                if (kind == AMM_BOND_LJC) {   // forces.py:406
-                    const double rinv2 = 1.0 / r2, rinv = sqrt(rinv2);
-                    const double s2 = p[1] * p[1] * rinv2, x6 = s2 * s2 * s2;
-                    e = 4.0 * p[2] * x6 * (x6 - 1.0) + A.Kc_ljc * p[0] * rinv;
-                    fr = (4.0 * p[2] * (12.0 * x6 * x6 - 6.0 * x6) + A.Kc_ljc * p[0] * rinv) * rinv2;
-                } else {
-                    amm_pair_math_rt(A.near_pc, r2, A.near_pc.Kc * p[0], p[1], 4.0 * p[2], e, fr);
-                }
-                f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
-                if (role == 0) esum += e;
-            } break;
-            case AMM_BOND_EWALD_EXCL: {
-                const int32_t *ix = A.idx[kind] + 2 * t;
-                const double qq = A.par[kind][t];
-                const int other = ix[1 - role];
-                double d[3];
-                delta3(A.pos, i, other, A.box, 1, d);
-                const double r2 = dot3(d, d), rr = sqrt(r2), ar = A.ewald_alpha * rr;
-                const double er = erf(ar);
-                // E = -qq erf(ar)/r ;  -dE/dr = qq [ tasp exp(-a^2 r^2)/r - erf(ar)/r^2 ]
-                const double fr = qq * (A.ewald_tasp * exp(-ar * ar) / rr - er / r2) / rr;
-                f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
-                if (role == 0) esum += -qq * er / rr;
-            } break;
-            case AMM_TORSION_PERIODIC: {
-                const int32_t *ix = A.idx[kind] + 4 * t;
-                const double *p = A.par[kind] + 3 * t;
-                double F[3], G[3], H[3], Av[3], Bv[3], BA[3];
-                delta3(A.pos, ix[0], ix[1], A.box, A.periodic[kind], F);
-                delta3(A.pos, ix[1], ix[2], A.box, A.periodic[kind], G);
-                delta3(A.pos, ix[3], ix[2], A.box, A.periodic[kind], H);
-                cross3(F, G, Av);
-                cross3(H, G, Bv);
-                cross3(Bv, Av, BA);
-                const double Gn = sqrt(dot3(G, G));
-                const double phi = atan2(dot3(BA, G) / Gn, dot3(Av, Bv));
-                const double nper = p[0];
-                const double dEdphi = -p[2] * nper * sin(nper * phi - p[1]);
-                const double A2 = dot3(Av, Av), B2 = dot3(Bv, Bv), FG = dot3(F, G), HG = dot3(H, G);
-#pragma unroll
-                for (int x = 0; x < 3; ++x) {
-                    const double gi = -Gn / A2 * Av[x], gl = Gn / B2 * Bv[x];
-                    const double gj = Gn / A2 * Av[x] + FG / (A2 * Gn) * Av[x] - HG / (B2 * Gn) * Bv[x];
-                    const double gk = -Gn / B2 * Bv[x] - FG / (A2 * Gn) * Av[x] + HG / (B2 * Gn) * Bv[x];
-                    const double g = role == 0 ? gi : (role == 1 ? gj : (role == 2 ? gk : gl));
-                    f[x] -= dEdphi * g;
-                }
-                if (role == 0) esum += p[2] * (1.0 + cos(nper * phi - p[1]));
-            } break;
-            default: break;
-            }
-        }
+        PosPlain pos{A.pos};
+        bonded_atom(A, pos, i, f, esum);
         if (A.accumulate) {
             A.force[3 * i] += f[0]; A.force[3 * i + 1] += f[1]; A.force[3 * i + 2] += f[2];
         } else {
@@ -161,6 +191,39 @@ __global__ void __launch_bounds__(256) k_bonded(BondedArgs A) {
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = esum;
         __syncthreads();
         if (threadIdx.x == 0) A.epart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+// Fused inner RESPA iteration (propagators.py:940-973, innermost level):
+//     v <- v + c1*f0/m ;  x <- x + d*v ;  f0 <- bonded(x) ;  v <- v + c2*f0/m
+// in ONE launch.  Each thread advances its own atom and, redundantly, the few atoms it shares bond-list terms
+// with (same arithmetic, same rounding, so every thread sees identical new positions); inputs and outputs are
+// separate buffers (ping-pong), so no grid-wide synchronisation is needed between the move and the force.
+struct FusedArgs {
+    const double *x_in, *v_in, *f_in, *mass;
+    double *x_out, *v_out, *f_out;
+    double c1, d, c2;
+};
+
+__global__ void __launch_bounds__(256) k_fused_inner(BondedArgs A, FusedArgs F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    PosAdvanced pos{F.x_in, F.v_in, F.f_in, F.mass, F.c1, F.d};
+    double f[3] = {0.0, 0.0, 0.0};
+    double esum = 0.0;
+    bonded_atom(A, pos, i, f, esum);
+    {
+#pragma clang fp contract(off)
+        const double mi = F.mass[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v1 = pos.vel(i, k);
+            F.x_out[3 * i + k] = pos.get(i, k);
+            const double num = F.c2 * f[k];
+            const double dv = num / mi;
+            F.v_out[3 * i + k] = v1 + dv;
+            F.f_out[3 * i + k] = f[k];
+        }
     }
 }
 
@@ -252,6 +315,36 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
     hipLaunchKernelGGL(k_bonded, dim3(nblk), dim3(256), 0, ctx->stream, A);
     AMM_HIP(hipGetLastError());
     if (d_energy) return amm_reduce_add(ctx, bs->d_epart, nblk, 1.0, d_energy);
+    return 0;
+}
+
+int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const double *v_in, const double *f_in,
+                         double *x_out, double *v_out, double *f_out, double c1, double d, double c2) {
+    const int n = ctx->n;
+    BondedArgs A;
+    A.n = n;
+    A.row_begin = 0;
+    A.row_end = n;
+    A.ref_ptr = bs->d_ref_ptr;
+    A.ref = bs->d_ref;
+    for (int k = 0; k < 6; ++k) {
+        A.idx[k] = bs->d_idx[k];
+        A.par[k] = bs->d_par[k];
+        A.periodic[k] = bs->periodic[k];
+    }
+    A.pos = nullptr;
+    A.force = nullptr;
+    A.epart = nullptr;
+    A.accumulate = 0;
+    A.want_energy = 0;
+    A.box = ctx->box;
+    A.near_pc = bs->near_pc;
+    A.ewald_alpha = bs->ewald_alpha;
+    A.ewald_tasp = bs->ewald_alpha * 1.1283791670955125739;
+    A.Kc_ljc = bs->ljc_Kc;
+    FusedArgs F{x_in, v_in, f_in, ctx->d_mass, x_out, v_out, f_out, c1, d, c2};
+    hipLaunchKernelGGL(k_fused_inner, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, F);
+    AMM_HIP(hipGetLastError());
     return 0;
 }
 

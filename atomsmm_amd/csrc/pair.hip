@@ -56,6 +56,8 @@ int amm_pair_build_consts(const amm_pair_desc &d, PairConsts &pc) {
     pc.sw_den = 1.0;
     pc.inv_sw_dr = 0.0;
     if (d.family == AMM_DAMPED) pc.sw_den = pow(d.rc, pc.degree) - pow(d.rswitch, pc.degree);
+    pc.inv_sw_den = 1.0 / pc.sw_den;
+    pc.rswitch_d = pow(d.rswitch, pc.degree);
     if (d.family == AMM_NONBONDED && (d.flags & AMM_SWITCH)) pc.inv_sw_dr = 1.0 / (d.rc - d.rswitch);
     return 0;
 }
@@ -420,6 +422,9 @@ struct PairArgs {
 
 #define AMM_UNROLL 4
 
+__device__ double amm_erfcx_table_dev[AMM_ERFCX_NI * AMM_ERFCX_NC];
+static bool g_erfcx_uploaded = false;
+
 template <int FAM, int CMODE, bool GUARD, bool EN>
 __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
     const int lpa = 1 << A.lpa_shift;
@@ -428,6 +433,12 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
     const int sub = tid & (lpa - 1);
     const int s = A.s_begin + a;
     const bool valid = s < A.s_end;
+    constexpr bool NEEDS_ERFC = (FAM == AMM_DAMPED) || (FAM == AMM_NONBONDED && CMODE == 1);
+    __shared__ double s_tab[NEEDS_ERFC ? AMM_ERFCX_NI * AMM_ERFCX_NC : 1];
+    if (NEEDS_ERFC) {
+        for (int k = threadIdx.x; k < AMM_ERFCX_NI * AMM_ERFCX_NC; k += blockDim.x) s_tab[k] = amm_erfcx_table_dev[k];
+        __syncthreads();
+    }
     double fx = 0.0, fy = 0.0, fz = 0.0, esum = 0.0;
     if (valid) {
         const double4 pi = A.posq_s[s];
@@ -464,7 +475,7 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
                 if (GUARD) pass = pass && (r2 <= guard2);          // step(rc0 - r)
                 const double r2s = pass ? r2 : 1.0;
                 double e, fr;
-                amm_pair_math<FAM, CMODE, false, EN>(c, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, e, fr);
+                amm_pair_math<FAM, CMODE, false, EN>(c, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, e, fr, s_tab);
                 fr = pass ? fr : 0.0;
                 fx += fr * dx;
                 fy += fr * dy;
@@ -644,6 +655,10 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
+    if (!g_erfcx_uploaded) {
+        AMM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(amm_erfcx_table_dev), amm_erfcx_table_host, sizeof(amm_erfcx_table_host)));
+        g_erfcx_uploaded = true;
+    }
     // the neighbour list may belong to another, longer-ranged pair force (amm_pair_share_list)
     PairForce *L = pf->host ? pf->host : pf;
     if (!L->built) {

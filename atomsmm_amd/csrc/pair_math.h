@@ -10,6 +10,7 @@
 //   NONBONDED     forces.py:134-190   S_b*LJ + Coulomb {plain | erfc | reaction field}
 #pragma once
 #include "amm_ctx.h"
+#include "erfcx_table.h"
 
 __device__ __forceinline__ double amm_sw_S(double u) { return 1.0 + u * u * u * (15.0 * u - 6.0 * u * u - 10.0); }
 __device__ __forceinline__ double amm_sw_dS(double u) {
@@ -33,9 +34,44 @@ __device__ __forceinline__ double amm_rsqrt(double x) {
     return fma(0.5 * y, e, y);
 }
 
+// exp(-y) for y >= 0: n = rint(-y log2 e), two-part ln2 reduction, degree-12 Taylor polynomial, ldexp.
+__device__ __forceinline__ double amm_exp_neg(double y) {
+    const double n = rint(-y * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, -y);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// erfc(x) and exp(-x^2) for x >= 0, branch-free: erfc = exp(-x^2) * erfcx(x), erfcx from the piecewise
+// degree-11 polynomials of erfcx_table.h staged in LDS (`tab`), max relative error ~2e-15.
+__device__ __forceinline__ void amm_erfc_exp(double x, const double *tab, double &ec, double &ex) {
+    int k = (int)(x * AMM_ERFCX_INVH);
+    k = k > AMM_ERFCX_NI - 1 ? AMM_ERFCX_NI - 1 : k;
+    const double t = x - ((double)k + 0.5) * AMM_ERFCX_H;
+    const double *cf = tab + k * AMM_ERFCX_NC;
+    double p = cf[AMM_ERFCX_NC - 1];
+#pragma unroll
+    for (int m = AMM_ERFCX_NC - 2; m >= 0; --m) p = fma(p, t, cf[m]);
+    ex = amm_exp_neg(x * x);
+    ec = ex * p;
+}
+
 template <int FAM, int CMODE, bool GUARD, bool EN>
 __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, double qq, double sig, double eps4,
-                                              double &e, double &fr) {
+                                              double &e, double &fr, const double *tab = nullptr) {
     const double rinv = amm_rsqrt(r2);
     const double r = r2 * rinv;
     const double rinv2 = rinv * rinv;
@@ -88,18 +124,17 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
         }
     } else if (FAM == AMM_DAMPED) {
         const double ar = c.alpha * r;
-        const double ec = erfc(ar);
-        const double ex = exp(-ar * ar);
+        double ec, ex;
+        amm_erfc_exp(ar, tab, ec, ex);
         const double V = eps4 * (s12 - s6) + ec * coul;
         const double mdV_r = dlj_r + ec * dcoul_r + coul * c.two_alpha_over_sqrtpi * ex * rinv;
-        double S = 1.0, dSdr = 0.0;
-        if (r - c.rswitch >= 0.0) {
-            const int d = c.degree;
-            const double rd1 = amm_powi(r, d - 1);
-            const double u = (rd1 * r - amm_powi(c.rswitch, d)) / c.sw_den;
-            S = amm_sw_S(u);
-            dSdr = amm_sw_dS(u) * d * rd1 / c.sw_den;
-        }
+        // u = 0 below rswitch gives S = 1, dS = 0: no branch needed (step(r - rswitch), forces.py:454)
+        const int d = c.degree;
+        const double rd1 = amm_powi(r, d - 1);
+        const double du = rd1 * r - c.rswitch_d;
+        const double u = du >= 0.0 ? du * c.inv_sw_den : 0.0;
+        const double S = amm_sw_S(u);
+        const double dSdr = amm_sw_dS(u) * d * rd1 * c.inv_sw_den;
         fr = S * mdV_r - dSdr * V * rinv;
         if (EN) e = S * V;
     } else {   // AMM_NONBONDED
@@ -114,8 +149,8 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
         if (EN) e = S * lj;
         if (CMODE == 1) {
             const double ar = c.alpha * r;
-            const double ec = erfc(ar);
-            const double ex = exp(-ar * ar);
+            double ec, ex;
+            amm_erfc_exp(ar, tab, ec, ex);
             fr += ec * dcoul_r + coul * c.two_alpha_over_sqrtpi * ex * rinv;
             if (EN) e += ec * coul;
         } else if (CMODE == 2) {

@@ -142,6 +142,8 @@ int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass)
 int amm_bind_buffer(amm_ctx *ctx, int32_t slot, double *d_buf);              /* per-DOF buffers f0.., _f2_, fm1 */
 int amm_group_define(amm_ctx *ctx, int32_t group, int32_t slot, const int32_t *force_ids, int32_t n_forces);
 int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat);
+/* amm_run_ops fuses KICK;MOVE;EVAL(bond-list group);KICK into one launch (bit-identical results); 0 disables. */
+int amm_set_fuse_inner(amm_ctx *ctx, int32_t on);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 typedef struct {

@@ -316,6 +316,42 @@ def test_lj_fluid_vs_oracle_cells(adj):
     ctx.close()
 
 
+def test_fused_inner_iteration_is_bit_identical(spcfw):
+    """amm_run_ops fuses KICK;MOVE;EVAL(bond lists);KICK into one launch: same bits as the four separate launches,
+    for an even and an odd number of fused iterations (the odd case copies the ping-pong state back)."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    rng = np.random.default_rng(2)
+    v0 = rng.normal(size=(n, 3)) * np.sqrt(2.494 / c['mass'])[:, None]
+    results = []
+    for fuse in (True, False):
+        for niter in (4, 3):
+            ctx = B.HipContext(n, c['box'])
+            ctx.set_fuse_inner(fuse)
+            bid = ctx.bonded_create()
+            ctx.bonded_add_terms(bid, B.BOND_HARMONIC, c['bonds'], np.stack([c['bond_r0'], c['bond_k']], 1))
+            ctx.bonded_add_terms(bid, B.ANGLE_HARMONIC, c['angles'], np.stack([c['angle_theta0'], c['angle_k']], 1))
+            ctx.bonded_finalize(bid)
+            x, v, m = dev(c['positions']), dev(v0), dev(c['mass'])
+            f0 = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+            ctx.bind_state(x, v, m)
+            ctx.bind_buffer(0, f0)
+            ctx.group_define(0, 0, [bid])
+            ops = [B.Op(B.OP_EVAL, 0, 0, 0, 0.0)]
+            for _ in range(niter):
+                ops += [B.Op(B.OP_KICK, 0, -1, 0, 0.25e-3), B.Op(B.OP_MOVE, 0, 0, 0, 0.5e-3), B.Op(B.OP_EVAL, 0, 0, 0, 0.0),
+                        B.Op(B.OP_KICK, 0, -1, 0, 0.25e-3)]
+            ctx.run_ops(ops, repeat=3)
+            ctx.check()
+            results.append((fuse, niter, x.cpu().numpy(), v.cpu().numpy(), f0.cpu().numpy()))
+            ctx.close()
+    for niter in (4, 3):
+        a = [r for r in results if r[0] and r[1] == niter][0]
+        b = [r for r in results if not r[0] and r[1] == niter][0]
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
 def test_respa_ops_vs_oracle_trajectory(spcfw, goldens):
     """RespaPropagator([4,2,1]) op list on flexible q-SPC-FW for 2 outer steps:
     groups 0 = bonds+angles, 1 = near force-switch(0.7,0.5), 2 = DampedSmoothed(2.9,1.0,0.9); the GPU
