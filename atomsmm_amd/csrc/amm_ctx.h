@@ -91,12 +91,11 @@ struct BondedSet {
     double ljc_Kc = 138.935456;
     bool sliced = false;           // world > 1: compute only this rank's rows (group is all-reduced by the host)
     bool finalized = false;
-    // device: term arrays per kind, CSR per atom of (kind, term, role)
-    int32_t *d_idx[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    double *d_par[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // device: CSR per atom of packed (atom, term) records
     int n_terms[6] = {0, 0, 0, 0, 0, 0};
     int *d_ref_ptr = nullptr;      // [n+1]
-    uint32_t *d_ref = nullptr;     // kind<<28 | role<<26 | term
+    int4 *d_rec_a = nullptr;       // atoms of the term
+    double4 *d_rec_q = nullptr;    // parameters + kind/role/periodic code
     double *d_epart = nullptr;
     int n_epart = 0;
 };

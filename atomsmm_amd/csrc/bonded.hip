@@ -9,6 +9,7 @@
 // lock-step).  In RESPA this kernel runs n0*n1*n2 times per outer step: it is latency-, not flop-bound.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "amm_ctx.h"
 #include "pair_math.h"
@@ -16,10 +17,10 @@
 struct BondedArgs {
     int n, row_begin, row_end;
     const int *ref_ptr;
-    const uint32_t *ref;
-    const int32_t *idx[6];
-    const double *par[6];
-    int periodic[6];
+    // one packed record per (atom, term) reference: the term's atoms and parameters inline, so a thread needs
+    // only two dependent load levels (ref_ptr -> records -> positions) instead of four
+    const int4 *rec_a;      // atom indices of the term (-1 padded)
+    const double4 *rec_q;   // p0, p1, p2, and kind | role<<3 | periodic<<5 in the bits of .w
     const double *pos;
     double *force;
     double *epart;
@@ -73,15 +74,17 @@ template <class P>
 __device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, int i, double *f, double &esum) {
     const int rb = A.ref_ptr[i], re = A.ref_ptr[i + 1];
     for (int r = rb; r < re; ++r) {
-        const uint32_t ref = A.ref[r];
-        const int kind = ref >> 28, role = (ref >> 26) & 3, t = ref & 0x3ffffff;
+        const int4 at = A.rec_a[r];
+        const double4 q = A.rec_q[r];
+        const long long code = __double_as_longlong(q.w);
+        const int kind = (int)(code & 7), role = (int)((code >> 3) & 3), periodic = (int)((code >> 5) & 1);
+        const int ix[4] = {at.x, at.y, at.z, at.w};
+        const double p[3] = {q.x, q.y, q.z};
         switch (kind) {
         case AMM_BOND_HARMONIC: {
-            const int32_t *ix = A.idx[kind] + 2 * t;
-            const double *p = A.par[kind] + 2 * t;
             const int other = ix[1 - role];
             double d[3];
-            delta3(pos, i, other, A.box, A.periodic[kind], d);
+            delta3(pos, i, other, A.box, periodic, d);
             const double rr = sqrt(dot3(d, d));
             const double dr = rr - p[0];
             const double fr = -p[1] * dr / rr;
@@ -89,11 +92,9 @@ __device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, i
             if (role == 0) esum += 0.5 * p[1] * dr * dr;
         } break;
         case AMM_ANGLE_HARMONIC: {
-            const int32_t *ix = A.idx[kind] + 3 * t;
-            const double *p = A.par[kind] + 2 * t;
             double d1[3], d2[3];
-            delta3(pos, ix[0], ix[1], A.box, A.periodic[kind], d1);
-            delta3(pos, ix[2], ix[1], A.box, A.periodic[kind], d2);
+            delta3(pos, ix[0], ix[1], A.box, periodic, d1);
+            delta3(pos, ix[2], ix[1], A.box, periodic, d2);
             const double r1 = sqrt(dot3(d1, d1)), r2 = sqrt(dot3(d2, d2));
             double c = dot3(d1, d2) / (r1 * r2);
             c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
@@ -111,11 +112,9 @@ __device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, i
         } break;
         case AMM_BOND_LJC:
         case AMM_BOND_NEAR: {
-            const int32_t *ix = A.idx[kind] + 2 * t;
-            const double *p = A.par[kind] + 3 * t;
             const int other = ix[1 - role];
             double d[3];
-            delta3(pos, i, other, A.box, A.periodic[kind], d);
+            delta3(pos, i, other, A.box, periodic, d);
             const double r2 = dot3(d, d);
             double e, fr;
             if (kind == AMM_BOND_LJC) {   // forces.py:406
@@ -130,8 +129,7 @@ __device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, i
             if (role == 0) esum += e;
         } break;
         case AMM_BOND_EWALD_EXCL: {
-            const int32_t *ix = A.idx[kind] + 2 * t;
-            const double qq = A.par[kind][t];
+            const double qq = p[0];
             const int other = ix[1 - role];
             double d[3];
             delta3(pos, i, other, A.box, 1, d);
@@ -143,12 +141,10 @@ __device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, i
             if (role == 0) esum += -qq * er / rr;
         } break;
         case AMM_TORSION_PERIODIC: {
-            const int32_t *ix = A.idx[kind] + 4 * t;
-            const double *p = A.par[kind] + 3 * t;
             double F[3], G[3], H[3], Av[3], Bv[3], BA[3];
-            delta3(pos, ix[0], ix[1], A.box, A.periodic[kind], F);
-            delta3(pos, ix[1], ix[2], A.box, A.periodic[kind], G);
-            delta3(pos, ix[3], ix[2], A.box, A.periodic[kind], H);
+            delta3(pos, ix[0], ix[1], A.box, periodic, F);
+            delta3(pos, ix[1], ix[2], A.box, periodic, G);
+            delta3(pos, ix[3], ix[2], A.box, periodic, H);
             cross3(F, G, Av);
             cross3(H, G, Bv);
             cross3(Bv, Av, BA);
@@ -251,24 +247,32 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
         }
     }
     for (int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
-    std::vector<uint32_t> ref(cnt[n]);
+    const size_t nref = (size_t)cnt[n];
+    std::vector<int4> rec_a(nref);
+    std::vector<double4> rec_q(nref);
     std::vector<int> fill(cnt.begin(), cnt.end() - 1);
     for (int kind = 0; kind < 6; ++kind)
         for (int t = 0; t < bs->n_terms[kind]; ++t)
             for (int r = 0; r < kArity[kind]; ++r) {
-                int a = bs->h_idx[kind][t * kArity[kind] + r];
-                ref[fill[a]++] = ((uint32_t)kind << 28) | ((uint32_t)r << 26) | (uint32_t)t;
+                const int a = bs->h_idx[kind][t * kArity[kind] + r];
+                const size_t slot = (size_t)fill[a]++;
+                int at[4] = {-1, -1, -1, -1};
+                for (int k = 0; k < kArity[kind]; ++k) at[k] = bs->h_idx[kind][t * kArity[kind] + k];
+                rec_a[slot] = make_int4(at[0], at[1], at[2], at[3]);
+                double pr[3] = {0.0, 0.0, 0.0};
+                for (int k = 0; k < kNpar[kind]; ++k) pr[k] = bs->h_par[kind][(size_t)t * kNpar[kind] + k];
+                const long long code = (long long)kind | ((long long)r << 3) | ((long long)(bs->periodic[kind] ? 1 : 0) << 5);
+                double w;
+                std::memcpy(&w, &code, sizeof(w));
+                rec_q[slot] = make_double4(pr[0], pr[1], pr[2], w);
             }
     AMM_HIP(hipMalloc(&bs->d_ref_ptr, sizeof(int) * (n + 1)));
     AMM_HIP(hipMemcpy(bs->d_ref_ptr, cnt.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
-    AMM_HIP(hipMalloc(&bs->d_ref, sizeof(uint32_t) * std::max<size_t>(ref.size(), 1)));
-    if (!ref.empty()) AMM_HIP(hipMemcpy(bs->d_ref, ref.data(), sizeof(uint32_t) * ref.size(), hipMemcpyHostToDevice));
-    for (int kind = 0; kind < 6; ++kind) {
-        if (bs->n_terms[kind] == 0) continue;
-        AMM_HIP(hipMalloc(&bs->d_idx[kind], sizeof(int32_t) * bs->h_idx[kind].size()));
-        AMM_HIP(hipMemcpy(bs->d_idx[kind], bs->h_idx[kind].data(), sizeof(int32_t) * bs->h_idx[kind].size(), hipMemcpyHostToDevice));
-        AMM_HIP(hipMalloc(&bs->d_par[kind], sizeof(double) * bs->h_par[kind].size()));
-        AMM_HIP(hipMemcpy(bs->d_par[kind], bs->h_par[kind].data(), sizeof(double) * bs->h_par[kind].size(), hipMemcpyHostToDevice));
+    AMM_HIP(hipMalloc(&bs->d_rec_a, sizeof(int4) * std::max<size_t>(nref, 1)));
+    AMM_HIP(hipMalloc(&bs->d_rec_q, sizeof(double4) * std::max<size_t>(nref, 1)));
+    if (nref) {
+        AMM_HIP(hipMemcpy(bs->d_rec_a, rec_a.data(), sizeof(int4) * nref, hipMemcpyHostToDevice));
+        AMM_HIP(hipMemcpy(bs->d_rec_q, rec_q.data(), sizeof(double4) * nref, hipMemcpyHostToDevice));
     }
     bs->n_epart = (n + 255) / 256;
     AMM_HIP(hipMalloc(&bs->d_epart, sizeof(double) * bs->n_epart));
@@ -294,12 +298,8 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
         if (!accumulate) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, ctx->stream));
     }
     A.ref_ptr = bs->d_ref_ptr;
-    A.ref = bs->d_ref;
-    for (int k = 0; k < 6; ++k) {
-        A.idx[k] = bs->d_idx[k];
-        A.par[k] = bs->d_par[k];
-        A.periodic[k] = bs->periodic[k];
-    }
+    A.rec_a = bs->d_rec_a;
+    A.rec_q = bs->d_rec_q;
     A.pos = d_pos;
     A.force = d_force;
     A.epart = bs->d_epart;
@@ -326,12 +326,8 @@ int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const 
     A.row_begin = 0;
     A.row_end = n;
     A.ref_ptr = bs->d_ref_ptr;
-    A.ref = bs->d_ref;
-    for (int k = 0; k < 6; ++k) {
-        A.idx[k] = bs->d_idx[k];
-        A.par[k] = bs->d_par[k];
-        A.periodic[k] = bs->periodic[k];
-    }
+    A.rec_a = bs->d_rec_a;
+    A.rec_q = bs->d_rec_q;
     A.pos = nullptr;
     A.force = nullptr;
     A.epart = nullptr;
@@ -349,12 +345,9 @@ int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const 
 }
 
 int amm_bonded_free(BondedSet *bs) {
-    for (int k = 0; k < 6; ++k) {
-        if (bs->d_idx[k]) (void)hipFree(bs->d_idx[k]);
-        if (bs->d_par[k]) (void)hipFree(bs->d_par[k]);
-    }
     if (bs->d_ref_ptr) (void)hipFree(bs->d_ref_ptr);
-    if (bs->d_ref) (void)hipFree(bs->d_ref);
+    if (bs->d_rec_a) (void)hipFree(bs->d_rec_a);
+    if (bs->d_rec_q) (void)hipFree(bs->d_rec_q);
     if (bs->d_epart) (void)hipFree(bs->d_epart);
     return 0;
 }
