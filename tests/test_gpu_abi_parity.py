@@ -423,3 +423,28 @@ def test_respa_ops_vs_oracle_trajectory(spcfw, goldens):
     assert np.abs(xd.cpu().numpy() - xo).max() < 1e-11
     assert np.abs(vd.cpu().numpy() - vo).max() < 1e-9
     ctx.close()
+
+
+@pytest.mark.parametrize('adj', ['force-switch'])
+def test_c2_full_size_lj_fluid(adj):
+    """Config C2 of BASELINE.json at full size: 32 768-atom LJ fluid, NearNonbondedForce only, fp64 -- energy and
+    forces vs the oracle's OpenMP cell-list traversal; plus size-independent checks (Newton's third law, and
+    invariance under a rigid translation that pushes every atom across the periodic boundary)."""
+    B = _backend()
+    from atomsmm_amd.testing import lj_fluid as lj32
+    c = lj32(32)
+    n = len(c['positions'])
+    assert n == 32768
+    d = near(adj, 0.85, 0.765)
+    e_ref, f_ref, npairs = O.pair_eval(d, c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], None, use_cells=True)
+    ctx = B.HipContext(n, c['box'])
+    fid = ctx.pair_create(B.pair_desc(d.family, d.rc, rc0=d.rc0, rs0=d.rs0), c['charge'], c['sigma'], c['epsilon'], None)
+    e, f = eval_force(ctx, fid, dev(c['positions']), n)
+    assert e == pytest.approx(e_ref, rel=1e-10)
+    assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    assert np.abs(f.sum(0)).max() <= 1e-8 * np.abs(f).max()
+    shifted = c['positions'] + np.array([0.61, -7.3, 23.9]) * c['box']
+    e2, f2 = eval_force(ctx, fid, dev(shifted), n)
+    assert e2 == pytest.approx(e, rel=1e-11)
+    assert np.abs(f2 - f).max() <= 1e-8 * np.abs(f).max()
+    ctx.close()

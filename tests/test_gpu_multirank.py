@@ -1,0 +1,79 @@
+"""GPU test of the real multi-rank path on ONE MI355X: two processes share cuda:0 and talk over gloo (RCCL needs
+one GPU per rank; the driver's 8-GPU run uses backend nccl).  Each rank evaluates the pair forces of its slice of
+the cell-sorted order with the HIP kernels, the engine all-reduces the group buffers, every rank integrates all
+atoms: after 3 RESPA steps both ranks hold the SAME bits as a single-rank run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _simulate(nsteps):
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import openmm, unit
+    from atomsmm_amd.openmm import app
+    from atomsmm_amd.testing import system_from_arrays, tip3p_box
+    c = tip3p_box(10)          # 3000 atoms, L = 3.1 nm
+    system = system_from_arrays(c, nonbondedMethod='CutoffPeriodic')
+    respa = atomsmm.RESPASystem(system, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
+    nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+    outer = atomsmm.DampedSmoothedForce(2.9 / unit.nanometers, 1.0 * unit.nanometers, 0.9 * unit.nanometers).importFrom(nb)
+    outer.setForceGroup(2)
+    outer.addTo(respa)
+    integrator = atomsmm.RespaPropagator([4, 2, 1]).integrator(2 * unit.femtoseconds)
+    sim = app.Simulation(app.Topology(), respa, integrator, openmm.Platform.getPlatformByName('HIP'))
+    sim.context.setPositions(c['positions'] * unit.nanometers)
+    sim.context.setVelocities(c['velocities'])
+    e0 = sim.context.getState(getEnergy=True).getPotentialEnergy()._value
+    sim.step(nsteps)
+    st = sim.context.getState(getPositions=True, getVelocities=True, getEnergy=True, getForces=True, groups={0, 1, 2})
+    eng = sim.context._engine
+    stats = eng.ctx.pair_stats(eng.pair_force_ids(2)[0])
+    return dict(x=st.getPositions(asNumpy=True)._value, v=st.getVelocities(asNumpy=True)._value,
+                f=st.getForces(asNumpy=True)._value, e=st.getPotentialEnergy()._value, e0=e0,
+                slice_atoms=stats['n_slice_atoms'], world=eng.world)
+
+
+def _worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ret[rank] = _simulate(3)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_rank_bit_for_bit():
+    import torch.multiprocessing as mp
+    single = _simulate(3)
+    assert single['world'] == 1
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as manager:
+        ret = manager.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        out = dict(ret)
+    for r in (0, 1):
+        assert out[r]['world'] == 2 and out[r]['slice_atoms'] == 1500
+        assert np.array_equal(out[r]['x'], single['x'])
+        assert np.array_equal(out[r]['v'], single['v'])
+        assert np.array_equal(out[r]['f'], single['f'])
+        assert out[r]['e0'] == pytest.approx(single['e0'], rel=1e-13)
+        assert out[r]['e'] == pytest.approx(single['e'], rel=1e-13)
