@@ -26,7 +26,7 @@ EXPORTS = [
     'amm_synchronize', 'amm_check', 'amm_pair_create', 'amm_pair_set_params', 'amm_pair_share_list', 'amm_bonded_create',
     'amm_bonded_add_terms', 'amm_bonded_finalize', 'amm_bonded_set_sliced', 'amm_force_eval', 'amm_kick',
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
-    'amm_set_fuse_inner',
+    'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
 ]
 
@@ -46,7 +46,8 @@ class PairStats(C.Structure):
     _fields_ = [('n_builds', C.c_int64), ('n_evals', C.c_int64), ('n_list_pairs', C.c_int64),
                 ('n_slice_atoms', C.c_int64), ('capacity', C.c_int32), ('max_neighbors', C.c_int32),
                 ('lanes_per_atom', C.c_int32), ('n_cells', C.c_int32), ('rlist', C.c_double),
-                ('shares_list', C.c_int32), ('pad_', C.c_int32)]
+                ('shares_list', C.c_int32), ('pad_', C.c_int32), ('n_outer_builds', C.c_int64),
+                ('n_outer_pairs', C.c_int64), ('rlist_outer', C.c_double)]
 
 
 def pair_desc(family, rc, rc0=0.0, rs0=0.0, rswitch=0.0, alpha=0.0, degree=1, flags=0, sign=1.0, Kc=KC,
@@ -96,6 +97,7 @@ def lib():
         L.amm_group_define.argtypes = [vp, C.c_int32, C.c_int32, ip, C.c_int32]
         L.amm_run_ops.argtypes = [vp, C.POINTER(Op), C.c_int32, C.c_int32]
         L.amm_set_fuse_inner.argtypes = [vp, C.c_int32]
+        L.amm_set_outer_skin.argtypes = [vp, C.c_double]
         L.amm_pair_get_stats.argtypes = [vp, C.c_int32, C.POINTER(PairStats)]
         L.amm_profile_enable.argtypes = [vp, C.c_int32]
         L.amm_profile_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), dp]
@@ -232,6 +234,9 @@ class HipContext:
     def run_ops(self, ops, repeat=1):
         arr = (Op * len(ops))(*ops)
         _chk(lib().amm_run_ops(self.h, arr, len(ops), int(repeat)))
+
+    def set_outer_skin(self, skin_out):
+        _chk(lib().amm_set_outer_skin(self.h, float(skin_out)))
 
     def set_fuse_inner(self, on=True):
         _chk(lib().amm_set_fuse_inner(self.h, int(bool(on))))

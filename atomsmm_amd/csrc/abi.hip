@@ -121,7 +121,7 @@ int amm_check(amm_ctx *ctx) {
     for (size_t id = 0; id < ctx->forces.size(); ++id) {
         PairForce *pf = ctx->forces[id].pair;
         if (!pf || !pf->built) continue;
-        int flags[4];
+        int flags[8];
         AMM_HIP(hipMemcpy(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
         if (flags[1]) {
             amm_set_error("neighbour list overflow in pair force " + std::to_string(id) + ": " + std::to_string(flags[2]) +
@@ -161,6 +161,11 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     pf->skin = skin;
     pf->rlist = desc->rc + skin;
     pf->rlist_build = pf->rlist + 2e-4;   // fp32 build: positions carry ~1e-6 nm rounding, superset is harmless
+    // outer buffer: large enough that the cell-based build is rare (hydrogens consume 0.05 nm in ~2 outer steps)
+    double skin_out = ctx->skin_out > 0 ? ctx->skin_out : 0.4;
+    skin_out = std::max(skin, std::min(skin_out, std::max(0.0, 0.5 * Lmin - desc->rc) * 0.999));
+    pf->skin_out = skin_out;
+    pf->rlist_out_build = desc->rc + skin_out + 2e-4;
     if (amm_pair_setup_grid(ctx, pf)) {
         delete pf;
         return 1;
@@ -203,10 +208,11 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     AMM_HIP(hipMalloc(&pf->d_lj_s, sizeof(double2) * n));
     AMM_HIP(hipMalloc(&pf->d_pos4f_s, sizeof(float4) * n));
     AMM_HIP(hipMalloc(&pf->d_xref, sizeof(double) * 3 * n));
-    AMM_HIP(hipMalloc(&pf->d_flags, sizeof(int) * 4));
-    AMM_HIP(hipMemset(pf->d_flags, 0, sizeof(int) * 4));
-    AMM_HIP(hipMalloc(&pf->d_counters, sizeof(unsigned long long) * 4));
-    AMM_HIP(hipMemset(pf->d_counters, 0, sizeof(unsigned long long) * 4));
+    AMM_HIP(hipMalloc(&pf->d_xref_out, sizeof(double) * 3 * n));
+    AMM_HIP(hipMalloc(&pf->d_flags, sizeof(int) * 8));
+    AMM_HIP(hipMemset(pf->d_flags, 0, sizeof(int) * 8));
+    AMM_HIP(hipMalloc(&pf->d_counters, sizeof(unsigned long long) * 8));
+    AMM_HIP(hipMemset(pf->d_counters, 0, sizeof(unsigned long long) * 8));
     ForceObj fo;
     fo.type = 1;
     fo.pair = pf;
@@ -257,6 +263,7 @@ int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id) {
     // the guest's skin must be consumed no later than the host's: same displacement trigger
     g->skin = std::min(g->skin, h->skin);
     h->skin = g->skin;
+    g->skin_out = h->skin_out;
     h->rnear_build = g->rlist_build;
     g->host = h;
     return 0;
@@ -523,14 +530,22 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     out->n_slice_atoms = L->s_end - L->s_begin;
     out->shares_list = pf->host ? 1 : 0;
     if (L->built) {
-        int flags[4];
-        unsigned long long cnt[4];
+        int flags[8];
+        unsigned long long cnt[8];
         AMM_HIP(hipMemcpy(flags, L->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
         AMM_HIP(hipMemcpy(cnt, L->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
         out->n_builds = (int64_t)cnt[0];
+        out->n_outer_builds = (int64_t)cnt[4];
+        out->n_outer_pairs = (int64_t)cnt[3];
+        out->rlist_outer = L->desc.rc + L->skin_out;
         out->n_list_pairs = (int64_t)(pf->host ? cnt[2] : cnt[1]);   // a guest walks the front parts only
         out->max_neighbors = flags[2];
     }
+    return 0;
+}
+
+int amm_set_outer_skin(amm_ctx *ctx, double skin_out) {
+    ctx->skin_out = skin_out;
     return 0;
 }
 

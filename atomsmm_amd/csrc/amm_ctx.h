@@ -49,7 +49,9 @@ struct PairForce {
     PairConsts pc;
     int n = 0;
     double skin = 0, rlist = 0;
-    double rlist_build = 0;        // rlist + fp32 safety margin used by the list build
+    double rlist_build = 0;        // rlist + fp32 safety margin used by the prune pass (inner list)
+    double skin_out = 0;           // outer Verlet buffer (cell-built list, radius rc + skin_out)
+    double rlist_out_build = 0;
     // per-atom parameters, original order: q, sigma/2, 2*sqrt(eps)
     double *d_q = nullptr, *d_hsig = nullptr, *d_seps2 = nullptr;
     int *d_excl_ptr = nullptr, *d_excl_idx = nullptr;
@@ -59,14 +61,17 @@ struct PairForce {
     double4 *d_posq_s = nullptr;   // sorted: wrapped x,y,z and charge
     double2 *d_lj_s = nullptr;     // sorted: sigma/2, 2*sqrt(eps)
     float4 *d_pos4f_s = nullptr;   // sorted fp32 positions at the last list build
-    double *d_xref = nullptr;      // positions at the last list build (original order)
+    double *d_xref = nullptr;      // positions at the last prune (original order)
+    double *d_xref_out = nullptr;  // positions at the last outer (cell-based) build
     int s_begin = 0, s_end = 0;    // sorted-slot range owned by this rank
     int cap = 0;
-    int *d_nl = nullptr, *d_nnb = nullptr, *d_nnb_near = nullptr;
+    int *d_nl = nullptr, *d_nnb = nullptr, *d_nnb_near = nullptr;   // inner list (traversed)
+    int *d_nl_out = nullptr, *d_nnb_out = nullptr, *d_nnb_scratch = nullptr;   // outer list (pruned from)
+    int cap_out = 0;
     PairForce *host = nullptr;     // owner of the neighbour list this force traverses (nullptr: its own)
     double rnear_build = 0;        // list radius of the guest force sharing this list (front part of each row)
-    int *d_flags = nullptr;        // [0] need_rebuild [1] overflow [2] max_nb [3] scratch
-    unsigned long long *d_counters = nullptr;  // [0] builds [1] list pairs [2] pairs in the front (near) parts
+    int *d_flags = nullptr;        // [0] need prune [1] overflow [2] max inner row [4] need outer build [5] max outer row
+    unsigned long long *d_counters = nullptr;  // [0] prunes [1] inner pairs [2] inner front pairs [3] outer pairs [4] outer builds
     unsigned long long *d_blockstats = nullptr; // per build-kernel block: (sum, max) of list lengths
     int lpa = 8;                   // lanes per i-atom in the traversal kernel
     int parts = 1;                 // wavefronts per cell in the list-build kernel
@@ -127,6 +132,7 @@ struct amm_ctx {
     // ping-pong partners of x, v and the group-0 force buffer for the fused inner RESPA iteration
     double *alt_x = nullptr, *alt_v = nullptr, *alt_f = nullptr;
     bool fuse_inner = true;
+    double skin_out = -1.0;        // outer Verlet buffer for pair forces created afterwards (<= 0: default)
 };
 
 // implemented in pair.hip / cells.hip / bonded.hip / integrate.hip

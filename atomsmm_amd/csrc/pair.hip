@@ -14,6 +14,7 @@
 // neighbour row (coalesced 4*lpa-byte reads); partial forces are combined with wavefront shuffles.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 #include "amm_ctx.h"
 #include "pair_math.h"
@@ -71,18 +72,25 @@ __device__ __forceinline__ double wrap1(double x, double L, double invL) {
     return w;
 }
 
-__global__ void k_check_displacement(int n, const double *__restrict__ pos, const double *__restrict__ xref,
-                                     double thr2, int *flags) {
+// Two Verlet buffers (dual list): flags[0] asks for a re-PRUNE of the inner list (some atom moved more than
+// skin_in/2 since the last prune), flags[4] for a rebuild of the outer list (moved more than (skin_out-skin_in)/2
+// since the last cell-based build; the outer list then no longer covers rc + skin_in).
+__global__ void k_check_displacement(int n, const double *__restrict__ pos, const double *__restrict__ xref_in,
+                                     const double *__restrict__ xref_out, double thr_in2, double thr_out2, int *flags) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double dx = pos[3 * i] - xref[3 * i], dy = pos[3 * i + 1] - xref[3 * i + 1], dz = pos[3 * i + 2] - xref[3 * i + 2];
+    const double x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+    double dx = x - xref_in[3 * i], dy = y - xref_in[3 * i + 1], dz = z - xref_in[3 * i + 2];
     double d2 = dx * dx + dy * dy + dz * dz;
-    if (!(d2 <= thr2)) flags[0] = 1;   // benign race: every writer stores 1 (NaN also triggers)
+    if (!(d2 <= thr_in2)) flags[0] = 1;   // benign race: every writer stores 1 (NaN also triggers)
+    dx = x - xref_out[3 * i]; dy = y - xref_out[3 * i + 1]; dz = z - xref_out[3 * i + 2];
+    d2 = dx * dx + dy * dy + dz * dz;
+    if (!(d2 <= thr_out2)) flags[4] = 1;
 }
 
 __global__ void k_cell_assign(int n, const double *__restrict__ pos, Box box, CellGrid g, int *cell_of, int *count,
                               double *xref, const int *flags, int force) {
-    if (!force && !flags[0]) return;
+    if (!force && !flags[4]) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c[3];
@@ -102,7 +110,7 @@ __global__ void k_cell_assign(int n, const double *__restrict__ pos, Box box, Ce
 // single block: exclusive scan of count[0..ncell) -> start[0..ncell], fill <- start, count <- 0
 __global__ void k_cell_scan(int ncell, int *count, int *start, int *fill, const int *flags, int *flags_rw,
                             unsigned long long *counters, int force) {
-    if (!force && !flags[0]) return;
+    if (!force && !flags[4]) return;
     __shared__ int part[1024];
     __shared__ int carry;
     int t = threadIdx.x;
@@ -135,7 +143,7 @@ __global__ void k_cell_scan(int ncell, int *count, int *start, int *fill, const 
 }
 
 __global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, int *perm_tmp, const int *flags, int force) {
-    if (!force && !flags[0]) return;
+    if (!force && !flags[4]) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int slot = atomicAdd(&fill[cell_of[i]], 1);
@@ -145,7 +153,7 @@ __global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, i
 // one wavefront per cell: rank sort by atom index -> deterministic order whatever the atomics did
 __global__ void k_cell_sort(int ncell, const int *__restrict__ start, const int *__restrict__ perm_tmp, int *perm,
                             const int *flags, int force) {
-    if (!force && !flags[0]) return;
+    if (!force && !flags[4]) return;
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     int lane = threadIdx.x & 63;
     if (wave >= ncell) return;
@@ -178,18 +186,23 @@ __global__ void k_gather_sorted(int n, const int *__restrict__ perm, const doubl
 // fp32 copy of the sorted, wrapped positions: the list build only has to find a SUPERSET of the pairs
 // within rlist (the traversal re-tests r^2 < rc^2 in fp64), so it runs on the fp32 pipe with a margin.
 __global__ void k_gather_f32(int n, const int *__restrict__ perm, const double *__restrict__ pos, Box box,
-                             float4 *pos4f_s, int *inv_perm, const int *flags, int force) {
-    if (!force && !flags[0]) return;
+                             float4 *pos4f_s, int *inv_perm, double *xref_in, const int *flags, int which, int force) {
+    if (!force && !flags[which]) return;
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     int i = perm[s];
+    if (xref_in) {        // prune pass: these positions become the inner reference
+        xref_in[3 * i] = pos[3 * i];
+        xref_in[3 * i + 1] = pos[3 * i + 1];
+        xref_in[3 * i + 2] = pos[3 * i + 2];
+    }
     float4 p;
     p.x = (float)wrap1(pos[3 * i], box.L[0], box.invL[0]);
     p.y = (float)wrap1(pos[3 * i + 1], box.L[1], box.invL[1]);
     p.z = (float)wrap1(pos[3 * i + 2], box.L[2], box.invL[2]);
     p.w = 0.f;
     pos4f_s[s] = p;
-    inv_perm[i] = s;
+    if (inv_perm) inv_perm[i] = s;
 }
 
 struct BoxF {
@@ -213,7 +226,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                               const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2, float rnear2,
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
                               int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats, int force) {
-    if (!force && !flags[0]) return;
+    if (!force && !flags[4]) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int c = wave / parts, part = wave - c * parts;
@@ -366,10 +379,10 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
     }
 }
 
-// single block: reduce the per-block list statistics, clear the rebuild request, count the build
+// single block: reduce the per-block list statistics of an outer build (which = 4) or of a prune (which = 0)
 __global__ void k_finish_build(int *flags, unsigned long long *counters, const unsigned long long *blockstats,
-                               int nblocks, int count_only, int force) {
-    if (!force && !flags[0]) return;
+                               int nblocks, int count_only, int which, int force) {
+    if (!force && !flags[which]) return;
     __shared__ unsigned long long sh_sum[256];
     __shared__ unsigned long long sh_max[256];
     __shared__ unsigned long long sh_near[256];
@@ -392,13 +405,115 @@ __global__ void k_finish_build(int *flags, unsigned long long *counters, const u
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        flags[2] = (int)sh_max[0];
-        counters[1] = sh_sum[0];
-        counters[2] = sh_near[0];
-        if (!count_only) {
-            flags[0] = 0;
-            counters[0] += 1;
+        if (which == 4) {                  // outer list
+            flags[5] = (int)sh_max[0];
+            counters[3] = sh_sum[0];
+            if (!count_only) {
+                flags[4] = 0;
+                flags[0] = 1;              // a fresh outer list must be pruned
+                counters[4] += 1;
+            }
+        } else {                           // inner list
+            flags[2] = (int)sh_max[0];
+            counters[1] = sh_sum[0];
+            counters[2] = sh_near[0];
+            if (!count_only) {
+                flags[0] = 0;
+                counters[0] += 1;
+            }
         }
+    }
+}
+
+// Prune: inner list <- entries of the outer list within rlist_in of the CURRENT positions.  `lpp` lanes per atom
+// stride through the outer row (coalesced), gather fp32 positions, and compact in order with group ballots; the
+// inner row is partitioned front (r < rnear, walked by a guest force) / back (the rest).
+template <bool COUNT_ONLY>
+__global__ void __launch_bounds__(256) k_prune(int s_begin, int s_end, int lpp_shift, const float4 *__restrict__ pos4f_s,
+                              BoxF box, float rlist2, float rnear2, const int *__restrict__ nl_out,
+                              const int *__restrict__ nnb_out, int cap_out, int cap, int *nl, int *nnb, int *nnb_near,
+                              int *flags, unsigned long long *blockstats, int force) {
+    if (!force && !flags[0]) return;
+    const int lpp = 1 << lpp_shift;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = tid >> lpp_shift;
+    const int sub = tid & (lpp - 1);
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane & ~(lpp - 1);
+    const unsigned long long gmask = (lpp == 64 ? ~0ull : ((1ull << lpp) - 1ull)) << gbase;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int s = s_begin + a;
+    const bool valid = s < s_end;
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    int nn = 0;
+    if (valid) {
+        pi = pos4f_s[s];
+        nn = nnb_out[a];
+    }
+    int nmax = nn;
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
+    const int *row_in = nl_out + (size_t)a * cap_out;
+    int *row_out = nl + (size_t)a * cap;
+    int cnt = 0, cntf = 0;
+    for (int base = 0; base < nmax; base += 4 * lpp) {
+        // four entries per trip, loads first: index -> position are two dependent round trips per entry otherwise
+        int js[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = base + u * lpp + sub;
+            ok[u] = k < nn;
+            js[u] = ok[u] ? row_in[k] : s;
+        }
+        float4 pj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pj[u] = pos4f_s[js[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float dx = pi.x - pj[u].x, dy = pi.y - pj[u].y, dz = pi.z - pj[u].z;
+            dx -= box.L[0] * rintf(dx * box.invL[0]);
+            dy -= box.L[1] * rintf(dy * box.invL[1]);
+            dz -= box.L[2] * rintf(dz * box.invL[2]);
+            const float r2 = dx * dx + dy * dy + dz * dz;
+            const bool pass = ok[u] && (r2 < rlist2);
+            const bool nearp = pass && (r2 < rnear2);
+            const unsigned long long bal = __ballot(nearp) & gmask, balf = __ballot(pass && !nearp) & gmask;
+            const int nb = __popcll(bal), nf = __popcll(balf);
+            if (pass && !COUNT_ONLY) {
+                const int pos_in = nearp ? cnt + __popcll(bal & below) : cap - 1 - (cntf + __popcll(balf & below));
+                if (cnt + cntf + nb + nf <= cap) row_out[pos_in] = js[u];
+            }
+            cnt += nb;
+            cntf += nf;
+        }
+    }
+    const int total = cnt + cntf;
+    if (valid && sub == 0 && !COUNT_ONLY) {
+        const bool over = total > cap;
+        nnb[a] = over ? 0 : total;
+        nnb_near[a] = over ? 0 : cnt;
+        if (over) flags[1] = 1;
+    }
+    unsigned long long wsum = (valid && sub == 0) ? (unsigned long long)total : 0ull;
+    unsigned long long wnear = (valid && sub == 0) ? (unsigned long long)cnt : 0ull;
+    int wmax = (valid && sub == 0) ? total : 0;
+    for (int off = 32; off > 0; off >>= 1) {
+        wsum += __shfl_xor(wsum, off);
+        wnear += __shfl_xor(wnear, off);
+        wmax = max(wmax, __shfl_xor(wmax, off));
+    }
+    __shared__ unsigned long long s_sum[4], s_near[4];
+    __shared__ int s_max[4];
+    if (lane == 0) {
+        s_sum[threadIdx.x >> 6] = wsum;
+        s_near[threadIdx.x >> 6] = wnear;
+        s_max[threadIdx.x >> 6] = wmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blockstats[3 * blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        blockstats[3 * blockIdx.x + 1] = (unsigned long long)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        blockstats[3 * blockIdx.x + 2] = s_near[0] + s_near[1] + s_near[2] + s_near[3];
     }
 }
 
@@ -560,7 +675,7 @@ static int setup_grid(amm_ctx *ctx, PairForce *pf) {
             return 1;
         }
         // cell edge >= rlist/2  ->  neighbours within +-2 cells; fewer than 5 cells: visit every cell once
-        int nc = (int)floor(L / (0.5 * pf->rlist_build));
+        int nc = (int)floor(L / (0.5 * pf->rlist_out_build));
         if (nc < 1) nc = 1;
         if (nc > 512) nc = 512;
         g.nc[k] = nc;
@@ -573,12 +688,13 @@ static int setup_grid(amm_ctx *ctx, PairForce *pf) {
     return 0;
 }
 
-static int build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int force, bool count_only) {
+// outer list: cell list -> candidate sweep, radius rc + skin_out (conditional on flags[4] unless force)
+static int outer_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int force, bool count_only) {
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_cell_assign, dim3(nb), dim3(256), 0, st, n, d_pos, ctx->box, pf->grid, pf->d_cell_of,
-                       pf->d_cell_count, pf->d_xref, pf->d_flags, force);
+                       pf->d_cell_count, pf->d_xref_out, pf->d_flags, force);
     hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, pf->grid.ncell, pf->d_cell_count, pf->d_cell_start,
                        pf->d_cell_fill, pf->d_flags, pf->d_flags, pf->d_counters, force);
     hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, st, n, pf->d_cell_of, pf->d_cell_fill, pf->d_perm_tmp,
@@ -586,7 +702,7 @@ static int build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int for
     hipLaunchKernelGGL(k_cell_sort, dim3((pf->grid.ncell * 64 + 255) / 256), dim3(256), 0, st, pf->grid.ncell,
                        pf->d_cell_start, pf->d_perm_tmp, pf->d_perm, pf->d_flags, force);
     hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, st, n, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s,
-                       pf->d_inv_perm, pf->d_flags, force);
+                       pf->d_inv_perm, (double *)nullptr, pf->d_flags, 4, force);
     const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
@@ -594,13 +710,14 @@ static int build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int for
         bf.L[k] = (float)ctx->box.L[k];
         bf.invL[k] = (float)ctx->box.invL[k];
     }
-    const float rl2 = (float)(pf->rlist_build * pf->rlist_build);
-    const float rn2 = pf->rnear_build > 0 ? (float)(pf->rnear_build * pf->rnear_build) : 3.0e38f;
+    const float rl2 = (float)(pf->rlist_out_build * pf->rlist_out_build);
+    const float rn2 = 3.0e38f;     // the outer rows are not partitioned
     const bool use_rint = pf->grid.nc[0] < 5 || pf->grid.nc[1] < 5 || pf->grid.nc[2] < 5;
 #define AMM_LAUNCH_BUILD(CO, RI)                                                                                       \
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
                        pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
-                       pf->d_excl_idx, pf->cap, pf->d_nl, pf->d_nnb, pf->d_nnb_near, pf->d_flags, pf->d_blockstats, force)
+                       pf->d_excl_idx, pf->cap_out, pf->d_nl_out, pf->d_nnb_out, pf->d_nnb_scratch, pf->d_flags,        \
+                       pf->d_blockstats, force)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
         else AMM_LAUNCH_BUILD(true, false);
@@ -610,7 +727,39 @@ static int build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int for
     }
 #undef AMM_LAUNCH_BUILD
     hipLaunchKernelGGL(k_finish_build, dim3(1), dim3(256), 0, st, pf->d_flags, pf->d_counters, pf->d_blockstats, (int)grid.x,
-                       count_only ? 1 : 0, force);
+                       count_only ? 1 : 0, 4, force);
+    AMM_HIP(hipGetLastError());
+    return 0;
+}
+
+// inner list: prune the outer rows with the current positions (conditional on flags[0] unless force)
+static int prune_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int force, bool count_only) {
+    hipStream_t st = ctx->stream;
+    const int n = pf->n;
+    const int nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, st, n, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s,
+                       (int *)nullptr, count_only ? (double *)nullptr : pf->d_xref, pf->d_flags, 0, force);
+    const int nslice = pf->s_end - pf->s_begin;
+    const int lpp_shift = 4;                                      // 16 lanes per atom
+    const long threads = (long)std::max(nslice, 1) << lpp_shift;
+    dim3 grid((unsigned)((threads + 255) / 256));
+    BoxF bf;
+    for (int k = 0; k < 3; ++k) {
+        bf.L[k] = (float)ctx->box.L[k];
+        bf.invL[k] = (float)ctx->box.invL[k];
+    }
+    const float rl2 = (float)(pf->rlist_build * pf->rlist_build);
+    const float rn2 = pf->rnear_build > 0 ? (float)(pf->rnear_build * pf->rnear_build) : 3.0e38f;
+    if (count_only)
+        hipLaunchKernelGGL((k_prune<true>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, lpp_shift, pf->d_pos4f_s, bf, rl2,
+                           rn2, pf->d_nl_out, pf->d_nnb_out, pf->cap_out, pf->cap, pf->d_nl, pf->d_nnb, pf->d_nnb_near,
+                           pf->d_flags, pf->d_blockstats, force);
+    else
+        hipLaunchKernelGGL((k_prune<false>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, lpp_shift, pf->d_pos4f_s, bf, rl2,
+                           rn2, pf->d_nl_out, pf->d_nnb_out, pf->cap_out, pf->cap, pf->d_nl, pf->d_nnb, pf->d_nnb_near,
+                           pf->d_flags, pf->d_blockstats, force);
+    hipLaunchKernelGGL(k_finish_build, dim3(1), dim3(256), 0, st, pf->d_flags, pf->d_counters, pf->d_blockstats, (int)grid.x,
+                       count_only ? 1 : 0, 0, force);
     AMM_HIP(hipGetLastError());
     return 0;
 }
@@ -622,8 +771,11 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     pf->s_begin = std::min(n, ctx->rank * per);
     pf->s_end = std::min(n, pf->s_begin + per);
     const int nslice = pf->s_end - pf->s_begin;
-    AMM_HIP(hipMalloc(&pf->d_nnb, sizeof(int) * std::max(nslice, 1)));
-    AMM_HIP(hipMalloc(&pf->d_nnb_near, sizeof(int) * std::max(nslice, 1)));
+    const size_t ns = (size_t)std::max(nslice, 1);
+    AMM_HIP(hipMalloc(&pf->d_nnb, sizeof(int) * ns));
+    AMM_HIP(hipMalloc(&pf->d_nnb_near, sizeof(int) * ns));
+    AMM_HIP(hipMalloc(&pf->d_nnb_out, sizeof(int) * ns));
+    AMM_HIP(hipMalloc(&pf->d_nnb_scratch, sizeof(int) * ns));
     // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding
     int lpa = 1;
     while (lpa < 64 && (long)nslice * lpa < 64L * 1024 * 8) lpa <<= 1;
@@ -632,20 +784,27 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         // waves per cell: enough that a cell's atoms are covered by about one batch per wave
         const double per_cell = (double)n / pf->grid.ncell;
         pf->parts = std::max(1, std::min(8, (int)std::ceil(per_cell / AMM_BATCH)));
-        const long threads = (long)pf->grid.ncell * pf->parts * 64;
-        const size_t nblk = (size_t)((threads + 255) / 256);
+        const long t1 = (long)pf->grid.ncell * pf->parts * 64, t2 = (long)ns * 16;
+        const size_t nblk = (size_t)((std::max(t1, t2) + 255) / 256);
         AMM_HIP(hipMalloc(&pf->d_blockstats, sizeof(unsigned long long) * 3 * nblk));
     }
-    // pass 1: count only -> capacity
-    pf->cap = 0;
-    if (build_chain(ctx, pf, d_pos, 1, true)) return 1;
-    int flags[4];
+    int flags[8];
+    // outer list: count, size, build
+    pf->cap_out = 0;
+    if (outer_chain(ctx, pf, d_pos, 1, true)) return 1;
     AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
     AMM_HIP(hipStreamSynchronize(ctx->stream));
-    int maxnb = flags[2];
-    pf->cap = ((int)(maxnb * 1.5) + 32 + 15) / 16 * 16;   // head-room for density fluctuations between rebuilds
-    AMM_HIP(hipMalloc(&pf->d_nl, sizeof(int) * (size_t)std::max(nslice, 1) * pf->cap));
-    if (build_chain(ctx, pf, d_pos, 1, false)) return 1;
+    pf->cap_out = ((int)(flags[5] * 1.5) + 32 + 15) / 16 * 16;   // head-room for density fluctuations between rebuilds
+    AMM_HIP(hipMalloc(&pf->d_nl_out, sizeof(int) * ns * pf->cap_out));
+    if (outer_chain(ctx, pf, d_pos, 1, false)) return 1;
+    // inner list: count, size, prune
+    pf->cap = 0;
+    if (prune_chain(ctx, pf, d_pos, 1, true)) return 1;
+    AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    pf->cap = ((int)(flags[2] * 1.5) + 32 + 15) / 16 * 16;
+    AMM_HIP(hipMalloc(&pf->d_nl, sizeof(int) * ns * pf->cap));
+    if (prune_chain(ctx, pf, d_pos, 1, false)) return 1;
     pf->built = true;
     return 0;
 }
@@ -664,9 +823,11 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     if (!L->built) {
         if (first_build(ctx, L, d_pos)) return 1;
     } else {
-        const double thr = 0.5 * L->skin;
-        hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, L->d_xref, thr * thr, L->d_flags);
-        if (build_chain(ctx, L, d_pos, 0, false)) return 1;
+        const double thr_in = 0.5 * L->skin, thr_out = 0.5 * (L->skin_out - L->skin);
+        hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, L->d_xref, L->d_xref_out,
+                           thr_in * thr_in, thr_out * thr_out, L->d_flags);
+        if (outer_chain(ctx, L, d_pos, 0, false)) return 1;
+        if (prune_chain(ctx, L, d_pos, 0, false)) return 1;
     }
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, n, L->d_perm, d_pos, pf->d_q, pf->d_hsig,
                        pf->d_seps2, ctx->box, pf->d_posq_s, pf->d_lj_s);
@@ -740,7 +901,8 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
 int amm_pair_free(PairForce *pf) {
     void *ptrs[] = {pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_excl_ptr, pf->d_excl_idx, pf->d_cell_of, pf->d_cell_count,
                     pf->d_cell_start, pf->d_cell_fill, pf->d_perm_tmp, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
-                    pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near};
+                    pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near, pf->d_nl_out, pf->d_nnb_out,
+                    pf->d_nnb_scratch, pf->d_xref_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);

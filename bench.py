@@ -189,8 +189,10 @@ def main():
                                  'at 60 flop per in-cutoff pair' % (fp64_tf, fp64_tf / FP64_VECTOR_PEAK_TF, FP64_VECTOR_PEAK_TF)},
             'detail': {'near_kernel_us': round(t_near * 1e6, 2), 'far_kernel_us': round(ms_far / max(n_far, 1) * 1e3, 2),
                        'near_launches': n_near, 'far_launches': n_far,
-                       'near_list_builds_in_timed_region': st1[near_id]['n_builds'] - st0[near_id]['n_builds'],
-                       'far_list_builds_in_timed_region': st1[far_id]['n_builds'] - st0[far_id]['n_builds'],
+                       'near_list_prunes_in_timed_region': st1[near_id]['n_builds'] - st0[near_id]['n_builds'],
+                       'far_list_prunes_in_timed_region': st1[far_id]['n_builds'] - st0[far_id]['n_builds'],
+                       'outer_list_builds_in_timed_region': st1[far_id]['n_outer_builds'] - st0[far_id]['n_outer_builds'],
+                       'outer_rlist_nm': st1[far_id]['rlist_outer'], 'shared_list': bool(near_stats['shares_list']),
                        'near_lanes_per_atom': near_stats['lanes_per_atom'], 'near_rlist_nm': near_stats['rlist'],
                        'near_list_pairs': near_stats['n_list_pairs'], 'fp64_tflops_near': round(fp64_tf, 3)},
         }

@@ -142,6 +142,9 @@ int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass)
 int amm_bind_buffer(amm_ctx *ctx, int32_t slot, double *d_buf);              /* per-DOF buffers f0.., _f2_, fm1 */
 int amm_group_define(amm_ctx *ctx, int32_t group, int32_t slot, const int32_t *force_ids, int32_t n_forces);
 int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat);
+/* Dual Verlet list: an OUTER list (radius rc + skin_out, built from the cell list, rare) is PRUNED to the inner list
+ * (rc + skin) that the traversal walks whenever an atom moved more than skin/2.  Applies to pair forces created later. */
+int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
 /* amm_run_ops fuses KICK;MOVE;EVAL(bond-list group);KICK into one launch (bit-identical results); 0 disables. */
 int amm_set_fuse_inner(amm_ctx *ctx, int32_t on);
 
@@ -158,6 +161,9 @@ typedef struct {
     double rlist;
     int32_t shares_list;    /* 1 if this force traverses another force's list */
     int32_t pad_;
+    int64_t n_outer_builds; /* cell-based builds of the outer list (n_builds counts prunes of the inner list) */
+    int64_t n_outer_pairs;
+    double rlist_outer;
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
 /* HIP-event timing of the dominant kernel (pair traversal) on the context stream. */
