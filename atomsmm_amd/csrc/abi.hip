@@ -162,7 +162,9 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     pf->rlist = desc->rc + skin;
     pf->rlist_build = pf->rlist + 2e-4;   // fp32 build: positions carry ~1e-6 nm rounding, superset is harmless
     // outer buffer: large enough that the cell-based build is rare (hydrogens consume 0.05 nm in ~2 outer steps)
-    double skin_out = ctx->skin_out > 0 ? ctx->skin_out : 0.4;
+    // default: single list (skin_out = skin).  Measured at C3: the prune pass costs about as much as a cell build
+    // (both are bound by L1 line-access rate / instruction issue), so the dual list only pays for slow-moving systems.
+    double skin_out = ctx->skin_out > 0 ? ctx->skin_out : skin;
     skin_out = std::max(skin, std::min(skin_out, std::max(0.0, 0.5 * Lmin - desc->rc) * 0.999));
     pf->skin_out = skin_out;
     pf->rlist_out_build = desc->rc + skin_out + 2e-4;
@@ -264,6 +266,10 @@ int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id) {
     g->skin = std::min(g->skin, h->skin);
     h->skin = g->skin;
     g->skin_out = h->skin_out;
+    h->rlist = h->desc.rc + h->skin;
+    h->rlist_build = h->rlist + 2e-4;
+    if (h->skin_out < h->skin) h->skin_out = h->skin;
+    h->rlist_out_build = h->desc.rc + h->skin_out + 2e-4;
     h->rnear_build = g->rlist_build;
     g->host = h;
     return 0;

@@ -68,6 +68,7 @@ struct PairForce {
     int *d_nl = nullptr, *d_nnb = nullptr, *d_nnb_near = nullptr;   // inner list (traversed)
     int *d_nl_out = nullptr, *d_nnb_out = nullptr, *d_nnb_scratch = nullptr;   // outer list (pruned from)
     int cap_out = 0;
+    bool dual = false;             // outer list + prune (skin_out > skin) or a single list built from the cells
     PairForce *host = nullptr;     // owner of the neighbour list this force traverses (nullptr: its own)
     double rnear_build = 0;        // list radius of the guest force sharing this list (front part of each row)
     int *d_flags = nullptr;        // [0] need prune [1] overflow [2] max inner row [4] need outer build [5] max outer row

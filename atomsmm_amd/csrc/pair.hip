@@ -89,8 +89,8 @@ __global__ void k_check_displacement(int n, const double *__restrict__ pos, cons
 }
 
 __global__ void k_cell_assign(int n, const double *__restrict__ pos, Box box, CellGrid g, int *cell_of, int *count,
-                              double *xref, const int *flags, int force) {
-    if (!force && !flags[4]) return;
+                              double *xref, const int *flags, int which, int force) {
+    if (!force && !flags[which]) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c[3];
@@ -109,8 +109,8 @@ __global__ void k_cell_assign(int n, const double *__restrict__ pos, Box box, Ce
 
 // single block: exclusive scan of count[0..ncell) -> start[0..ncell], fill <- start, count <- 0
 __global__ void k_cell_scan(int ncell, int *count, int *start, int *fill, const int *flags, int *flags_rw,
-                            unsigned long long *counters, int force) {
-    if (!force && !flags[4]) return;
+                            unsigned long long *counters, int which, int force) {
+    if (!force && !flags[which]) return;
     __shared__ int part[1024];
     __shared__ int carry;
     int t = threadIdx.x;
@@ -142,8 +142,9 @@ __global__ void k_cell_scan(int ncell, int *count, int *start, int *fill, const 
     }
 }
 
-__global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, int *perm_tmp, const int *flags, int force) {
-    if (!force && !flags[4]) return;
+__global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, int *perm_tmp, const int *flags, int which,
+                            int force) {
+    if (!force && !flags[which]) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int slot = atomicAdd(&fill[cell_of[i]], 1);
@@ -152,8 +153,8 @@ __global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, i
 
 // one wavefront per cell: rank sort by atom index -> deterministic order whatever the atomics did
 __global__ void k_cell_sort(int ncell, const int *__restrict__ start, const int *__restrict__ perm_tmp, int *perm,
-                            const int *flags, int force) {
-    if (!force && !flags[4]) return;
+                            const int *flags, int which, int force) {
+    if (!force && !flags[which]) return;
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     int lane = threadIdx.x & 63;
     if (wave >= ncell) return;
@@ -225,8 +226,8 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                               const int *__restrict__ inv_perm, const int *__restrict__ cell_start,
                               const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2, float rnear2,
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
-                              int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats, int force) {
-    if (!force && !flags[4]) return;
+                              int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats, int which, int force) {
+    if (!force && !flags[which]) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int c = wave / parts, part = wave - c * parts;
@@ -675,7 +676,8 @@ static int setup_grid(amm_ctx *ctx, PairForce *pf) {
             return 1;
         }
         // cell edge >= rlist/2  ->  neighbours within +-2 cells; fewer than 5 cells: visit every cell once
-        int nc = (int)floor(L / (0.5 * pf->rlist_out_build));
+        const double rgrid = pf->skin_out > pf->skin * (1 + 1e-9) ? pf->rlist_out_build : pf->rlist_build;
+        int nc = (int)floor(L / (0.5 * rgrid));
         if (nc < 1) nc = 1;
         if (nc > 512) nc = 512;
         g.nc[k] = nc;
@@ -688,21 +690,23 @@ static int setup_grid(amm_ctx *ctx, PairForce *pf) {
     return 0;
 }
 
-// outer list: cell list -> candidate sweep, radius rc + skin_out (conditional on flags[4] unless force)
-static int outer_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int force, bool count_only) {
+// cell list -> candidate sweep.  direct = false: OUTER list (radius rc + skin_out, conditional on flags[4]);
+// direct = true (single-list mode, skin_out <= skin): straight into the traversed inner list (flags[0]).
+static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int force, bool count_only, bool direct) {
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
+    const int which = direct ? 0 : 4;
     hipLaunchKernelGGL(k_cell_assign, dim3(nb), dim3(256), 0, st, n, d_pos, ctx->box, pf->grid, pf->d_cell_of,
-                       pf->d_cell_count, pf->d_xref_out, pf->d_flags, force);
+                       pf->d_cell_count, direct ? pf->d_xref : pf->d_xref_out, pf->d_flags, which, force);
     hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, pf->grid.ncell, pf->d_cell_count, pf->d_cell_start,
-                       pf->d_cell_fill, pf->d_flags, pf->d_flags, pf->d_counters, force);
+                       pf->d_cell_fill, pf->d_flags, pf->d_flags, pf->d_counters, which, force);
     hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, st, n, pf->d_cell_of, pf->d_cell_fill, pf->d_perm_tmp,
-                       pf->d_flags, force);
+                       pf->d_flags, which, force);
     hipLaunchKernelGGL(k_cell_sort, dim3((pf->grid.ncell * 64 + 255) / 256), dim3(256), 0, st, pf->grid.ncell,
-                       pf->d_cell_start, pf->d_perm_tmp, pf->d_perm, pf->d_flags, force);
+                       pf->d_cell_start, pf->d_perm_tmp, pf->d_perm, pf->d_flags, which, force);
     hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, st, n, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s,
-                       pf->d_inv_perm, (double *)nullptr, pf->d_flags, 4, force);
+                       pf->d_inv_perm, (double *)nullptr, pf->d_flags, which, force);
     const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
@@ -710,14 +714,17 @@ static int outer_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int for
         bf.L[k] = (float)ctx->box.L[k];
         bf.invL[k] = (float)ctx->box.invL[k];
     }
-    const float rl2 = (float)(pf->rlist_out_build * pf->rlist_out_build);
-    const float rn2 = 3.0e38f;     // the outer rows are not partitioned
+    const double rl = direct ? pf->rlist_build : pf->rlist_out_build;
+    const float rl2 = (float)(rl * rl);
+    const float rn2 = (direct && pf->rnear_build > 0) ? (float)(pf->rnear_build * pf->rnear_build) : 3.0e38f;
+    int *nl = direct ? pf->d_nl : pf->d_nl_out, *nnb = direct ? pf->d_nnb : pf->d_nnb_out;
+    int *nnb_near = direct ? pf->d_nnb_near : pf->d_nnb_scratch;
+    const int cap = direct ? pf->cap : pf->cap_out;
     const bool use_rint = pf->grid.nc[0] < 5 || pf->grid.nc[1] < 5 || pf->grid.nc[2] < 5;
 #define AMM_LAUNCH_BUILD(CO, RI)                                                                                       \
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
                        pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
-                       pf->d_excl_idx, pf->cap_out, pf->d_nl_out, pf->d_nnb_out, pf->d_nnb_scratch, pf->d_flags,        \
-                       pf->d_blockstats, force)
+                       pf->d_excl_idx, cap, nl, nnb, nnb_near, pf->d_flags, pf->d_blockstats, which, force)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
         else AMM_LAUNCH_BUILD(true, false);
@@ -727,7 +734,7 @@ static int outer_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int for
     }
 #undef AMM_LAUNCH_BUILD
     hipLaunchKernelGGL(k_finish_build, dim3(1), dim3(256), 0, st, pf->d_flags, pf->d_counters, pf->d_blockstats, (int)grid.x,
-                       count_only ? 1 : 0, 4, force);
+                       count_only ? 1 : 0, which, force);
     AMM_HIP(hipGetLastError());
     return 0;
 }
@@ -789,22 +796,34 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         AMM_HIP(hipMalloc(&pf->d_blockstats, sizeof(unsigned long long) * 3 * nblk));
     }
     int flags[8];
-    // outer list: count, size, build
-    pf->cap_out = 0;
-    if (outer_chain(ctx, pf, d_pos, 1, true)) return 1;
-    AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-    AMM_HIP(hipStreamSynchronize(ctx->stream));
-    pf->cap_out = ((int)(flags[5] * 1.5) + 32 + 15) / 16 * 16;   // head-room for density fluctuations between rebuilds
-    AMM_HIP(hipMalloc(&pf->d_nl_out, sizeof(int) * ns * pf->cap_out));
-    if (outer_chain(ctx, pf, d_pos, 1, false)) return 1;
-    // inner list: count, size, prune
-    pf->cap = 0;
-    if (prune_chain(ctx, pf, d_pos, 1, true)) return 1;
-    AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-    AMM_HIP(hipStreamSynchronize(ctx->stream));
-    pf->cap = ((int)(flags[2] * 1.5) + 32 + 15) / 16 * 16;
-    AMM_HIP(hipMalloc(&pf->d_nl, sizeof(int) * ns * pf->cap));
-    if (prune_chain(ctx, pf, d_pos, 1, false)) return 1;
+    pf->dual = pf->skin_out > pf->skin * (1 + 1e-9);
+    if (pf->dual) {
+        // outer list: count, size, build
+        pf->cap_out = 0;
+        if (cell_build_chain(ctx, pf, d_pos, 1, true, false)) return 1;
+        AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+        AMM_HIP(hipStreamSynchronize(ctx->stream));
+        pf->cap_out = ((int)(flags[5] * 1.5) + 32 + 15) / 16 * 16;   // head-room for density fluctuations between rebuilds
+        AMM_HIP(hipMalloc(&pf->d_nl_out, sizeof(int) * ns * pf->cap_out));
+        if (cell_build_chain(ctx, pf, d_pos, 1, false, false)) return 1;
+        // inner list: count, size, prune
+        pf->cap = 0;
+        if (prune_chain(ctx, pf, d_pos, 1, true)) return 1;
+        AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+        AMM_HIP(hipStreamSynchronize(ctx->stream));
+        pf->cap = ((int)(flags[2] * 1.5) + 32 + 15) / 16 * 16;
+        AMM_HIP(hipMalloc(&pf->d_nl, sizeof(int) * ns * pf->cap));
+        if (prune_chain(ctx, pf, d_pos, 1, false)) return 1;
+    } else {
+        // single list: the cell sweep writes the traversed list directly
+        pf->cap = 0;
+        if (cell_build_chain(ctx, pf, d_pos, 1, true, true)) return 1;
+        AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+        AMM_HIP(hipStreamSynchronize(ctx->stream));
+        pf->cap = ((int)(flags[2] * 1.5) + 32 + 15) / 16 * 16;
+        AMM_HIP(hipMalloc(&pf->d_nl, sizeof(int) * ns * pf->cap));
+        if (cell_build_chain(ctx, pf, d_pos, 1, false, true)) return 1;
+    }
     pf->built = true;
     return 0;
 }
@@ -823,11 +842,15 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     if (!L->built) {
         if (first_build(ctx, L, d_pos)) return 1;
     } else {
-        const double thr_in = 0.5 * L->skin, thr_out = 0.5 * (L->skin_out - L->skin);
-        hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, L->d_xref, L->d_xref_out,
-                           thr_in * thr_in, thr_out * thr_out, L->d_flags);
-        if (outer_chain(ctx, L, d_pos, 0, false)) return 1;
-        if (prune_chain(ctx, L, d_pos, 0, false)) return 1;
+        const double thr_in = 0.5 * L->skin, thr_out = L->dual ? 0.5 * (L->skin_out - L->skin) : 1.0e30;
+        hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, L->d_xref,
+                           L->dual ? L->d_xref_out : L->d_xref, thr_in * thr_in, thr_out * thr_out, L->d_flags);
+        if (L->dual) {
+            if (cell_build_chain(ctx, L, d_pos, 0, false, false)) return 1;
+            if (prune_chain(ctx, L, d_pos, 0, false)) return 1;
+        } else {
+            if (cell_build_chain(ctx, L, d_pos, 0, false, true)) return 1;
+        }
     }
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, n, L->d_perm, d_pos, pf->d_q, pf->d_hsig,
                        pf->d_seps2, ctx->box, pf->d_posq_s, pf->d_lj_s);

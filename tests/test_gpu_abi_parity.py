@@ -204,14 +204,18 @@ def test_kick_move_bit_exact():
     ctx.close()
 
 
-def test_neighbour_list_rebuild_and_reuse(spcfw):
+@pytest.mark.parametrize('outer_skin', [None, 0.3])
+def test_neighbour_list_rebuild_and_reuse(spcfw, outer_skin):
     """Positions drift: the Verlet list is reused while max displacement < skin/2 and rebuilt after;
-    forces match the oracle at every stage."""
+    forces match the oracle at every stage.  outer_skin = 0.3: dual list (outer cell-built list pruned to the
+    traversed one); None: single list."""
     B = _backend()
     c = spcfw
     n = len(c['positions'])
     d = near('force-switch', 0.7, 0.5)
     ctx = B.HipContext(n, c['box'])
+    if outer_skin:
+        ctx.set_outer_skin(outer_skin)
     fid = hip_pair(B, ctx, d, c, skin=0.1)
     rng = np.random.default_rng(3)
     pos = c['positions'].copy()
@@ -225,6 +229,10 @@ def test_neighbour_list_rebuild_and_reuse(spcfw):
         pos = pos + rng.normal(scale=0.012, size=pos.shape)     # random walk, ~0.02 nm per step
     assert builds[0] == 1 and builds[1] == 1          # reused
     assert builds[-1] > 1                              # rebuilt once the skin was consumed
+    st = ctx.pair_stats(fid)
+    if outer_skin:
+        assert st['rlist_outer'] == pytest.approx(1.0) and 1 <= st['n_outer_builds'] < st['n_builds']
+        assert st['n_outer_pairs'] > st['n_list_pairs']
     # a big jump (atoms leave the box) forces a rebuild and wrapping
     pos = pos + np.array([3.1, -2.7, 5.0])
     e_ref, f_ref, _ = O.pair_eval(d, pos, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])
