@@ -424,6 +424,49 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
     for (int rep = 0; rep < repeat; ++rep)
         for (int k = 0; k < n_ops; ++k) {
             const amm_op &op = ops[k];
+            // component-parallel inner loop: [up to 3 KICKs] + n x {KICK(c1, fg) ; MOVE(d) ; EVAL(g) ; KICK(c2, fg)} in one launch
+            if (ctx->fuse_inner && !swapped && op.op == AMM_OP_KICK) {
+                int p = k, npre = 0;
+                while (p < n_ops && ops[p].op == AMM_OP_KICK && npre < 4) { ++p; ++npre; }
+                // the last KICK of the run is the first op of the inner pattern
+                int start = p - 1;
+                npre -= 1;
+                auto is_iter = [&](int q, const amm_op &first) {
+                    return q + 3 < n_ops && ops[q].op == AMM_OP_KICK && ops[q].b < 0 && ops[q + 1].op == AMM_OP_MOVE &&
+                           ops[q + 2].op == AMM_OP_EVAL && ops[q + 3].op == AMM_OP_KICK && ops[q + 3].b < 0 &&
+                           ops[q + 3].a == ops[q].a && ops[q].a == first.a && ops[q].coef == first.coef &&
+                           ops[q + 1].coef == ops[start + 1].coef && ops[q + 3].coef == ops[start + 3].coef &&
+                           ops[q + 2].a == ops[start + 2].a;
+                };
+                if (npre <= 3 && start >= k && is_iter(start, ops[start]) && ops[start + 2].a >= 0 && ops[start + 2].a < AMM_MAX_GROUPS) {
+                    GroupDef &g = ctx->groups[ops[start + 2].a];
+                    BondedSet *bs = (g.slot == ops[start].a && g.forces.size() == 1 && ctx->forces[g.forces[0]].type == 2)
+                                        ? ctx->forces[g.forces[0]].bonded : nullptr;
+                    if (bs && bs->max_comp <= 8 && !(bs->sliced && ctx->world > 1)) {
+                        int niter = 0, q = start;
+                        while (is_iter(q, ops[start])) { ++niter; q += 4; }
+                        const double *pa[3] = {nullptr, nullptr, nullptr}, *pb[3] = {nullptr, nullptr, nullptr};
+                        double pc[3] = {0, 0, 0};
+                        int pp[3] = {0, 0, 0};
+                        bool ok = true;
+                        for (int j = 0; j < npre; ++j) {
+                            const amm_op &ko = ops[k + j];
+                            pa[j] = (ko.a >= 0 && ko.a < AMM_MAX_SLOTS) ? ctx->slots[ko.a] : nullptr;
+                            pb[j] = (ko.b >= 0 && ko.b < AMM_MAX_SLOTS) ? ctx->slots[ko.b] : nullptr;
+                            pc[j] = ko.coef;
+                            pp[j] = ko.c;
+                            if (!pa[j] || (ko.b >= 0 && !pb[j])) ok = false;
+                        }
+                        double *f0 = ctx->slots[g.slot];
+                        if (ok && f0) {
+                            if (amm_inner_components_impl(ctx, bs, ctx->d_x, ctx->d_v, f0, npre, pa, pb, pc, pp, ops[start].coef,
+                                                          ops[start + 1].coef, ops[start + 3].coef, niter)) return 1;
+                            k = q - 1;
+                            continue;
+                        }
+                    }
+                }
+            }
             // fused inner RESPA iteration: KICK(c1, fg) ; MOVE(d) ; EVAL(g) ; KICK(c2, fg) with g = one bond-list set
             if (ctx->fuse_inner && op.op == AMM_OP_KICK && op.b < 0 && k + 3 < n_ops && ops[k + 1].op == AMM_OP_MOVE &&
                 ops[k + 2].op == AMM_OP_EVAL && ops[k + 3].op == AMM_OP_KICK && ops[k + 3].b < 0 && ops[k + 3].a == op.a &&

@@ -102,6 +102,9 @@ struct BondedSet {
     int *d_ref_ptr = nullptr;      // [n+1]
     int4 *d_rec_a = nullptr;       // atoms of the term
     double4 *d_rec_q = nullptr;    // parameters + kind/role/periodic code
+    int4 *d_rec_l = nullptr;       // atoms of the term as slots within their connected component
+    int *d_comp_ptr = nullptr, *d_comp_atoms = nullptr;   // connected components of the term graph (CSR)
+    int ncomp = 0, max_comp = 0;
     double *d_epart = nullptr;
     int n_epart = 0;
 };
@@ -145,6 +148,9 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
                          double *d_energy);
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
 int amm_bonded_free(BondedSet *bs);
+int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v, double *f0, int npre, const double *const *pre_a,
+                              const double *const *pre_b, const double *pre_coef, const int *pre_plus, double c1, double d,
+                              double c2, int niter);
 int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const double *v_in, const double *f_in,
                          double *x_out, double *v_out, double *f_out, double c1, double d, double c2);
 int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef);

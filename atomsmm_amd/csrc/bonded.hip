@@ -21,6 +21,7 @@ struct BondedArgs {
     // only two dependent load levels (ref_ptr -> records -> positions) instead of four
     const int4 *rec_a;      // atom indices of the term (-1 padded)
     const double4 *rec_q;   // p0, p1, p2, and kind | role<<3 | periodic<<5 in the bits of .w
+    const int4 *rec_l;      // the same atoms as slots inside their connected component (component kernel)
     const double *pos;
     double *force;
     double *epart;
@@ -70,11 +71,11 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
 }
 
 // force on atom i (and, for role-0 references, the energy) of every bond-list term that contains it
-template <class P>
-__device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, int i, double *f, double &esum) {
-    const int rb = A.ref_ptr[i], re = A.ref_ptr[i + 1];
+template <class P, bool LOCAL = false>
+__device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, int iglobal, int i, double *f, double &esum) {
+    const int rb = A.ref_ptr[iglobal], re = A.ref_ptr[iglobal + 1];
     for (int r = rb; r < re; ++r) {
-        const int4 at = A.rec_a[r];
+        const int4 at = LOCAL ? A.rec_l[r] : A.rec_a[r];
         const double4 q = A.rec_q[r];
         const long long code = __double_as_longlong(q.w);
         const int kind = (int)(code & 7), role = (int)((code >> 3) & 3), periodic = (int)((code >> 5) & 1);
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(256) k_bonded(BondedArgs A) {
     double esum = 0.0;
     if (i < A.row_end) {
         PosPlain pos{A.pos};
-        bonded_atom(A, pos, i, f, esum);
+        bonded_atom(A, pos, i, i, f, esum);
         if (A.accumulate) {
             A.force[3 * i] += f[0]; A.force[3 * i + 1] += f[1]; A.force[3 * i + 2] += f[2];
         } else {
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(256) k_fused_inner(BondedArgs A, FusedArgs F) 
     PosAdvanced pos{F.x_in, F.v_in, F.f_in, F.mass, F.c1, F.d};
     double f[3] = {0.0, 0.0, 0.0};
     double esum = 0.0;
-    bonded_atom(A, pos, i, f, esum);
+    bonded_atom(A, pos, i, i, f, esum);
     {
 #pragma clang fp contract(off)
         const double mi = F.mass[i];
@@ -219,6 +220,122 @@ __global__ void __launch_bounds__(256) k_fused_inner(BondedArgs A, FusedArgs F) 
             const double dv = num / mi;
             F.v_out[3 * i + k] = v1 + dv;
             F.f_out[3 * i + k] = f[k];
+        }
+    }
+}
+
+// Component-parallel inner loop.  The bond-list terms of group 0 only couple atoms of the same connected component
+// (a water molecule, a small solute): ONE THREAD integrates ONE COMPONENT through ALL n0 inner RESPA iterations
+//     [pre-kicks]  n0 x { v += c1 f0/m ; x += d v ; f0 = bonded(x) ; v += c2 f0/m }
+// with positions in a thread-private LDS strip (dynamic indexing by the term records), velocities/forces in
+// registers: one launch instead of 4*n0, no inter-thread dependence at all, same arithmetic and rounding as the
+// separate kernels (bit-identical).  Used when every component has at most MAXC atoms.
+struct PosLocal {
+    const double *lds;   // base of this thread's strip: element (slot*3+k) at lds[(slot*3+k)*256]
+    __device__ __forceinline__ double get(int slot, int k) const { return lds[(slot * 3 + k) * 256]; }
+};
+
+struct PreKick {
+    const double *a, *b;   // v += coef*(a -/+ b)/m ; b may be null
+    double coef;
+    int plus;
+};
+
+struct CompArgs {
+    const int *comp_ptr, *comp_atoms;
+    int ncomp, niter, npre;
+    double *x, *v, *f0;
+    const double *mass;
+    double c1, d, c2;
+    PreKick pre[3];
+};
+
+template <int MAXC>
+__global__ void __launch_bounds__(256) k_inner_components(BondedArgs A, CompArgs C) {
+    __shared__ double strip[MAXC * 3 * 256];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C.ncomp) return;
+    double *px = strip + threadIdx.x;
+    const int cb = C.comp_ptr[c], n = C.comp_ptr[c + 1] - cb;
+    int at[MAXC];
+    double xk[MAXC][3], vk[MAXC][3], fk[MAXC][3], mk[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        at[k] = k < n ? C.comp_atoms[cb + k] : 0;
+        mk[k] = k < n ? C.mass[at[k]] : 1.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            xk[k][j] = k < n ? C.x[3 * at[k] + j] : 0.0;
+            vk[k][j] = k < n ? C.v[3 * at[k] + j] : 0.0;
+            fk[k][j] = k < n ? C.f0[3 * at[k] + j] : 0.0;
+        }
+    }
+    {
+#pragma clang fp contract(off)
+        for (int p = 0; p < C.npre; ++p) {
+            const PreKick pk = C.pre[p];
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) {
+                if (k < n) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        double ff = pk.a[3 * at[k] + j];
+                        if (pk.b) ff = pk.plus ? ff + pk.b[3 * at[k] + j] : ff - pk.b[3 * at[k] + j];
+                        const double num = pk.coef * ff;
+                        const double dv = num / mk[k];
+                        vk[k][j] = vk[k][j] + dv;
+                    }
+                }
+            }
+        }
+    }
+    PosLocal pos{px};
+    for (int it = 0; it < C.niter; ++it) {
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double num = C.c1 * fk[k][j];
+                    const double dv = num / mk[k];
+                    vk[k][j] = vk[k][j] + dv;
+                    const double dx = C.d * vk[k][j];
+                    xk[k][j] = xk[k][j] + dx;
+                    px[(k * 3 + j) * 256] = xk[k][j];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            if (k < n) {
+                double f[3] = {0.0, 0.0, 0.0}, e = 0.0;
+                bonded_atom<PosLocal, true>(A, pos, at[k], k, f, e);
+                fk[k][0] = f[0]; fk[k][1] = f[1]; fk[k][2] = f[2];
+            }
+        }
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double num = C.c2 * fk[k][j];
+                    const double dv = num / mk[k];
+                    vk[k][j] = vk[k][j] + dv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        if (k < n) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                C.x[3 * at[k] + j] = xk[k][j];
+                C.v[3 * at[k] + j] = vk[k][j];
+                C.f0[3 * at[k] + j] = fk[k][j];
+            }
         }
     }
 }
@@ -266,6 +383,59 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
                 std::memcpy(&w, &code, sizeof(w));
                 rec_q[slot] = make_double4(pr[0], pr[1], pr[2], w);
             }
+    // connected components of the term graph (union-find); component kernel if all are small
+    std::vector<int> parent(n);
+    for (int i = 0; i < n; ++i) parent[i] = i;
+    auto find = [&](int a) {
+        while (parent[a] != a) {
+            parent[a] = parent[parent[a]];
+            a = parent[a];
+        }
+        return a;
+    };
+    for (int kind = 0; kind < 6; ++kind)
+        for (int t = 0; t < bs->n_terms[kind]; ++t)
+            for (int r = 1; r < kArity[kind]; ++r) {
+                int a = find(bs->h_idx[kind][t * kArity[kind]]), b = find(bs->h_idx[kind][t * kArity[kind] + r]);
+                if (a != b) parent[std::max(a, b)] = std::min(a, b);
+            }
+    std::vector<int> comp_of(n), csize;
+    std::vector<int> root_to_comp(n, -1);
+    for (int i = 0; i < n; ++i) {           // components numbered by their smallest atom -> ascending, deterministic
+        int r = find(i);
+        if (root_to_comp[r] < 0) {
+            root_to_comp[r] = (int)csize.size();
+            csize.push_back(0);
+        }
+        comp_of[i] = root_to_comp[r];
+        csize[comp_of[i]]++;
+    }
+    const int ncomp = (int)csize.size();
+    int maxc = 0;
+    for (int c2 = 0; c2 < ncomp; ++c2) maxc = std::max(maxc, csize[c2]);
+    std::vector<int> comp_ptr(ncomp + 1, 0), comp_atoms(n), local_of(n);
+    for (int c2 = 0; c2 < ncomp; ++c2) comp_ptr[c2 + 1] = comp_ptr[c2] + csize[c2];
+    {
+        std::vector<int> fillc(comp_ptr.begin(), comp_ptr.end() - 1);
+        for (int i = 0; i < n; ++i) {
+            local_of[i] = fillc[comp_of[i]] - comp_ptr[comp_of[i]];
+            comp_atoms[fillc[comp_of[i]]++] = i;
+        }
+    }
+    std::vector<int4> rec_l(nref);
+    for (size_t r = 0; r < nref; ++r) {
+        const int4 a = rec_a[r];
+        rec_l[r] = make_int4(a.x >= 0 ? local_of[a.x] : -1, a.y >= 0 ? local_of[a.y] : -1, a.z >= 0 ? local_of[a.z] : -1,
+                             a.w >= 0 ? local_of[a.w] : -1);
+    }
+    bs->ncomp = ncomp;
+    bs->max_comp = maxc;
+    AMM_HIP(hipMalloc(&bs->d_comp_ptr, sizeof(int) * (ncomp + 1)));
+    AMM_HIP(hipMemcpy(bs->d_comp_ptr, comp_ptr.data(), sizeof(int) * (ncomp + 1), hipMemcpyHostToDevice));
+    AMM_HIP(hipMalloc(&bs->d_comp_atoms, sizeof(int) * n));
+    AMM_HIP(hipMemcpy(bs->d_comp_atoms, comp_atoms.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    AMM_HIP(hipMalloc(&bs->d_rec_l, sizeof(int4) * std::max<size_t>(nref, 1)));
+    if (nref) AMM_HIP(hipMemcpy(bs->d_rec_l, rec_l.data(), sizeof(int4) * nref, hipMemcpyHostToDevice));
     AMM_HIP(hipMalloc(&bs->d_ref_ptr, sizeof(int) * (n + 1)));
     AMM_HIP(hipMemcpy(bs->d_ref_ptr, cnt.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
     AMM_HIP(hipMalloc(&bs->d_rec_a, sizeof(int4) * std::max<size_t>(nref, 1)));
@@ -300,6 +470,7 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
     A.ref_ptr = bs->d_ref_ptr;
     A.rec_a = bs->d_rec_a;
     A.rec_q = bs->d_rec_q;
+    A.rec_l = bs->d_rec_l;
     A.pos = d_pos;
     A.force = d_force;
     A.epart = bs->d_epart;
@@ -328,6 +499,7 @@ int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const 
     A.ref_ptr = bs->d_ref_ptr;
     A.rec_a = bs->d_rec_a;
     A.rec_q = bs->d_rec_q;
+    A.rec_l = bs->d_rec_l;
     A.pos = nullptr;
     A.force = nullptr;
     A.epart = nullptr;
@@ -344,10 +516,60 @@ int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const 
     return 0;
 }
 
+int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v, double *f0, int npre, const double *const *pre_a,
+                              const double *const *pre_b, const double *pre_coef, const int *pre_plus, double c1, double d,
+                              double c2, int niter) {
+    BondedArgs A;
+    A.n = ctx->n;
+    A.row_begin = 0;
+    A.row_end = ctx->n;
+    A.ref_ptr = bs->d_ref_ptr;
+    A.rec_a = bs->d_rec_a;
+    A.rec_q = bs->d_rec_q;
+    A.rec_l = bs->d_rec_l;
+    A.pos = nullptr;
+    A.force = nullptr;
+    A.epart = nullptr;
+    A.accumulate = 0;
+    A.want_energy = 0;
+    A.box = ctx->box;
+    A.near_pc = bs->near_pc;
+    A.ewald_alpha = bs->ewald_alpha;
+    A.ewald_tasp = bs->ewald_alpha * 1.1283791670955125739;
+    A.Kc_ljc = bs->ljc_Kc;
+    CompArgs C;
+    C.comp_ptr = bs->d_comp_ptr;
+    C.comp_atoms = bs->d_comp_atoms;
+    C.ncomp = bs->ncomp;
+    C.niter = niter;
+    C.npre = npre;
+    C.x = x;
+    C.v = v;
+    C.f0 = f0;
+    C.mass = ctx->d_mass;
+    C.c1 = c1;
+    C.d = d;
+    C.c2 = c2;
+    for (int p = 0; p < 3; ++p) {
+        C.pre[p].a = p < npre ? pre_a[p] : nullptr;
+        C.pre[p].b = p < npre ? pre_b[p] : nullptr;
+        C.pre[p].coef = p < npre ? pre_coef[p] : 0.0;
+        C.pre[p].plus = p < npre ? pre_plus[p] : 0;
+    }
+    dim3 grid((bs->ncomp + 255) / 256), block(256);
+    if (bs->max_comp <= 4) hipLaunchKernelGGL((k_inner_components<4>), grid, block, 0, ctx->stream, A, C);
+    else hipLaunchKernelGGL((k_inner_components<8>), grid, block, 0, ctx->stream, A, C);
+    AMM_HIP(hipGetLastError());
+    return 0;
+}
+
 int amm_bonded_free(BondedSet *bs) {
     if (bs->d_ref_ptr) (void)hipFree(bs->d_ref_ptr);
     if (bs->d_rec_a) (void)hipFree(bs->d_rec_a);
     if (bs->d_rec_q) (void)hipFree(bs->d_rec_q);
+    if (bs->d_rec_l) (void)hipFree(bs->d_rec_l);
+    if (bs->d_comp_ptr) (void)hipFree(bs->d_comp_ptr);
+    if (bs->d_comp_atoms) (void)hipFree(bs->d_comp_atoms);
     if (bs->d_epart) (void)hipFree(bs->d_epart);
     return 0;
 }
