@@ -70,6 +70,111 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// Forces of ONE bond-list term on all of its atoms (fo[role][xyz]) and its energy.  Every path (owner-computes
+// per atom, fused inner iteration, component kernel) goes through this one function, so they agree bit for bit;
+// roles are related by exact IEEE symmetries (x_j - x_i = -(x_i - x_j), rint odd), e.g. f_1 = -f_0 for a bond.
+template <class P>
+__device__ __forceinline__ void bonded_term_forces(const BondedArgs &A, const P &pos, const int *ix, const double *p, int kind,
+                                                   int periodic, double fo[4][3], double &e) {
+    switch (kind) {
+    case AMM_BOND_HARMONIC: {
+        double d[3];
+        delta3(pos, ix[0], ix[1], A.box, periodic, d);
+        const double rr = sqrt(dot3(d, d));
+        const double dr = rr - p[0];
+        const double fr = -p[1] * dr / rr;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            fo[0][x] = fr * d[x];
+            fo[1][x] = -fo[0][x];
+        }
+        e = 0.5 * p[1] * dr * dr;
+    } break;
+    case AMM_ANGLE_HARMONIC: {
+        double d1[3], d2[3];
+        delta3(pos, ix[0], ix[1], A.box, periodic, d1);
+        delta3(pos, ix[2], ix[1], A.box, periodic, d2);
+        const double r1 = sqrt(dot3(d1, d1)), r2 = sqrt(dot3(d2, d2));
+        double c = dot3(d1, d2) / (r1 * r2);
+        c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+        const double th = acos(c), dth = th - p[0];
+        double sn = sqrt(1.0 - c * c);
+        if (sn < 1e-12) sn = 1e-12;
+        const double g = p[1] * dth / sn;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            const double fi = g * (d2[x] / r2 - c * d1[x] / r1) / r1;
+            const double fk = g * (d1[x] / r1 - c * d2[x] / r2) / r2;
+            fo[0][x] = fi;
+            fo[2][x] = fk;
+            fo[1][x] = -(fi + fk);
+        }
+        e = 0.5 * p[1] * dth * dth;
+    } break;
+    case AMM_BOND_LJC:
+    case AMM_BOND_NEAR: {
+        double d[3];
+        delta3(pos, ix[0], ix[1], A.box, periodic, d);
+        const double r2 = dot3(d, d);
+        double fr;
+        if (kind == AMM_BOND_LJC) {   // forces.py:406
+            const double rinv2 = 1.0 / r2, rinv = sqrt(rinv2);
+            const double s2 = p[1] * p[1] * rinv2, x6 = s2 * s2 * s2;
+            e = 4.0 * p[2] * x6 * (x6 - 1.0) + A.Kc_ljc * p[0] * rinv;
+            fr = (4.0 * p[2] * (12.0 * x6 * x6 - 6.0 * x6) + A.Kc_ljc * p[0] * rinv) * rinv2;
+        } else {
+            amm_pair_math_rt(A.near_pc, r2, A.near_pc.Kc * p[0], p[1], 4.0 * p[2], e, fr);
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            fo[0][x] = fr * d[x];
+            fo[1][x] = -fo[0][x];
+        }
+    } break;
+    case AMM_BOND_EWALD_EXCL: {
+        const double qq = p[0];
+        double d[3];
+        delta3(pos, ix[0], ix[1], A.box, 1, d);
+        const double r2 = dot3(d, d), rr = sqrt(r2), ar = A.ewald_alpha * rr;
+        const double er = erf(ar);
+        // E = -qq erf(ar)/r ;  -dE/dr = qq [ tasp exp(-a^2 r^2)/r - erf(ar)/r^2 ]
+        const double fr = qq * (A.ewald_tasp * exp(-ar * ar) / rr - er / r2) / rr;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            fo[0][x] = fr * d[x];
+            fo[1][x] = -fo[0][x];
+        }
+        e = -qq * er / rr;
+    } break;
+    case AMM_TORSION_PERIODIC: {
+        double F[3], G[3], H[3], Av[3], Bv[3], BA[3];
+        delta3(pos, ix[0], ix[1], A.box, periodic, F);
+        delta3(pos, ix[1], ix[2], A.box, periodic, G);
+        delta3(pos, ix[3], ix[2], A.box, periodic, H);
+        cross3(F, G, Av);
+        cross3(H, G, Bv);
+        cross3(Bv, Av, BA);
+        const double Gn = sqrt(dot3(G, G));
+        const double phi = atan2(dot3(BA, G) / Gn, dot3(Av, Bv));
+        const double nper = p[0];
+        const double dEdphi = -p[2] * nper * sin(nper * phi - p[1]);
+        const double A2 = dot3(Av, Av), B2 = dot3(Bv, Bv), FG = dot3(F, G), HG = dot3(H, G);
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            const double gi = -Gn / A2 * Av[x], gl = Gn / B2 * Bv[x];
+            const double gj = Gn / A2 * Av[x] + FG / (A2 * Gn) * Av[x] - HG / (B2 * Gn) * Bv[x];
+            const double gk = -Gn / B2 * Bv[x] - FG / (A2 * Gn) * Av[x] + HG / (B2 * Gn) * Bv[x];
+            fo[0][x] = -(dEdphi * gi);
+            fo[1][x] = -(dEdphi * gj);
+            fo[2][x] = -(dEdphi * gk);
+            fo[3][x] = -(dEdphi * gl);
+        }
+        e = p[2] * (1.0 + cos(nper * phi - p[1]));
+    } break;
+    default: e = 0.0; break;
+    }
+}
+
 // force on atom i (and, for role-0 references, the energy) of every bond-list term that contains it
 template <class P, bool LOCAL = false>
 __device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, int iglobal, int i, double *f, double &esum) {
@@ -81,91 +186,11 @@ __device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, i
         const int kind = (int)(code & 7), role = (int)((code >> 3) & 3), periodic = (int)((code >> 5) & 1);
         const int ix[4] = {at.x, at.y, at.z, at.w};
         const double p[3] = {q.x, q.y, q.z};
-        switch (kind) {
-        case AMM_BOND_HARMONIC: {
-            const int other = ix[1 - role];
-            double d[3];
-            delta3(pos, i, other, A.box, periodic, d);
-            const double rr = sqrt(dot3(d, d));
-            const double dr = rr - p[0];
-            const double fr = -p[1] * dr / rr;
-            f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
-            if (role == 0) esum += 0.5 * p[1] * dr * dr;
-        } break;
-        case AMM_ANGLE_HARMONIC: {
-            double d1[3], d2[3];
-            delta3(pos, ix[0], ix[1], A.box, periodic, d1);
-            delta3(pos, ix[2], ix[1], A.box, periodic, d2);
-            const double r1 = sqrt(dot3(d1, d1)), r2 = sqrt(dot3(d2, d2));
-            double c = dot3(d1, d2) / (r1 * r2);
-            c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
-            const double th = acos(c), dth = th - p[0];
-            double sn = sqrt(1.0 - c * c);
-            if (sn < 1e-12) sn = 1e-12;
-            const double g = p[1] * dth / sn;
+        double fo[4][3], e;
+        bonded_term_forces(A, pos, ix, p, kind, periodic, fo, e);
 #pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                const double fi = g * (d2[x] / r2 - c * d1[x] / r1) / r1;
-                const double fk = g * (d1[x] / r1 - c * d2[x] / r2) / r2;
-                f[x] += role == 0 ? fi : (role == 2 ? fk : -(fi + fk));
-            }
-            if (role == 0) esum += 0.5 * p[1] * dth * dth;
-        } break;
-        case AMM_BOND_LJC:
-        case AMM_BOND_NEAR: {
-            const int other = ix[1 - role];
-            double d[3];
-            delta3(pos, i, other, A.box, periodic, d);
-            const double r2 = dot3(d, d);
-            double e, fr;
-            if (kind == AMM_BOND_LJC) {   // forces.py:406
-                const double rinv2 = 1.0 / r2, rinv = sqrt(rinv2);
-                const double s2 = p[1] * p[1] * rinv2, x6 = s2 * s2 * s2;
-                e = 4.0 * p[2] * x6 * (x6 - 1.0) + A.Kc_ljc * p[0] * rinv;
-                fr = (4.0 * p[2] * (12.0 * x6 * x6 - 6.0 * x6) + A.Kc_ljc * p[0] * rinv) * rinv2;
-            } else {
-                amm_pair_math_rt(A.near_pc, r2, A.near_pc.Kc * p[0], p[1], 4.0 * p[2], e, fr);
-            }
-            f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
-            if (role == 0) esum += e;
-        } break;
-        case AMM_BOND_EWALD_EXCL: {
-            const double qq = p[0];
-            const int other = ix[1 - role];
-            double d[3];
-            delta3(pos, i, other, A.box, 1, d);
-            const double r2 = dot3(d, d), rr = sqrt(r2), ar = A.ewald_alpha * rr;
-            const double er = erf(ar);
-            // E = -qq erf(ar)/r ;  -dE/dr = qq [ tasp exp(-a^2 r^2)/r - erf(ar)/r^2 ]
-            const double fr = qq * (A.ewald_tasp * exp(-ar * ar) / rr - er / r2) / rr;
-            f[0] += fr * d[0]; f[1] += fr * d[1]; f[2] += fr * d[2];
-            if (role == 0) esum += -qq * er / rr;
-        } break;
-        case AMM_TORSION_PERIODIC: {
-            double F[3], G[3], H[3], Av[3], Bv[3], BA[3];
-            delta3(pos, ix[0], ix[1], A.box, periodic, F);
-            delta3(pos, ix[1], ix[2], A.box, periodic, G);
-            delta3(pos, ix[3], ix[2], A.box, periodic, H);
-            cross3(F, G, Av);
-            cross3(H, G, Bv);
-            cross3(Bv, Av, BA);
-            const double Gn = sqrt(dot3(G, G));
-            const double phi = atan2(dot3(BA, G) / Gn, dot3(Av, Bv));
-            const double nper = p[0];
-            const double dEdphi = -p[2] * nper * sin(nper * phi - p[1]);
-            const double A2 = dot3(Av, Av), B2 = dot3(Bv, Bv), FG = dot3(F, G), HG = dot3(H, G);
-#pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                const double gi = -Gn / A2 * Av[x], gl = Gn / B2 * Bv[x];
-                const double gj = Gn / A2 * Av[x] + FG / (A2 * Gn) * Av[x] - HG / (B2 * Gn) * Bv[x];
-                const double gk = -Gn / B2 * Bv[x] - FG / (A2 * Gn) * Av[x] + HG / (B2 * Gn) * Bv[x];
-                const double g = role == 0 ? gi : (role == 1 ? gj : (role == 2 ? gk : gl));
-                f[x] -= dEdphi * g;
-            }
-            if (role == 0) esum += p[2] * (1.0 + cos(nper * phi - p[1]));
-        } break;
-        default: break;
-        }
+        for (int x = 0; x < 3; ++x) f[x] += role == 0 ? fo[0][x] : (role == 1 ? fo[1][x] : (role == 2 ? fo[2][x] : fo[3][x]));
+        if (role == 0) esum += e;
     }
 }
 
@@ -230,9 +255,17 @@ __global__ void __launch_bounds__(256) k_fused_inner(BondedArgs A, FusedArgs F) 
 // with positions in a thread-private LDS strip (dynamic indexing by the term records), velocities/forces in
 // registers: one launch instead of 4*n0, no inter-thread dependence at all, same arithmetic and rounding as the
 // separate kernels (bit-identical).  Used when every component has at most MAXC atoms.
-struct PosLocal {
-    const double *lds;   // base of this thread's strip: element (slot*3+k) at lds[(slot*3+k)*256]
-    __device__ __forceinline__ double get(int slot, int k) const { return lds[(slot * 3 + k) * 256]; }
+template <int MAXC>
+struct PosRegs {
+    // positions of the component's atoms live in registers; a runtime slot is resolved by a select chain
+    // (an LDS strip costs a ~100-cycle dependent read per access: measured 4x slower at half a wave per SIMD)
+    const double (*x)[3];
+    __device__ __forceinline__ double get(int slot, int k) const {
+        double r = x[0][k];
+#pragma unroll
+        for (int s = 1; s < MAXC; ++s) r = slot == s ? x[s][k] : r;
+        return r;
+    }
 };
 
 struct PreKick {
@@ -243,6 +276,7 @@ struct PreKick {
 
 struct CompArgs {
     const int *comp_ptr, *comp_atoms;
+    const int *cterm_ptr, *cterm_rec;   // terms of each component: index of the term's role-0 record, (kind, term) order
     int ncomp, niter, npre;
     double *x, *v, *f0;
     const double *mass;
@@ -252,10 +286,8 @@ struct CompArgs {
 
 template <int MAXC>
 __global__ void __launch_bounds__(256) k_inner_components(BondedArgs A, CompArgs C) {
-    __shared__ double strip[MAXC * 3 * 256];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C.ncomp) return;
-    double *px = strip + threadIdx.x;
     const int cb = C.comp_ptr[c], n = C.comp_ptr[c + 1] - cb;
     int at[MAXC];
     double xk[MAXC][3], vk[MAXC][3], fk[MAXC][3], mk[MAXC];
@@ -289,7 +321,18 @@ __global__ void __launch_bounds__(256) k_inner_components(BondedArgs A, CompArgs
             }
         }
     }
-    PosLocal pos{px};
+    PosRegs<MAXC> pos{xk};
+    // the component's term records stay in registers across the iterations (first MAXT terms; the rest is re-read)
+    constexpr int MAXT = MAXC <= 4 ? 4 : 12;
+    const int tb = C.cterm_ptr[c], nterm = C.cterm_ptr[c + 1] - tb;
+    int4 tl[MAXT];
+    double4 tq[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int r = t < nterm ? C.cterm_rec[tb + t] : 0;
+        tl[t] = A.rec_l[r];
+        tq[t] = A.rec_q[r];
+    }
     for (int it = 0; it < C.niter; ++it) {
         {
 #pragma clang fp contract(off)
@@ -302,17 +345,35 @@ __global__ void __launch_bounds__(256) k_inner_components(BondedArgs A, CompArgs
                     vk[k][j] = vk[k][j] + dv;
                     const double dx = C.d * vk[k][j];
                     xk[k][j] = xk[k][j] + dx;
-                    px[(k * 3 + j) * 256] = xk[k][j];
                 }
             }
         }
+        // every term of the component ONCE, in (kind, term) order = the order of each atom's own reference list,
+        // so the per-atom sums match the owner-computes kernels bit for bit
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) {
-            if (k < n) {
-                double f[3] = {0.0, 0.0, 0.0}, e = 0.0;
-                bonded_atom<PosLocal, true>(A, pos, at[k], k, f, e);
-                fk[k][0] = f[0]; fk[k][1] = f[1]; fk[k][2] = f[2];
+        for (int k = 0; k < MAXC; ++k) fk[k][0] = fk[k][1] = fk[k][2] = 0.0;
+        auto do_term = [&](const int4 al, const double4 q) {
+            const long long code = __double_as_longlong(q.w);
+            const int kind = (int)(code & 7), periodic = (int)((code >> 5) & 1);
+            const int ix[4] = {al.x, al.y, al.z, al.w};
+            const double p[3] = {q.x, q.y, q.z};
+            double fo[4][3], e;
+            bonded_term_forces(A, pos, ix, p, kind, periodic, fo, e);
+#pragma unroll
+            for (int role = 0; role < 4; ++role) {
+#pragma unroll
+                for (int sl = 0; sl < MAXC; ++sl) {
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) fk[sl][x] = ix[role] == sl ? fk[sl][x] + fo[role][x] : fk[sl][x];
+                }
             }
+        };
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (t < nterm) do_term(tl[t], tq[t]);
+        for (int t = MAXT; t < nterm; ++t) {
+            const int r = C.cterm_rec[tb + t];
+            do_term(A.rec_l[r], A.rec_q[r]);
         }
         {
 #pragma clang fp contract(off)
@@ -428,6 +489,36 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
         rec_l[r] = make_int4(a.x >= 0 ? local_of[a.x] : -1, a.y >= 0 ? local_of[a.y] : -1, a.z >= 0 ? local_of[a.z] : -1,
                              a.w >= 0 ? local_of[a.w] : -1);
     }
+    // terms per component, (kind, t) ascending; each entry = slot of the term's role-0 record
+    std::vector<int> role0_slot_of_term[6];
+    {
+        std::vector<int> fill2(cnt.begin(), cnt.end() - 1);
+        for (int kind = 0; kind < 6; ++kind) {
+            role0_slot_of_term[kind].assign(bs->n_terms[kind], -1);
+            for (int t = 0; t < bs->n_terms[kind]; ++t)
+                for (int r = 0; r < kArity[kind]; ++r) {
+                    const int a = bs->h_idx[kind][t * kArity[kind] + r];
+                    const int slot = fill2[a]++;
+                    if (r == 0) role0_slot_of_term[kind][t] = slot;
+                }
+        }
+    }
+    std::vector<int> cterm_ptr(ncomp + 1, 0);
+    for (int kind = 0; kind < 6; ++kind)
+        for (int t = 0; t < bs->n_terms[kind]; ++t) cterm_ptr[comp_of[bs->h_idx[kind][t * kArity[kind]]] + 1]++;
+    for (int c2 = 0; c2 < ncomp; ++c2) cterm_ptr[c2 + 1] += cterm_ptr[c2];
+    std::vector<int> cterm_rec(cterm_ptr[ncomp]);
+    {
+        std::vector<int> fill3(cterm_ptr.begin(), cterm_ptr.end() - 1);
+        for (int kind = 0; kind < 6; ++kind)
+            for (int t = 0; t < bs->n_terms[kind]; ++t)
+                cterm_rec[fill3[comp_of[bs->h_idx[kind][t * kArity[kind]]]]++] = role0_slot_of_term[kind][t];
+    }
+    AMM_HIP(hipMalloc(&bs->d_cterm_ptr, sizeof(int) * (ncomp + 1)));
+    AMM_HIP(hipMemcpy(bs->d_cterm_ptr, cterm_ptr.data(), sizeof(int) * (ncomp + 1), hipMemcpyHostToDevice));
+    AMM_HIP(hipMalloc(&bs->d_cterm_rec, sizeof(int) * std::max<size_t>(cterm_rec.size(), 1)));
+    if (!cterm_rec.empty())
+        AMM_HIP(hipMemcpy(bs->d_cterm_rec, cterm_rec.data(), sizeof(int) * cterm_rec.size(), hipMemcpyHostToDevice));
     bs->ncomp = ncomp;
     bs->max_comp = maxc;
     AMM_HIP(hipMalloc(&bs->d_comp_ptr, sizeof(int) * (ncomp + 1)));
@@ -540,6 +631,8 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     CompArgs C;
     C.comp_ptr = bs->d_comp_ptr;
     C.comp_atoms = bs->d_comp_atoms;
+    C.cterm_ptr = bs->d_cterm_ptr;
+    C.cterm_rec = bs->d_cterm_rec;
     C.ncomp = bs->ncomp;
     C.niter = niter;
     C.npre = npre;
@@ -570,6 +663,8 @@ int amm_bonded_free(BondedSet *bs) {
     if (bs->d_rec_l) (void)hipFree(bs->d_rec_l);
     if (bs->d_comp_ptr) (void)hipFree(bs->d_comp_ptr);
     if (bs->d_comp_atoms) (void)hipFree(bs->d_comp_atoms);
+    if (bs->d_cterm_ptr) (void)hipFree(bs->d_cterm_ptr);
+    if (bs->d_cterm_rec) (void)hipFree(bs->d_cterm_rec);
     if (bs->d_epart) (void)hipFree(bs->d_epart);
     return 0;
 }

@@ -21,6 +21,7 @@ def _free_port():
 
 def _worker(rank, world, port, fn, ret):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')      # no hostname resolution on the box
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -39,7 +40,11 @@ def run_ranks(fn, world=2):
             p.start()
         for p in procs:
             p.join(120)
-            assert p.exitcode == 0
+        stuck = [p for p in procs if p.is_alive()]
+        for p in stuck:
+            p.kill()
+        assert not stuck, 'a rank did not finish within 120 s'
+        assert all(p.exitcode == 0 for p in procs)
         return dict(ret)
 
 

@@ -47,6 +47,7 @@ def _simulate(nsteps):
 def _worker(rank, world, port, ret):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')      # no hostname resolution on the box
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -67,8 +68,12 @@ def test_two_ranks_match_single_rank_bit_for_bit():
         for p in procs:
             p.start()
         for p in procs:
-            p.join(300)
-            assert p.exitcode == 0
+            p.join(90)
+        stuck = [p for p in procs if p.is_alive()]
+        for p in stuck:          # never leave a rank behind on the GPU box
+            p.kill()
+        assert not stuck, 'a rank did not finish within 90 s'
+        assert all(p.exitcode == 0 for p in procs)
         out = dict(ret)
     for r in (0, 1):
         assert out[r]['world'] == 2 and out[r]['slice_atoms'] == 1500
