@@ -80,9 +80,10 @@ __device__ __forceinline__ void bonded_term_forces(const BondedArgs &A, const P 
     case AMM_BOND_HARMONIC: {
         double d[3];
         delta3(pos, ix[0], ix[1], A.box, periodic, d);
-        const double rr = sqrt(dot3(d, d));
-        const double dr = rr - p[0];
-        const double fr = -p[1] * dr / rr;
+        const double r2 = dot3(d, d);
+        const double rinv = amm_rsqrt(r2);         // reciprocal-sqrt + Newton: no IEEE sqrt/divide sequences
+        const double dr = r2 * rinv - p[0];
+        const double fr = -p[1] * dr * rinv;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
             fo[0][x] = fr * d[x];
@@ -94,17 +95,18 @@ __device__ __forceinline__ void bonded_term_forces(const BondedArgs &A, const P 
         double d1[3], d2[3];
         delta3(pos, ix[0], ix[1], A.box, periodic, d1);
         delta3(pos, ix[2], ix[1], A.box, periodic, d2);
-        const double r1 = sqrt(dot3(d1, d1)), r2 = sqrt(dot3(d2, d2));
-        double c = dot3(d1, d2) / (r1 * r2);
+        const double i1 = amm_rsqrt(dot3(d1, d1)), i2 = amm_rsqrt(dot3(d2, d2));
+        double c = dot3(d1, d2) * i1 * i2;
         c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
         const double th = acos(c), dth = th - p[0];
-        double sn = sqrt(1.0 - c * c);
-        if (sn < 1e-12) sn = 1e-12;
-        const double g = p[1] * dth / sn;
+        double s2 = 1.0 - c * c;
+        if (s2 < 1e-24) s2 = 1e-24;
+        const double g = p[1] * dth * amm_rsqrt(s2);
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-            const double fi = g * (d2[x] / r2 - c * d1[x] / r1) / r1;
-            const double fk = g * (d1[x] / r1 - c * d2[x] / r2) / r2;
+            const double u1 = d1[x] * i1, u2 = d2[x] * i2;      // unit vectors
+            const double fi = g * (u2 - c * u1) * i1;
+            const double fk = g * (u1 - c * u2) * i2;
             fo[0][x] = fi;
             fo[2][x] = fk;
             fo[1][x] = -(fi + fk);
@@ -291,15 +293,18 @@ __global__ void __launch_bounds__(256) k_inner_components(BondedArgs A, CompArgs
     const int cb = C.comp_ptr[c], n = C.comp_ptr[c + 1] - cb;
     int at[MAXC];
     double xk[MAXC][3], vk[MAXC][3], fk[MAXC][3], mk[MAXC];
+    // all loads unconditional and issued back to back (slots beyond the component alias its first atom and are
+    // never stored): a chain of exec-masked loads would serialise ~40 memory round trips
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) at[k] = C.comp_atoms[cb + (k < n ? k : 0)];
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
-        at[k] = k < n ? C.comp_atoms[cb + k] : 0;
-        mk[k] = k < n ? C.mass[at[k]] : 1.0;
+        mk[k] = C.mass[at[k]];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            xk[k][j] = k < n ? C.x[3 * at[k] + j] : 0.0;
-            vk[k][j] = k < n ? C.v[3 * at[k] + j] : 0.0;
-            fk[k][j] = k < n ? C.f0[3 * at[k] + j] : 0.0;
+            xk[k][j] = C.x[3 * at[k] + j];
+            vk[k][j] = C.v[3 * at[k] + j];
+            fk[k][j] = C.f0[3 * at[k] + j];
         }
     }
     {
@@ -308,15 +313,13 @@ __global__ void __launch_bounds__(256) k_inner_components(BondedArgs A, CompArgs
             const PreKick pk = C.pre[p];
 #pragma unroll
             for (int k = 0; k < MAXC; ++k) {
-                if (k < n) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        double ff = pk.a[3 * at[k] + j];
-                        if (pk.b) ff = pk.plus ? ff + pk.b[3 * at[k] + j] : ff - pk.b[3 * at[k] + j];
-                        const double num = pk.coef * ff;
-                        const double dv = num / mk[k];
-                        vk[k][j] = vk[k][j] + dv;
-                    }
+                for (int j = 0; j < 3; ++j) {
+                    double ff = pk.a[3 * at[k] + j];
+                    if (pk.b) ff = pk.plus ? ff + pk.b[3 * at[k] + j] : ff - pk.b[3 * at[k] + j];
+                    const double num = pk.coef * ff;
+                    const double dv = num / mk[k];
+                    vk[k][j] = vk[k][j] + dv;
                 }
             }
         }
@@ -361,6 +364,7 @@ __global__ void __launch_bounds__(256) k_inner_components(BondedArgs A, CompArgs
             bonded_term_forces(A, pos, ix, p, kind, periodic, fo, e);
 #pragma unroll
             for (int role = 0; role < 4; ++role) {
+                if (ix[role] < 0) continue;          // same for every lane of a homogeneous solvent: cheap uniform skip
 #pragma unroll
                 for (int sl = 0; sl < MAXC; ++sl) {
 #pragma unroll
