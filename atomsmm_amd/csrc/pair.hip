@@ -210,14 +210,17 @@ struct BoxF {
     float L[3], invL[3];
 };
 
-// neighbour-list build: one wavefront per (cell, part).  All i-atoms of a cell share the same candidate
-// rows (cells are x-fastest, so the 2h+1 x-neighbours of a (y,z) row are one or two contiguous runs of the
-// sorted arrays): the wave loads a chunk of up to 128 candidates ONCE into registers (coalesced float4
-// loads), shifts it by the periodic image of its run, and tests it against up to AMM_BATCH i-atoms whose
-// coordinates sit one-per-lane and are broadcast with v_readlane.  Range bookkeeping is wave-uniform (scalar
-// registers).  Ordered ballot compaction keeps the list order -- and hence the force summation order --
-// deterministic.  Exclusions are looked up (in sorted-slot space, via inv_perm) only for the rare chunks that
-// overlap the slot range [exlo, exhi] spanned by the atom and its excluded partners.
+// neighbour-list build: one wavefront per (cell, part).  All i-atoms of a cell share the same candidates: the
+// (2h+1)^2 (y,z) rows of the stencil, each one or two contiguous runs of the cell-sorted arrays (cells are
+// x-fastest) with one periodic image per run.  The wave tabulates its runs once (start slot, exclusive prefix of
+// the lengths, image shift; LDS, <= 50 runs) and then walks the CONCATENATED candidate stream in chunks of 128:
+// lane l of a chunk finds its run by binary search of the prefix, loads the candidate (coalesced float4 within
+// a run) and applies the image shift, so every chunk but the last is full whatever the run lengths are.  A chunk
+// is tested against up to AMM_BATCH i-atoms of the cell, whose coordinates, exclusion slot ranges and running
+// list lengths live in scalar registers (the t loop is unrolled).  Ordered ballot compaction keeps the list
+// order -- and hence the force summation order -- deterministic.  Exclusions are looked up (in sorted-slot
+// space, via inv_perm) only for the rare chunks that hold a slot inside the range spanned by the batch's atoms
+// and their excluded partners.
 #define AMM_BCHUNK 128
 #define AMM_BATCH 8
 
@@ -228,30 +231,74 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
                               int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats, int which, int force) {
     if (!force && !flags[which]) return;
-    const int lane = threadIdx.x & 63;
+    __shared__ int s_rstart[4][64];
+    __shared__ int s_rpref[4][64];
+    __shared__ float s_rshift[4][3][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int c = wave / parts, part = wave - c * parts;
     const unsigned long long below = (1ull << lane) - 1ull;
     const float FAR = 1.0e9f;
     unsigned long long wsum = 0, wnear = 0;
     int wmax = 0;
+    int a_begin = 0, a_end = 0;
     if (c < g.ncell) {
-        const int ib = max(__builtin_amdgcn_readfirstlane(cell_start[c]), s_begin);
-        const int ie = min(__builtin_amdgcn_readfirstlane(cell_start[c + 1]), s_end);
+        // this wave's share of the cell's atoms (even split over the parts), clipped to the rank's slice
+        const int cb0 = __builtin_amdgcn_readfirstlane(cell_start[c]), cb1 = __builtin_amdgcn_readfirstlane(cell_start[c + 1]);
+        const int per = (cb1 - cb0 + parts - 1) / parts;
+        a_begin = max(cb0 + part * per, s_begin);
+        a_end = min(min(cb0 + (part + 1) * per, cb1), s_end);
+    }
+    if (a_begin < a_end) {
         const int ncx = g.nc[0], ncy = g.nc[1], ncz = g.nc[2];
         const int cx = c % ncx, cy = (c / ncx) % ncy, cz = c / (ncx * ncy);
-        // x runs: [xa0,xa1] and [xb0,xb1] (second may be empty) with their periodic image (-1, 0, +1)
-        int xa0, xa1, xb0 = 0, xb1 = -1, xsa = 0, xsb = 0;
-        if (ncx < 2 * g.h[0] + 1) {       // stencil would wrap onto itself: visit every cell once (RINT build)
-            xa0 = 0; xa1 = ncx - 1;
-        } else {
-            const int x0 = cx - g.h[0], x1 = cx + g.h[0];
-            if (x0 < 0) { xa0 = x0 + ncx; xa1 = ncx - 1; xb0 = 0; xb1 = x1; xsa = -1; }
-            else if (x1 >= ncx) { xa0 = x0; xa1 = ncx - 1; xb0 = 0; xb1 = x1 - ncx; xsb = 1; }
-            else { xa0 = x0; xa1 = x1; }
+        // ---- run table: lane r describes run r = (oz, oy, seg) ----
+        const int nry = g.nstencil[1], nr = g.nstencil[2] * nry * 2;
+        int rstart = 0, rlen = 0;
+        float rsx = 0.f, rsy = 0.f, rsz = 0.f;
+        if (lane < nr) {
+            const int seg = lane & 1, oy = (lane >> 1) % nry, oz = (lane >> 1) / nry;
+            int nz = ncz < 2 * g.h[2] + 1 ? oz : cz - g.h[2] + oz;
+            rsz = nz < 0 ? -box.L[2] : (nz >= ncz ? box.L[2] : 0.f);
+            nz = nz < 0 ? nz + ncz : (nz >= ncz ? nz - ncz : nz);
+            int ny = ncy < 2 * g.h[1] + 1 ? oy : cy - g.h[1] + oy;
+            rsy = ny < 0 ? -box.L[1] : (ny >= ncy ? box.L[1] : 0.f);
+            ny = ny < 0 ? ny + ncy : (ny >= ncy ? ny - ncy : ny);
+            // x runs: [xa0,xa1] and [xb0,xb1] (second may be empty) with their periodic image (-1, 0, +1)
+            int xa0, xa1, xb0 = 0, xb1 = -1, xsa = 0, xsb = 0;
+            if (ncx < 2 * g.h[0] + 1) {       // stencil would wrap onto itself: visit every cell once (RINT build)
+                xa0 = 0; xa1 = ncx - 1;
+            } else {
+                const int x0 = cx - g.h[0], x1 = cx + g.h[0];
+                if (x0 < 0) { xa0 = x0 + ncx; xa1 = ncx - 1; xb0 = 0; xb1 = x1; xsa = -1; }
+                else if (x1 >= ncx) { xa0 = x0; xa1 = ncx - 1; xb0 = 0; xb1 = x1 - ncx; xsb = 1; }
+                else { xa0 = x0; xa1 = x1; }
+            }
+            const int c0 = seg == 0 ? xa0 : xb0, c1 = seg == 0 ? xa1 : xb1;
+            if (c1 >= c0) {
+                const int row = (nz * ncy + ny) * ncx;
+                rstart = cell_start[row + c0];
+                rlen = cell_start[row + c1 + 1] - rstart;
+                rsx = (float)(seg == 0 ? xsa : xsb) * box.L[0];
+            }
         }
-        for (int tb = ib + part * AMM_BATCH; tb < ie; tb += parts * AMM_BATCH) {
-            const int nt = min(AMM_BATCH, ie - tb);
+        int incl = rlen;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        s_rstart[w][lane] = rstart;
+        s_rpref[w][lane] = incl - rlen;          // exclusive prefix; lanes >= nr hold `total`
+        s_rshift[w][0][lane] = rsx;
+        s_rshift[w][1][lane] = rsy;
+        s_rshift[w][2][lane] = rsz;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        for (int tb = a_begin; tb < a_end; tb += AMM_BATCH) {
+            const int nt = min(AMM_BATCH, a_end - tb);
             float4 my = make_float4(0.f, 0.f, 0.f, 0.f);
             int exlo = 0x7fffffff, exhi = -1;             // slot range of {self, excluded partners}
             if (lane < nt) {
@@ -264,97 +311,107 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                     exhi = max(exhi, es);
                 }
             }
-            // lane t: list lengths of i-atom tb+t.  Row layout: entries with r < rnear fill the row from the front,
-            // the others from the back, so a shorter-ranged force sharing this list walks only the front part.
-            int count = 0, countf = 0;
-            for (int oz = 0; oz < g.nstencil[2]; ++oz) {
-                int nz = ncz < 2 * g.h[2] + 1 ? oz : cz - g.h[2] + oz;
-                const float sz = nz < 0 ? -box.L[2] : (nz >= ncz ? box.L[2] : 0.f);
-                nz = nz < 0 ? nz + ncz : (nz >= ncz ? nz - ncz : nz);
-                for (int oy = 0; oy < g.nstencil[1]; ++oy) {
-                    int ny = ncy < 2 * g.h[1] + 1 ? oy : cy - g.h[1] + oy;
-                    const float sy = ny < 0 ? -box.L[1] : (ny >= ncy ? box.L[1] : 0.f);
-                    ny = ny < 0 ? ny + ncy : (ny >= ncy ? ny - ncy : ny);
-                    const int row = (nz * ncy + ny) * ncx;
-                    for (int seg = 0; seg < 2; ++seg) {
-                        const int c0 = seg == 0 ? xa0 : xb0, c1 = seg == 0 ? xa1 : xb1;
-                        if (c1 < c0) continue;
-                        const float sx = (float)(seg == 0 ? xsa : xsb) * box.L[0];
-                        const int rb = __builtin_amdgcn_readfirstlane(cell_start[row + c0]);
-                        const int re = __builtin_amdgcn_readfirstlane(cell_start[row + c1 + 1]);
-                        for (int jb = rb; jb < re; jb += AMM_BCHUNK) {
-                            const int len = min(AMM_BCHUNK, re - jb);
-                            float4 cand[2];
+            int blo = exlo, bhi = exhi;                   // batch-wide range
+            for (int off = 32; off > 0; off >>= 1) {
+                blo = min(blo, __shfl_xor(blo, off));
+                bhi = max(bhi, __shfl_xor(bhi, off));
+            }
+            blo = __builtin_amdgcn_readfirstlane(blo);
+            bhi = __builtin_amdgcn_readfirstlane(bhi);
+            float px[AMM_BATCH], py[AMM_BATCH], pz[AMM_BATCH];
+            int cnt[AMM_BATCH], cntf[AMM_BATCH];
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                const int idx = u * 64 + lane;
-                                const bool in = idx < len;
-                                float4 q = pos4f_s[jb + (in ? idx : 0)];
-                                if (RINT) {
-                                    q.w = in ? 1.f : 0.f;
-                                } else {                 // image shift; lanes beyond the run are parked far away
-                                    q.x = in ? q.x + sx : FAR;
-                                    q.y = in ? q.y + sy : FAR;
-                                    q.z = in ? q.z + sz : FAR;
-                                }
-                                cand[u] = q;
-                            }
-                            for (int t = 0; t < nt; ++t) {
-                                const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.x), t));
-                                const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.y), t));
-                                const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.z), t));
-                                const int lo = __builtin_amdgcn_readlane(exlo, t), hi = __builtin_amdgcn_readlane(exhi, t);
-                                const bool special = (lo < jb + len) && (hi >= jb);     // wave-uniform, rare
-                                int cnt = __builtin_amdgcn_readlane(count, t), cntf = __builtin_amdgcn_readlane(countf, t);
-                                int *row_out = nl + (size_t)(tb + t - s_begin) * cap;
+            for (int t = 0; t < AMM_BATCH; ++t) {
+                px[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.x), t));
+                py[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.y), t));
+                pz[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.z), t));
+                cnt[t] = 0;
+                cntf[t] = 0;
+            }
+            // Row layout: entries with r < rnear fill the row from the front, the others from the back, so a
+            // shorter-ranged force sharing this list walks only the front part.
+            for (int cb = 0; cb < total; cb += AMM_BCHUNK) {
+                float4 cand[2];
+                int js[2];
+                bool inr = false;
 #pragma unroll
-                                for (int u = 0; u < 2; ++u) {
-                                    if (u * 64 >= len) continue;                        // wave-uniform
-                                    const int js = jb + u * 64 + lane;
-                                    float dx = px - cand[u].x, dy = py - cand[u].y, dz = pz - cand[u].z;
-                                    if (RINT) {
-                                        dx -= box.L[0] * rintf(dx * box.invL[0]);
-                                        dy -= box.L[1] * rintf(dy * box.invL[1]);
-                                        dz -= box.L[2] * rintf(dz * box.invL[2]);
-                                    }
-                                    const float r2 = dx * dx + dy * dy + dz * dz;
-                                    bool pass = r2 < rlist2;
-                                    if (RINT) pass = pass && (cand[u].w != 0.f);
-                                    if (special && pass) {
-                                        const int st = tb + t;
-                                        if (js == st) pass = false;
-                                        const int i = perm[st];
-                                        for (int k = excl_ptr[i]; k < excl_ptr[i + 1]; ++k)
-                                            if (inv_perm[excl_idx[k]] == js) pass = false;
-                                    }
-                                    const bool nearp = pass && (r2 < rnear2);
-                                    const unsigned long long bal = __ballot(nearp), balf = __ballot(pass && !nearp);
-                                    if (pass && !COUNT_ONLY) {
-                                        const int pos_in = nearp ? cnt + __popcll(bal & below)
-                                                                 : cap - 1 - (cntf + __popcll(balf & below));
-                                        if (cnt + cntf + __popcll(bal) + __popcll(balf) <= cap) row_out[pos_in] = js;
-                                    }
-                                    cnt += __popcll(bal);
-                                    cntf += __popcll(balf);
-                                }
-                                count = (lane == t) ? cnt : count;
-                                countf = (lane == t) ? cntf : countf;
-                            }
+                for (int u = 0; u < 2; ++u) {
+                    const int idx = cb + u * 64 + lane;
+                    const bool in = idx < total;
+                    int r = 0;
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1)
+                        if (s_rpref[w][r + step] <= idx) r += step;
+                    const int slot = in ? s_rstart[w][r] + idx - s_rpref[w][r] : 0;
+                    float4 q = pos4f_s[slot];
+                    if (RINT) {
+                        q.w = in ? 1.f : 0.f;
+                    } else {                 // image shift; lanes beyond the stream are parked far away
+                        q.x = in ? q.x + s_rshift[w][0][r] : FAR;
+                        q.y = in ? q.y + s_rshift[w][1][r] : FAR;
+                        q.z = in ? q.z + s_rshift[w][2][r] : FAR;
+                    }
+                    cand[u] = q;
+                    js[u] = in ? slot : -1;
+                    inr = inr || (js[u] >= blo && js[u] <= bhi);
+                }
+                const bool special = __ballot(inr) != 0ull;      // wave-uniform, rare
+#pragma unroll
+                for (int t = 0; t < AMM_BATCH; ++t) {
+                    if (t >= nt) break;
+                    int *row_out = nl + (size_t)(tb + t - s_begin) * cap;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (cb + u * 64 >= total) continue;                        // wave-uniform
+                        float dx = px[t] - cand[u].x, dy = py[t] - cand[u].y, dz = pz[t] - cand[u].z;
+                        if (RINT) {
+                            dx -= box.L[0] * rintf(dx * box.invL[0]);
+                            dy -= box.L[1] * rintf(dy * box.invL[1]);
+                            dz -= box.L[2] * rintf(dz * box.invL[2]);
                         }
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        bool pass = r2 < rlist2;
+                        if (RINT) pass = pass && (cand[u].w != 0.f);
+                        if (special && pass) {
+                            const int st = tb + t;
+                            if (js[u] == st) pass = false;
+                            const int i = perm[st];
+                            for (int k = excl_ptr[i]; k < excl_ptr[i + 1]; ++k)
+                                if (inv_perm[excl_idx[k]] == js[u]) pass = false;
+                        }
+                        const bool nearp = pass && (r2 < rnear2);
+                        const unsigned long long balp = __builtin_amdgcn_ballot_w64(pass);
+                        const unsigned long long baln = __builtin_amdgcn_ballot_w64(nearp);
+                        const int np_ = __popcll(balp), nn_ = __popcll(baln);
+                        if (!COUNT_ONLY) {
+                            const int mp = __builtin_amdgcn_mbcnt_hi((unsigned)(balp >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balp, 0u));
+                            const int mn = __builtin_amdgcn_mbcnt_hi((unsigned)(baln >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)baln, 0u));
+                            const int pos_in = nearp ? cnt[t] + mn : (cap - 1 - cntf[t]) - (mp - mn);
+                            const bool fits = cnt[t] + cntf[t] + np_ <= cap;           // wave-uniform
+                            if (pass && fits) row_out[pos_in] = js[u];
+                        }
+                        cnt[t] = __builtin_amdgcn_readfirstlane(cnt[t] + nn_);
+                        cntf[t] = __builtin_amdgcn_readfirstlane(cntf[t] + (np_ - nn_));
                     }
                 }
             }
+            int count = 0, countf = 0;
+#pragma unroll
+            for (int t = 0; t < AMM_BATCH; ++t) {
+                count = (lane == t) ? cnt[t] : count;
+                countf = (lane == t) ? cntf[t] : countf;
+            }
             if (lane < nt) {
-                const int total = count + countf;
+                const int total_nb = count + countf;
                 if (!COUNT_ONLY) {
-                    const bool over = total > cap;      // rows that overflow are flagged; amm_check() raises
-                    nnb[tb + lane - s_begin] = over ? 0 : total;
+                    const bool over = total_nb > cap;      // rows that overflow are flagged; amm_check() raises
+                    nnb[tb + lane - s_begin] = over ? 0 : total_nb;
                     nnb_near[tb + lane - s_begin] = over ? 0 : count;
                     if (over) flags[1] = 1;
                 }
-                wsum += (unsigned long long)total;
+                wsum += (unsigned long long)total_nb;
                 wnear += (unsigned long long)count;
-                wmax = max(wmax, total);
+                wmax = max(wmax, total_nb);
             }
         }
     }
