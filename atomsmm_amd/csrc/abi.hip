@@ -213,6 +213,8 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     AMM_HIP(hipMalloc(&pf->d_xref_out, sizeof(double) * 3 * n));
     AMM_HIP(hipMalloc(&pf->d_flags, sizeof(int) * 8));
     AMM_HIP(hipMemset(pf->d_flags, 0, sizeof(int) * 8));
+    AMM_HIP(hipMalloc(&pf->d_ticket, sizeof(int) * 4));
+    AMM_HIP(hipMemset(pf->d_ticket, 0, sizeof(int) * 4));
     AMM_HIP(hipMalloc(&pf->d_counters, sizeof(unsigned long long) * 8));
     AMM_HIP(hipMemset(pf->d_counters, 0, sizeof(unsigned long long) * 8));
     ForceObj fo;
@@ -367,22 +369,34 @@ int amm_bonded_set_sliced(amm_ctx *ctx, int32_t force_id, int32_t on) {
     return 0;
 }
 
+static int force_eval_dispatch(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_force, int32_t accumulate,
+                               double *d_energy) {
+    ForceObj &f = ctx->forces[force_id];
+    if (f.type == 1) return amm_pair_eval_impl(ctx, f.pair, d_pos, d_force, accumulate, d_energy);
+    return amm_bonded_eval_impl(ctx, f.bonded, d_pos, d_force, accumulate, d_energy);
+}
+
 int amm_force_eval(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_force, int32_t accumulate,
                    double *d_energy) {
     if (!ctx || force_id < 0 || force_id >= (int)ctx->forces.size() || !d_pos || !d_force) {
         amm_set_error("amm_force_eval: bad arguments");
         return 1;
     }
-    ForceObj &f = ctx->forces[force_id];
-    if (f.type == 1) return amm_pair_eval_impl(ctx, f.pair, d_pos, d_force, accumulate, d_energy);
-    return amm_bonded_eval_impl(ctx, f.bonded, d_pos, d_force, accumulate, d_energy);
+    ctx->pos_epoch++;                 // a caller's positions may have changed in any way since the last call
+    return force_eval_dispatch(ctx, force_id, d_pos, d_force, accumulate, d_energy);
 }
 
 int amm_kick(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int32_t plus, const double *d_mass, double coef) {
     return amm_kick_impl(ctx, d_v, d_f, d_f2, plus, d_mass, coef);
 }
-int amm_move(amm_ctx *ctx, double *d_x, const double *d_v, double coef) { return amm_move_impl(ctx, d_x, d_v, coef); }
-int amm_copy(amm_ctx *ctx, double *d_dst, const double *d_src) { return amm_copy_impl(ctx, d_dst, d_src); }
+int amm_move(amm_ctx *ctx, double *d_x, const double *d_v, double coef) {
+    ctx->pos_epoch++;
+    return amm_move_impl(ctx, d_x, d_v, coef);
+}
+int amm_copy(amm_ctx *ctx, double *d_dst, const double *d_src) {
+    ctx->pos_epoch++;
+    return amm_copy_impl(ctx, d_dst, d_src);
+}
 int amm_mvv(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out) { return amm_mvv_impl(ctx, d_v, d_m, d_out); }
 
 int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass) {
@@ -418,6 +432,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
     }
     // user-visible buffers; the fused inner iteration ping-pongs between them and library-owned partners
     double *const user_x = ctx->d_x, *const user_v = ctx->d_v;
+    ctx->pos_epoch++;                 // the caller may have written the bound position buffer
     int f0_slot = -1;
     double *user_f0 = nullptr;
     bool swapped = false;
@@ -461,6 +476,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                         if (ok && f0) {
                             if (amm_inner_components_impl(ctx, bs, ctx->d_x, ctx->d_v, f0, npre, pa, pb, pc, pp, ops[start].coef,
                                                           ops[start + 1].coef, ops[start + 3].coef, niter)) return 1;
+                            ctx->pos_epoch++;
                             k = q - 1;
                             continue;
                         }
@@ -489,6 +505,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     double *xo = swapped ? user_x : ctx->alt_x, *vo = swapped ? user_v : ctx->alt_v,
                            *fo = swapped ? user_f0 : ctx->alt_f;
                     if (amm_fused_inner_impl(ctx, bs, xi, vi, fi, xo, vo, fo, op.coef, ops[k + 1].coef, ops[k + 3].coef)) return 1;
+                    ctx->pos_epoch++;
                     ctx->d_x = xo;
                     ctx->d_v = vo;
                     ctx->slots[f0_slot] = fo;
@@ -513,7 +530,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 }
                 if (g.forces.empty()) AMM_HIP(hipMemsetAsync(buf, 0, sizeof(double) * 3 * (size_t)ctx->n, ctx->stream));
                 for (size_t j = 0; j < g.forces.size(); ++j)
-                    if (amm_force_eval(ctx, g.forces[j], ctx->d_x, buf, j > 0, nullptr)) return 1;
+                    if (force_eval_dispatch(ctx, g.forces[j], ctx->d_x, buf, j > 0, nullptr)) return 1;
             } break;
             case AMM_OP_KICK: {
                 double *fa = (op.a >= 0 && op.a < AMM_MAX_SLOTS) ? ctx->slots[op.a] : nullptr;
@@ -526,6 +543,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
             } break;
             case AMM_OP_MOVE:
                 if (amm_move_impl(ctx, ctx->d_x, ctx->d_v, op.coef)) return 1;
+                ctx->pos_epoch++;
                 break;
             case AMM_OP_COPY: {
                 double *dst = (op.a >= 0 && op.a < AMM_MAX_SLOTS) ? ctx->slots[op.a] : nullptr;
@@ -535,6 +553,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     return 1;
                 }
                 if (amm_copy_impl(ctx, dst, src)) return 1;
+                if (dst == ctx->d_x) ctx->pos_epoch++;
             } break;
             case AMM_OP_COMBINE: {
                 double *dst = (op.a >= 0 && op.a < AMM_MAX_SLOTS) ? ctx->slots[op.a] : nullptr;
@@ -545,6 +564,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     return 1;
                 }
                 if (amm_combine_impl(ctx, dst, sa, sb, op.coef)) return 1;
+                if (dst == ctx->d_x) ctx->pos_epoch++;
             } break;
             default: amm_set_error("amm_run_ops: unknown op"); return 1;
             }

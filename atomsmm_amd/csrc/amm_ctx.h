@@ -74,6 +74,9 @@ struct PairForce {
     int *d_flags = nullptr;        // [0] need prune [1] overflow [2] max inner row [4] need outer build [5] max outer row
     unsigned long long *d_counters = nullptr;  // [0] prunes [1] inner pairs [2] inner front pairs [3] outer pairs [4] outer builds
     unsigned long long *d_blockstats = nullptr; // per build-kernel block: (sum, max) of list lengths
+    int *d_ticket = nullptr;       // last-block tickets: [0] cell assign/scan [1] list build/statistics
+    long checked_epoch = -1;       // ctx->pos_epoch / position buffer of the last displacement check
+    const double *checked_pos = nullptr;
     int lpa = 8;                   // lanes per i-atom in the traversal kernel
     int parts = 1;                 // wavefronts per cell in the list-build kernel
     double *d_epart = nullptr;
@@ -137,6 +140,7 @@ struct amm_ctx {
     // ping-pong partners of x, v and the group-0 force buffer for the fused inner RESPA iteration
     double *alt_x = nullptr, *alt_v = nullptr, *alt_f = nullptr;
     bool fuse_inner = true;
+    long pos_epoch = 0;            // bumped whenever the positions may have changed (see amm_pair_eval_impl)
     double skin_out = -1.0;        // outer Verlet buffer for pair forces created afterwards (<= 0: default)
 };
 

@@ -88,58 +88,79 @@ __global__ void k_check_displacement(int n, const double *__restrict__ pos, cons
     if (!(d2 <= thr_out2)) flags[4] = 1;
 }
 
-__global__ void k_cell_assign(int n, const double *__restrict__ pos, Box box, CellGrid g, int *cell_of, int *count,
-                              double *xref, const int *flags, int which, int force) {
-    if (!force && !flags[which]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int c[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        double x = pos[3 * i + k];
-        xref[3 * i + k] = x;
-        double w = wrap1(x, box.L[k], box.invL[k]);
-        int ck = (w == w) ? (int)(w * g.inv_cw[k]) : 0;      // NaN-safe: a blown-up trajectory must not index out of range
-        c[k] = ck >= g.nc[k] ? g.nc[k] - 1 : (ck < 0 ? 0 : ck);
+// "last block" idiom: every block takes a ticket when its results have reached the device coherence point; the
+// block that draws the last one runs the serial tail of the kernel (a scan / a reduction) -- one launch less per
+// stage of the chain.  The results handed to the last block are written with device-scope atomics / atomic
+// stores only (write-through to the level shared by the 8 XCDs) and read back with device-scope atomic loads:
+// waiting for the writes to be acknowledged (s_waitcnt 0) then orders them before the ticket.  A __threadfence()
+// here would instead write back each XCD's whole dirty L2 -- including the list being built -- once per block
+// (measured: 2.6x on the build kernel).
+__device__ __forceinline__ bool amm_last_block(int *ticket) {
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(ticket, 1);
+        s_last = (t == (int)gridDim.x - 1);
+        if (s_last) *ticket = 0;        // every other block has already drawn: safe to re-arm
     }
-    int cell = (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
-    cell_of[i] = cell;
-    atomicAdd(&count[cell], 1);
+    __syncthreads();
+    return s_last != 0;
+}
+__device__ __forceinline__ int amm_ld_l2(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long amm_ld_l2(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void amm_st_l2(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// single block: exclusive scan of count[0..ncell) -> start[0..ncell], fill <- start, count <- 0
-__global__ void k_cell_scan(int ncell, int *count, int *start, int *fill, const int *flags, int *flags_rw,
-                            unsigned long long *counters, int which, int force) {
+// cell index of every atom + per-cell counts; the last block turns the counts into the exclusive scan
+// start[0..ncell] (fill <- start, count <- 0)
+__global__ void __launch_bounds__(256) k_cell_assign(int n, const double *__restrict__ pos, Box box, CellGrid g, int *cell_of,
+                              int *count, int *start, int *fill, double *xref, const int *flags, int *ticket, int which,
+                              int force) {
     if (!force && !flags[which]) return;
-    __shared__ int part[1024];
-    __shared__ int carry;
-    int t = threadIdx.x;
-    if (t == 0) carry = 0;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double x = pos[3 * i + k];
+            xref[3 * i + k] = x;
+            double w = wrap1(x, box.L[k], box.invL[k]);
+            int ck = (w == w) ? (int)(w * g.inv_cw[k]) : 0;      // NaN-safe: a blown-up trajectory must not index out of range
+            c[k] = ck >= g.nc[k] ? g.nc[k] - 1 : (ck < 0 ? 0 : ck);
+        }
+        int cell = (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
+        cell_of[i] = cell;
+        atomicAdd(&count[cell], 1);
+    }
+    if (!amm_last_block(ticket)) return;
+    // thread t scans the contiguous segment [t*per, (t+1)*per) of the counts
+    __shared__ int part[256];
+    const int t = threadIdx.x, ncell = g.ncell;
+    const int per = (ncell + 255) / 256;
+    const int c0 = min(t * per, ncell), c1 = min(c0 + per, ncell);
+    int sum = 0;
+    for (int c = c0; c < c1; ++c) sum += amm_ld_l2(&count[c]);
+    part[t] = sum;
     __syncthreads();
-    for (int base = 0; base < ncell; base += 1024) {
-        int idx = base + t;
-        int v = idx < ncell ? count[idx] : 0;
-        part[t] = v;
+    for (int off = 1; off < 256; off <<= 1) {
+        const int add = t >= off ? part[t - off] : 0;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int add = t >= off ? part[t - off] : 0;
-            __syncthreads();
-            part[t] += add;
-            __syncthreads();
-        }
-        int excl = part[t] - v + carry;
-        if (idx < ncell) {
-            start[idx] = excl;
-            fill[idx] = excl;
-            count[idx] = 0;
-        }
-        __syncthreads();
-        if (t == 1023) carry += part[1023];
+        part[t] += add;
         __syncthreads();
     }
-    if (t == 0) {
-        start[ncell] = carry;
+    int run = part[t] - sum;
+    for (int c = c0; c < c1; ++c) {
+        const int v = amm_ld_l2(&count[c]);
+        start[c] = run;
+        fill[c] = run;
+        count[c] = 0;
+        run += v;
     }
+    if (t == 255) start[ncell] = part[255];
 }
 
 __global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, int *perm_tmp, const int *flags, int which,
@@ -151,9 +172,13 @@ __global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, i
     perm_tmp[slot] = i;
 }
 
-// one wavefront per cell: rank sort by atom index -> deterministic order whatever the atomics did
+// one wavefront per cell: rank sort by atom index -> deterministic order whatever the atomics did; the lane
+// that places atom i at sorted slot s also writes the fp32 copy of its wrapped position (the list build only has
+// to find a SUPERSET of the pairs within rlist -- the traversal re-tests r^2 < rc^2 in fp64 -- so it runs on the
+// fp32 pipe with a margin) and inv_perm[i] = s
 __global__ void k_cell_sort(int ncell, const int *__restrict__ start, const int *__restrict__ perm_tmp, int *perm,
-                            const int *flags, int which, int force) {
+                            const double *__restrict__ pos, Box box, float4 *pos4f_s, int *inv_perm, const int *flags,
+                            int which, int force) {
     if (!force && !flags[which]) return;
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     int lane = threadIdx.x & 63;
@@ -163,7 +188,15 @@ __global__ void k_cell_sort(int ncell, const int *__restrict__ start, const int 
         int me = perm_tmp[a];
         int rank = 0;
         for (int k = b; k < e; ++k) rank += perm_tmp[k] < me;
-        perm[b + rank] = me;
+        const int sl = b + rank;
+        perm[sl] = me;
+        float4 p;
+        p.x = (float)wrap1(pos[3 * me], box.L[0], box.invL[0]);
+        p.y = (float)wrap1(pos[3 * me + 1], box.L[1], box.invL[1]);
+        p.z = (float)wrap1(pos[3 * me + 2], box.L[2], box.invL[2]);
+        p.w = 0.f;
+        pos4f_s[sl] = p;
+        inv_perm[me] = sl;
     }
 }
 
@@ -184,8 +217,8 @@ __global__ void k_gather_sorted(int n, const int *__restrict__ perm, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// fp32 copy of the sorted, wrapped positions: the list build only has to find a SUPERSET of the pairs
-// within rlist (the traversal re-tests r^2 < rc^2 in fp64), so it runs on the fp32 pipe with a margin.
+// fp32 copy of the sorted, wrapped positions for a re-prune of the dual list (the cell sweep gets its copy
+// from k_cell_sort)
 __global__ void k_gather_f32(int n, const int *__restrict__ perm, const double *__restrict__ pos, Box box,
                              float4 *pos4f_s, int *inv_perm, double *xref_in, const int *flags, int which, int force) {
     if (!force && !flags[which]) return;
@@ -210,6 +243,52 @@ struct BoxF {
     float L[3], invL[3];
 };
 
+// one block: reduce the per-block list statistics of an outer build (which = 4) or of an inner build / prune
+// (which = 0), re-arm the rebuild flag
+__device__ void amm_finish_build_block(int *flags, unsigned long long *counters, const unsigned long long *blockstats,
+                                       int nblocks, int count_only, int which) {
+    __shared__ unsigned long long sh_sum[256];
+    __shared__ unsigned long long sh_max[256];
+    __shared__ unsigned long long sh_near[256];
+    unsigned long long sum = 0, mx = 0, nr = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        sum += amm_ld_l2(&blockstats[3 * b]);
+        mx = max(mx, amm_ld_l2(&blockstats[3 * b + 1]));
+        nr += amm_ld_l2(&blockstats[3 * b + 2]);
+    }
+    sh_sum[threadIdx.x] = sum;
+    sh_max[threadIdx.x] = mx;
+    sh_near[threadIdx.x] = nr;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            sh_sum[threadIdx.x] += sh_sum[threadIdx.x + off];
+            sh_near[threadIdx.x] += sh_near[threadIdx.x + off];
+            sh_max[threadIdx.x] = max(sh_max[threadIdx.x], sh_max[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (which == 4) {                  // outer list
+            flags[5] = (int)sh_max[0];
+            counters[3] = sh_sum[0];
+            if (!count_only) {
+                flags[4] = 0;
+                flags[0] = 1;              // a fresh outer list must be pruned
+                counters[4] += 1;
+            }
+        } else {                           // inner list
+            flags[2] = (int)sh_max[0];
+            counters[1] = sh_sum[0];
+            counters[2] = sh_near[0];
+            if (!count_only) {
+                flags[0] = 0;
+                counters[0] += 1;
+            }
+        }
+    }
+}
+
 // neighbour-list build: one wavefront per (cell, part).  All i-atoms of a cell share the same candidates: the
 // (2h+1)^2 (y,z) rows of the stencil, each one or two contiguous runs of the cell-sorted arrays (cells are
 // x-fastest) with one periodic image per run.  The wave tabulates its runs once (start slot, exclusive prefix of
@@ -229,7 +308,8 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                               const int *__restrict__ inv_perm, const int *__restrict__ cell_start,
                               const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2, float rnear2,
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
-                              int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats, int which, int force) {
+                              int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
+                              unsigned long long *counters, int *ticket, int which, int force) {
     if (!force && !flags[which]) return;
     __shared__ int s_rstart[4][64];
     __shared__ int s_rpref[4][64];
@@ -415,7 +495,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
             }
         }
     }
-    // per-block (sum, max) of the list lengths -> blockstats; k_finish_build reduces them.  (One same-address
+    // per-block (sum, max) of the list lengths -> blockstats; the last block reduces them.  (One same-address
     // atomic per atom serialises at L2: ~0.5 ms for 98k atoms -- measured -- so no atomics here.)
     for (int off = 32; off > 0; off >>= 1) {
         wsum += __shfl_xor(wsum, off);
@@ -431,56 +511,17 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        blockstats[3 * blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-        blockstats[3 * blockIdx.x + 1] = (unsigned long long)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-        blockstats[3 * blockIdx.x + 2] = s_near[0] + s_near[1] + s_near[2] + s_near[3];
+        amm_st_l2(&blockstats[3 * blockIdx.x], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        amm_st_l2(&blockstats[3 * blockIdx.x + 1], (unsigned long long)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+        amm_st_l2(&blockstats[3 * blockIdx.x + 2], s_near[0] + s_near[1] + s_near[2] + s_near[3]);
     }
+    if (amm_last_block(ticket)) amm_finish_build_block(flags, counters, blockstats, (int)gridDim.x, COUNT_ONLY ? 1 : 0, which);
 }
 
-// single block: reduce the per-block list statistics of an outer build (which = 4) or of a prune (which = 0)
 __global__ void k_finish_build(int *flags, unsigned long long *counters, const unsigned long long *blockstats,
                                int nblocks, int count_only, int which, int force) {
     if (!force && !flags[which]) return;
-    __shared__ unsigned long long sh_sum[256];
-    __shared__ unsigned long long sh_max[256];
-    __shared__ unsigned long long sh_near[256];
-    unsigned long long sum = 0, mx = 0, nr = 0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) {
-        sum += blockstats[3 * b];
-        mx = max(mx, blockstats[3 * b + 1]);
-        nr += blockstats[3 * b + 2];
-    }
-    sh_sum[threadIdx.x] = sum;
-    sh_max[threadIdx.x] = mx;
-    sh_near[threadIdx.x] = nr;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            sh_sum[threadIdx.x] += sh_sum[threadIdx.x + off];
-            sh_near[threadIdx.x] += sh_near[threadIdx.x + off];
-            sh_max[threadIdx.x] = max(sh_max[threadIdx.x], sh_max[threadIdx.x + off]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (which == 4) {                  // outer list
-            flags[5] = (int)sh_max[0];
-            counters[3] = sh_sum[0];
-            if (!count_only) {
-                flags[4] = 0;
-                flags[0] = 1;              // a fresh outer list must be pruned
-                counters[4] += 1;
-            }
-        } else {                           // inner list
-            flags[2] = (int)sh_max[0];
-            counters[1] = sh_sum[0];
-            counters[2] = sh_near[0];
-            if (!count_only) {
-                flags[0] = 0;
-                counters[0] += 1;
-            }
-        }
-    }
+    amm_finish_build_block(flags, counters, blockstats, nblocks, count_only, which);
 }
 
 // Prune: inner list <- entries of the outer list within rlist_in of the CURRENT positions.  `lpp` lanes per atom
@@ -755,15 +796,13 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
     const int nb = (n + 255) / 256;
     const int which = direct ? 0 : 4;
     hipLaunchKernelGGL(k_cell_assign, dim3(nb), dim3(256), 0, st, n, d_pos, ctx->box, pf->grid, pf->d_cell_of,
-                       pf->d_cell_count, direct ? pf->d_xref : pf->d_xref_out, pf->d_flags, which, force);
-    hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, pf->grid.ncell, pf->d_cell_count, pf->d_cell_start,
-                       pf->d_cell_fill, pf->d_flags, pf->d_flags, pf->d_counters, which, force);
+                       pf->d_cell_count, pf->d_cell_start, pf->d_cell_fill, direct ? pf->d_xref : pf->d_xref_out, pf->d_flags,
+                       pf->d_ticket, which, force);
     hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, st, n, pf->d_cell_of, pf->d_cell_fill, pf->d_perm_tmp,
                        pf->d_flags, which, force);
     hipLaunchKernelGGL(k_cell_sort, dim3((pf->grid.ncell * 64 + 255) / 256), dim3(256), 0, st, pf->grid.ncell,
-                       pf->d_cell_start, pf->d_perm_tmp, pf->d_perm, pf->d_flags, which, force);
-    hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, st, n, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s,
-                       pf->d_inv_perm, (double *)nullptr, pf->d_flags, which, force);
+                       pf->d_cell_start, pf->d_perm_tmp, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s, pf->d_inv_perm,
+                       pf->d_flags, which, force);
     const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
@@ -781,7 +820,8 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
 #define AMM_LAUNCH_BUILD(CO, RI)                                                                                       \
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
                        pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
-                       pf->d_excl_idx, cap, nl, nnb, nnb_near, pf->d_flags, pf->d_blockstats, which, force)
+                       pf->d_excl_idx, cap, nl, nnb, nnb_near, pf->d_flags, pf->d_blockstats, pf->d_counters,      \
+                       pf->d_ticket + 1, which, force)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
         else AMM_LAUNCH_BUILD(true, false);
@@ -790,8 +830,6 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
         else AMM_LAUNCH_BUILD(false, false);
     }
 #undef AMM_LAUNCH_BUILD
-    hipLaunchKernelGGL(k_finish_build, dim3(1), dim3(256), 0, st, pf->d_flags, pf->d_counters, pf->d_blockstats, (int)grid.x,
-                       count_only ? 1 : 0, which, force);
     AMM_HIP(hipGetLastError());
     return 0;
 }
@@ -898,6 +936,9 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     PairForce *L = pf->host ? pf->host : pf;
     if (!L->built) {
         if (first_build(ctx, L, d_pos)) return 1;
+    } else if (L->checked_epoch == ctx->pos_epoch && L->checked_pos == d_pos) {
+        // positions unchanged since this list was last checked (e.g. the far force right after the near force
+        // that shares the list): nothing to do
     } else {
         const double thr_in = 0.5 * L->skin, thr_out = L->dual ? 0.5 * (L->skin_out - L->skin) : 1.0e30;
         hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, L->d_xref,
@@ -909,6 +950,8 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             if (cell_build_chain(ctx, L, d_pos, 0, false, true)) return 1;
         }
     }
+    L->checked_epoch = ctx->pos_epoch;
+    L->checked_pos = d_pos;
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, n, L->d_perm, d_pos, pf->d_q, pf->d_hsig,
                        pf->d_seps2, ctx->box, pf->d_posq_s, pf->d_lj_s);
     pf->s_begin = L->s_begin;
@@ -982,7 +1025,7 @@ int amm_pair_free(PairForce *pf) {
     void *ptrs[] = {pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_excl_ptr, pf->d_excl_idx, pf->d_cell_of, pf->d_cell_count,
                     pf->d_cell_start, pf->d_cell_fill, pf->d_perm_tmp, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
                     pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near, pf->d_nl_out, pf->d_nnb_out,
-                    pf->d_nnb_scratch, pf->d_xref_out};
+                    pf->d_nnb_scratch, pf->d_xref_out, pf->d_ticket};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);
