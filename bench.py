@@ -196,6 +196,15 @@ def main():
                        'near_lanes_per_atom': near_stats['lanes_per_atom'], 'near_rlist_nm': near_stats['rlist'],
                        'near_list_pairs': near_stats['n_list_pairs'], 'fp64_tflops_near': round(fp64_tf, 3)},
         }
+        # HBM traffic of the near kernel from the PMC passes (rocprofv3 cannot run inside this process; the passes
+        # are made with scripts/pmc_summary.py on this same command and committed under profiles/)
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
+        if world == 1 and args.nside == 32 and os.path.exists(tfile):
+            try:
+                result['roofline']['traffic'] = json.load(open(tfile))['near']['hbm_bytes_per_launch']
+                result['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)'
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result['cpu_baseline'] = cpu_baseline(args.nside, loops, dt_fs)

@@ -1,0 +1,51 @@
+"""Summarise rocprofv3 --pmc passes (one counter set per pass/dir) per kernel.
+
+usage: python scripts/pmc_summary.py OUT.txt [--traffic-json FILE] DIR [DIR ...]
+
+FETCH_SIZE / WRITE_SIZE are in KB per dispatch.  Following /opt/skills/guides/MI355X_MICROARCH.md (HBM section) the
+HBM traffic of a kernel is 2 x FETCH_SIZE + WRITE_SIZE on gfx950 (FETCH_SIZE tallies 128-B read requests at 64 B).
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def main():
+    args = sys.argv[1:]
+    out = args.pop(0)
+    tj = None
+    if args and args[0] == '--traffic-json':
+        args.pop(0)
+        tj = args.pop(0)
+    acc = collections.defaultdict(list)
+    for d in args:
+        for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+            for r in csv.DictReader(open(f)):
+                acc[(r['Counter_Name'], r['Kernel_Name'])].append(float(r['Counter_Value']))
+    lines = []
+    for (cn, kn), v in sorted(acc.items()):
+        lines.append('%-18s %-90s n=%5d avg=%14.1f max=%14.1f' % (cn, kn[:90], len(v), sum(v) / len(v), max(v)))
+    open(out, 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines))
+    if tj:
+        res = {}
+        for tag, pat in (('near', 'k_pair_nlist<2'), ('far', 'k_pair_nlist<3'), ('build', 'k_build_nlist<false')):
+            fe = [x for (cn, kn), v in acc.items() if cn == 'FETCH_SIZE' and pat in kn for x in v]
+            wr = [x for (cn, kn), v in acc.items() if cn == 'WRITE_SIZE' and pat in kn for x in v]
+            if tag == 'build':      # only the launches that actually rebuilt (the others return at once)
+                fe = [x for x in fe if x > 100.0]
+                wr = [x for x in wr if x > 100.0]
+            if fe and wr:
+                f_kb, w_kb = sum(fe) / len(fe), sum(wr) / len(wr)
+                res[tag] = {'fetch_size_kb_avg': round(f_kb, 1), 'write_size_kb_avg': round(w_kb, 1),
+                            'launches': len(fe), 'hbm_bytes_per_launch': int((2 * f_kb + w_kb) * 1024)}
+        res['note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py; '
+                       'hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of MI355X_MICROARCH.md)')
+        json.dump(res, open(tj, 'w'), indent=1)
+        print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()
