@@ -28,6 +28,7 @@ EXPORTS = [
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
+    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced',
 ]
 
 
@@ -101,6 +102,9 @@ def lib():
         L.amm_pair_get_stats.argtypes = [vp, C.c_int32, C.POINTER(PairStats)]
         L.amm_profile_enable.argtypes = [vp, C.c_int32]
         L.amm_profile_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), dp]
+        L.amm_pme_create.argtypes = [vp, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_double, dp, ip]
+        L.amm_pme_set_charges.argtypes = [vp, C.c_int32, dp]
+        L.amm_pme_set_sliced.argtypes = [vp, C.c_int32, C.c_int32]
         for name in EXPORTS:
             if name not in ('amm_last_error',):
                 getattr(L, name).restype = C.c_int
@@ -201,6 +205,20 @@ class HipContext:
         _chk(lib().amm_bonded_finalize(self.h, fid))
         if sliced:
             _chk(lib().amm_bonded_set_sliced(self.h, fid, 1))
+
+    def pme_create(self, alpha, grid, q, Kc=KC):
+        """Reciprocal space of a PME / Ewald NonbondedForce (smooth PME, order 5) on a grid[0] x grid[1] x grid[2] mesh."""
+        q_, qp = _hd(q)
+        fid = C.c_int32(-1)
+        _chk(lib().amm_pme_create(self.h, float(alpha), int(grid[0]), int(grid[1]), int(grid[2]), float(Kc), qp, C.byref(fid)))
+        return fid.value
+
+    def pme_set_charges(self, fid, q):
+        q_, qp = _hd(q)
+        _chk(lib().amm_pme_set_charges(self.h, fid, qp))
+
+    def pme_set_sliced(self, fid, on=True):
+        _chk(lib().amm_pme_set_sliced(self.h, fid, int(bool(on))))
 
     def force_eval(self, fid, pos, force, accumulate=False, energy=None):
         _chk(lib().amm_force_eval(self.h, fid, _ptr(pos), _ptr(force), int(bool(accumulate)), _ptr(energy)))

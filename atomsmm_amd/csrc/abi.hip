@@ -82,6 +82,7 @@ int amm_destroy(amm_ctx *ctx) {
             amm_bonded_free(f.bonded);
             delete f.bonded;
         }
+        if (f.pme) amm_pme_free(f.pme);
     }
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->alt_x) (void)hipFree(ctx->alt_x);
@@ -373,7 +374,46 @@ static int force_eval_dispatch(amm_ctx *ctx, int32_t force_id, const double *d_p
                                double *d_energy) {
     ForceObj &f = ctx->forces[force_id];
     if (f.type == 1) return amm_pair_eval_impl(ctx, f.pair, d_pos, d_force, accumulate, d_energy);
+    if (f.type == 3) return amm_pme_eval_impl(ctx, f.pme, d_pos, d_force, accumulate, d_energy);
     return amm_bonded_eval_impl(ctx, f.bonded, d_pos, d_force, accumulate, d_energy);
+}
+
+int amm_pme_create(amm_ctx *ctx, double alpha, int32_t nx, int32_t ny, int32_t nz, double Kc, const double *h_q,
+                   int32_t *force_id) {
+    if (!ctx || !h_q || !force_id) {
+        amm_set_error("amm_pme_create: bad arguments");
+        return 1;
+    }
+    AMM_HIP(hipSetDevice(ctx->device));
+    const int K[3] = {nx, ny, nz};
+    PmeForce *pm = nullptr;
+    if (amm_pme_create_impl(ctx, alpha, K, Kc, h_q, &pm)) return 1;
+    ForceObj fo;
+    fo.type = 3;
+    fo.pme = pm;
+    ctx->forces.push_back(fo);
+    *force_id = (int32_t)ctx->forces.size() - 1;
+    return 0;
+}
+
+static PmeForce *get_pme(amm_ctx *ctx, int id) {
+    if (!ctx || id < 0 || id >= (int)ctx->forces.size() || ctx->forces[id].type != 3) {
+        amm_set_error("not a PME force id");
+        return nullptr;
+    }
+    return ctx->forces[id].pme;
+}
+
+int amm_pme_set_charges(amm_ctx *ctx, int32_t force_id, const double *h_q) {
+    PmeForce *pm = get_pme(ctx, force_id);
+    if (!pm || !h_q) return 1;
+    return amm_pme_set_charges_impl(ctx, pm, h_q);
+}
+
+int amm_pme_set_sliced(amm_ctx *ctx, int32_t force_id, int32_t on) {
+    PmeForce *pm = get_pme(ctx, force_id);
+    if (!pm) return 1;
+    return amm_pme_set_sliced_impl(pm, on);
 }
 
 int amm_force_eval(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_force, int32_t accumulate,

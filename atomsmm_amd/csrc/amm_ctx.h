@@ -113,10 +113,13 @@ struct BondedSet {
     int n_epart = 0;
 };
 
+struct PmeForce;      // pme.hip
+
 struct ForceObj {
-    int type = 0;   // 1 pair, 2 bonded
+    int type = 0;   // 1 pair, 2 bonded, 3 PME reciprocal space
     PairForce *pair = nullptr;
     BondedSet *bonded = nullptr;
+    PmeForce *pme = nullptr;
 };
 
 struct GroupDef {
@@ -158,6 +161,11 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
                               double c2, int niter);
 int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const double *v_in, const double *f_in,
                          double *x_out, double *v_out, double *f_out, double c1, double d, double c2);
+int amm_pme_create_impl(amm_ctx *ctx, double alpha, const int *K, double Kc, const double *h_q, PmeForce **out);
+int amm_pme_set_charges_impl(amm_ctx *ctx, PmeForce *pm, const double *h_q);
+int amm_pme_eval_impl(amm_ctx *ctx, PmeForce *pm, const double *d_pos, double *d_force, int accumulate, double *d_energy);
+int amm_pme_set_sliced_impl(PmeForce *pm, int on);
+int amm_pme_free(PmeForce *pm);
 int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef);
 int amm_combine_impl(amm_ctx *ctx, double *d_dst, const double *d_a, const double *d_b, double coef);
 int amm_move_impl(amm_ctx *ctx, double *d_x, const double *d_v, double coef);

@@ -1,0 +1,336 @@
+// Smooth particle-mesh Ewald reciprocal space (Essmann et al., J. Chem. Phys. 103, 8577) for the group-2
+// NonbondedForce that RESPASystem / FarNonbondedForce keep with the source force's method, Ewald tolerance and
+// PME parameters (/root/reference/src/atomsmm/systems.py:74-75, forces.py:185-188).  OpenMM is an un-vendored
+// dependency of the reference; this restates the published algorithm with OpenMM's conventions [recalled]:
+// B-spline order 5, grid size ceil(2 alpha L / (3 tol^(1/5))), energy = 1/2 sum_m eterm(m) |S(m)|^2 with
+// eterm = Kc exp(-pi^2 m^2 / alpha^2) / (pi V m^2 B(m)), self energy -Kc alpha/sqrt(pi) sum q^2 in the same group.
+//
+// MI355X mapping: the charge spread uses 64-bit FIXED-POINT atomics (integer adds commute => the grid, and with
+// it the forces, are bit-reproducible whatever order the 125 x N adds land in); rocFFT (through hipFFT) does the
+// two 3-D transforms; the convolution kernel also reduces the energy; the gather is one thread per atom.
+#include "amm_ctx.h"
+#include <hipfft/hipfft.h>
+
+#define PME_ORDER 5
+#define PME_FIXED_SCALE 4398046511104.0   // 2^42
+
+struct PmeForce {
+    int n = 0;
+    int K[3] = {0, 0, 0};
+    int nzc = 0;                  // K[2]/2 + 1
+    double alpha = 0, Kc = 138.935456;
+    bool sliced = false;
+    double self_energy = 0;       // -Kc alpha/sqrt(pi) sum q^2  - pi Kc Q^2 / (2 V alpha^2)
+    double *d_q = nullptr;
+    long long *d_gridi = nullptr; // fixed-point charge grid [Kx][Ky][Kz]
+    double *d_grid = nullptr;     // real grid
+    double2 *d_gridc = nullptr;   // half-complex grid [Kx][Ky][Kz/2+1]
+    double *d_bmod[3] = {nullptr, nullptr, nullptr};
+    double *d_epart = nullptr;
+    int n_epart = 0;
+    hipfftHandle plan_f = 0, plan_b = 0;
+    bool plans = false;
+};
+
+// B-spline weights and derivatives of order 5 at fractional offset fr (OpenMM reference PME recursion)
+__device__ __forceinline__ void pme_bspline(double fr, double *w, double *dw) {
+    w[PME_ORDER - 1] = 0.0;
+    w[1] = fr;
+    w[0] = 1.0 - fr;
+#pragma unroll
+    for (int k = 3; k < PME_ORDER; ++k) {
+        const double div = 1.0 / (k - 1.0);
+        w[k - 1] = div * fr * w[k - 2];
+#pragma unroll
+        for (int l = 1; l < k - 1; ++l) w[k - l - 1] = div * ((fr + l) * w[k - l - 2] + (k - l - fr) * w[k - l - 1]);
+        w[0] = div * (1.0 - fr) * w[0];
+    }
+    dw[0] = -w[0];
+#pragma unroll
+    for (int l = 1; l < PME_ORDER; ++l) dw[l] = w[l - 1] - w[l];
+    const double div = 1.0 / (PME_ORDER - 1.0);
+    w[PME_ORDER - 1] = div * fr * w[PME_ORDER - 2];
+#pragma unroll
+    for (int l = 1; l < PME_ORDER - 1; ++l)
+        w[PME_ORDER - l - 1] = div * ((fr + l) * w[PME_ORDER - l - 2] + (PME_ORDER - l - fr) * w[PME_ORDER - l - 1]);
+    w[0] = div * (1.0 - fr) * w[0];
+}
+
+__device__ __forceinline__ void pme_locate(double x, double L, double invL, int K, int &idx, double &fr) {
+    double t = x * invL;
+    t = (t - floor(t)) * K;
+    int ti = (int)t;
+    fr = t - ti;
+    idx = ti % K;      // t can round up to K
+}
+
+__global__ void k_pme_spread(int n, const double *__restrict__ pos, const double *__restrict__ q, Box box, int Kx, int Ky,
+                             int Kz, unsigned long long *gridi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double qi = q[i];
+    if (qi == 0.0) return;
+    int ix, iy, iz;
+    double fx, fy, fz, wx[PME_ORDER], wy[PME_ORDER], wz[PME_ORDER], d[PME_ORDER];
+    pme_locate(pos[3 * i], box.L[0], box.invL[0], Kx, ix, fx);
+    pme_locate(pos[3 * i + 1], box.L[1], box.invL[1], Ky, iy, fy);
+    pme_locate(pos[3 * i + 2], box.L[2], box.invL[2], Kz, iz, fz);
+    pme_bspline(fx, wx, d);
+    pme_bspline(fy, wy, d);
+    pme_bspline(fz, wz, d);
+    for (int a = 0; a < PME_ORDER; ++a) {
+        int gx = ix + a;
+        gx -= gx >= Kx ? Kx : 0;
+        for (int b = 0; b < PME_ORDER; ++b) {
+            int gy = iy + b;
+            gy -= gy >= Ky ? Ky : 0;
+            const double qxy = qi * wx[a] * wy[b];
+            for (int c = 0; c < PME_ORDER; ++c) {
+                int gz = iz + c;
+                gz -= gz >= Kz ? Kz : 0;
+                const long long v = __double2ll_rn(qxy * wz[c] * PME_FIXED_SCALE);
+                atomicAdd(&gridi[((size_t)gx * Ky + gy) * Kz + gz], (unsigned long long)v);
+            }
+        }
+    }
+}
+
+// fixed point -> double; re-arms the integer grid for the next spread
+__global__ void k_pme_finish_spread(size_t m, long long *gridi, double *grid) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    grid[p] = (double)gridi[p] * (1.0 / PME_FIXED_SCALE);
+    gridi[p] = 0;
+}
+
+// S(m) <- eterm(m) S(m); block partial sums of 1/2 sum_m w(m) eterm(m) |S(m)|^2 (w = 2 for the planes that the
+// half-complex storage holds once for a conjugate pair)
+__global__ void k_pme_convolve(int Kx, int Ky, int Kz, int nzc, Box box, double alpha, double Kc, const double *__restrict__ bx,
+                               const double *__restrict__ by, const double *__restrict__ bz, double2 *gridc, double *epart) {
+    const size_t m = (size_t)Kx * Ky * nzc;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double e = 0.0;
+    if (p < m) {
+        const int kz = (int)(p % nzc), ky = (int)((p / nzc) % Ky), kx = (int)(p / ((size_t)nzc * Ky));
+        if (kx == 0 && ky == 0 && kz == 0) {
+            gridc[p] = make_double2(0.0, 0.0);
+        } else {
+            const int mx = kx < (Kx + 1) / 2 ? kx : kx - Kx, my = ky < (Ky + 1) / 2 ? ky : ky - Ky, mz = kz;
+            const double hx = mx * box.invL[0], hy = my * box.invL[1], hz = mz * box.invL[2];
+            const double m2 = hx * hx + hy * hy + hz * hz;
+            const double pi = 3.14159265358979323846;
+            const double vol = box.L[0] * box.L[1] * box.L[2];
+            const double eterm = Kc * exp(-pi * pi * m2 / (alpha * alpha)) / (pi * vol * m2 * bx[kx] * by[ky] * bz[kz]);
+            const double2 s = gridc[p];
+            const double wgt = (kz == 0 || (Kz % 2 == 0 && kz == Kz / 2)) ? 1.0 : 2.0;
+            e = 0.5 * wgt * eterm * (s.x * s.x + s.y * s.y);
+            gridc[p] = make_double2(s.x * eterm, s.y * eterm);
+        }
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = e;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) epart[blockIdx.x] = sh[0];
+}
+
+__global__ void k_pme_gather(int a_begin, int a_end, const double *__restrict__ pos, const double *__restrict__ q, Box box,
+                             int Kx, int Ky, int Kz, const double *__restrict__ grid, double *force, int accumulate,
+                             int zero_outside, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i < a_begin || i >= a_end) {
+        if (!accumulate && zero_outside) force[3 * i] = force[3 * i + 1] = force[3 * i + 2] = 0.0;
+        return;
+    }
+    const double qi = q[i];
+    int ix, iy, iz;
+    double fx, fy, fz, wx[PME_ORDER], wy[PME_ORDER], wz[PME_ORDER], dx[PME_ORDER], dy[PME_ORDER], dz[PME_ORDER];
+    pme_locate(pos[3 * i], box.L[0], box.invL[0], Kx, ix, fx);
+    pme_locate(pos[3 * i + 1], box.L[1], box.invL[1], Ky, iy, fy);
+    pme_locate(pos[3 * i + 2], box.L[2], box.invL[2], Kz, iz, fz);
+    pme_bspline(fx, wx, dx);
+    pme_bspline(fy, wy, dy);
+    pme_bspline(fz, wz, dz);
+    double gx_ = 0.0, gy_ = 0.0, gz_ = 0.0;
+    for (int a = 0; a < PME_ORDER; ++a) {
+        int gx = ix + a;
+        gx -= gx >= Kx ? Kx : 0;
+        for (int b = 0; b < PME_ORDER; ++b) {
+            int gy = iy + b;
+            gy -= gy >= Ky ? Ky : 0;
+            const double *row = grid + ((size_t)gx * Ky + gy) * Kz;
+            for (int c = 0; c < PME_ORDER; ++c) {
+                int gz = iz + c;
+                gz -= gz >= Kz ? Kz : 0;
+                const double g = row[gz];
+                gx_ += dx[a] * wy[b] * wz[c] * g;
+                gy_ += wx[a] * dy[b] * wz[c] * g;
+                gz_ += wx[a] * wy[b] * dz[c] * g;
+            }
+        }
+    }
+    const double f0 = -qi * gx_ * Kx * box.invL[0], f1 = -qi * gy_ * Ky * box.invL[1], f2 = -qi * gz_ * Kz * box.invL[2];
+    if (accumulate) {
+        force[3 * i] += f0;
+        force[3 * i + 1] += f1;
+        force[3 * i + 2] += f2;
+    } else {
+        force[3 * i] = f0;
+        force[3 * i + 1] = f1;
+        force[3 * i + 2] = f2;
+    }
+}
+
+// |sum_k M_n(k+1) exp(2 pi i m k / K)|^2, zeros patched by the neighbours' mean (Essmann eq. 4.4 / OpenMM)
+static void pme_bspline_moduli(int K, std::vector<double> &mod) {
+    double data[PME_ORDER], fr = 0.0;
+    // same recursion as the device code at fr = 0
+    data[PME_ORDER - 1] = 0.0;
+    data[1] = fr;
+    data[0] = 1.0 - fr;
+    for (int k = 3; k < PME_ORDER; ++k) {
+        const double div = 1.0 / (k - 1.0);
+        data[k - 1] = div * fr * data[k - 2];
+        for (int l = 1; l < k - 1; ++l) data[k - l - 1] = div * ((fr + l) * data[k - l - 2] + (k - l - fr) * data[k - l - 1]);
+        data[0] = div * (1.0 - fr) * data[0];
+    }
+    const double div = 1.0 / (PME_ORDER - 1.0);
+    data[PME_ORDER - 1] = div * fr * data[PME_ORDER - 2];
+    for (int l = 1; l < PME_ORDER - 1; ++l)
+        data[PME_ORDER - l - 1] = div * ((fr + l) * data[PME_ORDER - l - 2] + (PME_ORDER - l - fr) * data[PME_ORDER - l - 1]);
+    data[0] = div * (1.0 - fr) * data[0];
+    std::vector<double> b(K, 0.0);
+    for (int i = 1; i <= PME_ORDER; ++i) b[i % K] += data[i - 1];   // M_n sampled at the knots, shifted by one
+    mod.assign(K, 0.0);
+    const double two_pi = 6.283185307179586476925;
+    for (int i = 0; i < K; ++i) {
+        double sc = 0.0, ss = 0.0;
+        for (int j = 0; j < K; ++j) {
+            const double arg = two_pi * i * j / K;
+            sc += b[j] * cos(arg);
+            ss += b[j] * sin(arg);
+        }
+        mod[i] = sc * sc + ss * ss;
+    }
+    for (int i = 0; i < K; ++i)
+        if (mod[i] < 1.0e-7) mod[i] = 0.5 * (mod[(i - 1 + K) % K] + mod[(i + 1) % K]);
+}
+
+#define AMM_FFT(call)                                                                                                   \
+    do {                                                                                                                \
+        hipfftResult r_ = (call);                                                                                       \
+        if (r_ != HIPFFT_SUCCESS) {                                                                                     \
+            char msg_[160];                                                                                             \
+            snprintf(msg_, sizeof(msg_), "hipFFT error %d at %s:%d", (int)r_, __FILE__, __LINE__);                      \
+            amm_set_error(msg_);                                                                                        \
+            return 1;                                                                                                   \
+        }                                                                                                               \
+    } while (0)
+
+static void pme_set_self(amm_ctx *ctx, PmeForce *pm, const double *h_q) {
+    double s2 = 0.0, s1 = 0.0;
+    for (int i = 0; i < pm->n; ++i) {
+        s2 += h_q[i] * h_q[i];
+        s1 += h_q[i];
+    }
+    const double pi = 3.14159265358979323846;
+    const double vol = ctx->box.L[0] * ctx->box.L[1] * ctx->box.L[2];
+    pm->self_energy = -pm->Kc * pm->alpha / sqrt(pi) * s2 - pi * pm->Kc * s1 * s1 / (2.0 * vol * pm->alpha * pm->alpha);
+}
+
+int amm_pme_create_impl(amm_ctx *ctx, double alpha, const int *K, double Kc, const double *h_q, PmeForce **out) {
+    if (!(alpha > 0) || K[0] < PME_ORDER || K[1] < PME_ORDER || K[2] < PME_ORDER) {
+        amm_set_error("amm_pme_create: need alpha > 0 and at least 5 grid points per axis");
+        return 1;
+    }
+    PmeForce *pm = new PmeForce();
+    pm->n = ctx->n;
+    pm->alpha = alpha;
+    pm->Kc = Kc;
+    for (int k = 0; k < 3; ++k) pm->K[k] = K[k];
+    pm->nzc = K[2] / 2 + 1;
+    const size_t m = (size_t)K[0] * K[1] * K[2], mc = (size_t)K[0] * K[1] * pm->nzc;
+    AMM_HIP(hipMalloc(&pm->d_q, sizeof(double) * pm->n));
+    AMM_HIP(hipMemcpy(pm->d_q, h_q, sizeof(double) * pm->n, hipMemcpyHostToDevice));
+    AMM_HIP(hipMalloc(&pm->d_gridi, sizeof(long long) * m));
+    AMM_HIP(hipMemset(pm->d_gridi, 0, sizeof(long long) * m));
+    AMM_HIP(hipMalloc(&pm->d_grid, sizeof(double) * m));
+    AMM_HIP(hipMalloc(&pm->d_gridc, sizeof(double2) * mc));
+    for (int k = 0; k < 3; ++k) {
+        std::vector<double> mod;
+        pme_bspline_moduli(K[k], mod);
+        AMM_HIP(hipMalloc(&pm->d_bmod[k], sizeof(double) * K[k]));
+        AMM_HIP(hipMemcpy(pm->d_bmod[k], mod.data(), sizeof(double) * K[k], hipMemcpyHostToDevice));
+    }
+    pm->n_epart = (int)((mc + 255) / 256);
+    AMM_HIP(hipMalloc(&pm->d_epart, sizeof(double) * pm->n_epart));
+    pme_set_self(ctx, pm, h_q);
+    *out = pm;
+    return 0;
+}
+
+int amm_pme_set_charges_impl(amm_ctx *ctx, PmeForce *pm, const double *h_q) {
+    AMM_HIP(hipMemcpyAsync(pm->d_q, h_q, sizeof(double) * pm->n, hipMemcpyHostToDevice, ctx->stream));
+    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    pme_set_self(ctx, pm, h_q);
+    return 0;
+}
+
+int amm_reduce_add(amm_ctx *ctx, const double *d_part, int n, double scale, double *d_out);
+
+__global__ void k_add_scalar(double *out, double v) { *out += v; }
+
+int amm_pme_eval_impl(amm_ctx *ctx, PmeForce *pm, const double *d_pos, double *d_force, int accumulate, double *d_energy) {
+    hipStream_t st = ctx->stream;
+    if (!pm->plans) {
+        AMM_FFT(hipfftPlan3d(&pm->plan_f, pm->K[0], pm->K[1], pm->K[2], HIPFFT_D2Z));
+        AMM_FFT(hipfftPlan3d(&pm->plan_b, pm->K[0], pm->K[1], pm->K[2], HIPFFT_Z2D));
+        pm->plans = true;
+    }
+    AMM_FFT(hipfftSetStream(pm->plan_f, st));
+    AMM_FFT(hipfftSetStream(pm->plan_b, st));
+    const int n = pm->n, nb = (n + 255) / 256;
+    const size_t m = (size_t)pm->K[0] * pm->K[1] * pm->K[2], mc = (size_t)pm->K[0] * pm->K[1] * pm->nzc;
+    hipLaunchKernelGGL(k_pme_spread, dim3(nb), dim3(256), 0, st, n, d_pos, pm->d_q, ctx->box, pm->K[0], pm->K[1], pm->K[2],
+                       (unsigned long long *)pm->d_gridi);
+    hipLaunchKernelGGL(k_pme_finish_spread, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, pm->d_gridi, pm->d_grid);
+    AMM_FFT(hipfftExecD2Z(pm->plan_f, pm->d_grid, (hipfftDoubleComplex *)pm->d_gridc));
+    hipLaunchKernelGGL(k_pme_convolve, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, st, pm->K[0], pm->K[1], pm->K[2], pm->nzc,
+                       ctx->box, pm->alpha, pm->Kc, pm->d_bmod[0], pm->d_bmod[1], pm->d_bmod[2], pm->d_gridc, pm->d_epart);
+    AMM_FFT(hipfftExecZ2D(pm->plan_b, (hipfftDoubleComplex *)pm->d_gridc, pm->d_grid));
+    int a0 = 0, a1 = n;
+    if (pm->sliced && ctx->world > 1) {
+        const int per = (n + ctx->world - 1) / ctx->world;
+        a0 = std::min(n, ctx->rank * per);
+        a1 = std::min(n, a0 + per);
+    }
+    hipLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, st, a0, a1, d_pos, pm->d_q, ctx->box, pm->K[0], pm->K[1], pm->K[2],
+                       pm->d_grid, d_force, accumulate, 1, n);
+    AMM_HIP(hipGetLastError());
+    if (d_energy && !(pm->sliced && ctx->world > 1 && ctx->rank != 0)) {
+        if (amm_reduce_add(ctx, pm->d_epart, pm->n_epart, 1.0, d_energy)) return 1;
+        hipLaunchKernelGGL(k_add_scalar, dim3(1), dim3(1), 0, st, d_energy, pm->self_energy);
+    }
+    return 0;
+}
+
+int amm_pme_set_sliced_impl(PmeForce *pm, int on) {
+    pm->sliced = on != 0;
+    return 0;
+}
+
+int amm_pme_free(PmeForce *pm) {
+    void *ptrs[] = {pm->d_q, pm->d_gridi, pm->d_grid, pm->d_gridc, pm->d_bmod[0], pm->d_bmod[1], pm->d_bmod[2], pm->d_epart};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (pm->plans) {
+        (void)hipfftDestroy(pm->plan_f);
+        (void)hipfftDestroy(pm->plan_b);
+    }
+    delete pm;
+    return 0;
+}

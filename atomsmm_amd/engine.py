@@ -258,6 +258,14 @@ class Engine:
         entry.ewald = ewald
         if ewald:
             entry.recip_group = nb._recip_group if nb._recip_group >= 0 else nb.getForceGroup()
+            # PME mesh: explicit setPMEParameters, else OpenMM's rule ceil(2 alpha L / (3 tol^(1/5))) [recalled];
+            # nonbondedMethod Ewald is evaluated on the same mesh (smooth PME stands in for the explicit k-sum)
+            if nb._pme[0] > 0 and min(nb._pme[1:]) > 0:
+                grid = [int(k) for k in nb._pme[1:]]
+            else:
+                grid = [max(6, int(math.ceil(2 * alpha * L / (3 * nb._ewald_tol ** 0.2)))) for L in self.box]
+            entry.recip = self.ctx.pme_create(alpha, grid, eff[:, 0])
+            entry.recip_grid = grid
 
         def bonded_terms(parameters):
             q = self._effective(base, scales, names, parameters)[:, 0]
@@ -286,6 +294,8 @@ class Engine:
                     return False
                 p = self._effective(base, scales, names, parameters)
                 self.ctx.pair_set_params(pid, p[:, 0], p[:, 1], p[:, 2])
+                if entry.recip is not None:
+                    self.ctx.pme_set_charges(entry.recip, p[:, 0])
                 entry.terms = bonded_terms(parameters)
                 entry.bonded_id = self._make_bonded(entry.terms, sliced=False) if entry.terms else None
                 entry.constant = constant(parameters)
@@ -454,11 +464,6 @@ class Engine:
         torch = self.torch
         energy = forces = None
         if want_forces or want_energy:
-            for entry in self.entries:
-                if entry.recip_group is not None and mask & (1 << entry.recip_group):
-                    raise NotImplementedError(
-                        'Ewald/PME reciprocal space is not implemented in this round (SURVEY.md 8f-1): exclude group '
-                        '%d, or use a DampedSmoothedForce / CutoffPeriodic outer force' % entry.recip_group)
             e_pair = self._energy.zero_() if want_energy else None
             fp = self._fwork.zero_()
             fb = self._fwork2.zero_()
@@ -471,6 +476,11 @@ class Engine:
                     if entry.bonded_id is not None:
                         self.ctx.force_eval(entry.bonded_id, self.x, fb, accumulate=True, energy=e_bond)
                     const += entry.constant
+                if entry.recip is not None and mask & (1 << entry.recip_group):
+                    # reciprocal space: every rank evaluates all of it (spread + FFTs are not sharded)
+                    self.ctx.pme_set_sliced(entry.recip, False)
+                    self.ctx.force_eval(entry.recip, self.x, fb, accumulate=True, energy=e_bond)
+                    self.ctx.pme_set_sliced(entry.recip, getattr(entry, 'recip_sliced', False))
             self.ctx.check()
             if self.world > 1:
                 self._allreduce(fp)
@@ -510,16 +520,17 @@ class Engine:
         if g in self._group_defs:
             return self._group_defs[g]
         members = [e for e in self.entries if (e.group == g if g != 'all' else True)]
-        for e in members:
-            if e.recip_group is not None and (g == 'all' or e.recip_group == g):
-                raise NotImplementedError('Ewald/PME reciprocal space is not implemented in this round (SURVEY.md 8f-1); '
-                                          'use a DampedSmoothedForce or CutoffPeriodic outer force for group %s' % g)
         pair_ids = [pid for e in members for pid in e.pair_ids]
         terms = [t for e in members for t in e.terms]
         reduced = self.world > 1 and bool(pair_ids)
         ids = list(pair_ids)
         if terms:
             ids.append(self._make_bonded(terms, sliced=reduced))
+        for e in self.entries:
+            if e.recip is not None and (g == 'all' or e.recip_group == g):
+                e.recip_sliced = reduced
+                self.ctx.pme_set_sliced(e.recip, reduced)
+                ids.append(e.recip)
         index = B.GROUP_ALL if g == 'all' else int(g)
         slot = self._slot('f' if g == 'all' else 'f{}'.format(g))
         self.ctx.group_define(index, slot, ids)

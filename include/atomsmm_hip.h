@@ -123,6 +123,17 @@ int amm_bonded_finalize(amm_ctx *ctx, int32_t force_id);
 /* world > 1: evaluate only this rank's block of atoms (use for bonded sets living in an all-reduced group). */
 int amm_bonded_set_sliced(amm_ctx *ctx, int32_t force_id, int32_t on);
 
+/* Reciprocal space of a NonbondedForce with nonbondedMethod PME / Ewald, as RESPASystem and FarNonbondedForce
+ * keep it in group 2 with the source force's Ewald tolerance / PME parameters (systems.py:74-75,
+ * forces.py:185-188; setReciprocalSpaceForceGroup: utils.py:147-152).  Smooth PME, B-spline order 5, grid
+ * nx x ny x nz; the energy includes the Ewald self term (and the neutralising-background term of a charged box).
+ * Evaluated through amm_force_eval like the other force objects. */
+int amm_pme_create(amm_ctx *ctx, double alpha, int32_t nx, int32_t ny, int32_t nz, double Kc, const double *h_q,
+                   int32_t *force_id);
+int amm_pme_set_charges(amm_ctx *ctx, int32_t force_id, const double *h_q);   /* parameter offsets on charges */
+/* world > 1: gather forces only for this rank's block of atoms (use inside an all-reduced group). */
+int amm_pme_set_sliced(amm_ctx *ctx, int32_t force_id, int32_t on);
+
 /* Context.getState(getForces=True, getEnergy=True, groups=...)  (utils.py:159-164).
  * d_force [n][3]: overwritten (accumulate=0) or added to; d_energy: *d_energy += E (skipped if NULL). */
 int amm_force_eval(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_force,

@@ -42,6 +42,18 @@ class RecordingContext:
     def bonded_finalize(self, fid, sliced=False):
         [b for b in self.bonded if b['id'] == fid][0]['sliced'] = sliced
 
+    def pme_create(self, alpha, grid, q, Kc=138.935456):
+        fid = self._new()
+        self.pme = getattr(self, 'pme', [])
+        self.pme.append(dict(id=fid, alpha=alpha, grid=list(grid), q=q.copy(), sliced=False))
+        return fid
+
+    def pme_set_charges(self, fid, q):
+        self.calls.append(('pme_set_charges', fid, q.copy()))
+
+    def pme_set_sliced(self, fid, on=True):
+        [p for p in self.pme if p['id'] == fid][0]['sliced'] = bool(on)
+
     def bind_state(self, x, v, mass):
         pass
 

@@ -95,9 +95,9 @@ def test_RESPASystem_split_energies(spcfw, goldens):
     assert value['Total'] == pytest.approx(sum(v for k, v in value.items() if k != 'Total'))
 
 
-def test_pme_direct_space_group_G7(spcfw, goldens):
+def test_pme_direct_and_reciprocal_groups_G7_G8(spcfw, goldens):
     """Group-2 NonbondedForce of RESPASystem on a PME system: the direct-space group (pair erfc + exclusion erf
-    term + dispersion constant) reproduces tests/test_systems.py:142; the reciprocal group raises (next row)."""
+    term + dispersion constant) reproduces tests/test_systems.py:142, the reciprocal-space group :143."""
     system, positions, topology = create_system(spcfw, nonbondedMethod='PME', switch=0.9)
     respa_system = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
     nb = respa_system.getForce(atomsmm.findNonbondedForce(respa_system))
@@ -107,8 +107,25 @@ def test_pme_direct_space_group_G7(spcfw, goldens):
     context.setPositions(positions)
     e = context.getState(getEnergy=True, groups={5}).getPotentialEnergy()
     assert e / e.unit == pytest.approx(goldens['G7']['value'])
-    with pytest.raises(NotImplementedError):
-        context.getState(getEnergy=True, groups={6})
+    e = context.getState(getEnergy=True, groups={6}).getPotentialEnergy()
+    assert e / e.unit == pytest.approx(goldens['G8']['value'])
+
+
+def test_RESPASystem_split_energies_pme(spcfw, goldens):
+    """tests/test_systems.py:128-152 without the special-bond redefinitions: every component of the PME system."""
+    system, positions, topology = create_system(spcfw, nonbondedMethod='PME', switch=0.9)
+    respa_system = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    components = atomsmm.splitPotentialEnergy(respa_system, topology, positions)
+    value = {k: v / v.unit for k, v in components.items()}
+    assert value['Real-Space'] == pytest.approx(84694.39953220935)
+    assert value['Reciprocal-Space'] == pytest.approx(-111582.71281220087)
+    assert value['CustomNonbondedForce'] == pytest.approx(-25531.129587235544)
+    assert value['CustomNonbondedForce(1)'] == pytest.approx(25531.129587235544)
+    assert value['CustomBondForce'] == 0.0
+    # the reference redefines bonds/angles and adds the difference as CustomBond/CustomAngle corrections
+    # (G_bonds = 3665.68... - 1175.25..., G_angles = 1811.19... - 305.02...), so its Total is this system's Total
+    assert value['HarmonicBondForce'] + value['HarmonicAngleForce'] == pytest.approx(goldens['G_bonds']['value'] + goldens['G_angles']['value'])
+    assert value['Total'] == pytest.approx(-22891.707373668243)
 
 
 def test_solvation_offsets_G9(heaq, goldens):
@@ -141,18 +158,19 @@ def test_solvation_offsets_G9(heaq, goldens):
     assert value['PeriodicTorsionForce'] == pytest.approx(1.5998609986459567)
 
 
-def test_far_plus_near_equals_total(spcfw):
-    """tests/test_respa_forces.py:41-79 (G12) with a CutoffPeriodic source: near + FarNonbondedForce ==
+@pytest.mark.parametrize('method', ['CutoffPeriodic', 'PME'])
+def test_far_plus_near_equals_total(spcfw, method):
+    """tests/test_respa_forces.py:41-79 (G12; the reference runs it on the PME source): near + FarNonbondedForce ==
     the plain switched NonbondedForce, for the three adjustments."""
     for adjustment in (None, 'shift', 'force-switch'):
-        system, positions, topology = create_system(spcfw, nonbondedMethod='CutoffPeriodic', flexible=False)
+        system, positions, topology = create_system(spcfw, nonbondedMethod=method, flexible=False)
         nbforce = atomsmm.hijackForce(system, atomsmm.findNonbondedForce(system))
         inner = atomsmm.NearNonbondedForce(7.0 * unit.angstroms, 6.5 * unit.angstroms, adjustment)
         inner.importFrom(nbforce).addTo(system)
         outer = atomsmm.FarNonbondedForce(inner, 10 * unit.angstroms, 9.5 * unit.angstroms).setForceGroup(2)
         outer.importFrom(nbforce).addTo(system)
         potential = atomsmm.splitPotentialEnergy(system, topology, positions)['Total']
-        refsys, _, _ = create_system(spcfw, nonbondedMethod='CutoffPeriodic', cutoff=1.0, switch=0.95, flexible=False)
+        refsys, _, _ = create_system(spcfw, nonbondedMethod=method, cutoff=1.0, switch=0.95, flexible=False)
         refpot = atomsmm.splitPotentialEnergy(refsys, topology, positions)['Total']
         assert potential / potential.unit == pytest.approx(refpot / refpot.unit)
 
@@ -246,6 +264,46 @@ def test_time_reversibility_and_energy_conservation(spcfw):
 
     def total():
         s = context.getState(getEnergy=True)      # all groups: 31 (-near) cancels 1, leaving E0 + E2 = the Hamiltonian
+        return s.getPotentialEnergy()._value + s.getKineticEnergy()._value
+    e0 = total()
+    integrator.step(50)
+    e1 = total()
+    ke = context.getState(getEnergy=True).getKineticEnergy()._value
+    assert abs(e1 - e0) < 0.02 * ke
+    s = context.getState(getVelocities=True)
+    context.setVelocities(-s.getVelocities(asNumpy=True)._value)
+    integrator.step(50)
+    back = context.getState(getPositions=True).getPositions(asNumpy=True)._value
+    assert np.abs(back - c['positions']).max() < 1e-7
+
+
+def test_pme_respa_system_forces_and_dynamics(spcfw):
+    """RESPASystem on the PME source exactly as the reference builds it (systems.py:62-82: group 2 = the PME
+    NonbondedForce, reciprocal space included): (i) the group-2 forces are the gradient of the group-2 energy
+    (central differences; the B-spline derivative in the gather is analytic), (ii) [4,2,1] RESPA at 2 fs conserves
+    energy and is time-reversible."""
+    c = spcfw
+    system, positions, topology = create_system(c, nonbondedMethod='PME', switch=0.9)
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    integrator = atomsmm.RespaPropagator([4, 2, 1]).integrator(2 * unit.femtoseconds)
+    context = openmm.Context(respa, integrator)
+    context.setPositions(positions)
+    f = context.getState(getForces=True, groups={2}).getForces(asNumpy=True)._value
+    x0 = c['positions'].copy()
+    h = 1e-5
+    for atom, k in ((0, 0), (1, 2), (700, 1), (1535, 0)):
+        e = []
+        for sgn in (+1, -1):
+            x = x0.copy()
+            x[atom, k] += sgn * h
+            context.setPositions(x * unit.nanometers)
+            e.append(context.getState(getEnergy=True, groups={2}).getPotentialEnergy()._value)
+        assert -(e[0] - e[1]) / (2 * h) == pytest.approx(f[atom, k], abs=2e-5 * np.abs(f).max())
+    context.setPositions(positions)
+    context.setVelocitiesToTemperature(300 * unit.kelvin, 7)
+
+    def total():
+        s = context.getState(getEnergy=True)
         return s.getPotentialEnergy()._value + s.getKineticEnergy()._value
     e0 = total()
     integrator.step(50)

@@ -18,18 +18,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _simulate(nsteps):
+def _simulate(nsteps, pme=False):
     import atomsmm_amd as atomsmm
     from atomsmm_amd import openmm, unit
     from atomsmm_amd.openmm import app
     from atomsmm_amd.testing import system_from_arrays, tip3p_box
     c = tip3p_box(10)          # 3000 atoms, L = 3.1 nm
-    system = system_from_arrays(c, nonbondedMethod='CutoffPeriodic')
+    system = system_from_arrays(c, nonbondedMethod='PME' if pme else 'CutoffPeriodic')
     respa = atomsmm.RESPASystem(system, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
-    nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
-    outer = atomsmm.DampedSmoothedForce(2.9 / unit.nanometers, 1.0 * unit.nanometers, 0.9 * unit.nanometers).importFrom(nb)
-    outer.setForceGroup(2)
-    outer.addTo(respa)
+    if not pme:      # SURVEY 8d C3 composition; with pme the group-2 force stays the PME NonbondedForce
+        nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+        outer = atomsmm.DampedSmoothedForce(2.9 / unit.nanometers, 1.0 * unit.nanometers, 0.9 * unit.nanometers).importFrom(nb)
+        outer.setForceGroup(2)
+        outer.addTo(respa)
     integrator = atomsmm.RespaPropagator([4, 2, 1]).integrator(2 * unit.femtoseconds)
     sim = app.Simulation(app.Topology(), respa, integrator, openmm.Platform.getPlatformByName('HIP'))
     sim.context.setPositions(c['positions'] * unit.nanometers)
@@ -44,27 +45,31 @@ def _simulate(nsteps):
                 slice_atoms=stats['n_slice_atoms'], world=eng.world)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, pme=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')      # no hostname resolution on the box
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        ret[rank] = _simulate(3)
+        ret[rank] = _simulate(3, pme)
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_rank_bit_for_bit():
+@pytest.mark.parametrize('pme', [False, True])
+def test_two_ranks_match_single_rank_bit_for_bit(pme):
+    """pme=True: the group-2 buffer also carries the sliced exclusion and reciprocal-space terms, whose owner rank
+    (atom-index block) can differ from the owner of the atom's pair row (cell-sorted slice): the all-reduce then adds
+    p + (b + m) where one rank adds (p + b) + m -- agreement to rounding instead of bit for bit."""
     import torch.multiprocessing as mp
-    single = _simulate(3)
+    single = _simulate(3, pme)
     assert single['world'] == 1
     ctx = mp.get_context('spawn')
     with ctx.Manager() as manager:
         ret = manager.dict()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, pme)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
@@ -77,8 +82,14 @@ def test_two_ranks_match_single_rank_bit_for_bit():
         out = dict(ret)
     for r in (0, 1):
         assert out[r]['world'] == 2 and out[r]['slice_atoms'] == 1500
-        assert np.array_equal(out[r]['x'], single['x'])
-        assert np.array_equal(out[r]['v'], single['v'])
-        assert np.array_equal(out[r]['f'], single['f'])
+        if pme:
+            assert np.abs(out[r]['x'] - single['x']).max() < 1e-13
+            assert np.abs(out[r]['v'] - single['v']).max() < 1e-11
+            assert np.abs(out[r]['f'] - single['f']).max() < 1e-9 * np.abs(single['f']).max()
+            assert np.array_equal(out[r]['x'], out[0]['x']) and np.array_equal(out[r]['v'], out[0]['v'])
+        else:
+            assert np.array_equal(out[r]['x'], single['x'])
+            assert np.array_equal(out[r]['v'], single['v'])
+            assert np.array_equal(out[r]['f'], single['f'])
         assert out[r]['e0'] == pytest.approx(single['e0'], rel=1e-13)
         assert out[r]['e'] == pytest.approx(single['e'], rel=1e-13)

@@ -312,10 +312,15 @@ def test_engine_rejects_what_it_cannot_run(spcfw, recorder):
     respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
     ctx = openmm.Context(respa, integ)
     ctx.setPositions(spcfw['positions'])
-    with pytest.raises(NotImplementedError, match='reciprocal'):
-        integ.step(1)
-    with pytest.raises(NotImplementedError, match='reciprocal'):
-        ctx.getState(getEnergy=True)
+    # PME reciprocal space: one mesh object, OpenMM's grid rule, evaluated with the group-2 force
+    rec = ctx._engine.ctx
+    assert len(rec.pme) == 1
+    alpha = np.sqrt(-np.log(2 * 5e-4)) / 1.0
+    assert rec.pme[0]['alpha'] == pytest.approx(alpha)
+    assert rec.pme[0]['grid'] == [int(np.ceil(2 * alpha * 2.5 / (3 * 5e-4 ** 0.2)))] * 3 == [21, 21, 21]
+    integ.step(1)
+    index2, ids2 = [v for k, v in rec.groups.items() if k == 2][0]
+    assert rec.pme[0]['id'] in ids2
     custom = openmm.CustomNonbondedForce('k*r^2')
     custom.setNonbondedMethod(custom.CutoffPeriodic)
     for _ in range(1536):

@@ -62,6 +62,16 @@ def test_ewald_direct_golden_G7_and_reciprocal_G8(spcfw, goldens):
     assert e_rec == pytest.approx(goldens['G8']['value'], rel=REL)
 
 
+def test_reciprocal_golden_G14_heaq(heaq, goldens):
+    """Second reciprocal-space literal: HEAQ in water with the solute charges scaled by lambda_coul = 0.5
+    (tests/test_systems.py:84-101)."""
+    h = heaq
+    q = solvation_respa_inputs(h, 0.5)[0]
+    alpha = np.sqrt(-np.log(2 * 5e-4)) / 1.0
+    e_rec, _ = O.ewald_reciprocal(h['positions'], h['box'], q, alpha, 16)
+    assert e_rec == pytest.approx(goldens['G14']['value'], rel=REL)
+
+
 def test_bonded_goldens(spcfw, heaq, goldens):
     c = spcfw
     eb, _ = O.harmonic_bonds(c['bonds'], c['bond_r0'], c['bond_k'], c['positions'], c['box'], want_forces=False)
