@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "amm_ctx.h"
+#include "device_utils.h"
 #include "pair_math.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -88,33 +89,6 @@ __global__ void k_check_displacement(int n, const double *__restrict__ pos, cons
     if (!(d2 <= thr_out2)) flags[4] = 1;
 }
 
-// "last block" idiom: every block takes a ticket when its results have reached the device coherence point; the
-// block that draws the last one runs the serial tail of the kernel (a scan / a reduction) -- one launch less per
-// stage of the chain.  The results handed to the last block are written with device-scope atomics / atomic
-// stores only (write-through to the level shared by the 8 XCDs) and read back with device-scope atomic loads:
-// waiting for the writes to be acknowledged (s_waitcnt 0) then orders them before the ticket.  A __threadfence()
-// here would instead write back each XCD's whole dirty L2 -- including the list being built -- once per block
-// (measured: 2.6x on the build kernel).
-__device__ __forceinline__ bool amm_last_block(int *ticket) {
-    __shared__ int s_last;
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(ticket, 1);
-        s_last = (t == (int)gridDim.x - 1);
-        if (s_last) *ticket = 0;        // every other block has already drawn: safe to re-arm
-    }
-    __syncthreads();
-    return s_last != 0;
-}
-__device__ __forceinline__ int amm_ld_l2(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long amm_ld_l2(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void amm_st_l2(unsigned long long *p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // cell index of every atom + per-cell counts; the last block turns the counts into the exclusive scan
 // start[0..ncell] (fill <- start, count <- 0)
 __global__ void __launch_bounds__(256) k_cell_assign(int n, const double *__restrict__ pos, Box box, CellGrid g, int *cell_of,
@@ -137,30 +111,7 @@ __global__ void __launch_bounds__(256) k_cell_assign(int n, const double *__rest
         atomicAdd(&count[cell], 1);
     }
     if (!amm_last_block(ticket)) return;
-    // thread t scans the contiguous segment [t*per, (t+1)*per) of the counts
-    __shared__ int part[256];
-    const int t = threadIdx.x, ncell = g.ncell;
-    const int per = (ncell + 255) / 256;
-    const int c0 = min(t * per, ncell), c1 = min(c0 + per, ncell);
-    int sum = 0;
-    for (int c = c0; c < c1; ++c) sum += amm_ld_l2(&count[c]);
-    part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int add = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += add;
-        __syncthreads();
-    }
-    int run = part[t] - sum;
-    for (int c = c0; c < c1; ++c) {
-        const int v = amm_ld_l2(&count[c]);
-        start[c] = run;
-        fill[c] = run;
-        count[c] = 0;
-        run += v;
-    }
-    if (t == 255) start[ncell] = part[255];
+    amm_block_scan_counts(g.ncell, count, start, fill);
 }
 
 __global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, int *perm_tmp, const int *flags, int which,

@@ -9,10 +9,15 @@
 // it the forces, are bit-reproducible whatever order the 125 x N adds land in); rocFFT (through hipFFT) does the
 // two 3-D transforms; the convolution kernel also reduces the energy; the gather is one thread per atom.
 #include "amm_ctx.h"
+#include "device_utils.h"
 #include <hipfft/hipfft.h>
 
 #define PME_ORDER 5
 #define PME_FIXED_SCALE 4398046511104.0   // 2^42
+#define PME_TILE 8                         // mesh points per tile edge (tiled spread)
+#define PME_TS (PME_TILE + PME_ORDER - 1)  // tile edge + spline halo = 12
+#define PME_TVOL (PME_TS * PME_TS * PME_TS)
+#define PME_MAXCOVER 4
 
 struct PmeForce {
     int n = 0;
@@ -28,6 +33,14 @@ struct PmeForce {
     double *d_bmod[3] = {nullptr, nullptr, nullptr};
     double *d_epart = nullptr;
     int n_epart = 0;
+    // tiled spread (all K >= PME_TS): atoms binned by the tile of their base mesh index
+    bool tiled = false;
+    int nb[3] = {0, 0, 0}, nbins = 0;
+    int *d_bin_of = nullptr, *d_bin_count = nullptr, *d_bin_start = nullptr, *d_bin_fill = nullptr, *d_bin_atoms = nullptr;
+    int *d_ticket = nullptr;
+    long long *d_stage = nullptr;  // [nbins][PME_TVOL] fixed-point tiles
+    int *d_cover = nullptr;        // per axis and mesh index: n, then (tile, local index) pairs
+    int cover_off[3] = {0, 0, 0};
     hipfftHandle plan_f = 0, plan_b = 0;
     bool plans = false;
 };
@@ -101,6 +114,92 @@ __global__ void k_pme_finish_spread(size_t m, long long *gridi, double *grid) {
     if (p >= m) return;
     grid[p] = (double)gridi[p] * (1.0 / PME_FIXED_SCALE);
     gridi[p] = 0;
+}
+
+// ---- tiled spread: bin -> accumulate each tile in LDS (64-bit fixed-point LDS atomics) -> sum the <= 8 tiles that
+// cover a mesh point.  12.3 M device-scope atomics (404 us at C3, measured) become 98 k bin atomics + LDS traffic.
+__global__ void __launch_bounds__(256) k_pme_bin_count(int n, const double *__restrict__ pos, Box box, int Kx, int Ky, int Kz,
+                                                       int nby, int nbz, int nbins, int *bin_of, int *count, int *start,
+                                                       int *fill, int *ticket) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int ix, iy, iz;
+        double fr;
+        pme_locate(pos[3 * i], box.L[0], box.invL[0], Kx, ix, fr);
+        pme_locate(pos[3 * i + 1], box.L[1], box.invL[1], Ky, iy, fr);
+        pme_locate(pos[3 * i + 2], box.L[2], box.invL[2], Kz, iz, fr);
+        const int bin = ((ix / PME_TILE) * nby + iy / PME_TILE) * nbz + iz / PME_TILE;
+        bin_of[i] = bin;
+        atomicAdd(&count[bin], 1);
+    }
+    if (amm_last_block(ticket)) amm_block_scan_counts(nbins, count, start, fill);
+}
+
+__global__ void k_pme_bin_fill(int n, const int *__restrict__ bin_of, int *fill, int *atoms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atoms[atomicAdd(&fill[bin_of[i]], 1)] = i;
+}
+
+__global__ void __launch_bounds__(256) k_pme_spread_tiled(const double *__restrict__ pos, const double *__restrict__ q, Box box,
+                                                          int Kx, int Ky, int Kz, int nby, int nbz,
+                                                          const int *__restrict__ bin_start, const int *__restrict__ bin_atoms,
+                                                          long long *stage) {
+    __shared__ unsigned long long tile[PME_TVOL];
+    for (int t = threadIdx.x; t < PME_TVOL; t += 256) tile[t] = 0ull;
+    __syncthreads();
+    const int bin = blockIdx.x;
+    const int bz = bin % nbz, by = (bin / nbz) % nby, bx = bin / (nbz * nby);
+    const int a0 = bin_start[bin], na = bin_start[bin + 1] - a0;
+    for (int w = threadIdx.x; w < na * PME_ORDER; w += 256) {      // one (atom, x-offset) pair per thread and trip
+        const int i = bin_atoms[a0 + w / PME_ORDER], a = w % PME_ORDER;
+        const double qi = q[i];
+        if (qi == 0.0) continue;
+        int ix, iy, iz;
+        double fx, fy, fz, wx[PME_ORDER], wy[PME_ORDER], wz[PME_ORDER], d[PME_ORDER];
+        pme_locate(pos[3 * i], box.L[0], box.invL[0], Kx, ix, fx);
+        pme_locate(pos[3 * i + 1], box.L[1], box.invL[1], Ky, iy, fy);
+        pme_locate(pos[3 * i + 2], box.L[2], box.invL[2], Kz, iz, fz);
+        pme_bspline(fx, wx, d);
+        pme_bspline(fy, wy, d);
+        pme_bspline(fz, wz, d);
+        double wxa = 0.0;                       // wx[a] without dynamic register indexing
+#pragma unroll
+        for (int k = 0; k < PME_ORDER; ++k) wxa = (k == a) ? wx[k] : wxa;
+        const int lx = ix - bx * PME_TILE + a, ly = iy - by * PME_TILE, lz = iz - bz * PME_TILE;
+#pragma unroll
+        for (int b = 0; b < PME_ORDER; ++b) {
+            const double qxy = qi * wxa * wy[b];
+#pragma unroll
+            for (int c = 0; c < PME_ORDER; ++c) {
+                const long long v = __double2ll_rn(qxy * wz[c] * PME_FIXED_SCALE);
+                atomicAdd(&tile[(lx * PME_TS + ly + b) * PME_TS + lz + c], (unsigned long long)v);
+            }
+        }
+    }
+    __syncthreads();
+    long long *out = stage + (size_t)bin * PME_TVOL;
+    for (int t = threadIdx.x; t < PME_TVOL; t += 256) out[t] = (long long)tile[t];
+}
+
+// mesh point <- sum of the tiles that cover it (cover tables: per axis and index, n then n x (tile, local index))
+__global__ void k_pme_reduce_tiles(int Kx, int Ky, int Kz, int nby, int nbz, const int *__restrict__ cover, int offy, int offz,
+                                   const long long *__restrict__ stage, double *grid) {
+    const size_t m = (size_t)Kx * Ky * Kz;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const int pz = (int)(p % Kz), py = (int)((p / Kz) % Ky), px = (int)(p / ((size_t)Kz * Ky));
+    const int *cx = cover + px * (1 + 2 * PME_MAXCOVER), *cy = cover + offy + py * (1 + 2 * PME_MAXCOVER),
+              *cz = cover + offz + pz * (1 + 2 * PME_MAXCOVER);
+    long long sum = 0;
+    for (int a = 0; a < cx[0]; ++a)
+        for (int b = 0; b < cy[0]; ++b)
+            for (int c = 0; c < cz[0]; ++c) {
+                const int bin = (cx[1 + 2 * a] * nby + cy[1 + 2 * b]) * nbz + cz[1 + 2 * c];
+                const int loc = (cx[2 + 2 * a] * PME_TS + cy[2 + 2 * b]) * PME_TS + cz[2 + 2 * c];
+                sum += stage[(size_t)bin * PME_TVOL + loc];
+            }
+    grid[p] = (double)sum * (1.0 / PME_FIXED_SCALE);
 }
 
 // S(m) <- eterm(m) S(m); block partial sums of 1/2 sum_m w(m) eterm(m) |S(m)|^2 (w = 2 for the planes that the
@@ -266,6 +365,42 @@ int amm_pme_create_impl(amm_ctx *ctx, double alpha, const int *K, double Kc, con
         AMM_HIP(hipMalloc(&pm->d_bmod[k], sizeof(double) * K[k]));
         AMM_HIP(hipMemcpy(pm->d_bmod[k], mod.data(), sizeof(double) * K[k], hipMemcpyHostToDevice));
     }
+    pm->tiled = K[0] >= PME_TS && K[1] >= PME_TS && K[2] >= PME_TS;
+    if (pm->tiled) {
+        std::vector<int> cover;
+        for (int k = 0; k < 3; ++k) {
+            pm->nb[k] = (K[k] + PME_TILE - 1) / PME_TILE;
+            pm->cover_off[k] = (int)cover.size();
+            for (int p = 0; p < K[k]; ++p) {
+                std::vector<int> rec(1 + 2 * PME_MAXCOVER, 0);
+                for (int b = 0; b < pm->nb[k]; ++b) {
+                    const int l = ((p - b * PME_TILE) % K[k] + K[k]) % K[k];
+                    if (l < PME_TS) {
+                        if (rec[0] >= PME_MAXCOVER) {
+                            amm_set_error("amm_pme_create: internal error (tile cover table overflow)");
+                            return 1;
+                        }
+                        rec[1 + 2 * rec[0]] = b;
+                        rec[2 + 2 * rec[0]] = l;
+                        rec[0]++;
+                    }
+                }
+                cover.insert(cover.end(), rec.begin(), rec.end());
+            }
+        }
+        pm->nbins = pm->nb[0] * pm->nb[1] * pm->nb[2];
+        AMM_HIP(hipMalloc(&pm->d_cover, sizeof(int) * cover.size()));
+        AMM_HIP(hipMemcpy(pm->d_cover, cover.data(), sizeof(int) * cover.size(), hipMemcpyHostToDevice));
+        AMM_HIP(hipMalloc(&pm->d_bin_of, sizeof(int) * pm->n));
+        AMM_HIP(hipMalloc(&pm->d_bin_atoms, sizeof(int) * pm->n));
+        AMM_HIP(hipMalloc(&pm->d_bin_count, sizeof(int) * pm->nbins));
+        AMM_HIP(hipMemset(pm->d_bin_count, 0, sizeof(int) * pm->nbins));
+        AMM_HIP(hipMalloc(&pm->d_bin_start, sizeof(int) * (pm->nbins + 1)));
+        AMM_HIP(hipMalloc(&pm->d_bin_fill, sizeof(int) * pm->nbins));
+        AMM_HIP(hipMalloc(&pm->d_ticket, sizeof(int) * 2));
+        AMM_HIP(hipMemset(pm->d_ticket, 0, sizeof(int) * 2));
+        AMM_HIP(hipMalloc(&pm->d_stage, sizeof(long long) * (size_t)pm->nbins * PME_TVOL));
+    }
     pm->n_epart = (int)((mc + 255) / 256);
     AMM_HIP(hipMalloc(&pm->d_epart, sizeof(double) * pm->n_epart));
     pme_set_self(ctx, pm, h_q);
@@ -295,9 +430,19 @@ int amm_pme_eval_impl(amm_ctx *ctx, PmeForce *pm, const double *d_pos, double *d
     AMM_FFT(hipfftSetStream(pm->plan_b, st));
     const int n = pm->n, nb = (n + 255) / 256;
     const size_t m = (size_t)pm->K[0] * pm->K[1] * pm->K[2], mc = (size_t)pm->K[0] * pm->K[1] * pm->nzc;
-    hipLaunchKernelGGL(k_pme_spread, dim3(nb), dim3(256), 0, st, n, d_pos, pm->d_q, ctx->box, pm->K[0], pm->K[1], pm->K[2],
-                       (unsigned long long *)pm->d_gridi);
-    hipLaunchKernelGGL(k_pme_finish_spread, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, pm->d_gridi, pm->d_grid);
+    if (pm->tiled) {
+        hipLaunchKernelGGL(k_pme_bin_count, dim3(nb), dim3(256), 0, st, n, d_pos, ctx->box, pm->K[0], pm->K[1], pm->K[2], pm->nb[1],
+                           pm->nb[2], pm->nbins, pm->d_bin_of, pm->d_bin_count, pm->d_bin_start, pm->d_bin_fill, pm->d_ticket);
+        hipLaunchKernelGGL(k_pme_bin_fill, dim3(nb), dim3(256), 0, st, n, pm->d_bin_of, pm->d_bin_fill, pm->d_bin_atoms);
+        hipLaunchKernelGGL(k_pme_spread_tiled, dim3(pm->nbins), dim3(256), 0, st, d_pos, pm->d_q, ctx->box, pm->K[0], pm->K[1],
+                           pm->K[2], pm->nb[1], pm->nb[2], pm->d_bin_start, pm->d_bin_atoms, pm->d_stage);
+        hipLaunchKernelGGL(k_pme_reduce_tiles, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, pm->K[0], pm->K[1], pm->K[2],
+                           pm->nb[1], pm->nb[2], pm->d_cover, pm->cover_off[1], pm->cover_off[2], pm->d_stage, pm->d_grid);
+    } else {      // meshes narrower than one tile + halo: plain device-scope fixed-point atomics
+        hipLaunchKernelGGL(k_pme_spread, dim3(nb), dim3(256), 0, st, n, d_pos, pm->d_q, ctx->box, pm->K[0], pm->K[1], pm->K[2],
+                           (unsigned long long *)pm->d_gridi);
+        hipLaunchKernelGGL(k_pme_finish_spread, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, pm->d_gridi, pm->d_grid);
+    }
     AMM_FFT(hipfftExecD2Z(pm->plan_f, pm->d_grid, (hipfftDoubleComplex *)pm->d_gridc));
     hipLaunchKernelGGL(k_pme_convolve, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, st, pm->K[0], pm->K[1], pm->K[2], pm->nzc,
                        ctx->box, pm->alpha, pm->Kc, pm->d_bmod[0], pm->d_bmod[1], pm->d_bmod[2], pm->d_gridc, pm->d_epart);
@@ -324,7 +469,9 @@ int amm_pme_set_sliced_impl(PmeForce *pm, int on) {
 }
 
 int amm_pme_free(PmeForce *pm) {
-    void *ptrs[] = {pm->d_q, pm->d_gridi, pm->d_grid, pm->d_gridc, pm->d_bmod[0], pm->d_bmod[1], pm->d_bmod[2], pm->d_epart};
+    void *ptrs[] = {pm->d_q, pm->d_gridi, pm->d_grid, pm->d_gridc, pm->d_bmod[0], pm->d_bmod[1], pm->d_bmod[2], pm->d_epart,
+                    pm->d_bin_of, pm->d_bin_atoms, pm->d_bin_count, pm->d_bin_start, pm->d_bin_fill, pm->d_ticket, pm->d_stage,
+                    pm->d_cover};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (pm->plans) {

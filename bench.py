@@ -38,19 +38,23 @@ FLOP_PER_PAIR_NEAR = 60        # force-switch near, force only
 KB = 0.0083144626181532
 
 
-def build_simulation(nside, loops, dt_fs):
+def build_simulation(nside, loops, dt_fs, outer_kind='damped'):
     import atomsmm_amd as atomsmm
     from atomsmm_amd import openmm, unit
     from atomsmm_amd.openmm import app
     from atomsmm_amd.testing import system_from_arrays, tip3p_box
     case = tip3p_box(nside)
-    system = system_from_arrays(case, nonbondedMethod='CutoffPeriodic', cutoff=1.0, switch=0.9)
-    respa = atomsmm.RESPASystem(system, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
-    nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
-    outer = atomsmm.DampedSmoothedForce(2.9 / unit.nanometers, 1.0 * unit.nanometers, 0.9 * unit.nanometers)
-    outer.importFrom(nb)
-    outer.setForceGroup(2)
-    outer.addTo(respa)
+    if outer_kind == 'pme':      # the group-2 force stays the source PME NonbondedForce
+        system = system_from_arrays(case, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
+        respa = atomsmm.RESPASystem(system, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
+    else:                        # DampedSmoothedForce outer force
+        system = system_from_arrays(case, nonbondedMethod='CutoffPeriodic', cutoff=1.0, switch=0.9)
+        respa = atomsmm.RESPASystem(system, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
+        nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+        outer = atomsmm.DampedSmoothedForce(2.9 / unit.nanometers, 1.0 * unit.nanometers, 0.9 * unit.nanometers)
+        outer.importFrom(nb)
+        outer.setForceGroup(2)
+        outer.addTo(respa)
     integrator = atomsmm.RespaPropagator(list(loops)).integrator(dt_fs * unit.femtoseconds)
     simulation = app.Simulation(app.Topology(len(case['positions'])), respa, integrator,
                                 openmm.Platform.getPlatformByName('HIP'))
@@ -101,6 +105,8 @@ def main():
     ap.add_argument('--steps', type=int, default=500)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--nside', type=int, default=32, help='waters per box edge (32 -> 98 304 atoms)')
+    ap.add_argument('--outer', choices=['damped', 'pme'], default='damped',
+                    help="group-2 force: DampedSmoothedForce (headline, SURVEY 8d C3 i) or the PME NonbondedForce (C3 ii)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-relax', action='store_true')
     ap.add_argument('--verbose', action='store_true')
@@ -126,7 +132,7 @@ def main():
 
     loops, dt_fs = (4, 2, 1), 4.0
     t_setup = time.perf_counter()
-    simulation, case = build_simulation(args.nside, loops, dt_fs)
+    simulation, case = build_simulation(args.nside, loops, dt_fs, args.outer)
     eng = simulation.context._engine
     n = eng.n
     log('system built in %.1f s: %d atoms' % (time.perf_counter() - t_setup, n))
@@ -175,8 +181,9 @@ def main():
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'C3: %d-atom flexible TIP3P box (L = %.3f nm), RESPASystem(0.7, 0.5, force-switch) + '
-                                   'DampedSmoothedForce(2.9/nm, 1.0, 0.9) outer force, RespaPropagator([4,2,1]), 4 fs outer step'
-                                   % (n, case['box'][0]),
+                                   '%s outer force, RespaPropagator([4,2,1]), 4 fs outer step'
+                                   % (n, case['box'][0], 'DampedSmoothedForce(2.9/nm, 1.0, 0.9)' if args.outer == 'damped'
+                                      else 'PME NonbondedForce (rc 1.0, switch 0.9, tol 5e-4: direct + reciprocal space)'),
                        'atoms': n, 'loops': list(loops), 'outer_step_fs': dt_fs, 'relax_steps': relaxed,
                        'parallelism': 'atom-decomposition x%d, all-reduce of group force buffers' % world if world > 1 else 'single GPU',
                        'temperature_K_end': round(T_end, 1)},
@@ -205,7 +212,7 @@ def main():
                 result['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)'
             except Exception:
                 pass
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.outer == 'damped':
             try:
                 result['cpu_baseline'] = cpu_baseline(args.nside, loops, dt_fs)
             except Exception as exc:   # the baseline is a reported figure, never a reason to lose the GPU result

@@ -155,6 +155,29 @@ def test_pme_reciprocal_vs_exact_ewald_and_goldens(spcfw, heaq, goldens, case_na
     ctx.close()
 
 
+def test_pme_small_mesh_atomic_path_is_consistent(spcfw):
+    """Meshes narrower than one spread tile + halo (K < 12) take the plain fixed-point-atomics spread: forces are the
+    gradient of the mesh energy (central differences) and repeated evaluations are bit-identical."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    ctx = B.HipContext(n, c['box'])
+    fid = ctx.pme_create(1.2, [10, 11, 9], c['charge'])
+    x0 = c['positions'].copy()
+    e0, f0 = eval_force(ctx, fid, dev(x0), n)
+    e0b, f0b = eval_force(ctx, fid, dev(x0), n)
+    assert e0 == e0b and np.array_equal(f0, f0b)
+    h = 1e-5
+    for atom, k in ((0, 0), (5, 1), (1000, 2)):
+        e = []
+        for sgn in (+1, -1):
+            x = x0.copy()
+            x[atom, k] += sgn * h
+            e.append(eval_force(ctx, fid, dev(x), n)[0])
+        assert -(e[0] - e[1]) / (2 * h) == pytest.approx(f0[atom, k], abs=1e-6 * np.abs(f0).max())
+    ctx.close()
+
+
 def test_bonded_terms_vs_oracle(heaq, goldens):
     B = _backend()
     h = heaq
