@@ -568,9 +568,10 @@ __global__ void __launch_bounds__(256) k_prune(int s_begin, int s_end, int lpp_s
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2/K3: pair traversal.  lpa lanes per i-atom stride through the atom's neighbour row, four entries
+// K2/K3: pair traversal.  lpa lanes per i-atom stride through the atom's neighbour row, UNR entries
 // per trip with all loads issued up front (index -> position/charge -> sigma/eps gathers are the latency
-// chain; four independent chains per lane hide it), branch-free arithmetic, wavefront-shuffle reduction.
+// chain; independent chains per lane + 4-6 waves per SIMD hide it), branch-free arithmetic, wavefront-shuffle
+// reduction.
 struct PairArgs {
     int s_begin, s_end, lpa_shift, cap;
     const int *perm;
@@ -585,12 +586,11 @@ struct PairArgs {
     Box box;
 };
 
-#define AMM_UNROLL 4
 
 __device__ double amm_erfcx_table_dev[AMM_ERFCX_NI * AMM_ERFCX_NC];
 static bool g_erfcx_uploaded = false;
 
-template <int FAM, int CMODE, bool GUARD, bool EN>
+template <int FAM, int CMODE, bool GUARD, bool EN, int UNR>
 __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
     const int lpa = 1 << A.lpa_shift;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -614,24 +614,24 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
         const int *row = A.nl + (size_t)a * A.cap;
         const int back = A.cap - 1 + nfront;
         const double guard2 = GUARD ? c.rc0 * c.rc0 : 0.0;
-        for (int k0 = sub; k0 < nn; k0 += AMM_UNROLL * lpa) {
-            int js[AMM_UNROLL];
-            bool ok[AMM_UNROLL];
+        for (int k0 = sub; k0 < nn; k0 += UNR * lpa) {
+            int js[UNR];
+            bool ok[UNR];
 #pragma unroll
-            for (int u = 0; u < AMM_UNROLL; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const int k = k0 + u * lpa;
                 ok[u] = k < nn;
                 js[u] = ok[u] ? row[k < nfront ? k : back - k] : s;
             }
-            double4 pj[AMM_UNROLL];
-            double2 lj[AMM_UNROLL];
+            double4 pj[UNR];
+            double2 lj[UNR];
 #pragma unroll
-            for (int u = 0; u < AMM_UNROLL; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 pj[u] = A.posq_s[js[u]];
                 lj[u] = A.lj_s[js[u]];
             }
 #pragma unroll
-            for (int u = 0; u < AMM_UNROLL; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const double dx = amm_min_image(pi.x - pj[u].x, A.box.L[0], A.box.invL[0]);
                 const double dy = amm_min_image(pi.y - pj[u].y, A.box.L[1], A.box.invL[1]);
                 const double dz = amm_min_image(pi.z - pj[u].z, A.box.L[2], A.box.invL[2]);
@@ -676,15 +676,30 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
     }
 }
 
+template <int FAM, int CMODE, int UNR>
+static void launch_pair_u(dim3 grid, dim3 block, hipStream_t st, bool guard, bool en, const PairArgs &A, const PairConsts &c) {
+    if (guard) {
+        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, true, true, UNR>), grid, block, 0, st, A, c);
+        else hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, true, false, UNR>), grid, block, 0, st, A, c);
+    } else {
+        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, true, UNR>), grid, block, 0, st, A, c);
+        else hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, UNR>), grid, block, 0, st, A, c);
+    }
+}
+
 template <int FAM, int CMODE>
 static void launch_pair(dim3 grid, dim3 block, hipStream_t st, bool guard, bool en, const PairArgs &A, const PairConsts &c) {
-    if (guard) {
-        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, true, true>), grid, block, 0, st, A, c);
-        else hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, true, false>), grid, block, 0, st, A, c);
-    } else {
-        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, true>), grid, block, 0, st, A, c);
-        else hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false>), grid, block, 0, st, A, c);
+    // list entries per lane and trip.  2: the erfc families fit 128 VGPRs = 4 waves/SIMD (218 VGPRs = 2 waves at 4:
+    // far kernel 295 -> 254 us at C3, near kernel unchanged); AMM_UNROLL / AMM_LPA are tuning knobs for experiments.
+    static int unr = -1;
+    if (unr < 0) {
+        const char *e = getenv("AMM_UNROLL");
+        unr = e ? atoi(e) : 2;
     }
+    if (unr == 1) launch_pair_u<FAM, CMODE, 1>(grid, block, st, guard, en, A, c);
+    else if (unr == 2) launch_pair_u<FAM, CMODE, 2>(grid, block, st, guard, en, A, c);
+    else if (unr == 3) launch_pair_u<FAM, CMODE, 3>(grid, block, st, guard, en, A, c);
+    else launch_pair_u<FAM, CMODE, 4>(grid, block, st, guard, en, A, c);
 }
 
 // deterministic single-block reduction: *out += scale * sum(part[0..n))
@@ -832,6 +847,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding
     int lpa = 1;
     while (lpa < 64 && (long)nslice * lpa < 64L * 1024 * 8) lpa <<= 1;
+    if (const char *e = getenv("AMM_LPA")) lpa = atoi(e);
     pf->lpa = lpa;
     {
         // waves per cell: enough that a cell's atoms are covered by about one batch per wave
