@@ -270,8 +270,8 @@ class HipContext:
         _chk(lib().amm_pair_get_stats(self.h, fid, C.byref(st)))
         return {name: getattr(st, name) for name, _ in PairStats._fields_}
 
-    def profile_enable(self, on=True):
-        _chk(lib().amm_profile_enable(self.h, int(bool(on))))
+    def profile_enable(self, on=True, only=None):
+        _chk(lib().amm_profile_enable(self.h, -(int(only) + 1) if (on and only is not None) else int(bool(on))))
 
     def profile_read(self, fid):
         n = C.c_int64(); ms = C.c_double()

@@ -223,6 +223,7 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     fo.pair = pf;
     ctx->forces.push_back(fo);
     *force_id = (int)ctx->forces.size() - 1;
+    pf->id = *force_id;
     return amm_pair_set_params(ctx, *force_id, h_q, h_sigma, h_eps);
 }
 
@@ -517,6 +518,10 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                             if (amm_inner_components_impl(ctx, bs, ctx->d_x, ctx->d_v, f0, npre, pa, pb, pc, pp, ops[start].coef,
                                                           ops[start + 1].coef, ops[start + 3].coef, niter)) return 1;
                             ctx->pos_epoch++;
+                            for (int w = 0; w < ctx->n_prechecked; ++w) {
+                                ctx->prechecked[w]->pre_epoch = ctx->pos_epoch;
+                                ctx->prechecked[w]->pre_pos = ctx->d_x;
+                            }
                             k = q - 1;
                             continue;
                         }
@@ -665,6 +670,7 @@ int amm_set_fuse_inner(amm_ctx *ctx, int32_t on) {
 
 int amm_profile_enable(amm_ctx *ctx, int32_t on) {
     ctx->profile = on != 0;
+    ctx->profile_only = on < 0 ? -on - 1 : -1;
     return 0;
 }
 

@@ -48,6 +48,7 @@ struct PairForce {
     amm_pair_desc desc;
     PairConsts pc;
     int n = 0;
+    int id = -1;                   // force id within the context
     double skin = 0, rlist = 0;
     double rlist_build = 0;        // rlist + fp32 safety margin used by the prune pass (inner list)
     double skin_out = 0;           // outer Verlet buffer (cell-built list, radius rc + skin_out)
@@ -77,6 +78,8 @@ struct PairForce {
     int *d_ticket = nullptr;       // last-block tickets: [0] cell assign/scan [1] list build/statistics
     long checked_epoch = -1;       // ctx->pos_epoch / position buffer of the last displacement check
     const double *checked_pos = nullptr;
+    long pre_epoch = -1;           // same, for a check already made by the kernel that moved the atoms
+    const double *pre_pos = nullptr;
     int lpa = 8;                   // lanes per i-atom in the traversal kernel
     int parts = 1;                 // wavefronts per cell in the list-build kernel
     double *d_epart = nullptr;
@@ -139,11 +142,14 @@ struct amm_ctx {
     double *slots[AMM_MAX_SLOTS] = {nullptr};
     GroupDef groups[AMM_MAX_GROUPS];
     bool profile = false;
+    int profile_only = -1;         // >= 0: time only this force id (each timed launch costs two event packets)
     double *d_scratch = nullptr;   // small scratch (reductions)
     // ping-pong partners of x, v and the group-0 force buffer for the fused inner RESPA iteration
     double *alt_x = nullptr, *alt_v = nullptr, *alt_f = nullptr;
     bool fuse_inner = true;
     long pos_epoch = 0;            // bumped whenever the positions may have changed (see amm_pair_eval_impl)
+    PairForce *prechecked[2] = {nullptr, nullptr};   // lists whose displacement trigger the last integration kernel evaluated
+    int n_prechecked = 0;
     double skin_out = -1.0;        // outer Verlet buffer for pair forces created afterwards (<= 0: default)
 };
 

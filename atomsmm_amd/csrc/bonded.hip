@@ -284,6 +284,12 @@ struct CompArgs {
     const double *mass;
     double c1, d, c2;
     PreKick pre[3];
+    // displacement watchers: neighbour lists whose rebuild trigger this kernel evaluates for the positions it
+    // writes (saves the separate k_check_displacement launch before the next pair-force evaluation)
+    int nwatch;
+    const double *wref[2];
+    double wthr2[2];
+    int *wflags[2];
 };
 
 template <int MAXC>
@@ -402,6 +408,16 @@ __global__ void __launch_bounds__(256) k_inner_components(BondedArgs A, CompArgs
                 C.f0[3 * at[k] + j] = fk[k][j];
             }
         }
+    }
+    for (int w = 0; w < C.nwatch; ++w) {
+        bool moved = false;
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            const double dx = xk[k][0] - C.wref[w][3 * at[k]], dy = xk[k][1] - C.wref[w][3 * at[k] + 1],
+                         dz = xk[k][2] - C.wref[w][3 * at[k] + 2];
+            moved = moved || !(dx * dx + dy * dy + dz * dz <= C.wthr2[w]);      // slots beyond n alias atom 0 of the component
+        }
+        if (moved) C.wflags[w][0] = 1;   // benign race: every writer stores 1 (NaN also triggers)
     }
 }
 
@@ -644,6 +660,23 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     C.v = v;
     C.f0 = f0;
     C.mass = ctx->d_mass;
+    C.nwatch = 0;
+    ctx->n_prechecked = 0;
+    {
+        // single-list owners with a built list (dual lists keep their two-threshold check kernel)
+        std::vector<PairForce *> owners;
+        for (auto &fo : ctx->forces)
+            if (fo.type == 1 && fo.pair->built && !fo.pair->host && !fo.pair->dual) owners.push_back(fo.pair);
+        if (owners.size() <= 2)
+            for (PairForce *L : owners) {
+                C.wref[C.nwatch] = L->d_xref;
+                C.wthr2[C.nwatch] = 0.25 * L->skin * L->skin;
+                C.wflags[C.nwatch] = L->d_flags;
+                ctx->prechecked[C.nwatch] = L;
+                C.nwatch++;
+            }
+        ctx->n_prechecked = C.nwatch;
+    }
     C.c1 = c1;
     C.d = d;
     C.c2 = c2;

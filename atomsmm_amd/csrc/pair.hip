@@ -908,8 +908,9 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         // that shares the list): nothing to do
     } else {
         const double thr_in = 0.5 * L->skin, thr_out = L->dual ? 0.5 * (L->skin_out - L->skin) : 1.0e30;
-        hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, L->d_xref,
-                           L->dual ? L->d_xref_out : L->d_xref, thr_in * thr_in, thr_out * thr_out, L->d_flags);
+        if (!(L->pre_epoch == ctx->pos_epoch && L->pre_pos == d_pos && !L->dual))   // else: the integration kernel already checked
+            hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, L->d_xref,
+                               L->dual ? L->d_xref_out : L->d_xref, thr_in * thr_in, thr_out * thr_out, L->d_flags);
         if (L->dual) {
             if (cell_build_chain(ctx, L, d_pos, 0, false, false)) return 1;
             if (prune_chain(ctx, L, d_pos, 0, false)) return 1;
@@ -953,7 +954,8 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         A.epart = pf->d_epart;
         const bool guard = (pf->desc.flags & AMM_GUARD_RC0) != 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ctx->profile) {
+        const bool timed = ctx->profile && (ctx->profile_only < 0 || ctx->profile_only == pf->id);
+        if (timed) {
             if (pf->ev_used + 2 > pf->ev.size()) {
                 for (int k = 0; k < 64; ++k) {
                     hipEvent_t ev;
@@ -978,7 +980,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             break;
         default: amm_set_error("unknown pair family"); return 1;
         }
-        if (ctx->profile) AMM_HIP(hipEventRecord(e1, st));
+        if (timed) AMM_HIP(hipEventRecord(e1, st));
         AMM_HIP(hipGetLastError());
         if (en) {
             if (amm_reduce_add(ctx, pf->d_epart, nblk, 1.0, d_energy)) return 1;

@@ -126,6 +126,7 @@ class Engine:
         self._buffers = {}
         self._group_defs = {}
         self._valid = {}
+        self._mirror = {}           # per-DOF buffer -> force symbol it currently mirrors (`_f2_ <- f2`)
         self._programs = {}
         self._energy = torch.zeros(1, dtype=f64, device=dev)
         self._fwork = torch.zeros((n, 3), dtype=f64, device=dev)
@@ -447,6 +448,7 @@ class Engine:
 
     def fill_per_dof(self, name, value):
         self._buffer(name).fill_(value)
+        self._mirror.pop(name, None)
 
     def get_per_dof(self, name):
         return [mm.Vec3(*row) for row in self._buffer(name).cpu().numpy().tolist()]
@@ -454,6 +456,7 @@ class Engine:
     def set_per_dof(self, name, values):
         arr = np.array([list(v) for v in values], dtype=np.float64).reshape(self.n, 3)
         self._buffer(name).copy_(self.torch.as_tensor(arr, device=self.x.device))
+        self._mirror.pop(name, None)
 
     # ------------------------------------------------------------------------------- getState
     def _allreduce(self, tensor):
@@ -558,6 +561,7 @@ class Engine:
         env.update(zip(integ._gnames, integ._gvalues))
         env['dt'] = integ._dt
         valid = dict(self._valid)
+        self._mirror_work = dict(self._mirror)
         ops = []
         pc = 0
         guard = 0
@@ -586,7 +590,7 @@ class Engine:
                     pc = match[pc] - 1
             pc += 1
         finals = {name: env[name] for name in integ._gnames}
-        return ops, valid, finals
+        return ops, valid, finals, dict(self._mirror_work)
 
     def _condition(self, expr, env):
         m = re.match(r'^(.*?)(<=|>=|!=|=|<|>)(.*)$', expr)
@@ -621,6 +625,8 @@ class Engine:
                 if reduced:
                     ops.append((ALLREDUCE, slot))
                 valid[g] = True
+                for dst in [d for d, src in self._mirror_work.items() if src == name]:
+                    del self._mirror_work[dst]          # copies of the old contents are no longer copies
             return slot
         integ = self.integrator
         if name not in integ._pnames and name not in ('x', 'v'):
@@ -659,11 +665,22 @@ class Engine:
             if terms and terms[0][0] == 1 and len(terms) <= 2:
                 src = self._force_ref(terms[0][1], ops, valid)
                 dst = self._slot(target)
+                for d in [d for d, sname in self._mirror_work.items() if sname == target]:
+                    del self._mirror_work[d]
                 if len(terms) == 1:
+                    # `_f2_ <- f2` opens AND closes the RESPA program (propagators.py:940-973): the copy at the top
+                    # of the next step finds _f2_ still equal to the unchanged f2 and is dropped
+                    if self._mirror_work.get(target) == terms[0][1]:
+                        return
                     ops.append(B.Op(B.OP_COPY, dst, src, 0, 0.0))
+                    if re.fullmatch(r'f[0-9]*', terms[0][1]):
+                        self._mirror_work[target] = terms[0][1]
+                    else:
+                        self._mirror_work.pop(target, None)
                 else:
                     second = self._force_ref(terms[1][1], ops, valid)
                     ops.append(B.Op(B.OP_COMBINE, dst, src, second, float(terms[1][0])))
+                    self._mirror_work.pop(target, None)
                 return
         raise NotImplementedError('per-DOF computation outside the RESPA hot path: {} <- {}'.format(target, expr))
 
@@ -696,20 +713,25 @@ class Engine:
             if current:
                 self.ctx.run_ops(current, 1)
 
+    @staticmethod
+    def _program_key(valid, mirror):
+        return (tuple(sorted((str(g), ok) for g, ok in valid.items())), tuple(sorted(mirror.items())))
+
     def step(self, n):
         integ = self.integrator
         if not isinstance(integ, mm.CustomIntegrator):
             raise NotImplementedError('only CustomIntegrator step programs run on the HIP path')
         remaining = int(n)
         while remaining > 0:
-            key = tuple(sorted((str(g), ok) for g, ok in self._valid.items()))
+            key = self._program_key(self._valid, self._mirror)
             if key not in self._programs:
                 self._programs[key] = self._compile()
-            ops, valid_after, finals = self._programs[key]
-            after_key = tuple(sorted((str(g), ok) for g, ok in valid_after.items()))
+            ops, valid_after, finals, mirror_after = self._programs[key]
+            after_key = self._program_key(valid_after, mirror_after)
             count = remaining if after_key == key else 1
             self._run(ops, count)
             self._valid = dict(valid_after)
+            self._mirror = dict(mirror_after)
             for name, value in finals.items():
                 integ._gvalues[integ._gnames.index(name)] = value
             remaining -= count

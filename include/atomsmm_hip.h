@@ -178,6 +178,8 @@ typedef struct {
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
 /* HIP-event timing of the dominant kernel (pair traversal) on the context stream. */
+/* on = 1: HIP events around every pair-kernel launch; on = -(force_id + 1): only around that force's launches
+ * (two event packets per timed launch cost ~4 us of stream time each: time what you report); 0: off. */
 int amm_profile_enable(amm_ctx *ctx, int32_t on);
 int amm_profile_read(amm_ctx *ctx, int32_t force_id, int64_t *n_launches, double *total_ms); /* synchronises, resets */
 
