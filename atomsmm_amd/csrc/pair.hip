@@ -349,15 +349,17 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
             }
             blo = __builtin_amdgcn_readfirstlane(blo);
             bhi = __builtin_amdgcn_readfirstlane(bhi);
+            // per i-atom scalars: coordinates and the two running row lengths packed into one register
+            // (front | back << 16; rows are shorter than 65536 -- checked on the host); the kernel lives on the
+            // scalar-register budget, 8 atoms x 4 registers
             float px[AMM_BATCH], py[AMM_BATCH], pz[AMM_BATCH];
-            int cnt[AMM_BATCH], cntf[AMM_BATCH];
+            int c2[AMM_BATCH];
 #pragma unroll
             for (int t = 0; t < AMM_BATCH; ++t) {
                 px[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.x), t));
                 py[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.y), t));
                 pz[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.z), t));
-                cnt[t] = 0;
-                cntf[t] = 0;
+                c2[t] = 0;
             }
             // Row layout: entries with r < rnear fill the row from the front, the others from the back, so a
             // shorter-ranged force sharing this list walks only the front part.
@@ -375,9 +377,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                         if (s_rpref[w][r + step] <= idx) r += step;
                     const int slot = in ? s_rstart[w][r] + idx - s_rpref[w][r] : 0;
                     float4 q = pos4f_s[slot];
-                    if (RINT) {
-                        q.w = in ? 1.f : 0.f;
-                    } else {                 // image shift; lanes beyond the stream are parked far away
+                    if (!RINT) {             // image shift; lanes beyond the stream are parked far away
                         q.x = in ? q.x + s_rshift[w][0][r] : FAR;
                         q.y = in ? q.y + s_rshift[w][1][r] : FAR;
                         q.z = in ? q.z + s_rshift[w][2][r] : FAR;
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                     js[u] = in ? slot : -1;
                     inr = inr || (js[u] >= blo && js[u] <= bhi);
                 }
-                const bool special = __ballot(inr) != 0ull;      // wave-uniform, rare
+                const bool special = __builtin_amdgcn_ballot_w64(inr) != 0ull;      // wave-uniform, rare
 #pragma unroll
                 for (int t = 0; t < AMM_BATCH; ++t) {
                     if (t >= nt) break;
@@ -401,36 +401,39 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                             dz -= box.L[2] * rintf(dz * box.invL[2]);
                         }
                         const float r2 = dx * dx + dy * dy + dz * dz;
-                        bool pass = r2 < rlist2;
-                        if (RINT) pass = pass && (cand[u].w != 0.f);
-                        if (special && pass) {
+                        // lane masks live in scalar registers: ballots of plain compares, combined with scalar logic
+                        unsigned long long m_pass = __builtin_amdgcn_ballot_w64(r2 < rlist2);
+                        if (RINT) m_pass &= __builtin_amdgcn_ballot_w64(js[u] >= 0);
+                        if (special) {       // wave-uniform branch, scalar loop over the atom's exclusions
                             const int st = tb + t;
-                            if (js[u] == st) pass = false;
+                            unsigned long long m_excl = __builtin_amdgcn_ballot_w64(js[u] == st);
                             const int i = perm[st];
                             for (int k = excl_ptr[i]; k < excl_ptr[i + 1]; ++k)
-                                if (inv_perm[excl_idx[k]] == js[u]) pass = false;
+                                m_excl |= __builtin_amdgcn_ballot_w64(js[u] == inv_perm[excl_idx[k]]);
+                            m_pass &= ~m_excl;
                         }
-                        const bool nearp = pass && (r2 < rnear2);
-                        const unsigned long long balp = __builtin_amdgcn_ballot_w64(pass);
-                        const unsigned long long baln = __builtin_amdgcn_ballot_w64(nearp);
-                        const int np_ = __popcll(balp), nn_ = __popcll(baln);
+                        const unsigned long long m_near = m_pass & __builtin_amdgcn_ballot_w64(r2 < rnear2);
+                        const int np_ = __popcll(m_pass), nn_ = __popcll(m_near);
+                        const int cnt = c2[t] & 0xffff, cntf = (int)((unsigned)c2[t] >> 16);
                         if (!COUNT_ONLY) {
-                            const int mp = __builtin_amdgcn_mbcnt_hi((unsigned)(balp >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balp, 0u));
-                            const int mn = __builtin_amdgcn_mbcnt_hi((unsigned)(baln >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)baln, 0u));
-                            const int pos_in = nearp ? cnt[t] + mn : (cap - 1 - cntf[t]) - (mp - mn);
-                            const bool fits = cnt[t] + cntf[t] + np_ <= cap;           // wave-uniform
-                            if (pass && fits) row_out[pos_in] = js[u];
+                            const int mp = __builtin_amdgcn_mbcnt_hi((unsigned)(m_pass >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_pass, 0u));
+                            const int mn = __builtin_amdgcn_mbcnt_hi((unsigned)(m_near >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_near, 0u));
+                            const int pos_near = cnt + mn, pos_far = (cap - 1 - cntf) - (mp - mn);
+                            int pos_in;      // select by the scalar mask (the compiler would branch on a ternary)
+                            asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(pos_in) : "v"(pos_far), "v"(pos_near), "s"(m_near));
+                            if (cnt + cntf + np_ <= cap) {                           // wave-uniform
+                                if (__builtin_amdgcn_inverse_ballot_w64(m_pass)) row_out[pos_in] = js[u];
+                            }
                         }
-                        cnt[t] = __builtin_amdgcn_readfirstlane(cnt[t] + nn_);
-                        cntf[t] = __builtin_amdgcn_readfirstlane(cntf[t] + (np_ - nn_));
+                        c2[t] += nn_ + ((np_ - nn_) << 16);
                     }
                 }
             }
             int count = 0, countf = 0;
 #pragma unroll
             for (int t = 0; t < AMM_BATCH; ++t) {
-                count = (lane == t) ? cnt[t] : count;
-                countf = (lane == t) ? cntf[t] : countf;
+                count = (lane == t) ? (c2[t] & 0xffff) : count;
+                countf = (lane == t) ? (int)((unsigned)c2[t] >> 16) : countf;
             }
             if (lane < nt) {
                 const int total_nb = count + countf;
@@ -866,6 +869,10 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
         AMM_HIP(hipStreamSynchronize(ctx->stream));
         pf->cap_out = ((int)(flags[5] * 1.5) + 32 + 15) / 16 * 16;   // head-room for density fluctuations between rebuilds
+        if (pf->cap_out > 65535) {
+            amm_set_error("neighbour rows longer than 65535 entries are not supported (cutoff too large for this density)");
+            return 1;
+        }
         AMM_HIP(hipMalloc(&pf->d_nl_out, sizeof(int) * ns * pf->cap_out));
         if (cell_build_chain(ctx, pf, d_pos, 1, false, false)) return 1;
         // inner list: count, size, prune
@@ -883,6 +890,10 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
         AMM_HIP(hipStreamSynchronize(ctx->stream));
         pf->cap = ((int)(flags[2] * 1.5) + 32 + 15) / 16 * 16;
+        if (pf->cap > 65535) {     // the build kernel packs the two running row lengths into 16 + 16 bits
+            amm_set_error("neighbour rows longer than 65535 entries are not supported (cutoff too large for this density)");
+            return 1;
+        }
         AMM_HIP(hipMalloc(&pf->d_nl, sizeof(int) * ns * pf->cap));
         if (cell_build_chain(ctx, pf, d_pos, 1, false, true)) return 1;
     }

@@ -38,7 +38,7 @@ FLOP_PER_PAIR_NEAR = 60        # force-switch near, force only
 KB = 0.0083144626181532
 
 
-def build_simulation(nside, loops, dt_fs, outer_kind='damped'):
+def build_simulation(nside, loops, dt_fs, outer_kind='damped', skin=None):
     import atomsmm_amd as atomsmm
     from atomsmm_amd import openmm, unit
     from atomsmm_amd.openmm import app
@@ -57,7 +57,8 @@ def build_simulation(nside, loops, dt_fs, outer_kind='damped'):
         outer.addTo(respa)
     integrator = atomsmm.RespaPropagator(list(loops)).integrator(dt_fs * unit.femtoseconds)
     simulation = app.Simulation(app.Topology(len(case['positions'])), respa, integrator,
-                                openmm.Platform.getPlatformByName('HIP'))
+                                openmm.Platform.getPlatformByName('HIP'),
+                                {'Skin': str(skin)} if skin is not None else None)
     simulation.context.setPositions(case['positions'] * unit.nanometers)
     simulation.context.setVelocities(case['velocities'])
     return simulation, case
@@ -107,6 +108,7 @@ def main():
     ap.add_argument('--nside', type=int, default=32, help='waters per box edge (32 -> 98 304 atoms)')
     ap.add_argument('--outer', choices=['damped', 'pme'], default='damped',
                     help="group-2 force: DampedSmoothedForce (headline, SURVEY 8d C3 i) or the PME NonbondedForce (C3 ii)")
+    ap.add_argument('--skin', type=float, default=None, help='Verlet buffer in nm (default: the library default, 0.1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-relax', action='store_true')
     ap.add_argument('--verbose', action='store_true')
@@ -132,7 +134,7 @@ def main():
 
     loops, dt_fs = (4, 2, 1), 4.0
     t_setup = time.perf_counter()
-    simulation, case = build_simulation(args.nside, loops, dt_fs, args.outer)
+    simulation, case = build_simulation(args.nside, loops, dt_fs, args.outer, args.skin)
     eng = simulation.context._engine
     n = eng.n
     log('system built in %.1f s: %d atoms' % (time.perf_counter() - t_setup, n))
