@@ -110,7 +110,6 @@ struct BondedSet {
     double4 *d_rec_q = nullptr;    // parameters + kind/role/periodic code
     int4 *d_rec_l = nullptr;       // atoms of the term as slots within their connected component
     int *d_comp_ptr = nullptr, *d_comp_atoms = nullptr;   // connected components of the term graph (CSR)
-    int *d_cterm_ptr = nullptr, *d_cterm_rec = nullptr;   // terms of each component (role-0 record slots)
     int ncomp = 0, max_comp = 0;
     double *d_epart = nullptr;
     int n_epart = 0;

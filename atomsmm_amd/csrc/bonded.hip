@@ -252,24 +252,10 @@ __global__ void __launch_bounds__(256) k_fused_inner(BondedArgs A, FusedArgs F) 
 }
 
 // Component-parallel inner loop.  The bond-list terms of group 0 only couple atoms of the same connected component
-// (a water molecule, a small solute): ONE THREAD integrates ONE COMPONENT through ALL n0 inner RESPA iterations
+// (a water molecule, a small solute), so a component can be integrated through ALL n0 inner RESPA iterations
 //     [pre-kicks]  n0 x { v += c1 f0/m ; x += d v ; f0 = bonded(x) ; v += c2 f0/m }
-// with positions in a thread-private LDS strip (dynamic indexing by the term records), velocities/forces in
-// registers: one launch instead of 4*n0, no inter-thread dependence at all, same arithmetic and rounding as the
-// separate kernels (bit-identical).  Used when every component has at most MAXC atoms.
-template <int MAXC>
-struct PosRegs {
-    // positions of the component's atoms live in registers; a runtime slot is resolved by a select chain
-    // (an LDS strip costs a ~100-cycle dependent read per access: measured 4x slower at half a wave per SIMD)
-    const double (*x)[3];
-    __device__ __forceinline__ double get(int slot, int k) const {
-        double r = x[0][k];
-#pragma unroll
-        for (int s = 1; s < MAXC; ++s) r = slot == s ? x[s][k] : r;
-        return r;
-    }
-};
-
+// without looking at any other: one launch instead of 4*n0, same arithmetic and rounding as the separate kernels
+// (bit-identical).  Used when every component has at most 8 atoms.
 struct PreKick {
     const double *a, *b;   // v += coef*(a -/+ b)/m ; b may be null
     double coef;
@@ -289,7 +275,6 @@ __device__ __forceinline__ double amm_div_mass(double num, double m, double r, b
 
 struct CompArgs {
     const int *comp_ptr, *comp_atoms;
-    const int *cterm_ptr, *cterm_rec;   // terms of each component: index of the term's role-0 record, (kind, term) order
     int ncomp, niter, npre;
     double *x, *v, *f0;
     const double *mass;
@@ -303,139 +288,120 @@ struct CompArgs {
     int *wflags[2];
 };
 
-template <int MAXC>
-__global__ void __launch_bounds__(256) k_inner_components(BondedArgs A, CompArgs C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C.ncomp) return;
-    const int cb = C.comp_ptr[c], n = C.comp_ptr[c + 1] - cb;
-    int at[MAXC];
-    double xk[MAXC][3], vk[MAXC][3], fk[MAXC][3], mk[MAXC];
-    // all loads unconditional and issued back to back (slots beyond the component alias its first atom and are
-    // never stored): a chain of exec-masked loads would serialise ~40 memory round trips
+// G lanes (4 or 8, a power of two dividing the wavefront) share one component, lane l owns the component's atom l.  Each lane kicks/moves its own atom, publishes the new position in
+// an LDS strip of its group (same wavefront: no block barrier), and walks ITS OWN (atom, term) records exactly like
+// k_bonded does (owner-computes, same order, same bonded_term_forces) -- hence bit-identical -- reading the partner
+// atoms from the strip.  (A first version ran one THREAD per component with everything in registers: 0.5 wavefronts
+// per SIMD at C3 and select chains over register slots, 50 us per 4 iterations; this one: 2 wavefronts per SIMD, 40 us.)
+struct PosLds {
+    const double *sx, *sy, *sz;     // strip of this lane's group, indexed by component slot
+    __device__ __forceinline__ double get(int slot, int k) const { return k == 0 ? sx[slot] : (k == 1 ? sy[slot] : sz[slot]); }
+};
+
+template <int G>
+__global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
+    __shared__ double s_x[3][256];
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = tid / G, l = tid % G;
+    const bool cvalid = c < C.ncomp;
+    const int cb = cvalid ? C.comp_ptr[c] : 0, n = cvalid ? C.comp_ptr[c + 1] - cb : 0;
+    const bool has = l < n;
+    const int a = C.comp_atoms[has ? cb + l : 0];      // idle lanes alias a valid atom and never store
+    const double m = C.mass[a];
+    double x[3], v[3], f[3];
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) at[k] = C.comp_atoms[cb + (k < n ? k : 0)];
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-        mk[k] = C.mass[at[k]];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            xk[k][j] = C.x[3 * at[k] + j];
-            vk[k][j] = C.v[3 * at[k] + j];
-            fk[k][j] = C.f0[3 * at[k] + j];
-        }
+    for (int j = 0; j < 3; ++j) {
+        x[j] = C.x[3 * a + j];
+        v[j] = C.v[3 * a + j];
+        f[j] = C.f0[3 * a + j];
     }
-    double rk[MAXC];
-    bool rok[MAXC];
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-        rk[k] = 1.0 / mk[k];
-        rok[k] = (__double_as_longlong(mk[k]) & 0xFFFFFFFFFFFFFll) != 0xFFFFFFFFFFFFFll && mk[k] > 1e-200 && mk[k] < 1e200;
-    }
+    const double rm = 1.0 / m;
+    const bool rok = (__double_as_longlong(m) & 0xFFFFFFFFFFFFFll) != 0xFFFFFFFFFFFFFll && m > 1e-200 && m < 1e200;
     {
 #pragma clang fp contract(off)
         for (int p = 0; p < C.npre; ++p) {
             const PreKick pk = C.pre[p];
 #pragma unroll
-            for (int k = 0; k < MAXC; ++k) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    double ff = pk.a[3 * at[k] + j];
-                    if (pk.b) ff = pk.plus ? ff + pk.b[3 * at[k] + j] : ff - pk.b[3 * at[k] + j];
-                    const double num = pk.coef * ff;
-                    const double dv = amm_div_mass(num, mk[k], rk[k], rok[k]);
-                    vk[k][j] = vk[k][j] + dv;
-                }
+            for (int j = 0; j < 3; ++j) {
+                double ff = pk.a[3 * a + j];
+                if (pk.b) ff = pk.plus ? ff + pk.b[3 * a + j] : ff - pk.b[3 * a + j];
+                const double num = pk.coef * ff;
+                const double dv = amm_div_mass(num, m, rm, rok);
+                v[j] = v[j] + dv;
             }
         }
     }
-    PosRegs<MAXC> pos{xk};
-    // the component's term records stay in registers across the iterations (first MAXT terms; the rest is re-read)
-    constexpr int MAXT = MAXC <= 4 ? 4 : 12;
-    const int tb = C.cterm_ptr[c], nterm = C.cterm_ptr[c + 1] - tb;
-    int4 tl[MAXT];
-    double4 tq[MAXT];
+    // this atom's term records stay in registers across the iterations (first MAXR; the rest is re-read)
+    constexpr int MAXR = 4;
+    const int rb = has ? A.ref_ptr[a] : 0, nrec = has ? A.ref_ptr[a + 1] - rb : 0;
+    int4 tl[MAXR];
+    double4 tq[MAXR];
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int r = t < nterm ? C.cterm_rec[tb + t] : 0;
+    for (int t = 0; t < MAXR; ++t) {
+        const int r = t < nrec ? rb + t : 0;      // record 0 always exists (the buffers hold at least one)
         tl[t] = A.rec_l[r];
         tq[t] = A.rec_q[r];
     }
+    const int gbase = (int)threadIdx.x - l;
+    PosLds pos{&s_x[0][gbase], &s_x[1][gbase], &s_x[2][gbase]};
     for (int it = 0; it < C.niter; ++it) {
         {
 #pragma clang fp contract(off)
 #pragma unroll
-            for (int k = 0; k < MAXC; ++k) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double num = C.c1 * fk[k][j];
-                    const double dv = amm_div_mass(num, mk[k], rk[k], rok[k]);
-                    vk[k][j] = vk[k][j] + dv;
-                    const double dx = C.d * vk[k][j];
-                    xk[k][j] = xk[k][j] + dx;
-                }
+            for (int j = 0; j < 3; ++j) {
+                const double num = C.c1 * f[j];
+                const double dv = amm_div_mass(num, m, rm, rok);
+                v[j] = v[j] + dv;
+                const double dx = C.d * v[j];
+                x[j] = x[j] + dx;
             }
         }
-        // every term of the component ONCE, in (kind, term) order = the order of each atom's own reference list,
-        // so the per-atom sums match the owner-computes kernels bit for bit
-#pragma unroll
-        for (int k = 0; k < MAXC; ++k) fk[k][0] = fk[k][1] = fk[k][2] = 0.0;
-        auto do_term = [&](const int4 al, const double4 q) {
+        // publish the new position to the group (wavefront-synchronous: the group never spans two wavefronts)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // earlier reads of the strip are done
+        __builtin_amdgcn_wave_barrier();
+        s_x[0][threadIdx.x] = x[0];
+        s_x[1][threadIdx.x] = x[1];
+        s_x[2][threadIdx.x] = x[2];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f[0] = f[1] = f[2] = 0.0;
+        auto do_rec = [&](const int4 al, const double4 q) {
             const long long code = __double_as_longlong(q.w);
-            const int kind = (int)(code & 7), periodic = (int)((code >> 5) & 1);
+            const int kind = (int)(code & 7), role = (int)((code >> 3) & 3), periodic = (int)((code >> 5) & 1);
             const int ix[4] = {al.x, al.y, al.z, al.w};
             const double p[3] = {q.x, q.y, q.z};
             double fo[4][3], e;
             bonded_term_forces(A, pos, ix, p, kind, periodic, fo, e);
 #pragma unroll
-            for (int role = 0; role < 4; ++role) {
-                if (ix[role] < 0) continue;          // same for every lane of a homogeneous solvent: cheap uniform skip
-#pragma unroll
-                for (int sl = 0; sl < MAXC; ++sl) {
-#pragma unroll
-                    for (int x = 0; x < 3; ++x) fk[sl][x] = ix[role] == sl ? fk[sl][x] + fo[role][x] : fk[sl][x];
-                }
-            }
+            for (int xx = 0; xx < 3; ++xx)
+                f[xx] += role == 0 ? fo[0][xx] : (role == 1 ? fo[1][xx] : (role == 2 ? fo[2][xx] : fo[3][xx]));
         };
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (t < nterm) do_term(tl[t], tq[t]);
-        for (int t = MAXT; t < nterm; ++t) {
-            const int r = C.cterm_rec[tb + t];
-            do_term(A.rec_l[r], A.rec_q[r]);
-        }
+        for (int t = 0; t < MAXR; ++t)
+            if (t < nrec) do_rec(tl[t], tq[t]);
+        for (int t = MAXR; t < nrec; ++t) do_rec(A.rec_l[rb + t], A.rec_q[rb + t]);
         {
 #pragma clang fp contract(off)
 #pragma unroll
-            for (int k = 0; k < MAXC; ++k) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double num = C.c2 * fk[k][j];
-                    const double dv = amm_div_mass(num, mk[k], rk[k], rok[k]);
-                    vk[k][j] = vk[k][j] + dv;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-        if (k < n) {
-#pragma unroll
             for (int j = 0; j < 3; ++j) {
-                C.x[3 * at[k] + j] = xk[k][j];
-                C.v[3 * at[k] + j] = vk[k][j];
-                C.f0[3 * at[k] + j] = fk[k][j];
+                const double num = C.c2 * f[j];
+                const double dv = amm_div_mass(num, m, rm, rok);
+                v[j] = v[j] + dv;
             }
         }
     }
-    for (int w = 0; w < C.nwatch; ++w) {
-        bool moved = false;
+    if (has) {
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) {
-            const double dx = xk[k][0] - C.wref[w][3 * at[k]], dy = xk[k][1] - C.wref[w][3 * at[k] + 1],
-                         dz = xk[k][2] - C.wref[w][3 * at[k] + 2];
-            moved = moved || !(dx * dx + dy * dy + dz * dz <= C.wthr2[w]);      // slots beyond n alias atom 0 of the component
+        for (int j = 0; j < 3; ++j) {
+            C.x[3 * a + j] = x[j];
+            C.v[3 * a + j] = v[j];
+            C.f0[3 * a + j] = f[j];
         }
-        if (moved) C.wflags[w][0] = 1;   // benign race: every writer stores 1 (NaN also triggers)
+        for (int w = 0; w < C.nwatch; ++w) {
+            const double dx = x[0] - C.wref[w][3 * a], dy = x[1] - C.wref[w][3 * a + 1], dz = x[2] - C.wref[w][3 * a + 2];
+            if (!(dx * dx + dy * dy + dz * dz <= C.wthr2[w])) C.wflags[w][0] = 1;   // benign race (NaN also triggers)
+        }
     }
 }
 
@@ -527,36 +493,6 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
         rec_l[r] = make_int4(a.x >= 0 ? local_of[a.x] : -1, a.y >= 0 ? local_of[a.y] : -1, a.z >= 0 ? local_of[a.z] : -1,
                              a.w >= 0 ? local_of[a.w] : -1);
     }
-    // terms per component, (kind, t) ascending; each entry = slot of the term's role-0 record
-    std::vector<int> role0_slot_of_term[6];
-    {
-        std::vector<int> fill2(cnt.begin(), cnt.end() - 1);
-        for (int kind = 0; kind < 6; ++kind) {
-            role0_slot_of_term[kind].assign(bs->n_terms[kind], -1);
-            for (int t = 0; t < bs->n_terms[kind]; ++t)
-                for (int r = 0; r < kArity[kind]; ++r) {
-                    const int a = bs->h_idx[kind][t * kArity[kind] + r];
-                    const int slot = fill2[a]++;
-                    if (r == 0) role0_slot_of_term[kind][t] = slot;
-                }
-        }
-    }
-    std::vector<int> cterm_ptr(ncomp + 1, 0);
-    for (int kind = 0; kind < 6; ++kind)
-        for (int t = 0; t < bs->n_terms[kind]; ++t) cterm_ptr[comp_of[bs->h_idx[kind][t * kArity[kind]]] + 1]++;
-    for (int c2 = 0; c2 < ncomp; ++c2) cterm_ptr[c2 + 1] += cterm_ptr[c2];
-    std::vector<int> cterm_rec(cterm_ptr[ncomp]);
-    {
-        std::vector<int> fill3(cterm_ptr.begin(), cterm_ptr.end() - 1);
-        for (int kind = 0; kind < 6; ++kind)
-            for (int t = 0; t < bs->n_terms[kind]; ++t)
-                cterm_rec[fill3[comp_of[bs->h_idx[kind][t * kArity[kind]]]]++] = role0_slot_of_term[kind][t];
-    }
-    AMM_HIP(hipMalloc(&bs->d_cterm_ptr, sizeof(int) * (ncomp + 1)));
-    AMM_HIP(hipMemcpy(bs->d_cterm_ptr, cterm_ptr.data(), sizeof(int) * (ncomp + 1), hipMemcpyHostToDevice));
-    AMM_HIP(hipMalloc(&bs->d_cterm_rec, sizeof(int) * std::max<size_t>(cterm_rec.size(), 1)));
-    if (!cterm_rec.empty())
-        AMM_HIP(hipMemcpy(bs->d_cterm_rec, cterm_rec.data(), sizeof(int) * cterm_rec.size(), hipMemcpyHostToDevice));
     bs->ncomp = ncomp;
     bs->max_comp = maxc;
     AMM_HIP(hipMalloc(&bs->d_comp_ptr, sizeof(int) * (ncomp + 1)));
@@ -669,8 +605,6 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     CompArgs C;
     C.comp_ptr = bs->d_comp_ptr;
     C.comp_atoms = bs->d_comp_atoms;
-    C.cterm_ptr = bs->d_cterm_ptr;
-    C.cterm_rec = bs->d_cterm_rec;
     C.ncomp = bs->ncomp;
     C.niter = niter;
     C.npre = npre;
@@ -704,9 +638,11 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
         C.pre[p].coef = p < npre ? pre_coef[p] : 0.0;
         C.pre[p].plus = p < npre ? pre_plus[p] : 0;
     }
-    dim3 grid((bs->ncomp + 255) / 256), block(256);
-    if (bs->max_comp <= 4) hipLaunchKernelGGL((k_inner_components<4>), grid, block, 0, ctx->stream, A, C);
-    else hipLaunchKernelGGL((k_inner_components<8>), grid, block, 0, ctx->stream, A, C);
+    dim3 block(256);
+    const int G = bs->max_comp <= 4 ? 4 : 8;
+    dim3 grid((unsigned)(((long)bs->ncomp * G + 255) / 256));
+    if (G == 4) hipLaunchKernelGGL((k_inner_lanes<4>), grid, block, 0, ctx->stream, A, C);
+    else hipLaunchKernelGGL((k_inner_lanes<8>), grid, block, 0, ctx->stream, A, C);
     AMM_HIP(hipGetLastError());
     return 0;
 }
@@ -718,8 +654,6 @@ int amm_bonded_free(BondedSet *bs) {
     if (bs->d_rec_l) (void)hipFree(bs->d_rec_l);
     if (bs->d_comp_ptr) (void)hipFree(bs->d_comp_ptr);
     if (bs->d_comp_atoms) (void)hipFree(bs->d_comp_atoms);
-    if (bs->d_cterm_ptr) (void)hipFree(bs->d_cterm_ptr);
-    if (bs->d_cterm_rec) (void)hipFree(bs->d_cterm_rec);
     if (bs->d_epart) (void)hipFree(bs->d_epart);
     return 0;
 }
