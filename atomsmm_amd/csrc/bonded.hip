@@ -331,16 +331,17 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
             }
         }
     }
-    // this atom's term records stay in registers across the iterations (first MAXR; the rest is re-read)
+    // this atom's term records stay in LDS across the iterations (first MAXR; the rest is re-read): the record loop
+    // below is a real loop with ONE inlined copy of the term code, so the records need a dynamically indexed home
     constexpr int MAXR = 4;
+    __shared__ int4 s_tl[MAXR][256];
+    __shared__ double4 s_tq[MAXR][256];
     const int rb = has ? A.ref_ptr[a] : 0, nrec = has ? A.ref_ptr[a + 1] - rb : 0;
-    int4 tl[MAXR];
-    double4 tq[MAXR];
 #pragma unroll
     for (int t = 0; t < MAXR; ++t) {
         const int r = t < nrec ? rb + t : 0;      // record 0 always exists (the buffers hold at least one)
-        tl[t] = A.rec_l[r];
-        tq[t] = A.rec_q[r];
+        s_tl[t][threadIdx.x] = A.rec_l[r];
+        s_tq[t][threadIdx.x] = A.rec_q[r];
     }
     const int gbase = (int)threadIdx.x - l;
     PosLds pos{&s_x[0][gbase], &s_x[1][gbase], &s_x[2][gbase]};
@@ -377,10 +378,14 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
             for (int xx = 0; xx < 3; ++xx)
                 f[xx] += role == 0 ? fo[0][xx] : (role == 1 ? fo[1][xx] : (role == 2 ? fo[2][xx] : fo[3][xx]));
         };
-#pragma unroll
-        for (int t = 0; t < MAXR; ++t)
-            if (t < nrec) do_rec(tl[t], tq[t]);
-        for (int t = MAXR; t < nrec; ++t) do_rec(A.rec_l[rb + t], A.rec_q[rb + t]);
+        // ONE inlined copy of the term code (it covers every bond-list kind: unrolling this loop over a register
+        // cache multiplied the kernel to 10 k instructions, beyond the instruction cache)
+        for (int t = 0; t < nrec; ++t) {
+            const bool cached = t < MAXR;
+            const int4 al = cached ? s_tl[cached ? t : 0][threadIdx.x] : A.rec_l[rb + t];
+            const double4 q = cached ? s_tq[cached ? t : 0][threadIdx.x] : A.rec_q[rb + t];
+            do_rec(al, q);
+        }
         {
 #pragma clang fp contract(off)
 #pragma unroll
