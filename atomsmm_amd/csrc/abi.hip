@@ -297,6 +297,10 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
     AMM_HIP(hipMemcpy(pf->d_q, h_q, sizeof(double) * n, hipMemcpyHostToDevice));
     AMM_HIP(hipMemcpy(pf->d_hsig, hs.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     AMM_HIP(hipMemcpy(pf->d_seps2, se.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    // dual evaluation needs bitwise equal parameters on guest and host: re-check after any change
+    pf->dual_ok = -1;
+    for (auto &fo : ctx->forces)
+        if (fo.type == 1 && fo.pair->host == pf) fo.pair->dual_ok = -1;
     return 0;
 }
 
@@ -559,6 +563,25 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     swapped = !swapped;
                     k += 3;
                     continue;
+                }
+            }
+            // EVAL(ga) ; EVAL(gb) of a guest pair force and the owner of its list, same positions: one pass for both
+            if (ctx->fuse_inner && op.op == AMM_OP_EVAL && k + 1 < n_ops && ops[k + 1].op == AMM_OP_EVAL && op.a >= 0 &&
+                op.a < AMM_MAX_GROUPS && ops[k + 1].a >= 0 && ops[k + 1].a < AMM_MAX_GROUPS && op.a != ops[k + 1].a) {
+                GroupDef &g1 = ctx->groups[op.a], &g2 = ctx->groups[ops[k + 1].a];
+                if (g1.forces.size() == 1 && g2.forces.size() == 1 && g1.slot >= 0 && g2.slot >= 0 && ctx->slots[g1.slot] &&
+                    ctx->slots[g2.slot] && ctx->forces[g1.forces[0]].type == 1 && ctx->forces[g2.forces[0]].type == 1) {
+                    PairForce *pa = ctx->forces[g1.forces[0]].pair, *pb = ctx->forces[g2.forces[0]].pair;
+                    PairForce *guest = pa->host == pb ? pa : (pb->host == pa ? pb : nullptr);
+                    if (guest) {
+                        PairForce *host = guest->host;
+                        double *fg = ctx->slots[guest == pa ? g1.slot : g2.slot], *fh = ctx->slots[guest == pa ? g2.slot : g1.slot];
+                        if (amm_pair_can_eval_dual(ctx, guest, host)) {
+                            if (amm_pair_eval_impl(ctx, host, ctx->d_x, fh, 0, nullptr, guest, fg, 0)) return 1;
+                            k += 1;
+                            continue;
+                        }
+                    }
                 }
             }
             switch (op.op) {

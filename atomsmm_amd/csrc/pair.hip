@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "amm_ctx.h"
 #include "device_utils.h"
@@ -587,14 +588,19 @@ struct PairArgs {
     double *epart;     // per-block energy partials
     int accumulate;
     Box box;
+    double *gforce;    // dual evaluation: force buffer of the guest force that shares this list (same particles)
+    int gaccumulate;
 };
 
 
 __device__ double amm_erfcx_table_dev[AMM_ERFCX_NI * AMM_ERFCX_NC];
 static bool g_erfcx_uploaded = false;
 
-template <int FAM, int CMODE, bool GUARD, bool EN, int UNR>
-__global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
+// GFAM >= 0: the guest force of a shared list (RESPA near force, same particles, shorter cutoff) is evaluated on the
+// same pass into its own buffer: geometry, gathers, 1/r and the LJ / Coulomb pieces are common, so the guest costs a
+// switching polynomial instead of a second traversal.
+template <int FAM, int CMODE, bool GUARD, bool EN, int UNR, int GFAM>
+__global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, PairConsts gc) {
     const int lpa = 1 << A.lpa_shift;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int a = tid >> A.lpa_shift;
@@ -608,6 +614,7 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
         __syncthreads();
     }
     double fx = 0.0, fy = 0.0, fz = 0.0, esum = 0.0;
+    double gx = 0.0, gy = 0.0, gz = 0.0;
     if (valid) {
         const double4 pi = A.posq_s[s];
         const double2 li = A.lj_s[s];
@@ -649,6 +656,14 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
                 fy += fr * dy;
                 fz += fr * dz;
                 if (EN) esum += pass ? e : 0.0;
+                if (GFAM >= 0) {
+                    double eg, frg;
+                    amm_pair_math<GFAM, 0, false, false>(gc, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, eg, frg, s_tab);
+                    frg = (pass && r2 < gc.rc2) ? frg : 0.0;
+                    gx += frg * dx;
+                    gy += frg * dy;
+                    gz += frg * dz;
+                }
             }
         }
     }
@@ -657,9 +672,25 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
         fx += __shfl_xor(fx, off);
         fy += __shfl_xor(fy, off);
         fz += __shfl_xor(fz, off);
+        if (GFAM >= 0) {
+            gx += __shfl_xor(gx, off);
+            gy += __shfl_xor(gy, off);
+            gz += __shfl_xor(gz, off);
+        }
     }
     if (valid && sub == 0) {
         const int i = A.perm[s];
+        if (GFAM >= 0) {
+            if (A.gaccumulate) {
+                A.gforce[3 * i] += gx;
+                A.gforce[3 * i + 1] += gy;
+                A.gforce[3 * i + 2] += gz;
+            } else {
+                A.gforce[3 * i] = gx;
+                A.gforce[3 * i + 1] = gy;
+                A.gforce[3 * i + 2] = gz;
+            }
+        }
         if (A.accumulate) {
             A.force[3 * i] += fx;
             A.force[3 * i + 1] += fy;
@@ -682,27 +713,45 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c) {
 template <int FAM, int CMODE, int UNR>
 static void launch_pair_u(dim3 grid, dim3 block, hipStream_t st, bool guard, bool en, const PairArgs &A, const PairConsts &c) {
     if (guard) {
-        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, true, true, UNR>), grid, block, 0, st, A, c);
-        else hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, true, false, UNR>), grid, block, 0, st, A, c);
+        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, true, true, UNR, -1>), grid, block, 0, st, A, c, c);
+        else hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, true, false, UNR, -1>), grid, block, 0, st, A, c, c);
     } else {
-        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, true, UNR>), grid, block, 0, st, A, c);
-        else hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, UNR>), grid, block, 0, st, A, c);
+        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, true, UNR, -1>), grid, block, 0, st, A, c, c);
+        else hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, UNR, -1>), grid, block, 0, st, A, c, c);
     }
 }
 
-template <int FAM, int CMODE>
-static void launch_pair(dim3 grid, dim3 block, hipStream_t st, bool guard, bool en, const PairArgs &A, const PairConsts &c) {
-    // list entries per lane and trip.  2: the erfc families fit 128 VGPRs = 4 waves/SIMD (218 VGPRs = 2 waves at 4:
-    // far kernel 295 -> 254 us at C3, near kernel unchanged); AMM_UNROLL / AMM_LPA are tuning knobs for experiments.
+// list entries per lane and trip.  2: the erfc families fit 128 VGPRs = 4 waves/SIMD (218 VGPRs = 2 waves at 4:
+// far kernel 295 -> 254 us at C3, near kernel unchanged); AMM_UNROLL / AMM_LPA are tuning knobs for experiments.
+static int pair_unroll() {
     static int unr = -1;
     if (unr < 0) {
         const char *e = getenv("AMM_UNROLL");
         unr = e ? atoi(e) : 2;
     }
+    return unr;
+}
+
+template <int FAM, int CMODE>
+static void launch_pair(dim3 grid, dim3 block, hipStream_t st, bool guard, bool en, const PairArgs &A, const PairConsts &c) {
+    const int unr = pair_unroll();
     if (unr == 1) launch_pair_u<FAM, CMODE, 1>(grid, block, st, guard, en, A, c);
     else if (unr == 2) launch_pair_u<FAM, CMODE, 2>(grid, block, st, guard, en, A, c);
     else if (unr == 3) launch_pair_u<FAM, CMODE, 3>(grid, block, st, guard, en, A, c);
     else launch_pair_u<FAM, CMODE, 4>(grid, block, st, guard, en, A, c);
+}
+
+// host force + guest force of the shared list in one pass (force only, no guard on either)
+template <int FAM, int CMODE>
+static int launch_pair_dual(dim3 grid, dim3 block, hipStream_t st, int gfam, const PairArgs &A, const PairConsts &c,
+                            const PairConsts &gc) {
+    switch (gfam) {
+    case AMM_NEAR_NONE: hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, 2, AMM_NEAR_NONE>), grid, block, 0, st, A, c, gc); break;
+    case AMM_NEAR_SHIFT: hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, 2, AMM_NEAR_SHIFT>), grid, block, 0, st, A, c, gc); break;
+    case AMM_NEAR_FSWITCH: hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, 2, AMM_NEAR_FSWITCH>), grid, block, 0, st, A, c, gc); break;
+    default: amm_set_error("dual evaluation: unsupported guest family"); return 1;
+    }
+    return 0;
 }
 
 // deterministic single-block reduction: *out += scale * sum(part[0..n))
@@ -901,8 +950,10 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     return 0;
 }
 
+// guest != nullptr: `pf` owns the list `guest` traverses, both forces act on the same particles (checked by
+// amm_pair_can_eval_dual) and only forces are wanted: one pass writes pf's force to d_force and the guest's to g_force.
 int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate,
-                       double *d_energy) {
+                       double *d_energy, PairForce *guest, double *g_force, int g_accumulate) {
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
@@ -939,6 +990,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     pf->cap = L->cap;
     const int nslice = pf->s_end - pf->s_begin;
     if (!accumulate && ctx->world > 1) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, st));
+    if (guest && !g_accumulate && ctx->world > 1) AMM_HIP(hipMemsetAsync(g_force, 0, sizeof(double) * 3 * (size_t)n, st));
     if (nslice > 0) {
         PairArgs A;
         A.s_begin = pf->s_begin;
@@ -954,6 +1006,8 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         A.force = d_force;
         A.accumulate = accumulate;
         A.box = ctx->box;
+        A.gforce = g_force;
+        A.gaccumulate = g_accumulate;
         const long threads = (long)nslice << A.lpa_shift;
         const int nblk = (int)((threads + 255) / 256);
         const bool en = d_energy != nullptr;
@@ -979,6 +1033,22 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             AMM_HIP(hipEventRecord(e0, st));
         }
         dim3 grid(nblk), block(256);
+        if (guest) {
+            int rc_ = 0;
+            if (pf->desc.family == AMM_DAMPED) rc_ = launch_pair_dual<AMM_DAMPED, 0>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
+            else if (pf->desc.family == AMM_NONBONDED && pf->pc.cmode == 1)
+                rc_ = launch_pair_dual<AMM_NONBONDED, 1>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
+            else if (pf->desc.family == AMM_NONBONDED && pf->pc.cmode == 2)
+                rc_ = launch_pair_dual<AMM_NONBONDED, 2>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
+            else if (pf->desc.family == AMM_NONBONDED)
+                rc_ = launch_pair_dual<AMM_NONBONDED, 0>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
+            else {
+                amm_set_error("dual evaluation: unsupported host family");
+                rc_ = 1;
+            }
+            if (rc_) return 1;
+            guest->n_evals++;
+        } else
         switch (pf->desc.family) {
         case AMM_NEAR_NONE: launch_pair<AMM_NEAR_NONE, 0>(grid, block, st, guard, en, A, pf->pc); break;
         case AMM_NEAR_SHIFT: launch_pair<AMM_NEAR_SHIFT, 0>(grid, block, st, guard, en, A, pf->pc); break;
@@ -999,6 +1069,30 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     }
     pf->n_evals++;
     return 0;
+}
+
+// Can `guest` be evaluated on the pass of its list owner `host`?  Same particles (bitwise equal parameters), plain
+// near family without the rc0 guard on the guest, unguarded DAMPED / NONBONDED host, guest cutoff inside the front
+// part of the rows.
+bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host) {
+    if (!guest || !host || guest->host != host || host->host) return false;
+    if (guest->dual_ok >= 0) return guest->dual_ok == 1;
+    guest->dual_ok = 0;
+    const int gf = guest->desc.family, hf = host->desc.family;
+    if (!(gf == AMM_NEAR_NONE || gf == AMM_NEAR_SHIFT || gf == AMM_NEAR_FSWITCH)) return false;
+    if (!(hf == AMM_DAMPED || hf == AMM_NONBONDED)) return false;
+    if ((guest->desc.flags & AMM_GUARD_RC0) || (host->desc.flags & AMM_GUARD_RC0)) return false;
+    if (!(guest->desc.rc <= host->desc.rc)) return false;
+    const size_t n = (size_t)ctx->n;
+    std::vector<double> a(n), b(n);
+    const double *ga[3] = {guest->d_q, guest->d_hsig, guest->d_seps2}, *ha[3] = {host->d_q, host->d_hsig, host->d_seps2};
+    for (int k = 0; k < 3; ++k) {
+        if (hipMemcpy(a.data(), ga[k], sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (hipMemcpy(b.data(), ha[k], sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (std::memcmp(a.data(), b.data(), sizeof(double) * n) != 0) return false;
+    }
+    guest->dual_ok = 1;
+    return true;
 }
 
 int amm_pair_free(PairForce *pf) {

@@ -12,6 +12,10 @@
 #include "amm_ctx.h"
 #include "erfcx_table.h"
 
+// Contraction is decided per source expression (not by the optimiser across statements), so that the same pair
+// evaluated by two different kernels -- alone, or next to the guest force of a shared list -- rounds identically.
+#pragma clang fp contract(on)
+
 __device__ __forceinline__ double amm_sw_S(double u) { return 1.0 + u * u * u * (15.0 * u - 6.0 * u * u - 10.0); }
 __device__ __forceinline__ double amm_sw_dS(double u) {
     double w = u * (1.0 - u);

@@ -590,7 +590,66 @@ class Engine:
                     pc = match[pc] - 1
             pc += 1
         finals = {name: env[name] for name in integ._gnames}
-        return ops, valid, finals, dict(self._mirror_work)
+        return self._pair_up_evals(ops), valid, finals, dict(self._mirror_work)
+
+    def _pair_up_evals(self, ops):
+        """RESPA evaluates the near force (group 1) and, one kick later, the outer force (group 2) at the same positions
+        (propagators.py:940-973); the two traverse one neighbour list (_share_lists).  Move the second EVAL (and its
+        all-reduce marker) right behind the first, so that the backend evaluates both in one pass: legal when nothing in
+        between moves the atoms or touches the second group's buffer."""
+        fusable = set()
+        for gid, host in self.shared.items():
+            ga = [e.group for e in self.entries if gid in e.pair_ids]
+            gb = [e.group for e in self.entries if host in e.pair_ids]
+            if ga and gb:
+                fusable.add(frozenset((ga[0], gb[0])))
+
+        def is_eval(op):
+            return not isinstance(op, tuple) and op.op == B.OP_EVAL
+
+        def touches(op, slot):
+            if isinstance(op, tuple):
+                return op[1] == slot
+            if op.op == B.OP_KICK:
+                return slot in (op.a, op.b)
+            if op.op == B.OP_COPY:
+                return slot in (op.a, op.b)
+            if op.op == B.OP_COMBINE:
+                return slot in (op.a, op.b, op.c)
+            return False
+
+        slot_of = {index: slot for (index, slot, _) in self._group_defs.values()}
+        out = list(ops)
+        k = 0
+        while k < len(out):
+            if is_eval(out[k]):
+                first = k
+                end = first + 1
+                while end < len(out) and isinstance(out[end], tuple):      # the first EVAL's all-reduce marker
+                    end += 1
+                j = end
+                while j < len(out):
+                    op = out[j]
+                    if is_eval(op):
+                        if frozenset((out[first].a, op.a)) in fusable:
+                            slot2 = slot_of.get(op.a)
+                            if not any(touches(mid, slot2) for mid in out[end:j]):
+                                block = [op]
+                                nxt = j + 1
+                                while nxt < len(out) and isinstance(out[nxt], tuple):
+                                    block.append(out[nxt])
+                                    nxt += 1
+                                del out[j:nxt]
+                                evals = [out[first], block[0]]
+                                markers = out[first + 1:end] + block[1:]
+                                out[first:end] = evals + markers
+                        break
+                    if isinstance(op, tuple) or op.op in (B.OP_KICK,) or (op.op in (B.OP_COPY, B.OP_COMBINE) and op.a != B.SLOT_X):
+                        j += 1
+                        continue
+                    break                       # MOVE / writes to x: positions change
+            k += 1
+        return out
 
     def _condition(self, expr, env):
         m = re.match(r'^(.*?)(<=|>=|!=|=|<|>)(.*)$', expr)

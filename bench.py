@@ -121,10 +121,19 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    # one rank per GPU over RCCL; AMM_BENCH_BACKEND=gloo lets several ranks share one card to REHEARSE the
+    # multi-rank path on a 1-GPU box (numbers from such a run mean nothing)
+    backend = os.environ.get('AMM_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
 

@@ -126,5 +126,5 @@ def test_engine_collectives_under_gloo():
     # step 1: f2 reduced twice, f1 three times; step 2 (steady state): f2 once, f1 twice.  Sum over 2 ranks each time:
     # f1: 1,2 -> x2 five times = x32 ; f2: x2 three times = x8 (values double at every all-reduce)
     assert out[0]['f1'] == out[1]['f1'] and out[0]['f2'] == out[1]['f2']
-    assert out[0]['n_runs'] == out[1]['n_runs'] and out[0]['n_runs'] >= 8
+    assert out[0]['n_runs'] == out[1]['n_runs'] and out[0]['n_runs'] >= 6     # near+outer EVALs at the step boundary share a segment
     assert not any(out[0]['sliced'])
