@@ -566,7 +566,8 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 }
             }
             // EVAL(ga) ; EVAL(gb) of a guest pair force and the owner of its list, same positions: one pass for both
-            if (ctx->fuse_inner && op.op == AMM_OP_EVAL && k + 1 < n_ops && ops[k + 1].op == AMM_OP_EVAL && op.a >= 0 &&
+            static const bool no_dual = getenv("AMM_NO_DUAL") != nullptr;     // tuning knob
+            if (ctx->fuse_inner && !no_dual && op.op == AMM_OP_EVAL && k + 1 < n_ops && ops[k + 1].op == AMM_OP_EVAL && op.a >= 0 &&
                 op.a < AMM_MAX_GROUPS && ops[k + 1].a >= 0 && ops[k + 1].a < AMM_MAX_GROUPS && op.a != ops[k + 1].a) {
                 GroupDef &g1 = ctx->groups[op.a], &g2 = ctx->groups[ops[k + 1].a];
                 if (g1.forces.size() == 1 && g2.forces.size() == 1 && g1.slot >= 0 && g2.slot >= 0 && ctx->slots[g1.slot] &&

@@ -742,16 +742,29 @@ static void launch_pair(dim3 grid, dim3 block, hipStream_t st, bool guard, bool 
 }
 
 // host force + guest force of the shared list in one pass (force only, no guard on either)
-template <int FAM, int CMODE>
-static int launch_pair_dual(dim3 grid, dim3 block, hipStream_t st, int gfam, const PairArgs &A, const PairConsts &c,
-                            const PairConsts &gc) {
+template <int FAM, int CMODE, int UNR>
+static int launch_pair_dual_u(dim3 grid, dim3 block, hipStream_t st, int gfam, const PairArgs &A, const PairConsts &c,
+                              const PairConsts &gc) {
     switch (gfam) {
-    case AMM_NEAR_NONE: hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, 2, AMM_NEAR_NONE>), grid, block, 0, st, A, c, gc); break;
-    case AMM_NEAR_SHIFT: hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, 2, AMM_NEAR_SHIFT>), grid, block, 0, st, A, c, gc); break;
-    case AMM_NEAR_FSWITCH: hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, 2, AMM_NEAR_FSWITCH>), grid, block, 0, st, A, c, gc); break;
+    case AMM_NEAR_NONE: hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, UNR, AMM_NEAR_NONE>), grid, block, 0, st, A, c, gc); break;
+    case AMM_NEAR_SHIFT: hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, UNR, AMM_NEAR_SHIFT>), grid, block, 0, st, A, c, gc); break;
+    case AMM_NEAR_FSWITCH: hipLaunchKernelGGL((k_pair_nlist<FAM, CMODE, false, false, UNR, AMM_NEAR_FSWITCH>), grid, block, 0, st, A, c, gc); break;
     default: amm_set_error("dual evaluation: unsupported guest family"); return 1;
     }
     return 0;
+}
+
+// host force + guest force of the shared list in one pass (force only, no guard on either)
+template <int FAM, int CMODE>
+static int launch_pair_dual(dim3 grid, dim3 block, hipStream_t st, int gfam, const PairArgs &A, const PairConsts &c,
+                            const PairConsts &gc) {
+    static int unr = -1;
+    if (unr < 0) {
+        const char *e = getenv("AMM_DUAL_UNROLL");
+        unr = e ? atoi(e) : 2;
+    }
+    if (unr == 1) return launch_pair_dual_u<FAM, CMODE, 1>(grid, block, st, gfam, A, c, gc);
+    return launch_pair_dual_u<FAM, CMODE, 2>(grid, block, st, gfam, A, c, gc);
 }
 
 // deterministic single-block reduction: *out += scale * sum(part[0..n))
