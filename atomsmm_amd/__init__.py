@@ -28,7 +28,7 @@ from .propagators import TranslationPropagator  # noqa: F401
 from .propagators import TrotterSuzukiPropagator  # noqa: F401
 from .propagators import VelocityBoostPropagator  # noqa: F401
 from .propagators import VelocityVerletPropagator  # noqa: F401
-from .systems import RESPASystem  # noqa: F401
+from .systems import RESPASystem, SolvationSystem  # noqa: F401
 from .utils import InputError  # noqa: F401
 from .utils import countDegreesOfFreedom  # noqa: F401
 from .utils import evaluateForce  # noqa: F401
@@ -43,6 +43,6 @@ __integrators__ = ['GlobalThermostatIntegrator', 'MultipleTimeScaleIntegrator']
 __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPropagator', 'SplitPropagator',
                    'SuzukiYoshidaPropagator', 'TranslationPropagator', 'TrotterSuzukiPropagator',
                    'VelocityBoostPropagator', 'VelocityVerletPropagator']
-__systems__ = ['RESPASystem']
+__systems__ = ['RESPASystem', 'SolvationSystem']
 __utils__ = ['countDegreesOfFreedom', 'evaluateForce', 'findNonbondedForce', 'hijackForce', 'splitPotentialEnergy']
 __all__ = __forces__ + __integrators__ + __propagators__ + __systems__ + __utils__

@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libatomsmm_hip.so')
 
-NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED = range(5)
+NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE = range(6)
 GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH = 1, 2, 4, 8
 BOND_HARMONIC, ANGLE_HARMONIC, BOND_LJC, BOND_NEAR, TORSION_PERIODIC, BOND_EWALD_EXCL = range(6)
 OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE = 1, 2, 3, 4, 5
@@ -28,7 +28,7 @@ EXPORTS = [
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
-    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced',
+    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda',
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
         L.amm_pme_create.argtypes = [vp, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_double, dp, ip]
         L.amm_pme_set_charges.argtypes = [vp, C.c_int32, dp]
         L.amm_pme_set_sliced.argtypes = [vp, C.c_int32, C.c_int32]
+        L.amm_pair_set_lambda.argtypes = [vp, C.c_int32, C.c_double]
         for name in EXPORTS:
             if name not in ('amm_last_error',):
                 getattr(L, name).restype = C.c_int
@@ -188,6 +189,9 @@ class HipContext:
     def pair_set_params(self, fid, q, sigma, eps):
         q_, qp = _hd(q); s_, sp = _hd(sigma); e_, ep = _hd(eps)
         _chk(lib().amm_pair_set_params(self.h, fid, qp, sp, ep))
+
+    def pair_set_lambda(self, fid, value):
+        _chk(lib().amm_pair_set_lambda(self.h, fid, float(value)))
 
     def bonded_create(self):
         fid = C.c_int32(-1)

@@ -140,7 +140,7 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
         amm_set_error("amm_pair_create: null argument");
         return 1;
     }
-    if (desc->family < AMM_NEAR_NONE || desc->family > AMM_NONBONDED) {
+    if (desc->family < AMM_NEAR_NONE || desc->family > AMM_SOFTCORE) {
         amm_set_error("amm_pair_create: unknown family");
         return 1;
     }
@@ -225,6 +225,17 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     *force_id = (int)ctx->forces.size() - 1;
     pf->id = *force_id;
     return amm_pair_set_params(ctx, *force_id, h_q, h_sigma, h_eps);
+}
+
+int amm_pair_set_lambda(amm_ctx *ctx, int32_t force_id, double value) {
+    PairForce *pf = get_pair(ctx, force_id);
+    if (!pf) return 1;
+    if (pf->desc.family != AMM_SOFTCORE) {
+        amm_set_error("amm_pair_set_lambda: not a softcore pair force");
+        return 1;
+    }
+    pf->desc.alpha = value;
+    return amm_pair_build_consts(pf->desc, pf->pc);
 }
 
 int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id) {

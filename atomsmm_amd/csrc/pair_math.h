@@ -8,6 +8,7 @@
 //   NEAR_FSWITCH  forces.py:550-563   force-switched potential; V'(r) = S(u) V'_LJC(r) (forces.py:628)
 //   DAMPED        forces.py:448-455   SW*(LJ + erfc(alpha r) Kc qq/r), u = (r^d-rs^d)/(rc^d-rs^d)
 //   NONBONDED     forces.py:134-190   S_b*LJ + Coulomb {plain | erfc | reaction field}
+//   SOFTCORE      systems.py:266-272  S_b * 4 lambda eps (1-x)/x^2, x = (r/sigma)^6 + (1-lambda)/2, set 1 x set 2 only
 #pragma once
 #include "amm_ctx.h"
 #include "erfcx_table.h"
@@ -141,6 +142,25 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
         const double dSdr = amm_sw_dS(u) * d * rd1 * c.inv_sw_den;
         fr = S * mdV_r - dSdr * V * rinv;
         if (EN) e = S * V;
+    } else if (FAM == AMM_SOFTCORE) {
+        // qq = code_i*code_j (Kc = 1): 2 for a (set 1, set 2) pair of the interaction group; lambda travels in alpha
+        const bool member = (qq == 2.0) && (sig > 0.0);
+        const double sg = member ? sig : 1.0;
+        const double isg2 = 1.0 / (sg * sg);
+        const double t2 = r2 * isg2, t6 = t2 * t2 * t2;                 // (r/sigma)^6
+        const double x = t6 + 0.5 * (1.0 - c.alpha);
+        const double ix = 1.0 / x, ix2 = ix * ix;
+        const double le = c.alpha * eps4;                               // 4 lambda eps
+        const double V = le * (1.0 - x) * ix2;
+        const double mdV_r = 6.0 * le * (2.0 - x) * ix2 * ix * t6 * rinv2;      // (-dV/dr)/r
+        double S = 1.0, dSdr = 0.0;
+        if ((c.flags & AMM_SWITCH) && r > c.rswitch) {
+            const double t = (r - c.rswitch) * c.inv_sw_dr;
+            S = amm_sw_S(t);
+            dSdr = amm_sw_dS(t) * c.inv_sw_dr;
+        }
+        fr = member ? S * mdV_r - dSdr * V * rinv : 0.0;
+        if (EN) e = member ? S * V : 0.0;
     } else {   // AMM_NONBONDED
         double S = 1.0, dSdr = 0.0;
         if ((c.flags & AMM_SWITCH) && r > c.rswitch) {

@@ -36,6 +36,45 @@ ALLREDUCE = 'allreduce'
 _context_factory = B.HipContext   # the only backend; tests of the host logic substitute a call recorder
 
 
+def softcore_long_range_correction(sigma, eps, codes, box, rc, rswitch, lam):
+    """Long-range correction of the softcore solute-solvent CustomNonbondedForce as OpenMM defines it for a
+    CustomNonbondedForce with interaction groups [recalled; confirmed to 1e-9 by tests/test_systems.py:39]:
+        E = 4 pi N/(N+1)/V * sum over (set 1, set 2) pairs of [ int_rc^inf u r^2 dr + int_rs^rc (1 - S) u r^2 dr ],
+    u = 4 lambda eps (1-x)/x^2, x = (r/sigma)^6 + (1-lambda)/2, S the built-in switch; N = number of particles."""
+    n = len(sigma)
+    one, two = np.where(codes == 1.0)[0], np.where(codes == 2.0)[0]
+    classes = {}
+    for group in (one, two):
+        for i in group:
+            classes.setdefault((codes[i], sigma[i], eps[i]), 0)
+            classes[(codes[i], sigma[i], eps[i])] += 1
+    xg, wg = np.polynomial.legendre.leggauss(96)
+    xg, wg = 0.5 * (xg + 1.0), 0.5 * wg            # nodes / weights on (0, 1)
+
+    def u(r, s, e):
+        x = (r / s) ** 6 + 0.5 * (1.0 - lam)
+        return 4.0 * lam * e * (1.0 - x) / (x * x)
+
+    total = 0.0
+    for (c1, s1, e1), n1 in classes.items():
+        if c1 != 1.0:
+            continue
+        for (c2, s2, e2), n2 in classes.items():
+            if c2 != 2.0:
+                continue
+            s, e = 0.5 * (s1 + s2), math.sqrt(e1 * e2)
+            if e == 0.0 or s <= 0.0:
+                continue
+            r = rc / xg                                # int_rc^inf u r^2 dr = int_0^1 u(rc/x) r^4 / rc dx
+            integral = float(np.sum(wg * u(r, s, e) * r ** 4)) / rc
+            if rswitch is not None:
+                r = rswitch + xg * (rc - rswitch)
+                sw = xg ** 3 * (10.0 + xg * (-15.0 + 6.0 * xg))      # 1 - S
+                integral += (rc - rswitch) * float(np.sum(wg * sw * u(r, s, e) * r * r))
+            total += n1 * n2 * integral
+    return 4.0 * math.pi * n / (n + 1.0) * total / float(np.prod(box))
+
+
 def dispersion_correction(sigma, eps, box, rc, rswitch=None):
     """Long-range LJ correction of OpenMM's NonbondedForce, with the switching-function term
     (SURVEY.md Appendix B.6): (2 pi N^2/V) <int_rc^inf V r^2 dr + int_rs^rc (1-S) V r^2 dr> over type pairs."""
@@ -280,10 +319,16 @@ class Engine:
                               B.pair_desc(B.NONBONDED, rc, alpha=alpha)))
             return terms
 
+        defaults = {nb.getGlobalParameterName(i): nb.getGlobalParameterDefaultValue(i)
+                    for i in range(nb.getNumGlobalParameters())}
+
         def constant(parameters):
+            # OpenMM evaluates the dispersion coefficient with the global parameters at their DEFAULT values and keeps
+            # it when Context.setParameter changes them -- pinned by tests/test_systems.py:54 and :121 (sigma/epsilon
+            # offsets at lambda_vdw = 0.5: the literals are met to 2e-7 kJ/mol only this way)
             if not nb._dispersion:
                 return 0.0
-            p = self._effective(base, scales, names, parameters)
+            p = self._effective(base, scales, names, defaults)
             return dispersion_correction(p[:, 1], p[:, 2], self.box, rc, nb._switch if nb._use_switch else None)
 
         entry.terms = bonded_terms(self.parameters)
@@ -333,10 +378,12 @@ class Engine:
             raise InputError('the LJC exception expression belongs in a CustomBondForce')
         if force.getNonbondedMethod() != force.CutoffPeriodic:
             raise InputError('the HIP path evaluates CutoffPeriodic CustomNonbondedForces only')
+        if d['family'] == 'softcore':
+            return self._translate_softcore(force, entry, d)
         if force.getNumInteractionGroups() > 0:
-            raise NotImplementedError('interaction groups are outside the HIP hot path (alchemical features)')
+            raise NotImplementedError('interaction groups are supported for the softcore solute-solvent force only')
         if force.getUseLongRangeCorrection():
-            raise NotImplementedError('long-range correction of CustomNonbondedForce is not implemented')
+            raise NotImplementedError('long-range correction is supported for the softcore solute-solvent force only')
         rc = force._cutoff
         for key in ('rc0', 'rs0', 'alpha', 'rswitch', 'Kc'):
             if d.get(key) is None and key in self.parameters:
@@ -366,6 +413,53 @@ class Engine:
                 self.ctx.pair_set_params(pid, p[:, 0], p[:, 1], p[:, 2])
                 return True
             entry.update = update
+
+    def _translate_softcore(self, force, entry, d):
+        """SolvationSystem's softcore CustomNonbondedForce (systems.py:266-272): one interaction group solute x
+        solvent, cutoff / built-in switch / long-range correction imported from the NonbondedForce
+        (forces.py:284-291), lambda_vdw a global parameter."""
+        n = self.n
+        if force.getNumInteractionGroups() != 1:
+            raise NotImplementedError('softcore force: exactly one interaction group is supported')
+        set1, set2 = force._groups[0]
+        if set1 & set2:
+            raise NotImplementedError('softcore force: overlapping interaction-group sets')
+        names = list(getattr(force, '_offset_parameters', []))
+        allp = np.array(force._particles, dtype=np.float64).reshape(n, -1)
+        base = allp[:, :3]
+        scales = np.stack([allp[:, 3 * (k + 1):3 * (k + 2)] for k in range(len(names))]) if names else np.zeros((0, n, 3))
+        codes = np.zeros(n)
+        codes[sorted(set1)] = 1.0
+        codes[sorted(set2)] = 2.0
+        lam_name = d['lambda_name']
+        rc = force._cutoff
+        rswitch = force._switch if force.getUseSwitchingFunction() else None
+        excl = np.array(force._exclusions, dtype=np.int32).reshape(-1, 2)
+        eff = self._effective(base, scales, names, self.parameters)
+        desc = B.pair_desc(B.SOFTCORE, rc, rswitch=rswitch or 0.0, alpha=self.parameters[lam_name],
+                           flags=B.SWITCH if rswitch is not None else 0, Kc=1.0)
+        pid = self._pair_create(desc, codes, eff[:, 1], eff[:, 2], excl)
+        entry.pair_ids.append(pid)
+        use_lrc = force.getUseLongRangeCorrection()
+
+        def constant(parameters):
+            if not use_lrc:
+                return 0.0
+            p = self._effective(base, scales, names, parameters)
+            return softcore_long_range_correction(p[:, 1], p[:, 2], codes, self.box, rc, rswitch, parameters[lam_name])
+
+        entry.constant = constant(self.parameters)
+        lam = set(names) | {lam_name}
+
+        def update(parameters, changed):
+            if not (lam & changed):
+                return False
+            p = self._effective(base, scales, names, parameters)
+            self.ctx.pair_set_params(pid, codes, p[:, 1], p[:, 2])
+            self.ctx.pair_set_lambda(pid, parameters[lam_name])
+            entry.constant = constant(parameters)
+            return True
+        entry.update = update
 
     def _translate_custom_bond(self, force, entry):
         d = dict(self._descriptor_of(force))

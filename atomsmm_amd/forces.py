@@ -116,7 +116,13 @@ def describe_energy(energy, global_parameters=None):
     elif head == '4*epsilon*x*(x-1)+Kc*chargeprod/r':
         desc['family'] = 'ljc'
     else:
-        return None
+        # SolvationSystem's solute-solvent softcore Lennard-Jones (systems.py:268)
+        m = re.fullmatch(r'4\*(\w+)\*epsilon\*\(1-x\)/x\^2', head)
+        aux = [p.replace(' ', '') for p in parts[1:]]
+        if m and 'x=(r/sigma)^6+0.5*(1-%s)' % m.group(1) in aux:
+            desc.update(family='softcore', lambda_name=m.group(1))
+        else:
+            return None
     return desc
 
 

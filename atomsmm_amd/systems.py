@@ -14,8 +14,10 @@ Alchemical inputs (CustomNonbondedForces named U_linear/U_spline/U_art/U_general
 and the special bond/angle redefinitions (systems.py:121-237) are outside this round's scope.
 """
 import copy
+import itertools
+import math
 
-from . import forces, openmm
+from . import forces, openmm, utils
 from .unit import md_value
 
 
@@ -63,3 +65,65 @@ class RESPASystem(openmm.System):
         if force.getNumBonds() > 0:
             force.setForceGroup(group)
             self.addForce(force)
+
+
+class SolvationSystem(openmm.System):
+    """`atomsmm.systems.SolvationSystem(system, solute_atoms, use_softcore=True, softcore_group=0,
+    split_exceptions=False)` (reference: src/atomsmm/systems.py:240-313): a System prepared for solvation
+    free-energy calculations.
+
+    * solute-solvent Lennard-Jones either as a softcore CustomNonbondedForce over the interaction group
+      (solute, solvent) with global parameter `lambda_vdw` (systems.py:266-272), or -- `use_softcore=False` -- by
+      `lambda_vdw` parameter offsets on sigma and epsilon of the solute atoms (systems.py:309-312);
+    * every solute-solute pair becomes an exception of the NonbondedForce (systems.py:274-287);
+    * solute LJ parameters are zeroed and the solute charges become `lambda_coul` offsets (systems.py:289-308).
+    """
+
+    def __init__(self, system, solute_atoms, use_softcore=True, softcore_group=0, split_exceptions=False):
+        openmm.System.__init__(self)
+        self._copy_from(system)
+        nonbonded = self.getForce(utils.findNonbondedForce(self))
+        solute_atoms = set(int(i) for i in solute_atoms)
+        solvent_atoms = set(range(nonbonded.getNumParticles())) - solute_atoms
+        if split_exceptions:
+            exceptions = forces._AtomsMM_CustomBondForce('4*epsilon*x*(x-1) + Kc*chargeprod/r; x=(sigma/r)^6; Kc=138.935456')
+            exceptions.importFrom(nonbonded, extract=True)
+            exceptions._amm = dict(family='ljc', sign=1.0, guard=False, Kc=forces.KC)
+            if exceptions.getNumBonds() > 0:
+                self.addForce(exceptions)
+        softcore = None
+        if use_softcore:
+            softcore = forces._AtomsMM_CustomNonbondedForce(
+                '4*lambda_vdw*epsilon*(1-x)/x^2; x=(r/sigma)^6+0.5*(1-lambda_vdw)', lambda_vdw=1)
+            softcore.importFrom(nonbonded)
+            softcore.addInteractionGroup(solute_atoms, solvent_atoms)
+            softcore.setForceGroup(softcore_group)
+            self.addForce(softcore)
+        have = set()
+        for index in range(nonbonded.getNumExceptions()):
+            i, j = nonbonded.getExceptionParameters(index)[:2]
+            if i in solute_atoms and j in solute_atoms:
+                have.add(frozenset((i, j)))
+        for i, j in itertools.combinations(sorted(solute_atoms), 2):
+            if frozenset((i, j)) not in have:
+                q1, sig1, eps1 = nonbonded.getParticleParameters(i)
+                q2, sig2, eps2 = nonbonded.getParticleParameters(j)
+                nonbonded.addException(i, j, q1 * q2, (sig1 + sig2) / 2, (eps1 * eps2).sqrt())
+                if softcore is not None:
+                    softcore.addExclusion(i, j)
+        charges, lj_parameters = {}, {}
+        for index in sorted(solute_atoms):
+            charge, sigma, epsilon = nonbonded.getParticleParameters(index)
+            nonbonded.setParticleParameters(index, 0.0, 0.0, 0.0)
+            if md_value(charge) != 0.0:
+                charges[index] = charge
+            if md_value(epsilon) != 0.0:
+                lj_parameters[index] = (sigma, epsilon)
+        if charges:
+            nonbonded.addGlobalParameter('lambda_coul', 1.0)
+            for index, charge in charges.items():
+                nonbonded.addParticleParameterOffset('lambda_coul', index, charge, 0.0, 0.0)
+        if lj_parameters and not use_softcore:
+            nonbonded.addGlobalParameter('lambda_vdw', 1.0)
+            for index, (sigma, epsilon) in lj_parameters.items():
+                nonbonded.addParticleParameterOffset('lambda_vdw', index, 0.0, sigma, epsilon)

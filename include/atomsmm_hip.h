@@ -36,13 +36,18 @@ enum {
     AMM_NEAR_SHIFT = 1,     /* S(u) (V_LJC(r) - V_LJC(rc0))    forces.py:544-548                        */
     AMM_NEAR_FSWITCH = 2,   /* force-switched LJC              forces.py:549-563 (V' = S V'_LJC, :628)  */
     AMM_DAMPED = 3,         /* DampedSmoothedForce             forces.py:448-455                        */
-    AMM_NONBONDED = 4       /* _AtomsMM_NonbondedForce direct space  forces.py:134-190, 723             */
+    AMM_NONBONDED = 4,      /* _AtomsMM_NonbondedForce direct space  forces.py:134-190, 723             */
+    AMM_SOFTCORE = 5        /* SolvationSystem's solute-solvent softcore LJ, 4 lambda eps (1-x)/x^2 with
+                               x = (r/sigma)^6 + (1-lambda)/2, restricted to an interaction group
+                               (systems.py:266-272).  lambda = desc.alpha; the charge array carries the set of
+                               each atom (1, 2, 0 = neither; use Kc = 1): a pair counts iff the codes multiply
+                               to 2; AMM_SWITCH = OpenMM's built-in switch imported with the cutoff            */
 };
 enum {
     AMM_GUARD_RC0 = 1,      /* energy *= step(rc0 - r)         forces.py:661, 714 ; systems.py:73      */
     AMM_COULOMB_EWALD = 2,  /* NONBONDED: Kc qq erfc(alpha r)/r                                         */
     AMM_COULOMB_RF = 4,     /* NONBONDED: reaction field (parity unpinned)              */
-    AMM_SWITCH = 8          /* NONBONDED: OpenMM built-in switch on the LJ term                         */
+    AMM_SWITCH = 8          /* NONBONDED / SOFTCORE: OpenMM built-in switch rswitch -> rc                */
 };
 
 typedef struct {
@@ -115,6 +120,9 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
 int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id);
 
 /* CustomBondForce / HarmonicBondForce / HarmonicAngleForce term lists of one force group. */
+/* context.setParameter('lambda_vdw', value) for a softcore pair force (systems.py:267: global parameter). */
+int amm_pair_set_lambda(amm_ctx *ctx, int32_t force_id, double value);
+
 int amm_bonded_create(amm_ctx *ctx, int32_t *force_id);
 int amm_bonded_add_terms(amm_ctx *ctx, int32_t force_id, int32_t kind, const int32_t *h_idx,
                          const double *h_params, int32_t n_terms, int32_t periodic,

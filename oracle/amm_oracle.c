@@ -135,6 +135,22 @@ void ammo_pair_kernel(const ammo_pair_desc *d, double r2, double qq, double sig,
             dedr += dcoul;
         }
     } break;
+    case AMMO_SOFTCORE: {        /* systems.py:268 with OpenMM's built-in switch (imported flags, forces.py:286-289) */
+        if (qq != 2.0 || !(sig > 0.0)) break;                     /* interaction group: set 1 x set 2 only */
+        double lam = d->alpha;
+        double rs_ = r / sig, rs2 = rs_ * rs_, rs6 = rs2 * rs2 * rs2;
+        double x = rs6 + 0.5 * (1.0 - lam);
+        double V = 4.0 * lam * eps * (1.0 - x) / (x * x);
+        double dV = 4.0 * lam * eps * (x - 2.0) / (x * x * x) * 6.0 * rs6 * inv;
+        double S = 1.0, dS = 0.0;
+        if ((d->flags & AMMO_SWITCH) && r > d->rswitch) {
+            double t = (r - d->rswitch) / (d->rc - d->rswitch);
+            S = sw_S(t);
+            dS = sw_dS(t) / (d->rc - d->rswitch);
+        }
+        e = S * V;
+        dedr = dS * V + S * dV;
+    } break;
     default: break;
     }
     *e_out = d->sign * e;

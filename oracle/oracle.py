@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED = range(5)
+NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE = range(6)
 GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH = 1, 2, 4, 8
 KC = 138.935456   # forces.py:407
 ADJ = {None: NEAR_NONE, 'shift': NEAR_SHIFT, 'force-switch': NEAR_FSWITCH}
@@ -148,6 +148,37 @@ def ewald_reciprocal(pos, box, q, alpha, kmax, Kc=KC, want_forces=False):
 def dispersion_correction(sigma, eps, box, rc, rswitch=None):
     s_, sp = _d(sigma); e_, ep = _d(eps); b_, bp = _d(box)
     return lib().ammo_dispersion_correction(len(s_), sp, ep, bp, rc, rswitch or 0.0, int(rswitch is not None))
+
+
+def softcore_lrc(sigma, eps, codes, box, rc, rswitch, lam):
+    """Long-range correction of a softcore CustomNonbondedForce with one interaction group (OpenMM
+    CustomNonbondedForceImpl::calcLongRangeCorrection [recalled]): (4 pi / V) N/(N+1) sum over (set 1, set 2) pairs
+    of int_rc^inf u r^2 dr + int_rs^rc (1 - S) u r^2 dr.  scipy adaptive quadrature (independent of the product's
+    Gauss-Legendre rule)."""
+    from scipy.integrate import quad
+
+    def u(r, s, e):
+        x = (r / s) ** 6 + 0.5 * (1.0 - lam)
+        return 4.0 * lam * e * (1.0 - x) / (x * x)
+
+    n = len(sigma)
+    cls = {}
+    for i in np.where(np.asarray(codes) == 1)[0]:
+        for j in np.where(np.asarray(codes) == 2)[0]:
+            e = np.sqrt(eps[i] * eps[j])
+            if e > 0:
+                key = (0.5 * (sigma[i] + sigma[j]), e)
+                cls[key] = cls.get(key, 0) + 1
+    total = 0.0
+    for (s, e), count in cls.items():
+        integral = quad(lambda r: u(r, s, e) * r * r, rc, np.inf, epsabs=0, epsrel=1e-12)[0]
+        if rswitch is not None:
+            def f(r):
+                t = (r - rswitch) / (rc - rswitch)
+                return t ** 3 * (10 - 15 * t + 6 * t * t) * u(r, s, e) * r * r
+            integral += quad(f, rswitch, rc, epsabs=0, epsrel=1e-12)[0]
+        total += count * integral
+    return 4 * np.pi * n / (n + 1.0) * total / float(np.prod(box))
 
 
 def _bonded(fn, idx, params, pos, box, periodic, want_forces, pre=()):

@@ -31,6 +31,9 @@ class RecordingContext:
     def pair_set_params(self, fid, q, sigma, eps):
         self.calls.append(('pair_set_params', fid, q.copy(), sigma.copy(), eps.copy()))
 
+    def pair_set_lambda(self, fid, value):
+        self.calls.append(('pair_set_lambda', fid, value))
+
     def bonded_create(self):
         fid = self._new()
         self.bonded.append(dict(id=fid, terms=[], sliced=False))

@@ -178,6 +178,31 @@ def test_pme_small_mesh_atomic_path_is_consistent(spcfw):
     ctx.close()
 
 
+def test_softcore_interaction_group_vs_oracle_and_G15(heaq, goldens):
+    """AMM_SOFTCORE (SolvationSystem's solute-solvent softcore LJ, systems.py:266-272) through the C-ABI: energy
+    and forces vs the oracle at three lambdas (amm_pair_set_lambda), and with the long-range correction vs the
+    reference literal tests/test_systems.py:39."""
+    B = _backend()
+    h = heaq
+    n = len(h['positions'])
+    codes = np.where(h['resname'] == 'aaa', 1.0, 2.0)
+    ctx = B.HipContext(n, h['box'])
+    desc = B.pair_desc(B.SOFTCORE, 1.0, rswitch=0.9, alpha=0.5, flags=B.SWITCH, Kc=1.0)
+    fid = ctx.pair_create(desc, codes, h['sigma'], h['epsilon'], h['exc_pairs'])
+    pos = dev(h['positions'])
+    for lam in (0.5, 1.0, 0.1):
+        ctx.pair_set_lambda(fid, lam)
+        e, f = eval_force(ctx, fid, pos, n)
+        d = O.desc(O.SOFTCORE, rc=1.0, rswitch=0.9, alpha=lam, flags=O.SWITCH, Kc=1.0)
+        e_ref, f_ref, _ = O.pair_eval(d, h['positions'], h['box'], codes, h['sigma'], h['epsilon'], h['exc_pairs'])
+        assert e == pytest.approx(e_ref, rel=1e-10)
+        assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+        if lam == 0.5:
+            e_lrc = O.softcore_lrc(h['sigma'], h['epsilon'], codes, h['box'], 1.0, 0.9, 0.5)
+            assert e + e_lrc == pytest.approx(goldens['G15']['value'], rel=2e-7)
+    ctx.close()
+
+
 def test_bonded_terms_vs_oracle(heaq, goldens):
     B = _backend()
     h = heaq

@@ -315,3 +315,76 @@ def test_pme_respa_system_forces_and_dynamics(spcfw):
     integrator.step(50)
     back = context.getState(getPositions=True).getPositions(asNumpy=True)._value
     assert np.abs(back - c['positions']).max() < 1e-7
+
+
+def _heaq_system(heaq):
+    """readSystem of tests/test_systems.py:13-26: PME, rc 1.0 nm, switch 0.9 nm, flexible, no constraints."""
+    system, positions, topology = create_system(heaq, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
+    solute = set(int(i) for i in np.where(heaq['resname'] == 'aaa')[0])
+    return system, positions, topology, solute
+
+
+def _check(components, potential):
+    assert set(components) == set(potential)
+    for term, value in components.items():
+        assert value / value.unit == pytest.approx(potential[term]), term
+
+
+def test_SolvationSystem(heaq):                                    # tests/test_systems.py:28-42
+    system, positions, topology, solute = _heaq_system(heaq)
+    solvation_system = atomsmm.SolvationSystem(system, solute)
+    components = atomsmm.splitPotentialEnergy(solvation_system, topology, positions, lambda_vdw=0.5, lambda_coul=0.5)
+    _check(components, {'HarmonicBondForce': 1815.1848188179738, 'HarmonicAngleForce': 1111.5544374007236,
+                        'PeriodicTorsionForce': 1.5998609986459567, 'Real-Space': 58273.35327317236,
+                        'Reciprocal-Space': -76436.3982762784, 'CustomNonbondedForce': -64.67189605331785,
+                        'Total': -15299.377781942014})
+
+
+def test_SolvationSystem_with_lj_parameter_scaling(heaq):          # tests/test_systems.py:45-58
+    system, positions, topology, solute = _heaq_system(heaq)
+    solvation_system = atomsmm.SolvationSystem(system, solute, use_softcore=False)
+    components = atomsmm.splitPotentialEnergy(solvation_system, topology, positions, lambda_vdw=0.5, lambda_coul=0.5)
+    _check(components, {'HarmonicBondForce': 1815.1848188179738, 'HarmonicAngleForce': 1111.5544374007236,
+                        'PeriodicTorsionForce': 1.5998609986459567, 'Real-Space': 58235.03496195241,
+                        'Reciprocal-Space': -76436.3982762784, 'Total': -15273.024197108643})
+
+
+def test_RESPASystem_on_SolvationSystem(heaq):                     # tests/test_systems.py:61-80
+    system, positions, topology, solute = _heaq_system(heaq)
+    solvation_system = atomsmm.SolvationSystem(system, solute)
+    respa_system = atomsmm.RESPASystem(solvation_system, 7 * unit.angstroms, 5 * unit.angstroms)
+    components = atomsmm.splitPotentialEnergy(respa_system, topology, positions, lambda_vdw=0.5, lambda_coul=0.5)
+    _check(components, {'HarmonicBondForce': 1815.1848188179738, 'HarmonicAngleForce': 1111.5544374007236,
+                        'PeriodicTorsionForce': 1.5998609986459567, 'Real-Space': 58161.10011792888,
+                        'Reciprocal-Space': -76436.3982762784, 'CustomNonbondedForce': -64.67189605331785,
+                        'CustomNonbondedForce(1)': -17294.836032921234, 'CustomNonbondedForce(2)': 17294.836032921194,
+                        'CustomBondForce': 112.25315524350334, 'Total': -15299.377781942032})
+
+
+def test_RESPASystem_with_exception_offsets(heaq):                 # tests/test_systems.py:83-107
+    system, positions, topology, solute = _heaq_system(heaq)
+    solvation_system = atomsmm.SolvationSystem(system, solute)
+    nbforce = solvation_system.getForce(atomsmm.findNonbondedForce(solvation_system))
+    for index in range(nbforce.getNumExceptions()):
+        i, j, chargeprod, sigma, epsilon = nbforce.getExceptionParameters(index)
+        nbforce.setExceptionParameters(index, i, j, 0.0, sigma, epsilon)
+        nbforce.addExceptionParameterOffset('lambda_coul', index, chargeprod, 0.0, 0.0)
+    respa_system = atomsmm.RESPASystem(solvation_system, 7 * unit.angstroms, 5 * unit.angstroms)
+    components = atomsmm.splitPotentialEnergy(respa_system, topology, positions, lambda_vdw=0.5, lambda_coul=0.5)
+    _check(components, {'HarmonicBondForce': 1815.1848188179738, 'HarmonicAngleForce': 1111.5544374007236,
+                        'PeriodicTorsionForce': 1.5998609986459567, 'Real-Space': 58201.09912379701,
+                        'Reciprocal-Space': -76436.3982762784, 'CustomNonbondedForce': -64.67189605331785,
+                        'CustomNonbondedForce(1)': -17294.836032921234, 'CustomNonbondedForce(2)': 17294.836032921194,
+                        'CustomBondForce': 72.25414937535754, 'Total': -15299.377781942048})
+
+
+def test_RESPASystem_with_lj_parameter_scaling(heaq):              # tests/test_systems.py:110-128
+    system, positions, topology, solute = _heaq_system(heaq)
+    solvation_system = atomsmm.SolvationSystem(system, solute, use_softcore=False)
+    respa_system = atomsmm.RESPASystem(solvation_system, 7 * unit.angstroms, 5 * unit.angstroms)
+    components = atomsmm.splitPotentialEnergy(respa_system, topology, positions, lambda_vdw=0.5, lambda_coul=0.5)
+    _check(components, {'HarmonicBondForce': 1815.1848188179738, 'HarmonicAngleForce': 1111.5544374007236,
+                        'PeriodicTorsionForce': 1.5998609986459567, 'Real-Space': 58122.78180670893,
+                        'Reciprocal-Space': -76436.3982762784, 'CustomNonbondedForce': -17317.054135213173,
+                        'CustomNonbondedForce(1)': 17317.054135213126, 'CustomBondForce': 112.25315524350334,
+                        'Total': -15273.024197108669})

@@ -72,6 +72,29 @@ def test_reciprocal_golden_G14_heaq(heaq, goldens):
     assert e_rec == pytest.approx(goldens['G14']['value'], rel=REL)
 
 
+def test_softcore_golden_G15(heaq, goldens):
+    """SolvationSystem's softcore force (systems.py:266-272) on HEAQ at lambda_vdw = 0.5: pair sum over the
+    (solute, solvent) interaction group with OpenMM's built-in switch + the CustomNonbondedForce long-range
+    correction = tests/test_systems.py:39."""
+    h = heaq
+    codes = np.where(h['resname'] == 'aaa', 1.0, 2.0)
+    d = O.desc(O.SOFTCORE, rc=1.0, rswitch=0.9, alpha=0.5, flags=O.SWITCH, Kc=1.0)
+    e_pair, f, _ = O.pair_eval(d, h['positions'], h['box'], codes, h['sigma'], h['epsilon'], h['exc_pairs'])
+    e_lrc = O.softcore_lrc(h['sigma'], h['epsilon'], codes, h['box'], 1.0, 0.9, 0.5)
+    # 2.3e-8 observed: OpenMM integrates the correction with a 1e-5 relative stopping criterion
+    assert e_pair + e_lrc == pytest.approx(goldens['G15']['value'], rel=2e-7)
+    # forces of the pinned energy: central differences on a solute and a solvent atom
+    x0, eps_ = h['positions'], 1e-5
+    for atom in (int(np.where(codes == 1.0)[0][3]), int(np.where(codes == 2.0)[0][0])):
+        for k in range(3):
+            ep = []
+            for sgn in (1, -1):
+                x = x0.copy()
+                x[atom, k] += sgn * eps_
+                ep.append(O.pair_eval(d, x, h['box'], codes, h['sigma'], h['epsilon'], h['exc_pairs'], want_forces=False)[0])
+            assert -(ep[0] - ep[1]) / (2 * eps_) == pytest.approx(f[atom, k], abs=2e-5)
+
+
 def test_bonded_goldens(spcfw, heaq, goldens):
     c = spcfw
     eb, _ = O.harmonic_bonds(c['bonds'], c['bond_r0'], c['bond_k'], c['positions'], c['box'], want_forces=False)
