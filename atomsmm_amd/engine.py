@@ -201,6 +201,15 @@ class Engine:
             a = np.array([r[:3] for r in force._angles], dtype=np.int32).reshape(-1, 3)
             p = np.array([r[3:] for r in force._angles], dtype=np.float64).reshape(-1, 2)
             entry.terms.append((B.ANGLE_HARMONIC, a, p, force.usesPeriodicBoundaryConditions(), None))
+        elif isinstance(force, mm.CustomAngleForce):
+            if force.getEnergyFunction().replace(' ', '') != '0.5*(K0*(theta-t0)^2-Kn*(theta-tn)^2)':
+                raise InputError('CustomAngleForce: only the redefine_angle difference potential is supported')
+            # difference of two harmonic angles (RESPASystem.redefine_angle, systems.py:226)
+            a = np.array([r[:3] for r in force._angles], dtype=np.int32).reshape(-1, 3)
+            p = np.array([r[3] for r in force._angles], dtype=np.float64).reshape(-1, 4)
+            periodic = force.usesPeriodicBoundaryConditions()
+            entry.terms.append((B.ANGLE_HARMONIC, a, p[:, [0, 1]], periodic, None))
+            entry.terms.append((B.ANGLE_HARMONIC, a, np.stack([p[:, 2], -p[:, 3]], axis=1), periodic, None))
         elif isinstance(force, mm.PeriodicTorsionForce):
             t = np.array([r[:4] for r in force._torsions], dtype=np.int32).reshape(-1, 4)
             p = np.array([[r[4], r[5], r[6]] for r in force._torsions], dtype=np.float64).reshape(-1, 3)
@@ -462,6 +471,14 @@ class Engine:
         entry.update = update
 
     def _translate_custom_bond(self, force, entry):
+        if force.getEnergyFunction().replace(' ', '') == '0.5*(K0*(r-r0)^2-Kn*(r-rn)^2)':
+            # difference of two harmonic bonds (RESPASystem.redefine_bond, systems.py:162): +K0 at r0, -Kn at rn
+            idx = np.array([[b[0], b[1]] for b in force._bonds], dtype=np.int32).reshape(-1, 2)
+            par = np.array([b[2] for b in force._bonds], dtype=np.float64).reshape(-1, 4)
+            periodic = force.usesPeriodicBoundaryConditions()
+            entry.terms.append((B.BOND_HARMONIC, idx, par[:, [0, 1]], periodic, None))
+            entry.terms.append((B.BOND_HARMONIC, idx, np.stack([par[:, 2], -par[:, 3]], axis=1), periodic, None))
+            return
         d = dict(self._descriptor_of(force))
         nb_ = force.getNumBonds()
         idx = np.array([[b[0], b[1]] for b in force._bonds], dtype=np.int32).reshape(-1, 2)

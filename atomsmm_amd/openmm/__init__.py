@@ -440,6 +440,46 @@ class HarmonicBondForce(Force):
         return self._periodic
 
 
+class CustomAngleForce(Force, _GlobalParams):
+    def __init__(self, energy):
+        Force.__init__(self)
+        self._init_globals()
+        self._energy = energy
+        self._anames = []
+        self._angles = []
+        self._periodic = False
+
+    def getEnergyFunction(self):
+        return self._energy
+
+    def addPerAngleParameter(self, name):
+        self._anames.append(name)
+        return len(self._anames) - 1
+
+    def getNumPerAngleParameters(self):
+        return len(self._anames)
+
+    def getPerAngleParameterName(self, index):
+        return self._anames[index]
+
+    def addAngle(self, particle1, particle2, particle3, parameters=()):
+        self._angles.append([int(particle1), int(particle2), int(particle3), [float(md_value(p)) for p in parameters]])
+        return len(self._angles) - 1
+
+    def getNumAngles(self):
+        return len(self._angles)
+
+    def getAngleParameters(self, index):
+        i, j, k, p = self._angles[index]
+        return [i, j, k, tuple(p)]
+
+    def setUsesPeriodicBoundaryConditions(self, periodic):
+        self._periodic = bool(periodic)
+
+    def usesPeriodicBoundaryConditions(self):
+        return self._periodic
+
+
 class HarmonicAngleForce(Force):
     def __init__(self):
         Force.__init__(self)
@@ -456,6 +496,9 @@ class HarmonicAngleForce(Force):
     def getAngleParameters(self, index):
         i, j, k_, t0, k = self._angles[index]
         return [i, j, k_, Quantity(t0, _unit.radian), Quantity(k, kjmol / _unit.radian ** 2)]
+
+    def setAngleParameters(self, index, particle1, particle2, particle3, angle, k):
+        self._angles[index] = [int(particle1), int(particle2), int(particle3), float(md_value(angle)), float(md_value(k))]
 
     def setUsesPeriodicBoundaryConditions(self, periodic):
         self._periodic = bool(periodic)

@@ -11,11 +11,12 @@ Given a System, it re-groups the nonbonded interactions for RESPA integration:
 The integrator forms the slow force as f2 - f1 (propagators.py:917-919).  Each custom force built
 here also carries the structured descriptor the HIP engine consumes (see atomsmm_amd.forces).
 Alchemical inputs (CustomNonbondedForces named U_linear/U_spline/U_art/U_general, systems.py:83-95)
-and the special bond/angle redefinitions (systems.py:121-237) are outside this round's scope.
+are outside this round's scope.
 """
 import copy
 import itertools
 import math
+import re
 
 from . import forces, openmm, utils
 from .unit import md_value
@@ -49,6 +50,63 @@ class RESPASystem(openmm.System):
                 head = force.getEnergyFunction().split(';')[0]
                 if head in ('U_linear', 'U_spline', 'U_art', 'U_general'):
                     raise NotImplementedError('alchemical CustomNonbondedForces are outside the HIP hot path (SURVEY.md 8a-7)')
+
+    # The equilibrium value of a bond / an angle is changed for integration at the fastest time scale; the
+    # difference between the original and the redefined harmonic potentials goes to another force group as a
+    # CustomBondForce / CustomAngleForce (systems.py:121-237).
+    def _matcher(self, topology, residue, atoms):
+        resname = [atom.residue.name for atom in topology.atoms()]
+        name = [atom.name for atom in topology.atoms()]
+        r_regex = re.compile(residue)
+        a_regex = [re.compile(a) for a in atoms]
+
+        def match(*idx):
+            if not all(r_regex.match(resname[j]) for j in idx):
+                return False
+            forward = all(a_regex[k].match(name[j]) for k, j in enumerate(idx))
+            backward = all(a_regex[k].match(name[j]) for k, j in enumerate(reversed(idx)))
+            return forward or backward
+        return match
+
+    def redefine_bond(self, topology, residue, atom1, atom2, length, K=None, group=1):
+        match = self._matcher(topology, residue, [atom1, atom2])
+        changed = []
+        for force in self.getForces():
+            if isinstance(force, openmm.HarmonicBondForce):
+                for index in range(force.getNumBonds()):
+                    i, j, r0, K0 = force.getBondParameters(index)
+                    if match(i, j):
+                        force.setBondParameters(index, i, j, length, K0 if K is None else K)
+                        changed.append((i, j, r0, K0))
+        if changed and getattr(self, '_special_bond_force', None) is None:
+            new_force = openmm.CustomBondForce('0.5*(K0*(r - r0)^2 - Kn*(r - rn)^2)')
+            for name in ('r0', 'K0', 'rn', 'Kn'):
+                new_force.addPerBondParameter(name)
+            new_force.setForceGroup(group)
+            self.addForce(new_force)
+            self._special_bond_force = new_force
+        for (i, j, r0, K0) in changed:
+            self._special_bond_force.addBond(i, j, (r0, K0, length, K0 if K is None else K))
+
+    def redefine_angle(self, topology, residue, atom1, atom2, atom3, angle, K=None, group=1):
+        match = self._matcher(topology, residue, [atom1, atom2, atom3])
+        changed = []
+        for force in self.getForces():
+            if isinstance(force, openmm.HarmonicAngleForce):
+                for index in range(force.getNumAngles()):
+                    i, j, k, theta0, K0 = force.getAngleParameters(index)
+                    if match(i, j, k):
+                        force.setAngleParameters(index, i, j, k, angle, K0 if K is None else K)
+                        changed.append((i, j, k, theta0, K0))
+        if changed and getattr(self, '_special_angle_force', None) is None:
+            new_force = openmm.CustomAngleForce('0.5*(K0*(theta - t0)^2 - Kn*(theta - tn)^2)')
+            for name in ('t0', 'K0', 'tn', 'Kn'):
+                new_force.addPerAngleParameter(name)
+            new_force.setForceGroup(group)
+            self.addForce(new_force)
+            self._special_angle_force = new_force
+        for (i, j, k, theta0, K0) in changed:
+            self._special_angle_force.addAngle(i, j, k, (theta0, K0, angle, K0 if K is None else K))
 
     def _addCustomNonbondedForce(self, expressions, rcut, group, source, descriptor):
         force = forces._AtomsMM_CustomNonbondedForce(';'.join(expressions), rcut, use_switching_function=False,

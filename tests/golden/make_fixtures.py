@@ -184,7 +184,7 @@ def build(case, datadir):
         exc_sig.append(0.5 * (sigma[i] + sigma[j])); exc_eps.append(l14 * np.sqrt(epsilon[i] * epsilon[j]))
     out = dict(
         positions=pos, box=box, charge=charge, sigma=sigma, epsilon=epsilon, mass=mass,
-        residue=resid, resname=np.array(resnames),
+        residue=resid, resname=np.array(resnames), atomname=np.array(names),
         bonds=np.array(b_keep, dtype=np.int32).reshape(-1, 2), bond_r0=np.array(b_r0), bond_k=np.array(b_k),
         angles=np.array(angles, dtype=np.int32).reshape(-1, 3), angle_theta0=np.array(a_t0), angle_k=np.array(a_k),
         torsions=np.array(tors, dtype=np.int32).reshape(-1, 4), torsion_n=np.array(t_n, dtype=np.int32),

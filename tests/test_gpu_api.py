@@ -388,3 +388,18 @@ def test_RESPASystem_with_lj_parameter_scaling(heaq):              # tests/test_
                         'Reciprocal-Space': -76436.3982762784, 'CustomNonbondedForce': -17317.054135213173,
                         'CustomNonbondedForce(1)': 17317.054135213126, 'CustomBondForce': 112.25315524350334,
                         'Total': -15273.024197108669})
+
+
+def test_RESPASystem_with_special_bonds(spcfw):                    # tests/test_systems.py:131-152
+    system, positions, _ = create_system(spcfw, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
+    topology = app.Topology.from_arrays(spcfw['atomname'], spcfw['resname'], spcfw['residue'])
+    respa_system = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    respa_system.redefine_bond(topology, 'HOH', 'H[1-2]', 'O', 1.05 * unit.angstroms)
+    respa_system.redefine_angle(topology, 'HOH', 'H[1-2]', 'O', 'H[1-2]', 113 * unit.degrees)
+    components = atomsmm.splitPotentialEnergy(respa_system, topology, positions)
+    potential = {'HarmonicBondForce': 3665.684696323676, 'HarmonicAngleForce': 1811.197218501007,
+                 'Real-Space': 84694.39953220935, 'Reciprocal-Space': -111582.71281220087,
+                 'CustomNonbondedForce': -25531.129587235544, 'CustomNonbondedForce(1)': 25531.129587235544,
+                 'CustomBondForce': 0.0, 'CustomBondForce(1)': -1175.253817235862, 'CustomAngleForce': -305.0221912655623,
+                 'Total': -22891.707373668243}          # (the reference also lists an empty PeriodicTorsionForce: 0.0)
+    _check(components, potential)
