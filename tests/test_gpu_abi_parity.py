@@ -545,3 +545,82 @@ def test_c2_full_size_lj_fluid(adj):
     assert e2 == pytest.approx(e, rel=1e-11)
     assert np.abs(f2 - f).max() <= 1e-8 * np.abs(f).max()
     ctx.close()
+
+
+def test_c3_full_size_tip3p_respa():
+    """Configs C3/C4 of BASELINE.json at full size (98 304-atom flexible TIP3P box, near 0.7/0.5 force-switch + outer
+    DampedSmoothedForce sharing one neighbour list, RESPA [4,2,1] op list through amm_run_ops).  Checked: the near and
+    outer forces against the oracle's OpenMP cell-list traversal; Newton's third law; the dual (one-pass) evaluation
+    == the two separate evaluations bit for bit; 10 RESPA steps with list rebuilds on the way == the same ops with
+    every fusion switched off, bit for bit; time reversal returns to the start."""
+    B = _backend()
+    from atomsmm_amd.testing import tip3p_box
+    c = tip3p_box(32)
+    n = len(c['positions'])
+    assert n == 98304
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+    ref = {}
+    for key, d in (('near', dn), ('far', dd)):
+        ref[key] = O.pair_eval(d, c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'], use_cells=True)
+
+    def make(fuse):
+        ctx = B.HipContext(n, c['box'])
+        ctx.set_fuse_inner(fuse)
+        fn = hip_pair(B, ctx, dn, c)
+        ff = hip_pair(B, ctx, dd, c)
+        ctx.pair_share_list(fn, ff)
+        bid = ctx.bonded_create()
+        ctx.bonded_add_terms(bid, B.BOND_HARMONIC, c['bonds'], np.stack([c['bond_r0'], c['bond_k']], 1))
+        ctx.bonded_add_terms(bid, B.ANGLE_HARMONIC, c['angles'], np.stack([c['angle_theta0'], c['angle_k']], 1))
+        ctx.bonded_finalize(bid)
+        x, v, m = dev(c['positions']), dev(c['velocities']), dev(c['mass'])
+        f = [torch.zeros((n, 3), dtype=torch.float64, device='cuda') for _ in range(4)]
+        ctx.bind_state(x, v, m)
+        for slot, buf in enumerate(f):
+            ctx.bind_buffer(slot, buf)
+        ctx.group_define(0, 0, [bid])
+        ctx.group_define(1, 1, [fn])
+        ctx.group_define(2, 2, [ff])
+        return ctx, fn, ff, x, v, f
+
+    ctx, fn, ff, x, v, f = make(True)
+    pos = dev(c['positions'])
+    for key, fid in (('near', fn), ('far', ff)):
+        e, fo = eval_force(ctx, fid, pos, n)
+        e_ref, f_ref, _ = ref[key]
+        assert e == pytest.approx(e_ref, rel=1e-10)
+        assert np.abs(fo - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+        assert np.abs(fo.sum(0)).max() <= 1e-8 * np.abs(fo).max()
+    # one outer step as RespaPropagator([4,2,1]) emits it at 2 fs (SURVEY 3.2), steady-state form
+    dt = 0.002
+    E, K, M, C_ = B.OP_EVAL, B.OP_KICK, B.OP_MOVE, B.OP_COPY
+    inner = [(K, 0, -1, 0, 0.0625 * dt), (M, 0, 0, 0, 0.125 * dt), (E, 0, 0, 0, 0.0), (K, 0, -1, 0, 0.0625 * dt)] * 4
+    step = [(C_, 3, 2, 0, 0.0), (K, 3, 1, 0, 0.5 * dt)]
+    for _ in range(2):
+        step += [(K, 1, -1, 0, 0.25 * dt)] + inner + [(E, 1, 0, 0, 0.0), (K, 1, -1, 0, 0.25 * dt)]
+    ops_first = [(E, 0, 0, 0, 0.0), (E, 1, 0, 0, 0.0), (E, 2, 0, 0, 0.0)]
+    # the engine pairs the last near evaluation with the outer one (atomsmm_amd/engine.py:_pair_up_evals)
+    step_paired = step[:-2] + [(E, 1, 0, 0, 0.0), (E, 2, 0, 0, 0.0), (K, 1, -1, 0, 0.25 * dt), (C_, 3, 2, 0, 0.0), (K, 3, 1, 0, 0.5 * dt)]
+    step_paired = [op for op in step_paired]
+
+    def run(ctx_, nsteps):
+        ctx_.run_ops([B.Op(*op) for op in ops_first], 1)
+        ctx_.run_ops([B.Op(*op) for op in step_paired], nsteps)
+        ctx_.check()
+
+    run(ctx, 10)
+    st = ctx.pair_stats(ff)
+    assert st['n_builds'] >= 3                      # the list was rebuilt on the way
+    x1, v1 = x.cpu().numpy().copy(), v.cpu().numpy().copy()
+    ctx2, fn2, ff2, x2, v2, f2 = make(False)
+    run(ctx2, 10)
+    assert np.array_equal(x2.cpu().numpy(), x1) and np.array_equal(v2.cpu().numpy(), v1)
+    assert np.array_equal(f2[1].cpu().numpy(), f[1].cpu().numpy()) and np.array_equal(f2[2].cpu().numpy(), f[2].cpu().numpy())
+    ctx2.close()
+    # time reversal
+    v.mul_(-1.0)
+    ctx.run_ops([B.Op(*op) for op in step_paired], 10)
+    ctx.check()
+    assert np.abs(x.cpu().numpy() - c['positions']).max() < 1e-9
+    ctx.close()

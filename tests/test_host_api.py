@@ -379,3 +379,73 @@ def test_distributed_markers(spcfw, recorder, monkeypatch):
     f1, f2 = eng._buffers['f1'].data_ptr(), eng._buffers['f2'].data_ptr()
     assert reduced == [f2, f1, f1, f1, f2] + [f1, f1, f2]
     assert all(not b['sliced'] for b in rec.bonded)            # group 0 holds no pair force -> redundant, unsliced
+
+
+# ------------------------------------------------------------------------------------ SolvationSystem (systems.py:240-313)
+def test_solvation_system_structure_and_softcore_translation(heaq, recorder, goldens):
+    from oracle import oracle as O
+    system = system_from_arrays(heaq, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
+    solute = set(int(i) for i in np.where(heaq['resname'] == 'aaa')[0])
+    n_exc0 = system.getForce(atomsmm.findNonbondedForce(system)).getNumExceptions()
+    solv = atomsmm.SolvationSystem(system, solute)
+    nb = solv.getForce(atomsmm.findNonbondedForce(solv))
+    soft = [f for f in solv.getForces() if isinstance(f, openmm.CustomNonbondedForce)]
+    assert len(soft) == 1 and soft[0].getNumInteractionGroups() == 1
+    assert soft[0].getEnergyFunction().startswith('4*lambda_vdw*epsilon*(1-x)/x^2; x=(r/sigma)^6+0.5*(1-lambda_vdw)')
+    assert soft[0].getUseSwitchingFunction() and soft[0].getUseLongRangeCorrection()       # imported (forces.py:284-291)
+    assert soft[0].getCutoffDistance() == 1.0 * unit.nanometers
+    # every solute-solute pair is an exception now, and an exclusion of the softcore force
+    assert nb.getNumExceptions() == len(heaq['exc_pairs']) + (len(solute) * (len(solute) - 1) // 2
+                                                            - sum(1 for a, b in heaq['exc_pairs'] if a in solute and b in solute))
+    assert nb.getNumExceptions() > n_exc0 and soft[0].getNumExclusions() == nb.getNumExceptions()
+    for i in solute:
+        q, s, e = nb.getParticleParameters(i)
+        assert (q._value, s._value, e._value) == (0.0, 0.0, 0.0)
+    assert nb.getNumParticleParameterOffsets() == sum(1 for i in solute if heaq['charge'][i] != 0.0)
+    # use_softcore=False: sigma / epsilon offsets instead of the softcore force
+    solv2 = atomsmm.SolvationSystem(system, solute, use_softcore=False)
+    assert not [f for f in solv2.getForces() if isinstance(f, openmm.CustomNonbondedForce)]
+    nb2 = solv2.getForce(atomsmm.findNonbondedForce(solv2))
+    assert {nb2.getParticleParameterOffset(k)[0] for k in range(nb2.getNumParticleParameterOffsets())} == {'lambda_coul', 'lambda_vdw'}
+    # engine translation: one softcore pair force with group codes in the charge slot, lambda in alpha, and the
+    # host-side long-range correction == the oracle's (scipy) == what the reference literal needs
+    ctx = openmm.Context(solv, openmm.VerletIntegrator(0.0))
+    rec = recorder[-1]
+    sc = [p for p in rec.pairs if p['family'] == B.SOFTCORE]
+    assert len(sc) == 1 and sc[0]['alpha'] == 1.0 and sc[0]['rswitch'] == 0.9 and sc[0]['flags'] & B.SWITCH
+    codes = np.where(heaq['resname'] == 'aaa', 1.0, 2.0)
+    assert np.array_equal(sc[0]['q'], codes)
+    ctx.setParameter('lambda_vdw', 0.5)
+    assert ('pair_set_lambda', sc[0]['id'], 0.5) in rec.calls
+    entry = [e for e in ctx._engine.entries if sc[0]['id'] in e.pair_ids][0]
+    lrc_oracle = O.softcore_lrc(heaq['sigma'], heaq['epsilon'], codes, heaq['box'], 1.0, 0.9, 0.5)
+    assert entry.constant == pytest.approx(lrc_oracle, rel=1e-10)
+    d = O.desc(O.SOFTCORE, rc=1.0, rswitch=0.9, alpha=0.5, flags=O.SWITCH, Kc=1.0)
+    e_pair = O.pair_eval(d, heaq['positions'], heaq['box'], codes, heaq['sigma'], heaq['epsilon'], heaq['exc_pairs'],
+                         want_forces=False)[0]
+    assert e_pair + entry.constant == pytest.approx(goldens['G15']['value'], rel=2e-7)
+
+
+def test_redefine_bond_and_angle(spcfw, recorder):
+    system = system_from_arrays(spcfw, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
+    topology = app.Topology.from_arrays(spcfw['atomname'], spcfw['resname'], spcfw['residue'])
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    n0 = respa.getNumForces()
+    respa.redefine_bond(topology, 'HOH', 'H[1-2]', 'O', 1.05 * unit.angstroms)
+    respa.redefine_angle(topology, 'HOH', 'H[1-2]', 'O', 'H[1-2]', 113 * unit.degrees)
+    assert respa.getNumForces() == n0 + 2
+    bond = [f for f in respa.getForces() if isinstance(f, openmm.HarmonicBondForce)][0]
+    assert all(bond.getBondParameters(k)[2] == 1.05 * unit.angstroms for k in range(bond.getNumBonds()))
+    special = respa.getForce(n0)
+    assert special.getEnergyFunction() == '0.5*(K0*(r - r0)^2 - Kn*(r - rn)^2)' and special.getForceGroup() == 1
+    assert special.getNumBonds() == bond.getNumBonds() == 1024
+    i, j, (r0, K0, rn, Kn) = special.getBondParameters(0)
+    assert (r0, rn, K0) == (pytest.approx(spcfw['bond_r0'][0]), pytest.approx(0.105), Kn)
+    angle_force = respa.getForce(n0 + 1)
+    assert isinstance(angle_force, openmm.CustomAngleForce) and angle_force.getNumAngles() == 512
+    openmm.Context(respa, openmm.VerletIntegrator(0.0))
+    rec = recorder[-1]
+    kinds = sorted(t[0] for b in rec.bonded for t in b['terms'])
+    assert kinds.count(B.BOND_HARMONIC) == 3 and kinds.count(B.ANGLE_HARMONIC) == 3      # original + (K0, -Kn) pair each
+    with pytest.raises(ValueError):
+        respa.redefine_bond(app.Topology(1536), 'HOH', 'H[1-2]', 'O', 1.05 * unit.angstroms)
