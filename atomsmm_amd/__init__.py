@@ -28,6 +28,8 @@ from .propagators import TranslationPropagator  # noqa: F401
 from .propagators import TrotterSuzukiPropagator  # noqa: F401
 from .propagators import VelocityBoostPropagator  # noqa: F401
 from .propagators import VelocityVerletPropagator  # noqa: F401
+from .propagators import (MassiveNoseHooverPropagator, NoseHooverPropagator, OrnsteinUhlenbeckPropagator,  # noqa: F401
+                          UnconstrainedVelocityVerletPropagator, VelocityRescalingPropagator)
 from .systems import RESPASystem, SolvationSystem  # noqa: F401
 from .utils import InputError  # noqa: F401
 from .utils import countDegreesOfFreedom  # noqa: F401
@@ -42,7 +44,9 @@ __forces__ = ['DampedSmoothedForce', 'NonbondedExceptionsForce', 'NearExceptionF
 __integrators__ = ['GlobalThermostatIntegrator', 'MultipleTimeScaleIntegrator']
 __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPropagator', 'SplitPropagator',
                    'SuzukiYoshidaPropagator', 'TranslationPropagator', 'TrotterSuzukiPropagator',
-                   'VelocityBoostPropagator', 'VelocityVerletPropagator']
+                   'VelocityBoostPropagator', 'VelocityVerletPropagator', 'UnconstrainedVelocityVerletPropagator',
+                   'VelocityRescalingPropagator', 'NoseHooverPropagator', 'MassiveNoseHooverPropagator',
+                   'OrnsteinUhlenbeckPropagator']
 __systems__ = ['RESPASystem', 'SolvationSystem']
 __utils__ = ['countDegreesOfFreedom', 'evaluateForce', 'findNonbondedForce', 'hijackForce', 'splitPotentialEnergy']
 __all__ = __forces__ + __integrators__ + __propagators__ + __systems__ + __utils__

@@ -28,7 +28,7 @@ EXPORTS = [
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
-    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda',
+    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval',
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
         L.amm_pme_set_charges.argtypes = [vp, C.c_int32, dp]
         L.amm_pme_set_sliced.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_pair_set_lambda.argtypes = [vp, C.c_int32, C.c_double]
+        L.amm_expr_eval.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp]
         for name in EXPORTS:
             if name not in ('amm_last_error',):
                 getattr(L, name).restype = C.c_int
@@ -223,6 +224,14 @@ class HipContext:
 
     def pme_set_sliced(self, fid, on=True):
         _chk(lib().amm_pme_set_sliced(self.h, fid, int(bool(on))))
+
+    def expr_eval(self, code, consts, globals_, seed, counter, dst=None, total=None):
+        """Per-DOF postfix program (atomsmm_amd.expr): dst <- values, total <- their sum (device tensors or None)."""
+        c_, cp = _hi(code)
+        k_, kp = _hd(consts if len(consts) else [0.0])
+        g_, gp = _hd(globals_ if len(globals_) else [0.0])
+        _chk(lib().amm_expr_eval(self.h, cp, len(c_), kp, len(consts), gp, len(globals_), int(seed) & (2 ** 64 - 1),
+                                 int(counter) & (2 ** 64 - 1), _ptr(dst), _ptr(total)))
 
     def force_eval(self, fid, pos, force, accumulate=False, energy=None):
         _chk(lib().amm_force_eval(self.h, fid, _ptr(pos), _ptr(force), int(bool(accumulate)), _ptr(energy)))

@@ -85,6 +85,7 @@ int amm_destroy(amm_ctx *ctx) {
         if (f.pme) amm_pme_free(f.pme);
     }
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_expr_part) (void)hipFree(ctx->d_expr_part);
     if (ctx->alt_x) (void)hipFree(ctx->alt_x);
     if (ctx->alt_v) (void)hipFree(ctx->alt_v);
     if (ctx->alt_f) (void)hipFree(ctx->alt_f);
@@ -454,6 +455,15 @@ int amm_copy(amm_ctx *ctx, double *d_dst, const double *d_src) {
     return amm_copy_impl(ctx, d_dst, d_src);
 }
 int amm_mvv(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out) { return amm_mvv_impl(ctx, d_v, d_m, d_out); }
+
+int amm_expr_eval(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
+                  const double *globals, int32_t n_globals, uint64_t seed, uint64_t counter, double *d_dst, double *d_sum) {
+    if (!ctx || !code || (n_consts > 0 && !consts) || (n_globals > 0 && !globals) || (!d_dst && !d_sum)) {
+        amm_set_error("amm_expr_eval: bad arguments");
+        return 1;
+    }
+    return amm_expr_eval_impl(ctx, code, n_code, consts, n_consts, globals, n_globals, seed, counter, d_dst, d_sum);
+}
 
 int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass) {
     ctx->d_x = d_x;

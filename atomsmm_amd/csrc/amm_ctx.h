@@ -144,6 +144,7 @@ struct amm_ctx {
     bool profile = false;
     int profile_only = -1;         // >= 0: time only this force id (each timed launch costs two event packets)
     double *d_scratch = nullptr;   // small scratch (reductions)
+    double *d_expr_part = nullptr; // block partial sums of amm_expr_eval
     // ping-pong partners of x, v and the group-0 force buffer for the fused inner RESPA iteration
     double *alt_x = nullptr, *alt_v = nullptr, *alt_f = nullptr;
     bool fuse_inner = true;
@@ -173,6 +174,8 @@ int amm_pme_set_charges_impl(amm_ctx *ctx, PmeForce *pm, const double *h_q);
 int amm_pme_eval_impl(amm_ctx *ctx, PmeForce *pm, const double *d_pos, double *d_force, int accumulate, double *d_energy);
 int amm_pme_set_sliced_impl(PmeForce *pm, int on);
 int amm_pme_free(PmeForce *pm);
+int amm_expr_eval_impl(amm_ctx *ctx, const int32_t *code, int n_code, const double *consts, int n_consts, const double *globals,
+                       int n_globals, unsigned long long seed, unsigned long long counter, double *d_dst, double *d_sum);
 int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef);
 int amm_combine_impl(amm_ctx *ctx, double *d_dst, const double *d_a, const double *d_b, double coef);
 int amm_move_impl(amm_ctx *ctx, double *d_x, const double *d_v, double coef);

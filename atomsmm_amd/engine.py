@@ -23,6 +23,7 @@ import re
 import numpy as np
 
 from . import backend as B
+from . import expr as X
 from . import openmm as mm
 from .forces import describe_energy
 from .utils import InputError
@@ -165,6 +166,9 @@ class Engine:
         self._buffers = {}
         self._group_defs = {}
         self._valid = {}
+        self._interpreted = None    # None: undecided; True: general (host-walked) step programs
+        self._host_rng = None
+        self._expr_counter = 0
         self._mirror = {}           # per-DOF buffer -> force symbol it currently mirrors (`_f2_ <- f2`)
         self._programs = {}
         self._energy = torch.zeros(1, dtype=f64, device=dev)
@@ -543,6 +547,7 @@ class Engine:
 
     def invalidate_program(self):
         self._programs.clear()
+        self._interpreted = None
 
     def reinitialize(self, preserveState=False):
         raise NotImplementedError('Context.reinitialize: create a new Context instead')
@@ -887,10 +892,120 @@ class Engine:
     def _program_key(valid, mirror):
         return (tuple(sorted((str(g), ok) for g, ok in valid.items())), tuple(sorted(mirror.items())))
 
+    # ------------------------------------------------------------------------------- general step programs
+    def _step_interpreted(self, n):
+        """Programs with data-dependent globals (ComputeSum results, random numbers) or per-DOF expressions beyond kick /
+        move / copy -- the thermostat propagators (propagators.py:276-827, 1108-2172): the host walks the program step by
+        step; runs of kick / move / copy / EVAL ops still go to amm_run_ops, every other per-DOF or sum expression is
+        compiled (atomsmm_amd/expr.py) and interpreted on the GPU (amm_expr_eval); global expressions are evaluated on
+        the host.  A ComputeSum costs one device -> host read."""
+        torch = self.torch
+        integ = self.integrator
+        steps = integ._steps
+        C = mm.CustomIntegrator
+        match, stack = {}, []
+        for pc, (kind, _, _) in enumerate(steps):
+            if kind in (C.IfBlock, C.WhileBlock):
+                stack.append(pc)
+            elif kind == C.EndBlock:
+                begin = stack.pop()
+                match[begin], match[pc] = pc, begin
+        if self._host_rng is None:
+            self._host_rng = np.random.default_rng(integ.getRandomNumberSeed())
+        seed = int(integ.getRandomNumberSeed()) & (2 ** 64 - 1)
+        total = torch.zeros(1, dtype=torch.float64, device=self.x.device)
+        for _ in range(int(n)):
+            env = dict(_SAFE_FUNCS)
+            env.update(self.parameters)
+            env.update(zip(integ._gnames, integ._gvalues))
+            env['dt'] = integ._dt
+            valid = self._valid
+            self._mirror_work = self._mirror
+            ops = []
+
+            def flush():
+                if ops:
+                    self._run(list(ops), 1)
+                    del ops[:]
+
+            def resolve(name):
+                if name == 'm':
+                    return ('mass',)
+                if name in ('x', 'v') or re.fullmatch(r'f[0-9]*', name) or name in integ._pnames:
+                    return ('buf', self._force_ref(name, ops, valid))
+                if name in env and not callable(env[name]):
+                    return ('global',)
+                return None
+
+            pc = 0
+            guard = 0
+            while pc < len(steps):
+                guard += 1
+                if guard > 2_000_000:
+                    raise RuntimeError('step program does not terminate')
+                kind, target, expr = steps[pc]
+                if kind == C.ComputeGlobal:
+                    value = X.eval_global(expr, env, self._host_rng)
+                    if target in self.parameters and target not in integ._gnames and value != self.parameters[target]:
+                        raise NotImplementedError('step programs that change Context parameters (%s) are not supported' % target)
+                    env[target] = value
+                elif kind in (C.ComputePerDof, C.ComputeSum):
+                    done = False
+                    if kind == C.ComputePerDof:
+                        try:
+                            self._emit_per_dof(target, expr, env, ops, valid)
+                            done = True
+                        except (NotImplementedError, NameError, SyntaxError, TypeError):
+                            done = False
+                    if not done:
+                        prog = X.compile_per_dof(expr, resolve)
+                        flush()                                   # EVALs emitted by resolve() run first
+                        gvals = [float(env[name]) for name in prog.globals_]
+                        self._expr_counter += 1
+                        if kind == C.ComputePerDof:
+                            if target not in ('x', 'v') and target not in integ._pnames:
+                                raise mm.OpenMMException('unknown per-DOF variable: ' + target)
+                            dst = self.x if target == 'x' else (self.v if target == 'v' else self._buffer(target))
+                            self._slot(target)
+                            self.ctx.expr_eval(prog.code, prog.consts, gvals, seed, self._expr_counter, dst=dst)
+                            self._mirror_work.pop(target, None)
+                            for d in [d for d, sname in self._mirror_work.items() if sname == target]:
+                                del self._mirror_work[d]
+                            if target == 'x':
+                                for g in valid:
+                                    valid[g] = False
+                        else:
+                            self.ctx.expr_eval(prog.code, prog.consts, gvals, seed, self._expr_counter, total=total)
+                            env[target] = total.item()          # device -> host (synchronises)
+                elif kind in (C.ConstrainPositions, C.ConstrainVelocities, C.UpdateContextState):
+                    pass
+                elif kind in (C.IfBlock, C.WhileBlock):
+                    if not self._condition(expr, env):
+                        pc = match[pc]
+                elif kind == C.EndBlock:
+                    if steps[match[pc]][0] == C.WhileBlock:
+                        pc = match[pc] - 1
+                pc += 1
+            flush()
+            for k, name in enumerate(integ._gnames):
+                integ._gvalues[k] = env[name]
+            self.time += integ._dt
+        self.ctx.check()
+
     def step(self, n):
         integ = self.integrator
         if not isinstance(integ, mm.CustomIntegrator):
             raise NotImplementedError('only CustomIntegrator step programs run on the HIP path')
+        if self._interpreted is None:
+            # static programs (RESPA and friends) are unrolled once and replayed; anything the unroller cannot express
+            # goes through the general path
+            try:
+                self._compile()
+                self._interpreted = False
+            except (NotImplementedError, NameError, SyntaxError, TypeError, X.ExpressionError):
+                self._interpreted = True
+        if self._interpreted:
+            return self._step_interpreted(n)
         remaining = int(n)
         while remaining > 0:
             key = self._program_key(self._valid, self._mirror)

@@ -1,0 +1,203 @@
+"""Host compiler for CustomIntegrator expressions that are not a kick or a move.
+
+The reference's thermostat / stochastic propagators (src/atomsmm/propagators.py:276-827, 1108-2172) call
+`addComputePerDof(variable, expression)`, `addComputeSum(variable, expression)` and `addComputeGlobal(variable,
+expression)` with OpenMM's expression syntax: `^` for powers, functions (sqrt, exp, log, sin, ..., step, delta,
+select, min, max), and auxiliary definitions after ';' (`vscaling*v; vscaling = exp(-a*dt)`).  Per-DOF and sum
+expressions are compiled here into the postfix program that `amm_expr_eval` interprets on the GPU (csrc/expr.hip);
+global expressions are evaluated on the host.  `gaussian` / `uniform` are ONE draw per evaluation and degree of
+freedom, as in OpenMM (every occurrence inside one expression sees the same value).
+"""
+import ast
+import math
+
+OPCODES = dict(
+    CONST=0, GLOBAL=1, BUF=2, MASS=3, GAUSS=4, UNIFORM=5, LOAD=6, STORE=7,
+    ADD=10, SUB=11, MUL=12, DIV=13, NEG=14, POW=15, POWI=16,
+    sqrt=20, exp=21, log=22, sin=23, cos=24, tan=25, asin=26, acos=27, atan=28, sinh=29, cosh=30, tanh=31, erf=32,
+    erfc=33, abs=34, floor=35, ceil=36, step=37, delta=38, min=39, max=40, select=41, atan2=42)
+_ARITY = {'min': 2, 'max': 2, 'select': 3, 'atan2': 2}
+MAX_LOCALS = 16
+
+
+class ExpressionError(ValueError):
+    pass
+
+
+def split_definitions(text):
+    """'a*v; a = exp(-g*dt); g = 2' -> ('a*v', {'a': 'exp(-g*dt)', 'g': '2'})."""
+    parts = [p.strip() for p in text.split(';') if p.strip()]
+    if not parts:
+        raise ExpressionError('empty expression')
+    defs = {}
+    for p in parts[1:]:
+        if '=' not in p:
+            raise ExpressionError('auxiliary definition without "=": ' + p)
+        name, rhs = p.split('=', 1)
+        defs[name.strip()] = rhs.strip()
+    return parts[0], defs
+
+
+def _parse(text):
+    try:
+        return ast.parse(text.replace('^', '**'), mode='eval').body
+    except SyntaxError as exc:
+        raise ExpressionError('cannot parse expression %r: %s' % (text, exc))
+
+
+class Program:
+    """Postfix program for amm_expr_eval: `code` (opcode | arg << 8), `consts`, and the names of the global values the
+    launch must supply, in order (`globals_`)."""
+
+    def __init__(self):
+        self.code, self.consts, self.globals_ = [], [], []
+
+    def emit(self, op, arg=0):
+        self.code.append(OPCODES[op] | (int(arg) << 8))
+
+    def const(self, value):
+        value = float(value)
+        for k, c in enumerate(self.consts):
+            if c == value and math.copysign(1.0, c) == math.copysign(1.0, value):
+                return k
+        self.consts.append(value)
+        return len(self.consts) - 1
+
+    def global_index(self, name):
+        if name not in self.globals_:
+            self.globals_.append(name)
+        return self.globals_.index(name)
+
+
+def compile_per_dof(text, resolve):
+    """Compile a per-DOF (or sum) expression.  `resolve(name)` returns ('buf', slot), ('mass',), ('global',) or None."""
+    main, defs = split_definitions(text)
+    prog = Program()
+    local_of, in_progress = {}, set()
+
+    def gen(node):
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)):
+            prog.emit('CONST', prog.const(node.value))
+        elif isinstance(node, ast.Name):
+            name = node.id
+            if name in defs:
+                if name not in local_of:
+                    if name in in_progress:
+                        raise ExpressionError('circular auxiliary definition: ' + name)
+                    if len(local_of) + len(in_progress) >= MAX_LOCALS:
+                        raise ExpressionError('too many auxiliary definitions')
+                    in_progress.add(name)
+                    gen(_parse(defs[name]))
+                    in_progress.discard(name)
+                    local_of[name] = len(local_of)
+                    prog.emit('STORE', local_of[name])
+                prog.emit('LOAD', local_of[name])
+            elif name == 'gaussian':
+                prog.emit('GAUSS')
+            elif name in ('uniform', 'random'):
+                prog.emit('UNIFORM')
+            else:
+                kind = resolve(name)
+                if kind is None:
+                    raise ExpressionError('unknown symbol in per-DOF expression: ' + name)
+                if kind[0] == 'buf':
+                    prog.emit('BUF', kind[1])
+                elif kind[0] == 'mass':
+                    prog.emit('MASS')
+                else:
+                    prog.emit('GLOBAL', prog.global_index(name))
+        elif isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            gen(node.operand)
+            if isinstance(node.op, ast.USub):
+                prog.emit('NEG')
+        elif isinstance(node, ast.BinOp) and isinstance(node.op, (ast.Add, ast.Sub, ast.Mult, ast.Div, ast.Pow)):
+            if isinstance(node.op, ast.Pow):
+                e = node.right
+                neg = isinstance(e, ast.UnaryOp) and isinstance(e.op, ast.USub)
+                ev = e.operand if neg else e
+                if isinstance(ev, ast.Constant) and float(ev.value) == int(ev.value) and abs(int(ev.value)) < 1 << 20:
+                    gen(node.left)
+                    prog.emit('POWI', -int(ev.value) if neg else int(ev.value))
+                    return
+            gen(node.left)
+            gen(node.right)
+            prog.emit({ast.Add: 'ADD', ast.Sub: 'SUB', ast.Mult: 'MUL', ast.Div: 'DIV', ast.Pow: 'POW'}[type(node.op)])
+        elif isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and not node.keywords:
+            fn = node.func.id
+            if fn not in OPCODES or fn.isupper() or len(node.args) != _ARITY.get(fn, 1):
+                raise ExpressionError('unsupported function call: %s/%d' % (fn, len(node.args)))
+            for a in node.args:
+                gen(a)
+            prog.emit(fn)
+        else:
+            raise ExpressionError('unsupported syntax in expression: ' + ast.dump(node))
+
+    gen(_parse(main))
+    return prog
+
+
+_HOST_FUNCS = dict(sqrt=math.sqrt, exp=math.exp, log=math.log, sin=math.sin, cos=math.cos, tan=math.tan, asin=math.asin,
+                   acos=math.acos, atan=math.atan, sinh=math.sinh, cosh=math.cosh, tanh=math.tanh, erf=math.erf,
+                   erfc=math.erfc, abs=abs, floor=math.floor, ceil=math.ceil, atan2=math.atan2, min=min, max=max,
+                   step=lambda x: 1.0 if x >= 0 else 0.0, delta=lambda x: 1.0 if x == 0 else 0.0,
+                   select=lambda c, a, b: a if c != 0 else b)
+
+
+def eval_global(text, env, rng=None):
+    """Value of a global expression (addComputeGlobal) for the variable values in `env`; `rng` (numpy Generator)
+    supplies `gaussian` / `uniform` (one draw of each per evaluation)."""
+    main, defs = split_definitions(text)
+    cache, draws = {}, {}
+
+    def value_of(name):
+        if name in defs:
+            if name not in cache:
+                cache[name] = ev(_parse(defs[name]))
+            return cache[name]
+        if name in ('gaussian', 'uniform', 'random'):
+            key = 'gaussian' if name == 'gaussian' else 'uniform'
+            if key not in draws:
+                if rng is None:
+                    raise ExpressionError('random numbers in a global expression need a generator')
+                draws[key] = float(rng.standard_normal()) if key == 'gaussian' else float(rng.random())
+            return draws[key]
+        if name in env:
+            return float(env[name])
+        raise ExpressionError('unknown symbol in global expression: ' + name)
+
+    def ev(node):
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)):
+            return float(node.value)
+        if isinstance(node, ast.Name):
+            return value_of(node.id)
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            v = ev(node.operand)
+            return -v if isinstance(node.op, ast.USub) else v
+        if isinstance(node, ast.BinOp):
+            a, b = ev(node.left), ev(node.right)
+            if isinstance(node.op, ast.Add):
+                return a + b
+            if isinstance(node.op, ast.Sub):
+                return a - b
+            if isinstance(node.op, ast.Mult):
+                return a * b
+            if isinstance(node.op, ast.Div):
+                return a / b
+            if isinstance(node.op, ast.Pow):
+                return a ** b
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id in _HOST_FUNCS and not node.keywords:
+            return float(_HOST_FUNCS[node.func.id](*[ev(a) for a in node.args]))
+        raise ExpressionError('unsupported syntax in expression: ' + ast.dump(node))
+
+    return ev(_parse(main))
+
+
+def symbols(text):
+    """Names referenced by an expression (auxiliary definitions expanded, their own names removed)."""
+    main, defs = split_definitions(text)
+    found = set()
+    for part in [main] + list(defs.values()):
+        for node in ast.walk(_parse(part)):
+            if isinstance(node, ast.Name):
+                found.add(node.id)
+    return found - set(defs) - set(_HOST_FUNCS)

@@ -8,10 +8,16 @@ later unrolls that program into kick / move / copy / force-group-evaluation ops 
 (include/atomsmm_hip.h, amm_run_ops).  The emitted text is identical to the reference's
 (tests/golden/goldens.json -> programs), which is the cheapest parity check there is.
 
-Thermostat, 'regulated' and 'limited-speed' propagators (reference :276-827, :1045-2172) are out of
-scope of this round (per-DOF elementwise math, no pair work: SURVEY.md section 8f-2).
+The basic thermostat propagators are here too -- unconstrained velocity Verlet, stochastic
+velocity rescaling, global and massive Nose-Hoover, Ornstein-Uhlenbeck / Langevin, generic boost and scaling; their
+programs contain ComputeSum steps, random numbers and general per-DOF expressions, which the engine runs through
+`amm_expr_eval` (atomsmm_amd/expr.py).  The 'regulated', 'limited-speed' and isokinetic families (reference :276-682,
+:1452-2172) are not restated.
 """
-from .utils import InputError
+import math
+
+from . import unit
+from .utils import InputError, kB
 
 
 class Propagator:
@@ -284,3 +290,133 @@ class VelocityVerletPropagator(Propagator):
         integrator.addConstrainPositions()
         integrator.addComputePerDof('v', '(x-x0)/Dt+0.5*Dt*f/m' + Dt)
         integrator.addConstrainVelocities()
+
+
+class UnconstrainedVelocityVerletPropagator(Propagator):
+    """Velocity Verlet without constraints (propagators.py:1136-1153)."""
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        integrator.addComputePerDof('v', 'v+0.5*{}*dt*f/m'.format(fraction))
+        integrator.addComputePerDof('x', 'x+{}*dt*v'.format(fraction))
+        integrator.addComputePerDof('v', 'v+0.5*{}*dt*f/m'.format(fraction))
+
+
+class VelocityRescalingPropagator(Propagator):
+    """Stochastic velocity rescaling of Bussi, Donadio and Parrinello (propagators.py:1156-1227): a gamma-distributed
+    sum of squared Gaussians by Marsaglia-Tsang rejection in the global variables, then `v <- vscaling*v`."""
+
+    def __init__(self, temperature, degreesOfFreedom, timeScale):
+        super().__init__()
+        self.tau = unit.md_value(timeScale)
+        self.dof = degreesOfFreedom
+        self.kT = unit.md_value(kB * temperature)
+        for name in ('V', 'X', 'U', 'ready'):
+            self.globalVariables[name] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        a = (self.dof - 2 + self.dof % 2) / 2
+        d = a - 1 / 3
+        c = 1 / math.sqrt(9 * d)
+        integrator.addComputeGlobal('ready', '0')
+        integrator.beginWhileBlock('ready < 0.5')
+        integrator.addComputeGlobal('X', 'gaussian')
+        integrator.addComputeGlobal('V', '1+%s*X' % c)
+        integrator.beginWhileBlock('V <= 0.0')
+        integrator.addComputeGlobal('X', 'gaussian')
+        integrator.addComputeGlobal('V', '1+%s*X' % c)
+        integrator.endBlock()
+        integrator.addComputeGlobal('V', 'V^3')
+        integrator.addComputeGlobal('U', 'random')
+        integrator.addComputeGlobal('ready', 'step(1-0.0331*X^4-U)')
+        integrator.beginIfBlock('ready < 0.5')
+        integrator.addComputeGlobal('ready', 'step(0.5*X^2+%s*(1-V+log(V))-log(U))' % d)
+        integrator.endBlock()
+        integrator.endBlock()
+        odd = self.dof % 2 == 1
+        if odd:
+            integrator.addComputeGlobal('X', 'gaussian')
+        pieces = ['vscaling*v',
+                  'vscaling = sqrt(A+C*B*(gaussian^2+sumRs)+2*sqrt(C*B*A)*gaussian)',
+                  'C = %s/mvv' % self.kT,
+                  'B = 1-A',
+                  'A = exp(-dt*%s)' % (fraction / self.tau),
+                  'sumRs = %s*V' % (2 * d) + ('+X^2' if odd else '')]
+        integrator.addComputePerDof('v', '; '.join(pieces))
+
+
+class NoseHooverPropagator(Propagator):
+    """Global Nose-Hoover thermostat with `nloops` RESPA-like subdivisions (propagators.py:1230-1273)."""
+
+    def __init__(self, temperature, degreesOfFreedom, timeScale, nloops=1):
+        super().__init__()
+        self.nloops = nloops
+        self.globalVariables['LkT'] = degreesOfFreedom * kB * temperature
+        self.globalVariables['Q'] = degreesOfFreedom * kB * temperature * timeScale ** 2
+        for name in ('vscaling', 'p_eta', 'n_NH'):
+            self.globalVariables[name] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        n = self.nloops
+        subfrac = fraction / n
+        integrator.addComputeGlobal('p_eta', 'p_eta + ({}*dt)*(mvv - LkT)'.format(0.5 * subfrac))
+        integrator.addComputeGlobal('vscaling', 'exp(-({}*dt)*p_eta/Q)'.format(subfrac))
+        if n > 2:
+            integrator.addComputeGlobal('n_NH', '1')
+            integrator.beginWhileBlock('n_NH < {}'.format(n))
+            integrator.addComputeGlobal('p_eta', 'p_eta + ({}*dt)*(vscaling^2*mvv - LkT)'.format(subfrac))
+            integrator.addComputeGlobal('vscaling', 'vscaling*exp(-({}*dt)*p_eta/Q)'.format(subfrac))
+            integrator.addComputeGlobal('n_NH', 'n_NH + 1')
+            integrator.endBlock()
+        integrator.addComputeGlobal('p_eta', 'p_eta + ({}*dt)*(vscaling^2*mvv - LkT)'.format(0.5 * subfrac))
+        integrator.addComputePerDof('v', 'vscaling*v')
+
+
+class MassiveNoseHooverPropagator(Propagator):
+    """One Nose-Hoover thermostat per degree of freedom (propagators.py:1276-1311)."""
+
+    def __init__(self, temperature, timeScale, nloops=1):
+        super().__init__()
+        self.nloops = nloops
+        self.globalVariables['kT'] = kB * temperature
+        self.globalVariables['Q'] = kB * temperature * timeScale ** 2
+        self.globalVariables['nMNH'] = 0
+        self.perDofVariables['p_eta'] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        subfrac = fraction / self.nloops
+        if self.nloops > 1:
+            integrator.addComputeGlobal('nMNH', '0')
+            integrator.beginWhileBlock('nMNH < {}'.format(self.nloops))
+        integrator.addComputePerDof('p_eta', 'p_eta + ({}*dt)*(m*v^2 - kT)'.format(0.5 * subfrac))
+        integrator.addComputePerDof('v', 'v*exp(-({}*dt)*p_eta/Q)'.format(subfrac))
+        integrator.addComputePerDof('p_eta', 'p_eta + ({}*dt)*(m*v^2 - kT)'.format(0.5 * subfrac))
+        if self.nloops > 1:
+            integrator.addComputeGlobal('nMNH', 'nMNH + 1')
+            integrator.endBlock()
+
+
+class OrnsteinUhlenbeckPropagator(Propagator):
+    """Exact solution of dV = (F/M) dt - gamma V dt + sqrt(2 gamma kT/M) dW per degree of freedom
+    (propagators.py:685-741): the Langevin bath of the 'middle' schemes."""
+
+    def __init__(self, temperature, frictionConstant, velocity='v', mass='m', force=None, overall=False, **globals):
+        super().__init__()
+        self.globalVariables['kT'] = kB * temperature
+        self.globalVariables['friction'] = frictionConstant
+        self.velocity, self.mass, self.force, self.overall = velocity, mass, force, overall
+        for key, value in globals.items():
+            self.globalVariables[key] = value
+        if velocity != 'v':
+            (self.globalVariables if overall else self.perDofVariables)[velocity] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        expression = 'z*{} + sqrt(kT*(1 - z*z)/mass)*gaussian'.format(self.velocity, self.mass)
+        if self.force is not None:
+            expression += ' + force*(1 - z)/(mass*friction)'
+            expression += '; force = {}'.format(self.force)
+        expression += '; mass = {}'.format(self.mass)
+        expression += '; z = exp(-({}*dt)*friction)'.format(fraction)
+        if self.overall:
+            integrator.addComputeGlobal(self.velocity, expression)
+        else:
+            integrator.addComputePerDof(self.velocity, expression)

@@ -154,6 +154,15 @@ int amm_copy(amm_ctx *ctx, double *d_dst, const double *d_src);
 int amm_mvv(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out); /* addComputeSum('mvv','m*v*v') */
 
 /* CustomIntegrator.step(n)  (integrators.py:153-163): bind state buffers, define groups, run ops. */
+/* CustomIntegrator.addComputePerDof(variable, expression) / addComputeSum(variable, expression) for expressions
+ * beyond kick and move -- the thermostat / stochastic propagators (propagators.py:276-827, 1108-2172), and
+ * integrators.py:113 `addComputeSum('mvv', 'm*v*v')`.  `code` is a postfix program (opcode | arg << 8; opcodes in
+ * atomsmm_amd/expr.py and csrc/expr.hip) over constants, global variables, the bound per-DOF buffers (by slot), the
+ * masses and `gaussian` / `uniform` draws (Philox-4x32-10 keyed by seed; counter = launch index).  d_dst ([n][3],
+ * may be one of the bound buffers) receives the per-DOF values, *d_sum (device) their sum; either may be NULL. */
+int amm_expr_eval(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
+                  const double *globals, int32_t n_globals, uint64_t seed, uint64_t counter, double *d_dst, double *d_sum);
+
 int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass);
 #define AMM_MAX_SLOTS 64
 #define AMM_SLOT_X 62   /* positions and velocities are addressable as buffers too (`x0 <- x`) */

@@ -57,6 +57,11 @@ class RecordingContext:
     def pme_set_sliced(self, fid, on=True):
         [p for p in self.pme if p['id'] == fid][0]['sliced'] = bool(on)
 
+    def expr_eval(self, code, consts, globals_, seed, counter, dst=None, total=None):
+        self.calls.append(('expr_eval', list(code), list(consts), list(globals_), counter, dst is not None, total is not None))
+        if total is not None:
+            total.fill_(1.0)
+
     def bind_state(self, x, v, mass):
         pass
 

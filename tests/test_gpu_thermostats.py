@@ -1,0 +1,203 @@
+"""GPU tests of the general step-program path: per-DOF / sum expressions compiled by
+atomsmm_amd/expr.py and interpreted by amm_expr_eval, against the numpy restatement in oracle/expr_oracle.py (same
+postfix programs, same Philox-4x32-10 stream), and the thermostat propagators built on it.
+
+Parity status: UNPINNED against the reference -- its thermostat tests (tests/test_propagators.py:51-111) need OpenMM's
+random number generator, HBonds constraints and PME on the EMIM fixture; what is checked here is the program text
+semantics (deterministic thermostats step for step against a numpy evaluation of the same program) and the physics
+(energy conservation without a bath, equipartition with one)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+import atomsmm_amd as atomsmm  # noqa: E402
+from atomsmm_amd import backend as B  # noqa: E402
+from atomsmm_amd import expr as X  # noqa: E402
+from atomsmm_amd import openmm, unit  # noqa: E402
+from atomsmm_amd.testing import system_from_arrays  # noqa: E402
+from oracle import expr_oracle as XO  # noqa: E402  (checker only)
+from oracle import oracle as O  # noqa: E402
+
+KB = 0.0083144626181532
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device='cuda')
+
+
+EXPRESSIONS = [
+    'v + 0.5*1.0*dt*f0/m',
+    'vscaling*v; vscaling = sqrt(A+C*B*(gaussian^2+sumRs)+2*sqrt(C*B*A)*gaussian); C = 2.49/mvv; B = 1-A; A = exp(-dt*10.0); sumRs = 7*V+X^2',
+    'z*v + sqrt(kT*(1 - z*z)/mass)*gaussian; mass = m; z = exp(-(0.5*dt)*friction)',
+    'select(step(x-1.2), min(v, 0.5), max(v, -0.5))*abs(f0)^1.5 + delta(0*x)*uniform - erfc(v)/(1+x^2) + v^-3 + atan2(x, v)',
+    'p + (0.25*dt)*(m*v^2 - kT)',
+]
+
+
+@pytest.mark.parametrize('expression', EXPRESSIONS)
+def test_expression_interpreter_vs_numpy(expression):
+    rng = np.random.default_rng(11)
+    n = 1000
+    ctx = B.HipContext(n, np.array([3.0, 3.0, 3.0]))
+    arrays = dict(x=rng.uniform(0.5, 2.5, (n, 3)), v=rng.normal(0, 0.6, (n, 3)), f0=rng.normal(0, 300, (n, 3)),
+                  p=rng.normal(0, 1, (n, 3)))
+    mass = rng.choice([1.008, 15.9994, 12.011], n)
+    t = {k: dev(a) for k, a in arrays.items()}
+    ctx.bind_state(t['x'], t['v'], dev(mass))
+    slots = {'x': B.SLOT_X, 'v': B.SLOT_V, 'f0': 0, 'p': 1}
+    ctx.bind_buffer(0, t['f0'])
+    ctx.bind_buffer(1, t['p'])
+    env = dict(dt=0.002, mvv=8123.4, V=0.93, X=-0.41, kT=2.494, friction=10.0)
+
+    def resolve(name):
+        if name == 'm':
+            return ('mass',)
+        if name in slots:
+            return ('buf', slots[name])
+        return ('global',) if name in env else None
+    prog = X.compile_per_dof(expression, resolve)
+    gvals = [env[g] for g in prog.globals_]
+    out = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+    total = torch.zeros(1, dtype=torch.float64, device='cuda')
+    ctx.expr_eval(prog.code, prog.consts, gvals, seed=20240521, counter=7, dst=out, total=total)
+    ctx.check()
+    ref = XO.run(prog.code, prog.consts, gvals, {slots[k]: arrays[k] for k in arrays}, mass, 20240521, 7)
+    got = out.cpu().numpy()
+    assert np.allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    assert total.item() == pytest.approx(ref.sum(), rel=1e-11, abs=1e-9)
+    # a different launch counter gives a different random stream, the same one the same stream
+    if 'gaussian' in expression or 'uniform' in expression:
+        ctx.expr_eval(prog.code, prog.consts, gvals, seed=20240521, counter=8, dst=out)
+        assert not np.allclose(out.cpu().numpy(), got)
+        ctx.expr_eval(prog.code, prog.consts, gvals, seed=20240521, counter=7, dst=out)
+        assert np.array_equal(out.cpu().numpy(), got)
+    # in place: the destination may be one of the operands
+    ctx.expr_eval(prog.code, prog.consts, gvals, seed=20240521, counter=7, dst=t['v'])
+    assert np.array_equal(t['v'].cpu().numpy(), got)
+    with pytest.raises(B.HipError):
+        ctx.expr_eval([X.OPCODES['ADD']], [], [], 0, 0, dst=out)          # stack underflow is caught on the host
+    ctx.close()
+
+
+def test_gaussian_stream_statistics():
+    n = 200000
+    ctx = B.HipContext(n, np.array([3.0, 3.0, 3.0]))
+    x = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+    ctx.bind_state(x, x.clone(), torch.ones(n, dtype=torch.float64, device='cuda'))
+    out = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+    prog = X.compile_per_dof('gaussian', lambda name: None)
+    ctx.expr_eval(prog.code, prog.consts, [], seed=3, counter=1, dst=out)
+    g = out.cpu().numpy().ravel()
+    assert abs(g.mean()) < 0.01 and abs(g.std() - 1.0) < 0.01 and abs((g ** 4).mean() - 3.0) < 0.1
+    assert abs(np.corrcoef(g[:-1], g[1:])[0, 1]) < 0.01
+    ctx.close()
+
+
+def _water(spcfw):
+    system = system_from_arrays(spcfw, nonbondedMethod='CutoffPeriodic')
+    nb = atomsmm.hijackForce(system, atomsmm.findNonbondedForce(system))
+    force = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9 * unit.angstroms).importFrom(nb)
+    force.addTo(system)
+    return system
+
+
+def test_unconstrained_velocity_verlet_vs_oracle(spcfw):
+    """UnconstrainedVelocityVerletPropagator (propagators.py:1136-1153): its three per-DOF assignments are neither a
+    kick nor a move in the RESPA form, so every one of them runs through the interpreter; 5 steps against numpy."""
+    c = spcfw
+    system = _water(c)
+    integrator = atomsmm.UnconstrainedVelocityVerletPropagator().integrator(0.5 * unit.femtoseconds)
+    context = openmm.Context(system, integrator)
+    context.setPositions(c['positions'] * unit.nanometers)
+    context.setVelocitiesToTemperature(300 * unit.kelvin, 5)
+    v = context.getState(getVelocities=True).getVelocities(asNumpy=True)._value.copy()
+    x = c['positions'].copy()
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+
+    def force(p):
+        return (O.pair_eval(dd, p, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1] +
+                O.harmonic_bonds(c['bonds'], c['bond_r0'], c['bond_k'], p, c['box'])[1] +
+                O.harmonic_angles(c['angles'], c['angle_theta0'], c['angle_k'], p, c['box'])[1])
+    dt, m = 0.0005, c['mass'][:, None]
+    f = force(x)
+    for _ in range(5):
+        v = v + 0.5 * 1.0 * dt * f / m
+        x = x + 1.0 * dt * v
+        f = force(x)
+        v = v + 0.5 * 1.0 * dt * f / m
+    integrator.step(5)
+    assert context._engine._interpreted is True
+    state = context.getState(getPositions=True, getVelocities=True)
+    assert np.abs(state.getPositions(asNumpy=True)._value - x).max() < 1e-12
+    assert np.abs(state.getVelocities(asNumpy=True)._value - v).max() < 1e-10
+
+
+def test_nose_hoover_program_step_for_step(spcfw):
+    """NoseHooverPropagator alone (propagators.py:1230-1273): mvv <- sum(m*v*v) on the GPU, the globals on the host,
+    v <- vscaling*v on the GPU -- against a numpy evaluation of the same program text."""
+    c = spcfw
+    system = _water(c)
+    dof = atomsmm.countDegreesOfFreedom(system)
+    thermostat = atomsmm.NoseHooverPropagator(300 * unit.kelvin, dof, 10 * unit.femtoseconds, 3)
+    integrator = thermostat.integrator(2 * unit.femtoseconds)
+    context = openmm.Context(system, integrator)
+    context.setPositions(c['positions'] * unit.nanometers)
+    context.setVelocitiesToTemperature(450 * unit.kelvin, 9)
+    v = context.getState(getVelocities=True).getVelocities(asNumpy=True)._value.copy()
+    m = c['mass'][:, None]
+    LkT, Q, dt, p_eta = dof * KB * 300.0, dof * KB * 300.0 * 0.01 ** 2, 0.002, 0.0
+    sub = 1.0 / 3
+    for _ in range(4):
+        mvv = float((m * v * v).sum())
+        p_eta = p_eta + (0.5 * sub * dt) * (mvv - LkT)
+        vs = np.exp(-(sub * dt) * p_eta / Q)
+        for _k in range(2):
+            p_eta = p_eta + (sub * dt) * (vs ** 2 * mvv - LkT)
+            vs = vs * np.exp(-(sub * dt) * p_eta / Q)
+        p_eta = p_eta + (0.5 * sub * dt) * (vs ** 2 * mvv - LkT)
+        v = vs * v
+    integrator.step(4)
+    got = context.getState(getVelocities=True).getVelocities(asNumpy=True)._value
+    assert np.abs(got - v).max() < 1e-11 * np.abs(v).max()
+    assert integrator.getGlobalVariableByName('p_eta') == pytest.approx(p_eta, rel=1e-11)
+
+
+def test_langevin_middle_scheme_equilibrates(spcfw):
+    """B A O A B with the Ornstein-Uhlenbeck bath (propagators.py:685-741): a cold start reaches the bath temperature."""
+    c = spcfw
+    system = _water(c)
+    nve = atomsmm.UnconstrainedVelocityVerletPropagator()
+    bath = atomsmm.OrnsteinUhlenbeckPropagator(300 * unit.kelvin, 20 / unit.picoseconds)
+    integrator = atomsmm.TrotterSuzukiPropagator(nve, bath).integrator(1 * unit.femtoseconds)
+    integrator.setRandomNumberSeed(1234)
+    context = openmm.Context(system, integrator)
+    context.setPositions(c['positions'] * unit.nanometers)
+    context.setVelocitiesToTemperature(30 * unit.kelvin, 1)
+    temps = []
+    for _ in range(12):
+        integrator.step(50)
+        ke = context.getState(getEnergy=True).getKineticEnergy()._value
+        temps.append(2 * ke / (3 * len(c['mass']) * KB))
+    assert temps[0] > 60 and abs(np.mean(temps[-4:]) - 300) < 25, temps
+    pe = context.getState(getEnergy=True).getPotentialEnergy()._value
+    assert np.isfinite(pe)
+
+
+def test_bussi_thermostat_runs_and_holds_temperature(spcfw):
+    """GlobalThermostatIntegrator(NVE, VelocityRescalingPropagator) (integrators.py:173-211, propagators.py:1156-1227):
+    while-blocks on host-side random globals + a per-DOF expression with auxiliary definitions."""
+    c = spcfw
+    system = _water(c)
+    dof = atomsmm.countDegreesOfFreedom(system)
+    nve = atomsmm.UnconstrainedVelocityVerletPropagator()
+    thermostat = atomsmm.VelocityRescalingPropagator(300 * unit.kelvin, dof, 0.05 * unit.picoseconds)
+    integrator = atomsmm.GlobalThermostatIntegrator(1 * unit.femtoseconds, nve, thermostat)
+    integrator.setRandomNumberSeed(1)
+    context = openmm.Context(system, integrator)
+    context.setPositions(c['positions'] * unit.nanometers)
+    context.setVelocitiesToTemperature(300 * unit.kelvin, 1)
+    integrator.step(200)
+    ke = context.getState(getEnergy=True).getKineticEnergy()._value
+    assert 200 < 2 * ke / (dof * KB) < 400

@@ -297,13 +297,16 @@ def test_engine_memory_program_and_unsupported_steps(spcfw, recorder):
     plus = [o for o in ops if o[0] == B.OP_KICK and o[3] == 1]
     assert len(plus) == 4                                                                    # (f0+fm1) kicks
     assert [o for o in ops if o[0] == B.OP_KICK][-1][3] == 0                                 # (f1-fm1)
-    # constrained propagators are accepted on constraint-free systems only up to what the HIP path implements
+    # constrained propagators on a constraint-free system: `v <- (x - x0)/((1.0*dt)*...)` is no kick or move, so the
+    # program takes the general path (host-walked steps, per-DOF expressions compiled for amm_expr_eval)
     nve = atomsmm.RespaPropagator([2, 1], move=atomsmm.TranslationPropagator(constrained=True))
     integ2 = atomsmm.GlobalThermostatIntegrator(1 * unit.femtoseconds, nve)
     ctx2 = openmm.Context(respa, integ2)
     ctx2.setPositions(spcfw['positions'])
-    with pytest.raises(NotImplementedError):
-        integ2.step(1)                                                                      # v <- (x - x0)/(c*dt)
+    integ2.step(1)
+    assert ctx2._engine._interpreted is True
+    exprs = [c for c in recorder[-1].calls if c[0] == 'expr_eval']
+    assert len(exprs) == 2 and all(c[5] and not c[6] for c in exprs)        # two per-DOF assignments, no sums
 
 
 def test_engine_rejects_what_it_cannot_run(spcfw, recorder):
