@@ -19,6 +19,7 @@ from .forces import NearNonbondedForce  # noqa: F401
 from .forces import NonbondedExceptionsForce  # noqa: F401
 from .integrators import GlobalThermostatIntegrator  # noqa: F401
 from .integrators import MultipleTimeScaleIntegrator  # noqa: F401
+from .integrators import Langevin_R_Integrator, NHL_R_Integrator  # noqa: F401
 from .propagators import ChainedPropagator  # noqa: F401
 from .propagators import MultipleTimeScalePropagator  # noqa: F401
 from .propagators import RespaPropagator  # noqa: F401
@@ -29,7 +30,8 @@ from .propagators import TrotterSuzukiPropagator  # noqa: F401
 from .propagators import VelocityBoostPropagator  # noqa: F401
 from .propagators import VelocityVerletPropagator  # noqa: F401
 from .propagators import (MassiveNoseHooverPropagator, NoseHooverPropagator, OrnsteinUhlenbeckPropagator,  # noqa: F401
-                          UnconstrainedVelocityVerletPropagator, VelocityRescalingPropagator)
+                          UnconstrainedVelocityVerletPropagator, VelocityRescalingPropagator,
+                          GenericBoostPropagator, GenericScalingPropagator)
 from .systems import RESPASystem, SolvationSystem  # noqa: F401
 from .utils import InputError  # noqa: F401
 from .utils import countDegreesOfFreedom  # noqa: F401
@@ -41,12 +43,12 @@ from . import forces, integrators, propagators, systems, utils  # noqa: F401
 
 __forces__ = ['DampedSmoothedForce', 'NonbondedExceptionsForce', 'NearExceptionForce', 'NearNonbondedForce',
               'FarNonbondedForce']
-__integrators__ = ['GlobalThermostatIntegrator', 'MultipleTimeScaleIntegrator']
+__integrators__ = ['GlobalThermostatIntegrator', 'MultipleTimeScaleIntegrator', 'Langevin_R_Integrator', 'NHL_R_Integrator']
 __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPropagator', 'SplitPropagator',
                    'SuzukiYoshidaPropagator', 'TranslationPropagator', 'TrotterSuzukiPropagator',
                    'VelocityBoostPropagator', 'VelocityVerletPropagator', 'UnconstrainedVelocityVerletPropagator',
                    'VelocityRescalingPropagator', 'NoseHooverPropagator', 'MassiveNoseHooverPropagator',
-                   'OrnsteinUhlenbeckPropagator']
+                   'OrnsteinUhlenbeckPropagator', 'GenericBoostPropagator', 'GenericScalingPropagator']
 __systems__ = ['RESPASystem', 'SolvationSystem']
 __utils__ = ['countDegreesOfFreedom', 'evaluateForce', 'findNonbondedForce', 'hijackForce', 'splitPotentialEnergy']
 __all__ = __forces__ + __integrators__ + __propagators__ + __systems__ + __utils__

@@ -9,13 +9,14 @@ expression that references several force groups through `_f{k}_` buffers (a Cust
 computation may read one force group only).  The reference finds free symbols with sympy; an
 identifier scan is equivalent for these expressions and keeps sympy off the import path.
 """
+import math
 import re
 
 import numpy as np
 
 from . import openmm
 from . import propagators
-from .utils import InputError
+from .utils import InputError, kB
 
 _IDENT = re.compile(r'[A-Za-z_][A-Za-z_0-9]*')
 _FUNCS = {'sqrt', 'exp', 'log', 'sin', 'cos', 'sec', 'csc', 'tan', 'cot', 'asin', 'acos', 'atan', 'atan2', 'sinh',
@@ -155,3 +156,33 @@ class MultipleTimeScaleIntegrator(_AtomsMM_Integrator):
         propagator = propagators.MultipleTimeScalePropagator(loops, move, boost, bath, **kwargs)
         propagator.addVariables(self)
         propagator.addSteps(self)
+
+
+class Langevin_R_Integrator(MultipleTimeScaleIntegrator):
+    """Multiple time scale Langevin integrator (integrators.py:296-323): RESPA with an Ornstein-Uhlenbeck bath
+    dv = -gamma v dt + sqrt(2 gamma kT/m) dW placed by `scheme` (default 'middle')."""
+
+    def __init__(self, stepSize, loops, temperature, frictionConstant, **kwargs):
+        bath = propagators.OrnsteinUhlenbeckPropagator(temperature, frictionConstant)
+        super().__init__(stepSize, loops, None, None, bath, **kwargs)
+
+
+class NHL_R_Integrator(MultipleTimeScaleIntegrator):
+    """Massive Nose-Hoover-Langevin RESPA integrator (integrators.py:272-318): every DOF carries a thermostat
+    velocity v2 (inertia Q2 = kT tau^2) driven by m v^2 - kT and by its own Ornstein-Uhlenbeck bath; v <- v exp(-v2 dt)."""
+
+    def __init__(self, stepSize, loops, temperature, timeScale, frictionConstant, **kwargs):
+        scaling = propagators.GenericScalingPropagator('v', 'v2')
+        DOU = propagators.OrnsteinUhlenbeckPropagator(temperature, frictionConstant, 'v2', 'Q2', 'm*v^2 - kT',
+                                                      Q2=kB * temperature * timeScale ** 2, kT=kB * temperature)
+        bath = propagators.TrotterSuzukiPropagator(DOU, scaling)
+        super().__init__(stepSize, loops, None, None, bath, **kwargs)
+
+    def initialize(self):
+        kT = self.getGlobalVariableByName('kT')
+        Q2 = self.getGlobalVariableByName('Q2')
+        v2 = self.getPerDofVariableByName('v2')
+        S = math.sqrt(kT / Q2)
+        for i in range(len(v2)):
+            v2[i] = S * self._normalVec()
+        self.setPerDofVariableByName('v2', v2)

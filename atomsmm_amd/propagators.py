@@ -420,3 +420,39 @@ class OrnsteinUhlenbeckPropagator(Propagator):
             integrator.addComputeGlobal(self.velocity, expression)
         else:
             integrator.addComputePerDof(self.velocity, expression)
+
+
+class GenericBoostPropagator(Propagator):
+    """dV/dt = F/M for a named velocity / mass / force triple, per-DOF or global (propagators.py:744-790)."""
+
+    def __init__(self, velocity='v', mass='m', force='f', perDof=True, **globals):
+        super().__init__()
+        self.velocity, self.mass, self.force, self.perDof = velocity, mass, force, perDof
+        for key, value in globals.items():
+            self.globalVariables[key] = value
+        if velocity != 'v':
+            (self.perDofVariables if perDof else self.globalVariables)[velocity] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        expression = '{} + ({}*dt)*F/M'.format(self.velocity, fraction)
+        expression += '; F = {}'.format(self.force)
+        expression += '; M = {}'.format(self.mass)
+        (integrator.addComputePerDof if self.perDof else integrator.addComputeGlobal)(self.velocity, expression)
+
+
+class GenericScalingPropagator(Propagator):
+    """dV/dt = -damping*V for a named velocity and damping variable (propagators.py:793-827)."""
+
+    def __init__(self, velocity, damping, perDof=True, **globals):
+        super().__init__()
+        self.velocity, self.damping, self.perDof = velocity, damping, perDof
+        for key, value in globals.items():
+            self.globalVariables[key] = value
+        if perDof and velocity != 'v':
+            self.perDofVariables[velocity] = 0
+        elif not perDof:
+            self.globalVariables[velocity] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        expression = '{}*exp(-({}*dt)*{})'.format(self.velocity, fraction, self.damping)
+        (integrator.addComputePerDof if self.perDof else integrator.addComputeGlobal)(self.velocity, expression)

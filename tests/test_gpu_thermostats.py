@@ -201,3 +201,39 @@ def test_bussi_thermostat_runs_and_holds_temperature(spcfw):
     integrator.step(200)
     ke = context.getState(getEnergy=True).getKineticEnergy()._value
     assert 200 < 2 * ke / (dof * KB) < 400
+
+
+@pytest.mark.parametrize('kind', ['langevin', 'nhl'])
+def test_respa_with_bath_equilibrates(spcfw, kind):
+    """Langevin_R_Integrator / NHL_R_Integrator (integrators.py:272-323): RESPA [2,2,1] over RESPASystem with the bath in
+    the 'middle' of the innermost loop.  The pair-force evaluations still go through amm_run_ops; the bath steps through
+    the interpreter.  A cold start reaches the bath temperature and the near / outer force caches stay consistent."""
+    c = spcfw
+    system = system_from_arrays(c, nonbondedMethod='CutoffPeriodic')
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+    outer = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9 * unit.angstroms).importFrom(nb)
+    outer.setForceGroup(2)
+    outer.addTo(respa)
+    if kind == 'langevin':
+        integrator = atomsmm.Langevin_R_Integrator(2 * unit.femtoseconds, [2, 2, 1], 300 * unit.kelvin, 20 / unit.picoseconds)
+    else:
+        integrator = atomsmm.NHL_R_Integrator(2 * unit.femtoseconds, [2, 2, 1], 300 * unit.kelvin, 10 * unit.femtoseconds,
+                                              20 / unit.picoseconds)
+    integrator.setRandomNumberSeed(77)
+    context = openmm.Context(respa, integrator)
+    context.setPositions(c['positions'] * unit.nanometers)
+    context.setVelocitiesToTemperature(30 * unit.kelvin, 3)
+    temps = []
+    for _ in range(10):
+        integrator.step(40)
+        ke = context.getState(getEnergy=True).getKineticEnergy()._value
+        temps.append(2 * ke / (3 * len(c['mass']) * KB))
+    assert context._engine._interpreted is True
+    assert abs(np.mean(temps[-3:]) - 300) < 30, temps
+    # the cached group forces the program leaves behind equal a fresh evaluation at the final positions
+    eng = context._engine
+    x = context.getState(getPositions=True).getPositions(asNumpy=True)._value
+    dn = O.desc(O.NEAR_FSWITCH, rc=0.7, rc0=0.7, rs0=0.5)
+    f1 = O.pair_eval(dn, x, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
+    assert np.abs(eng._buffer('f1').cpu().numpy() - f1).max() <= 1e-9 * np.abs(f1).max()
