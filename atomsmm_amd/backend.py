@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, 'libatomsmm_hip.so')
 NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE = range(6)
 GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH = 1, 2, 4, 8
 BOND_HARMONIC, ANGLE_HARMONIC, BOND_LJC, BOND_NEAR, TORSION_PERIODIC, BOND_EWALD_EXCL = range(6)
-OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE = 1, 2, 3, 4, 5
+OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE, OP_EXPR, OP_BATH = 1, 2, 3, 4, 5, 6, 7
 MAX_SLOTS, SLOT_X, SLOT_V = 64, 62, 63
 GROUP_ALL = 32   # pseudo-group of the force symbol `f` (all groups)
 KC = 138.935456   # forces.py:407
@@ -28,7 +28,7 @@ EXPORTS = [
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
-    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval',
+    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define',
 ]
 
 
@@ -106,6 +106,9 @@ def lib():
         L.amm_pme_set_charges.argtypes = [vp, C.c_int32, dp]
         L.amm_pme_set_sliced.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_pair_set_lambda.argtypes = [vp, C.c_int32, C.c_double]
+        L.amm_expr_define.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, ip]
+        L.amm_expr_seed.argtypes = [vp, C.c_uint64]
+        L.amm_bath_define.argtypes = [vp, C.c_double, C.c_double, ip]
         L.amm_expr_eval.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp]
         for name in EXPORTS:
             if name not in ('amm_last_error',):
@@ -224,6 +227,22 @@ class HipContext:
 
     def pme_set_sliced(self, fid, on=True):
         _chk(lib().amm_pme_set_sliced(self.h, fid, int(bool(on))))
+
+    def expr_define(self, code, consts, globals_):
+        c_, cp = _hi(code)
+        k_, kp = _hd(consts if len(consts) else [0.0])
+        g_, gp = _hd(globals_ if len(globals_) else [0.0])
+        eid = C.c_int32(-1)
+        _chk(lib().amm_expr_define(self.h, cp, len(c_), kp, len(consts), gp, len(globals_), C.byref(eid)))
+        return eid.value
+
+    def bath_define(self, z, kT):
+        bid = C.c_int32(-1)
+        _chk(lib().amm_bath_define(self.h, float(z), float(kT), C.byref(bid)))
+        return bid.value
+
+    def expr_seed(self, seed):
+        _chk(lib().amm_expr_seed(self.h, int(seed) & (2 ** 64 - 1)))
 
     def expr_eval(self, code, consts, globals_, seed, counter, dst=None, total=None):
         """Per-DOF postfix program (atomsmm_amd.expr): dst <- values, total <- their sum (device tensors or None)."""

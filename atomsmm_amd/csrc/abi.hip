@@ -465,6 +465,37 @@ int amm_expr_eval(amm_ctx *ctx, const int32_t *code, int32_t n_code, const doubl
     return amm_expr_eval_impl(ctx, code, n_code, consts, n_consts, globals, n_globals, seed, counter, d_dst, d_sum);
 }
 
+int amm_expr_define(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
+                    const double *globals, int32_t n_globals, int32_t *expr_id) {
+    if (!ctx || !code || n_code < 1 || !expr_id || (n_consts > 0 && !consts) || (n_globals > 0 && !globals)) {
+        amm_set_error("amm_expr_define: bad arguments");
+        return 1;
+    }
+    ExprDef e;
+    e.code.assign(code, code + n_code);
+    if (n_consts > 0) e.consts.assign(consts, consts + n_consts);
+    if (n_globals > 0) e.globals.assign(globals, globals + n_globals);
+    ctx->exprs.push_back(e);
+    *expr_id = (int32_t)ctx->exprs.size() - 1;
+    return 0;
+}
+
+int amm_bath_define(amm_ctx *ctx, double z, double kT, int32_t *bath_id) {
+    if (!ctx || !bath_id || !(z >= 0.0 && z <= 1.0) || !(kT >= 0.0)) {
+        amm_set_error("amm_bath_define: need 0 <= z <= 1 and kT >= 0");
+        return 1;
+    }
+    ctx->baths.push_back(BathDef{z, kT});
+    *bath_id = (int32_t)ctx->baths.size() - 1;
+    return 0;
+}
+
+int amm_expr_seed(amm_ctx *ctx, uint64_t seed) {
+    ctx->expr_seed = seed;
+    ctx->expr_counter = 0;
+    return 0;
+}
+
 int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass) {
     ctx->d_x = d_x;
     ctx->d_v = d_v;
@@ -512,20 +543,29 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 // the last KICK of the run is the first op of the inner pattern
                 int start = p - 1;
                 npre -= 1;
+                // iteration = KICK(c1, fg) ; MOVE(d) ; [BATH(b) ; MOVE(d2) ;] EVAL(g) ; KICK(c2, fg)
+                const bool bathed = start + 5 < n_ops && ops[start + 2].op == AMM_OP_BATH && ops[start + 3].op == AMM_OP_MOVE;
+                const int stride = bathed ? 6 : 4, eo = bathed ? 4 : 2;       // ops per iteration / offset of the EVAL
                 auto is_iter = [&](int q, const amm_op &first) {
-                    return q + 3 < n_ops && ops[q].op == AMM_OP_KICK && ops[q].b < 0 && ops[q + 1].op == AMM_OP_MOVE &&
-                           ops[q + 2].op == AMM_OP_EVAL && ops[q + 3].op == AMM_OP_KICK && ops[q + 3].b < 0 &&
-                           ops[q + 3].a == ops[q].a && ops[q].a == first.a && ops[q].coef == first.coef &&
-                           ops[q + 1].coef == ops[start + 1].coef && ops[q + 3].coef == ops[start + 3].coef &&
-                           ops[q + 2].a == ops[start + 2].a;
+                    if (!(q + stride - 1 < n_ops && ops[q].op == AMM_OP_KICK && ops[q].b < 0 && ops[q + 1].op == AMM_OP_MOVE &&
+                          ops[q + eo].op == AMM_OP_EVAL && ops[q + eo + 1].op == AMM_OP_KICK && ops[q + eo + 1].b < 0 &&
+                          ops[q + eo + 1].a == ops[q].a && ops[q].a == first.a && ops[q].coef == first.coef &&
+                          ops[q + 1].coef == ops[start + 1].coef && ops[q + eo + 1].coef == ops[start + eo + 1].coef &&
+                          ops[q + eo].a == ops[start + eo].a))
+                        return false;
+                    if (bathed)
+                        return ops[q + 2].op == AMM_OP_BATH && ops[q + 2].a == ops[start + 2].a && ops[q + 2].a >= 0 &&
+                               ops[q + 2].a < (int)ctx->baths.size() && ops[q + 3].op == AMM_OP_MOVE &&
+                               ops[q + 3].coef == ops[start + 3].coef;
+                    return true;
                 };
-                if (npre <= 3 && start >= k && is_iter(start, ops[start]) && ops[start + 2].a >= 0 && ops[start + 2].a < AMM_MAX_GROUPS) {
-                    GroupDef &g = ctx->groups[ops[start + 2].a];
+                if (npre <= 3 && start >= k && is_iter(start, ops[start]) && ops[start + eo].a >= 0 && ops[start + eo].a < AMM_MAX_GROUPS) {
+                    GroupDef &g = ctx->groups[ops[start + eo].a];
                     BondedSet *bs = (g.slot == ops[start].a && g.forces.size() == 1 && ctx->forces[g.forces[0]].type == 2)
                                         ? ctx->forces[g.forces[0]].bonded : nullptr;
                     if (bs && bs->max_comp <= 8 && !(bs->sliced && ctx->world > 1)) {
                         int niter = 0, q = start;
-                        while (is_iter(q, ops[start])) { ++niter; q += 4; }
+                        while (is_iter(q, ops[start])) { ++niter; q += stride; }
                         const double *pa[3] = {nullptr, nullptr, nullptr}, *pb[3] = {nullptr, nullptr, nullptr};
                         double pc[3] = {0, 0, 0};
                         int pp[3] = {0, 0, 0};
@@ -541,7 +581,9 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                         double *f0 = ctx->slots[g.slot];
                         if (ok && f0) {
                             if (amm_inner_components_impl(ctx, bs, ctx->d_x, ctx->d_v, f0, npre, pa, pb, pc, pp, ops[start].coef,
-                                                          ops[start + 1].coef, ops[start + 3].coef, niter)) return 1;
+                                                          ops[start + 1].coef, ops[start + eo + 1].coef, niter,
+                                                          bathed ? &ctx->baths[ops[start + 2].a] : nullptr,
+                                                          bathed ? ops[start + 3].coef : 0.0)) return 1;
                             ctx->pos_epoch++;
                             for (int w = 0; w < ctx->n_prechecked; ++w) {
                                 ctx->prechecked[w]->pre_epoch = ctx->pos_epoch;
@@ -655,6 +697,25 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 }
                 if (amm_combine_impl(ctx, dst, sa, sb, op.coef)) return 1;
                 if (dst == ctx->d_x) ctx->pos_epoch++;
+            } break;
+            case AMM_OP_EXPR: {
+                double *dst = (op.b >= 0 && op.b < AMM_MAX_SLOTS) ? ctx->slots[op.b] : nullptr;
+                if (op.a < 0 || op.a >= (int)ctx->exprs.size() || !dst) {
+                    amm_set_error("amm_run_ops: EXPR with an unknown expression or an unbound destination");
+                    return 1;
+                }
+                const ExprDef &e = ctx->exprs[op.a];
+                // the high bit of the counter keeps these streams apart from those of direct amm_expr_eval calls
+                const unsigned long long counter = (1ull << 63) | ++ctx->expr_counter;
+                if (amm_expr_eval_impl(ctx, e.code.data(), (int)e.code.size(), e.consts.data(), (int)e.consts.size(),
+                                       e.globals.data(), (int)e.globals.size(), ctx->expr_seed, counter, dst, nullptr)) return 1;
+            } break;
+            case AMM_OP_BATH: {
+                if (op.a < 0 || op.a >= (int)ctx->baths.size()) {
+                    amm_set_error("amm_run_ops: BATH with an unknown bath id");
+                    return 1;
+                }
+                if (amm_bath_impl(ctx, ctx->baths[op.a], ctx->d_v, (1ull << 63) | ++ctx->expr_counter)) return 1;
             } break;
             default: amm_set_error("amm_run_ops: unknown op"); return 1;
             }

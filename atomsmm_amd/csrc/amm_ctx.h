@@ -125,6 +125,16 @@ struct ForceObj {
     PmeForce *pme = nullptr;
 };
 
+struct ExprDef {
+    std::vector<int32_t> code;
+    std::vector<double> consts, globals;
+};
+
+// native bath step of Langevin-type integrators: v <- z v + sqrt(kT (1 - z^2) / m) * gaussian  (propagators.py:727-741)
+struct BathDef {
+    double z, kT;
+};
+
 struct GroupDef {
     int slot = -1;
     std::vector<int> forces;
@@ -145,6 +155,9 @@ struct amm_ctx {
     int profile_only = -1;         // >= 0: time only this force id (each timed launch costs two event packets)
     double *d_scratch = nullptr;   // small scratch (reductions)
     double *d_expr_part = nullptr; // block partial sums of amm_expr_eval
+    std::vector<ExprDef> exprs;    // registered per-DOF expressions (AMM_OP_EXPR)
+    std::vector<BathDef> baths;    // registered Ornstein-Uhlenbeck baths (AMM_OP_BATH)
+    unsigned long long expr_seed = 0, expr_counter = 0;
     // ping-pong partners of x, v and the group-0 force buffer for the fused inner RESPA iteration
     double *alt_x = nullptr, *alt_v = nullptr, *alt_f = nullptr;
     bool fuse_inner = true;
@@ -166,7 +179,8 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
 int amm_bonded_free(BondedSet *bs);
 int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v, double *f0, int npre, const double *const *pre_a,
                               const double *const *pre_b, const double *pre_coef, const int *pre_plus, double c1, double d,
-                              double c2, int niter);
+                              double c2, int niter, const BathDef *bath = nullptr, double d2 = 0.0);
+int amm_bath_impl(amm_ctx *ctx, const BathDef &bath, double *d_v, unsigned long long counter);
 int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const double *v_in, const double *f_in,
                          double *x_out, double *v_out, double *f_out, double c1, double d, double c2);
 int amm_pme_create_impl(amm_ctx *ctx, double alpha, const int *K, double Kc, const double *h_q, PmeForce **out);

@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "amm_ctx.h"
+#include "expr_vm.h"
 #include "pair_math.h"
 
 struct BondedArgs {
@@ -279,6 +280,9 @@ struct CompArgs {
     double *x, *v, *f0;
     const double *mass;
     double c1, d, c2;
+    // BATH: kick ; move(d) ; Ornstein-Uhlenbeck step ; move(d2) ; forces ; kick  (Langevin_R 'middle' scheme)
+    double d2, bath_z, bath_kT;
+    unsigned long long seed, counter0;
     PreKick pre[3];
     // displacement watchers: neighbour lists whose rebuild trigger this kernel evaluates for the positions it
     // writes (saves the separate k_check_displacement launch before the next pair-force evaluation)
@@ -298,7 +302,7 @@ struct PosLds {
     __device__ __forceinline__ double get(int slot, int k) const { return k == 0 ? sx[slot] : (k == 1 ? sy[slot] : sz[slot]); }
 };
 
-template <int G>
+template <int G, bool BATH>
 __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
     __shared__ double s_x[3][256];
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -355,6 +359,20 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
                 v[j] = v[j] + dv;
                 const double dx = C.d * v[j];
                 x[j] = x[j] + dx;
+            }
+        }
+        if (BATH) {
+            // the same amm_ou_step / random stream as a separate AMM_OP_BATH launch of this iteration would use
+            const unsigned long long counter = (1ull << 63) | (C.counter0 + (unsigned long long)it + 1ull);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[j] = amm_ou_step(v[j], m, C.bath_z, C.bath_kT, amm_gaussian(C.seed, counter, (unsigned)(3 * a + j)));
+            {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double dx = C.d2 * v[j];
+                    x[j] = x[j] + dx;
+                }
             }
         }
         // publish the new position to the group (wavefront-synchronous: the group never spans two wavefronts)
@@ -588,7 +606,7 @@ int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const 
 
 int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v, double *f0, int npre, const double *const *pre_a,
                               const double *const *pre_b, const double *pre_coef, const int *pre_plus, double c1, double d,
-                              double c2, int niter) {
+                              double c2, int niter, const BathDef *bath, double d2) {
     BondedArgs A;
     A.n = ctx->n;
     A.row_begin = 0;
@@ -646,8 +664,19 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     dim3 block(256);
     const int G = bs->max_comp <= 4 ? 4 : 8;
     dim3 grid((unsigned)(((long)bs->ncomp * G + 255) / 256));
-    if (G == 4) hipLaunchKernelGGL((k_inner_lanes<4>), grid, block, 0, ctx->stream, A, C);
-    else hipLaunchKernelGGL((k_inner_lanes<8>), grid, block, 0, ctx->stream, A, C);
+    C.d2 = d2;
+    C.bath_z = bath ? bath->z : 1.0;
+    C.bath_kT = bath ? bath->kT : 0.0;
+    C.seed = ctx->expr_seed;
+    C.counter0 = ctx->expr_counter;
+    if (bath) {
+        ctx->expr_counter += (unsigned long long)niter;      // one BATH op per iteration, as the unfused sequence counts
+        if (G == 4) hipLaunchKernelGGL((k_inner_lanes<4, true>), grid, block, 0, ctx->stream, A, C);
+        else hipLaunchKernelGGL((k_inner_lanes<8, true>), grid, block, 0, ctx->stream, A, C);
+    } else {
+        if (G == 4) hipLaunchKernelGGL((k_inner_lanes<4, false>), grid, block, 0, ctx->stream, A, C);
+        else hipLaunchKernelGGL((k_inner_lanes<8, false>), grid, block, 0, ctx->stream, A, C);
+    }
     AMM_HIP(hipGetLastError());
     return 0;
 }

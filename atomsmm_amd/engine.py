@@ -167,6 +167,9 @@ class Engine:
         self._group_defs = {}
         self._valid = {}
         self._interpreted = None    # None: undecided; True: general (host-walked) step programs
+        self._static_exprs = False
+        self._expr_ids = {}
+        self._seed_set = None
         self._host_rng = None
         self._expr_counter = 0
         self._mirror = {}           # per-DOF buffer -> force symbol it currently mirrors (`_f2_ <- f2`)
@@ -678,6 +681,7 @@ class Engine:
         env['dt'] = integ._dt
         valid = dict(self._valid)
         self._mirror_work = dict(self._mirror)
+        self._static_exprs = True
         ops = []
         pc = 0
         guard = 0
@@ -705,6 +709,7 @@ class Engine:
                 if steps[match[pc]][0] == C.WhileBlock:
                     pc = match[pc] - 1
             pc += 1
+        self._static_exprs = False
         finals = {name: env[name] for name in integ._gnames}
         return self._pair_up_evals(ops), valid, finals, dict(self._mirror_work)
 
@@ -811,7 +816,7 @@ class Engine:
     def _emit_per_dof(self, target, expr, env, ops, valid):
         text = expr.replace(' ', '')
         if ';' in text:
-            raise NotImplementedError('per-DOF expressions with auxiliary definitions are outside this round\'s scope: ' + expr)
+            text = ''         # auxiliary definitions: never a plain kick / move / copy -> general expression below
         # kick: v <- v + (coef)*FORCE/m
         if target == 'v' and text.startswith('v+') and text.endswith('/m'):
             parts = self._split_leading_group(text[2:-2])
@@ -857,6 +862,45 @@ class Engine:
                     ops.append(B.Op(B.OP_COMBINE, dst, src, second, float(terms[1][0])))
                     self._mirror_work.pop(target, None)
                 return
+        # any other per-DOF expression whose globals are known now (a bath step inside a RESPA loop, ...): registered
+        # once with the backend and replayed by amm_run_ops as an EXPR op
+        if getattr(self, '_static_exprs', False):
+            integ = self.integrator
+
+            def resolve(name):
+                if name == 'm':
+                    return ('mass',)
+                if name in ('x', 'v') or re.fullmatch(r'f[0-9]*', name) or name in integ._pnames:
+                    return ('buf', self._force_ref(name, ops, valid))
+                if name in env and not callable(env[name]):
+                    return ('global',)
+                return None
+            if target not in ('x', 'v') and target not in integ._pnames:
+                raise mm.OpenMMException('unknown per-DOF variable: ' + target)
+            # the Ornstein-Uhlenbeck bath on (v, m) without force, as OrnsteinUhlenbeckPropagator writes it
+            # (propagators.py:727-733): a native op, which the inner-loop kernel can carry (Langevin_R)
+            ou = re.fullmatch(r'z\*v\+sqrt\(kT\*\(1-z\*z\)/mass\)\*gaussian;mass=m;z=exp\(-\((.+)\*dt\)\*friction\)',
+                              expr.replace(' ', ''))
+            if ou and target == 'v' and 'kT' in env and 'friction' in env:
+                z = math.exp(-(self._eval(ou.group(1), env) * env['dt']) * env['friction'])
+                key = ('ou', z, float(env['kT']))
+                if key not in self._expr_ids:
+                    self._expr_ids[key] = self.ctx.bath_define(z, float(env['kT']))
+                ops.append(B.Op(B.OP_BATH, self._expr_ids[key], B.SLOT_V, 0, 0.0))
+                return
+            prog = X.compile_per_dof(expr, resolve)
+            gvals = tuple(float(env[name]) for name in prog.globals_)
+            key = (expr, gvals)
+            if key not in self._expr_ids:
+                self._expr_ids[key] = self.ctx.expr_define(prog.code, prog.consts, list(gvals))
+            ops.append(B.Op(B.OP_EXPR, self._expr_ids[key], self._slot(target), 0, 0.0))
+            self._mirror_work.pop(target, None)
+            for d in [d for d, sname in self._mirror_work.items() if sname == target]:
+                del self._mirror_work[d]
+            if target == 'x':
+                for g in valid:
+                    valid[g] = False
+            return
         raise NotImplementedError('per-DOF computation outside the RESPA hot path: {} <- {}'.format(target, expr))
 
     @staticmethod
@@ -996,13 +1040,17 @@ class Engine:
         integ = self.integrator
         if not isinstance(integ, mm.CustomIntegrator):
             raise NotImplementedError('only CustomIntegrator step programs run on the HIP path')
+        if self._seed_set != integ.getRandomNumberSeed():
+            self._seed_set = integ.getRandomNumberSeed()
+            self.ctx.expr_seed(self._seed_set)
         if self._interpreted is None:
-            # static programs (RESPA and friends) are unrolled once and replayed; anything the unroller cannot express
-            # goes through the general path
+            # static programs (RESPA, also with bath steps inside the loops) are unrolled once and replayed; programs
+            # with data-dependent globals (ComputeSum results, random globals) go through the general path
             try:
                 self._compile()
                 self._interpreted = False
-            except (NotImplementedError, NameError, SyntaxError, TypeError, X.ExpressionError):
+            except (NotImplementedError, NameError, SyntaxError, TypeError, KeyError, X.ExpressionError):
+                self._static_exprs = False
                 self._interpreted = True
         if self._interpreted:
             return self._step_interpreted(n)

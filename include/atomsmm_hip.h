@@ -82,7 +82,13 @@ enum {
                           force expressions (f0), (f2-f1), (f0+fm1) ... of propagators.py:917-928 */
     AMM_OP_MOVE = 3,   /* x <- x + coef*v                                                propagators.py:249 */
     AMM_OP_COPY = 4,   /* buf[a] <- buf[b]                          integrators.py:139-144 (`_f2_ <- f2`)    */
-    AMM_OP_COMBINE = 5 /* buf[a] <- buf[b] + coef*buf[c]            propagators.py:951 (`fm2 <- f2-f1`)       */
+    AMM_OP_COMBINE = 5,/* buf[a] <- buf[b] + coef*buf[c]            propagators.py:951 (`fm2 <- f2-f1`)       */
+    AMM_OP_EXPR = 6,   /* buf[b] <- per-DOF expression a (amm_expr_define): bath steps inside a RESPA loop, e.g. a
+                          thermostat update on a per-DOF variable (NHL_R, integrators.py:272-318); each execution draws from the
+                          next random-stream counter                                                                  */
+    AMM_OP_BATH = 7    /* v <- z v + sqrt(kT (1 - z^2)/m) gaussian with (z, kT) = bath a (amm_bath_define): the Ornstein-Uhlenbeck
+                          step of OrnsteinUhlenbeckPropagator on (v, m) without force (propagators.py:727-741), as a native op so
+                          that the inner-loop kernel can carry it (Langevin_R 'middle' scheme)                        */
 };
 typedef struct {
     int32_t op, a, b, c;
@@ -162,6 +168,14 @@ int amm_mvv(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out); 
  * may be one of the bound buffers) receives the per-DOF values, *d_sum (device) their sum; either may be NULL. */
 int amm_expr_eval(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
                   const double *globals, int32_t n_globals, uint64_t seed, uint64_t counter, double *d_dst, double *d_sum);
+
+/* Register a per-DOF expression with fixed globals for AMM_OP_EXPR; amm_expr_seed sets the random stream used by the
+ * ops (integrator.setRandomNumberSeed, integrators.py:149-151) and restarts its counter. */
+int amm_expr_define(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
+                    const double *globals, int32_t n_globals, int32_t *expr_id);
+int amm_expr_seed(amm_ctx *ctx, uint64_t seed);
+/* z = exp(-gamma * fraction * dt), kT in kJ/mol: the constants of one Ornstein-Uhlenbeck bath step for AMM_OP_BATH. */
+int amm_bath_define(amm_ctx *ctx, double z, double kT, int32_t *bath_id);
 
 int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass);
 #define AMM_MAX_SLOTS 64

@@ -57,6 +57,19 @@ class RecordingContext:
     def pme_set_sliced(self, fid, on=True):
         [p for p in self.pme if p['id'] == fid][0]['sliced'] = bool(on)
 
+    def expr_define(self, code, consts, globals_):
+        self.exprs = getattr(self, 'exprs', [])
+        self.exprs.append((list(code), list(consts), list(globals_)))
+        return len(self.exprs) - 1
+
+    def bath_define(self, z, kT):
+        self.baths = getattr(self, 'baths', [])
+        self.baths.append((z, kT))
+        return len(self.baths) - 1
+
+    def expr_seed(self, seed):
+        self.calls.append(('expr_seed', seed))
+
     def expr_eval(self, code, consts, globals_, seed, counter, dst=None, total=None):
         self.calls.append(('expr_eval', list(code), list(consts), list(globals_), counter, dst is not None, total is not None))
         if total is not None:

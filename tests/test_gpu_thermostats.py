@@ -128,7 +128,7 @@ def test_unconstrained_velocity_verlet_vs_oracle(spcfw):
         f = force(x)
         v = v + 0.5 * 1.0 * dt * f / m
     integrator.step(5)
-    assert context._engine._interpreted is True
+    assert context._engine._interpreted is False      # static program: EXPR ops replayed by amm_run_ops
     state = context.getState(getPositions=True, getVelocities=True)
     assert np.abs(state.getPositions(asNumpy=True)._value - x).max() < 1e-12
     assert np.abs(state.getVelocities(asNumpy=True)._value - v).max() < 1e-10
@@ -206,8 +206,8 @@ def test_bussi_thermostat_runs_and_holds_temperature(spcfw):
 @pytest.mark.parametrize('kind', ['langevin', 'nhl'])
 def test_respa_with_bath_equilibrates(spcfw, kind):
     """Langevin_R_Integrator / NHL_R_Integrator (integrators.py:272-323): RESPA [2,2,1] over RESPASystem with the bath in
-    the 'middle' of the innermost loop.  The pair-force evaluations still go through amm_run_ops; the bath steps through
-    the interpreter.  A cold start reaches the bath temperature and the near / outer force caches stay consistent."""
+    the 'middle' of the innermost loop.  The pair-force evaluations still go through amm_run_ops; the bath steps are EXPR ops of
+    the same unrolled program.  A cold start reaches the bath temperature and the near / outer force caches stay consistent."""
     c = spcfw
     system = system_from_arrays(c, nonbondedMethod='CutoffPeriodic')
     respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
@@ -229,7 +229,7 @@ def test_respa_with_bath_equilibrates(spcfw, kind):
         integrator.step(40)
         ke = context.getState(getEnergy=True).getKineticEnergy()._value
         temps.append(2 * ke / (3 * len(c['mass']) * KB))
-    assert context._engine._interpreted is True
+    assert context._engine._interpreted is False      # the bath is an EXPR op inside the unrolled RESPA loop
     assert abs(np.mean(temps[-3:]) - 300) < 30, temps
     # the cached group forces the program leaves behind equal a fresh evaluation at the final positions
     eng = context._engine
@@ -237,3 +237,52 @@ def test_respa_with_bath_equilibrates(spcfw, kind):
     dn = O.desc(O.NEAR_FSWITCH, rc=0.7, rc0=0.7, rs0=0.5)
     f1 = O.pair_eval(dn, x, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
     assert np.abs(eng._buffer('f1').cpu().numpy() - f1).max() <= 1e-9 * np.abs(f1).max()
+
+
+def test_bath_inside_the_inner_loop_kernel_is_bit_identical(spcfw):
+    """Langevin_R: the inner-loop kernel runs kick ; move ; OU bath ; move ; forces ; kick for all n0 iterations in one
+    launch, calling the same expression interpreter with the same random-stream counters as the separate EXPR launches
+    do: the trajectory is bit-identical to the op-by-op execution."""
+    c = spcfw
+    out = []
+    for fuse in (True, False):
+        system = system_from_arrays(c, nonbondedMethod='CutoffPeriodic')
+        respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+        nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+        outer = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9 * unit.angstroms).importFrom(nb)
+        outer.setForceGroup(2)
+        outer.addTo(respa)
+        integrator = atomsmm.Langevin_R_Integrator(2 * unit.femtoseconds, [4, 2, 1], 300 * unit.kelvin, 5 / unit.picoseconds)
+        integrator.setRandomNumberSeed(99)
+        context = openmm.Context(respa, integrator)
+        context._engine.ctx.set_fuse_inner(fuse)
+        context.setPositions(c['positions'] * unit.nanometers)
+        context.setVelocitiesToTemperature(300 * unit.kelvin, 3)
+        integrator.step(12)
+        st = context.getState(getPositions=True, getVelocities=True)
+        out.append((st.getPositions(asNumpy=True)._value.copy(), st.getVelocities(asNumpy=True)._value.copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[0][0] - c['positions']).max() > 1e-3
+
+
+def test_native_ou_bath_vs_numpy():
+    """AMM_OP_BATH: v <- z v + sqrt(kT (1 - z^2)/m) gaussian, the Gaussian from the Philox stream of the EXPR/BATH ops."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    ctx = B.HipContext(n, np.array([3.0, 3.0, 3.0]))
+    v0 = rng.normal(0, 0.5, (n, 3))
+    mass = rng.choice([1.008, 15.9994], n)
+    x, v = dev(rng.uniform(0, 3, (n, 3))), dev(v0)
+    ctx.bind_state(x, v, dev(mass))
+    z, kT = float(np.exp(-0.002 * 5.0)), 2.494
+    bid = ctx.bath_define(z, kT)
+    ctx.expr_seed(424242)
+    ctx.run_ops([B.Op(B.OP_BATH, bid, B.SLOT_V, 0, 0.0)] * 2, 1)
+    ctx.check()
+    ref = v0.copy()
+    for k in (1, 2):
+        u1, u2 = XO.uniforms(3 * n, 0, 424242, (1 << 63) | k)
+        g = (np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586476925 * u2)).reshape(n, 3)
+        ref = z * ref + np.sqrt(kT * (1.0 - z * z) / mass[:, None]) * g
+    assert np.abs(v.cpu().numpy() - ref).max() < 1e-13
+    ctx.close()

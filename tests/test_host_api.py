@@ -304,9 +304,18 @@ def test_engine_memory_program_and_unsupported_steps(spcfw, recorder):
     ctx2 = openmm.Context(respa, integ2)
     ctx2.setPositions(spcfw['positions'])
     integ2.step(1)
-    assert ctx2._engine._interpreted is True
-    exprs = [c for c in recorder[-1].calls if c[0] == 'expr_eval']
-    assert len(exprs) == 2 and all(c[5] and not c[6] for c in exprs)        # two per-DOF assignments, no sums
+    assert ctx2._engine._interpreted is False       # static control flow: unrolled, the odd assignment as an EXPR op
+    ops2 = recorder[-1].runs[0][0]
+    assert sum(1 for o in ops2 if o[0] == B.OP_EXPR) == 2 and len(recorder[-1].exprs) == 1
+    # a ComputeSum (mvv) makes the globals data dependent: general, host-walked path
+    nh = atomsmm.NoseHooverPropagator(300 * unit.kelvin, 4605, 10 * unit.femtoseconds)
+    integ3 = atomsmm.GlobalThermostatIntegrator(1 * unit.femtoseconds, atomsmm.UnconstrainedVelocityVerletPropagator(), nh)
+    ctx3 = openmm.Context(respa, integ3)
+    ctx3.setPositions(spcfw['positions'])
+    integ3.step(1)
+    assert ctx3._engine._interpreted is True
+    sums = [c for c in recorder[-1].calls if c[0] == 'expr_eval' and c[6]]
+    assert len(sums) == 2                             # mvv before each half thermostat step
 
 
 def test_engine_rejects_what_it_cannot_run(spcfw, recorder):
