@@ -20,6 +20,7 @@ from .forces import NonbondedExceptionsForce  # noqa: F401
 from .integrators import GlobalThermostatIntegrator  # noqa: F401
 from .integrators import MultipleTimeScaleIntegrator  # noqa: F401
 from .integrators import Langevin_R_Integrator, NHL_R_Integrator  # noqa: F401
+from .integrators import AdiabaticDynamicsIntegrator, ExtendedSystemVariable  # noqa: F401
 from .propagators import ChainedPropagator  # noqa: F401
 from .propagators import MultipleTimeScalePropagator  # noqa: F401
 from .propagators import RespaPropagator  # noqa: F401
@@ -43,7 +44,8 @@ from . import forces, integrators, propagators, systems, utils  # noqa: F401
 
 __forces__ = ['DampedSmoothedForce', 'NonbondedExceptionsForce', 'NearExceptionForce', 'NearNonbondedForce',
               'FarNonbondedForce']
-__integrators__ = ['GlobalThermostatIntegrator', 'MultipleTimeScaleIntegrator', 'Langevin_R_Integrator', 'NHL_R_Integrator']
+__integrators__ = ['GlobalThermostatIntegrator', 'MultipleTimeScaleIntegrator', 'Langevin_R_Integrator', 'NHL_R_Integrator',
+                   'AdiabaticDynamicsIntegrator', 'ExtendedSystemVariable']
 __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPropagator', 'SplitPropagator',
                    'SuzukiYoshidaPropagator', 'TranslationPropagator', 'TrotterSuzukiPropagator',
                    'VelocityBoostPropagator', 'VelocityVerletPropagator', 'UnconstrainedVelocityVerletPropagator',

@@ -28,7 +28,7 @@ EXPORTS = [
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
-    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define',
+    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_pair_energy_derivative',
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
         L.amm_pair_set_lambda.argtypes = [vp, C.c_int32, C.c_double]
         L.amm_expr_define.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, ip]
         L.amm_expr_seed.argtypes = [vp, C.c_uint64]
+        L.amm_pair_energy_derivative.argtypes = [vp, C.c_int32, vp, vp]
         L.amm_bath_define.argtypes = [vp, C.c_double, C.c_double, ip]
         L.amm_expr_eval.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp]
         for name in EXPORTS:
@@ -193,6 +194,9 @@ class HipContext:
     def pair_set_params(self, fid, q, sigma, eps):
         q_, qp = _hd(q); s_, sp = _hd(sigma); e_, ep = _hd(eps)
         _chk(lib().amm_pair_set_params(self.h, fid, qp, sp, ep))
+
+    def pair_energy_derivative(self, fid, pos, out):
+        _chk(lib().amm_pair_energy_derivative(self.h, fid, _ptr(pos), _ptr(out)))
 
     def pair_set_lambda(self, fid, value):
         _chk(lib().amm_pair_set_lambda(self.h, fid, float(value)))

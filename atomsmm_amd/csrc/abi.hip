@@ -86,6 +86,7 @@ int amm_destroy(amm_ctx *ctx) {
     }
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_expr_part) (void)hipFree(ctx->d_expr_part);
+    if (ctx->d_fscratch) (void)hipFree(ctx->d_fscratch);
     if (ctx->alt_x) (void)hipFree(ctx->alt_x);
     if (ctx->alt_v) (void)hipFree(ctx->alt_v);
     if (ctx->alt_f) (void)hipFree(ctx->alt_f);
@@ -237,6 +238,21 @@ int amm_pair_set_lambda(amm_ctx *ctx, int32_t force_id, double value) {
     }
     pf->desc.alpha = value;
     return amm_pair_build_consts(pf->desc, pf->pc);
+}
+
+int amm_pair_energy_derivative(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_out) {
+    PairForce *pf = get_pair(ctx, force_id);
+    if (!pf || !d_pos || !d_out) return 1;
+    if (pf->desc.family != AMM_SOFTCORE) {
+        amm_set_error("amm_pair_energy_derivative: only the softcore family depends on a global parameter");
+        return 1;
+    }
+    if (!ctx->d_fscratch) AMM_HIP(hipMalloc(&ctx->d_fscratch, sizeof(double) * 3 * (size_t)ctx->n));
+    ctx->pos_epoch++;
+    pf->pc.flags |= AMM_DERIV_LAMBDA;
+    const int rc = amm_pair_eval_impl(ctx, pf, d_pos, ctx->d_fscratch, 0, d_out);
+    pf->pc.flags &= ~AMM_DERIV_LAMBDA;
+    return rc;
 }
 
 int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id) {

@@ -9,6 +9,7 @@
 #include "../../include/atomsmm_hip.h"
 
 #define AMM_WAVE 64
+#define AMM_DERIV_LAMBDA 1024   // internal PairConsts flag: energy output = dE/dlambda (softcore family)
 #define AMM_MAX_GROUPS 33   // 0..31 = OpenMM force groups, 32 = all forces (`f`)
 
 void amm_set_error(const std::string &msg);
@@ -155,6 +156,7 @@ struct amm_ctx {
     int profile_only = -1;         // >= 0: time only this force id (each timed launch costs two event packets)
     double *d_scratch = nullptr;   // small scratch (reductions)
     double *d_expr_part = nullptr; // block partial sums of amm_expr_eval
+    double *d_fscratch = nullptr;  // [n][3] force sink of amm_pair_energy_derivative
     std::vector<ExprDef> exprs;    // registered per-DOF expressions (AMM_OP_EXPR)
     std::vector<BathDef> baths;    // registered Ornstein-Uhlenbeck baths (AMM_OP_BATH)
     unsigned long long expr_seed = 0, expr_counter = 0;

@@ -160,7 +160,12 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
             dSdr = amm_sw_dS(t) * c.inv_sw_dr;
         }
         fr = member ? S * mdV_r - dSdr * V * rinv : 0.0;
-        if (EN) e = member ? S * V : 0.0;
+        if (EN) {
+            // AMM_DERIV_LAMBDA: the "energy" output is dE/dlambda of the pair (deriv(energy, lambda), integrators.py:735):
+            //   d/dlambda [4 lambda eps (1-x)/x^2] = 4 eps [(1-x)/x^2 - lambda (x-2)/(2 x^3)],  dx/dlambda = -1/2
+            const double dVdl = eps4 * ((1.0 - x) * ix2 - 0.5 * c.alpha * (x - 2.0) * ix2 * ix);
+            e = member ? S * ((c.flags & AMM_DERIV_LAMBDA) ? dVdl : V) : 0.0;
+        }
     } else {   // AMM_NONBONDED
         double S = 1.0, dSdr = 0.0;
         if ((c.flags & AMM_SWITCH) && r > c.rswitch) {

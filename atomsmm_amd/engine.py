@@ -120,6 +120,8 @@ class _Entry:
         self.recip_group = None
         self.recip = None
         self.update = None          # callable(parameters) refreshing lambda-dependent parameters
+        self.softcore = None        # softcore pair force: dict(pid, lambda_name, constant, depends)
+        self.depends = set()        # global parameters this entry's backend data depend on
 
 
 class Engine:
@@ -363,6 +365,7 @@ class Engine:
                 entry.constant = constant(parameters)
                 return True
             entry.update = update
+            entry.depends = set(lam)
 
     def _descriptor_of(self, force):
         desc = getattr(force, '_amm', None)
@@ -429,6 +432,7 @@ class Engine:
                 self.ctx.pair_set_params(pid, p[:, 0], p[:, 1], p[:, 2])
                 return True
             entry.update = update
+            entry.depends = set(lam)
 
     def _translate_softcore(self, force, entry, d):
         """SolvationSystem's softcore CustomNonbondedForce (systems.py:266-272): one interaction group solute x
@@ -466,16 +470,19 @@ class Engine:
 
         entry.constant = constant(self.parameters)
         lam = set(names) | {lam_name}
+        entry.softcore = dict(pid=pid, lambda_name=lam_name, constant=constant, depends=lam)
 
         def update(parameters, changed):
             if not (lam & changed):
                 return False
-            p = self._effective(base, scales, names, parameters)
-            self.ctx.pair_set_params(pid, codes, p[:, 1], p[:, 2])
+            if set(names) & changed:
+                p = self._effective(base, scales, names, parameters)
+                self.ctx.pair_set_params(pid, codes, p[:, 1], p[:, 2])
             self.ctx.pair_set_lambda(pid, parameters[lam_name])
             entry.constant = constant(parameters)
-            return True
+            return 'values'            # no bond-list terms changed: group definitions stay
         entry.update = update
+        entry.depends = set(lam)
 
     def _translate_custom_bond(self, force, entry):
         if force.getEnergyFunction().replace(' ', '') == '0.5*(K0*(r-r0)^2-Kn*(r-rn)^2)':
@@ -516,6 +523,7 @@ class Engine:
                 entry.bonded_id = self._make_bonded(entry.terms, sliced=False)
                 return True
             entry.update = update
+            entry.depends = set(lam)
 
     # ------------------------------------------------------------------------------- state
     def _invalidate_forces(self):
@@ -538,10 +546,13 @@ class Engine:
         changed = {name}
         dirty = False
         for entry in self.entries:
-            if entry.update is not None and entry.update(self.parameters, changed):
-                dirty = True
+            if entry.update is not None:
+                result = entry.update(self.parameters, changed)
+                if result:
+                    dirty = True
+                    if result != 'values':
+                        self._group_defs.clear()       # bond-list terms were rebuilt
         if dirty:
-            self._group_defs.clear()
             self._programs.clear()
             self._invalidate_forces()
 
@@ -936,6 +947,35 @@ class Engine:
     def _program_key(valid, mirror):
         return (tuple(sorted((str(g), ok) for g, ok in valid.items())), tuple(sorted(mirror.items())))
 
+    def _deriv(self, what, name):
+        if what != 'energy':
+            raise NotImplementedError('deriv(%s, ...): only deriv(energy, parameter) is supported' % what)
+        return self.energy_derivative(name)
+
+    def energy_derivative(self, name):
+        """deriv(energy, name): d(total potential energy)/d(global parameter) at the current positions
+        (ExtendedSystemVariable.update_velocity, integrators.py:735-737).  Supported for the lambda of softcore pair
+        forces (pair kernel in derivative mode + the long-range correction's derivative)."""
+        if name not in self.parameters:
+            raise mm.OpenMMException('deriv(energy, %s): no such Context parameter' % name)
+        torch = self.torch
+        total = 0.0
+        for entry in self.entries:
+            sc = entry.softcore
+            if sc is not None and sc['lambda_name'] == name:
+                out = torch.zeros(1, dtype=torch.float64, device=self.x.device)
+                self.ctx.pair_energy_derivative(sc['pid'], self.x, out)
+                if self.world > 1:
+                    self._allreduce(out)
+                h = 1e-6
+                up, dn = dict(self.parameters), dict(self.parameters)
+                up[name] += h
+                dn[name] -= h
+                total += out.item() + (sc['constant'](up) - sc['constant'](dn)) / (2 * h)
+            elif name in getattr(entry, 'depends', ()):
+                raise NotImplementedError('deriv(energy, %s): only softcore pair forces provide parameter derivatives' % name)
+        return total
+
     # ------------------------------------------------------------------------------- general step programs
     def _step_interpreted(self, n):
         """Programs with data-dependent globals (ComputeSum results, random numbers) or per-DOF expressions beyond kick /
@@ -963,6 +1003,7 @@ class Engine:
             env.update(self.parameters)
             env.update(zip(integ._gnames, integ._gvalues))
             env['dt'] = integ._dt
+            env['__deriv__'] = lambda what, name: self._deriv(what, name)
             valid = self._valid
             self._mirror_work = self._mirror
             ops = []
@@ -989,9 +1030,14 @@ class Engine:
                     raise RuntimeError('step program does not terminate')
                 kind, target, expr = steps[pc]
                 if kind == C.ComputeGlobal:
+                    if 'deriv(' in expr:
+                        flush()                                   # the derivative is taken at the current positions
                     value = X.eval_global(expr, env, self._host_rng)
-                    if target in self.parameters and target not in integ._gnames and value != self.parameters[target]:
-                        raise NotImplementedError('step programs that change Context parameters (%s) are not supported' % target)
+                    if target in self.parameters and target not in integ._gnames:
+                        if value != self.parameters[target]:
+                            flush()
+                            self.set_parameter(target, value)     # an extended-system variable (AFED): forces change
+                            valid = self._valid
                     env[target] = value
                 elif kind in (C.ComputePerDof, C.ComputeSum):
                     done = False

@@ -185,6 +185,12 @@ def eval_global(text, env, rng=None):
                 return a / b
             if isinstance(node.op, ast.Pow):
                 return a ** b
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == 'deriv' and len(node.args) == 2 \
+                and all(isinstance(a, ast.Name) for a in node.args):
+            # deriv(energy, parameter): supplied by the engine (force kernels), integrators.py:735
+            if '__deriv__' not in env:
+                raise ExpressionError('deriv() is not available in this context')
+            return float(env['__deriv__'](node.args[0].id, node.args[1].id))
         if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id in _HOST_FUNCS and not node.keywords:
             return float(_HOST_FUNCS[node.func.id](*[ev(a) for a in node.args]))
         raise ExpressionError('unsupported syntax in expression: ' + ast.dump(node))

@@ -186,3 +186,148 @@ class NHL_R_Integrator(MultipleTimeScaleIntegrator):
         for i in range(len(v2)):
             v2[i] = S * self._normalVec()
         self.setPerDofVariableByName('v2', v2)
+
+
+class ExtendedSystemVariable(object):
+    """An extended-space variable of Adiabatic Free Energy Dynamics (integrators.py:642-744): a global Context
+    parameter `name` (e.g. `lambda_vdw`) with mass, its own temperature kT and a Nose-Hoover or Langevin thermostat, moving
+    between `lower_limit` and `upper_limit` (elastic walls, or periodic)."""
+
+    def __init__(self, name, mass, kT, time_scale, lower_limit=0, upper_limit=1, periodic=False,
+                 thermostat='Nose-Hoover', friction_constant=None):
+        from . import unit
+        self._m_value = mass
+        self._kT_value = kT
+        self._Q_eta_value = kT * time_scale ** 2
+        self._lower_limit, self._upper_limit, self._periodic = lower_limit, upper_limit, periodic
+        self._gamma_value = 0.1 / unit.femtoseconds if friction_constant is None else friction_constant
+        self._thermostat = thermostat
+        self._x = name
+        self._v, self._m, self._kT = '_v_' + name, '_m_' + name, '_kT_' + name
+        self._kTbym, self._v_eta, self._Q_eta, self._gamma = '_kTbym_' + name, '_v_eta_' + name, '_Q_eta_' + name, '_gamma_' + name
+
+    def add_global_variables(self, integrator):
+        integrator.addGlobalVariable(self._v, 0.0)
+        integrator.addGlobalVariable(self._m, self._m_value)
+        if self._thermostat == 'Nose-Hoover':
+            integrator.addGlobalVariable(self._v_eta, 0.0)
+            integrator.addGlobalVariable(self._kT, self._kT_value)
+            integrator.addGlobalVariable(self._Q_eta, self._Q_eta_value)
+        elif self._thermostat == 'Langevin':
+            integrator.addGlobalVariable(self._kTbym, self._kT_value / self._m_value)
+            integrator.addGlobalVariable(self._gamma, self._gamma_value)
+
+    def _apply_boundary_conditions(self, integrator):
+        above_lower = 'step({}-({}))'.format(self._x, self._lower_limit)
+        below_upper = 'step({}-{})'.format(self._upper_limit, self._x)
+        integrator.beginIfBlock('{}*{} = 0'.format(above_lower, below_upper))
+        if self._periodic:
+            L = self._upper_limit - self._lower_limit
+            integrator.addComputeGlobal(self._x, '{} + select({},{},{})'.format(self._x, above_lower, -L, L))
+        else:
+            integrator.addComputeGlobal(self._x, 'select({},{},{})-{}'.format(above_lower, 2 * self._upper_limit,
+                                                                              2 * self._lower_limit, self._x))
+            integrator.addComputeGlobal(self._v, '-{}'.format(self._v))
+        integrator.endBlock()
+
+    def add_integration_steps(self, integrator):
+        move = '{} + 0.5*dt*{}'.format(self._x, self._v)
+        integrator.addComputeGlobal(self._x, move)
+        self._apply_boundary_conditions(integrator)
+        if self._thermostat == 'Nose-Hoover':
+            kick = '{0} + 0.5*dt*({1}*{2}^2-{3})/{4}'.format(self._v_eta, self._m, self._v, self._kT, self._Q_eta)
+            integrator.addComputeGlobal(self._v_eta, kick)
+            integrator.addComputeGlobal(self._v, '{}*exp(-dt*{})'.format(self._v, self._v_eta))
+            integrator.addComputeGlobal(self._v_eta, kick)
+        elif self._thermostat == 'Langevin':
+            integrator.addComputeGlobal(self._v, 'z*{}+sqrt((1-z*z)*{})*gaussian; z=exp(-dt*{})'.format(self._v, self._kTbym,
+                                                                                                          self._gamma))
+        integrator.addComputeGlobal(self._x, move)
+        self._apply_boundary_conditions(integrator)
+
+    def update_velocity(self, integrator, divisor):
+        integrator.addComputeGlobal(self._v, '{} - 0.5*(dt/{})*deriv(energy,{})/{}'.format(self._v, divisor, self._x, self._m))
+
+    def initialize(self, integrator):
+        from .unit import md_value
+        sigma_v = math.sqrt(md_value(self._kT_value) / md_value(self._m_value))
+        integrator.setGlobalVariableByName(self._v, sigma_v * integrator._random.normal())
+        if self._thermostat == 'Nose-Hoover':
+            sigma_v_eta = math.sqrt(md_value(self._kT_value) / md_value(self._Q_eta_value))
+            integrator.setGlobalVariableByName(self._v_eta, sigma_v_eta * integrator._random.normal())
+
+
+class AdiabaticDynamicsIntegrator(_AtomsMM_Integrator):
+    """Adiabatic Free Energy Dynamics (integrators.py:747-860): over one step of size 2 n dt,
+    [kick lambda ; atoms over dt ; kick lambda]^n ; lambda move + bath ; [...]^n, where "atoms over dt" is the program of
+    `custom_integrator` with dt rewritten to dt/(2n) and the kicks use deriv(energy, lambda)."""
+
+    def __init__(self, custom_integrator, nsteps, variables):
+        super().__init__(2 * nsteps * custom_integrator.getStepSize())
+        self._variables = variables
+        if nsteps > 1:
+            self._counter = '_nsteps_counter'
+            self.addGlobalVariable(self._counter, 0)
+        for variable in self._variables:
+            variable.add_global_variables(self)
+        self._import_variables_and_initializer(custom_integrator)
+        self.addUpdateContextState()
+        self._add_physical_steps(custom_integrator, nsteps)
+        for variable in self._variables:
+            variable.add_integration_steps(self)
+        self._add_physical_steps(custom_integrator, nsteps)
+
+    def _add_physical_steps(self, integrator, nsteps):
+        if nsteps > 1:
+            self.addComputeGlobal(self._counter, '0')
+            self.beginWhileBlock('{} < {}'.format(self._counter, nsteps))
+        for variable in self._variables:
+            variable.update_velocity(self, 2 * nsteps)
+        self._import_computations(integrator, nsteps)
+        for variable in self._variables:
+            variable.update_velocity(self, 2 * nsteps)
+        if nsteps > 1:
+            self.addComputeGlobal(self._counter, '{} + 1'.format(self._counter))
+            self.endBlock()
+
+    def _import_computations(self, integrator, nsteps):
+        C = openmm.CustomIntegrator
+        for index in range(integrator.getNumComputations()):
+            computation, variable, expression = integrator.getComputationStep(index)
+            expression = re.sub(r'\bdt\b', '(dt/{})'.format(2 * nsteps), expression)
+            if computation == C.ComputeGlobal:
+                self.addComputeGlobal(variable, expression)
+            elif computation == C.ComputePerDof:
+                self.addComputePerDof(variable, expression)
+            elif computation == C.ComputeSum:
+                self.addComputeSum(variable, expression)
+            elif computation == C.ConstrainPositions:
+                self.addConstrainPositions()
+            elif computation == C.ConstrainVelocities:
+                self.addConstrainVelocities()
+            elif computation == C.UpdateContextState:
+                self.addUpdateContextState()
+            elif computation == C.IfBlock:
+                self.beginIfBlock(expression)
+            elif computation == C.WhileBlock:
+                self.beginWhileBlock(expression)
+            elif computation == C.EndBlock:
+                self.endBlock()
+
+    def _import_variables_and_initializer(self, integrator):
+        for index in range(integrator.getNumGlobalVariables()):
+            name = integrator.getGlobalVariableName(index)
+            if name not in ('mvv', 'NDOF'):
+                self.addGlobalVariable(name, integrator.getGlobalVariable(index))
+        self._imported_per_dof = {}
+        for index in range(integrator.getNumPerDofVariables()):
+            name = integrator.getPerDofVariableName(index)
+            if name != 'ndof':
+                self.addPerDofVariable(name, 0)
+        self._inner_initialize = getattr(type(integrator), 'initialize', None)
+
+    def initialize(self):
+        if self._inner_initialize is not None:
+            self._inner_initialize(self)
+        for variable in self._variables:
+            variable.initialize(self)

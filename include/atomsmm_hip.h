@@ -128,6 +128,9 @@ int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id);
 /* CustomBondForce / HarmonicBondForce / HarmonicAngleForce term lists of one force group. */
 /* context.setParameter('lambda_vdw', value) for a softcore pair force (systems.py:267: global parameter). */
 int amm_pair_set_lambda(amm_ctx *ctx, int32_t force_id, double value);
+/* deriv(energy, lambda) of a softcore pair force (addEnergyParameterDerivative, systems.py:712-718; used by the AFED
+ * kicks, integrators.py:735-737): *d_out (device) += sum over pairs of dE/dlambda at d_pos. */
+int amm_pair_energy_derivative(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_out);
 
 int amm_bonded_create(amm_ctx *ctx, int32_t *force_id);
 int amm_bonded_add_terms(amm_ctx *ctx, int32_t force_id, int32_t kind, const int32_t *h_idx,

@@ -31,6 +31,9 @@ class RecordingContext:
     def pair_set_params(self, fid, q, sigma, eps):
         self.calls.append(('pair_set_params', fid, q.copy(), sigma.copy(), eps.copy()))
 
+    def pair_energy_derivative(self, fid, pos, out):
+        self.calls.append(('pair_energy_derivative', fid))
+
     def pair_set_lambda(self, fid, value):
         self.calls.append(('pair_set_lambda', fid, value))
 

@@ -286,3 +286,63 @@ def test_native_ou_bath_vs_numpy():
         ref = z * ref + np.sqrt(kT * (1.0 - z * z) / mass[:, None]) * g
     assert np.abs(v.cpu().numpy() - ref).max() < 1e-13
     ctx.close()
+
+
+def _solvated(heaq):
+    system = system_from_arrays(heaq, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
+    solute = set(int(i) for i in np.where(heaq['resname'] == 'aaa')[0])
+    return atomsmm.SolvationSystem(system, solute)
+
+
+def test_energy_parameter_derivative_of_softcore_force(heaq):
+    """deriv(energy, lambda_vdw) (ExtendedSystemVariable.update_velocity, integrators.py:735-737): the pair kernel in
+    derivative mode + the derivative of the long-range correction == central differences of the energy, and == the
+    oracle's finite difference of the pinned softcore energy (G15 family)."""
+    h = heaq
+    solv = _solvated(h)
+    context = openmm.Context(solv, openmm.VerletIntegrator(0.0))
+    context.setPositions(h['positions'] * unit.nanometers)
+    codes = np.where(h['resname'] == 'aaa', 1.0, 2.0)
+    for lam in (0.5, 0.9, 0.15):
+        context.setParameter('lambda_vdw', lam)
+        d = context._engine.energy_derivative('lambda_vdw')
+        eps_ = 1e-5
+        e = []
+        for sgn in (1, -1):
+            context.setParameter('lambda_vdw', lam + sgn * eps_)
+            e.append(context.getState(getEnergy=True).getPotentialEnergy()._value)
+        assert d == pytest.approx((e[0] - e[1]) / (2 * eps_), rel=2e-6)
+        ref = []
+        for sgn in (1, -1):
+            dd = O.desc(O.SOFTCORE, rc=1.0, rswitch=0.9, alpha=lam + sgn * eps_, flags=O.SWITCH, Kc=1.0)
+            ref.append(O.pair_eval(dd, h['positions'], h['box'], codes, h['sigma'], h['epsilon'], h['exc_pairs'], want_forces=False)[0] +
+                       O.softcore_lrc(h['sigma'], h['epsilon'], codes, h['box'], 1.0, 0.9, lam + sgn * eps_))
+        assert d == pytest.approx((ref[0] - ref[1]) / (2 * eps_), rel=2e-6)
+    with pytest.raises(NotImplementedError):
+        context._engine.energy_derivative('lambda_coul')       # charge offsets: no derivative kernels
+
+
+def test_adiabatic_free_energy_dynamics_runs(heaq):
+    """AFED (config 5 of BASELINE.json in miniature): RESPASystem over a SolvationSystem, RESPA [2,2,1] inside
+    AdiabaticDynamicsIntegrator with lambda_vdw as extended variable.  lambda moves, stays inside its walls, the
+    Context parameter follows it, and the dynamics stays finite."""
+    h = heaq
+    respa = atomsmm.RESPASystem(_solvated(h), 7 * unit.angstroms, 5 * unit.angstroms)
+    inner = atomsmm.RespaPropagator([2, 2, 1]).integrator(1 * unit.femtoseconds)
+    lam = atomsmm.ExtendedSystemVariable('lambda_vdw', 50, 2.5, 20 * unit.femtoseconds)
+    integrator = atomsmm.AdiabaticDynamicsIntegrator(inner, 2, [lam])
+    integrator.setRandomNumberSeed(11)
+    context = openmm.Context(respa, integrator)
+    context.setPositions(h['positions'] * unit.nanometers)
+    context.setVelocitiesToTemperature(300 * unit.kelvin, 2)
+    context.setParameter('lambda_vdw', 0.8)
+    context.setParameter('lambda_coul', 0.0)
+    seen = []
+    for _ in range(10):
+        integrator.step(3)
+        seen.append(context.getParameter('lambda_vdw'))
+    assert context._engine._interpreted is True
+    assert all(0.0 <= v <= 1.0 for v in seen) and max(seen) - min(seen) > 1e-3, seen
+    st = context.getState(getEnergy=True)
+    assert np.isfinite(st.getPotentialEnergy()._value) and np.isfinite(st.getKineticEnergy()._value)
+    assert integrator.getGlobalVariableByName('_v_lambda_vdw') != 0.0

@@ -461,3 +461,23 @@ def test_redefine_bond_and_angle(spcfw, recorder):
     assert kinds.count(B.BOND_HARMONIC) == 3 and kinds.count(B.ANGLE_HARMONIC) == 3      # original + (K0, -Kn) pair each
     with pytest.raises(ValueError):
         respa.redefine_bond(app.Topology(1536), 'HOH', 'H[1-2]', 'O', 1.05 * unit.angstroms)
+
+
+def test_afed_program_matches_reference_capture(goldens):
+    """AdiabaticDynamicsIntegrator over RespaPropagator([2,1]) with one ExtendedSystemVariable (integrators.py:642-860):
+    the 44-step program captured from the reference."""
+    inner = atomsmm.RespaPropagator([2, 1]).integrator(1 * unit.femtoseconds)
+    lam = atomsmm.ExtendedSystemVariable('lambda_vdw', 1000, 5, 40 * unit.femtoseconds)
+    integ = atomsmm.AdiabaticDynamicsIntegrator(inner, 2, [lam])
+    g = goldens['programs']['afed_respa_2_1_nsteps_2']
+    assert integ.pretty_steps() == g['steps']
+    names = [integ.getGlobalVariableName(i) for i in range(integ.getNumGlobalVariables())]
+    assert names == ['mvv', 'NDOF'] + g['globals']
+    assert integ.getStepSize() == 4 * unit.femtoseconds
+    assert integ.getGlobalVariableByName('_Q_eta_lambda_vdw') == pytest.approx(5 * 0.04 ** 2)
+    # Langevin bath on lambda and periodic boundaries: the other two branches of integrators.py:701-733
+    lam2 = atomsmm.ExtendedSystemVariable('lambda_vdw', 1000, 5, 40 * unit.femtoseconds, periodic=True, thermostat='Langevin')
+    text = '\n'.join(atomsmm.AdiabaticDynamicsIntegrator(inner, 1, [lam2]).pretty_steps())
+    assert 'lambda_vdw <- lambda_vdw + select(step(lambda_vdw-(0)),-1,1)' in text
+    assert '_v_lambda_vdw <- z*_v_lambda_vdw+sqrt((1-z*z)*_kTbym_lambda_vdw)*gaussian; z=exp(-dt*_gamma_lambda_vdw)' in text
+    assert '_nsteps_counter' not in text
