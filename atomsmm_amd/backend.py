@@ -15,6 +15,7 @@ NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE = range(6)
 GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH = 1, 2, 4, 8
 BOND_HARMONIC, ANGLE_HARMONIC, BOND_LJC, BOND_NEAR, TORSION_PERIODIC, BOND_EWALD_EXCL = range(6)
 OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE, OP_EXPR, OP_BATH = 1, 2, 3, 4, 5, 6, 7
+OP_SAVE_REF, OP_CONSTRAIN_X, OP_CONSTRAIN_V = 8, 9, 10
 MAX_SLOTS, SLOT_X, SLOT_V = 64, 62, 63
 GROUP_ALL = 32   # pseudo-group of the force symbol `f` (all groups)
 KC = 138.935456   # forces.py:407
@@ -28,7 +29,7 @@ EXPORTS = [
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
-    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_pair_energy_derivative',
+    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_pair_energy_derivative', 'amm_constraints_create',
 ]
 
 
@@ -108,6 +109,7 @@ def lib():
         L.amm_pair_set_lambda.argtypes = [vp, C.c_int32, C.c_double]
         L.amm_expr_define.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, ip]
         L.amm_expr_seed.argtypes = [vp, C.c_uint64]
+        L.amm_constraints_create.argtypes = [vp, ip, dp, C.c_int32, C.c_double]
         L.amm_pair_energy_derivative.argtypes = [vp, C.c_int32, vp, vp]
         L.amm_bath_define.argtypes = [vp, C.c_double, C.c_double, ip]
         L.amm_expr_eval.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp]
@@ -239,6 +241,12 @@ class HipContext:
         eid = C.c_int32(-1)
         _chk(lib().amm_expr_define(self.h, cp, len(c_), kp, len(consts), gp, len(globals_), C.byref(eid)))
         return eid.value
+
+    def constraints_create(self, pairs, distances, tolerance=1e-5):
+        p_, pp = _hi(np.asarray(pairs).reshape(-1, 2))
+        d_, dp_ = _hd(distances)
+        assert len(p_) == len(d_)
+        _chk(lib().amm_constraints_create(self.h, pp, dp_, len(d_), float(tolerance)))
 
     def bath_define(self, z, kT):
         bid = C.c_int32(-1)

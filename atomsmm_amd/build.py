@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['abi.hip', 'pair.hip', 'bonded.hip', 'integrate.hip', 'pme.hip', 'expr.hip']
+SOURCES = ['abi.hip', 'pair.hip', 'bonded.hip', 'integrate.hip', 'pme.hip', 'expr.hip', 'constraints.hip']
 HEADERS = ['amm_ctx.h', 'pair_math.h', 'erfcx_table.h', 'device_utils.h', 'expr_vm.h', os.path.join('..', '..', 'include', 'atomsmm_hip.h')]
 LIB = os.path.join(HERE, 'libatomsmm_hip.so')
 ARCH = 'gfx950'

@@ -87,6 +87,7 @@ int amm_destroy(amm_ctx *ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_expr_part) (void)hipFree(ctx->d_expr_part);
     if (ctx->d_fscratch) (void)hipFree(ctx->d_fscratch);
+    if (ctx->constraints) amm_constraints_free(ctx->constraints);
     if (ctx->alt_x) (void)hipFree(ctx->alt_x);
     if (ctx->alt_v) (void)hipFree(ctx->alt_v);
     if (ctx->alt_f) (void)hipFree(ctx->alt_f);
@@ -121,6 +122,10 @@ int amm_synchronize(amm_ctx *ctx) {
 
 int amm_check(amm_ctx *ctx) {
     AMM_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->constraints && amm_constraints_failed(ctx, ctx->constraints)) {
+        amm_set_error("constraint solver did not converge (SHAKE / RATTLE, 500 iterations): time step too large or bad geometry");
+        return 2;
+    }
     for (size_t id = 0; id < ctx->forces.size(); ++id) {
         PairForce *pf = ctx->forces[id].pair;
         if (!pf || !pf->built) continue;
@@ -481,6 +486,19 @@ int amm_expr_eval(amm_ctx *ctx, const int32_t *code, int32_t n_code, const doubl
     return amm_expr_eval_impl(ctx, code, n_code, consts, n_consts, globals, n_globals, seed, counter, d_dst, d_sum);
 }
 
+int amm_constraints_create(amm_ctx *ctx, const int32_t *h_pairs, const double *h_dist, int32_t n_constraints, double tolerance) {
+    if (!ctx || (n_constraints > 0 && (!h_pairs || !h_dist)) || n_constraints < 0) {
+        amm_set_error("amm_constraints_create: bad arguments");
+        return 1;
+    }
+    if (ctx->constraints) {
+        amm_constraints_free(ctx->constraints);
+        ctx->constraints = nullptr;
+    }
+    AMM_HIP(hipSetDevice(ctx->device));
+    return amm_constraints_create_impl(ctx, h_pairs, h_dist, n_constraints, tolerance, &ctx->constraints);
+}
+
 int amm_expr_define(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
                     const double *globals, int32_t n_globals, int32_t *expr_id) {
     if (!ctx || !code || n_code < 1 || !expr_id || (n_consts > 0 && !consts) || (n_globals > 0 && !globals)) {
@@ -725,6 +743,17 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 const unsigned long long counter = (1ull << 63) | ++ctx->expr_counter;
                 if (amm_expr_eval_impl(ctx, e.code.data(), (int)e.code.size(), e.consts.data(), (int)e.consts.size(),
                                        e.globals.data(), (int)e.globals.size(), ctx->expr_seed, counter, dst, nullptr)) return 1;
+            } break;
+            case AMM_OP_SAVE_REF:
+            case AMM_OP_CONSTRAIN_X:
+            case AMM_OP_CONSTRAIN_V: {
+                if (!ctx->constraints) break;       // no constraints in the System: identity (OpenMM does the same)
+                if (op.op == AMM_OP_SAVE_REF) {
+                    if (amm_constraints_save_reference(ctx, ctx->constraints, ctx->d_x)) return 1;
+                } else if (op.op == AMM_OP_CONSTRAIN_X) {
+                    if (amm_constrain_positions(ctx, ctx->constraints, ctx->d_x)) return 1;
+                    ctx->pos_epoch++;
+                } else if (amm_constrain_velocities(ctx, ctx->constraints, ctx->d_x, ctx->d_v)) return 1;
             } break;
             case AMM_OP_BATH: {
                 if (op.a < 0 || op.a >= (int)ctx->baths.size()) {

@@ -118,6 +118,7 @@ struct BondedSet {
 };
 
 struct PmeForce;      // pme.hip
+struct ConstraintSet; // constraints.hip
 
 struct ForceObj {
     int type = 0;   // 1 pair, 2 bonded, 3 PME reciprocal space
@@ -157,6 +158,7 @@ struct amm_ctx {
     double *d_scratch = nullptr;   // small scratch (reductions)
     double *d_expr_part = nullptr; // block partial sums of amm_expr_eval
     double *d_fscratch = nullptr;  // [n][3] force sink of amm_pair_energy_derivative
+    ConstraintSet *constraints = nullptr;   // distance constraints of the System (AMM_OP_CONSTRAIN_*)
     std::vector<ExprDef> exprs;    // registered per-DOF expressions (AMM_OP_EXPR)
     std::vector<BathDef> baths;    // registered Ornstein-Uhlenbeck baths (AMM_OP_BATH)
     unsigned long long expr_seed = 0, expr_counter = 0;
@@ -183,6 +185,13 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
                               const double *const *pre_b, const double *pre_coef, const int *pre_plus, double c1, double d,
                               double c2, int niter, const BathDef *bath = nullptr, double d2 = 0.0);
 int amm_bath_impl(amm_ctx *ctx, const BathDef &bath, double *d_v, unsigned long long counter);
+int amm_constraints_create_impl(amm_ctx *ctx, const int32_t *h_pairs, const double *h_dist, int n_cons, double tol,
+                                ConstraintSet **out);
+int amm_constraints_save_reference(amm_ctx *ctx, ConstraintSet *cs, const double *d_x);
+int amm_constrain_positions(amm_ctx *ctx, ConstraintSet *cs, double *d_x);
+int amm_constrain_velocities(amm_ctx *ctx, ConstraintSet *cs, const double *d_x, double *d_v);
+int amm_constraints_failed(amm_ctx *ctx, ConstraintSet *cs);
+int amm_constraints_free(ConstraintSet *cs);
 int amm_fused_inner_impl(amm_ctx *ctx, BondedSet *bs, const double *x_in, const double *v_in, const double *f_in,
                          double *x_out, double *v_out, double *f_out, double c1, double d, double c2);
 int amm_pme_create_impl(amm_ctx *ctx, double alpha, const int *K, double Kc, const double *h_q, PmeForce **out);

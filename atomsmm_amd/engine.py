@@ -180,8 +180,11 @@ class Engine:
         self._fwork = torch.zeros((n, 3), dtype=f64, device=dev)
         self._fwork2 = torch.zeros((n, 3), dtype=f64, device=dev)
         self.ctx.bind_state(self.x, self.v, self.mass)
-        if system.getNumConstraints() > 0:
-            raise NotImplementedError('distance constraints are outside this round\'s scope (SURVEY.md 8f-3)')
+        self._has_constraints = system.getNumConstraints() > 0
+        if self._has_constraints:
+            cons = system._constraints
+            self.ctx.constraints_create(np.array([[c[0], c[1]] for c in cons], dtype=np.int32), np.array([c[2] for c in cons]),
+                                        integrator.getConstraintTolerance() if hasattr(integrator, 'getConstraintTolerance') else 1e-5)
         if isinstance(integrator, mm.CustomIntegrator):
             integrator._n_hint = n
 
@@ -670,6 +673,28 @@ class Engine:
         self._group_defs[g] = (index, slot, reduced)
         return self._group_defs[g]
 
+    def _emit_constraint(self, kind, ops, valid):
+        """addConstrainPositions / addConstrainVelocities (propagators.py:250, 272): identity without constraints."""
+        if not self._has_constraints:
+            return
+        if kind == mm.CustomIntegrator.ConstrainPositions:
+            ops.append(B.Op(B.OP_CONSTRAIN_X, 0, 0, 0, 0.0))
+            for g in valid:
+                valid[g] = False
+        else:
+            ops.append(B.Op(B.OP_CONSTRAIN_V, 0, 0, 0, 0.0))
+
+    def apply_constraints(self):
+        if self._has_constraints:
+            self.ctx.run_ops([B.Op(B.OP_SAVE_REF, 0, 0, 0, 0.0), B.Op(B.OP_CONSTRAIN_X, 0, 0, 0, 0.0)], 1)
+            self._invalidate_forces()
+            self.ctx.check()
+
+    def apply_velocity_constraints(self):
+        if self._has_constraints:
+            self.ctx.run_ops([B.Op(B.OP_CONSTRAIN_V, 0, 0, 0, 0.0)], 1)
+            self.ctx.check()
+
     def _eval(self, expr, env):
         return float(eval(expr.replace('^', '**'), {'__builtins__': {}}, env))
 
@@ -693,7 +718,7 @@ class Engine:
         valid = dict(self._valid)
         self._mirror_work = dict(self._mirror)
         self._static_exprs = True
-        ops = []
+        ops = [B.Op(B.OP_SAVE_REF, 0, 0, 0, 0.0)] if self._has_constraints else []
         pc = 0
         guard = 0
         while pc < len(steps):
@@ -711,8 +736,10 @@ class Engine:
                 self._emit_per_dof(target, expr, env, ops, valid)
             elif kind == C.ComputeSum:
                 raise NotImplementedError('ComputeSum steps (thermostat propagators) are outside this round\'s scope')
-            elif kind in (C.ConstrainPositions, C.ConstrainVelocities, C.UpdateContextState):
-                pass    # no constraints in the System (checked at Context creation): identity
+            elif kind in (C.ConstrainPositions, C.ConstrainVelocities):
+                self._emit_constraint(kind, ops, valid)
+            elif kind == C.UpdateContextState:
+                pass
             elif kind in (C.IfBlock, C.WhileBlock):
                 if not self._condition(expr, env):
                     pc = match[pc]
@@ -1006,7 +1033,7 @@ class Engine:
             env['__deriv__'] = lambda what, name: self._deriv(what, name)
             valid = self._valid
             self._mirror_work = self._mirror
-            ops = []
+            ops = [B.Op(B.OP_SAVE_REF, 0, 0, 0, 0.0)] if self._has_constraints else []
 
             def flush():
                 if ops:
@@ -1067,7 +1094,9 @@ class Engine:
                         else:
                             self.ctx.expr_eval(prog.code, prog.consts, gvals, seed, self._expr_counter, total=total)
                             env[target] = total.item()          # device -> host (synchronises)
-                elif kind in (C.ConstrainPositions, C.ConstrainVelocities, C.UpdateContextState):
+                elif kind in (C.ConstrainPositions, C.ConstrainVelocities):
+                    self._emit_constraint(kind, ops, valid)
+                elif kind == C.UpdateContextState:
                     pass
                 elif kind in (C.IfBlock, C.WhileBlock):
                     if not self._condition(expr, env):

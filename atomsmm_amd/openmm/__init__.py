@@ -611,6 +611,12 @@ class Integrator:
         self._context = None
         self._seed = 0
 
+    def getConstraintTolerance(self):
+        return getattr(self, '_ctol', 1e-5)
+
+    def setConstraintTolerance(self, tol):
+        self._ctol = float(tol)
+
     def getStepSize(self):
         return Quantity(self._dt, _unit.picosecond)
 
@@ -849,6 +855,14 @@ class Context:
         v = rng.normal(size=(len(m), 3)) * np.sqrt(kT / np.where(m > 0, m, 1.0))[:, None]
         v[m <= 0] = 0.0
         self._engine.set_velocities(v)
+        self._engine.apply_velocity_constraints()     # as OpenMM does after drawing the velocities
+
+    def applyConstraints(self, tol=None):
+        """Move the positions onto the constraint surface (reference = the current positions)."""
+        self._engine.apply_constraints()
+
+    def applyVelocityConstraints(self, tol=None):
+        self._engine.apply_velocity_constraints()
 
     def setParameter(self, name, value):
         self._engine.set_parameter(name, float(md_value(value)))

@@ -64,27 +64,56 @@ def tip3p_box(nside=32, seed=SEED, density=33.368):
 
 
 def system_from_arrays(c, nonbondedMethod='CutoffPeriodic', cutoff=1.0, switch=None, flexible=True,
-                       ewaldTolerance=5e-4, dispersionCorrection=True):
+                       ewaldTolerance=5e-4, dispersionCorrection=True, constraints=None, rigidWater=False):
     """Build the System `app.ForceField.createSystem(topology, ...)` would produce for a case given as arrays
     (positions, box, charge, sigma, epsilon, mass, bonds/angles/torsions, exception list): the reference's
     tests start from exactly such a System (tests/test_respa_forces.py:14-17, tests/test_systems.py:12-24).
-    flexible=False drops the harmonic bond/angle terms of water (rigidWater=True turns them into
-    constraints, which carry no energy: SURVEY.md Appendix B.8) -- constraints themselves are not modelled."""
+    flexible=False drops the harmonic bond/angle terms altogether (what the static energy tests need: constraints carry
+    no energy).  constraints='HBonds' turns every bond to a hydrogen (mass < 1.5) into a distance
+    constraint and drops its harmonic term; rigidWater=True does the same for the three-site waters (residues whose
+    three atoms are O, H, H bonded O-H twice) and also fixes their H-H distance, dropping the H-O-H angle term -- the
+    combination the reference's dynamic tests use (tests/test_propagators.py:11-18)."""
     from .. import openmm
     system = openmm.System()
     for m in c['mass']:
         system.addParticle(float(m))
     L = c['box']
     system.setDefaultPeriodicBoxVectors((float(L[0]), 0, 0), (0, float(L[1]), 0), (0, 0, float(L[2])))
+    mass = np.asarray(c['mass'])
+    is_h = mass < 1.5
+    constrained_bonds, dropped_angles = set(), set()
+    if rigidWater and 'angles' in c:
+        r0_of = {(int(i), int(j)): float(r0) for (i, j), r0 in zip(c['bonds'], c['bond_r0'])}
+        r0_of.update({(j, i): r for (i, j), r in list(r0_of.items())})
+        for idx, ((i, j, k_), t0) in enumerate(zip(c['angles'], c['angle_theta0'])):
+            i, j, k_ = int(i), int(j), int(k_)
+            if is_h[i] and is_h[k_] and not is_h[j] and (i, j) in r0_of and (k_, j) in r0_of and c['residue'][i] == c['residue'][k_] \
+                    and int(np.sum(c['residue'] == c['residue'][j])) == 3:
+                r1, r2 = r0_of[(i, j)], r0_of[(k_, j)]
+                system.addConstraint(i, j, r1)
+                system.addConstraint(k_, j, r2)
+                system.addConstraint(i, k_, float(np.sqrt(r1 * r1 + r2 * r2 - 2 * r1 * r2 * np.cos(float(t0)))))
+                constrained_bonds.update({(i, j), (j, i), (k_, j), (j, k_)})
+                dropped_angles.add(idx)
+    if constraints == 'HBonds' and 'bonds' in c:
+        for (i, j), r0 in zip(c['bonds'], c['bond_r0']):
+            i, j = int(i), int(j)
+            if (is_h[i] or is_h[j]) and (i, j) not in constrained_bonds:
+                system.addConstraint(i, j, float(r0))
+                constrained_bonds.update({(i, j), (j, i)})
+    elif constraints not in (None, 'HBonds'):
+        raise ValueError("constraints must be None or 'HBonds'")
     if flexible and 'bonds' in c and len(c['bonds']):
         f = openmm.HarmonicBondForce()
         for (i, j), r0, k in zip(c['bonds'], c['bond_r0'], c['bond_k']):
-            f.addBond(int(i), int(j), float(r0), float(k))
+            if (int(i), int(j)) not in constrained_bonds:
+                f.addBond(int(i), int(j), float(r0), float(k))
         system.addForce(f)
     if flexible and 'angles' in c and len(c['angles']):
         f = openmm.HarmonicAngleForce()
-        for (i, j, k_), t0, k in zip(c['angles'], c['angle_theta0'], c['angle_k']):
-            f.addAngle(int(i), int(j), int(k_), float(t0), float(k))
+        for idx, ((i, j, k_), t0, k) in enumerate(zip(c['angles'], c['angle_theta0'], c['angle_k'])):
+            if idx not in dropped_angles:
+                f.addAngle(int(i), int(j), int(k_), float(t0), float(k))
         system.addForce(f)
     if 'torsions' in c and len(c['torsions']):
         f = openmm.PeriodicTorsionForce()

@@ -86,9 +86,13 @@ enum {
     AMM_OP_EXPR = 6,   /* buf[b] <- per-DOF expression a (amm_expr_define): bath steps inside a RESPA loop, e.g. a
                           thermostat update on a per-DOF variable (NHL_R, integrators.py:272-318); each execution draws from the
                           next random-stream counter                                                                  */
-    AMM_OP_BATH = 7    /* v <- z v + sqrt(kT (1 - z^2)/m) gaussian with (z, kT) = bath a (amm_bath_define): the Ornstein-Uhlenbeck
+    AMM_OP_BATH = 7,   /* v <- z v + sqrt(kT (1 - z^2)/m) gaussian with (z, kT) = bath a (amm_bath_define): the Ornstein-Uhlenbeck
                           step of OrnsteinUhlenbeckPropagator on (v, m) without force (propagators.py:727-741), as a native op so
                           that the inner-loop kernel can carry it (Langevin_R 'middle' scheme)                        */
+    AMM_OP_SAVE_REF = 8,    /* reference positions of the constraint solver <- x (start of a step)                   */
+    AMM_OP_CONSTRAIN_X = 9, /* addConstrainPositions (propagators.py:250, 1129): SHAKE along the reference bond vectors,
+                               then reference <- x                                                                    */
+    AMM_OP_CONSTRAIN_V = 10 /* addConstrainVelocities (propagators.py:272, 1131): RATTLE                              */
 };
 typedef struct {
     int32_t op, a, b, c;
@@ -171,6 +175,11 @@ int amm_mvv(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out); 
  * may be one of the bound buffers) receives the per-DOF values, *d_sum (device) their sum; either may be NULL. */
 int amm_expr_eval(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
                   const double *globals, int32_t n_globals, uint64_t seed, uint64_t counter, double *d_dst, double *d_sum);
+
+/* System.addConstraint(i, j, distance) x n (forcefield.createSystem(constraints=HBonds, rigidWater=True) in the
+ * reference's tests, tests/test_propagators.py:11-18).  Clusters of coupled constraints (<= 8 atoms, <= 16 constraints)
+ * are solved by one thread each; tolerance as CustomIntegrator.getConstraintTolerance() (<= 0: 1e-5). */
+int amm_constraints_create(amm_ctx *ctx, const int32_t *h_pairs, const double *h_dist, int32_t n_constraints, double tolerance);
 
 /* Register a per-DOF expression with fixed globals for AMM_OP_EXPR; amm_expr_seed sets the random stream used by the
  * ops (integrator.setRandomNumberSeed, integrators.py:149-151) and restarts its counter. */

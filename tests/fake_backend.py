@@ -65,6 +65,9 @@ class RecordingContext:
         self.exprs.append((list(code), list(consts), list(globals_)))
         return len(self.exprs) - 1
 
+    def constraints_create(self, pairs, distances, tolerance=1e-5):
+        self.constraints = (len(distances), tolerance)
+
     def bath_define(self, z, kT):
         self.baths = getattr(self, 'baths', [])
         self.baths.append((z, kT))

@@ -1,0 +1,147 @@
+"""GPU tests of the constraint solver: SHAKE / RATTLE behind addConstrainPositions /
+addConstrainVelocities (propagators.py:246-252, 272-273, 1126-1133).
+
+Parity status: UNPINNED against the reference (its constrained dynamic tests, tests/test_propagators.py:37-48, need
+OpenMM's random velocities and its own SETTLE/CCMA round-off); checked here: the solver against a numpy restatement of
+the same iteration, constraint satisfaction, and energy conservation of constrained dynamics."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+import atomsmm_amd as atomsmm  # noqa: E402
+from atomsmm_amd import backend as B  # noqa: E402
+from atomsmm_amd import openmm, unit  # noqa: E402
+from atomsmm_amd.testing import system_from_arrays  # noqa: E402
+
+KB = 0.0083144626181532
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device='cuda')
+
+
+def shake_numpy(x, xref, mass, pairs, dist, tol):
+    """Sequential SHAKE over each molecule's constraints, the iteration of csrc/constraints.hip."""
+    x = x.copy()
+    lower, upper = 1 - 2 * tol + tol * tol, 1 + 2 * tol + tol * tol
+    im = 1.0 / mass
+    for _ in range(500):
+        done = True
+        for (i, j), d in zip(pairs, dist):
+            dp, dr = x[i] - x[j], xref[i] - xref[j]
+            pp = dp @ dp
+            if pp < lower * d * d or pp > upper * d * d:
+                done = False
+                g = (d * d - pp) / (2 * (im[i] + im[j]) * (dr @ dp))
+                x[i] += g * im[i] * dr
+                x[j] -= g * im[j] * dr
+        if done:
+            break
+    return x
+
+
+def test_shake_and_rattle_through_the_abi():
+    rng = np.random.default_rng(3)
+    nmol = 400
+    n = 3 * nmol
+    r_oh, r_hh = 0.09572, 0.15139
+    # rigid three-site molecules: O at random places, H's at the right geometry, then perturbed
+    o = rng.uniform(0, 5, (nmol, 3))
+    x0 = np.zeros((n, 3))
+    for k in range(nmol):
+        a = rng.normal(size=3); a /= np.linalg.norm(a)
+        b = np.cross(a, rng.normal(size=3)); b /= np.linalg.norm(b)
+        half = np.arcsin(0.5 * r_hh / r_oh)
+        x0[3 * k] = o[k]
+        x0[3 * k + 1] = o[k] + r_oh * (np.cos(half) * a + np.sin(half) * b)
+        x0[3 * k + 2] = o[k] + r_oh * (np.cos(half) * a - np.sin(half) * b)
+    mass = np.tile([15.9994, 1.008, 1.008], nmol)
+    pairs = np.array([[3 * k, 3 * k + 1] for k in range(nmol)] + [[3 * k, 3 * k + 2] for k in range(nmol)] +
+                     [[3 * k + 1, 3 * k + 2] for k in range(nmol)], dtype=np.int32)
+    dist = np.array([r_oh] * (2 * nmol) + [r_hh] * nmol)
+    moved = x0 + rng.normal(0, 0.004, (n, 3))
+    ctx = B.HipContext(n, np.array([5.0, 5.0, 5.0]))
+    x, v = dev(x0), dev(rng.normal(0, 0.5, (n, 3)))
+    ctx.bind_state(x, v, dev(mass))
+    ctx.constraints_create(pairs, dist, 1e-7)
+    ctx.run_ops([B.Op(B.OP_SAVE_REF, 0, 0, 0, 0.0)], 1)
+    x.copy_(dev(moved))
+    ctx.run_ops([B.Op(B.OP_CONSTRAIN_X, 0, 0, 0, 0.0), B.Op(B.OP_CONSTRAIN_V, 0, 0, 0, 0.0)], 1)
+    ctx.check()
+    got = x.cpu().numpy()
+    d = np.linalg.norm(got[pairs[:, 0]] - got[pairs[:, 1]], axis=1)
+    assert np.abs(d / dist - 1).max() < 2e-7
+    # the same iteration in numpy, molecule by molecule in the kernel's constraint order (O-H1, O-H2, H1-H2)
+    ref = moved.copy()
+    for k in range(nmol):
+        idx = [3 * k, 3 * k + 1, 3 * k + 2]
+        loc = shake_numpy(moved[idx], x0[idx], mass[idx], [(0, 1), (0, 2), (1, 2)], [r_oh, r_oh, r_hh], 1e-7)
+        ref[idx] = loc
+    assert np.abs(got - ref).max() < 1e-12
+    # SHAKE conserves each molecule's centre of mass; RATTLE leaves no velocity along the bonds
+    com = lambda a: (a.reshape(nmol, 3, 3) * mass.reshape(nmol, 3, 1)).sum(1)      # noqa: E731
+    assert np.abs(com(got) - com(moved)).max() < 1e-12
+    w = v.cpu().numpy()
+    rel = ((got[pairs[:, 0]] - got[pairs[:, 1]]) * (w[pairs[:, 0]] - w[pairs[:, 1]])).sum(1)
+    assert np.abs(rel / dist ** 2).max() < 2e-7
+    ctx.close()
+
+
+def _rigid_water(spcfw):
+    system = system_from_arrays(spcfw, nonbondedMethod='CutoffPeriodic', rigidWater=True)
+    assert system.getNumConstraints() == 3 * 512
+    assert not [f for f in system.getForces() if isinstance(f, openmm.HarmonicBondForce) and f.getNumBonds()]
+    nb = atomsmm.hijackForce(system, atomsmm.findNonbondedForce(system))
+    force = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9 * unit.angstroms).importFrom(nb)
+    force.addTo(system)
+    return system
+
+
+def _bond_error(context, spcfw, system):
+    x = context.getState(getPositions=True).getPositions(asNumpy=True)._value
+    worst = 0.0
+    for k in range(system.getNumConstraints()):
+        i, j, d = system._constraints[k]
+        worst = max(worst, abs(np.linalg.norm(x[i] - x[j]) / d - 1))
+    return worst
+
+
+@pytest.mark.parametrize('kind', ['velocity-verlet', 'respa'])
+def test_rigid_water_dynamics_conserves_energy(spcfw, kind):
+    """VelocityVerletPropagator (propagators.py:1108-1133) and the reference's constrained RESPA (tests/test_propagators.py:
+    43-48: RespaPropagator([4, 1], boost/move constrained) in a GlobalThermostatIntegrator) on rigid q-SPC-FW water."""
+    system = _rigid_water(spcfw)
+    if kind == 'velocity-verlet':
+        integrator = atomsmm.GlobalThermostatIntegrator(2 * unit.femtoseconds, atomsmm.VelocityVerletPropagator())
+    else:
+        boost = atomsmm.propagators.VelocityBoostPropagator(constrained=True)
+        move = atomsmm.propagators.TranslationPropagator(constrained=True)
+        system2 = atomsmm.RESPASystem(system_from_arrays(spcfw, nonbondedMethod='CutoffPeriodic', rigidWater=True),
+                                      7 * unit.angstroms, 5 * unit.angstroms)
+        nb = atomsmm.hijackForce(system2, atomsmm.findNonbondedForce(system2))
+        outer = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9 * unit.angstroms).importFrom(nb)
+        outer.setForceGroup(2)
+        outer.addTo(system2)
+        system = system2
+        integrator = atomsmm.GlobalThermostatIntegrator(3 * unit.femtoseconds, atomsmm.RespaPropagator([1, 3, 1], boost=boost, move=move))
+    integrator.setConstraintTolerance(1e-8)
+    context = openmm.Context(system, integrator)
+    context.setPositions(spcfw['positions'] * unit.nanometers)
+    context.applyConstraints()
+    assert _bond_error(context, spcfw, system) < 1e-7
+    context.setVelocitiesToTemperature(300 * unit.kelvin, 4)
+    dof = atomsmm.countDegreesOfFreedom(system)
+    assert dof == 3 * 1536 - 3 - 3 * 512
+
+    def energies():
+        s = context.getState(getEnergy=True)
+        return s.getPotentialEnergy()._value, s.getKineticEnergy()._value
+    pe0, ke0 = energies()
+    assert 200 < 2 * ke0 / (dof * KB) < 400           # the constrained components were removed, not rescaled
+    integrator.step(150)
+    pe1, ke1 = energies()
+    assert _bond_error(context, spcfw, system) < 1e-7
+    assert abs((pe1 + ke1) - (pe0 + ke0)) < 0.01 * ke1
+    assert abs(pe1 - pe0) > 1.0                          # something did move
