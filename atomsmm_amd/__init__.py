@@ -33,7 +33,8 @@ from .propagators import VelocityVerletPropagator  # noqa: F401
 from .propagators import (MassiveNoseHooverPropagator, NoseHooverPropagator, OrnsteinUhlenbeckPropagator,  # noqa: F401
                           UnconstrainedVelocityVerletPropagator, VelocityRescalingPropagator,
                           GenericBoostPropagator, GenericScalingPropagator)
-from .systems import RESPASystem, SolvationSystem  # noqa: F401
+from .systems import ComputingSystem, RESPASystem, SolvationSystem  # noqa: F401
+from .computers import PressureComputer  # noqa: F401
 from .utils import InputError  # noqa: F401
 from .utils import countDegreesOfFreedom  # noqa: F401
 from .utils import evaluateForce  # noqa: F401
@@ -51,6 +52,6 @@ __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPro
                    'VelocityBoostPropagator', 'VelocityVerletPropagator', 'UnconstrainedVelocityVerletPropagator',
                    'VelocityRescalingPropagator', 'NoseHooverPropagator', 'MassiveNoseHooverPropagator',
                    'OrnsteinUhlenbeckPropagator', 'GenericBoostPropagator', 'GenericScalingPropagator']
-__systems__ = ['RESPASystem', 'SolvationSystem']
+__systems__ = ['RESPASystem', 'SolvationSystem', 'ComputingSystem', 'PressureComputer']
 __utils__ = ['countDegreesOfFreedom', 'evaluateForce', 'findNonbondedForce', 'hijackForce', 'splitPotentialEnergy']
 __all__ = __forces__ + __integrators__ + __propagators__ + __systems__ + __utils__

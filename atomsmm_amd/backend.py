@@ -11,16 +11,19 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libatomsmm_hip.so')
 
-NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE = range(6)
+NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE, LJ_VIRIAL = range(7)
 GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH = 1, 2, 4, 8
 BOND_HARMONIC, ANGLE_HARMONIC, BOND_LJC, BOND_NEAR, TORSION_PERIODIC, BOND_EWALD_EXCL = range(6)
+BOND_VIRIAL_HARMONIC, BOND_VIRIAL_LJ = 6, 7
 OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE, OP_EXPR, OP_BATH = 1, 2, 3, 4, 5, 6, 7
 OP_SAVE_REF, OP_CONSTRAIN_X, OP_CONSTRAIN_V = 8, 9, 10
 MAX_SLOTS, SLOT_X, SLOT_V = 64, 62, 63
 GROUP_ALL = 32   # pseudo-group of the force symbol `f` (all groups)
 KC = 138.935456   # forces.py:407
-ARITY = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 3, BOND_LJC: 2, BOND_NEAR: 2, TORSION_PERIODIC: 4, BOND_EWALD_EXCL: 2}
-NPAR = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 2, BOND_LJC: 3, BOND_NEAR: 3, TORSION_PERIODIC: 3, BOND_EWALD_EXCL: 1}
+ARITY = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 3, BOND_LJC: 2, BOND_NEAR: 2, TORSION_PERIODIC: 4, BOND_EWALD_EXCL: 2,
+         BOND_VIRIAL_HARMONIC: 2, BOND_VIRIAL_LJ: 2}
+NPAR = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 2, BOND_LJC: 3, BOND_NEAR: 3, TORSION_PERIODIC: 3, BOND_EWALD_EXCL: 1,
+        BOND_VIRIAL_HARMONIC: 2, BOND_VIRIAL_LJ: 3}
 
 EXPORTS = [
     'amm_abi_version', 'amm_last_error', 'amm_create', 'amm_destroy', 'amm_set_stream', 'amm_set_slice',

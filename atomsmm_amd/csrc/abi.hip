@@ -147,7 +147,7 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
         amm_set_error("amm_pair_create: null argument");
         return 1;
     }
-    if (desc->family < AMM_NEAR_NONE || desc->family > AMM_SOFTCORE) {
+    if (desc->family < AMM_NEAR_NONE || desc->family > AMM_LJ_VIRIAL) {
         amm_set_error("amm_pair_create: unknown family");
         return 1;
     }
@@ -356,7 +356,7 @@ int amm_bonded_add_terms(amm_ctx *ctx, int32_t force_id, int32_t kind, const int
         amm_set_error("amm_bonded_add_terms after finalize");
         return 1;
     }
-    if (kind < 0 || kind > 5) {
+    if (kind < 0 || kind > 7) {
         amm_set_error("amm_bonded_add_terms: unknown kind");
         return 1;
     }

@@ -95,9 +95,9 @@ struct PairForce {
 
 struct BondedSet {
     // host staging
-    std::vector<int32_t> h_idx[6];
-    std::vector<double> h_par[6];
-    int periodic[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<int32_t> h_idx[8];
+    std::vector<double> h_par[8];
+    int periodic[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool has_near = false;
     amm_pair_desc near_desc;
     PairConsts near_pc;
@@ -106,7 +106,7 @@ struct BondedSet {
     bool sliced = false;           // world > 1: compute only this rank's rows (group is all-reduced by the host)
     bool finalized = false;
     // device: CSR per atom of packed (atom, term) records
-    int n_terms[6] = {0, 0, 0, 0, 0, 0};
+    int n_terms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int *d_ref_ptr = nullptr;      // [n+1]
     int4 *d_rec_a = nullptr;       // atoms of the term
     double4 *d_rec_q = nullptr;    // parameters + kind/role/periodic code

@@ -149,6 +149,26 @@ __device__ __forceinline__ void bonded_term_forces(const BondedArgs &A, const P 
         }
         e = -qq * er / rr;
     } break;
+    case AMM_BOND_VIRIAL_HARMONIC:
+    case AMM_BOND_VIRIAL_LJ: {       // virial contributions as energies (ComputingSystem, systems.py:894-915)
+        double d[3];
+        delta3(pos, ix[0], ix[1], A.box, periodic, d);
+        const double r2 = dot3(d, d), r = sqrt(r2);
+        double fr;
+        if (kind == AMM_BOND_VIRIAL_HARMONIC) {
+            e = -p[1] * r * (r - p[0]);
+            fr = p[1] * (2.0 * r - p[0]) / r;                      // -(dE/dr)/r
+        } else {
+            const double s2 = p[1] * p[1] / r2, x = s2 * s2 * s2;
+            e = 24.0 * p[2] * (2.0 * x * x - x);
+            fr = 24.0 * p[2] * (24.0 * x * x - 6.0 * x) / r2;
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            fo[0][x] = fr * d[x];
+            fo[1][x] = -fo[0][x];
+        }
+    } break;
     case AMM_TORSION_PERIODIC: {
         double F[3], G[3], H[3], Av[3], Bv[3], BA[3];
         delta3(pos, ix[0], ix[1], A.box, periodic, F);
@@ -428,13 +448,13 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
     }
 }
 
-static const int kArity[6] = {2, 3, 2, 2, 4, 2};
-static const int kNpar[6] = {2, 2, 3, 3, 3, 1};
+static const int kArity[8] = {2, 3, 2, 2, 4, 2, 2, 2};
+static const int kNpar[8] = {2, 2, 3, 3, 3, 1, 2, 3};
 
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
     const int n = ctx->n;
     std::vector<int> cnt(n + 1, 0);
-    for (int kind = 0; kind < 6; ++kind) {
+    for (int kind = 0; kind < 8; ++kind) {
         const int nt = (int)bs->h_idx[kind].size() / kArity[kind];
         bs->n_terms[kind] = nt;
         for (int t = 0; t < nt; ++t)
@@ -456,7 +476,7 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
     std::vector<int4> rec_a(nref);
     std::vector<double4> rec_q(nref);
     std::vector<int> fill(cnt.begin(), cnt.end() - 1);
-    for (int kind = 0; kind < 6; ++kind)
+    for (int kind = 0; kind < 8; ++kind)
         for (int t = 0; t < bs->n_terms[kind]; ++t)
             for (int r = 0; r < kArity[kind]; ++r) {
                 const int a = bs->h_idx[kind][t * kArity[kind] + r];
@@ -481,7 +501,7 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
         }
         return a;
     };
-    for (int kind = 0; kind < 6; ++kind)
+    for (int kind = 0; kind < 8; ++kind)
         for (int t = 0; t < bs->n_terms[kind]; ++t)
             for (int r = 1; r < kArity[kind]; ++r) {
                 int a = find(bs->h_idx[kind][t * kArity[kind]]), b = find(bs->h_idx[kind][t * kArity[kind] + r]);

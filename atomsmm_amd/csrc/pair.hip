@@ -61,7 +61,7 @@ int amm_pair_build_consts(const amm_pair_desc &d, PairConsts &pc) {
     if (d.family == AMM_DAMPED) pc.sw_den = pow(d.rc, pc.degree) - pow(d.rswitch, pc.degree);
     pc.inv_sw_den = 1.0 / pc.sw_den;
     pc.rswitch_d = pow(d.rswitch, pc.degree);
-    if ((d.family == AMM_NONBONDED || d.family == AMM_SOFTCORE) && (d.flags & AMM_SWITCH)) pc.inv_sw_dr = 1.0 / (d.rc - d.rswitch);
+    if ((d.family == AMM_NONBONDED || d.family == AMM_SOFTCORE || d.family == AMM_LJ_VIRIAL) && (d.flags & AMM_SWITCH)) pc.inv_sw_dr = 1.0 / (d.rc - d.rswitch);
     return 0;
 }
 
@@ -1068,6 +1068,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         case AMM_NEAR_FSWITCH: launch_pair<AMM_NEAR_FSWITCH, 0>(grid, block, st, guard, en, A, pf->pc); break;
         case AMM_DAMPED: launch_pair<AMM_DAMPED, 0>(grid, block, st, false, en, A, pf->pc); break;
         case AMM_SOFTCORE: launch_pair<AMM_SOFTCORE, 0>(grid, block, st, false, en, A, pf->pc); break;
+        case AMM_LJ_VIRIAL: launch_pair<AMM_LJ_VIRIAL, 0>(grid, block, st, false, en, A, pf->pc); break;
         case AMM_NONBONDED:
             if (pf->pc.cmode == 1) launch_pair<AMM_NONBONDED, 1>(grid, block, st, false, en, A, pf->pc);
             else if (pf->pc.cmode == 2) launch_pair<AMM_NONBONDED, 2>(grid, block, st, false, en, A, pf->pc);

@@ -9,6 +9,7 @@
 //   DAMPED        forces.py:448-455   SW*(LJ + erfc(alpha r) Kc qq/r), u = (r^d-rs^d)/(rc^d-rs^d)
 //   NONBONDED     forces.py:134-190   S_b*LJ + Coulomb {plain | erfc | reaction field}
 //   SOFTCORE      systems.py:266-272  S_b * 4 lambda eps (1-x)/x^2, x = (r/sigma)^6 + (1-lambda)/2, set 1 x set 2 only
+//   LJ_VIRIAL     systems.py:894      S_b * 24 eps (2 (s/r)^12 - (s/r)^6)   (ComputingSystem: the virial as an energy)
 #pragma once
 #include "amm_ctx.h"
 #include "erfcx_table.h"
@@ -166,6 +167,18 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
             const double dVdl = eps4 * ((1.0 - x) * ix2 - 0.5 * c.alpha * (x - 2.0) * ix2 * ix);
             e = member ? S * ((c.flags & AMM_DERIV_LAMBDA) ? dVdl : V) : 0.0;
         }
+    } else if (FAM == AMM_LJ_VIRIAL) {
+        // W = -r dV_LJ/dr = 24 eps (2 s12 - s6) as an "energy" (systems.py:894); eps4 = 4 eps
+        const double W = 6.0 * eps4 * (2.0 * s12 - s6);
+        const double mdW_r = 6.0 * eps4 * (24.0 * s12 - 6.0 * s6) * rinv2;
+        double S = 1.0, dSdr = 0.0;
+        if ((c.flags & AMM_SWITCH) && r > c.rswitch) {
+            const double t = (r - c.rswitch) * c.inv_sw_dr;
+            S = amm_sw_S(t);
+            dSdr = amm_sw_dS(t) * c.inv_sw_dr;
+        }
+        fr = S * mdW_r - dSdr * W * rinv;
+        if (EN) e = S * W;
     } else {   // AMM_NONBONDED
         double S = 1.0, dSdr = 0.0;
         if ((c.flags & AMM_SWITCH) && r > c.rswitch) {

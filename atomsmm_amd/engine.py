@@ -37,43 +37,72 @@ ALLREDUCE = 'allreduce'
 _context_factory = B.HipContext   # the only backend; tests of the host logic substitute a call recorder
 
 
-def softcore_long_range_correction(sigma, eps, codes, box, rc, rswitch, lam):
-    """Long-range correction of the softcore solute-solvent CustomNonbondedForce as OpenMM defines it for a
-    CustomNonbondedForce with interaction groups [recalled; confirmed to 1e-9 by tests/test_systems.py:39]:
-        E = 4 pi N/(N+1)/V * sum over (set 1, set 2) pairs of [ int_rc^inf u r^2 dr + int_rs^rc (1 - S) u r^2 dr ],
-    u = 4 lambda eps (1-x)/x^2, x = (r/sigma)^6 + (1-lambda)/2, S the built-in switch; N = number of particles."""
+def custom_long_range_correction(u, sigma, eps, box, rc, rswitch, codes=None):
+    """Long-range correction of a CustomNonbondedForce as OpenMM defines it [recalled; pinned by tests/test_systems.py:39
+    (interaction group, met to 2e-8) and tests/test_computers.py:31 (no groups)]: with I(s, e) = int_rc^inf u r^2 dr +
+    int_rs^rc (1 - S) u r^2 dr for a pair of mixed parameters (s, e),
+        E = 2 pi N^2 / V * [sum over class pairs of count * I] / (N (N + 1)/2),
+    classes = atoms of equal (sigma, epsilon); count = n_i n_j for two classes, n_i (n_i + 1)/2 within a class; with an
+    interaction group (`codes` 1 / 2) the count is the number of (set 1, set 2) pairs.  N = number of particles."""
     n = len(sigma)
-    one, two = np.where(codes == 1.0)[0], np.where(codes == 2.0)[0]
-    classes = {}
-    for group in (one, two):
-        for i in group:
-            classes.setdefault((codes[i], sigma[i], eps[i]), 0)
-            classes[(codes[i], sigma[i], eps[i])] += 1
-    xg, wg = np.polynomial.legendre.leggauss(96)
-    xg, wg = 0.5 * (xg + 1.0), 0.5 * wg            # nodes / weights on (0, 1)
 
+    def refine(f):
+        """OpenMM's quadrature (CustomNonbondedForceImpl::integrateInteraction [recalled]): midpoint rule on (0, 1),
+        the number of points tripled (the old midpoints stay) until two sums agree to 1e-5 -- reproduced as is, because
+        the reference literals carry ITS truncation error (tests/test_systems.py:39 is met to 1e-9 this way, to 2e-8
+        with an exact quadrature; tests/test_computers.py:33 needs the former)."""
+        total, points = 0.0, 1
+        for iteration in range(9):
+            idx = np.arange(points)
+            xs = (idx[idx % 3 != 1] + 0.5) / points
+            old = total
+            total = float(np.sum(f(xs))) / points + old / 3.0
+            if iteration > 2 and (total == 0.0 or abs((total - old) / total) < 1e-5):
+                return total
+            points *= 3
+        raise RuntimeError('long-range correction did not converge')
+
+    def integral(s, e):
+        def tail(x):                                   # int_rc^inf u r^2 dr = (1/rc) int_0^1 u(rc/x) r^4 dx, r = rc/x
+            r = rc / x
+            return u(r, s, e) * r ** 4
+        out = refine(tail) / rc
+        if rswitch is not None:
+            def shell(x):                              # int_rs^rc (1 - S) u r^2 dr
+                r = rswitch + x * (rc - rswitch)
+                return x ** 3 * (10.0 + x * (-15.0 + x * 6.0)) * u(r, s, e) * r * r
+            out += refine(shell) * (rc - rswitch)
+        return out
+
+    def classes(members):
+        table = {}
+        for i in members:
+            table[(sigma[i], eps[i])] = table.get((sigma[i], eps[i]), 0) + 1
+        return table
+
+    total = 0.0
+    if codes is not None:
+        for (s1, e1), n1 in classes(np.where(codes == 1.0)[0]).items():
+            for (s2, e2), n2 in classes(np.where(codes == 2.0)[0]).items():
+                s, e = 0.5 * (s1 + s2), math.sqrt(e1 * e2)
+                if e != 0.0 and s > 0.0:
+                    total += n1 * n2 * integral(s, e)
+    else:
+        table = list(classes(range(n)).items())
+        for a, ((s1, e1), n1) in enumerate(table):
+            for (s2, e2), n2 in table[a:]:
+                s, e = 0.5 * (s1 + s2), math.sqrt(e1 * e2)
+                if e != 0.0 and s > 0.0:
+                    total += (n1 * (n1 + 1) / 2 if (s1, e1) == (s2, e2) else n1 * n2) * integral(s, e)
+    return 2.0 * math.pi * n * n / float(np.prod(box)) * total / (n * (n + 1) / 2.0)
+
+
+def softcore_long_range_correction(sigma, eps, codes, box, rc, rswitch, lam):
+    """SolvationSystem's softcore force (systems.py:266-272): u = 4 lambda eps (1-x)/x^2, x = (r/sigma)^6 + (1-lambda)/2."""
     def u(r, s, e):
         x = (r / s) ** 6 + 0.5 * (1.0 - lam)
         return 4.0 * lam * e * (1.0 - x) / (x * x)
-
-    total = 0.0
-    for (c1, s1, e1), n1 in classes.items():
-        if c1 != 1.0:
-            continue
-        for (c2, s2, e2), n2 in classes.items():
-            if c2 != 2.0:
-                continue
-            s, e = 0.5 * (s1 + s2), math.sqrt(e1 * e2)
-            if e == 0.0 or s <= 0.0:
-                continue
-            r = rc / xg                                # int_rc^inf u r^2 dr = int_0^1 u(rc/x) r^4 / rc dx
-            integral = float(np.sum(wg * u(r, s, e) * r ** 4)) / rc
-            if rswitch is not None:
-                r = rswitch + xg * (rc - rswitch)
-                sw = xg ** 3 * (10.0 + xg * (-15.0 + 6.0 * xg))      # 1 - S
-                integral += (rc - rswitch) * float(np.sum(wg * sw * u(r, s, e) * r * r))
-            total += n1 * n2 * integral
-    return 4.0 * math.pi * n / (n + 1.0) * total / float(np.prod(box))
+    return custom_long_range_correction(u, sigma, eps, box, rc, rswitch, codes)
 
 
 def dispersion_correction(sigma, eps, box, rc, rswitch=None):
@@ -402,6 +431,8 @@ class Engine:
             raise InputError('the HIP path evaluates CutoffPeriodic CustomNonbondedForces only')
         if d['family'] == 'softcore':
             return self._translate_softcore(force, entry, d)
+        if d['family'] == 'lj-virial':
+            return self._translate_lj_virial(force, entry)
         if force.getNumInteractionGroups() > 0:
             raise NotImplementedError('interaction groups are supported for the softcore solute-solvent force only')
         if force.getUseLongRangeCorrection():
@@ -436,6 +467,22 @@ class Engine:
                 return True
             entry.update = update
             entry.depends = set(lam)
+
+    def _translate_lj_virial(self, force, entry):
+        """ComputingSystem's dispersion virial (systems.py:893-897): a CustomNonbondedForce with the cutoff, switch and
+        long-range-correction settings imported from the NonbondedForce."""
+        n = self.n
+        if force.getNumInteractionGroups() > 0 or getattr(force, '_offset_parameters', []):
+            raise NotImplementedError('virial force with interaction groups or parameter offsets')
+        p = np.array(force._particles, dtype=np.float64).reshape(n, -1)[:, :3]
+        rc = force._cutoff
+        rswitch = force._switch if force.getUseSwitchingFunction() else None
+        excl = np.array(force._exclusions, dtype=np.int32).reshape(-1, 2)
+        desc = B.pair_desc(B.LJ_VIRIAL, rc, rswitch=rswitch or 0.0, flags=B.SWITCH if rswitch is not None else 0)
+        entry.pair_ids.append(self._pair_create(desc, p[:, 0], p[:, 1], p[:, 2], excl))
+        if force.getUseLongRangeCorrection():
+            entry.constant = custom_long_range_correction(
+                lambda r, s, e: 24.0 * e * (2.0 * (s / r) ** 12 - (s / r) ** 6), p[:, 1], p[:, 2], self.box, rc, rswitch)
 
     def _translate_softcore(self, force, entry, d):
         """SolvationSystem's softcore CustomNonbondedForce (systems.py:266-272): one interaction group solute x
@@ -496,6 +543,12 @@ class Engine:
             entry.terms.append((B.BOND_HARMONIC, idx, par[:, [0, 1]], periodic, None))
             entry.terms.append((B.BOND_HARMONIC, idx, np.stack([par[:, 2], -par[:, 3]], axis=1), periodic, None))
             return
+        if force.getEnergyFunction().replace(' ', '') == '-K*r*(r-r0)':
+            # bond-stretching virial of ComputingSystem (systems.py:914): per-bond (r0, K)
+            idx = np.array([[b[0], b[1]] for b in force._bonds], dtype=np.int32).reshape(-1, 2)
+            par = np.array([b[2] for b in force._bonds], dtype=np.float64).reshape(-1, 2)
+            entry.terms.append((B.BOND_VIRIAL_HARMONIC, idx, par, force.usesPeriodicBoundaryConditions(), None))
+            return
         d = dict(self._descriptor_of(force))
         nb_ = force.getNumBonds()
         idx = np.array([[b[0], b[1]] for b in force._bonds], dtype=np.int32).reshape(-1, 2)
@@ -506,6 +559,8 @@ class Engine:
         periodic = force.usesPeriodicBoundaryConditions()
         if d['family'] == 'ljc':
             kind, desc = B.BOND_LJC, B.pair_desc(B.NONBONDED, 1.0, Kc=d.get('Kc', B.KC))
+        elif d['family'] == 'lj-virial':
+            kind, desc = B.BOND_VIRIAL_LJ, None
         else:
             for key in ('rc0', 'rs0', 'Kc'):
                 if d.get(key) is None and key in self.parameters:

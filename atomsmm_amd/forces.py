@@ -115,6 +115,8 @@ def describe_energy(energy, global_parameters=None):
         desc.update(family='damped', degree=int(num('d') or 2), alpha=num('alpha'), rswitch=num('rswitch'))
     elif head == '4*epsilon*x*(x-1)+Kc*chargeprod/r':
         desc['family'] = 'ljc'
+    elif head == '24*epsilon*(2*(sigma/r)^12-(sigma/r)^6)':
+        desc['family'] = 'lj-virial'          # ComputingSystem's dispersion virial (systems.py:894)
     else:
         # SolvationSystem's solute-solvent softcore Lennard-Jones (systems.py:268)
         m = re.fullmatch(r'4\*(\w+)\*epsilon\*\(1-x\)/x\^2', head)

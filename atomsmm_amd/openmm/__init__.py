@@ -851,7 +851,7 @@ class Context:
         T = float(md_value(temperature))
         rng = np.random.default_rng(randomSeed)
         m = np.array(self._system._masses)
-        kT = 8.31446261815324e-3 * T
+        kT = _unit.BOLTZMANN_CONSTANT_kB._value * T
         v = rng.normal(size=(len(m), 3)) * np.sqrt(kT / np.where(m > 0, m, 1.0))[:, None]
         v[m <= 0] = 0.0
         self._engine.set_velocities(v)
@@ -874,7 +874,38 @@ class Context:
         return dict(self._engine.parameters)
 
     def setPeriodicBoxVectors(self, a, b, c):
-        raise OpenMMException('changing the box of a live Context is not supported by the HIP path')
+        new = [float(md_value(a[0])), float(md_value(b[1])), float(md_value(c[2]))]
+        if not np.allclose(new, self._engine.box, rtol=0, atol=1e-12):
+            raise OpenMMException('changing the box of a live Context is not supported by the HIP path')
+
+    def getMolecules(self):
+        """Connected components of the bond graph (bonds of the bonded forces + constraints), as OpenMM's
+        Context.getMolecules(): a list of lists of atom indices, each in increasing order."""
+        n = self._system.getNumParticles()
+        parent = list(range(n))
+
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
+        pairs = [(c[0], c[1]) for c in self._system._constraints]
+        for force in self._system.getForces():
+            if isinstance(force, (HarmonicBondForce, CustomBondForce)):
+                pairs += [(b[0], b[1]) for b in force._bonds]
+            elif isinstance(force, (HarmonicAngleForce, CustomAngleForce)):
+                pairs += [(r[0], r[1]) for r in force._angles] + [(r[1], r[2]) for r in force._angles]
+            elif isinstance(force, PeriodicTorsionForce):
+                pairs += [(r[0], r[1]) for r in force._torsions] + [(r[1], r[2]) for r in force._torsions] + \
+                         [(r[2], r[3]) for r in force._torsions]
+        for i, j in pairs:
+            a, b = find(int(i)), find(int(j))
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+        groups = {}
+        for i in range(n):
+            groups.setdefault(find(i), []).append(i)
+        return [groups[r] for r in sorted(groups)]
 
     def getState(self, getPositions=False, getVelocities=False, getForces=False, getEnergy=False,
                  getParameters=False, enforcePeriodicBox=False, groups=-1):

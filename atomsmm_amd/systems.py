@@ -185,3 +185,60 @@ class SolvationSystem(openmm.System):
             nonbonded.addGlobalParameter('lambda_vdw', 1.0)
             for index, (sigma, epsilon) in lj_parameters.items():
                 nonbonded.addParticleParameterOffset('lambda_vdw', index, 0.0, sigma, epsilon)
+
+
+class _AtomsMM_System(openmm.System):
+    """A copy of a System, optionally without its forces (systems.py:26-31)."""
+
+    def __init__(self, system, copyForces=True):
+        openmm.System.__init__(self)
+        self._copy_from(system)
+        if not copyForces:
+            for index in reversed(range(self.getNumForces())):
+                self.removeForce(index)
+
+
+class ComputingSystem(_AtomsMM_System):
+    """A System whose "potential energies" are the Coulomb energy and the pieces of the internal atomic virial of the
+    original one (systems.py:867-934): group 0 the dispersion virial 24 eps (2 (sigma/r)^12 - (sigma/r)^6) of pairs and
+    exceptions, group 1 the bond-stretching virial -K r (r - r0), group 2 the NonbondedForce with the Lennard-Jones
+    parameters switched off (W_Coulomb = E_Coulomb).  Custom bond forces with other expressions (the reference
+    differentiates them with sympy, systems.py:936-947) are not supported."""
+
+    def __init__(self, system):
+        super().__init__(system, copyForces=False)
+        dispersionGroup, bondedGroup, coulombGroup = 0, 1, 2
+        self._dispersion, self._bonded, self._coulomb = 2 ** dispersionGroup, 2 ** bondedGroup, 2 ** coulombGroup
+        expression = '24*epsilon*(2*(sigma/r)^12-(sigma/r)^6)'
+        for force in system.getForces():
+            if isinstance(force, openmm.NonbondedForce) and force.getNumParticles() > 0:
+                nonbonded = copy.deepcopy(force)
+                virial = forces._AtomsMM_CustomNonbondedForce(expression)
+                virial.importFrom(nonbonded)
+                virial.setForceGroup(dispersionGroup)
+                self.addForce(virial)
+                exceptions = forces._AtomsMM_CustomBondForce(expression)
+                exceptions.importFrom(nonbonded, extract=False)
+                if exceptions.getNumBonds() > 0:
+                    exceptions.setForceGroup(dispersionGroup)
+                    self.addForce(exceptions)
+                for index in range(nonbonded.getNumParticles()):
+                    charge = nonbonded.getParticleParameters(index)[0]
+                    nonbonded.setParticleParameters(index, charge, 1.0, 0.0)
+                for index in range(nonbonded.getNumExceptions()):
+                    i, j, chargeprod = nonbonded.getExceptionParameters(index)[:3]
+                    nonbonded.setExceptionParameters(index, i, j, chargeprod, 1.0, 0.0)
+                nonbonded.setForceGroup(coulombGroup)
+                nonbonded.setReciprocalSpaceForceGroup(coulombGroup)
+                self.addForce(nonbonded)
+            elif isinstance(force, openmm.HarmonicBondForce) and force.getNumBonds() > 0:
+                bondforce = openmm.CustomBondForce('-K*r*(r-r0)')
+                bondforce.addPerBondParameter('r0')
+                bondforce.addPerBondParameter('K')
+                for index in range(force.getNumBonds()):
+                    i, j, r0, K = force.getBondParameters(index)
+                    bondforce.addBond(i, j, [r0, K])
+                bondforce.setForceGroup(bondedGroup)
+                self.addForce(bondforce)
+            elif isinstance(force, openmm.CustomBondForce) and force.getNumBonds() > 0:
+                raise NotImplementedError('ComputingSystem: virial of a user CustomBondForce is not supported')

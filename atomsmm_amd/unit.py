@@ -233,10 +233,15 @@ mole = moles = _u(1.0, name='mole')                      # amounts are folded in
 kilojoule_per_mole = kilojoules_per_mole = _u(1.0, length=2, time=-2, mass=1, name='kilojoule/mole')
 kilocalorie_per_mole = kilocalories_per_mole = _u(4.184, length=2, time=-2, mass=1, name='kilocalorie/mole')
 kilojoule = kilojoules = kilojoule_per_mole              # (per mole implied, as in MD unit systems)
-atmosphere = atmospheres = _u(1.01325e5 * 1e-27 * 6.02214076e23 * 1e-3, length=-1, time=-2, mass=1, name='atmosphere')
-bar = bars = _u(1e5 * 1e-27 * 6.02214076e23 * 1e-3, length=-1, time=-2, mass=1, name='bar')
+# physical constants as in simtk.unit of the OpenMM 7.x the reference's literals come from (CODATA 2006: kB = 1.3806504e-23
+# J/K, NA = 6.02214179e23 /mol): tests/test_computers.py:33-37, :70-74 are met to 1e-12 with these and to 8e-5 only
+# with the 2018 values
+_NA = 6.02214179e23
+_KB = 1.3806504e-23
+atmosphere = atmospheres = _u(1.01325e5 * 1e-27 * _NA * 1e-3, length=-1, time=-2, mass=1, name='atmosphere')
+bar = bars = _u(1e5 * 1e-27 * _NA * 1e-3, length=-1, time=-2, mass=1, name='bar')
 
-# kB*NA = R = 8.31446261815324e-3 kJ/mol/K ; the reference forms it as this product (utils.py:16)
-BOLTZMANN_CONSTANT_kB = Quantity(8.31446261815324e-3, kilojoule_per_mole / kelvin)
+# kB*NA = R in kJ/mol/K ; the reference forms it as this product (utils.py:16)
+BOLTZMANN_CONSTANT_kB = Quantity(_KB * _NA * 1e-3, kilojoule_per_mole / kelvin)
 AVOGADRO_CONSTANT_NA = 1.0
 MOLAR_GAS_CONSTANT_R = BOLTZMANN_CONSTANT_kB

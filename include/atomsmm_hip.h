@@ -37,11 +37,13 @@ enum {
     AMM_NEAR_FSWITCH = 2,   /* force-switched LJC              forces.py:549-563 (V' = S V'_LJC, :628)  */
     AMM_DAMPED = 3,         /* DampedSmoothedForce             forces.py:448-455                        */
     AMM_NONBONDED = 4,      /* _AtomsMM_NonbondedForce direct space  forces.py:134-190, 723             */
-    AMM_SOFTCORE = 5        /* SolvationSystem's solute-solvent softcore LJ, 4 lambda eps (1-x)/x^2 with
+    AMM_SOFTCORE = 5,       /* SolvationSystem's solute-solvent softcore LJ, 4 lambda eps (1-x)/x^2 with
                                x = (r/sigma)^6 + (1-lambda)/2, restricted to an interaction group
                                (systems.py:266-272).  lambda = desc.alpha; the charge array carries the set of
                                each atom (1, 2, 0 = neither; use Kc = 1): a pair counts iff the codes multiply
                                to 2; AMM_SWITCH = OpenMM's built-in switch imported with the cutoff            */
+    AMM_LJ_VIRIAL = 6       /* ComputingSystem's dispersion virial as an energy, 24 eps (2 (sigma/r)^12 - (sigma/r)^6)
+                               (systems.py:894), AMM_SWITCH as imported                                        */
 };
 enum {
     AMM_GUARD_RC0 = 1,      /* energy *= step(rc0 - r)         forces.py:661, 714 ; systems.py:73      */
@@ -71,7 +73,9 @@ enum {
     AMM_BOND_LJC = 2,        /* idx[2], params (qq, sigma, eps)   NonbondedExceptionsForce forces.py:400-407 */
     AMM_BOND_NEAR = 3,       /* idx[2], params (qq, sigma, eps)   NearExceptionForce forces.py:673-680     */
     AMM_TORSION_PERIODIC = 4,/* idx[4], params (n, phase, k)      OpenMM PeriodicTorsionForce              */
-    AMM_BOND_EWALD_EXCL = 5  /* idx[2], params (qi*qj)            -Kc qi qj erf(alpha r)/r, NonbondedForce exclusion term */
+    AMM_BOND_EWALD_EXCL = 5, /* idx[2], params (qi*qj)            -Kc qi qj erf(alpha r)/r, NonbondedForce exclusion term */
+    AMM_BOND_VIRIAL_HARMONIC = 6, /* idx[2], params (r0, k)       -k r (r - r0): bond-stretching virial, ComputingSystem systems.py:914 */
+    AMM_BOND_VIRIAL_LJ = 7   /* idx[2], params (qq, sigma, eps)   24 eps (2 x^2 - x), x = (sigma/r)^6: exception virial systems.py:898 */
 };
 
 /* ---- step-program ops (one flat, unrolled outer step; built by the host from the step program

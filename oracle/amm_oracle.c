@@ -151,6 +151,18 @@ void ammo_pair_kernel(const ammo_pair_desc *d, double r2, double qq, double sig,
         e = S * V;
         dedr = dS * V + S * dV;
     } break;
+    case AMMO_LJ_VIRIAL: {       /* systems.py:894 */
+        double W = 24.0 * eps * (2.0 * s12 - s6);
+        double dW = 24.0 * eps * (-24.0 * s12 + 6.0 * s6) * inv;
+        double S = 1.0, dS = 0.0;
+        if ((d->flags & AMMO_SWITCH) && r > d->rswitch) {
+            double t = (r - d->rswitch) / (d->rc - d->rswitch);
+            S = sw_S(t);
+            dS = sw_dS(t) / (d->rc - d->rswitch);
+        }
+        e = S * W;
+        dedr = dS * W + S * dW;
+    } break;
     default: break;
     }
     *e_out = d->sign * e;

@@ -28,9 +28,11 @@ enum {
     AMMO_NEAR_FSWITCH = 2,   /* force-switched LJC                    forces.py:549-563 */
     AMMO_DAMPED = 3,         /* SW * (LJ + erfc(alpha r) Kc qq / r)   forces.py:448-455 */
     AMMO_NONBONDED = 4,      /* OpenMM NonbondedForce direct space    forces.py:134-190, 723 */
-    AMMO_SOFTCORE = 5        /* 4 lambda eps (1-x)/x^2, x = (r/sigma)^6 + (1-lambda)/2, between the two sets of an
+    AMMO_SOFTCORE = 5,       /* 4 lambda eps (1-x)/x^2, x = (r/sigma)^6 + (1-lambda)/2, between the two sets of an
                                 interaction group (systems.py:266-272); lambda in `alpha`; the `charge` array carries
                                 the set of each atom (1, 2, 0 = none): a pair counts iff the codes multiply to 2 */
+    AMMO_LJ_VIRIAL = 6       /* -r dV_LJ/dr = 24 eps (2 (sigma/r)^12 - (sigma/r)^6) as an "energy" (ComputingSystem,
+                                systems.py:894), with the imported built-in switch */
 };
 
 /* flags */

@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE = range(6)
+NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE, LJ_VIRIAL = range(7)
 GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH = 1, 2, 4, 8
 KC = 138.935456   # forces.py:407
 ADJ = {None: NEAR_NONE, 'shift': NEAR_SHIFT, 'force-switch': NEAR_FSWITCH}
@@ -179,6 +179,34 @@ def softcore_lrc(sigma, eps, codes, box, rc, rswitch, lam):
             integral += quad(f, rswitch, rc, epsabs=0, epsrel=1e-12)[0]
         total += count * integral
     return 4 * np.pi * n / (n + 1.0) * total / float(np.prod(box))
+
+
+def custom_lrc(u, sigma, eps, box, rc, rswitch=None):
+    """Long-range correction of a CustomNonbondedForce WITHOUT interaction groups (OpenMM
+    CustomNonbondedForceImpl::calcLongRangeCorrection [recalled]; pinned by tests/test_computers.py:31): classes of
+    equal (sigma, epsilon); class pairs i <= j count n_i n_j (n_i (n_i + 1)/2 for i == j); the sum is divided by
+    N (N + 1)/2 and multiplied by 2 pi N^2 / V.  u(r, sigma_ij, eps_ij) is the pair energy."""
+    from scipy.integrate import quad
+    n = len(sigma)
+    cls = {}
+    for s_, e_ in zip(sigma, eps):
+        cls[(s_, e_)] = cls.get((s_, e_), 0) + 1
+    keys = list(cls)
+    total = 0.0
+    for a, k1 in enumerate(keys):
+        for k2 in keys[a:]:
+            s_, e_ = 0.5 * (k1[0] + k2[0]), np.sqrt(k1[1] * k2[1])
+            if e_ == 0:
+                continue
+            count = cls[k1] * (cls[k1] + 1) / 2 if k1 == k2 else cls[k1] * cls[k2]
+            integral = quad(lambda r: u(r, s_, e_) * r * r, rc, np.inf, epsabs=0, epsrel=1e-12)[0]
+            if rswitch is not None:
+                def f(r):
+                    t = (r - rswitch) / (rc - rswitch)
+                    return t ** 3 * (10 - 15 * t + 6 * t * t) * u(r, s_, e_) * r * r
+                integral += quad(f, rswitch, rc, epsabs=0, epsrel=1e-12)[0]
+            total += count * integral
+    return 2 * np.pi * n * n / float(np.prod(box)) * total / (n * (n + 1) / 2)
 
 
 def _bonded(fn, idx, params, pos, box, periodic, want_forces, pre=()):

@@ -403,3 +403,63 @@ def test_RESPASystem_with_special_bonds(spcfw):                    # tests/test_
                  'CustomBondForce': 0.0, 'CustomBondForce(1)': -1175.253817235862, 'CustomAngleForce': -305.0221912655623,
                  'Total': -22891.707373668243}          # (the reference also lists an empty PeriodicTorsionForce: 0.0)
     _check(components, potential)
+
+
+def _pressure_case(case, temperature):
+    system, positions, topology = create_system(case, nonbondedMethod='PME')
+    platform = openmm.Platform.getPlatformByName('Reference')
+    computer = atomsmm.PressureComputer(system, topology, platform, temperature=temperature)
+    context = openmm.Context(system, openmm.CustomIntegrator(0), platform)
+    context.setPositions(positions)
+    return computer, context
+
+
+def test_pressure_with_bath_temperature(spcfw):                    # tests/test_computers.py:22-38
+    computer, context = _pressure_case(spcfw, 300 * unit.kelvin)
+    state = context.getState(getPositions=True, getVelocities=True, getForces=True)
+    computer.import_configuration(state)
+    atomic_virial = computer.get_atomic_virial()
+    assert atomic_virial / atomic_virial.unit == pytest.approx(-11661.677650154408)
+    atomic_pressure = computer.get_atomic_pressure()
+    assert atomic_pressure / atomic_pressure.unit == pytest.approx(-58.64837784125407)
+    molecular_virial = computer.get_molecular_virial(state.getForces())
+    assert molecular_virial / molecular_virial.unit == pytest.approx(-5418.629781093525)
+    molecular_pressure = computer.get_molecular_pressure(state.getForces())
+    assert molecular_pressure / molecular_pressure.unit == pytest.approx(-554.9525554206972)
+
+
+def test_pressure_with_kinetic_temperature(spcfw):                 # tests/test_computers.py:41-57
+    """The virials do not depend on the velocities; the two pressures of the reference test do (OpenMM's random
+    velocities, not reproducible here) and are checked against their definitions instead."""
+    computer, context = _pressure_case(spcfw, None)
+    context.setVelocitiesToTemperature(300 * unit.kelvin, 1234)
+    state = context.getState(getPositions=True, getVelocities=True, getForces=True)
+    computer.import_configuration(state)
+    W = computer.get_atomic_virial()
+    assert W / W.unit == pytest.approx(-11661.677650154408)
+    Wm = computer.get_molecular_virial(state.getForces())
+    assert Wm / Wm.unit == pytest.approx(-5418.629781093525)
+    v = state.getVelocities(asNumpy=True)._value
+    m = spcfw['mass']
+    volume = float(np.prod(spcfw['box']))
+    atm = unit.md_value(1 * unit.atmospheres)
+    p_atomic = computer.get_atomic_pressure()
+    assert p_atomic / p_atomic.unit == pytest.approx((float((m[:, None] * v * v).sum()) + W._value) / (3 * volume) / atm)
+    vcm = (m[:, None] * v).reshape(-1, 3, 3).sum(1) / m.reshape(-1, 3).sum(1)[:, None]
+    kmol = 0.5 * float((m.reshape(-1, 3).sum(1)[:, None] * vcm ** 2).sum())
+    p_mol = computer.get_molecular_pressure(state.getForces())
+    assert p_mol / p_mol.unit == pytest.approx((2 * kmol + Wm._value) / (3 * volume) / atm)
+
+
+def test_pressure_with_exceptions(emim):                           # tests/test_computers.py:60-74
+    computer, context = _pressure_case(emim, 300 * unit.kelvin)
+    state = context.getState(getPositions=True, getVelocities=True, getForces=True)
+    computer.import_configuration(state)
+    atomic_virial = computer.get_atomic_virial()
+    assert atomic_virial / atomic_virial.unit == pytest.approx(-22827.477810819175)
+    atomic_pressure = computer.get_atomic_pressure()
+    assert atomic_pressure / atomic_pressure.unit == pytest.approx(-282.7243180164338)
+    molecular_virial = computer.get_molecular_virial(state.getForces())
+    assert molecular_virial / molecular_virial.unit == pytest.approx(-23272.958585794207)
+    molecular_pressure = computer.get_molecular_pressure(state.getForces())
+    assert molecular_pressure / molecular_pressure.unit == pytest.approx(-3283.563262288828)

@@ -15,7 +15,7 @@ from atomsmm_amd import backend as B  # noqa: E402
 from atomsmm_amd import openmm, unit  # noqa: E402
 from atomsmm_amd.testing import system_from_arrays  # noqa: E402
 
-KB = 0.0083144626181532
+KB = unit.BOLTZMANN_CONSTANT_kB._value        # kB*NA in kJ/mol/K as the unit module defines it
 
 
 def dev(a):

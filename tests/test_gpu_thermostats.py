@@ -20,7 +20,7 @@ from atomsmm_amd.testing import system_from_arrays  # noqa: E402
 from oracle import expr_oracle as XO  # noqa: E402  (checker only)
 from oracle import oracle as O  # noqa: E402
 
-KB = 0.0083144626181532
+KB = unit.BOLTZMANN_CONSTANT_kB._value        # kB*NA in kJ/mol/K as the unit module defines it
 
 
 def dev(a):
