@@ -33,7 +33,7 @@ from .propagators import VelocityVerletPropagator  # noqa: F401
 from .propagators import (MassiveNoseHooverPropagator, NoseHooverPropagator, OrnsteinUhlenbeckPropagator,  # noqa: F401
                           UnconstrainedVelocityVerletPropagator, VelocityRescalingPropagator,
                           GenericBoostPropagator, GenericScalingPropagator)
-from .systems import ComputingSystem, RESPASystem, SolvationSystem  # noqa: F401
+from .systems import AlchemicalRespaSystem, ComputingSystem, RESPASystem, SolvationSystem  # noqa: F401
 from .computers import PressureComputer  # noqa: F401
 from .utils import InputError  # noqa: F401
 from .utils import countDegreesOfFreedom  # noqa: F401
@@ -52,6 +52,7 @@ __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPro
                    'VelocityBoostPropagator', 'VelocityVerletPropagator', 'UnconstrainedVelocityVerletPropagator',
                    'VelocityRescalingPropagator', 'NoseHooverPropagator', 'MassiveNoseHooverPropagator',
                    'OrnsteinUhlenbeckPropagator', 'GenericBoostPropagator', 'GenericScalingPropagator']
-__systems__ = ['RESPASystem', 'SolvationSystem', 'ComputingSystem', 'PressureComputer']
+__systems__ = ['RESPASystem', 'SolvationSystem', 'ComputingSystem', 'PressureComputer',
+               'AlchemicalRespaSystem']
 __utils__ = ['countDegreesOfFreedom', 'evaluateForce', 'findNonbondedForce', 'hijackForce', 'splitPotentialEnergy']
 __all__ = __forces__ + __integrators__ + __propagators__ + __systems__ + __utils__

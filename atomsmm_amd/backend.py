@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libatomsmm_hip.so')
 
 NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE, LJ_VIRIAL = range(7)
-GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH = 1, 2, 4, 8
+GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH, NO_SHIFT, GROUP_LJ = 1, 2, 4, 8, 16, 32
 BOND_HARMONIC, ANGLE_HARMONIC, BOND_LJC, BOND_NEAR, TORSION_PERIODIC, BOND_EWALD_EXCL = range(6)
 BOND_VIRIAL_HARMONIC, BOND_VIRIAL_LJ = 6, 7
 OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE, OP_EXPR, OP_BATH = 1, 2, 3, 4, 5, 6, 7
@@ -32,7 +32,7 @@ EXPORTS = [
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
-    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_pair_energy_derivative', 'amm_constraints_create',
+    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
         L.amm_pme_set_charges.argtypes = [vp, C.c_int32, dp]
         L.amm_pme_set_sliced.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_pair_set_lambda.argtypes = [vp, C.c_int32, C.c_double]
+        L.amm_pair_set_scale.argtypes = [vp, C.c_int32, C.c_double]
         L.amm_expr_define.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, ip]
         L.amm_expr_seed.argtypes = [vp, C.c_uint64]
         L.amm_constraints_create.argtypes = [vp, ip, dp, C.c_int32, C.c_double]
@@ -202,6 +203,9 @@ class HipContext:
 
     def pair_energy_derivative(self, fid, pos, out):
         _chk(lib().amm_pair_energy_derivative(self.h, fid, _ptr(pos), _ptr(out)))
+
+    def pair_set_scale(self, fid, value):
+        _chk(lib().amm_pair_set_scale(self.h, fid, float(value)))
 
     def pair_set_lambda(self, fid, value):
         _chk(lib().amm_pair_set_lambda(self.h, fid, float(value)))

@@ -245,6 +245,14 @@ int amm_pair_set_lambda(amm_ctx *ctx, int32_t force_id, double value) {
     return amm_pair_build_consts(pf->desc, pf->pc);
 }
 
+int amm_pair_set_scale(amm_ctx *ctx, int32_t force_id, double scale) {
+    PairForce *pf = get_pair(ctx, force_id);
+    if (!pf) return 1;
+    pf->desc.sign = scale;
+    pf->pc.sign = scale;
+    return 0;
+}
+
 int amm_pair_energy_derivative(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_out) {
     PairForce *pf = get_pair(ctx, force_id);
     if (!pf || !d_pos || !d_out) return 1;

@@ -83,6 +83,11 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
     const double rinv2 = rinv * rinv;
     e = 0.0;
     fr = 0.0;
+    bool in_group = true;
+    if (c.flags & AMM_GROUP_LJ) {          // wave-uniform flag: qq carries the product of the atoms' set codes
+        in_group = qq == 2.0;
+        qq = 0.0;
+    }
     if (GUARD) {
         if (!(c.rc0 - r >= 0.0)) return;   // step(rc0 - r), forces.py:661,714
     }
@@ -113,8 +118,8 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
                                 u4 * (3 * u - 5 * b - 10) / 2);
                 }
                 const double sc2 = sig * sig * c.inv_rc0_2, sc6 = sc2 * sc2 * sc2, sc12 = sc6 * sc6;
-                e = eps4 * (f12 * s12 - f6 * s6) + qq * f1 * rinv -
-                    (eps4 * (c.f12c * sc12 - c.f6c * sc6) + qq * c.f1c * c.inv_rc0);
+                e = eps4 * (f12 * s12 - f6 * s6) + qq * f1 * rinv;
+                if (!(c.flags & AMM_NO_SHIFT)) e -= eps4 * (c.f12c * sc12 - c.f6c * sc6) + qq * c.f1c * c.inv_rc0;
             }
         } else {
             double V;
@@ -203,8 +208,8 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
             if (EN) e += coul;
         }
     }
-    fr *= c.sign;
-    if (EN) e *= c.sign;
+    fr = in_group ? fr * c.sign : 0.0;
+    if (EN) e = in_group ? e * c.sign : 0.0;
 }
 
 // Runtime-dispatched variant for the bond-list kernels (not hot: O(#exceptions)).

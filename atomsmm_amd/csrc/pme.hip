@@ -3,7 +3,8 @@
 // PME parameters (/root/reference/src/atomsmm/systems.py:74-75, forces.py:185-188).  OpenMM is an un-vendored
 // dependency of the reference; this restates the published algorithm with OpenMM's conventions [recalled]:
 // B-spline order 5, grid size ceil(2 alpha L / (3 tol^(1/5))), energy = 1/2 sum_m eterm(m) |S(m)|^2 with
-// eterm = Kc exp(-pi^2 m^2 / alpha^2) / (pi V m^2 B(m)), self energy -Kc alpha/sqrt(pi) sum q^2 in the same group.
+// eterm = Kc exp(-pi^2 m^2 / alpha^2) / (pi V m^2 B(m)), self energy -Kc alpha/sqrt(pi) sum q^2 in the same group
+// (no neutralising-background term: see pme_set_self).
 //
 // MI355X mapping: the charge spread uses 64-bit FIXED-POINT atomics (integer adds commute => the grid, and with
 // it the forces, are bit-reproducible whatever order the 125 x N adds land in); rocFFT (through hipFFT) does the
@@ -25,7 +26,7 @@ struct PmeForce {
     int nzc = 0;                  // K[2]/2 + 1
     double alpha = 0, Kc = 138.935456;
     bool sliced = false;
-    double self_energy = 0;       // -Kc alpha/sqrt(pi) sum q^2  - pi Kc Q^2 / (2 V alpha^2)
+    double self_energy = 0;       // -Kc alpha/sqrt(pi) sum q^2
     double *d_q = nullptr;
     long long *d_gridi = nullptr; // fixed-point charge grid [Kx][Ky][Kz]
     double *d_grid = nullptr;     // real grid
@@ -331,14 +332,14 @@ static void pme_bspline_moduli(int K, std::vector<double> &mod) {
     } while (0)
 
 static void pme_set_self(amm_ctx *ctx, PmeForce *pm, const double *h_q) {
-    double s2 = 0.0, s1 = 0.0;
-    for (int i = 0; i < pm->n; ++i) {
-        s2 += h_q[i] * h_q[i];
-        s1 += h_q[i];
-    }
+    // Ewald self energy only.  No neutralising-background term -pi Kc Q^2 / (2 V alpha^2) for a charged box: the OpenMM
+    // behind the reference's literals has none -- tests/test_systems.py:173 (phenol in water whose water model carries
+    // -0.02 e per molecule, Q = -9.98 e) is met without it and missed by 213.66 kJ/mol with it.
+    double s2 = 0.0;
+    for (int i = 0; i < pm->n; ++i) s2 += h_q[i] * h_q[i];
     const double pi = 3.14159265358979323846;
-    const double vol = ctx->box.L[0] * ctx->box.L[1] * ctx->box.L[2];
-    pm->self_energy = -pm->Kc * pm->alpha / sqrt(pi) * s2 - pi * pm->Kc * s1 * s1 / (2.0 * vol * pm->alpha * pm->alpha);
+    pm->self_energy = -pm->Kc * pm->alpha / sqrt(pi) * s2;
+    (void)ctx;
 }
 
 int amm_pme_create_impl(amm_ctx *ctx, double alpha, const int *K, double Kc, const double *h_q, PmeForce **out) {

@@ -234,6 +234,8 @@ class Engine:
             self._translate_custom_nonbonded(force, entry)
         elif isinstance(force, mm.CustomBondForce):
             self._translate_custom_bond(force, entry)
+        elif isinstance(force, mm.CustomCVForce):
+            self._translate_cv(force, entry)
         elif isinstance(force, mm.HarmonicBondForce):
             b = np.array([[r[0], r[1]] for r in force._bonds], dtype=np.int32).reshape(-1, 2)
             p = np.array([[r[2], r[3]] for r in force._bonds], dtype=np.float64).reshape(-1, 2)
@@ -421,6 +423,8 @@ class Engine:
         rc0, rs0 = d.get('rc0'), d.get('rs0')
         if rc0 is None or rs0 is None:
             raise InputError('near force without rc0/rs0')
+        if d.get('noshift'):
+            flags |= B.NO_SHIFT
         return B.pair_desc(_FAMILY[family], rc, rc0=rc0, rs0=rs0, flags=flags, sign=d.get('sign', 1.0), Kc=d.get('Kc', B.KC))
 
     def _translate_custom_nonbonded(self, force, entry):
@@ -433,6 +437,8 @@ class Engine:
             return self._translate_softcore(force, entry, d)
         if d['family'] == 'lj-virial':
             return self._translate_lj_virial(force, entry)
+        if d['family'] == 'lj' or d.get('noshift') or d.get('scale_name') or force.getNumInteractionGroups() > 0:
+            return self._translate_alchemical_pair(force, entry, d)
         if force.getNumInteractionGroups() > 0:
             raise NotImplementedError('interaction groups are supported for the softcore solute-solvent force only')
         if force.getUseLongRangeCorrection():
@@ -467,6 +473,107 @@ class Engine:
                 return True
             entry.update = update
             entry.depends = set(lam)
+
+    def _translate_alchemical_pair(self, force, entry, d, outer=None, outer_depends=()):
+        """Pair forces of AlchemicalRespaSystem (systems.py:628-772): force-switched potentials without the constant
+        shift, plain Lennard-Jones, optionally restricted to the (solute, solvent) interaction group, optionally
+        multiplied by a global parameter (`respa_switch`) and -- as the collective variable of a CustomCVForce -- by
+        `outer(parameters)`, the coupling function."""
+        n = self.n
+        if getattr(force, '_offset_parameters', []):
+            raise NotImplementedError('alchemical pair force with parameter offsets')
+        if force.getNonbondedMethod() != force.CutoffPeriodic:
+            raise InputError('the HIP path evaluates CutoffPeriodic CustomNonbondedForces only')
+        p = np.array(force._particles, dtype=np.float64).reshape(n, -1)[:, :3]
+        q = p[:, 0].copy()
+        ngroups = force.getNumInteractionGroups()
+        flags, Kc = 0, d.get('Kc', B.KC)
+        codes = None
+        if ngroups > 1:
+            raise NotImplementedError('more than one interaction group')
+        if ngroups == 1:
+            if not (d['family'] == 'lj' or d.get('lj_only')):
+                raise NotImplementedError('interaction groups on a force with electrostatics (coulomb_scaling)')
+            set1, set2 = force._groups[0]
+            if set1 & set2:
+                raise NotImplementedError('overlapping interaction-group sets')
+            codes = np.zeros(n)
+            codes[sorted(set1)] = 1.0
+            codes[sorted(set2)] = 2.0
+            q, Kc = codes, 1.0
+            flags |= B.GROUP_LJ
+        elif d['family'] == 'lj' or d.get('lj_only'):
+            q = np.zeros(n)
+        rc = force._cutoff
+        rswitch = force._switch if force.getUseSwitchingFunction() else None
+        scale_name = d.get('scale_name')
+
+        def scale(parameters):
+            value = d.get('sign', 1.0)
+            if scale_name:
+                value *= parameters[scale_name]
+            if outer is not None:
+                value *= outer(parameters)
+            return value
+
+        if d['family'] == 'lj':
+            if rswitch is not None:
+                flags |= B.SWITCH
+            desc = B.pair_desc(B.NONBONDED, rc, rswitch=rswitch or 0.0, flags=flags, sign=scale(self.parameters), Kc=Kc)
+        elif d['family'] == 'near-force-switch':
+            if rswitch is not None:
+                raise NotImplementedError('built-in switching function on a force-switched potential')
+            if d.get('noshift'):
+                flags |= B.NO_SHIFT
+            if d.get('guard'):
+                flags |= B.GUARD_RC0
+            desc = B.pair_desc(B.NEAR_FSWITCH, rc, rc0=d.get('rc0') or rc, rs0=d['rs0'], flags=flags,
+                               sign=scale(self.parameters), Kc=Kc)
+        else:
+            raise NotImplementedError('alchemical pair family ' + d['family'])
+        excl = np.array(force._exclusions, dtype=np.int32).reshape(-1, 2)
+        pid = self._pair_create(desc, q, p[:, 1], p[:, 2], excl)
+        entry.pair_ids.append(pid)
+        lrc = 0.0
+        if force.getUseLongRangeCorrection():
+            if d['family'] != 'lj':
+                raise NotImplementedError('long-range correction of this CustomNonbondedForce')
+            lrc = custom_long_range_correction(lambda r, s_, e_: 4.0 * e_ * ((s_ / r) ** 12 - (s_ / r) ** 6), p[:, 1], p[:, 2],
+                                               self.box, rc, rswitch, codes)
+        entry.constant = lrc * scale(self.parameters)
+        depends = set(outer_depends) | ({scale_name} if scale_name else set())
+        if depends:
+            def update(parameters, changed):
+                if not (depends & changed):
+                    return False
+                self.ctx.pair_set_scale(pid, scale(parameters))
+                entry.constant = lrc * scale(parameters)
+                return 'values'
+            entry.update = update
+            entry.depends = set(depends)
+
+    def _translate_cv(self, force, entry):
+        """CustomCVForce of AlchemicalRespaSystem (systems.py:738-772): ((gt0-gt1)*S(lambda) + gt1) times ONE collective
+        variable, the energy of a CustomNonbondedForce -- i.e. that pair force with a lambda-dependent overall factor."""
+        if force.getNumCollectiveVariables() != 1:
+            raise NotImplementedError('CustomCVForce with %d collective variables' % force.getNumCollectiveVariables())
+        name, inner = force.getCollectiveVariableName(0), force.getCollectiveVariable(0)
+        if not isinstance(inner, mm.CustomNonbondedForce):
+            raise NotImplementedError('CustomCVForce over a ' + inner.__class__.__name__)
+        text = force.getEnergyFunction()
+        used = X.symbols(text) - {name}
+        self._register_globals(inner)
+
+        def outer(parameters):
+            env = {k: parameters[k] for k in used}
+            e1 = X.eval_global(text, dict(env, **{name: 1.0}))
+            e0 = X.eval_global(text, dict(env, **{name: 0.0}))
+            e2 = X.eval_global(text, dict(env, **{name: 2.0}))
+            if e0 != 0.0 or abs(e2 - 2.0 * e1) > 1e-12 * max(1.0, abs(e1)):
+                raise NotImplementedError('CustomCVForce energy is not proportional to its collective variable')
+            return e1
+        d = dict(self._descriptor_of(inner))
+        self._translate_alchemical_pair(inner, entry, d, outer=outer, outer_depends=used)
 
     def _translate_lj_virial(self, force, entry):
         """ComputingSystem's dispersion virial (systems.py:893-897): a CustomNonbondedForce with the cutoff, switch and
@@ -506,8 +613,10 @@ class Engine:
         rswitch = force._switch if force.getUseSwitchingFunction() else None
         excl = np.array(force._exclusions, dtype=np.int32).reshape(-1, 2)
         eff = self._effective(base, scales, names, self.parameters)
+        scale_name = d.get('scale_name')
         desc = B.pair_desc(B.SOFTCORE, rc, rswitch=rswitch or 0.0, alpha=self.parameters[lam_name],
-                           flags=B.SWITCH if rswitch is not None else 0, Kc=1.0)
+                           flags=B.SWITCH if rswitch is not None else 0, Kc=1.0,
+                           sign=self.parameters[scale_name] if scale_name else 1.0)
         pid = self._pair_create(desc, codes, eff[:, 1], eff[:, 2], excl)
         entry.pair_ids.append(pid)
         use_lrc = force.getUseLongRangeCorrection()
@@ -516,10 +625,11 @@ class Engine:
             if not use_lrc:
                 return 0.0
             p = self._effective(base, scales, names, parameters)
-            return softcore_long_range_correction(p[:, 1], p[:, 2], codes, self.box, rc, rswitch, parameters[lam_name])
+            value = softcore_long_range_correction(p[:, 1], p[:, 2], codes, self.box, rc, rswitch, parameters[lam_name])
+            return value * (parameters[scale_name] if scale_name else 1.0)
 
         entry.constant = constant(self.parameters)
-        lam = set(names) | {lam_name}
+        lam = set(names) | {lam_name} | ({scale_name} if scale_name else set())
         entry.softcore = dict(pid=pid, lambda_name=lam_name, constant=constant, depends=lam)
 
         def update(parameters, changed):
@@ -529,6 +639,8 @@ class Engine:
                 p = self._effective(base, scales, names, parameters)
                 self.ctx.pair_set_params(pid, codes, p[:, 1], p[:, 2])
             self.ctx.pair_set_lambda(pid, parameters[lam_name])
+            if scale_name:
+                self.ctx.pair_set_scale(pid, parameters[scale_name])
             entry.constant = constant(parameters)
             return 'values'            # no bond-list terms changed: group definitions stay
         entry.update = update
@@ -567,12 +679,19 @@ class Engine:
                     d[key] = self.parameters[key]
             kind, desc = B.BOND_NEAR, self._pair_desc_from(d, d['rc0'])
 
+        scale_name = d.get('scale_name')
+        if scale_name and kind != B.BOND_NEAR:
+            raise NotImplementedError('global scale factor on a bond force of this kind')
+
         def terms(parameters):
-            return [(kind, idx, self._effective(base, scales, names, parameters), periodic, desc)]
+            dsc = desc
+            if scale_name:      # respa_switch (systems.py:643, 674): the whole energy times a global parameter
+                dsc = self._pair_desc_from(dict(d, sign=d.get('sign', 1.0) * parameters[scale_name]), d['rc0'])
+            return [(kind, idx, self._effective(base, scales, names, parameters), periodic, dsc)]
 
         entry.terms = terms(self.parameters)
-        if names:
-            lam = set(names)
+        if names or scale_name:
+            lam = set(names) | ({scale_name} if scale_name else set())
 
             def update(parameters, changed):
                 if not (lam & changed):

@@ -10,6 +10,7 @@ freedom, as in OpenMM (every occurrence inside one expression sees the same valu
 """
 import ast
 import math
+import re
 
 OPCODES = dict(
     CONST=0, GLOBAL=1, BUF=2, MASS=3, GAUSS=4, UNIFORM=5, LOAD=6, STORE=7,
@@ -38,9 +39,20 @@ def split_definitions(text):
     return parts[0], defs
 
 
+_KEYWORD = re.compile(r'\b(lambda)\b')       # a legal OpenMM variable name (tests/test_systems.py:165), a Python keyword
+
+
+def _name(node_id):
+    return node_id[:-len('__kw')] if node_id.endswith('__kw') else node_id
+
+
 def _parse(text):
     try:
-        return ast.parse(text.replace('^', '**'), mode='eval').body
+        tree = ast.parse(_KEYWORD.sub(r'\1__kw', text).replace('^', '**'), mode='eval').body
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Name):
+                node.id = _name(node.id)
+        return tree
     except SyntaxError as exc:
         raise ExpressionError('cannot parse expression %r: %s' % (text, exc))
 

@@ -118,13 +118,49 @@ def describe_energy(energy, global_parameters=None):
     elif head == '24*epsilon*(2*(sigma/r)^12-(sigma/r)^6)':
         desc['family'] = 'lj-virial'          # ComputingSystem's dispersion virial (systems.py:894)
     else:
-        # SolvationSystem's solute-solvent softcore Lennard-Jones (systems.py:268)
-        m = re.fullmatch(r'4\*(\w+)\*epsilon\*\(1-x\)/x\^2', head)
         aux = [p.replace(' ', '') for p in parts[1:]]
+        num = r'([0-9.eE+-]+)'
+        # a global parameter multiplying the whole energy (AlchemicalRespaSystem: respa_switch, systems.py:636-674)
+        scale_name = None
+        m = re.fullmatch(r'(\w+)\*(\(.*\)|4\*.*)', head)
+        if m and m.group(1) in g and m.group(1) not in ('epsilon',) and not m.group(2).startswith('4*') or \
+                (m and m.group(1) == 'respa_switch'):
+            scale_name, head = m.group(1), m.group(2)
+            if head.startswith('(') and head.endswith(')'):
+                head = head[1:-1]
+        # `step(rc-r)*U; U = <expression>` bond wrappers (systems.py:643, 674)
+        m = re.fullmatch(r'step\(' + num + r'-r\)\*U', head)
+        if m and any(a.startswith('U=') for a in aux):
+            inner = [a for a in aux if a.startswith('U=')][0][2:]
+            sub = describe_energy(';'.join([inner] + [a for a in aux if not a.startswith('U=')]), g)
+            if sub is None:
+                return None
+            sub.update(guard=True, rc0=float(m.group(1)))
+            return sub
+        # SolvationSystem's solute-solvent softcore Lennard-Jones (systems.py:268) and AlchemicalRespaSystem's (:712-713)
+        m = re.fullmatch(r'4\*(\w+)\*epsilon\*\(1-x\)/x\^2', head)
+        m2 = re.fullmatch(r'4\*(\w+)\*epsilon\*x\*\(x-1\)', head)
         if m and 'x=(r/sigma)^6+0.5*(1-%s)' % m.group(1) in aux:
             desc.update(family='softcore', lambda_name=m.group(1))
+        elif m2 and 'x=1/((r/sigma)^6+0.5*(1-%s))' % m2.group(1) in aux:
+            desc.update(family='softcore', lambda_name=m2.group(1))
+        elif head == '4*epsilon*x*(x-1)' and 'x=(sigma/r)^6' in aux:
+            desc.update(family='lj')                                   # systems.py:749: the collective variable
+        elif re.fullmatch(r'4\*epsilon\*x\*\(x-1\)\+' + num + r'\*chargeprod/r', head) and 'x=(sigma/r)^6' in aux:
+            desc.update(family='ljc', Kc=float(re.fullmatch(r'4\*epsilon\*x\*\(x-1\)\+' + num + r'\*chargeprod/r', head).group(1)))
         else:
-            return None
+            # force-switched potentials without the constant shift (systems.py:823-846); the coefficients in the text
+            # are functions of (rc, rs) only: rs is read from step(r-rs), rc is the cutoff of the force object
+            ma = re.fullmatch(r'4\*epsilon\*x\*\(x-1\)\+' + num + r'\*chargeprod/r\+step\(r-' + num + r'\)\*perturbation', head)
+            mb = re.fullmatch(r'4\*epsilon\*x\*\(x-1\)\+step\(r-' + num + r'\)\*perturbation', head)
+            if ma:
+                desc.update(family='near-force-switch', noshift=True, Kc=float(ma.group(1)), rs0=float(ma.group(2)))
+            elif mb:
+                desc.update(family='near-force-switch', noshift=True, Kc=0.0, lj_only=True, rs0=float(mb.group(1)))
+            else:
+                return None
+        if scale_name:
+            desc['scale_name'] = scale_name
     return desc
 
 

@@ -367,6 +367,36 @@ class CustomNonbondedForce(Force, _GlobalParams):
         self._derivs.append(name)
 
 
+class CustomCVForce(Force, _GlobalParams):
+    """Energy = function of collective variables, each the energy of an inner Force object."""
+
+    def __init__(self, energy):
+        Force.__init__(self)
+        self._init_globals()
+        self._energy = energy
+        self._cvs = []
+        self._derivs = []
+
+    def getEnergyFunction(self):
+        return self._energy
+
+    def addCollectiveVariable(self, name, force):
+        self._cvs.append((name, copy.deepcopy(force)))
+        return len(self._cvs) - 1
+
+    def getNumCollectiveVariables(self):
+        return len(self._cvs)
+
+    def getCollectiveVariableName(self, index):
+        return self._cvs[index][0]
+
+    def getCollectiveVariable(self, index):
+        return self._cvs[index][1]
+
+    def addEnergyParameterDerivative(self, name):
+        self._derivs.append(name)
+
+
 class CustomBondForce(Force, _GlobalParams):
     def __init__(self, energy):
         Force.__init__(self)

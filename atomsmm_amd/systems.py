@@ -242,3 +242,198 @@ class ComputingSystem(_AtomsMM_System):
                 self.addForce(bondforce)
             elif isinstance(force, openmm.CustomBondForce) and force.getNumBonds() > 0:
                 raise NotImplementedError('ComputingSystem: virial of a user CustomBondForce is not supported')
+
+
+class AlchemicalRespaSystem(openmm.System):
+    """`atomsmm.systems.AlchemicalRespaSystem(system, rcutIn, rswitchIn, alchemical_atoms, coupling_parameter='lambda',
+    coupling_function='lambda', middle_scale=True, coulomb_scaling=False, lambda_coul=0, use_softcore=False,
+    split_alchemical=True)` (reference: src/atomsmm/systems.py:492-783): RESPA splitting plus alchemical coupling of
+    the solute-solvent van der Waals interactions.
+
+    * the NonbondedForce keeps the solvent-solvent interactions only (solute parameters (0, 1, 0), every solute-solute
+      pair an exclusion), group 2 (1 without a middle scale);
+    * with a middle scale, group 1 gets a force-switched short-ranged copy, `respa_switch*(V_LJC + step(r-rs)*(...))`
+      -- no constant shift -- as CustomNonbondedForce, and the non-zero exceptions as `step(rc-r)*U` bonds;
+    * the solute-solute interactions become cutoff-less LJC bonds (group 2) plus their short-ranged copy (group 1);
+    * the solute-solvent Lennard-Jones energy is a collective variable multiplied by ((gt0-gt1)*S(lambda)+gt1) in a
+      CustomCVForce (group 2; its force-switched short-ranged copy in group 1), or a softcore force.
+    Coulomb scaling of the solute-solvent electrostatics (systems.py:686-708) is not supported."""
+
+    Kc = 138.935456637          # systems.py:572 (the other classes use 138.935456)
+
+    def __init__(self, system, rcutIn, rswitchIn, alchemical_atoms=[], coupling_parameter='lambda',
+                 coupling_function='lambda', middle_scale=True, coulomb_scaling=False, lambda_coul=0,
+                 use_softcore=False, split_alchemical=True):
+        openmm.System.__init__(self)
+        self._copy_from(system)
+        if coulomb_scaling:
+            raise NotImplementedError('AlchemicalRespaSystem: coulomb_scaling is not supported')
+        Kc = self.Kc
+        self._parameter, self._middle_scale, self._use_softcore = coupling_parameter, middle_scale, use_softcore
+        solute_atoms = set(int(i) for i in alchemical_atoms)
+        solvent_atoms = set(range(self.getNumParticles())) - solute_atoms
+        rci, rsi = md_value(rcutIn), md_value(rswitchIn)
+        fsp = self._force_switched_potential(rci, rsi, Kc)
+        mixing_rules = '; chargeprod = charge1*charge2; sigma = 0.5*(sigma1 + sigma2); epsilon = sqrt(epsilon1*epsilon2)'
+        outer_group = 2 if middle_scale else 1
+        nonbonded = None
+        for force in self.getForces():
+            if isinstance(force, openmm.NonbondedForce):
+                nonbonded = copy.deepcopy(force)
+                force.setForceGroup(outer_group)
+                force.setReciprocalSpaceForceGroup(outer_group)
+                for i in solute_atoms:
+                    force.setParticleParameters(i, 0.0, 1.0, 0.0)
+                have = set()
+                for index in range(force.getNumExceptions()):
+                    i, j = nonbonded.getExceptionParameters(index)[:2]
+                    if i in solute_atoms and j in solute_atoms:
+                        have.add(frozenset((i, j)))
+                        force.setExceptionParameters(index, i, j, 0.0, 1.0, 0.0)
+                for i, j in itertools.combinations(sorted(solute_atoms), 2):
+                    if frozenset((i, j)) not in have:
+                        force.addException(i, j, 0.0, 1.0, 0.0)
+                        q1, sig1, eps1 = nonbonded.getParticleParameters(i)
+                        q2, sig2, eps2 = nonbonded.getParticleParameters(j)
+                        nonbonded.addException(i, j, q1 * q2, (sig1 + sig2) / 2, (eps1 * eps2).sqrt())
+                if middle_scale:
+                    near_force = openmm.CustomNonbondedForce(fsp + mixing_rules)
+                    self._import_from_nonbonded(near_force, force)
+                    near_force.setCutoffDistance(rcutIn)
+                    near_force.setUseSwitchingFunction(False)
+                    near_force.setUseLongRangeCorrection(False)
+                    near_force.addGlobalParameter('respa_switch', 0)
+                    near_force.setForceGroup(1)
+                    self.addForce(near_force)
+                    exceptions = openmm.CustomBondForce('step({}-r)*U; U = {}'.format(rci, fsp))
+                    exceptions.addGlobalParameter('respa_switch', 0)
+                    for parameter in ['chargeprod', 'sigma', 'epsilon']:
+                        exceptions.addPerBondParameter(parameter)
+                    for index in range(force.getNumExceptions()):
+                        i, j, chargeprod, sigma, epsilon = force.getExceptionParameters(index)
+                        if md_value(chargeprod) != 0.0 or md_value(epsilon) != 0.0:
+                            exceptions.addBond(i, j, (chargeprod, sigma, epsilon))
+                    if exceptions.getNumBonds() > 0:
+                        exceptions.setForceGroup(1)
+                        self.addForce(exceptions)
+                self._nonbonded_force = force
+            else:
+                force.setForceGroup(0)
+        if not solute_atoms or nonbonded is None:
+            return
+        full_range = openmm.CustomBondForce('4*epsilon*x*(x - 1) + {}*chargeprod/r; x = (sigma/r)^6'.format(Kc))
+        full_range.setForceGroup(outer_group)
+        intrasolute_forces = [full_range]
+        if middle_scale:
+            short_range = openmm.CustomBondForce('step({}-r)*U; U = {}'.format(rci, fsp))
+            short_range.addGlobalParameter('respa_switch', 0)
+            short_range.setForceGroup(1)
+            intrasolute_forces.append(short_range)
+        for force in intrasolute_forces:
+            for parameter in ['chargeprod', 'sigma', 'epsilon']:
+                force.addPerBondParameter(parameter)
+            self.addForce(force)
+        for index in range(nonbonded.getNumExceptions()):
+            i, j, chargeprod, sigma, epsilon = nonbonded.getExceptionParameters(index)
+            if i in solute_atoms and j in solute_atoms:
+                for force in intrasolute_forces:
+                    force.addBond(i, j, (chargeprod, sigma, epsilon))
+        if use_softcore:
+            ljsoft = '4*{0}*epsilon*x*(x - 1); x = 1/((r/sigma)^6 + 0.5*(1-{0}))'.format(coupling_parameter)
+            full_range = openmm.CustomNonbondedForce(ljsoft + mixing_rules)
+            self._import_from_nonbonded(full_range, nonbonded, import_globals=True)
+            full_range.addInteractionGroup(solute_atoms, solvent_atoms)
+            full_range.addGlobalParameter(coupling_parameter, 1.0)
+            full_range.addEnergyParameterDerivative(coupling_parameter)
+            full_range.setForceGroup(outer_group)
+            self.addForce(full_range)
+            self._alchemical_vdw_force = full_range
+            if middle_scale:
+                short_range = copy.deepcopy(full_range)
+                short_range.setEnergyFunction('respa_switch*{}'.format(ljsoft) + mixing_rules)
+                short_range.addGlobalParameter('respa_switch', 0)
+                short_range.setForceGroup(1)
+                self.addForce(short_range)
+        else:
+            potential = '((gt0-gt1)*S + gt1)*alchemical_vdw_energy'
+            potential += '; gt0 = step({})'.format(coupling_parameter)
+            potential += '; gt1 = step({}-1)'.format(coupling_parameter)
+            potential += '; S = {}'.format(coupling_function)
+            cv_force = openmm.CustomCVForce(potential)
+            cv_force.addGlobalParameter(coupling_parameter, 1.0)
+            cv_force.addEnergyParameterDerivative(coupling_parameter)
+            lj = '4*epsilon*x*(x - 1); x = (sigma/r)^6'
+            full_range = openmm.CustomNonbondedForce(lj + mixing_rules)
+            self._import_from_nonbonded(full_range, nonbonded, import_globals=True)
+            full_range.addInteractionGroup(solute_atoms, solvent_atoms)
+            full_range_cv_force = copy.deepcopy(cv_force)
+            full_range_cv_force.addCollectiveVariable('alchemical_vdw_energy', full_range)
+            full_range_cv_force.setForceGroup(outer_group)
+            self.addForce(full_range_cv_force)
+            self._alchemical_vdw_force = full_range_cv_force
+            if middle_scale and split_alchemical:
+                fsljp = self._force_switched_potential(rci, rsi, 0.0)
+                short_range = openmm.CustomNonbondedForce(fsljp + mixing_rules)
+                self._import_from_nonbonded(short_range, nonbonded)
+                short_range.setCutoffDistance(rcutIn)
+                short_range.setUseSwitchingFunction(False)
+                short_range.setUseLongRangeCorrection(False)
+                short_range.addGlobalParameter('respa_switch', 0)
+                short_range.addInteractionGroup(solute_atoms, solvent_atoms)
+                cv_force.addCollectiveVariable('alchemical_vdw_energy', short_range)
+                cv_force.setForceGroup(1)
+                self.addForce(cv_force)
+            elif middle_scale:
+                short_range = copy.deepcopy(full_range)
+                short_range.setEnergyFunction('respa_switch*{}'.format(lj) + mixing_rules)
+                short_range.addGlobalParameter('respa_switch', 0)
+                short_range.setForceGroup(1)
+                self.addForce(short_range)
+
+    def get_alchemical_vdw_force(self):
+        return self._alchemical_vdw_force
+
+    @staticmethod
+    def _force_switched_potential(rc, rs, Kc):
+        """The expression text of systems.py:823-846: V_LJC plus, beyond rs, the force-switch perturbation, times the
+        global parameter respa_switch (no constant shift)."""
+        b = rs / (rc - rs)
+        a12 = (6 * b ** 2 - 21 * b + 28) / 462
+        a6 = 6 * b ** 2 - 3 * b + 1
+        f = {}
+        f[12] = '{}*({}*(R^12-1)-{}*u-{}*u^2-220*u^3)+({})*u^4-{}*u^5'.format(a12, b ** 3, 12 * b ** 2, 66 * b, 45 * (7 - 2 * b) / 14, 72 / 7)
+        f[6] = '{}*({}*(R^6-1)-{}*u-{}*u^2-20*u^3)+({})*u^4-36*u^5'.format(a6, b ** 3, 6 * b ** 2, 15 * b, 45 * (1 - 2 * b))
+        if Kc == 0.0:
+            fsp = 'respa_switch*(4*epsilon*x*(x-1) + step(r-{})*perturbation)'.format(rs)
+            fsp += '; perturbation = 4*epsilon*x*(f12*x-f6)'
+        else:
+            a1 = 5 * (b + 1) ** 2
+            f[1] = '{}*({}*R*log(R)-{}*u-{}*u^2+u^3)-{}*u^4+{}*u^5'.format(a1, 6 * b ** 3, 6 * b ** 2, 3 * b, 5 * (b / 2 + 1), 3 / 2)
+            fsp = 'respa_switch*(4*epsilon*x*(x-1) + {}*chargeprod/r + step(r-{})*perturbation)'.format(Kc, rs)
+            fsp += '; perturbation = 4*epsilon*x*(f12*x-f6) + {}*f1*chargeprod/r'.format(Kc)
+        fsp += '; x = (sigma/r)^6'
+        for variable, expression in f.items():
+            fsp += '; f{} = {}'.format(variable, expression)
+        fsp += '; R = {}*u + 1'.format(1 / b)
+        fsp += '; u = {}*r - {}'.format(b / rs, b)
+        return fsp
+
+    @staticmethod
+    def _import_from_nonbonded(force, nonbonded, import_globals=False):
+        """systems.py:856-875: method, particles, exceptions -> exclusions; optionally cutoff / switch / correction."""
+        if nonbonded.getNonbondedMethod() == openmm.NonbondedForce.NoCutoff:
+            force.setNonbondedMethod(openmm.CustomNonbondedForce.NoCutoff)
+        else:
+            force.setNonbondedMethod(openmm.CustomNonbondedForce.CutoffPeriodic)
+        for parameter in ['charge', 'sigma', 'epsilon']:
+            force.addPerParticleParameter(parameter)
+        for i in range(nonbonded.getNumParticles()):
+            force.addParticle(nonbonded.getParticleParameters(i))
+        for index in range(nonbonded.getNumExceptions()):
+            i, j = nonbonded.getExceptionParameters(index)[:2]
+            force.addExclusion(i, j)
+        if import_globals:
+            force.setCutoffDistance(nonbonded.getCutoffDistance())
+            force.setUseSwitchingFunction(nonbonded.getUseSwitchingFunction())
+            force.setSwitchingDistance(nonbonded.getSwitchingDistance())
+            force.setUseLongRangeCorrection(nonbonded.getUseDispersionCorrection())

@@ -49,7 +49,12 @@ enum {
     AMM_GUARD_RC0 = 1,      /* energy *= step(rc0 - r)         forces.py:661, 714 ; systems.py:73      */
     AMM_COULOMB_EWALD = 2,  /* NONBONDED: Kc qq erfc(alpha r)/r                                         */
     AMM_COULOMB_RF = 4,     /* NONBONDED: reaction field (parity unpinned)              */
-    AMM_SWITCH = 8          /* NONBONDED / SOFTCORE: OpenMM built-in switch rswitch -> rc                */
+    AMM_SWITCH = 8,         /* NONBONDED / SOFTCORE: OpenMM built-in switch rswitch -> rc                */
+    AMM_NO_SHIFT = 16,      /* NEAR_FSWITCH: energy without the constant -V*(rc0) (AlchemicalRespaSystem's
+                               force-switched potentials, systems.py:823-846)                            */
+    AMM_GROUP_LJ = 32       /* interaction group for Lennard-Jones-only forces: the charge array carries the set
+                               of each atom (1, 2, 0; Kc = 1), a pair counts iff the codes multiply to 2, no
+                               Coulomb term (systems.py:739-772)                                         */
 };
 
 typedef struct {
@@ -136,6 +141,9 @@ int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id);
 /* CustomBondForce / HarmonicBondForce / HarmonicAngleForce term lists of one force group. */
 /* context.setParameter('lambda_vdw', value) for a softcore pair force (systems.py:267: global parameter). */
 int amm_pair_set_lambda(amm_ctx *ctx, int32_t force_id, double value);
+/* Overall factor of a pair force (desc.sign): a global parameter that multiplies the whole energy -- `respa_switch`, or
+ * the coupling function of a CustomCVForce over this force (systems.py:738-772) -- changed by setParameter. */
+int amm_pair_set_scale(amm_ctx *ctx, int32_t force_id, double scale);
 /* deriv(energy, lambda) of a softcore pair force (addEnergyParameterDerivative, systems.py:712-718; used by the AFED
  * kicks, integrators.py:735-737): *d_out (device) += sum over pairs of dE/dlambda at d_pos. */
 int amm_pair_energy_derivative(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_out);
@@ -151,7 +159,8 @@ int amm_bonded_set_sliced(amm_ctx *ctx, int32_t force_id, int32_t on);
 /* Reciprocal space of a NonbondedForce with nonbondedMethod PME / Ewald, as RESPASystem and FarNonbondedForce
  * keep it in group 2 with the source force's Ewald tolerance / PME parameters (systems.py:74-75,
  * forces.py:185-188; setReciprocalSpaceForceGroup: utils.py:147-152).  Smooth PME, B-spline order 5, grid
- * nx x ny x nz; the energy includes the Ewald self term (and the neutralising-background term of a charged box).
+ * nx x ny x nz; the energy includes the Ewald self term (no neutralising-background term for a charged box: the
+ * reference's literals have none, tests/test_systems.py:173).
  * Evaluated through amm_force_eval like the other force objects. */
 int amm_pme_create(amm_ctx *ctx, double alpha, int32_t nx, int32_t ny, int32_t nz, double Kc, const double *h_q,
                    int32_t *force_id);

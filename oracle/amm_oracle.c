@@ -54,6 +54,10 @@ void ammo_pair_kernel(const ammo_pair_desc *d, double r2, double qq, double sig,
     if ((d->flags & AMMO_GUARD_RC0) && !(d->rc0 - r >= 0.0)) { /* step(rc0-r) forces.py:661,714 */
         *e_out = 0.0; *fr_out = 0.0; return;
     }
+    if (d->flags & AMMO_GROUP_LJ) {
+        if (qq != 2.0) { *e_out = 0.0; *fr_out = 0.0; return; }
+        qq = 0.0;
+    }
     double inv = 1.0 / r;
     double s = sig * inv, s2 = s * s, s6 = s2 * s2 * s2, s12 = s6 * s6;
     double lj = 4.0 * eps * (s12 - s6);
@@ -93,8 +97,8 @@ void ammo_pair_kernel(const ammo_pair_desc *d, double r2, double qq, double sig,
             S = sw_S(u);
         }
         double sc = sig / d->rc0, sc2 = sc * sc, sc6 = sc2 * sc2 * sc2, sc12 = sc6 * sc6;
-        e = 4.0 * eps * (f12 * s12 - f6 * s6) + d->Kc * qq * f1 * inv -
-            (4.0 * eps * (f12c * sc12 - f6c * sc6) + d->Kc * qq * f1c / d->rc0);
+        e = 4.0 * eps * (f12 * s12 - f6 * s6) + d->Kc * qq * f1 * inv;
+        if (!(d->flags & AMMO_NO_SHIFT)) e -= 4.0 * eps * (f12c * sc12 - f6c * sc6) + d->Kc * qq * f1c / d->rc0;
         dedr = S * (dlj + dcoul);
     } break;
     case AMMO_DAMPED: {          /* forces.py:448-455 ; degree 1 == OpenMM built-in switch (:459-460) */

@@ -40,7 +40,9 @@ enum {
     AMMO_GUARD_RC0 = 1,      /* multiply by step(rc0 - r)             forces.py:661, 714 */
     AMMO_COULOMB_EWALD = 2,  /* NONBONDED: Kc qq erfc(alpha r)/r (Ewald/PME direct space) */
     AMMO_COULOMB_RF = 4,     /* NONBONDED: reaction field (CutoffPeriodic); parity unpinned */
-    AMMO_SWITCH = 8          /* NONBONDED: built-in switch rswitch->rc on the LJ term */
+    AMMO_SWITCH = 8,         /* NONBONDED: built-in switch rswitch->rc on the LJ term */
+    AMMO_NO_SHIFT = 16,      /* NEAR_FSWITCH without the constant -V*(rc0)   systems.py:823-846 */
+    AMMO_GROUP_LJ = 32       /* LJ-only interaction group: charges = set codes, pair iff product == 2, no Coulomb */
 };
 
 typedef struct {

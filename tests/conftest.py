@@ -39,3 +39,8 @@ def heaq():
 @pytest.fixture(scope='session')
 def emim():
     return load_case('emim_BCN4_Jiung2014')
+
+
+@pytest.fixture(scope='session')
+def phenol():
+    return load_case('phenol-in-water')

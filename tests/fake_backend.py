@@ -34,6 +34,9 @@ class RecordingContext:
     def pair_energy_derivative(self, fid, pos, out):
         self.calls.append(('pair_energy_derivative', fid))
 
+    def pair_set_scale(self, fid, value):
+        self.calls.append(('pair_set_scale', fid, value))
+
     def pair_set_lambda(self, fid, value):
         self.calls.append(('pair_set_lambda', fid, value))
 

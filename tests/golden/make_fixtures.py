@@ -118,9 +118,15 @@ def build(case, datadir):
     bonds = np.array(bonds, dtype=np.int32).reshape(-1, 2)
 
     def lookup(table, key):
+        """Exact match first; then patterns with wildcards ('' matches any type: OpenMM ForceField semantics)."""
         for (k, *vals) in table:
             if tuple(k) == tuple(key) or tuple(k) == tuple(reversed(key)):
                 return vals
+        for (k, *vals) in table:
+            if '' in k:
+                for cand in (tuple(key), tuple(reversed(key))):
+                    if all(a == '' or a == b for a, b in zip(k, cand)):
+                        return vals
         return None
 
     # --- harmonic bonds

@@ -463,3 +463,45 @@ def test_pressure_with_exceptions(emim):                           # tests/test_
     assert molecular_virial / molecular_virial.unit == pytest.approx(-23272.958585794207)
     molecular_pressure = computer.get_molecular_pressure(state.getForces())
     assert molecular_pressure / molecular_pressure.unit == pytest.approx(-3283.563262288828)
+
+
+def _phenol_system(phenol):
+    system, positions, topology = create_system(phenol, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
+    solute = set(int(i) for i in np.where(phenol['resname'] == 'aaa')[0])
+    return system, positions, topology, solute
+
+
+def test_AlchemicalRespaSystem(phenol):                             # tests/test_systems.py:155-181
+    system, positions, topology, solute = _phenol_system(phenol)
+    solvation_system = atomsmm.AlchemicalRespaSystem(system, 7 * unit.angstroms, 5 * unit.angstroms, solute,
+                                                     coupling_function='lambda^4*(5-4*lambda)')
+    components = atomsmm.splitPotentialEnergy(solvation_system, topology, positions, **{'lambda': 0.5, 'respa_switch': 1})
+    _check(components, {'HarmonicBondForce': 2621.3223922886677, 'HarmonicAngleForce': 1525.1006876561419,
+                        'PeriodicTorsionForce': 18.767576693568476, 'Real-Space': 80089.51116719692,
+                        'Reciprocal-Space': -107038.52551657759, 'CustomNonbondedForce': 5037.152491649265,
+                        'CustomBondForce': -53.526446723139806, 'CustomBondForce(1)': -53.374675325650806,
+                        'CustomCVForce': -7.114065227572182, 'CustomCVForce(1)': -6.301336948673654,
+                        'Total': -17866.987725318053})
+
+
+def test_AlchemicalRespaSystem_without_middle_scale(phenol):       # tests/test_systems.py:184-208
+    system, positions, topology, solute = _phenol_system(phenol)
+    solvation_system = atomsmm.AlchemicalRespaSystem(system, 7 * unit.angstroms, 5 * unit.angstroms, solute,
+                                                     coupling_function='lambda^4*(5-4*lambda)', middle_scale=False)
+    components = atomsmm.splitPotentialEnergy(solvation_system, topology, positions, **{'lambda': 0.5})
+    _check(components, {'HarmonicBondForce': 2621.3223922886677, 'HarmonicAngleForce': 1525.1006876561419,
+                        'PeriodicTorsionForce': 18.767576693568476, 'Real-Space': 80089.51116719692,
+                        'Reciprocal-Space': -107038.52551657759, 'CustomBondForce': -53.526446723139806,
+                        'CustomCVForce': -7.114065227572182, 'Total': -22844.464204692995})
+
+
+def test_AlchemicalRespaSystem_with_softcore(phenol):              # tests/test_systems.py:252-292 (system components)
+    system, positions, topology, solute = _phenol_system(phenol)
+    solvation_system = atomsmm.AlchemicalRespaSystem(system, 7 * unit.angstroms, 5 * unit.angstroms, solute, use_softcore=True)
+    components = atomsmm.splitPotentialEnergy(solvation_system, topology, positions, **{'lambda': 0.5, 'respa_switch': 1})
+    _check(components, {'HarmonicBondForce': 2621.3223922886677, 'HarmonicAngleForce': 1525.1006876561419,
+                        'PeriodicTorsionForce': 18.767576693568476, 'Real-Space': 80089.51116719692,
+                        'Reciprocal-Space': -107038.52551657759, 'CustomNonbondedForce': 5037.152491649265,
+                        'CustomBondForce': -53.526446723139806, 'CustomBondForce(1)': -53.374675325650806,
+                        'CustomNonbondedForce(1)': -24.140118811594814, 'CustomNonbondedForce(2)': -24.140118811594814,
+                        'Total': -17901.852560765})

@@ -72,6 +72,24 @@ def test_reciprocal_golden_G14_heaq(heaq, goldens):
     assert e_rec == pytest.approx(goldens['G14']['value'], rel=REL)
 
 
+def test_reciprocal_of_a_charged_box_G18_and_torsions_G19(phenol, goldens):
+    """Phenol in water (the water model of this force field file carries -0.02 e per molecule: Q = -9.98 e once the
+    solute charges are zeroed): the reference literal is the plain Ewald sum, WITHOUT the neutralising-background term
+    -pi Kc Q^2/(2 V alpha^2) = -213.66 kJ/mol."""
+    c = phenol
+    q = c['charge'].copy()
+    q[c['resname'] == 'aaa'] = 0.0
+    assert abs(q.sum() + 9.98) < 1e-9
+    alpha = np.sqrt(-np.log(2 * 5e-4)) / 1.0
+    e_rec, _ = O.ewald_reciprocal(c['positions'], c['box'], q, alpha, 16)
+    assert e_rec == pytest.approx(goldens['G18']['value'], rel=REL)
+    plasma = -np.pi * O.KC * q.sum() ** 2 / (2 * np.prod(c['box']) * alpha ** 2)
+    assert abs(e_rec + plasma - goldens['G18']['value']) > 200
+    e_tor = O.periodic_torsions(c['torsions'], c['torsion_n'], c['torsion_phase'], c['torsion_k'], c['positions'], c['box'],
+                                want_forces=False)[0]
+    assert e_tor == pytest.approx(goldens['G19']['value'], rel=1e-12)
+
+
 def test_softcore_golden_G15(heaq, goldens):
     """SolvationSystem's softcore force (systems.py:266-272) on HEAQ at lambda_vdw = 0.5: pair sum over the
     (solute, solvent) interaction group with OpenMM's built-in switch + the CustomNonbondedForce long-range
