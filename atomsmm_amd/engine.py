@@ -603,12 +603,17 @@ class Engine:
             raise NotImplementedError('softcore force: overlapping interaction-group sets')
         names = list(getattr(force, '_offset_parameters', []))
         allp = np.array(force._particles, dtype=np.float64).reshape(n, -1)
+        if allp.shape[1] == 2:                         # per-particle (sigma, epsilon) only: AlchemicalSoftcoreCVForce
+            allp = np.concatenate([np.zeros((n, 1)), allp], axis=1)
         base = allp[:, :3]
         scales = np.stack([allp[:, 3 * (k + 1):3 * (k + 2)] for k in range(len(names))]) if names else np.zeros((0, n, 3))
         codes = np.zeros(n)
         codes[sorted(set1)] = 1.0
         codes[sorted(set2)] = 2.0
         lam_name = d['lambda_name']
+        if 'lambda_value' in d:                        # a constant written into the expression, not a Context parameter
+            lam_name = '__softcore_lambda_%d' % len(self.entries)
+            self.parameters[lam_name] = float(d['lambda_value'])
         rc = force._cutoff
         rswitch = force._switch if force.getUseSwitchingFunction() else None
         excl = np.array(force._exclusions, dtype=np.int32).reshape(-1, 2)

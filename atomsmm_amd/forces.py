@@ -144,6 +144,9 @@ def describe_energy(energy, global_parameters=None):
             desc.update(family='softcore', lambda_name=m.group(1))
         elif m2 and 'x=1/((r/sigma)^6+0.5*(1-%s))' % m2.group(1) in aux:
             desc.update(family='softcore', lambda_name=m2.group(1))
+            fixed = _first_number(parts[1:], m2.group(1))
+            if fixed is not None:
+                desc['lambda_value'] = fixed          # AlchemicalSoftcoreCVForce: `lambda = 0.4` among the definitions
         elif head == '4*epsilon*x*(x-1)' and 'x=(sigma/r)^6' in aux:
             desc.update(family='lj')                                   # systems.py:749: the collective variable
         elif re.fullmatch(r'4\*epsilon\*x\*\(x-1\)\+' + num + r'\*chargeprod/r', head) and 'x=(sigma/r)^6' in aux:

@@ -363,6 +363,9 @@ class CustomNonbondedForce(Force, _GlobalParams):
     def getNumInteractionGroups(self):
         return len(self._groups)
 
+    def getInteractionGroupParameters(self, index):
+        return [set(self._groups[index][0]), set(self._groups[index][1])]
+
     def addEnergyParameterDerivative(self, name):
         self._derivs.append(name)
 
@@ -907,6 +910,13 @@ class Context:
         new = [float(md_value(a[0])), float(md_value(b[1])), float(md_value(c[2]))]
         if not np.allclose(new, self._engine.box, rtol=0, atol=1e-12):
             raise OpenMMException('changing the box of a live Context is not supported by the HIP path')
+
+    def setState(self, state):
+        """Positions and velocities (those the State carries) of another Context's State."""
+        if state._x is not None:
+            self._engine.set_positions(state._x)
+        if state._v is not None:
+            self._engine.set_velocities(state._v)
 
     def getMolecules(self):
         """Connected components of the bond graph (bonds of the bonded forces + constraints), as OpenMM's

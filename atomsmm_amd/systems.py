@@ -390,7 +390,9 @@ class AlchemicalRespaSystem(openmm.System):
                 short_range.setForceGroup(1)
                 self.addForce(short_range)
 
-    def get_alchemical_vdw_force(self):
+    def get_alchemical_vdw_force(self, parameter_values=[1]):
+        if self._use_softcore:
+            return AlchemicalSoftcoreCVForce(self, parameter_values)
         return self._alchemical_vdw_force
 
     @staticmethod
@@ -437,3 +439,58 @@ class AlchemicalRespaSystem(openmm.System):
             force.setUseSwitchingFunction(nonbonded.getUseSwitchingFunction())
             force.setSwitchingDistance(nonbonded.getSwitchingDistance())
             force.setUseLongRangeCorrection(nonbonded.getUseDispersionCorrection())
+
+
+class AlchemicalSoftcoreCVForce(object):
+    """The softcore solute-solvent energy at a grid of coupling-parameter values, each in its own force group of a
+    private System / Context (systems.py:412-470): the collective variables E0, E1, ... used for reweighting."""
+
+    def __init__(self, alchemical_system, grid):
+        self._system = openmm.System()
+        for i in range(alchemical_system.getNumParticles()):
+            self._system.addParticle(alchemical_system.getParticleMass(i))
+        self._system.setDefaultPeriodicBoxVectors(*alchemical_system.getDefaultPeriodicBoxVectors())
+        self._context = None
+        self._numForces = len(grid)
+        original = alchemical_system._alchemical_vdw_force
+        for index, value in enumerate(grid):
+            ljsoft = '4*lambda*epsilon*x*(x - 1)'
+            ljsoft += '; x = 1/((r/sigma)^6 + 0.5*(1-lambda))'
+            ljsoft += '; lambda = {}'.format(value)
+            ljsoft += '; sigma = 0.5*(sigma1 + sigma2)'
+            ljsoft += '; epsilon = sqrt(epsilon1*epsilon2)'
+            force = openmm.CustomNonbondedForce(ljsoft)
+            force.setNonbondedMethod(original.getNonbondedMethod())
+            for parameter in ['sigma', 'epsilon']:
+                force.addPerParticleParameter(parameter)
+            for i in range(original.getNumParticles()):
+                _, sigma, epsilon = original.getParticleParameters(i)
+                force.addParticle((sigma, epsilon))
+            for i in range(original.getNumExclusions()):
+                force.addExclusion(*original.getExclusionParticles(i))
+            force.setCutoffDistance(original.getCutoffDistance())
+            force.setUseSwitchingFunction(original.getUseSwitchingFunction())
+            force.setSwitchingDistance(original.getSwitchingDistance())
+            if value != 0.0:
+                force.setUseLongRangeCorrection(original.getUseLongRangeCorrection())
+            for i in range(original.getNumInteractionGroups()):
+                force.addInteractionGroup(*original.getInteractionGroupParameters(i))
+            force.setForceGroup(index)
+            self._system.addForce(force)
+
+    def getNumCollectiveVariables(self):
+        return self._numForces
+
+    def getCollectiveVariableName(self, index):
+        return 'E{}'.format(index)
+
+    def getCollectiveVariableValues(self, context):
+        import numpy as np
+        if self._context is None:
+            self._context = openmm.Context(self._system, openmm.CustomIntegrator(0), context.getPlatform())
+        self._context.setState(context.getState(getPositions=True))
+        energy = np.empty(self._numForces)
+        for index in range(self._numForces):
+            state = self._context.getState(getEnergy=True, groups=set([index]))
+            energy[index] = md_value(state.getPotentialEnergy())
+        return energy

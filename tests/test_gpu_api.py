@@ -505,3 +505,11 @@ def test_AlchemicalRespaSystem_with_softcore(phenol):              # tests/test_
                         'CustomBondForce': -53.526446723139806, 'CustomBondForce(1)': -53.374675325650806,
                         'CustomNonbondedForce(1)': -24.140118811594814, 'CustomNonbondedForce(2)': -24.140118811594814,
                         'Total': -17901.852560765})
+    # the collective variables E0..E5: the softcore energy at lambda = 0, 0.2, ..., 1 (systems.py:412-470)
+    context = openmm.Context(system, openmm.CustomIntegrator(0), openmm.Platform.getPlatformByName('Reference'))
+    context.setPositions(positions)
+    force = solvation_system.get_alchemical_vdw_force([i / 5 for i in range(6)])
+    values = force.getCollectiveVariableValues(context)
+    assert [force.getCollectiveVariableName(i) for i in range(force.getNumCollectiveVariables())] == ['E%d' % i for i in range(6)]
+    assert values == pytest.approx([0.0, -10.071581499620784, -19.66450283710424, -28.284595753200428, -35.004158250494505,
+                                    -37.9416812137183])
