@@ -17,6 +17,8 @@ BOND_HARMONIC, ANGLE_HARMONIC, BOND_LJC, BOND_NEAR, TORSION_PERIODIC, BOND_EWALD
 BOND_VIRIAL_HARMONIC, BOND_VIRIAL_LJ = 6, 7
 OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE, OP_EXPR, OP_BATH = 1, 2, 3, 4, 5, 6, 7
 OP_SAVE_REF, OP_CONSTRAIN_X, OP_CONSTRAIN_V = 8, 9, 10
+OP_ALLREDUCE = 11
+COMM_ID_BYTES = 128
 MAX_SLOTS, SLOT_X, SLOT_V = 64, 62, 63
 GROUP_ALL = 32   # pseudo-group of the force symbol `f` (all groups)
 KC = 138.935456   # forces.py:407
@@ -33,6 +35,7 @@ EXPORTS = [
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
     'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
+    'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_allreduce',
 ]
 
 
@@ -84,6 +87,9 @@ def lib():
         L.amm_set_stream.argtypes = [vp, vp]
         L.amm_set_slice.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_synchronize.argtypes = [vp]
+        L.amm_comm_unique_id.argtypes = [C.c_char_p, C.c_char_p]
+        L.amm_comm_init.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
+        L.amm_comm_allreduce.argtypes = [vp, vp, C.c_int64]
         L.amm_check.argtypes = [vp]
         L.amm_pair_create.argtypes = [vp, C.POINTER(PairDesc), dp, dp, dp, ip, C.c_int32, C.c_double, ip]
         L.amm_pair_set_params.argtypes = [vp, C.c_int32, dp, dp, dp]
@@ -169,6 +175,7 @@ class HipContext:
         _chk(L.amm_create(self.n, bp, self.device, C.c_void_p(stream), C.byref(h)))
         self.h = h
         self.rank, self.world = rank, world
+        self.has_comm = False
         if world > 1:
             _chk(L.amm_set_slice(self.h, rank, world))
         self._keep = []
@@ -254,6 +261,29 @@ class HipContext:
         d_, dp_ = _hd(distances)
         assert len(p_) == len(d_)
         _chk(lib().amm_constraints_create(self.h, pp, dp_, len(d_), float(tolerance)))
+
+    # --- the library's own RCCL communicator (csrc/comm.hip)
+    @staticmethod
+    def rccl_path():
+        """The librccl that torch already carries in this process (one copy must serve both)."""
+        import torch
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        return path.encode() if os.path.exists(path) else None
+
+    @classmethod
+    def comm_unique_id(cls):
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _chk(lib().amm_comm_unique_id(cls.rccl_path(), buf))
+        return buf.raw
+
+    def comm_init(self, id_bytes):
+        if len(id_bytes) != COMM_ID_BYTES:
+            raise ValueError('communicator id must be %d bytes' % COMM_ID_BYTES)
+        _chk(lib().amm_comm_init(self.h, self.rccl_path(), bytes(id_bytes), self.rank, self.world))
+        self.has_comm = True
+
+    def comm_allreduce(self, tensor):
+        _chk(lib().amm_comm_allreduce(self.h, _ptr(tensor), tensor.numel()))
 
     def bath_define(self, z, kT):
         bid = C.c_int32(-1)

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['abi.hip', 'pair.hip', 'bonded.hip', 'integrate.hip', 'pme.hip', 'expr.hip', 'constraints.hip']
+SOURCES = ['abi.hip', 'pair.hip', 'bonded.hip', 'integrate.hip', 'pme.hip', 'expr.hip', 'constraints.hip', 'comm.hip']
 HEADERS = ['amm_ctx.h', 'pair_math.h', 'erfcx_table.h', 'device_utils.h', 'expr_vm.h', os.path.join('..', '..', 'include', 'atomsmm_hip.h')]
 LIB = os.path.join(HERE, 'libatomsmm_hip.so')
 ARCH = 'gfx950'
@@ -27,7 +27,7 @@ def build_hip(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get('HIPCC', 'hipcc')
     cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB] + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ['-lhipfft']
+          [os.path.join(CSRC, s) for s in SOURCES] + ['-lhipfft', '-ldl']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -73,6 +73,7 @@ int amm_create(int32_t n_atoms, const double h_box[3], int32_t device, void *str
 int amm_destroy(amm_ctx *ctx) {
     if (!ctx) return 0;
     (void)hipStreamSynchronize(ctx->stream);
+    amm_comm_destroy_impl(ctx);
     for (auto &f : ctx->forces) {
         if (f.pair) {
             amm_pair_free(f.pair);
@@ -532,6 +533,28 @@ int amm_bath_define(amm_ctx *ctx, double z, double kT, int32_t *bath_id) {
     return 0;
 }
 
+int amm_comm_unique_id(const char *rccl_path, uint8_t id[AMM_COMM_ID_BYTES]) {
+    if (!id) {
+        amm_set_error("amm_comm_unique_id: null output");
+        return 1;
+    }
+    return amm_comm_unique_id_impl(rccl_path, id);
+}
+int amm_comm_init(amm_ctx *ctx, const char *rccl_path, const uint8_t id[AMM_COMM_ID_BYTES], int32_t rank, int32_t world) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) {
+        amm_set_error("amm_comm_init: bad arguments");
+        return 1;
+    }
+    return amm_comm_init_impl(ctx, rccl_path, id, rank, world);
+}
+int amm_comm_allreduce(amm_ctx *ctx, double *d_buf, int64_t count) {
+    if (!ctx || !d_buf || count < 0) {
+        amm_set_error("amm_comm_allreduce: bad arguments");
+        return 1;
+    }
+    return amm_comm_allreduce_impl(ctx, d_buf, (size_t)count);
+}
+
 int amm_expr_seed(amm_ctx *ctx, uint64_t seed) {
     ctx->expr_seed = seed;
     ctx->expr_counter = 0;
@@ -769,6 +792,13 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     return 1;
                 }
                 if (amm_bath_impl(ctx, ctx->baths[op.a], ctx->d_v, (1ull << 63) | ++ctx->expr_counter)) return 1;
+            } break;
+            case AMM_OP_ALLREDUCE: {
+                if (op.a < 0 || op.a >= AMM_MAX_SLOTS || !ctx->slots[op.a]) {
+                    amm_set_error("amm_run_ops: ALLREDUCE of an unbound buffer");
+                    return 1;
+                }
+                if (amm_comm_allreduce_impl(ctx, ctx->slots[op.a], 3 * (size_t)ctx->n)) return 1;
             } break;
             default: amm_set_error("amm_run_ops: unknown op"); return 1;
             }

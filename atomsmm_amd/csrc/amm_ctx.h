@@ -169,7 +169,14 @@ struct amm_ctx {
     PairForce *prechecked[2] = {nullptr, nullptr};   // lists whose displacement trigger the last integration kernel evaluated
     int n_prechecked = 0;
     double skin_out = -1.0;        // outer Verlet buffer for pair forces created afterwards (<= 0: default)
+    void *comm = nullptr;          // ncclComm_t of the library's own communicator (comm.hip), or none
 };
+
+// comm.hip
+int amm_comm_unique_id_impl(const char *rccl_path, unsigned char *out);
+int amm_comm_init_impl(amm_ctx *ctx, const char *rccl_path, const unsigned char *id_bytes, int rank, int world);
+int amm_comm_destroy_impl(amm_ctx *ctx);
+int amm_comm_allreduce_impl(amm_ctx *ctx, double *d_buf, size_t count);
 
 // implemented in pair.hip / cells.hip / bonded.hip / integrate.hip
 int amm_pair_build_consts(const amm_pair_desc &d, PairConsts &pc);

@@ -17,6 +17,7 @@ Design (MI355X-first, not OpenMM's):
 
 There is no CPU path: creating a Context without the built HIP library or without a GPU raises.
 """
+import os
 import math
 import re
 
@@ -177,9 +178,18 @@ class Engine:
         dist = torch.distributed
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        # AMM_FORCE_COLLECTIVES=1: a 1-rank job takes the multi-rank code path (collectives over a 1-rank group), to
+        # measure its host-side cost on a single GPU
+        self._coll = self.world > 1 or (os.environ.get('AMM_FORCE_COLLECTIVES') == '1' and dist.is_available()
+                                        and dist.is_initialized())
         device = int(properties.get('DeviceIndex', torch.cuda.current_device() if torch.cuda.is_available() else 0))
         self.ctx = _context_factory(n, self.box, device=device, rank=self.rank, world=self.world)
         self.n = n
+        self._native_comm = False
+        self._native_ops = {}
+        if self._coll and hasattr(self.ctx, 'comm_init') and dist.get_backend() == 'nccl' \
+                and os.environ.get('AMM_NATIVE_COMM', '1') != '0':
+            self._init_native_comm(dist)
         dev = self.ctx.torch_device
         f64 = torch.float64
         self.x = torch.zeros((n, 3), dtype=f64, device=dev)
@@ -772,8 +782,11 @@ class Engine:
 
     # ------------------------------------------------------------------------------- getState
     def _allreduce(self, tensor):
-        if self.world > 1:
-            self.torch.distributed.all_reduce(tensor)
+        if self._coll:
+            if self._native_comm:
+                self.ctx.comm_allreduce(tensor)
+            else:
+                self.torch.distributed.all_reduce(tensor)
 
     def get_state(self, want_pos, want_vel, want_forces, want_energy, mask):
         torch = self.torch
@@ -797,7 +810,7 @@ class Engine:
                     self.ctx.force_eval(entry.recip, self.x, fb, accumulate=True, energy=e_bond)
                     self.ctx.pme_set_sliced(entry.recip, getattr(entry, 'recip_sliced', False))
             self.ctx.check()
-            if self.world > 1:
+            if self._coll:
                 self._allreduce(fp)
                 if want_energy:
                     self._allreduce(e_pair)
@@ -837,7 +850,7 @@ class Engine:
         members = [e for e in self.entries if (e.group == g if g != 'all' else True)]
         pair_ids = [pid for e in members for pid in e.pair_ids]
         terms = [t for e in members for t in e.terms]
-        reduced = self.world > 1 and bool(pair_ids)
+        reduced = self._coll and bool(pair_ids)
         ids = list(pair_ids)
         if terms:
             ids.append(self._make_bonded(terms, sliced=reduced))
@@ -1129,9 +1142,27 @@ class Engine:
             return None
         return [(-1 if s == '-' else 1, name) for s, name in re.findall(r'([+-]?)([A-Za-z_][A-Za-z_0-9]*)', text)]
 
+    def _init_native_comm(self, dist):
+        """Give the library its own RCCL communicator (csrc/comm.hip): the all-reduce after the EVAL of a sliced group
+        becomes an op of the step program and whole runs of steps stay inside ONE amm_run_ops call, instead of ~10 host
+        round trips per outer step (measured 480 us/step of host time).  torch.distributed only carries the 128-byte id."""
+        box = [None]
+        if self.rank == 0:
+            box[0] = self.ctx.comm_unique_id()
+        dist.broadcast_object_list(box, src=0)
+        self.ctx.comm_init(box[0])
+        self._native_comm = True
+
     def _run(self, ops, repeat):
-        if self.world == 1:
+        if not self._coll:
             self.ctx.run_ops([op for op in ops if not isinstance(op, tuple)], repeat)
+            return
+        if self._native_comm:
+            native = self._native_ops.get(id(ops))
+            if native is None or native[0] is not ops:
+                native = (ops, [B.Op(B.OP_ALLREDUCE, op[1], 0, 0, 0.0) if isinstance(op, tuple) else op for op in ops])
+                self._native_ops[id(ops)] = native
+            self.ctx.run_ops(native[1], repeat)
             return
         segments, current = [], []
         for op in ops:
@@ -1171,7 +1202,7 @@ class Engine:
             if sc is not None and sc['lambda_name'] == name:
                 out = torch.zeros(1, dtype=torch.float64, device=self.x.device)
                 self.ctx.pair_energy_derivative(sc['pid'], self.x, out)
-                if self.world > 1:
+                if self._coll:
                     self._allreduce(out)
                 h = 1e-6
                 up, dn = dict(self.parameters), dict(self.parameters)

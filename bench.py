@@ -127,8 +127,9 @@ def main():
     if backend != 'nccl':
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get('AMM_FORCE_COLLECTIVES') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
         else:

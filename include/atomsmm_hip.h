@@ -17,7 +17,9 @@
  *   - one context per process per GPU; not thread-safe.
  *   - atom decomposition: amm_set_slice(rank, world) makes pair forces compute only the atoms of
  *     this rank's slice (rows of other atoms are written as 0), so that an all-reduce(sum) over
- *     ranks (RCCL, done by the host through torch.distributed) yields the full force.
+ *     ranks yields the full force: either issued by the host (torch.distributed) between amm_run_ops
+ *     calls, or by the library itself on its own RCCL communicator (amm_comm_init + AMM_OP_ALLREDUCE),
+ *     which keeps a whole multi-rank step program inside one amm_run_ops call.
  */
 #ifndef ATOMSMM_HIP_H
 #define ATOMSMM_HIP_H
@@ -101,7 +103,9 @@ enum {
     AMM_OP_SAVE_REF = 8,    /* reference positions of the constraint solver <- x (start of a step)                   */
     AMM_OP_CONSTRAIN_X = 9, /* addConstrainPositions (propagators.py:250, 1129): SHAKE along the reference bond vectors,
                                then reference <- x                                                                    */
-    AMM_OP_CONSTRAIN_V = 10 /* addConstrainVelocities (propagators.py:272, 1131): RATTLE                              */
+    AMM_OP_CONSTRAIN_V = 10,/* addConstrainVelocities (propagators.py:272, 1131): RATTLE                              */
+    AMM_OP_ALLREDUCE = 11   /* buf[a] <- sum over ranks of buf[a] (RCCL, the context's own communicator: amm_comm_init):
+                               the exchange of atom decomposition after the EVAL of a sliced group      */
 };
 typedef struct {
     int32_t op, a, b, c;
@@ -119,6 +123,16 @@ int amm_create(int32_t n_atoms, const double h_box[3], int32_t device, void *str
 int amm_destroy(amm_ctx *ctx);
 int amm_set_stream(amm_ctx *ctx, void *stream);
 int amm_set_slice(amm_ctx *ctx, int32_t rank, int32_t world);
+/* The library's own RCCL communicator (one rank per process per GPU).  Rank 0 makes an id (amm_comm_unique_id), the
+ * host distributes its 128 bytes to all ranks by any means (torch.distributed broadcast, MPI, a file) and every rank
+ * calls amm_comm_init (collective, blocks until all ranks joined).  rccl_path: the librccl to bind (a torch process
+ * passes torch/lib/librccl.so so that one copy serves both), NULL = the dynamic loader's default.
+ * No reference counterpart: AtomsMM/OpenMM are single-device. */
+#define AMM_COMM_ID_BYTES 128
+int amm_comm_unique_id(const char *rccl_path, uint8_t id[AMM_COMM_ID_BYTES]);
+int amm_comm_init(amm_ctx *ctx, const char *rccl_path, const uint8_t id[AMM_COMM_ID_BYTES], int32_t rank, int32_t world);
+/* in-place sum over ranks of count doubles in device memory, on the context's stream */
+int amm_comm_allreduce(amm_ctx *ctx, double *d_buf, int64_t count);
 int amm_synchronize(amm_ctx *ctx);
 /* Raises pending device-side errors (neighbour-list overflow, NaN guard): returns non-zero + message. Synchronises. */
 int amm_check(amm_ctx *ctx);

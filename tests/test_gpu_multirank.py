@@ -42,7 +42,7 @@ def _simulate(nsteps, pme=False):
     stats = eng.ctx.pair_stats(eng.pair_force_ids(2)[0])
     return dict(x=st.getPositions(asNumpy=True)._value, v=st.getVelocities(asNumpy=True)._value,
                 f=st.getForces(asNumpy=True)._value, e=st.getPotentialEnergy()._value, e0=e0,
-                slice_atoms=stats['n_slice_atoms'], world=eng.world)
+                slice_atoms=stats['n_slice_atoms'], world=eng.world, native_comm=eng._native_comm)
 
 
 def _worker(rank, world, port, ret, pme=False):
@@ -93,3 +93,41 @@ def test_two_ranks_match_single_rank_bit_for_bit(pme):
             assert np.array_equal(out[r]['f'], single['f'])
         assert out[r]['e0'] == pytest.approx(single['e0'], rel=1e-13)
         assert out[r]['e'] == pytest.approx(single['e'], rel=1e-13)
+
+
+def _rccl_worker(port, ret, pme):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['AMM_FORCE_COLLECTIVES'] = '1'       # a 1-rank job takes the multi-rank code path
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        ret[0] = _simulate(3, pme)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('pme', [False, True])
+def test_library_owned_rccl_communicator(pme):
+    """The step program with AMM_OP_ALLREDUCE ops on the library's own RCCL communicator (csrc/comm.hip), over a 1-rank
+    group (RCCL refuses two ranks on one GPU): ncclCommInitRank from a broadcast id, ncclAllReduce on the context's
+    stream inside amm_run_ops, energies through amm_comm_allreduce -- same bits as the plain single-process run."""
+    import torch.multiprocessing as mp
+    single = _simulate(3, pme)
+    assert not single['native_comm']
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as manager:
+        ret = manager.dict()
+        p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret, pme))
+        p.start()
+        p.join(120)
+        if p.is_alive():
+            p.kill()
+            raise AssertionError('the RCCL rank did not finish within 120 s')
+        assert p.exitcode == 0
+        out = dict(ret)[0]
+    assert out['native_comm'] and out['slice_atoms'] == 3000
+    for key in ('x', 'v', 'f'):
+        assert np.array_equal(out[key], single[key]), key
+    assert out['e'] == single['e'] and out['e0'] == single['e0']
