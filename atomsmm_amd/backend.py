@@ -35,7 +35,7 @@ EXPORTS = [
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
     'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
-    'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_allreduce',
+    'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_allreduce', 'amm_comm_stats',
 ]
 
 
@@ -90,6 +90,7 @@ def lib():
         L.amm_comm_unique_id.argtypes = [C.c_char_p, C.c_char_p]
         L.amm_comm_init.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
         L.amm_comm_allreduce.argtypes = [vp, vp, C.c_int64]
+        L.amm_comm_stats.argtypes = [vp, C.POINTER(C.c_int64)]
         L.amm_check.argtypes = [vp]
         L.amm_pair_create.argtypes = [vp, C.POINTER(PairDesc), dp, dp, dp, ip, C.c_int32, C.c_double, ip]
         L.amm_pair_set_params.argtypes = [vp, C.c_int32, dp, dp, dp]
@@ -284,6 +285,11 @@ class HipContext:
 
     def comm_allreduce(self, tensor):
         _chk(lib().amm_comm_allreduce(self.h, _ptr(tensor), tensor.numel()))
+
+    def comm_stats(self):
+        out = (C.c_int64 * 2)()
+        _chk(lib().amm_comm_stats(self.h, out))
+        return dict(calls=out[0], doubles=out[1])
 
     def bath_define(self, z, kT):
         bid = C.c_int32(-1)

@@ -170,6 +170,7 @@ struct amm_ctx {
     int n_prechecked = 0;
     double skin_out = -1.0;        // outer Verlet buffer for pair forces created afterwards (<= 0: default)
     void *comm = nullptr;          // ncclComm_t of the library's own communicator (comm.hip), or none
+    long long comm_calls = 0, comm_doubles = 0;     // collectives issued / doubles per rank they carried
 };
 
 // comm.hip

@@ -111,5 +111,7 @@ int amm_comm_allreduce_impl(amm_ctx *ctx, double *d_buf, size_t count) {
     }
     ncclResult_t r = g_rccl.AllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
     if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+    ctx->comm_calls++;
+    ctx->comm_doubles += (long long)count;
     return 0;
 }

@@ -205,6 +205,8 @@ class Engine:
         self._share_lists()
         self._slots = {}
         self._buffers = {}
+        self._arena_free = []
+        self._arena_contiguous = True
         self._group_defs = {}
         self._valid = {}
         self._interpreted = None    # None: undecided; True: general (host-walked) step programs
@@ -759,13 +761,29 @@ class Engine:
         raise NotImplementedError('Context.reinitialize: create a new Context instead')
 
     # per-DOF variables live in named device buffers
-    def _buffer(self, name):
+    def _buffer(self, name, together=()):
+        """Per-DOF buffer `name`.  Buffers are carved from arenas; `together` names buffers to create in the same breath as
+        neighbours in memory: the force buffers of the sliced groups, whose all-reduces then travel as one message when
+        they follow one another (AMM_OP_ALLREDUCE)."""
         if name not in self._buffers:
-            t = self.torch.zeros((self.n, 3), dtype=self.torch.float64, device=self.x.device)
+            names = [name] + [other for other in together if other != name and other not in self._buffers]
+            if len(self._arena_free) < len(names) or (len(names) > 1 and not self._arena_contiguous):
+                count = max(8, len(names))
+                arena = self.torch.zeros((count, self.n, 3), dtype=self.torch.float64, device=self.x.device)
+                leftovers = self._arena_free
+                self._arena_free = [arena[k] for k in range(count)]
+                self._arena_contiguous = True
+            else:
+                leftovers = []
             integ = self.integrator
-            if isinstance(integ, mm.CustomIntegrator) and name in integ._pnames:
-                t.fill_(integ._pvalues[integ._pnames.index(name)])
-            self._buffers[name] = t
+            for nm in sorted(names):
+                t = self._arena_free.pop(0)
+                if isinstance(integ, mm.CustomIntegrator) and nm in integ._pnames:
+                    t.fill_(integ._pvalues[integ._pnames.index(nm)])
+                self._buffers[nm] = t
+            if leftovers:
+                self._arena_free += leftovers
+                self._arena_contiguous = False
         return self._buffers[name]
 
     def fill_per_dof(self, name, value):
@@ -860,6 +878,8 @@ class Engine:
                 self.ctx.pme_set_sliced(e.recip, reduced)
                 ids.append(e.recip)
         index = B.GROUP_ALL if g == 'all' else int(g)
+        if reduced and g != 'all':
+            self._buffer('f{}'.format(g), together=['f{}'.format(e.group) for e in self.entries if e.pair_ids])
         slot = self._slot('f' if g == 'all' else 'f{}'.format(g))
         self.ctx.group_define(index, slot, ids)
         self._group_defs[g] = (index, slot, reduced)

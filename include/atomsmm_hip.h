@@ -133,6 +133,9 @@ int amm_comm_unique_id(const char *rccl_path, uint8_t id[AMM_COMM_ID_BYTES]);
 int amm_comm_init(amm_ctx *ctx, const char *rccl_path, const uint8_t id[AMM_COMM_ID_BYTES], int32_t rank, int32_t world);
 /* in-place sum over ranks of count doubles in device memory, on the context's stream */
 int amm_comm_allreduce(amm_ctx *ctx, double *d_buf, int64_t count);
+/* out[0] = collectives issued so far, out[1] = doubles per rank they carried (AMM_OP_ALLREDUCE ops on buffers that are
+ * neighbours in memory are merged into one message) */
+int amm_comm_stats(amm_ctx *ctx, int64_t out[2]);
 int amm_synchronize(amm_ctx *ctx);
 /* Raises pending device-side errors (neighbour-list overflow, NaN guard): returns non-zero + message. Synchronises. */
 int amm_check(amm_ctx *ctx);

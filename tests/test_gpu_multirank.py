@@ -36,13 +36,16 @@ def _simulate(nsteps, pme=False):
     sim.context.setPositions(c['positions'] * unit.nanometers)
     sim.context.setVelocities(c['velocities'])
     e0 = sim.context.getState(getEnergy=True).getPotentialEnergy()._value
-    sim.step(nsteps)
-    st = sim.context.getState(getPositions=True, getVelocities=True, getEnergy=True, getForces=True, groups={0, 1, 2})
     eng = sim.context._engine
+    before = eng.ctx.comm_stats() if eng._native_comm else None
+    sim.step(nsteps)
+    after = eng.ctx.comm_stats() if eng._native_comm else None
+    st = sim.context.getState(getPositions=True, getVelocities=True, getEnergy=True, getForces=True, groups={0, 1, 2})
     stats = eng.ctx.pair_stats(eng.pair_force_ids(2)[0])
     return dict(x=st.getPositions(asNumpy=True)._value, v=st.getVelocities(asNumpy=True)._value,
                 f=st.getForces(asNumpy=True)._value, e=st.getPotentialEnergy()._value, e0=e0,
-                slice_atoms=stats['n_slice_atoms'], world=eng.world, native_comm=eng._native_comm)
+                slice_atoms=stats['n_slice_atoms'], world=eng.world, native_comm=eng._native_comm,
+                comm=None if before is None else {k: after[k] - before[k] for k in after})
 
 
 def _worker(rank, world, port, ret, pme=False):
@@ -131,3 +134,8 @@ def test_library_owned_rccl_communicator(pme):
     for key in ('x', 'v', 'f'):
         assert np.array_equal(out[key], single[key]), key
     assert out['e'] == single['e'] and out['e0'] == single['e0']
+    # [4,2,1]: the outer force once and the near force twice per step = 3 buffers of 3N doubles; the two evaluated at the
+    # same positions (step boundary) are neighbours in memory and travel as one message; the first step also evaluates
+    # both at its start
+    assert out['comm']['doubles'] == (3 * 3 + 2) * 9000, out['comm']
+    assert out['comm']['calls'] == 2 * 3 + 1, out['comm']
