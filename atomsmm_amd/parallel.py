@@ -11,7 +11,9 @@ neighbour-list rebuild decisions (made on device from identical positions) agree
 
 Per outer step of RespaPropagator([4,2,1]) that is 3 collectives of 3N doubles (2.36 MB at N = 98 304): 1 x f2 and
 2 x f1; group 0 (bond lists) is never reduced.  The engine (atomsmm_amd.engine) inserts the collective after the
-EVAL op of every group that contains a pair force; this module holds the slice arithmetic and thin wrappers."""
+EVAL op of every group that contains a pair force: with backend "nccl" as an AMM_OP_ALLREDUCE op on the library's own
+RCCL communicator (csrc/comm.hip; buffers that are neighbours in memory share one message), otherwise as a
+torch.distributed call between op segments; this module holds the slice arithmetic and thin wrappers."""
 import numpy as np
 
 
