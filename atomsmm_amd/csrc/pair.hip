@@ -640,6 +640,9 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, Pa
                 pj[u] = A.posq_s[js[u]];
                 lj[u] = A.lj_s[js[u]];
             }
+            // the guest's candidates are the FRONT part of the row (walked first): once every row of this wavefront is
+            // past its front part, the trips skip the guest arithmetic (its contribution there is an exact zero)
+            const bool guest_trip = GFAM >= 0 && __builtin_amdgcn_ballot_w64(k0 < nfront) != 0ull;
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const double dx = amm_min_image(pi.x - pj[u].x, A.box.L[0], A.box.invL[0]);
@@ -656,7 +659,7 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, Pa
                 fy += fr * dy;
                 fz += fr * dz;
                 if (EN) esum += pass ? e : 0.0;
-                if (GFAM >= 0) {
+                if (GFAM >= 0 && guest_trip) {
                     double eg, frg;
                     amm_pair_math<GFAM, 0, false, false>(gc, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, eg, frg, s_tab);
                     frg = (pass && r2 < gc.rc2) ? frg : 0.0;
