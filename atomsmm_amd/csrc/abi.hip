@@ -132,6 +132,11 @@ int amm_check(amm_ctx *ctx) {
         if (!pf || !pf->built) continue;
         int flags[8];
         AMM_HIP(hipMemcpy(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        if (flags[7]) {
+            amm_set_error("cell list overflow in pair force " + std::to_string(id) + ": a cell holds " + std::to_string(flags[6]) +
+                          " atoms > capacity " + std::to_string(pf->capc) + " (local density more than doubled since the first build)");
+            return 2;
+        }
         if (flags[1]) {
             amm_set_error("neighbour list overflow in pair force " + std::to_string(id) + ": " + std::to_string(flags[2]) +
                           " neighbours > capacity " + std::to_string(pf->cap) +
@@ -211,8 +216,6 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     AMM_HIP(hipMalloc(&pf->d_cell_count, sizeof(int) * (nc + 1)));
     AMM_HIP(hipMemset(pf->d_cell_count, 0, sizeof(int) * (nc + 1)));
     AMM_HIP(hipMalloc(&pf->d_cell_start, sizeof(int) * (nc + 1)));
-    AMM_HIP(hipMalloc(&pf->d_cell_fill, sizeof(int) * (nc + 1)));
-    AMM_HIP(hipMalloc(&pf->d_perm_tmp, sizeof(int) * n));
     AMM_HIP(hipMalloc(&pf->d_perm, sizeof(int) * n));
     AMM_HIP(hipMalloc(&pf->d_inv_perm, sizeof(int) * n));
     AMM_HIP(hipMalloc(&pf->d_posq_s, sizeof(double4) * n));

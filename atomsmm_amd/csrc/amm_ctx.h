@@ -58,8 +58,10 @@ struct PairForce {
     double *d_q = nullptr, *d_hsig = nullptr, *d_seps2 = nullptr;
     int *d_excl_ptr = nullptr, *d_excl_idx = nullptr;
     CellGrid grid;
-    int *d_cell_of = nullptr, *d_cell_count = nullptr, *d_cell_start = nullptr, *d_cell_fill = nullptr;
-    int *d_perm_tmp = nullptr, *d_perm = nullptr, *d_inv_perm = nullptr;
+    int *d_cell_of = nullptr, *d_cell_count = nullptr, *d_cell_start = nullptr;
+    int *d_cell_members = nullptr;   // [ncell][capc] atoms of each cell in arrival order (k_cell_assign)
+    int capc = 0;
+    int *d_perm = nullptr, *d_inv_perm = nullptr;
     double4 *d_posq_s = nullptr;   // sorted: wrapped x,y,z and charge
     double2 *d_lj_s = nullptr;     // sorted: sigma/2, 2*sqrt(eps)
     float4 *d_pos4f_s = nullptr;   // sorted fp32 positions at the last list build

@@ -31,15 +31,21 @@ __device__ __forceinline__ void amm_st_l2(unsigned long long *p, unsigned long l
 
 
 // run by ONE 256-thread block (the last block of the histogram kernel): exclusive scan of count[0..ncell) ->
-// start[0..ncell], fill <- start, count <- 0.  Thread t scans the contiguous segment [t*per, (t+1)*per).
-__device__ __forceinline__ void amm_block_scan_counts(int ncell, int *count, int *start, int *fill) {
+// start[0..ncell], count <- 0 (fill <- start when given); returns the largest count.  Thread t scans the contiguous segment [t*per, (t+1)*per).
+__device__ __forceinline__ int amm_block_scan_counts(int ncell, int *count, int *start, int *fill = nullptr) {
     __shared__ int part[256];
+    __shared__ int s_most[256];
     const int t = threadIdx.x;
     const int per = (ncell + 255) / 256;
     const int c0 = min(t * per, ncell), c1 = min(c0 + per, ncell);
-    int sum = 0;
-    for (int c = c0; c < c1; ++c) sum += amm_ld_l2(&count[c]);
+    int sum = 0, most = 0;
+    for (int c = c0; c < c1; ++c) {
+        const int v = amm_ld_l2(&count[c]);
+        sum += v;
+        most = max(most, v);
+    }
     part[t] = sum;
+    s_most[t] = most;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
         const int add = t >= off ? part[t - off] : 0;
@@ -51,9 +57,15 @@ __device__ __forceinline__ void amm_block_scan_counts(int ncell, int *count, int
     for (int c = c0; c < c1; ++c) {
         const int v = amm_ld_l2(&count[c]);
         start[c] = run;
-        fill[c] = run;
+        if (fill) fill[c] = run;
         count[c] = 0;
         run += v;
     }
     if (t == 255) start[ncell] = part[255];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) s_most[t] = max(s_most[t], s_most[t + off]);
+        __syncthreads();
+    }
+    return s_most[0];
 }

@@ -90,11 +90,12 @@ __global__ void k_check_displacement(int n, const double *__restrict__ pos, cons
     if (!(d2 <= thr_out2)) flags[4] = 1;
 }
 
-// cell index of every atom + per-cell counts; the last block turns the counts into the exclusive scan
-// start[0..ncell] (fill <- start, count <- 0)
+// cell index of every atom + per-cell counts; the atom's arrival rank in its cell places it in the cell's fixed-size
+// member table (capc entries per cell, sized at the first build: no scatter pass that would need the scan first);
+// the last block turns the counts into the exclusive scan start[0..ncell] (count <- 0) and records the fullest cell
 __global__ void __launch_bounds__(256) k_cell_assign(int n, const double *__restrict__ pos, Box box, CellGrid g, int *cell_of,
-                              int *count, int *start, int *fill, double *xref, const int *flags, int *ticket, int which,
-                              int force) {
+                              int *count, int *start, int *members, int capc, double *xref, int *flags, int *ticket,
+                              int which, int force) {
     if (!force && !flags[which]) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -109,46 +110,71 @@ __global__ void __launch_bounds__(256) k_cell_assign(int n, const double *__rest
         }
         int cell = (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
         cell_of[i] = cell;
-        atomicAdd(&count[cell], 1);
+        const int rank = atomicAdd(&count[cell], 1);
+        if (members) {
+            if (rank < capc) members[(size_t)cell * capc + rank] = i;
+            else flags[7] = 1;            // reported by amm_check: the density grew beyond the member tables
+        }
     }
     if (!amm_last_block(ticket)) return;
-    amm_block_scan_counts(g.ncell, count, start, fill);
+    const int fullest = amm_block_scan_counts(g.ncell, count, start);
+    if (threadIdx.x == 0) flags[6] = fullest;
 }
 
-__global__ void k_cell_fill(int n, const int *__restrict__ cell_of, int *fill, int *perm_tmp, const int *flags, int which,
-                            int force) {
-    if (!force && !flags[which]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int slot = atomicAdd(&fill[cell_of[i]], 1);
-    perm_tmp[slot] = i;
-}
-
-// one wavefront per cell: rank sort by atom index -> deterministic order whatever the atomics did; the lane
-// that places atom i at sorted slot s also writes the fp32 copy of its wrapped position (the list build only has
-// to find a SUPERSET of the pairs within rlist -- the traversal re-tests r^2 < rc^2 in fp64 -- so it runs on the
-// fp32 pipe with a margin) and inv_perm[i] = s
-__global__ void k_cell_sort(int ncell, const int *__restrict__ start, const int *__restrict__ perm_tmp, int *perm,
-                            const double *__restrict__ pos, Box box, float4 *pos4f_s, int *inv_perm, const int *flags,
-                            int which, int force) {
-    if (!force && !flags[which]) return;
-    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    int lane = threadIdx.x & 63;
+// rebuild: one wavefront per cell ranks the cell's members by atom index -> deterministic order whatever the atomics
+// did; the lane that places atom i at sorted slot s also writes the fp32 copy of its wrapped position (the list build
+// only has to find a SUPERSET of the pairs within rlist -- the traversal re-tests r^2 < rc^2 in fp64 -- so it runs on
+// the fp32 pipe with a margin), inv_perm[i] = s and, when asked (posq_s), the fp64 sorted copies of the evaluation
+// that follows.  No rebuild: only those sorted copies, with the permutation in place (the k_gather_sorted of this
+// evaluation) -- so a step without rebuild pays two conditional launches (this and k_cell_assign), not four.
+__global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, const int *__restrict__ start,
+                                                          const int *__restrict__ members, int capc, int *perm,
+                                                          const double *__restrict__ pos, Box box, float4 *pos4f_s,
+                                                          int *inv_perm, const int *flags, int which, int force,
+                                                          const double *__restrict__ q, const double *__restrict__ hsig,
+                                                          const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!force && !flags[which]) {
+        if (posq_s && gid < n) {
+            const int i = perm[gid];
+            double4 p;
+            p.x = wrap1(pos[3 * i], box.L[0], box.invL[0]);
+            p.y = wrap1(pos[3 * i + 1], box.L[1], box.invL[1]);
+            p.z = wrap1(pos[3 * i + 2], box.L[2], box.invL[2]);
+            p.w = q[i];
+            posq_s[gid] = p;
+            lj_s[gid] = make_double2(hsig[i], seps2[i]);
+        }
+        return;
+    }
+    const int wave = gid >> 6;
+    const int lane = threadIdx.x & 63;
     if (wave >= ncell) return;
-    int b = start[wave], e = start[wave + 1];
-    for (int a = b + lane; a < e; a += 64) {
-        int me = perm_tmp[a];
+    const int b = start[wave];
+    const int cnt = min(start[wave + 1] - b, capc);
+    const int *mem = members + (size_t)wave * capc;
+    for (int a = lane; a < cnt; a += 64) {
+        const int me = mem[a];
         int rank = 0;
-        for (int k = b; k < e; ++k) rank += perm_tmp[k] < me;
+        for (int k = 0; k < cnt; ++k) rank += mem[k] < me;
         const int sl = b + rank;
         perm[sl] = me;
+        double4 pd;
+        pd.x = wrap1(pos[3 * me], box.L[0], box.invL[0]);
+        pd.y = wrap1(pos[3 * me + 1], box.L[1], box.invL[1]);
+        pd.z = wrap1(pos[3 * me + 2], box.L[2], box.invL[2]);
         float4 p;
-        p.x = (float)wrap1(pos[3 * me], box.L[0], box.invL[0]);
-        p.y = (float)wrap1(pos[3 * me + 1], box.L[1], box.invL[1]);
-        p.z = (float)wrap1(pos[3 * me + 2], box.L[2], box.invL[2]);
+        p.x = (float)pd.x;
+        p.y = (float)pd.y;
+        p.z = (float)pd.z;
         p.w = 0.f;
         pos4f_s[sl] = p;
         inv_perm[me] = sl;
+        if (posq_s) {
+            pd.w = q[me];
+            posq_s[sl] = pd;
+            lj_s[sl] = make_double2(hsig[me], seps2[me]);
+        }
     }
 }
 
@@ -824,19 +850,23 @@ static int setup_grid(amm_ctx *ctx, PairForce *pf) {
 
 // cell list -> candidate sweep.  direct = false: OUTER list (radius rc + skin_out, conditional on flags[4]);
 // direct = true (single-list mode, skin_out <= skin): straight into the traversed inner list (flags[0]).
-static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int force, bool count_only, bool direct) {
+static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int force, bool count_only, bool direct,
+                            PairForce *gather_for = nullptr) {
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
     const int which = direct ? 0 : 4;
     hipLaunchKernelGGL(k_cell_assign, dim3(nb), dim3(256), 0, st, n, d_pos, ctx->box, pf->grid, pf->d_cell_of,
-                       pf->d_cell_count, pf->d_cell_start, pf->d_cell_fill, direct ? pf->d_xref : pf->d_xref_out, pf->d_flags,
-                       pf->d_ticket, which, force);
-    hipLaunchKernelGGL(k_cell_fill, dim3(nb), dim3(256), 0, st, n, pf->d_cell_of, pf->d_cell_fill, pf->d_perm_tmp,
-                       pf->d_flags, which, force);
-    hipLaunchKernelGGL(k_cell_sort, dim3((pf->grid.ncell * 64 + 255) / 256), dim3(256), 0, st, pf->grid.ncell,
-                       pf->d_cell_start, pf->d_perm_tmp, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s, pf->d_inv_perm,
-                       pf->d_flags, which, force);
+                       pf->d_cell_count, pf->d_cell_start, pf->d_cell_members, pf->capc, direct ? pf->d_xref : pf->d_xref_out,
+                       pf->d_flags, pf->d_ticket, which, force);
+    if (!pf->d_cell_members) return 0;         // sizing pass of the first build: only the counts were wanted
+    // gather_for: the sorted fp64 copies of the evaluation that follows ride on the same launch
+    PairForce *gf = gather_for;
+    const long sort_threads = std::max((long)pf->grid.ncell * 64, gf ? (long)n : 0L);
+    hipLaunchKernelGGL(k_cell_sort_gather, dim3((unsigned)((sort_threads + 255) / 256)), dim3(256), 0, st, pf->grid.ncell, n,
+                       pf->d_cell_start, pf->d_cell_members, pf->capc, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s,
+                       pf->d_inv_perm, pf->d_flags, which, force, gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr,
+                       gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr, gf ? gf->d_lj_s : (double2 *)nullptr);
     const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
@@ -926,6 +956,15 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         AMM_HIP(hipMalloc(&pf->d_blockstats, sizeof(unsigned long long) * 3 * nblk));
     }
     int flags[8];
+    {
+        // member tables of the cell list: twice the fullest cell of the first configuration + 16
+        pf->capc = 0;
+        if (cell_build_chain(ctx, pf, d_pos, 1, true, true)) return 1;
+        AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+        AMM_HIP(hipStreamSynchronize(ctx->stream));
+        pf->capc = 2 * flags[6] + 16;
+        AMM_HIP(hipMalloc(&pf->d_cell_members, sizeof(int) * (size_t)pf->grid.ncell * pf->capc));
+    }
     pf->dual = pf->skin_out > pf->skin * (1 + 1e-9);
     if (pf->dual) {
         // outer list: count, size, build
@@ -979,6 +1018,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     }
     // the neighbour list may belong to another, longer-ranged pair force (amm_pair_share_list)
     PairForce *L = pf->host ? pf->host : pf;
+    bool gathered = false;
     if (!L->built) {
         if (first_build(ctx, L, d_pos)) return 1;
     } else if (L->checked_epoch == ctx->pos_epoch && L->checked_pos == d_pos) {
@@ -993,13 +1033,15 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             if (cell_build_chain(ctx, L, d_pos, 0, false, false)) return 1;
             if (prune_chain(ctx, L, d_pos, 0, false)) return 1;
         } else {
-            if (cell_build_chain(ctx, L, d_pos, 0, false, true)) return 1;
+            if (cell_build_chain(ctx, L, d_pos, 0, false, true, pf)) return 1;
+            gathered = true;
         }
     }
     L->checked_epoch = ctx->pos_epoch;
     L->checked_pos = d_pos;
-    hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, n, L->d_perm, d_pos, pf->d_q, pf->d_hsig,
-                       pf->d_seps2, ctx->box, pf->d_posq_s, pf->d_lj_s);
+    if (!gathered)
+        hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, n, L->d_perm, d_pos, pf->d_q, pf->d_hsig,
+                           pf->d_seps2, ctx->box, pf->d_posq_s, pf->d_lj_s);
     pf->s_begin = L->s_begin;
     pf->s_end = L->s_end;
     pf->lpa = L->lpa;
@@ -1115,7 +1157,7 @@ bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host) {
 
 int amm_pair_free(PairForce *pf) {
     void *ptrs[] = {pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_excl_ptr, pf->d_excl_idx, pf->d_cell_of, pf->d_cell_count,
-                    pf->d_cell_start, pf->d_cell_fill, pf->d_perm_tmp, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
+                    pf->d_cell_start, pf->d_cell_members, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
                     pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near, pf->d_nl_out, pf->d_nnb_out,
                     pf->d_nnb_scratch, pf->d_xref_out, pf->d_ticket};
     for (void *p : ptrs)
