@@ -402,8 +402,18 @@ int amm_bonded_add_terms(amm_ctx *ctx, int32_t force_id, int32_t kind, const int
     }
     if (kind == AMM_BOND_LJC && desc) bs->ljc_Kc = desc->Kc;
     bs->periodic[kind] = periodic;
-    bs->h_idx[kind].insert(bs->h_idx[kind].end(), h_idx, h_idx + (size_t)n_terms * ar);
-    for (size_t k = 0; k < (size_t)n_terms * np; ++k) bs->h_par[kind].push_back(h_params[k] * scale);
+    // Terms whose energy is identically zero are not stored: the exceptions of a water model (chargeprod = 0,
+    // epsilon = 0: SURVEY.md 8a-6, `tests/test_systems.py:146` expects their energy to be 0.0) would otherwise be
+    // evaluated in every inner RESPA iteration -- 3 of the 6 terms of a flexible water.
+    for (int t = 0; t < n_terms; ++t) {
+        const double *pr = h_params + (size_t)t * np;
+        bool zero = false;
+        if (kind == AMM_BOND_LJC || kind == AMM_BOND_NEAR) zero = pr[0] == 0.0 && pr[2] == 0.0;
+        else if (kind == AMM_BOND_EWALD_EXCL) zero = pr[0] == 0.0;
+        if (zero) continue;
+        bs->h_idx[kind].insert(bs->h_idx[kind].end(), h_idx + (size_t)t * ar, h_idx + (size_t)(t + 1) * ar);
+        for (int k = 0; k < np; ++k) bs->h_par[kind].push_back(pr[k] * scale);
+    }
     return 0;
 }
 

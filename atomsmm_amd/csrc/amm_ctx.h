@@ -115,6 +115,11 @@ struct BondedSet {
     int4 *d_rec_l = nullptr;       // atoms of the term as slots within their connected component
     int *d_comp_ptr = nullptr, *d_comp_atoms = nullptr;   // connected components of the term graph (CSR)
     int ncomp = 0, max_comp = 0;
+    // term-parallel inner loop: every component has at most G terms (G lanes per component) -> lane l evaluates term l
+    bool terms_ok = false;
+    int4 *d_term_l = nullptr;                 // [ncomp*G] atoms of the term as component slots (x < 0: no term)
+    double4 *d_term_q = nullptr;              // [ncomp*G] parameters + kind/periodic code
+    unsigned long long *d_atom_recs = nullptr; // [n] the atom's records as (term slot | role << 3) in 5-bit fields, count in bits 60..63
     double *d_epart = nullptr;
     int n_epart = 0;
 };

@@ -296,6 +296,9 @@ __device__ __forceinline__ double amm_div_mass(double num, double m, double r, b
 
 struct CompArgs {
     const int *comp_ptr, *comp_atoms;
+    const int4 *term_l;             // term-parallel variant (TERMS): one term per lane, see BondedSet
+    const double4 *term_q;
+    const unsigned long long *atom_recs;
     int ncomp, niter, npre;
     double *x, *v, *f0;
     const double *mass;
@@ -322,7 +325,12 @@ struct PosLds {
     __device__ __forceinline__ double get(int slot, int k) const { return k == 0 ? sx[slot] : (k == 1 ? sy[slot] : sz[slot]); }
 };
 
-template <int G, bool BATH>
+// TERMS: when no component has more terms than lanes, lane l evaluates the component's term l ONCE per iteration (all
+// roles), parks the forces in LDS, and every atom adds up ITS records from there in the same order as before -- the
+// same numbers in the same order, so still bit-identical to k_bonded, with each term computed once instead of once per
+// atom and a dependency chain of one term instead of the atom's whole record list (a water: 1 bond + 1 angle path per
+// iteration instead of 2 + 2).
+template <int G, bool BATH, bool TERMS>
 __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
     __shared__ double s_x[3][256];
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,15 +365,27 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
     }
     // this atom's term records stay in LDS across the iterations (first MAXR; the rest is re-read): the record loop
     // below is a real loop with ONE inlined copy of the term code, so the records need a dynamically indexed home
-    constexpr int MAXR = 4;
-    __shared__ int4 s_tl[MAXR][256];
-    __shared__ double4 s_tq[MAXR][256];
+    constexpr int MAXR = TERMS ? 1 : 4;
+    __shared__ int4 s_tl[TERMS ? 1 : MAXR][TERMS ? 1 : 256];
+    __shared__ double4 s_tq[TERMS ? 1 : MAXR][TERMS ? 1 : 256];
+    __shared__ double s_out[TERMS ? 12 : 1][TERMS ? 256 : 1];      // [role*3 + xyz][lane]: forces of the lane's term
     const int rb = has ? A.ref_ptr[a] : 0, nrec = has ? A.ref_ptr[a + 1] - rb : 0;
+    int4 my_tl = make_int4(-1, -1, -1, -1);
+    double4 my_tq = make_double4(0.0, 0.0, 0.0, 0.0);
+    unsigned long long my_recs = 0ull;
+    if (TERMS) {
+        if (cvalid) {
+            my_tl = C.term_l[tid];
+            my_tq = C.term_q[tid];
+        }
+        if (has) my_recs = C.atom_recs[a];
+    } else {
 #pragma unroll
-    for (int t = 0; t < MAXR; ++t) {
-        const int r = t < nrec ? rb + t : 0;      // record 0 always exists (the buffers hold at least one)
-        s_tl[t][threadIdx.x] = A.rec_l[r];
-        s_tq[t][threadIdx.x] = A.rec_q[r];
+        for (int t = 0; t < MAXR; ++t) {
+            const int r = t < nrec ? rb + t : 0;      // record 0 always exists (the buffers hold at least one)
+            s_tl[t][threadIdx.x] = A.rec_l[r];
+            s_tq[t][threadIdx.x] = A.rec_q[r];
+        }
     }
     const int gbase = (int)threadIdx.x - l;
     PosLds pos{&s_x[0][gbase], &s_x[1][gbase], &s_x[2][gbase]};
@@ -416,6 +436,33 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
             for (int xx = 0; xx < 3; ++xx)
                 f[xx] += role == 0 ? fo[0][xx] : (role == 1 ? fo[1][xx] : (role == 2 ? fo[2][xx] : fo[3][xx]));
         };
+        if (TERMS) {
+            double fo[4][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+            if (my_tl.x >= 0) {
+                const long long code = __double_as_longlong(my_tq.w);
+                const int ix[4] = {my_tl.x, my_tl.y, my_tl.z, my_tl.w};
+                const double p[3] = {my_tq.x, my_tq.y, my_tq.z};
+                double e;
+                bonded_term_forces(A, pos, ix, p, (int)(code & 7), (int)((code >> 5) & 1), fo, e);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int xx = 0; xx < 3; ++xx) s_out[TERMS ? r * 3 + xx : 0][TERMS ? threadIdx.x : 0] = fo[r][xx];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nr = (int)(my_recs >> 60);
+            unsigned long long rr = my_recs;
+            for (int t = 0; t < nr; ++t) {
+                const int rcode = (int)(rr & 31ull);
+                rr >>= 5;
+                const int src = gbase + (rcode & 7), row = 3 * (rcode >> 3);
+                f[0] += s_out[TERMS ? row : 0][TERMS ? src : 0];
+                f[1] += s_out[TERMS ? row + 1 : 0][TERMS ? src : 0];
+                f[2] += s_out[TERMS ? row + 2 : 0][TERMS ? src : 0];
+            }
+        } else
         // ONE inlined copy of the term code (it covers every bond-list kind: unrolling this loop over a register
         // cache multiplied the kernel to 10 k instructions, beyond the instruction cache)
         for (int t = 0; t < nrec; ++t) {
@@ -538,6 +585,54 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
     }
     bs->ncomp = ncomp;
     bs->max_comp = maxc;
+    // term tables of the term-parallel inner loop: terms numbered within their component in the order the records were
+    // laid down above (kind, term), so that an atom's packed (term slot, role) list repeats its record order
+    bs->terms_ok = maxc <= 8 && nref > 0;
+    if (bs->terms_ok) {
+        const int G = maxc <= 4 ? 4 : 8;
+        std::vector<int> nterm(ncomp, 0);
+        std::vector<int4> term_l((size_t)ncomp * G, make_int4(-1, -1, -1, -1));
+        std::vector<double4> term_q((size_t)ncomp * G, make_double4(0.0, 0.0, 0.0, 0.0));
+        std::vector<unsigned long long> atom_recs(n, 0ull);
+        std::vector<int> nrec_of(n, 0);
+        for (int kind = 0; kind < 8 && bs->terms_ok; ++kind)
+            for (int t = 0; t < bs->n_terms[kind] && bs->terms_ok; ++t) {
+                const int *at = &bs->h_idx[kind][(size_t)t * kArity[kind]];
+                const int c2 = comp_of[at[0]];
+                const int tl = nterm[c2]++;
+                if (tl >= G) {
+                    bs->terms_ok = false;
+                    break;
+                }
+                int lo[4] = {-1, -1, -1, -1};
+                for (int k = 0; k < kArity[kind]; ++k) lo[k] = local_of[at[k]];
+                term_l[(size_t)c2 * G + tl] = make_int4(lo[0], lo[1], lo[2], lo[3]);
+                double pr[3] = {0.0, 0.0, 0.0};
+                for (int k = 0; k < kNpar[kind]; ++k) pr[k] = bs->h_par[kind][(size_t)t * kNpar[kind] + k];
+                const long long code = (long long)kind | ((long long)(bs->periodic[kind] ? 1 : 0) << 5);
+                double w;
+                std::memcpy(&w, &code, sizeof(w));
+                term_q[(size_t)c2 * G + tl] = make_double4(pr[0], pr[1], pr[2], w);
+                for (int r = 0; r < kArity[kind]; ++r) {
+                    const int a = at[r];
+                    if (nrec_of[a] >= 12) {
+                        bs->terms_ok = false;
+                        break;
+                    }
+                    atom_recs[a] |= (unsigned long long)(tl | (r << 3)) << (5 * nrec_of[a]);
+                    nrec_of[a]++;
+                }
+            }
+        if (bs->terms_ok) {
+            for (int i = 0; i < n; ++i) atom_recs[i] |= (unsigned long long)nrec_of[i] << 60;
+            AMM_HIP(hipMalloc(&bs->d_term_l, sizeof(int4) * term_l.size()));
+            AMM_HIP(hipMalloc(&bs->d_term_q, sizeof(double4) * term_q.size()));
+            AMM_HIP(hipMalloc(&bs->d_atom_recs, sizeof(unsigned long long) * n));
+            AMM_HIP(hipMemcpy(bs->d_term_l, term_l.data(), sizeof(int4) * term_l.size(), hipMemcpyHostToDevice));
+            AMM_HIP(hipMemcpy(bs->d_term_q, term_q.data(), sizeof(double4) * term_q.size(), hipMemcpyHostToDevice));
+            AMM_HIP(hipMemcpy(bs->d_atom_recs, atom_recs.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice));
+        }
+    }
     AMM_HIP(hipMalloc(&bs->d_comp_ptr, sizeof(int) * (ncomp + 1)));
     AMM_HIP(hipMemcpy(bs->d_comp_ptr, comp_ptr.data(), sizeof(int) * (ncomp + 1), hipMemcpyHostToDevice));
     AMM_HIP(hipMalloc(&bs->d_comp_atoms, sizeof(int) * n));
@@ -689,14 +784,21 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     C.bath_kT = bath ? bath->kT : 0.0;
     C.seed = ctx->expr_seed;
     C.counter0 = ctx->expr_counter;
+    static const bool no_terms = getenv("AMM_NO_TERM_LANES") != nullptr;     // tuning knob (A/B)
+    const bool terms = bs->terms_ok && !no_terms;
+    C.term_l = bs->d_term_l;
+    C.term_q = bs->d_term_q;
+    C.atom_recs = bs->d_atom_recs;
+    if (bath) ctx->expr_counter += (unsigned long long)niter;      // one BATH op per iteration, as the unfused sequence counts
+#define AMM_LAUNCH_INNER(GG, BB, TT) hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT>), grid, block, 0, ctx->stream, A, C)
     if (bath) {
-        ctx->expr_counter += (unsigned long long)niter;      // one BATH op per iteration, as the unfused sequence counts
-        if (G == 4) hipLaunchKernelGGL((k_inner_lanes<4, true>), grid, block, 0, ctx->stream, A, C);
-        else hipLaunchKernelGGL((k_inner_lanes<8, true>), grid, block, 0, ctx->stream, A, C);
+        if (G == 4) { if (terms) AMM_LAUNCH_INNER(4, true, true); else AMM_LAUNCH_INNER(4, true, false); }
+        else { if (terms) AMM_LAUNCH_INNER(8, true, true); else AMM_LAUNCH_INNER(8, true, false); }
     } else {
-        if (G == 4) hipLaunchKernelGGL((k_inner_lanes<4, false>), grid, block, 0, ctx->stream, A, C);
-        else hipLaunchKernelGGL((k_inner_lanes<8, false>), grid, block, 0, ctx->stream, A, C);
+        if (G == 4) { if (terms) AMM_LAUNCH_INNER(4, false, true); else AMM_LAUNCH_INNER(4, false, false); }
+        else { if (terms) AMM_LAUNCH_INNER(8, false, true); else AMM_LAUNCH_INNER(8, false, false); }
     }
+#undef AMM_LAUNCH_INNER
     AMM_HIP(hipGetLastError());
     return 0;
 }
@@ -706,6 +808,9 @@ int amm_bonded_free(BondedSet *bs) {
     if (bs->d_rec_a) (void)hipFree(bs->d_rec_a);
     if (bs->d_rec_q) (void)hipFree(bs->d_rec_q);
     if (bs->d_rec_l) (void)hipFree(bs->d_rec_l);
+    if (bs->d_term_l) (void)hipFree(bs->d_term_l);
+    if (bs->d_term_q) (void)hipFree(bs->d_term_q);
+    if (bs->d_atom_recs) (void)hipFree(bs->d_atom_recs);
     if (bs->d_comp_ptr) (void)hipFree(bs->d_comp_ptr);
     if (bs->d_comp_atoms) (void)hipFree(bs->d_comp_atoms);
     if (bs->d_epart) (void)hipFree(bs->d_epart);
