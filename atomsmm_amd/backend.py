@@ -18,6 +18,7 @@ BOND_VIRIAL_HARMONIC, BOND_VIRIAL_LJ = 6, 7
 OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE, OP_EXPR, OP_BATH = 1, 2, 3, 4, 5, 6, 7
 OP_SAVE_REF, OP_CONSTRAIN_X, OP_CONSTRAIN_V = 8, 9, 10
 OP_ALLREDUCE = 11
+EXCHANGE_REDUCE, EXCHANGE_GATHER = 0, 1
 COMM_ID_BYTES = 128
 MAX_SLOTS, SLOT_X, SLOT_V = 64, 62, 63
 GROUP_ALL = 32   # pseudo-group of the force symbol `f` (all groups)
@@ -35,7 +36,7 @@ EXPORTS = [
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
     'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
-    'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_allreduce', 'amm_comm_stats',
+    'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
 ]
 
 
@@ -91,6 +92,9 @@ def lib():
         L.amm_comm_init.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
         L.amm_comm_allreduce.argtypes = [vp, vp, C.c_int64]
         L.amm_comm_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.amm_group_set_exchange.argtypes = [vp, C.c_int32, C.c_int32]
+        L.amm_bind_exchange.argtypes = [vp, vp, C.c_int64]
+        L.amm_exchange_finish.argtypes = [vp]
         L.amm_check.argtypes = [vp]
         L.amm_pair_create.argtypes = [vp, C.POINTER(PairDesc), dp, dp, dp, ip, C.c_int32, C.c_double, ip]
         L.amm_pair_set_params.argtypes = [vp, C.c_int32, dp, dp, dp]
@@ -335,6 +339,17 @@ class HipContext:
     def group_define(self, group, slot, force_ids):
         ids, p = _hi(np.asarray(force_ids, dtype=np.int32).reshape(-1))
         _chk(lib().amm_group_define(self.h, group, slot, p, len(ids)))
+
+    def group_set_exchange(self, group, mode):
+        _chk(lib().amm_group_set_exchange(self.h, int(group), int(mode)))
+
+    def bind_exchange(self, tensor):
+        """Exchange buffer of the all-gather mode: world * 2 * ceil(n/world) * 3 doubles, owned by the caller."""
+        self._keep.append(tensor)
+        _chk(lib().amm_bind_exchange(self.h, _ptr(tensor), tensor.numel()))
+
+    def exchange_finish(self):
+        _chk(lib().amm_exchange_finish(self.h))
 
     def run_ops(self, ops, repeat=1):
         arr = (Op * len(ops))(*ops)

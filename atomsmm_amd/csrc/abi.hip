@@ -606,6 +606,36 @@ int amm_group_define(amm_ctx *ctx, int32_t group, int32_t slot, const int32_t *f
     return 0;
 }
 
+// without a communicator of its own the library cannot complete an exchanged EVAL inside a program: such an EVAL must
+// be the LAST op of its amm_run_ops call; the host then gathers the chunks and calls amm_exchange_finish
+static int exchange_left_to_host(amm_ctx *ctx, bool last_op) {
+    if (!ctx->pending.active || last_op) return 0;
+    amm_set_error("amm_run_ops: without a communicator (amm_comm_init) an exchanged EVAL must be the last op of the call");
+    return 1;
+}
+
+int amm_group_set_exchange(amm_ctx *ctx, int32_t group, int32_t mode) {
+    if (!ctx || group < 0 || group >= AMM_MAX_GROUPS || (mode != AMM_EXCHANGE_REDUCE && mode != AMM_EXCHANGE_GATHER)) {
+        amm_set_error("amm_group_set_exchange: bad group or mode");
+        return 1;
+    }
+    ctx->groups[group].exchange = mode;
+    return 0;
+}
+int amm_bind_exchange(amm_ctx *ctx, double *d_buf, int64_t n_doubles) {
+    if (!ctx || (n_doubles > 0 && !d_buf) || n_doubles < 0) {
+        amm_set_error("amm_bind_exchange: bad arguments");
+        return 1;
+    }
+    ctx->d_xchg = d_buf;
+    ctx->xchg_doubles = n_doubles;
+    return 0;
+}
+int amm_exchange_finish(amm_ctx *ctx) {
+    if (!ctx) return 1;
+    return amm_exchange_finish_impl(ctx);
+}
+
 int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) {
     if (!ctx->d_x || !ctx->d_v || !ctx->d_mass) {
         amm_set_error("amm_run_ops: state not bound (amm_bind_state)");
@@ -724,8 +754,9 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     if (guest) {
                         PairForce *host = guest->host;
                         double *fg = ctx->slots[guest == pa ? g1.slot : g2.slot], *fh = ctx->slots[guest == pa ? g2.slot : g1.slot];
-                        if (amm_pair_can_eval_dual(ctx, guest, host)) {
-                            if (amm_pair_eval_impl(ctx, host, ctx->d_x, fh, 0, nullptr, guest, fg, 0)) return 1;
+                        if (g1.exchange == g2.exchange && amm_pair_can_eval_dual(ctx, guest, host)) {
+                            if (amm_pair_eval_impl(ctx, host, ctx->d_x, fh, 0, nullptr, guest, fg, 0, g1.exchange)) return 1;
+                            if (exchange_left_to_host(ctx, rep == repeat - 1 && k + 1 == n_ops - 1)) return 1;
                             k += 1;
                             continue;
                         }
@@ -745,6 +776,15 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     return 1;
                 }
                 if (g.forces.empty()) AMM_HIP(hipMemsetAsync(buf, 0, sizeof(double) * 3 * (size_t)ctx->n, ctx->stream));
+                if (g.exchange) {
+                    if (g.forces.size() != 1 || ctx->forces[g.forces[0]].type != 1) {
+                        amm_set_error("amm_run_ops: an exchanged group must hold exactly one pair force");
+                        return 1;
+                    }
+                    if (amm_pair_eval_impl(ctx, ctx->forces[g.forces[0]].pair, ctx->d_x, buf, 0, nullptr, nullptr, nullptr, 0, 1)) return 1;
+                    if (exchange_left_to_host(ctx, rep == repeat - 1 && k == n_ops - 1)) return 1;
+                    break;
+                }
                 for (size_t j = 0; j < g.forces.size(); ++j)
                     if (force_eval_dispatch(ctx, g.forces[j], ctx->d_x, buf, j > 0, nullptr)) return 1;
             } break;

@@ -147,6 +147,17 @@ struct BathDef {
 struct GroupDef {
     int slot = -1;
     std::vector<int> forces;
+    int exchange = 0;              // AMM_EXCHANGE_*: how the forces of the rank's slice reach the other ranks
+};
+
+// exchange of owner-computed force slices: the pair kernel leaves the rows of this rank's slice of the
+// cell-sorted order in chunk `rank` of the exchange buffer, the chunks are all-gathered, and k_unsort spreads the
+// gathered rows to the group's buffer in atom order (every rank holds the same permutation).
+struct PendingExchange {
+    bool active = false;
+    int per = 0, nf = 0;           // slots per rank; forces per chunk (2 after a dual evaluation)
+    const int *perm = nullptr;
+    double *force = nullptr, *gforce = nullptr;
 };
 
 struct amm_ctx {
@@ -177,6 +188,9 @@ struct amm_ctx {
     int n_prechecked = 0;
     double skin_out = -1.0;        // outer Verlet buffer for pair forces created afterwards (<= 0: default)
     void *comm = nullptr;          // ncclComm_t of the library's own communicator (comm.hip), or none
+    double *d_xchg = nullptr;      // caller-owned exchange buffer (amm_bind_exchange): world chunks of 2 x ceil(n/world) x 3 doubles
+    long long xchg_doubles = 0;
+    PendingExchange pending;
     long long comm_calls = 0, comm_doubles = 0;     // collectives issued / doubles per rank they carried
 };
 
@@ -185,11 +199,14 @@ int amm_comm_unique_id_impl(const char *rccl_path, unsigned char *out);
 int amm_comm_init_impl(amm_ctx *ctx, const char *rccl_path, const unsigned char *id_bytes, int rank, int world);
 int amm_comm_destroy_impl(amm_ctx *ctx);
 int amm_comm_allreduce_impl(amm_ctx *ctx, double *d_buf, size_t count);
+int amm_comm_allgather_impl(amm_ctx *ctx, double *d_buf, size_t count_per_rank);
+int amm_exchange_finish_impl(amm_ctx *ctx);
 
 // implemented in pair.hip / cells.hip / bonded.hip / integrate.hip
 int amm_pair_build_consts(const amm_pair_desc &d, PairConsts &pc);
 int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate,
-                       double *d_energy, PairForce *guest = nullptr, double *g_force = nullptr, int g_accumulate = 0);
+                       double *d_energy, PairForce *guest = nullptr, double *g_force = nullptr, int g_accumulate = 0,
+                       int exchange = 0);
 bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host);
 int amm_pair_free(PairForce *pf);
 int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate,

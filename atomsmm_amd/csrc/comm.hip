@@ -24,6 +24,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 } g_rccl;
 
@@ -48,8 +49,9 @@ int rccl_load(const char *path) {
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
     api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+    api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather || !api.GetErrorString) {
         amm_set_error("amm_comm: the RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce");
         dlclose(h);
         return 1;
@@ -113,5 +115,19 @@ int amm_comm_allreduce_impl(amm_ctx *ctx, double *d_buf, size_t count) {
     if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
     ctx->comm_calls++;
     ctx->comm_doubles += (long long)count;
+    return 0;
+}
+
+// in-place all-gather: chunk `rank` of d_buf (count_per_rank doubles) goes to every rank's d_buf, on the context's stream
+int amm_comm_allgather_impl(amm_ctx *ctx, double *d_buf, size_t count_per_rank) {
+    if (!ctx->comm) {
+        amm_set_error("all-gather without a communicator (amm_comm_init)");
+        return 1;
+    }
+    ncclResult_t r = g_rccl.AllGather(d_buf + (size_t)ctx->rank * count_per_rank, d_buf, count_per_rank, ncclDouble,
+                                      (ncclComm_t)ctx->comm, ctx->stream);
+    if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+    ctx->comm_calls++;
+    ctx->comm_doubles += (long long)count_per_rank;
     return 0;
 }

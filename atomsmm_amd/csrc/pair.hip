@@ -616,6 +616,7 @@ struct PairArgs {
     Box box;
     double *gforce;    // dual evaluation: force buffer of the guest force that shares this list (same particles)
     int gaccumulate;
+    int sorted_out;    // exchange by all-gather: rows go to force[3 (s - s_begin)] (this rank's chunk of the exchange buffer)
 };
 
 
@@ -708,7 +709,7 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, Pa
         }
     }
     if (valid && sub == 0) {
-        const int i = A.perm[s];
+        const int i = A.sorted_out ? s - A.s_begin : A.perm[s];
         if (GFAM >= 0) {
             if (A.gaccumulate) {
                 A.gforce[3 * i] += gx;
@@ -1007,8 +1008,40 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
 
 // guest != nullptr: `pf` owns the list `guest` traverses, both forces act on the same particles (checked by
 // amm_pair_can_eval_dual) and only forces are wanted: one pass writes pf's force to d_force and the guest's to g_force.
+__global__ void k_unsort(int n, int per, int nf, const int *__restrict__ perm, const double *__restrict__ xchg, double *force,
+                         double *gforce) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int r = s / per, loc = s - r * per;
+    const double *src = xchg + ((size_t)r * nf * per + loc) * 3;
+    const int i = perm[s];
+    force[3 * i] = src[0];
+    force[3 * i + 1] = src[1];
+    force[3 * i + 2] = src[2];
+    if (nf == 2) {
+        src += (size_t)per * 3;
+        gforce[3 * i] = src[0];
+        gforce[3 * i + 1] = src[1];
+        gforce[3 * i + 2] = src[2];
+    }
+}
+
+// second half of an exchanged evaluation: the gathered chunks -> the force buffers, in atom order
+int amm_exchange_finish_impl(amm_ctx *ctx) {
+    PendingExchange &pe = ctx->pending;
+    if (!pe.active) {
+        amm_set_error("amm_exchange_finish: no evaluation is waiting for its exchange");
+        return 1;
+    }
+    hipLaunchKernelGGL(k_unsort, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, pe.per, pe.nf, pe.perm, ctx->d_xchg,
+                       pe.force, pe.gforce);
+    AMM_HIP(hipGetLastError());
+    pe.active = false;
+    return 0;
+}
+
 int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate,
-                       double *d_energy, PairForce *guest, double *g_force, int g_accumulate) {
+                       double *d_energy, PairForce *guest, double *g_force, int g_accumulate, int exchange) {
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
@@ -1047,8 +1080,27 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     pf->lpa = L->lpa;
     pf->cap = L->cap;
     const int nslice = pf->s_end - pf->s_begin;
-    if (!accumulate && ctx->world > 1) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, st));
-    if (guest && !g_accumulate && ctx->world > 1) AMM_HIP(hipMemsetAsync(g_force, 0, sizeof(double) * 3 * (size_t)n, st));
+    const int per = (n + ctx->world - 1) / ctx->world, nf = guest ? 2 : 1;
+    double *out = d_force, *gout = g_force;
+    if (exchange) {
+        if (accumulate || g_accumulate || d_energy) {
+            amm_set_error("exchanged evaluation: forces only, no accumulation");
+            return 1;
+        }
+        if (ctx->pending.active) {
+            amm_set_error("exchanged evaluation while the previous one still waits for amm_exchange_finish");
+            return 1;
+        }
+        if (!ctx->d_xchg || ctx->xchg_doubles < (long long)ctx->world * 2 * per * 3) {
+            amm_set_error("exchanged evaluation: bind an exchange buffer of world * 2 * ceil(n/world) * 3 doubles (amm_bind_exchange)");
+            return 1;
+        }
+        out = ctx->d_xchg + (size_t)ctx->rank * nf * per * 3;       // this rank's chunk: [nf][per][3]
+        gout = out + (size_t)per * 3;
+    } else {
+        if (!accumulate && ctx->world > 1) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, st));
+        if (guest && !g_accumulate && ctx->world > 1) AMM_HIP(hipMemsetAsync(g_force, 0, sizeof(double) * 3 * (size_t)n, st));
+    }
     if (nslice > 0) {
         PairArgs A;
         A.s_begin = pf->s_begin;
@@ -1061,11 +1113,12 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         A.nnb_total = (pf == L && L->rnear_build > 0) ? L->d_nnb : nullptr;
         A.posq_s = pf->d_posq_s;
         A.lj_s = pf->d_lj_s;
-        A.force = d_force;
+        A.force = out;
         A.accumulate = accumulate;
         A.box = ctx->box;
-        A.gforce = g_force;
+        A.gforce = gout;
         A.gaccumulate = g_accumulate;
+        A.sorted_out = exchange ? 1 : 0;
         const long threads = (long)nslice << A.lpa_shift;
         const int nblk = (int)((threads + 255) / 256);
         const bool en = d_energy != nullptr;
@@ -1128,6 +1181,21 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         }
     }
     pf->n_evals++;
+    if (exchange) {
+        PendingExchange &pe = ctx->pending;
+        pe.active = true;
+        pe.per = per;
+        pe.nf = nf;
+        pe.perm = L->d_perm;
+        pe.force = d_force;
+        pe.gforce = g_force;
+        // with a communicator of its own the library completes the exchange; otherwise the host gathers the chunks
+        // (torch.distributed, MPI ...) and calls amm_exchange_finish
+        if (ctx->comm) {
+            if (amm_comm_allgather_impl(ctx, ctx->d_xchg, (size_t)nf * per * 3)) return 1;
+            if (amm_exchange_finish_impl(ctx)) return 1;
+        }
+    }
     return 0;
 }
 

@@ -192,6 +192,14 @@ class Engine:
             self._init_native_comm(dist)
         dev = self.ctx.torch_device
         f64 = torch.float64
+        # exchange of the owner-computed force slices: all-gather of the slices in cell-sorted order (1/world of the bytes
+        # of the all-reduce of zero-filled buffers; AMM_EXCHANGE=reduce keeps the latter) for groups of ONE pair force
+        self._gather = self._coll and hasattr(self.ctx, 'bind_exchange') and os.environ.get('AMM_EXCHANGE', 'gather') == 'gather'
+        self._gather_groups = set()
+        if self._gather:
+            self._per = (n + self.world - 1) // self.world
+            self._xchg = torch.zeros(self.world * 2 * self._per * 3, dtype=f64, device=dev)
+            self.ctx.bind_exchange(self._xchg)
         self.x = torch.zeros((n, 3), dtype=f64, device=dev)
         self.v = torch.zeros((n, 3), dtype=f64, device=dev)
         self.mass = torch.as_tensor(np.array(system._masses, dtype=np.float64), device=dev)
@@ -869,6 +877,8 @@ class Engine:
         pair_ids = [pid for e in members for pid in e.pair_ids]
         terms = [t for e in members for t in e.terms]
         reduced = self._coll and bool(pair_ids)
+        gather = reduced and self._gather and g != 'all' and len(pair_ids) == 1 and not terms and not any(
+            e.recip is not None and e.recip_group == g for e in self.entries)
         ids = list(pair_ids)
         if terms:
             ids.append(self._make_bonded(terms, sliced=reduced))
@@ -882,6 +892,10 @@ class Engine:
             self._buffer('f{}'.format(g), together=['f{}'.format(e.group) for e in self.entries if e.pair_ids])
         slot = self._slot('f' if g == 'all' else 'f{}'.format(g))
         self.ctx.group_define(index, slot, ids)
+        if gather:       # the EVAL op exchanges the slices itself: no all-reduce of the buffer afterwards
+            self.ctx.group_set_exchange(index, B.EXCHANGE_GATHER)
+            self._gather_groups.add(index)
+            reduced = False
         self._group_defs[g] = (index, slot, reduced)
         return self._group_defs[g]
 
@@ -1184,21 +1198,50 @@ class Engine:
                 self._native_ops[id(ops)] = native
             self.ctx.run_ops(native[1], repeat)
             return
-        segments, current = [], []
-        for op in ops:
-            if isinstance(op, tuple):
-                segments.append((current, op[1]))
-                current = []
-            else:
-                current.append(op)
+        # collectives driven from here (torch.distributed): the op list is cut after every all-reduce marker and after
+        # every EVAL of an all-gather group (the library leaves the rank's chunk in the exchange buffer and waits)
+        plan = self._native_ops.get(id(ops))
+        if plan is None or plan[0] is not ops:
+            segments, current = [], []
+            for op in ops:
+                if isinstance(op, tuple):
+                    segments.append((current, ('reduce', op[1])))
+                    current = []
+                else:
+                    current.append(op)
+                    if op.op == B.OP_EVAL and op.a in self._gather_groups:
+                        segments.append((current, ('gather', None)))
+                        current = []
+            plan = (ops, segments, current)
+            self._native_ops[id(ops)] = plan
+        _, segments, tail = plan
         inv = {slot: name for name, slot in self._slots.items()}
         for _ in range(repeat):
-            for seg, slot in segments:
+            for seg, (kind, slot) in segments:
                 if seg:
                     self.ctx.run_ops(seg, 1)
-                self.torch.distributed.all_reduce(self._buffers[inv[slot]])
-            if current:
-                self.ctx.run_ops(current, 1)
+                if kind == 'reduce':
+                    self.torch.distributed.all_reduce(self._buffers[inv[slot]])
+                else:
+                    self._host_gather(1)
+            if tail:
+                self.ctx.run_ops(tail, 1)
+
+    def _host_gather(self, nf):
+        """All-gather of the exchange chunks by torch.distributed (no library-owned communicator), then the unsort."""
+        dist = self.torch.distributed
+        count = nf * self._per * 3
+        chunks = [self._xchg[r * count:(r + 1) * count] for r in range(self.world)]
+        if dist.get_backend() == 'nccl':
+            dist.all_gather_into_tensor(self._xchg[:self.world * count], chunks[self.rank].clone())
+        else:                     # gloo (CPU tests / several ranks sharing one card): staged through the host
+            mine = chunks[self.rank].cpu()
+            parts = [self.torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine)
+            for r in range(self.world):
+                if r != self.rank:
+                    chunks[r].copy_(parts[r])
+        self.ctx.exchange_finish()
 
     @staticmethod
     def _program_key(valid, mirror):

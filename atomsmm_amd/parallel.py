@@ -4,9 +4,10 @@ on ROCm, "gloo" in the CPU tests).
 The periodic box shards by atoms, not by space: every rank holds all positions (7 MB at 98k atoms) and integrates
 all atoms redundantly -- O(N) work, cheaper than exchanging x and v -- while the O(N x neighbours) pair work is
 split: rank r evaluates the pair forces of a contiguous slice of the *cell-sorted* atom order (equal pair work for
-a homogeneous box) with full neighbour rows (owner-computes), writes zeros elsewhere, and one all-reduce(sum) per
-evaluated force group gives every rank the full force.  Each row has exactly one non-zero contributor, so the
-sum is exact and identical on all ranks whatever the reduction order: ranks stay in lock-step bit for bit, and the
+a homogeneous box) with full neighbour rows (owner-computes), and the ranks exchange their slices: by all-gather of
+the sorted slices (groups of one pair force: csrc/pair.hip k_unsort) or, for groups with further sliced terms, by
+writing zeros elsewhere and one all-reduce(sum) of the group buffer.  Each row has exactly one producer, so the
+result is exact and identical on all ranks whatever the collective's internal order: ranks stay in lock-step bit for bit, and the
 neighbour-list rebuild decisions (made on device from identical positions) agree without any host exchange.
 
 Per outer step of RespaPropagator([4,2,1]) that is 3 collectives of 3N doubles (2.36 MB at N = 98 304): 1 x f2 and

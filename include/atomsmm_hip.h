@@ -133,6 +133,17 @@ int amm_comm_unique_id(const char *rccl_path, uint8_t id[AMM_COMM_ID_BYTES]);
 int amm_comm_init(amm_ctx *ctx, const char *rccl_path, const uint8_t id[AMM_COMM_ID_BYTES], int32_t rank, int32_t world);
 /* in-place sum over ranks of count doubles in device memory, on the context's stream */
 int amm_comm_allreduce(amm_ctx *ctx, double *d_buf, int64_t count);
+/* Exchange of owner-computed force slices by ALL-GATHER instead of all-reduce (1/world of the bytes, no additions).
+ * A group in AMM_EXCHANGE_GATHER mode must hold exactly one pair force.  Its EVAL op leaves the rows of the rank's slice
+ * of the cell-sorted order in chunk `rank` of the exchange buffer (caller-owned, world x 2 x ceil(n/world) x 3 doubles;
+ * a dual evaluation fills [2][ceil(n/world)][3] per chunk, a single one [ceil(n/world)][3]), all-gathers the chunks on
+ * the library's communicator and spreads them to the group's buffer in atom order (every rank holds the same
+ * permutation).  Without a communicator the EVAL must be the last op of its amm_run_ops call: the host gathers the
+ * chunks (count per rank = forces x ceil(n/world) x 3 doubles) and calls amm_exchange_finish. */
+enum { AMM_EXCHANGE_REDUCE = 0, AMM_EXCHANGE_GATHER = 1 };
+int amm_group_set_exchange(amm_ctx *ctx, int32_t group, int32_t mode);
+int amm_bind_exchange(amm_ctx *ctx, double *d_buf, int64_t n_doubles);
+int amm_exchange_finish(amm_ctx *ctx);
 /* out[0] = collectives issued so far, out[1] = doubles per rank they carried (AMM_OP_ALLREDUCE ops on buffers that are
  * neighbours in memory are merged into one message) */
 int amm_comm_stats(amm_ctx *ctx, int64_t out[2]);

@@ -1,7 +1,8 @@
 """GPU test of the real multi-rank path on ONE MI355X: two processes share cuda:0 and talk over gloo (RCCL needs
 one GPU per rank; the driver's 8-GPU run uses backend nccl).  Each rank evaluates the pair forces of its slice of
-the cell-sorted order with the HIP kernels, the engine all-reduces the group buffers, every rank integrates all
-atoms: after 3 RESPA steps both ranks hold the SAME bits as a single-rank run."""
+the cell-sorted order with the HIP kernels into its chunk of the exchange buffer, the engine all-gathers the chunks
+(groups of one pair force) or all-reduces the group buffers (groups with further sliced terms), every rank integrates
+all atoms: after 3 RESPA steps both ranks hold the SAME bits as a single-rank run."""
 import os
 import socket
 
@@ -134,8 +135,9 @@ def test_library_owned_rccl_communicator(pme):
     for key in ('x', 'v', 'f'):
         assert np.array_equal(out[key], single[key]), key
     assert out['e'] == single['e'] and out['e0'] == single['e0']
-    # [4,2,1]: the outer force once and the near force twice per step = 3 buffers of 3N doubles; the two evaluated at the
-    # same positions (step boundary) are neighbours in memory and travel as one message; the first step also evaluates
-    # both at its start
+    # [4,2,1]: the outer force once and the near force twice per step = 3 x 3N doubles; the first step also evaluates
+    # both at its start.  Groups of one pair force exchange their slices by all-gather, and the two evaluated in one
+    # pass at the step boundary share a message; with PME the group-2 buffer also carries sliced exclusion and
+    # reciprocal-space terms and is all-reduced on its own
     assert out['comm']['doubles'] == (3 * 3 + 2) * 9000, out['comm']
-    assert out['comm']['calls'] == 2 * 3 + 1, out['comm']
+    assert out['comm']['calls'] == (2 * 3 + 1 if not pme else 3 * 3 + 2), out['comm']
