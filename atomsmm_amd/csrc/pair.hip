@@ -943,9 +943,11 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     AMM_HIP(hipMalloc(&pf->d_nnb_near, sizeof(int) * ns));
     AMM_HIP(hipMalloc(&pf->d_nnb_out, sizeof(int) * ns));
     AMM_HIP(hipMalloc(&pf->d_nnb_scratch, sizeof(int) * ns));
-    // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding
+    // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding, but not beyond 16 lanes: longer
+    // strides waste the tail of every row (measured on 1/8 slices of C3, scripts/probe_slices.py: dual pass 63.6 us
+    // with 16 lanes, 71.9 us with 64)
     int lpa = 1;
-    while (lpa < 64 && (long)nslice * lpa < 64L * 1024 * 8) lpa <<= 1;
+    while (lpa < 16 && (long)nslice * lpa < 64L * 1024 * 8) lpa <<= 1;
     if (const char *e = getenv("AMM_LPA")) lpa = atoi(e);
     pf->lpa = lpa;
     {
