@@ -950,14 +950,6 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     while (lpa < 16 && (long)nslice * lpa < 64L * 1024 * 8) lpa <<= 1;
     if (const char *e = getenv("AMM_LPA")) lpa = atoi(e);
     pf->lpa = lpa;
-    {
-        // waves per cell: enough that a cell's atoms are covered by about one batch per wave
-        const double per_cell = (double)n / pf->grid.ncell;
-        pf->parts = std::max(1, std::min(8, (int)std::ceil(per_cell / AMM_BATCH)));
-        const long t1 = (long)pf->grid.ncell * pf->parts * 64, t2 = (long)ns * 16;
-        const size_t nblk = (size_t)((std::max(t1, t2) + 255) / 256);
-        AMM_HIP(hipMalloc(&pf->d_blockstats, sizeof(unsigned long long) * 3 * nblk));
-    }
     int flags[8];
     {
         // member tables of the cell list: twice the fullest cell of the first configuration + 16
@@ -967,6 +959,13 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         AMM_HIP(hipStreamSynchronize(ctx->stream));
         pf->capc = 2 * flags[6] + 16;
         AMM_HIP(hipMalloc(&pf->d_cell_members, sizeof(int) * (size_t)pf->grid.ncell * pf->capc));
+        // waves per cell: enough that even the fullest cell's share is one batch per wave (a second batch walks the
+        // whole candidate stream again; measured at C3: 315 us with 4 parts, 331 us with the 3 that the mean suggests)
+        pf->parts = std::max(1, std::min(8, (int)std::ceil(1.15 * flags[6] / AMM_BATCH)));
+        if (const char *e = getenv("AMM_PARTS")) pf->parts = std::max(1, std::min(8, atoi(e)));
+        const long t1 = (long)pf->grid.ncell * pf->parts * 64, t2 = (long)ns * 16;
+        const size_t nblk = (size_t)((std::max(t1, t2) + 255) / 256);
+        AMM_HIP(hipMalloc(&pf->d_blockstats, sizeof(unsigned long long) * 3 * nblk));
     }
     pf->dual = pf->skin_out > pf->skin * (1 + 1e-9);
     if (pf->dual) {

@@ -30,11 +30,10 @@ def timed(fn, reps=20):
     return 1e3 * e0.elapsed_time(e1) / reps
 
 
-for world in (1, 2, 4, 8):
-    for lpa in (4, 8, 16, 32, 64):
-        if world == 1 and lpa > 16 or world >= 4 and lpa < 8:
-            continue
+for world, parts in ((1, 3), (1, 4), (2, 3), (2, 5), (4, 3), (4, 5), (4, 8), (8, 3), (8, 5), (8, 8)):
+    for lpa in (8 if world == 1 else 16,):
         os.environ['AMM_LPA'] = str(lpa)
+        os.environ['AMM_PARTS'] = str(parts)
         ctx = B.HipContext(n, c['box'], rank=0, world=world)
         fn = hip_pair(B, ctx, dn, c)
         ff = hip_pair(B, ctx, dd, c)
@@ -49,5 +48,10 @@ for world in (1, 2, 4, 8):
         E = B.OP_EVAL
         t_near = timed(lambda: ctx.run_ops([B.Op(E, 1, 0, 0, 0.0)], 1))
         t_dual = timed(lambda: ctx.run_ops([B.Op(E, 1, 0, 0, 0.0), B.Op(E, 2, 0, 0, 0.0)], 1))
-        print('world %d lpa %2d: near %.1f us, dual %.1f us (incl. cell chain no-ops + sorted copies)' % (world, lpa, t_near, t_dual), flush=True)
+        def rebuild():          # a uniform shift beyond skin/2 triggers the rebuild and keeps the geometry
+            x.add_(0.06)
+            ctx.run_ops([B.Op(E, 1, 0, 0, 0.0)], 1)
+        t_rebuild = timed(rebuild) - t_near
+        print('parts %d' % parts, 'world %d lpa %2d: near %.1f us, dual %.1f us (incl. cell chain no-ops + sorted copies), rebuild %.1f us' %
+              (world, lpa, t_near, t_dual, t_rebuild), flush=True)
         ctx.close()
