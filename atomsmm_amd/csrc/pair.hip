@@ -371,15 +371,28 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
             const int nt = min(AMM_BATCH, a_end - tb);
             float4 my = make_float4(0.f, 0.f, 0.f, 0.f);
             int exlo = 0x7fffffff, exhi = -1;             // slot range of {self, excluded partners}
+            int ex_p0 = 0, ex_n = 0;                      // lane t: first exclusion / number of exclusions of atom t
             if (lane < nt) {
                 my = pos4f_s[tb + lane];
                 const int i = perm[tb + lane];
                 exlo = exhi = tb + lane;
-                for (int k = excl_ptr[i]; k < excl_ptr[i + 1]; ++k) {
+                ex_p0 = excl_ptr[i];
+                ex_n = excl_ptr[i + 1] - ex_p0;
+                for (int k = ex_p0; k < ex_p0 + ex_n; ++k) {
                     const int es = inv_perm[excl_idx[k]];
                     exlo = min(exlo, es);
                     exhi = max(exhi, es);
                 }
+            }
+            // excluded partners of the batch's atoms as sorted slots, in registers (exl[t], lane j = j-th partner of atom
+            // t): the chunks that can hold one then need no memory at all -- four dependent loads per atom before, which a
+            // wave that has the SIMD almost to itself (a rank's slice of a small box) waited out one by one
+            int exl[AMM_BATCH];
+#pragma unroll
+            for (int t = 0; t < AMM_BATCH; ++t) {
+                exl[t] = -1;
+                const int p0 = __builtin_amdgcn_readlane(ex_p0, t), ne = __builtin_amdgcn_readlane(ex_n, t);
+                if (lane < ne) exl[t] = inv_perm[excl_idx[p0 + lane]];
             }
             int blo = exlo, bhi = exhi;                   // batch-wide range
             for (int off = 32; off > 0; off >>= 1) {
@@ -446,9 +459,14 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                         if (special) {       // wave-uniform branch, scalar loop over the atom's exclusions
                             const int st = tb + t;
                             unsigned long long m_excl = __builtin_amdgcn_ballot_w64(js[u] == st);
-                            const int i = perm[st];
-                            for (int k = excl_ptr[i]; k < excl_ptr[i + 1]; ++k)
-                                m_excl |= __builtin_amdgcn_ballot_w64(js[u] == inv_perm[excl_idx[k]]);
+                            const int ne = __builtin_amdgcn_readlane(ex_n, t);
+                            for (int k = 0; k < min(ne, 64); ++k)
+                                m_excl |= __builtin_amdgcn_ballot_w64(js[u] == __builtin_amdgcn_readlane(exl[t], k));
+                            if (ne > 64) {       // more partners than lanes: the rest from memory
+                                const int p0 = __builtin_amdgcn_readlane(ex_p0, t);
+                                for (int k = 64; k < ne; ++k)
+                                    m_excl |= __builtin_amdgcn_ballot_w64(js[u] == inv_perm[excl_idx[p0 + k]]);
+                            }
                             m_pass &= ~m_excl;
                         }
                         const unsigned long long m_near = m_pass & __builtin_amdgcn_ballot_w64(r2 < rnear2);
