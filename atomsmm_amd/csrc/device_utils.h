@@ -38,11 +38,26 @@ __device__ __forceinline__ int amm_block_scan_counts(int ncell, int *count, int 
     const int t = threadIdx.x;
     const int per = (ncell + 255) / 256;
     const int c0 = min(t * per, ncell), c1 = min(c0 + per, ncell);
+    // the counts were written by device-scope atomics and are read past the XCD's L2 (about a microsecond per load):
+    // up to 32 per thread are fetched in one go and kept in registers for the second sweep
+    constexpr int KEEP = 32;
+    int keep[KEEP];
+    const bool kept = per <= KEEP;
     int sum = 0, most = 0;
-    for (int c = c0; c < c1; ++c) {
-        const int v = amm_ld_l2(&count[c]);
-        sum += v;
-        most = max(most, v);
+    if (kept) {
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) keep[j] = (c0 + j < c1) ? amm_ld_l2(&count[c0 + j]) : 0;
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) {
+            sum += keep[j];
+            most = max(most, keep[j]);
+        }
+    } else {
+        for (int c = c0; c < c1; ++c) {
+            const int v = amm_ld_l2(&count[c]);
+            sum += v;
+            most = max(most, v);
+        }
     }
     part[t] = sum;
     s_most[t] = most;
@@ -54,12 +69,23 @@ __device__ __forceinline__ int amm_block_scan_counts(int ncell, int *count, int 
         __syncthreads();
     }
     int run = part[t] - sum;
-    for (int c = c0; c < c1; ++c) {
-        const int v = amm_ld_l2(&count[c]);
-        start[c] = run;
-        if (fill) fill[c] = run;
-        count[c] = 0;
-        run += v;
+    if (kept) {
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j)
+            if (c0 + j < c1) {
+                start[c0 + j] = run;
+                if (fill) fill[c0 + j] = run;
+                count[c0 + j] = 0;
+                run += keep[j];
+            }
+    } else {
+        for (int c = c0; c < c1; ++c) {
+            const int v = amm_ld_l2(&count[c]);
+            start[c] = run;
+            if (fill) fill[c] = run;
+            count[c] = 0;
+            run += v;
+        }
     }
     if (t == 255) start[ncell] = part[255];
     __syncthreads();
