@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libatomsmm_hip.so')
 
 NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE, LJ_VIRIAL = range(7)
-GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH, NO_SHIFT, GROUP_LJ = 1, 2, 4, 8, 16, 32
+GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH, NO_SHIFT, GROUP_LJ, GROUP_Q = 1, 2, 4, 8, 16, 32, 64
 BOND_HARMONIC, ANGLE_HARMONIC, BOND_LJC, BOND_NEAR, TORSION_PERIODIC, BOND_EWALD_EXCL = range(6)
 BOND_VIRIAL_HARMONIC, BOND_VIRIAL_LJ = 6, 7
 OP_EVAL, OP_KICK, OP_MOVE, OP_COPY, OP_COMBINE, OP_EXPR, OP_BATH = 1, 2, 3, 4, 5, 6, 7

@@ -88,6 +88,11 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
         in_group = qq == 2.0;
         qq = 0.0;
     }
+    if (c.flags & AMM_GROUP_Q) {           // wave-uniform flag: sig carries the sum of the atoms' set codes
+        in_group = sig == 3.0;
+        sig = 1.0;
+        eps4 = 0.0;
+    }
     if (GUARD) {
         if (!(c.rc0 - r >= 0.0)) return;   // step(rc0 - r), forces.py:661,714
     }

@@ -406,18 +406,32 @@ class Engine:
         entry.terms = bonded_terms(self.parameters)
         entry.constant = constant(self.parameters)
         lam = set(names) | set(enames)
+
+        def update(parameters, changed, force=False):
+            if not (lam & changed) and not force:
+                return False
+            p = self._effective(base, scales, names, parameters)
+            self.ctx.pair_set_params(pid, p[:, 0], p[:, 1], p[:, 2])
+            if entry.recip is not None:
+                self.ctx.pme_set_charges(entry.recip, p[:, 0])
+            entry.terms = bonded_terms(parameters)
+            entry.bonded_id = self._make_bonded(entry.terms, sliced=False) if entry.terms else None
+            entry.constant = constant(parameters)
+            return True
+
+        def reload():
+            # NonbondedForce.updateParametersInContext: particle and exception parameters are read again (their number
+            # and the exception pairs must not have changed, as in OpenMM)
+            fresh = np.array(nb._particles, dtype=np.float64).reshape(n, 3)
+            fresh_exc = np.array([r[2:] for r in nb._exceptions], dtype=np.float64).reshape(-1, 3)
+            if fresh_exc.shape != exc_base.shape:
+                raise mm.OpenMMException('updateParametersInContext: the number of exceptions has changed')
+            base[:] = fresh
+            exc_base[:] = fresh_exc
+            return update(self.parameters, set(), force=True)
+
+        entry.reload = reload
         if lam:
-            def update(parameters, changed):
-                if not (lam & changed):
-                    return False
-                p = self._effective(base, scales, names, parameters)
-                self.ctx.pair_set_params(pid, p[:, 0], p[:, 1], p[:, 2])
-                if entry.recip is not None:
-                    self.ctx.pme_set_charges(entry.recip, p[:, 0])
-                entry.terms = bonded_terms(parameters)
-                entry.bonded_id = self._make_bonded(entry.terms, sliced=False) if entry.terms else None
-                entry.constant = constant(parameters)
-                return True
             entry.update = update
             entry.depends = set(lam)
 
@@ -511,17 +525,22 @@ class Engine:
         codes = None
         if ngroups > 1:
             raise NotImplementedError('more than one interaction group')
+        sigma, eps = p[:, 1], p[:, 2]
         if ngroups == 1:
-            if not (d['family'] == 'lj' or d.get('lj_only')):
-                raise NotImplementedError('interaction groups on a force with electrostatics (coulomb_scaling)')
+            if not (d['family'] == 'lj' or d.get('lj_only') or d.get('coulomb_only')):
+                raise NotImplementedError('interaction groups on a force with both electrostatics and Lennard-Jones')
             set1, set2 = force._groups[0]
             if set1 & set2:
                 raise NotImplementedError('overlapping interaction-group sets')
             codes = np.zeros(n)
             codes[sorted(set1)] = 1.0
             codes[sorted(set2)] = 2.0
-            q, Kc = codes, 1.0
-            flags |= B.GROUP_LJ
+            if d.get('coulomb_only'):      # the expression has no sigma / epsilon: the sigma slot selects the pairs
+                sigma, eps = 2.0 * codes, np.zeros(n)
+                flags |= B.GROUP_Q
+            else:
+                q, Kc = codes, 1.0
+                flags |= B.GROUP_LJ
         elif d['family'] == 'lj' or d.get('lj_only'):
             q = np.zeros(n)
         rc = force._cutoff
@@ -552,8 +571,14 @@ class Engine:
         else:
             raise NotImplementedError('alchemical pair family ' + d['family'])
         excl = np.array(force._exclusions, dtype=np.int32).reshape(-1, 2)
-        pid = self._pair_create(desc, q, p[:, 1], p[:, 2], excl)
+        pid = self._pair_create(desc, q, sigma, eps, excl)
         entry.pair_ids.append(pid)
+        if d.get('coulomb_only'):
+            def reload():          # updateParametersInContext: the charges may have changed (reset_coulomb_scaling_factor)
+                fresh = np.array(force._particles, dtype=np.float64).reshape(n, -1)[:, 0]
+                self.ctx.pair_set_params(pid, fresh, sigma, eps)
+                return 'values'
+            entry.reload = reload
         lrc = 0.0
         if force.getUseLongRangeCorrection():
             if d['family'] != 'lj':
@@ -760,6 +785,23 @@ class Engine:
 
     def get_parameter(self, name):
         return self.parameters[name]
+
+    def update_force_parameters(self, force):
+        """`force.updateParametersInContext(context)`: per-particle (and exception) parameters of an existing force are
+        uploaded again -- what AlchemicalRespaSystem.reset_coulomb_scaling_factor relies on (systems.py:806-815)."""
+        hits = [e for e in self.entries if e.force is force]
+        if not hits:
+            raise mm.OpenMMException('updateParametersInContext: the force does not belong to this Context')
+        for entry in hits:
+            reload = getattr(entry, 'reload', None)
+            if reload is None:
+                raise NotImplementedError('updateParametersInContext for ' + type(force).__name__ + ' with this energy expression')
+            result = reload()
+            if result:
+                if result != 'values':
+                    self._group_defs.clear()
+                self._programs.clear()
+                self._invalidate_forces()
 
     def invalidate_program(self):
         self._programs.clear()

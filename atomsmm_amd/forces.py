@@ -128,6 +128,12 @@ def describe_energy(energy, global_parameters=None):
             scale_name, head = m.group(1), m.group(2)
             if head.startswith('(') and head.endswith(')'):
                 head = head[1:-1]
+        # force-switched electrostatics of the solute-solvent pairs (systems.py:848-856): no Lennard-Jones part
+        m = re.fullmatch(r'(\w+)\*\(1\+step\(r-' + num + r'\)\*f1\)\*' + num + r'\*chargeprod/r', head)
+        if m:
+            desc.update(family='near-force-switch', noshift=True, coulomb_only=True, rs0=float(m.group(2)), Kc=float(m.group(3)),
+                        scale_name=m.group(1))
+            return desc
         # `step(rc-r)*U; U = <expression>` bond wrappers (systems.py:643, 674)
         m = re.fullmatch(r'step\(' + num + r'-r\)\*U', head)
         if m and any(a.startswith('U=') for a in aux):

@@ -138,6 +138,10 @@ class NonbondedForce(Force, _GlobalParams):
     def setParticleParameters(self, index, charge, sigma, epsilon):
         self._particles[index] = [float(md_value(charge)), float(md_value(sigma)), float(md_value(epsilon))]
 
+    def updateParametersInContext(self, context):
+        """Upload the particle and exception parameters again (systems.py:811-812)."""
+        context._engine.update_force_parameters(self)
+
     def getNumExceptions(self):
         return len(self._exceptions)
 
@@ -315,6 +319,10 @@ class CustomNonbondedForce(Force, _GlobalParams):
 
     def setParticleParameters(self, index, parameters):
         self._particles[index] = [float(md_value(p)) for p in parameters]
+
+    def updateParametersInContext(self, context):
+        """Upload the per-particle parameters again (systems.py:813-814)."""
+        context._engine.update_force_parameters(self)
 
     def addExclusion(self, particle1, particle2):
         self._exclusions.append((int(particle1), int(particle2)))

@@ -18,7 +18,7 @@ import itertools
 import math
 import re
 
-from . import forces, openmm, utils
+from . import forces, openmm, unit, utils
 from .unit import md_value
 
 
@@ -244,6 +244,30 @@ class ComputingSystem(_AtomsMM_System):
                 raise NotImplementedError('ComputingSystem: virial of a user CustomBondForce is not supported')
 
 
+class AlchemicalCoulombCVForce(object):
+    """`atomsmm.systems.AlchemicalCoulombCVForce(alchemical_system)` (systems.py:471-489): the solute-solvent Coulomb
+    energy as the difference of the outer group's energy at lambda_coul = 1 and 0."""
+
+    def __init__(self, alchemical_system):
+        self._system = alchemical_system
+
+    def getNumCollectiveVariables(self):
+        return 1
+
+    def getCollectiveVariableName(self, index):
+        return 'alchemical_coulomb_energy'
+
+    def getCollectiveVariableValues(self, context):
+        lambda_coul = self._system._lambda_coul
+        group = 2 if self._system._middle_scale else 1
+        self._system.reset_coulomb_scaling_factor(0.0, context)
+        E0 = context.getState(getEnergy=True, groups=2 ** group).getPotentialEnergy()
+        self._system.reset_coulomb_scaling_factor(1.0, context)
+        E1 = context.getState(getEnergy=True, groups=2 ** group).getPotentialEnergy()
+        self._system.reset_coulomb_scaling_factor(lambda_coul, context)
+        return [(E1 - E0).value_in_unit(unit.kilojoules_per_mole)]
+
+
 class AlchemicalRespaSystem(openmm.System):
     """`atomsmm.systems.AlchemicalRespaSystem(system, rcutIn, rswitchIn, alchemical_atoms, coupling_parameter='lambda',
     coupling_function='lambda', middle_scale=True, coulomb_scaling=False, lambda_coul=0, use_softcore=False,
@@ -257,7 +281,9 @@ class AlchemicalRespaSystem(openmm.System):
     * the solute-solute interactions become cutoff-less LJC bonds (group 2) plus their short-ranged copy (group 1);
     * the solute-solvent Lennard-Jones energy is a collective variable multiplied by ((gt0-gt1)*S(lambda)+gt1) in a
       CustomCVForce (group 2; its force-switched short-ranged copy in group 1), or a softcore force.
-    Coulomb scaling of the solute-solvent electrostatics (systems.py:686-708) is not supported."""
+    * with `coulomb_scaling`, the solute charges come back into the NonbondedForce scaled by `lambda_coul` (solute-solute
+      pairs stay excluded) and, with a middle scale, a force-switched electrostatic potential over the (solute, solvent)
+      interaction group joins group 1 (systems.py:686-708, 794-815, 848-856)."""
 
     Kc = 138.935456637          # systems.py:572 (the other classes use 138.935456)
 
@@ -266,10 +292,11 @@ class AlchemicalRespaSystem(openmm.System):
                  use_softcore=False, split_alchemical=True):
         openmm.System.__init__(self)
         self._copy_from(system)
-        if coulomb_scaling:
-            raise NotImplementedError('AlchemicalRespaSystem: coulomb_scaling is not supported')
         Kc = self.Kc
         self._parameter, self._middle_scale, self._use_softcore = coupling_parameter, middle_scale, use_softcore
+        self._coulomb_scaling = coulomb_scaling
+        self._solute_charges = {}
+        self._lambda_coul = 0
         solute_atoms = set(int(i) for i in alchemical_atoms)
         solvent_atoms = set(range(self.getNumParticles())) - solute_atoms
         rci, rsi = md_value(rcutIn), md_value(rswitchIn)
@@ -283,6 +310,7 @@ class AlchemicalRespaSystem(openmm.System):
                 force.setForceGroup(outer_group)
                 force.setReciprocalSpaceForceGroup(outer_group)
                 for i in solute_atoms:
+                    self._solute_charges[i] = force.getParticleParameters(i)[0]
                     force.setParticleParameters(i, 0.0, 1.0, 0.0)
                 have = set()
                 for index in range(force.getNumExceptions()):
@@ -338,6 +366,20 @@ class AlchemicalRespaSystem(openmm.System):
             if i in solute_atoms and j in solute_atoms:
                 for force in intrasolute_forces:
                     force.addBond(i, j, (chargeprod, sigma, epsilon))
+        if coulomb_scaling and middle_scale:
+            # short-ranged part of the solute-solvent electrostatics; its particles are imported with the ORIGINAL charges
+            # and only reset_coulomb_scaling_factor rescales the solute's (systems.py:698-708)
+            fsep = self._force_switched_eletrostatic_potential(rci, rsi, Kc)
+            short_range = openmm.CustomNonbondedForce(fsep + mixing_rules)
+            self._import_from_nonbonded(short_range, nonbonded)
+            short_range.setCutoffDistance(rcutIn)
+            short_range.setUseSwitchingFunction(False)
+            short_range.setUseLongRangeCorrection(False)
+            short_range.addGlobalParameter('respa_switch', 0)
+            short_range.setForceGroup(1)
+            short_range.addInteractionGroup(solute_atoms, solvent_atoms)
+            self.addForce(short_range)
+            self._fsep_force = short_range
         if use_softcore:
             ljsoft = '4*{0}*epsilon*x*(x - 1); x = 1/((r/sigma)^6 + 0.5*(1-{0}))'.format(coupling_parameter)
             full_range = openmm.CustomNonbondedForce(ljsoft + mixing_rules)
@@ -390,10 +432,45 @@ class AlchemicalRespaSystem(openmm.System):
                 short_range.setForceGroup(1)
                 self.addForce(short_range)
 
+        # stored as zero and reset only if a different value was passed (systems.py:781-783): with the default the
+        # force-switched electrostatic force keeps the solute's full charges, as in the reference
+        self._lambda_coul = 0
+        self.reset_coulomb_scaling_factor(lambda_coul)
+
     def get_alchemical_vdw_force(self, parameter_values=[1]):
         if self._use_softcore:
             return AlchemicalSoftcoreCVForce(self, parameter_values)
         return self._alchemical_vdw_force
+
+    def get_alchemical_coul_force(self):
+        return AlchemicalCoulombCVForce(self)
+
+    def reset_coulomb_scaling_factor(self, lambda_coul, context=None):
+        """Scaling factor of the solute-solvent electrostatics (systems.py:794-815); with a Context the particle
+        parameters are uploaded again."""
+        lambda_coul = md_value(lambda_coul)
+        if self._coulomb_scaling and lambda_coul != self._lambda_coul:
+            for i, charge in self._solute_charges.items():
+                self._nonbonded_force.setParticleParameters(i, lambda_coul * charge, 1.0, 0.0)
+                if self._middle_scale:
+                    self._fsep_force.setParticleParameters(i, (lambda_coul * charge, 1.0, 0.0))
+            if context is not None:
+                self._nonbonded_force.updateParametersInContext(context)
+                if self._middle_scale:
+                    self._fsep_force.updateParametersInContext(context)
+            self._lambda_coul = lambda_coul
+
+    @staticmethod
+    def _force_switched_eletrostatic_potential(rc, rs, Kc):
+        """Expression text of systems.py:848-856: Kc*chargeprod/r times (1 + step(r-rs)*f1), times respa_switch."""
+        b = rs / (rc - rs)
+        a1 = 5 * (b + 1) ** 2
+        f1 = '{}*({}*R*log(R)-{}*u-{}*u^2+u^3)-{}*u^4+{}*u^5'.format(a1, 6 * b ** 3, 6 * b ** 2, 3 * b, 5 * (b / 2 + 1), 3 / 2)
+        fsep = 'respa_switch*(1 + step(r-{})*f1)*{}*chargeprod/r'.format(rs, Kc)
+        fsep += '; f1 = {}'.format(f1)
+        fsep += '; R = {}*u + 1'.format(1 / b)
+        fsep += '; u = {}*r - {}'.format(b / rs, b)
+        return fsep
 
     @staticmethod
     def _force_switched_potential(rc, rs, Kc):

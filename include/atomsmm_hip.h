@@ -54,9 +54,13 @@ enum {
     AMM_SWITCH = 8,         /* NONBONDED / SOFTCORE: OpenMM built-in switch rswitch -> rc                */
     AMM_NO_SHIFT = 16,      /* NEAR_FSWITCH: energy without the constant -V*(rc0) (AlchemicalRespaSystem's
                                force-switched potentials, systems.py:823-846)                            */
-    AMM_GROUP_LJ = 32       /* interaction group for Lennard-Jones-only forces: the charge array carries the set
+    AMM_GROUP_LJ = 32,      /* interaction group for Lennard-Jones-only forces: the charge array carries the set
                                of each atom (1, 2, 0; Kc = 1), a pair counts iff the codes multiply to 2, no
                                Coulomb term (systems.py:739-772)                                         */
+    AMM_GROUP_Q = 64        /* interaction group for Coulomb-only forces (the force-switched solute-solvent
+                               electrostatics of Coulomb scaling, systems.py:696-708, 848-856): the sigma array
+                               carries TWICE the set code of each atom (2, 4, 0): the mixed sigma (sigma_i +
+                               sigma_j)/2 = 3 selects a (set 1, set 2) pair; epsilon is ignored         */
 };
 
 typedef struct {

@@ -58,6 +58,11 @@ void ammo_pair_kernel(const ammo_pair_desc *d, double r2, double qq, double sig,
         if (qq != 2.0) { *e_out = 0.0; *fr_out = 0.0; return; }
         qq = 0.0;
     }
+    if (d->flags & AMMO_GROUP_Q) {
+        if (sig != 3.0) { *e_out = 0.0; *fr_out = 0.0; return; }
+        sig = 1.0;
+        eps = 0.0;
+    }
     double inv = 1.0 / r;
     double s = sig * inv, s2 = s * s, s6 = s2 * s2 * s2, s12 = s6 * s6;
     double lj = 4.0 * eps * (s12 - s6);

@@ -42,7 +42,8 @@ enum {
     AMMO_COULOMB_RF = 4,     /* NONBONDED: reaction field (CutoffPeriodic); parity unpinned */
     AMMO_SWITCH = 8,         /* NONBONDED: built-in switch rswitch->rc on the LJ term */
     AMMO_NO_SHIFT = 16,      /* NEAR_FSWITCH without the constant -V*(rc0)   systems.py:823-846 */
-    AMMO_GROUP_LJ = 32       /* LJ-only interaction group: charges = set codes, pair iff product == 2, no Coulomb */
+    AMMO_GROUP_LJ = 32,      /* LJ-only interaction group: charges = set codes, pair iff product == 2, no Coulomb */
+    AMMO_GROUP_Q = 64        /* Coulomb-only interaction group: sigma_i = twice the set code, pair iff the mixed sigma is 3, no LJ (systems.py:848-856) */
 };
 
 typedef struct {

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE, LJ_VIRIAL = range(7)
-GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH, NO_SHIFT, GROUP_LJ = 1, 2, 4, 8, 16, 32
+GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH, NO_SHIFT, GROUP_LJ, GROUP_Q = 1, 2, 4, 8, 16, 32, 64
 KC = 138.935456   # forces.py:407
 ADJ = {None: NEAR_NONE, 'shift': NEAR_SHIFT, 'force-switch': NEAR_FSWITCH}
 

@@ -203,6 +203,37 @@ def test_softcore_interaction_group_vs_oracle_and_G15(heaq, goldens):
     ctx.close()
 
 
+def test_group_flags_vs_oracle(heaq):
+    """AMM_GROUP_LJ (Lennard-Jones over a (set 1, set 2) interaction group: the charge slot carries the set codes) and
+    AMM_GROUP_Q (Coulomb only: the sigma slot carries twice the set code; the force-switched electrostatics of Coulomb
+    scaling, systems.py:848-856) through the C-ABI vs the oracle, and the group energy as a difference of plain sums:
+    E(group) = E(all) - E(set 1 alone) - E(set 2 alone) for the Coulomb-only force."""
+    B = _backend()
+    h = heaq
+    n = len(h['positions'])
+    codes = np.where(h['resname'] == 'aaa', 1.0, 2.0)
+    pos = dev(h['positions'])
+    zero = np.zeros(n)
+    ctx = B.HipContext(n, h['box'])
+    cases = [(B.GROUP_LJ | B.NO_SHIFT, O.GROUP_LJ | O.NO_SHIFT, codes, h['sigma'], h['epsilon'], 1.0),
+             (B.GROUP_Q | B.NO_SHIFT, O.GROUP_Q | O.NO_SHIFT, h['charge'], 2.0 * codes, zero, 138.935456637)]
+    for bflags, oflags, q, sigma, eps, Kc in cases:
+        fid = ctx.pair_create(B.pair_desc(B.NEAR_FSWITCH, 0.7, rc0=0.7, rs0=0.5, flags=bflags, Kc=Kc), q, sigma, eps, h['exc_pairs'])
+        e, f = eval_force(ctx, fid, pos, n)
+        d = O.desc(O.NEAR_FSWITCH, rc=0.7, rc0=0.7, rs0=0.5, flags=oflags, Kc=Kc)
+        e_ref, f_ref, _ = O.pair_eval(d, h['positions'], h['box'], q, sigma, eps, h['exc_pairs'])
+        assert abs(e_ref) > 1.0
+        assert e == pytest.approx(e_ref, rel=1e-10)
+        assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    # Coulomb-only group energy from three plain (ungrouped) evaluations with masked charges
+    d = O.desc(O.NEAR_FSWITCH, rc=0.7, rc0=0.7, rs0=0.5, flags=O.NO_SHIFT, Kc=138.935456637)
+    one = np.full(n, 1.0)
+    parts = [O.pair_eval(d, h['positions'], h['box'], qq, one, zero, h['exc_pairs'])[0]
+             for qq in (h['charge'], np.where(codes == 1.0, h['charge'], 0.0), np.where(codes == 2.0, h['charge'], 0.0))]
+    assert e == pytest.approx(parts[0] - parts[1] - parts[2], rel=1e-9)
+    ctx.close()
+
+
 def test_bonded_terms_vs_oracle(heaq, goldens):
     B = _backend()
     h = heaq

@@ -495,6 +495,32 @@ def test_AlchemicalRespaSystem_without_middle_scale(phenol):       # tests/test_
                         'CustomCVForce': -7.114065227572182, 'Total': -22844.464204692995})
 
 
+def test_AlchemicalRespaSystem_with_coulomb_scaling(phenol):       # tests/test_systems.py:211-249
+    system, positions, topology, solute = _phenol_system(phenol)
+    solvation_system = atomsmm.AlchemicalRespaSystem(system, 7 * unit.angstroms, 5 * unit.angstroms, solute,
+                                                     coupling_function='lambda^4*(5-4*lambda)', coulomb_scaling=True,
+                                                     lambda_coul=0.5)
+    components = atomsmm.splitPotentialEnergy(solvation_system, topology, positions, **{'lambda': 0.5, 'respa_switch': 1})
+    simulation = app.Simulation(topology, solvation_system, openmm.CustomIntegrator(0),
+                                openmm.Platform.getPlatformByName("Reference"))
+    simulation.context.setPositions(positions)
+    force = solvation_system.get_alchemical_coul_force()
+    assert force.getNumCollectiveVariables() == 1 and force.getCollectiveVariableName(0) == 'alchemical_coulomb_energy'
+    before = simulation.context.getState(getEnergy=True, groups=2 ** 2).getPotentialEnergy()
+    Ecoul = force.getCollectiveVariableValues(simulation.context)
+    components['Ecoul'] = Ecoul[0] * unit.kilojoule_per_mole
+    _check(components, {'HarmonicBondForce': 2621.3223922886677, 'HarmonicAngleForce': 1525.1006876561419,
+                        'PeriodicTorsionForce': 18.767576693568476, 'Real-Space': 80078.91697014398,
+                        'Reciprocal-Space': -107074.49398119976, 'CustomNonbondedForce': 5037.152491649265,
+                        'CustomBondForce': -53.526446723139806, 'CustomBondForce(1)': -53.374675325650806,
+                        'CustomNonbondedForce(1)': -23.447733015522058, 'CustomCVForce': -7.114065227572182,
+                        'CustomCVForce(1)': -6.301336948673654, 'Total': -17936.998120008684,
+                        'Ecoul': -93.14060537915793})
+    # the scaling factor was put back: the outer group's energy is what it was
+    again = simulation.context.getState(getEnergy=True, groups=2 ** 2).getPotentialEnergy()
+    assert again / again.unit == pytest.approx(before / before.unit, rel=1e-13)
+
+
 def test_AlchemicalRespaSystem_with_softcore(phenol):              # tests/test_systems.py:252-292 (system components)
     system, positions, topology, solute = _phenol_system(phenol)
     solvation_system = atomsmm.AlchemicalRespaSystem(system, 7 * unit.angstroms, 5 * unit.angstroms, solute, use_softcore=True)

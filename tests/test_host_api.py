@@ -483,3 +483,43 @@ def test_afed_program_matches_reference_capture(goldens):
     assert 'lambda_vdw <- lambda_vdw + select(step(lambda_vdw-(0)),-1,1)' in text
     assert '_v_lambda_vdw <- z*_v_lambda_vdw+sqrt((1-z*z)*_kTbym_lambda_vdw)*gaussian; z=exp(-dt*_gamma_lambda_vdw)' in text
     assert '_nsteps_counter' not in text
+
+
+def test_alchemical_respa_coulomb_scaling_host_logic(phenol, recorder):
+    """AlchemicalRespaSystem(coulomb_scaling=True) (systems.py:686-708, 794-815, 848-856): the force-switched
+    electrostatic force over the (solute, solvent) group, its translation (Coulomb-only interaction group: the sigma
+    slot carries twice the set code), and reset_coulomb_scaling_factor through updateParametersInContext."""
+    system = system_from_arrays(phenol, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
+    solute = [int(i) for i in np.where(phenol['resname'] == 'aaa')[0]]
+    assert len(solute) == 13
+    sys0 = atomsmm.AlchemicalRespaSystem(system, 7 * unit.angstroms, 5 * unit.angstroms, solute, coulomb_scaling=True)
+    q0 = phenol['charge'][solute[0]]
+    # reference quirk (systems.py:781-783, 806): with the default lambda_coul = 0 nothing is reset, and the short-ranged
+    # force keeps the charges it was imported with
+    assert sys0._fsep_force.getParticleParameters(solute[0])[0] == pytest.approx(q0)
+    assert sys0._nonbonded_force.getParticleParameters(solute[0])[0]._value == 0.0
+    alch = atomsmm.AlchemicalRespaSystem(system, 7 * unit.angstroms, 5 * unit.angstroms, solute, coulomb_scaling=True,
+                                         lambda_coul=0.5)
+    fsep = alch._fsep_force
+    text = fsep.getEnergyFunction()
+    assert text.startswith('respa_switch*(1 + step(r-0.5)*f1)*138.935456637*chargeprod/r; f1 = ')
+    d = F.describe_energy(text, {"respa_switch": 0})
+    assert d['family'] == 'near-force-switch' and d['coulomb_only'] and d['noshift'] and d['scale_name'] == 'respa_switch'
+    assert d['rs0'] == 0.5 and d['Kc'] == 138.935456637
+    assert fsep.getForceGroup() == 1 and fsep.getNumInteractionGroups() == 1
+    assert fsep.getParticleParameters(solute[0])[0] == pytest.approx(0.5 * q0)
+    assert alch._nonbonded_force.getParticleParameters(solute[0])[0]._value == pytest.approx(0.5 * q0)
+    ctx = openmm.Context(alch, openmm.VerletIntegrator(0.0))
+    rec = recorder[-1]
+    mine = [p for p in rec.pairs if p['flags'] & B.GROUP_Q]
+    assert len(mine) == 1 and mine[0]['flags'] & B.NO_SHIFT
+    codes = mine[0]['sigma'] / 2
+    assert set(np.where(codes == 1.0)[0]) == set(solute) and (codes[[i for i in range(len(codes)) if i not in solute]] == 2.0).all()
+    assert (mine[0]['eps'] == 0.0).all() and mine[0]['q'][solute[0]] == pytest.approx(0.5 * q0)
+    n_before = len([c for c in rec.calls if c[0] == 'pair_set_params'])
+    alch.reset_coulomb_scaling_factor(1.0, ctx)
+    updates = [c for c in rec.calls if c[0] == 'pair_set_params'][n_before:]
+    assert len(updates) == 2 and all(u[2][solute[0]] == pytest.approx(q0) for u in updates)
+    assert [c for c in rec.calls if c[0] == 'pme_set_charges'][-1][2][solute[0]] == pytest.approx(q0)
+    with pytest.raises(openmm.OpenMMException):
+        openmm.NonbondedForce().updateParametersInContext(ctx)
