@@ -19,7 +19,7 @@ from .forces import NearNonbondedForce  # noqa: F401
 from .forces import NonbondedExceptionsForce  # noqa: F401
 from .integrators import GlobalThermostatIntegrator  # noqa: F401
 from .integrators import MultipleTimeScaleIntegrator  # noqa: F401
-from .integrators import Langevin_R_Integrator, NHL_R_Integrator  # noqa: F401
+from .integrators import Langevin_R_Integrator, NHL_R_Integrator, SIN_R_Integrator  # noqa: F401
 from .integrators import AdiabaticDynamicsIntegrator, ExtendedSystemVariable  # noqa: F401
 from .propagators import ChainedPropagator  # noqa: F401
 from .propagators import MultipleTimeScalePropagator  # noqa: F401
@@ -32,7 +32,8 @@ from .propagators import VelocityBoostPropagator  # noqa: F401
 from .propagators import VelocityVerletPropagator  # noqa: F401
 from .propagators import (MassiveNoseHooverPropagator, NoseHooverPropagator, OrnsteinUhlenbeckPropagator,  # noqa: F401
                           UnconstrainedVelocityVerletPropagator, VelocityRescalingPropagator,
-                          GenericBoostPropagator, GenericScalingPropagator)
+                          GenericBoostPropagator, GenericScalingPropagator, MassiveIsokineticPropagator,
+                          SIN_R_Propagator)
 from .systems import AlchemicalRespaSystem, ComputingSystem, RESPASystem, SolvationSystem  # noqa: F401
 from .computers import PressureComputer  # noqa: F401
 from .utils import InputError  # noqa: F401
@@ -45,13 +46,14 @@ from . import forces, integrators, propagators, systems, utils  # noqa: F401
 
 __forces__ = ['DampedSmoothedForce', 'NonbondedExceptionsForce', 'NearExceptionForce', 'NearNonbondedForce',
               'FarNonbondedForce']
-__integrators__ = ['GlobalThermostatIntegrator', 'MultipleTimeScaleIntegrator', 'Langevin_R_Integrator', 'NHL_R_Integrator',
+__integrators__ = ['GlobalThermostatIntegrator', 'MultipleTimeScaleIntegrator', 'Langevin_R_Integrator', 'NHL_R_Integrator', 'SIN_R_Integrator',
                    'AdiabaticDynamicsIntegrator', 'ExtendedSystemVariable']
 __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPropagator', 'SplitPropagator',
                    'SuzukiYoshidaPropagator', 'TranslationPropagator', 'TrotterSuzukiPropagator',
                    'VelocityBoostPropagator', 'VelocityVerletPropagator', 'UnconstrainedVelocityVerletPropagator',
                    'VelocityRescalingPropagator', 'NoseHooverPropagator', 'MassiveNoseHooverPropagator',
-                   'OrnsteinUhlenbeckPropagator', 'GenericBoostPropagator', 'GenericScalingPropagator']
+                   'OrnsteinUhlenbeckPropagator', 'GenericBoostPropagator', 'GenericScalingPropagator',
+                   'MassiveIsokineticPropagator', 'SIN_R_Propagator']
 __systems__ = ['RESPASystem', 'SolvationSystem', 'ComputingSystem', 'PressureComputer',
                'AlchemicalRespaSystem']
 __utils__ = ['countDegreesOfFreedom', 'evaluateForce', 'findNonbondedForce', 'hijackForce', 'splitPotentialEnergy']

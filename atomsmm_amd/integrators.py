@@ -188,6 +188,30 @@ class NHL_R_Integrator(MultipleTimeScaleIntegrator):
         self.setPerDofVariableByName('v2', v2)
 
 
+class SIN_R_Integrator(MultipleTimeScaleIntegrator):
+    """Stochastic-Iso-NH-RESPA integrator (integrators.py:358-416): see propagators.SIN_R_Propagator.  `initialize` draws
+    the thermostat velocities, v1 ~ N(0, (L+1)/L kT/Q1) and v2 ~ N(0, kT/Q2) per degree of freedom."""
+
+    def __init__(self, stepSize, loops, temperature, timeScale, frictionConstant, **kwargs):
+        _AtomsMM_Integrator.__init__(self, stepSize)
+        propagator = propagators.SIN_R_Propagator(loops, temperature, timeScale, frictionConstant, **kwargs)
+        propagator.addVariables(self)
+        propagator.addSteps(self)
+
+    def initialize(self):
+        kT = self.getGlobalVariableByName('kT')
+        Q1 = self.getGlobalVariableByName('Q1')
+        Q2 = self.getGlobalVariableByName('Q2')
+        L = round(self.getGlobalVariableByName('L'))
+        S1, S2 = math.sqrt((L + 1) / L * kT / Q1), math.sqrt(kT / Q2)
+        for i in range(L):
+            for name, S in (('v1_{}'.format(i), S1), ('v2_{}'.format(i), S2)):
+                values = self.getPerDofVariableByName(name)
+                for j in range(len(values)):
+                    values[j] = S * self._normalVec()
+                self.setPerDofVariableByName(name, values)
+
+
 class ExtendedSystemVariable(object):
     """An extended-space variable of Adiabatic Free Energy Dynamics (integrators.py:642-744): a global Context
     parameter `name` (e.g. `lambda_vdw`) with mass, its own temperature kT and a Nose-Hoover or Langevin thermostat, moving

@@ -422,6 +422,61 @@ class OrnsteinUhlenbeckPropagator(Propagator):
             integrator.addComputePerDof(self.velocity, expression)
 
 
+class MassiveIsokineticPropagator(Propagator):
+    """Unconstrained massive isokinetic propagator (propagators.py:276-355).  Every degree of freedom carries L thermostat
+    velocities v1_i (inertia Q1 = kT tau^2) and obeys m v^2 + L/(L+1) Q1 sum_i v1_i^2 = L kT.  `forceDependent`: the exact
+    solution of dv/dt = F/m - lambda_F v (v <- v cosh z + sqrt(LkT/m) sinh z, z = F t / sqrt(m LkT)); otherwise of the
+    thermostat coupling v1_i <- v1_i exp(-v2_i t).  Both are followed by the rescaling H that restores the constraint."""
+
+    def __init__(self, temperature, timeScale, L, forceDependent):
+        super().__init__()
+        self.L, self.forceDependent = L, forceDependent
+        self.globalVariables['Q1'] = kB * temperature * timeScale ** 2
+        self.globalVariables['L'] = L
+        self.globalVariables['LkT'] = L * kB * temperature
+        for i in range(L):
+            self.perDofVariables['v1_{}'.format(i)] = 1 / timeScale
+            self.perDofVariables['v2_{}'.format(i)] = 0
+        self.perDofVariables['H'] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        v1 = ['v1_{}'.format(i) for i in range(self.L)]
+        v2 = ['v2_{}'.format(i) for i in range(self.L)]
+        if self.forceDependent:
+            integrator.addComputePerDof('v', 'v*cosh(z) + sqrt(LkT/m)*sinh(z); z = ({}*dt)*{}/sqrt(m*LkT)'.format(fraction, force))
+        else:
+            for a, b in zip(v1, v2):
+                integrator.addComputePerDof(a, '{}*exp(-({}*dt)*{})'.format(a, fraction, b))
+        squares = '+'.join('{}^2'.format(a) for a in v1)
+        integrator.addComputePerDof('H', 'sqrt(LkT/(m*v^2 + {}*Q1*({})))'.format(self.L / (self.L + 1), squares))
+        integrator.addComputePerDof('v', 'H*v')
+        for a in v1:
+            integrator.addComputePerDof(a, 'H*{}'.format(a))
+
+
+class SIN_R_Propagator(MultipleTimeScalePropagator):
+    """Stochastic-Iso-NH-RESPA, SIN(R), of Leimkuhler, Margul and Tuckerman (propagators.py:1045-1105): the RESPA kicks
+    are the force-dependent isokinetic propagator; the bath -- an Ornstein-Uhlenbeck process on every v2_i driven by
+    Q1 v1_i^2 - kT (as part of the OU step, or as a separate boost with `split=True`), Trotter-split around the
+    force-independent isokinetic propagator -- sits where `scheme` puts it.  Keywords L (thermostats per DOF, default 1)
+    and split, then those of MultipleTimeScalePropagator."""
+
+    def __init__(self, loops, temperature, timeScale, frictionConstant, **kwargs):
+        L = kwargs.pop('L', 1)
+        split = kwargs.pop('split', False)
+        Q2 = kB * temperature * timeScale ** 2
+        with_force = MassiveIsokineticPropagator(temperature, timeScale, L, forceDependent=True)
+        without_force = MassiveIsokineticPropagator(temperature, timeScale, L, forceDependent=False)
+        drive = ['Q1*v1_{}^2 - kT'.format(i) for i in range(L)]
+        baths = [OrnsteinUhlenbeckPropagator(temperature, frictionConstant, 'v2_{}'.format(i), 'Q2',
+                                             None if split else drive[i], Q2=Q2) for i in range(L)]
+        DOU = ChainedPropagator(baths)
+        if split:
+            boosts = ChainedPropagator([GenericBoostPropagator('v2_{}'.format(i), 'Q2', drive[i], Q2=Q2) for i in range(L)])
+            DOU = TrotterSuzukiPropagator(DOU, boosts)
+        super().__init__(loops, None, with_force, TrotterSuzukiPropagator(DOU, without_force), **kwargs)
+
+
 class GenericBoostPropagator(Propagator):
     """dV/dt = F/M for a named velocity / mass / force triple, per-DOF or global (propagators.py:744-790)."""
 

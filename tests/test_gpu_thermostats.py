@@ -239,6 +239,47 @@ def test_respa_with_bath_equilibrates(spcfw, kind):
     assert np.abs(eng._buffer('f1').cpu().numpy() - f1).max() <= 1e-9 * np.abs(f1).max()
 
 
+@pytest.mark.parametrize('L,split', [(1, False), (2, False), (2, True)])
+def test_sin_r_keeps_the_isokinetic_constraint(spcfw, L, split):
+    """SIN_R_Integrator (integrators.py:358-416; SIN_R_Propagator / MassiveIsokineticPropagator, propagators.py:276-355,
+    1045-1105): RESPA [2,2,1] whose kicks are the force-dependent isokinetic propagator, with the stochastic bath on the
+    v2_i in the middle.  No reference literal exists; the size-independent invariant of the method is checked instead:
+    EVERY degree of freedom obeys m v^2 + L/(L+1) Q1 sum_i v1_i^2 = L kT after every step, whatever the forces did."""
+    c = spcfw
+    system = system_from_arrays(c, nonbondedMethod='CutoffPeriodic')
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+    outer = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9 * unit.angstroms).importFrom(nb)
+    outer.setForceGroup(2)
+    outer.addTo(respa)
+    integrator = atomsmm.SIN_R_Integrator(2 * unit.femtoseconds, [2, 2, 1], 300 * unit.kelvin, 10 * unit.femtoseconds,
+                                          20 / unit.picoseconds, L=L, split=split)
+    integrator.setRandomNumberSeed(5)
+    context = openmm.Context(respa, integrator)
+    context.setPositions(c['positions'] * unit.nanometers)
+    context.setVelocitiesToTemperature(300 * unit.kelvin, 3)
+    kT = integrator.getGlobalVariableByName('kT')
+    Q1 = integrator.getGlobalVariableByName('Q1')
+    assert kT == pytest.approx(300 * KB) and integrator.getGlobalVariableByName('LkT') == pytest.approx(L * kT)
+    mass = np.asarray(c['mass'])[:, None]
+    for nsteps in (1, 30):
+        integrator.step(nsteps)
+        v = context.getState(getVelocities=True).getVelocities(asNumpy=True)._value
+        v1 = [np.array([list(row) for row in integrator.getPerDofVariableByName('v1_%d' % i)]) for i in range(L)]
+        lhs = mass * v ** 2 + L / (L + 1) * Q1 * sum(a ** 2 for a in v1)
+        assert np.abs(lhs / (L * kT) - 1.0).max() < 1e-12
+    assert context._engine._interpreted is False      # isokinetic kicks and bath are EXPR ops of the unrolled RESPA program
+    x = context.getState(getPositions=True).getPositions(asNumpy=True)._value
+    assert np.isfinite(x).all() and np.abs(x - c['positions']).max() < 0.5
+    # the thermostat velocities were drawn by initialize(): v2 ~ N(0, kT/Q2)
+    v2 = np.array([list(row) for row in integrator.getPerDofVariableByName('v2_0')])
+    assert 0.5 < v2.std() / np.sqrt(kT / integrator.getGlobalVariableByName('Q2')) < 2.0
+    # the cached near force the program leaves behind equals a fresh evaluation at the final positions
+    dn = O.desc(O.NEAR_FSWITCH, rc=0.7, rc0=0.7, rs0=0.5)
+    f1 = O.pair_eval(dn, x, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
+    assert np.abs(context._engine._buffer('f1').cpu().numpy() - f1).max() <= 1e-9 * np.abs(f1).max()
+
+
 def test_bath_inside_the_inner_loop_kernel_is_bit_identical(spcfw):
     """Langevin_R: the inner-loop kernel runs kick ; move ; OU bath ; move ; forces ; kick for all n0 iterations in one
     launch, calling the same expression interpreter with the same random-stream counters as the separate EXPR launches

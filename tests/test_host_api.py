@@ -523,3 +523,35 @@ def test_alchemical_respa_coulomb_scaling_host_logic(phenol, recorder):
     assert [c for c in rec.calls if c[0] == 'pme_set_charges'][-1][2][solute[0]] == pytest.approx(q0)
     with pytest.raises(openmm.OpenMMException):
         openmm.NonbondedForce().updateParametersInContext(ctx)
+
+
+def test_sin_r_program_structure():
+    """SIN_R_Integrator (integrators.py:358-416): the step program that SIN_R_Propagator / MassiveIsokineticPropagator
+    (propagators.py:276-355, 1045-1105) emit -- isokinetic kicks in place of the RESPA boosts, the bath Trotter-split
+    around the force-independent isokinetic step in the middle of the innermost loop."""
+    integ = atomsmm.SIN_R_Integrator(2 * unit.femtoseconds, [2, 2, 1], 300 * unit.kelvin, 10 * unit.femtoseconds,
+                                     1 / unit.picoseconds, L=2)
+    text = [line.split(': ', 1)[1].strip() for line in repr(integ).split('Computation steps:')[1].strip().split('\n')]
+    kT = unit.BOLTZMANN_CONSTANT_kB._value * 300
+    assert integ.getGlobalVariableByName('LkT') == pytest.approx(2 * kT)
+    assert integ.getGlobalVariableByName('Q1') == pytest.approx(kT * 0.01 ** 2) == integ.getGlobalVariableByName('Q2')
+    assert text[2] == 'v <- v*cosh(z) + sqrt(LkT/m)*sinh(z); z = (0.5*dt)*(_f2_-f1)/sqrt(m*LkT)'
+    rescale = ['H <- sqrt(LkT/(m*v^2 + 0.6666666666666666*Q1*(v1_0^2+v1_1^2)))', 'v <- H*v', 'v1_0 <- H*v1_0', 'v1_1 <- H*v1_1']
+    assert text[3:7] == rescale
+    inner = text.index('while (n0RESPA < 2):')
+    body = text[inner + 1:text.index('n0RESPA <- n0RESPA + 1')]
+    assert body[0] == 'v <- v*cosh(z) + sqrt(LkT/m)*sinh(z); z = (0.125*dt)*(f0)/sqrt(m*LkT)' and body[1:5] == rescale
+    assert body[5] == 'x <- x + (0.125*dt)*v'
+    assert body[6:8] == ['v1_0 <- v1_0*exp(-(0.125*dt)*v2_0)', 'v1_1 <- v1_1*exp(-(0.125*dt)*v2_1)'] and body[8:12] == rescale
+    assert body[12] == ('v2_0 <- z*v2_0 + sqrt(kT*(1 - z*z)/mass)*gaussian + force*(1 - z)/(mass*friction); '
+                        'force = Q1*v1_0^2 - kT; mass = Q2; z = exp(-(0.25*dt)*friction)')
+    assert body[14:16] == body[6:8] and body[16:20] == rescale and body[20] == body[5] and body[21] == body[0]
+    assert len(body) == 26 and len(text) == 57
+    # split=True: the drive of v2 becomes a separate boost, Trotter-split around the force-free Ornstein-Uhlenbeck step
+    split = atomsmm.SIN_R_Integrator(2 * unit.femtoseconds, [2, 2, 1], 300 * unit.kelvin, 10 * unit.femtoseconds,
+                                     1 / unit.picoseconds, split=True)
+    lines = repr(split)
+    assert 'v2_0 <- v2_0 + (0.125*dt)*F/M; F = Q1*v1_0^2 - kT; M = Q2' in lines
+    assert 'v2_0 <- z*v2_0 + sqrt(kT*(1 - z*z)/mass)*gaussian; mass = Q2; z = exp(-(0.25*dt)*friction)' in lines
+    iso = atomsmm.MassiveIsokineticPropagator(300 * unit.kelvin, 10 * unit.femtoseconds, 1, forceDependent=False)
+    assert set(iso.perDofVariables) == {'v1_0', 'v2_0', 'H'} and unit.md_value(iso.perDofVariables['v1_0']) == pytest.approx(100.0)
