@@ -656,7 +656,7 @@ static bool g_erfcx_uploaded = false;
 // GFAM >= 0: the guest force of a shared list (RESPA near force, same particles, shorter cutoff) is evaluated on the
 // same pass into its own buffer: geometry, gathers, 1/r and the LJ / Coulomb pieces are common, so the guest costs a
 // switching polynomial instead of a second traversal.
-template <int FAM, int CMODE, bool GUARD, bool EN, int UNR, int GFAM>
+template <int FAM, int CMODE, bool GUARD, bool EN, int UNR, int GFAM, bool GROUPED = false>
 __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, PairConsts gc) {
     const int lpa = 1 << A.lpa_shift;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, Pa
                 if (GUARD) pass = pass && (r2 <= guard2);          // step(rc0 - r)
                 const double r2s = pass ? r2 : 1.0;
                 double e, fr;
-                amm_pair_math<FAM, CMODE, false, EN>(c, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, e, fr, s_tab);
+                amm_pair_math<FAM, CMODE, false, EN, GROUPED>(c, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, e, fr, s_tab);
                 fr = pass ? fr : 0.0;
                 fx += fr * dx;
                 fy += fr * dy;
@@ -815,6 +815,17 @@ static int launch_pair_dual_u(dim3 grid, dim3 block, hipStream_t st, int gfam, c
 }
 
 // host force + guest force of the shared list in one pass (force only, no guard on either)
+// interaction-group forces (AMM_GROUP_LJ / AMM_GROUP_Q): off the hot path, one entry per trip
+template <int FAM>
+static void launch_pair_grouped(dim3 grid, dim3 block, hipStream_t st, bool guard, bool en, const PairArgs &A, const PairConsts &c) {
+    if (guard) {
+        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, 0, true, true, 1, -1, true>), grid, block, 0, st, A, c, c);
+        else hipLaunchKernelGGL((k_pair_nlist<FAM, 0, true, false, 1, -1, true>), grid, block, 0, st, A, c, c);
+    } else {
+        if (en) hipLaunchKernelGGL((k_pair_nlist<FAM, 0, false, true, 1, -1, true>), grid, block, 0, st, A, c, c);
+        else hipLaunchKernelGGL((k_pair_nlist<FAM, 0, false, false, 1, -1, true>), grid, block, 0, st, A, c, c);
+    }
+}
 template <int FAM, int CMODE>
 static int launch_pair_dual(dim3 grid, dim3 block, hipStream_t st, int gfam, const PairArgs &A, const PairConsts &c,
                             const PairConsts &gc) {
@@ -1190,6 +1201,13 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             }
             if (rc_) return 1;
             guest->n_evals++;
+        } else if (pf->pc.flags & (AMM_GROUP_LJ | AMM_GROUP_Q)) {
+            if (pf->desc.family == AMM_NEAR_FSWITCH) launch_pair_grouped<AMM_NEAR_FSWITCH>(grid, block, st, guard, en, A, pf->pc);
+            else if (pf->desc.family == AMM_NONBONDED && pf->pc.cmode == 0) launch_pair_grouped<AMM_NONBONDED>(grid, block, st, false, en, A, pf->pc);
+            else {
+                amm_set_error("interaction groups (AMM_GROUP_LJ / AMM_GROUP_Q) are supported for the NEAR_FSWITCH and plain NONBONDED families");
+                return 1;
+            }
         } else
         switch (pf->desc.family) {
         case AMM_NEAR_NONE: launch_pair<AMM_NEAR_NONE, 0>(grid, block, st, guard, en, A, pf->pc); break;
@@ -1241,6 +1259,7 @@ bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host) {
     if (!(gf == AMM_NEAR_NONE || gf == AMM_NEAR_SHIFT || gf == AMM_NEAR_FSWITCH)) return false;
     if (!(hf == AMM_DAMPED || hf == AMM_NONBONDED)) return false;
     if ((guest->desc.flags & AMM_GUARD_RC0) || (host->desc.flags & AMM_GUARD_RC0)) return false;
+    if ((guest->desc.flags | host->desc.flags) & (AMM_GROUP_LJ | AMM_GROUP_Q)) return false;
     if (!(guest->desc.rc <= host->desc.rc)) return false;
     const size_t n = (size_t)ctx->n;
     std::vector<double> a(n), b(n);

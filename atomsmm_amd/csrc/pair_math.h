@@ -75,7 +75,9 @@ __device__ __forceinline__ void amm_erfc_exp(double x, const double *tab, double
     ec = ex * p;
 }
 
-template <int FAM, int CMODE, bool GUARD, bool EN>
+// GROUPED: interaction-group forces (AMM_GROUP_LJ / AMM_GROUP_Q) are separate instantiations, so that the common path
+// carries no per-pair flag tests or selects
+template <int FAM, int CMODE, bool GUARD, bool EN, bool GROUPED = false>
 __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, double qq, double sig, double eps4,
                                               double &e, double &fr, const double *tab = nullptr) {
     const double rinv = amm_rsqrt(r2);
@@ -84,14 +86,16 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
     e = 0.0;
     fr = 0.0;
     bool in_group = true;
-    if (c.flags & AMM_GROUP_LJ) {          // wave-uniform flag: qq carries the product of the atoms' set codes
-        in_group = qq == 2.0;
-        qq = 0.0;
-    }
-    if (c.flags & AMM_GROUP_Q) {           // wave-uniform flag: sig carries the sum of the atoms' set codes
-        in_group = sig == 3.0;
-        sig = 1.0;
-        eps4 = 0.0;
+    if (GROUPED) {
+        if (c.flags & AMM_GROUP_LJ) {      // wave-uniform flag: qq carries the product of the atoms' set codes
+            in_group = qq == 2.0;
+            qq = 0.0;
+        }
+        if (c.flags & AMM_GROUP_Q) {       // wave-uniform flag: sig carries the sum of the atoms' set codes
+            in_group = sig == 3.0;
+            sig = 1.0;
+            eps4 = 0.0;
+        }
     }
     if (GUARD) {
         if (!(c.rc0 - r >= 0.0)) return;   // step(rc0 - r), forces.py:661,714
@@ -213,8 +217,8 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
             if (EN) e += coul;
         }
     }
-    fr = in_group ? fr * c.sign : 0.0;
-    if (EN) e = in_group ? e * c.sign : 0.0;
+    fr = (!GROUPED || in_group) ? fr * c.sign : 0.0;
+    if (EN) e = (!GROUPED || in_group) ? e * c.sign : 0.0;
 }
 
 // Runtime-dispatched variant for the bond-list kernels (not hot: O(#exceptions)).
