@@ -1188,7 +1188,9 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         dim3 grid(nblk), block(256);
         if (guest) {
             int rc_ = 0;
-            if (pf->desc.family == AMM_DAMPED) rc_ = launch_pair_dual<AMM_DAMPED, 0>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
+            // DAMPED: CMODE 1 = the degree-1 specialisation (built-in switch in r: no power loop, no int -> double per pair)
+            if (pf->desc.family == AMM_DAMPED && pf->pc.degree == 1) rc_ = launch_pair_dual<AMM_DAMPED, 1>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
+            else if (pf->desc.family == AMM_DAMPED) rc_ = launch_pair_dual<AMM_DAMPED, 0>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
             else if (pf->desc.family == AMM_NONBONDED && pf->pc.cmode == 1)
                 rc_ = launch_pair_dual<AMM_NONBONDED, 1>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
             else if (pf->desc.family == AMM_NONBONDED && pf->pc.cmode == 2)
@@ -1213,7 +1215,10 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         case AMM_NEAR_NONE: launch_pair<AMM_NEAR_NONE, 0>(grid, block, st, guard, en, A, pf->pc); break;
         case AMM_NEAR_SHIFT: launch_pair<AMM_NEAR_SHIFT, 0>(grid, block, st, guard, en, A, pf->pc); break;
         case AMM_NEAR_FSWITCH: launch_pair<AMM_NEAR_FSWITCH, 0>(grid, block, st, guard, en, A, pf->pc); break;
-        case AMM_DAMPED: launch_pair<AMM_DAMPED, 0>(grid, block, st, false, en, A, pf->pc); break;
+        case AMM_DAMPED:
+            if (pf->pc.degree == 1) launch_pair<AMM_DAMPED, 1>(grid, block, st, false, en, A, pf->pc);
+            else launch_pair<AMM_DAMPED, 0>(grid, block, st, false, en, A, pf->pc);
+            break;
         case AMM_SOFTCORE: launch_pair<AMM_SOFTCORE, 0>(grid, block, st, false, en, A, pf->pc); break;
         case AMM_LJ_VIRIAL: launch_pair<AMM_LJ_VIRIAL, 0>(grid, block, st, false, en, A, pf->pc); break;
         case AMM_NONBONDED:

@@ -149,8 +149,8 @@ __device__ __forceinline__ void amm_pair_math(const PairConsts &c, double r2, do
         const double V = eps4 * (s12 - s6) + ec * coul;
         const double mdV_r = dlj_r + ec * dcoul_r + coul * c.two_alpha_over_sqrtpi * ex * rinv;
         // u = 0 below rswitch gives S = 1, dS = 0: no branch needed (step(r - rswitch), forces.py:454)
-        const int d = c.degree;
-        const double rd1 = amm_powi(r, d - 1);
+        const int d = (CMODE == 1) ? 1 : c.degree;          // CMODE 1: degree-1 specialisation (same values: x*1 is exact)
+        const double rd1 = (CMODE == 1) ? 1.0 : amm_powi(r, d - 1);
         const double du = rd1 * r - c.rswitch_d;
         const double u = du >= 0.0 ? du * c.inv_sw_den : 0.0;
         const double S = amm_sw_S(u);
