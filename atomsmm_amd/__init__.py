@@ -33,7 +33,8 @@ from .propagators import VelocityVerletPropagator  # noqa: F401
 from .propagators import (MassiveNoseHooverPropagator, NoseHooverPropagator, OrnsteinUhlenbeckPropagator,  # noqa: F401
                           UnconstrainedVelocityVerletPropagator, VelocityRescalingPropagator,
                           GenericBoostPropagator, GenericScalingPropagator, MassiveIsokineticPropagator,
-                          SIN_R_Propagator)
+                          SIN_R_Propagator, MassiveGeneralizedGaussianMomentPropagator, NoseHooverChainPropagator,
+                          NoseHooverLangevinPropagator)
 from .systems import AlchemicalRespaSystem, ComputingSystem, RESPASystem, SolvationSystem  # noqa: F401
 from .computers import PressureComputer  # noqa: F401
 from .utils import InputError  # noqa: F401
@@ -53,7 +54,8 @@ __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPro
                    'VelocityBoostPropagator', 'VelocityVerletPropagator', 'UnconstrainedVelocityVerletPropagator',
                    'VelocityRescalingPropagator', 'NoseHooverPropagator', 'MassiveNoseHooverPropagator',
                    'OrnsteinUhlenbeckPropagator', 'GenericBoostPropagator', 'GenericScalingPropagator',
-                   'MassiveIsokineticPropagator', 'SIN_R_Propagator']
+                   'MassiveIsokineticPropagator', 'SIN_R_Propagator', 'MassiveGeneralizedGaussianMomentPropagator',
+                   'NoseHooverChainPropagator', 'NoseHooverLangevinPropagator']
 __systems__ = ['RESPASystem', 'SolvationSystem', 'ComputingSystem', 'PressureComputer',
                'AlchemicalRespaSystem']
 __utils__ = ['countDegreesOfFreedom', 'evaluateForce', 'findNonbondedForce', 'hijackForce', 'splitPotentialEnergy']

@@ -395,6 +395,107 @@ class MassiveNoseHooverPropagator(Propagator):
             integrator.endBlock()
 
 
+class MassiveGeneralizedGaussianMomentPropagator(Propagator):
+    """One generalized-Gaussian-moment thermostat per degree of freedom (propagators.py:1314-1359): two thermostat momenta
+    p1 (driven by m v^2 - kT, inertia Q1 = kT tau^2) and p2 (driven by m^2 v^4/3 - kT^2, inertia Q2 = 2 kT^3 tau^2);
+    the velocity step is a scaling, the exact solution of dv/dt = -alpha' v^3, and the scaling again."""
+
+    def __init__(self, temperature, timeScale, nloops=1):
+        super().__init__()
+        self.nloops = nloops
+        self.globalVariables['kT'] = kB * temperature
+        self.globalVariables['Q1'] = kB * temperature * timeScale ** 2
+        self.globalVariables['Q2'] = 2 * (kB * temperature) ** 3 * timeScale ** 2
+        self.globalVariables['nGGM'] = 0
+        self.perDofVariables['p1'] = 0
+        self.perDofVariables['p2'] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        subfrac = fraction / self.nloops
+        half = subfrac / 2
+        boost1 = 'p1 + ({}*dt)*(m*v^2 - kT)'.format(half)
+        boost2 = 'p2 + ({}*dt)*(m^2*v^4/3 - kT^2)'.format(half)
+        scaling = 'exp(-{}*dt*(p1/Q1 + kT*p2/Q2))'.format(half)
+        velocity = ['v2*{}'.format(scaling), 'v2 = v1/sqrt(1 + 2*v1^2*alpha*{}*dt)'.format(subfrac), 'alpha = p2/(3*m*Q2)',
+                    'v1 = v*{}'.format(scaling)]
+        if self.nloops > 1:
+            integrator.addComputeGlobal('nGGM', '0')
+            integrator.beginWhileBlock('nGGM < {}'.format(self.nloops))
+        integrator.addComputePerDof('p1', boost1)
+        integrator.addComputePerDof('p2', boost2)
+        integrator.addComputePerDof('v', ';'.join(velocity))
+        integrator.addComputePerDof('p2', boost2)
+        integrator.addComputePerDof('p1', boost1)
+        if self.nloops > 1:
+            integrator.addComputeGlobal('nGGM', 'nGGM + 1')
+            integrator.endBlock()
+
+
+class _TwoStageGlobalThermostat(Propagator):
+    """Shared by the Nose-Hoover chain and Nose-Hoover-Langevin propagators: the constants of the global thermostat
+    written into the program text as numbers (kT, N kT, Q = N kT tau^2), default friction 1/tau."""
+
+    def __init__(self, temperature, degreesOfFreedom, timeScale, frictionConstant=None):
+        super().__init__()
+        self.temperature, self.degreesOfFreedom, self.timeScale = temperature, degreesOfFreedom, timeScale
+        self.frictionConstant = 1 / timeScale if frictionConstant is None else frictionConstant
+        self.globalVariables['vscaling'] = 0
+
+    def _constants(self):
+        kT = unit.md_value(kB * self.temperature)
+        NkT = self.degreesOfFreedom * kT
+        tau = unit.md_value(self.timeScale)
+        return kT, NkT, tau
+
+
+class NoseHooverChainPropagator(_TwoStageGlobalThermostat):
+    """Nose-Hoover chain of two global thermostats (propagators.py:1362-1449), Q1 = N kT tau^2, Q2 = kT tau^2, split as
+    B2 S1 B1 S B1 S1 B2: boost of thermostat 2, scaling of thermostat 1, boost of thermostat 1 by mvv - N kT, scaling of
+    the particle velocities."""
+
+    def __init__(self, temperature, degreesOfFreedom, timeScale, frictionConstant=None):
+        super().__init__(temperature, degreesOfFreedom, timeScale, frictionConstant)
+        self.globalVariables['p_NHC_1'] = 0
+        self.globalVariables['p_NHC_2'] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        kT, NkT, tau = self._constants()
+        Q1, Q2 = NkT * tau ** 2, kT * tau ** 2
+        half = 0.5 * fraction
+        boost2 = 'p_NHC_2 + (p_NHC_1^2/{}-{})*{}*dt'.format(Q1, kT, half)
+        scale1 = 'p_NHC_1*exp(-{}*p_NHC_2*dt)'.format(half / Q2)
+        integrator.addComputeGlobal('p_NHC_2', boost2)
+        integrator.addComputeGlobal('p_NHC_1', scale1)
+        integrator.addComputeGlobal('p_NHC_1', 'p_NHC_1 + (mvv-{})*{}*dt'.format(NkT, half))
+        integrator.addComputeGlobal('vscaling', 'exp(-{}*p_NHC_1*dt)'.format(fraction / Q1))
+        integrator.addComputeGlobal('p_NHC_1', 'p_NHC_1 + (vscaling^2*mvv-{})*{}*dt'.format(NkT, half))
+        integrator.addComputeGlobal('p_NHC_1', scale1)
+        integrator.addComputeGlobal('p_NHC_2', boost2)
+        integrator.addComputePerDof('v', 'vscaling*v')
+
+
+class NoseHooverLangevinPropagator(_TwoStageGlobalThermostat):
+    """Nose-Hoover-Langevin (propagators.py:1452-1536): one global thermostat momentum p_NHL (Q = N kT tau^2) boosted by
+    mvv - N kT, with an Ornstein-Uhlenbeck step of its own in the middle; the velocities are scaled by the product of
+    the two half scalings."""
+
+    def __init__(self, temperature, degreesOfFreedom, timeScale, frictionConstant=None):
+        super().__init__(temperature, degreesOfFreedom, timeScale, frictionConstant)
+        self.globalVariables['p_NHL'] = 0
+
+    def addSteps(self, integrator, fraction=1.0, force='f'):
+        kT, NkT, tau = self._constants()
+        Q = NkT * tau ** 2
+        gamma = unit.md_value(self.frictionConstant)
+        half = 0.5 * fraction
+        integrator.addComputeGlobal('p_NHL', 'p_NHL + (mvv-{})*{}*dt'.format(NkT, half))
+        integrator.addComputeGlobal('vscaling', 'exp(-{}*p_NHL*dt)'.format(half / Q))
+        integrator.addComputeGlobal('p_NHL', 'p_NHL*x + sqrt({}*(1-x^2))*gaussian; x = exp(-{}*dt)'.format(kT / Q, gamma * fraction))
+        integrator.addComputeGlobal('vscaling', 'vscaling*exp(-{}*p_NHL*dt)'.format(half / Q))
+        integrator.addComputeGlobal('p_NHL', 'p_NHL + (vscaling^2*mvv-{})*{}*dt'.format(NkT, half))
+        integrator.addComputePerDof('v', 'vscaling*v')
+
+
 class OrnsteinUhlenbeckPropagator(Propagator):
     """Exact solution of dV = (F/M) dt - gamma V dt + sqrt(2 gamma kT/M) dW per degree of freedom
     (propagators.py:685-741): the Langevin bath of the 'middle' schemes."""

@@ -164,6 +164,63 @@ def test_nose_hoover_program_step_for_step(spcfw):
     assert integrator.getGlobalVariableByName('p_eta') == pytest.approx(p_eta, rel=1e-11)
 
 
+def test_nose_hoover_chain_and_ggm_programs_step_for_step(spcfw):
+    """NoseHooverChainPropagator (propagators.py:1362-1449: globals on the host, one sum and one scaling on the GPU) and
+    MassiveGeneralizedGaussianMomentPropagator (:1314-1359: three per-DOF expressions with auxiliary definitions, inside a
+    while block) against numpy evaluations of the same program text."""
+    c = spcfw
+    system = _water(c)
+    dof = atomsmm.countDegreesOfFreedom(system)
+    m = c['mass'][:, None]
+    kT, tau, dt = KB * 300.0, 0.01, 0.002
+    # --- Nose-Hoover chain
+    integrator = atomsmm.NoseHooverChainPropagator(300 * unit.kelvin, dof, 10 * unit.femtoseconds).integrator(2 * unit.femtoseconds)
+    context = openmm.Context(system, integrator)
+    context.setPositions(c['positions'] * unit.nanometers)
+    context.setVelocitiesToTemperature(450 * unit.kelvin, 9)
+    v = context.getState(getVelocities=True).getVelocities(asNumpy=True)._value.copy()
+    NkT = dof * kT
+    Q1, Q2, p1, p2 = NkT * tau ** 2, kT * tau ** 2, 0.0, 0.0
+    for _ in range(5):
+        p2 = p2 + (p1 ** 2 / Q1 - kT) * 0.5 * dt
+        p1 = p1 * np.exp(-(0.5 / Q2) * p2 * dt)
+        mvv = float((m * v * v).sum())
+        p1 = p1 + (mvv - NkT) * 0.5 * dt
+        vs = np.exp(-(1.0 / Q1) * p1 * dt)
+        p1 = p1 + (vs ** 2 * mvv - NkT) * 0.5 * dt
+        p1 = p1 * np.exp(-(0.5 / Q2) * p2 * dt)
+        p2 = p2 + (p1 ** 2 / Q1 - kT) * 0.5 * dt
+        v = vs * v
+    integrator.step(5)
+    got = context.getState(getVelocities=True).getVelocities(asNumpy=True)._value
+    assert np.abs(got - v).max() < 1e-11 * np.abs(v).max()
+    assert integrator.getGlobalVariableByName('p_NHC_1') == pytest.approx(p1, rel=1e-10)
+    assert integrator.getGlobalVariableByName('p_NHC_2') == pytest.approx(p2, rel=1e-10)
+    # --- massive generalized Gaussian moment thermostat, 2 sub-steps per step
+    integrator = atomsmm.MassiveGeneralizedGaussianMomentPropagator(300 * unit.kelvin, 10 * unit.femtoseconds, 2).integrator(2 * unit.femtoseconds)
+    context = openmm.Context(system, integrator)
+    context.setPositions(c['positions'] * unit.nanometers)
+    context.setVelocitiesToTemperature(450 * unit.kelvin, 9)
+    v = context.getState(getVelocities=True).getVelocities(asNumpy=True)._value.copy()
+    Q1, Q2 = kT * tau ** 2, 2 * kT ** 3 * tau ** 2
+    p1, p2 = np.zeros_like(v), np.zeros_like(v)
+    sub = 0.5
+    for _ in range(3 * 2):
+        p1 = p1 + (sub / 2 * dt) * (m * v ** 2 - kT)
+        p2 = p2 + (sub / 2 * dt) * (m ** 2 * v ** 4 / 3 - kT ** 2)
+        scale = np.exp(-(sub / 2) * dt * (p1 / Q1 + kT * p2 / Q2))
+        v1 = v * scale
+        alpha = p2 / (3 * m * Q2)
+        v = v1 / np.sqrt(1 + 2 * v1 ** 2 * alpha * sub * dt) * scale
+        p2 = p2 + (sub / 2 * dt) * (m ** 2 * v ** 4 / 3 - kT ** 2)
+        p1 = p1 + (sub / 2 * dt) * (m * v ** 2 - kT)
+    integrator.step(3)
+    got = context.getState(getVelocities=True).getVelocities(asNumpy=True)._value
+    assert np.abs(got - v).max() < 1e-11 * np.abs(v).max()
+    gp2 = np.array([list(row) for row in integrator.getPerDofVariableByName('p2')])
+    assert np.abs(gp2 - p2).max() < 1e-10 * np.abs(p2).max()
+
+
 def test_langevin_middle_scheme_equilibrates(spcfw):
     """B A O A B with the Ornstein-Uhlenbeck bath (propagators.py:685-741): a cold start reaches the bath temperature."""
     c = spcfw
