@@ -647,10 +647,58 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
     int f0_slot = -1;
     double *user_f0 = nullptr;
     bool swapped = false;
+    // kicks that close one repetition of the program ride on the first inner-loop launch of the next (as further
+    // "preceding kicks"): same order, same arithmetic, two launches less per outer step
+    std::vector<amm_op> deferred;
+    auto flush_deferred = [&]() -> int {
+        for (const amm_op &ko : deferred) {
+            double *fa = (ko.a >= 0 && ko.a < AMM_MAX_SLOTS) ? ctx->slots[ko.a] : nullptr;
+            double *fb = (ko.b >= 0 && ko.b < AMM_MAX_SLOTS) ? ctx->slots[ko.b] : nullptr;
+            if (!fa || (ko.b >= 0 && !fb)) {
+                amm_set_error("amm_run_ops: KICK buffer not bound");
+                return 1;
+            }
+            if (amm_kick_impl(ctx, ctx->d_v, fa, fb, ko.c, ctx->d_mass, ko.coef)) return 1;
+        }
+        deferred.clear();
+        return 0;
+    };
+    static const bool no_defer = getenv("AMM_NO_DEFER") != nullptr;      // tuning knob (A/B)
     for (int rep = 0; rep < repeat; ++rep)
         for (int k = 0; k < n_ops; ++k) {
             const amm_op &op = ops[k];
-            // component-parallel inner loop: [up to 3 KICKs] + n x {KICK(c1, fg) ; MOVE(d) ; EVAL(g) ; KICK(c2, fg)} in one launch
+            if (!deferred.empty() && !(k == 0 && op.op == AMM_OP_KICK) && flush_deferred()) return 1;
+            // trailing block of the program = only KICKs and COPYs, and the program opens with KICKs: defer the kicks
+            if (ctx->fuse_inner && !no_defer && !swapped && f0_slot < 0 && rep + 1 < repeat && k > 0 && op.op == AMM_OP_KICK &&
+                deferred.empty() && ops[0].op == AMM_OP_KICK) {
+                bool safe = true;
+                int nk = 0;
+                for (int j = k; j < n_ops && safe; ++j) {
+                    if (ops[j].op == AMM_OP_KICK) ++nk;
+                    else if (ops[j].op == AMM_OP_COPY) {
+                        // the copy runs now, the kicks before it later: it must not feed or clobber what they read
+                        if (ops[j].a >= AMM_SLOT_X || ops[j].b >= AMM_SLOT_X) safe = false;
+                        for (int i = k; i < j; ++i)
+                            if (ops[i].op == AMM_OP_KICK && (ops[i].a == ops[j].a || ops[i].b == ops[j].a)) safe = false;
+                    } else safe = false;
+                }
+                if (safe && nk <= 3) {
+                    for (int j = k; j < n_ops; ++j) {
+                        if (ops[j].op == AMM_OP_KICK) deferred.push_back(ops[j]);
+                        else {
+                            double *dst = (ops[j].a >= 0 && ops[j].a < AMM_MAX_SLOTS) ? ctx->slots[ops[j].a] : nullptr;
+                            double *src = (ops[j].b >= 0 && ops[j].b < AMM_MAX_SLOTS) ? ctx->slots[ops[j].b] : nullptr;
+                            if (!dst || !src) {
+                                amm_set_error("amm_run_ops: COPY buffer not bound");
+                                return 1;
+                            }
+                            if (amm_copy_impl(ctx, dst, src)) return 1;
+                        }
+                    }
+                    break;          // next repetition
+                }
+            }
+            // component-parallel inner loop: [preceding KICKs] + n x {KICK(c1, fg) ; MOVE(d) ; EVAL(g) ; KICK(c2, fg)} in one launch
             if (ctx->fuse_inner && !swapped && op.op == AMM_OP_KICK) {
                 int p = k, npre = 0;
                 while (p < n_ops && ops[p].op == AMM_OP_KICK && npre < 4) { ++p; ++npre; }
@@ -673,6 +721,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                                ops[q + 3].coef == ops[start + 3].coef;
                     return true;
                 };
+                const int ndef = (int)deferred.size();
                 if (npre <= 3 && start >= k && is_iter(start, ops[start]) && ops[start + eo].a >= 0 && ops[start + eo].a < AMM_MAX_GROUPS) {
                     GroupDef &g = ctx->groups[ops[start + eo].a];
                     BondedSet *bs = (g.slot == ops[start].a && g.forces.size() == 1 && ctx->forces[g.forces[0]].type == 2)
@@ -680,12 +729,12 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     if (bs && bs->max_comp <= 8 && !(bs->sliced && ctx->world > 1)) {
                         int niter = 0, q = start;
                         while (is_iter(q, ops[start])) { ++niter; q += stride; }
-                        const double *pa[3] = {nullptr, nullptr, nullptr}, *pb[3] = {nullptr, nullptr, nullptr};
-                        double pc[3] = {0, 0, 0};
-                        int pp[3] = {0, 0, 0};
+                        const double *pa[AMM_MAX_PRE] = {nullptr}, *pb[AMM_MAX_PRE] = {nullptr};
+                        double pc[AMM_MAX_PRE] = {0};
+                        int pp[AMM_MAX_PRE] = {0};
                         bool ok = true;
-                        for (int j = 0; j < npre; ++j) {
-                            const amm_op &ko = ops[k + j];
+                        for (int j = 0; j < ndef + npre; ++j) {
+                            const amm_op &ko = j < ndef ? deferred[j] : ops[k + j - ndef];
                             pa[j] = (ko.a >= 0 && ko.a < AMM_MAX_SLOTS) ? ctx->slots[ko.a] : nullptr;
                             pb[j] = (ko.b >= 0 && ko.b < AMM_MAX_SLOTS) ? ctx->slots[ko.b] : nullptr;
                             pc[j] = ko.coef;
@@ -694,7 +743,8 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                         }
                         double *f0 = ctx->slots[g.slot];
                         if (ok && f0) {
-                            if (amm_inner_components_impl(ctx, bs, ctx->d_x, ctx->d_v, f0, npre, pa, pb, pc, pp, ops[start].coef,
+                            deferred.clear();
+                            if (amm_inner_components_impl(ctx, bs, ctx->d_x, ctx->d_v, f0, ndef + npre, pa, pb, pc, pp, ops[start].coef,
                                                           ops[start + 1].coef, ops[start + eo + 1].coef, niter,
                                                           bathed ? &ctx->baths[ops[start + 2].a] : nullptr,
                                                           bathed ? ops[start + 3].coef : 0.0)) return 1;
@@ -708,6 +758,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                         }
                     }
                 }
+                if (!deferred.empty() && flush_deferred()) return 1;      // no fused launch to ride on
             }
             // fused inner RESPA iteration: KICK(c1, fg) ; MOVE(d) ; EVAL(g) ; KICK(c2, fg) with g = one bond-list set
             if (ctx->fuse_inner && op.op == AMM_OP_KICK && op.b < 0 && k + 3 < n_ops && ops[k + 1].op == AMM_OP_MOVE &&
@@ -875,6 +926,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
             default: amm_set_error("amm_run_ops: unknown op"); return 1;
             }
         }
+    if (flush_deferred()) return 1;
     if (swapped) {   // odd number of fused iterations: bring the state back into the caller's buffers
         const size_t bytes = sizeof(double) * 3 * (size_t)ctx->n;
         AMM_HIP(hipMemcpyAsync(user_x, ctx->d_x, bytes, hipMemcpyDeviceToDevice, ctx->stream));

@@ -9,6 +9,7 @@
 #include "../../include/atomsmm_hip.h"
 
 #define AMM_WAVE 64
+#define AMM_MAX_PRE 6            // kicks that can ride on one inner-loop launch
 #define AMM_DERIV_LAMBDA 1024   // internal PairConsts flag: energy output = dE/dlambda (softcore family)
 #define AMM_MAX_GROUPS 33   // 0..31 = OpenMM force groups, 32 = all forces (`f`)
 

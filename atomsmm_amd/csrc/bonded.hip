@@ -306,7 +306,7 @@ struct CompArgs {
     // BATH: kick ; move(d) ; Ornstein-Uhlenbeck step ; move(d2) ; forces ; kick  (Langevin_R 'middle' scheme)
     double d2, bath_z, bath_kT;
     unsigned long long seed, counter0;
-    PreKick pre[3];
+    PreKick pre[AMM_MAX_PRE];
     // displacement watchers: neighbour lists whose rebuild trigger this kernel evaluates for the positions it
     // writes (saves the separate k_check_displacement launch before the next pair-force evaluation)
     int nwatch;
@@ -770,7 +770,7 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     C.c1 = c1;
     C.d = d;
     C.c2 = c2;
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < AMM_MAX_PRE; ++p) {
         C.pre[p].a = p < npre ? pre_a[p] : nullptr;
         C.pre[p].b = p < npre ? pre_b[p] : nullptr;
         C.pre[p].coef = p < npre ? pre_coef[p] : 0.0;
