@@ -36,7 +36,7 @@ EXPORTS = [
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read',
     'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
-    'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
+    'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_destroy', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
 ]
 
 
@@ -91,6 +91,7 @@ def lib():
         L.amm_comm_unique_id.argtypes = [C.c_char_p, C.c_char_p]
         L.amm_comm_init.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
         L.amm_comm_allreduce.argtypes = [vp, vp, C.c_int64]
+        L.amm_comm_destroy.argtypes = [vp]
         L.amm_comm_stats.argtypes = [vp, C.POINTER(C.c_int64)]
         L.amm_group_set_exchange.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_bind_exchange.argtypes = [vp, vp, C.c_int64]
@@ -286,6 +287,10 @@ class HipContext:
             raise ValueError('communicator id must be %d bytes' % COMM_ID_BYTES)
         _chk(lib().amm_comm_init(self.h, self.rccl_path(), bytes(id_bytes), self.rank, self.world))
         self.has_comm = True
+
+    def comm_destroy(self):
+        _chk(lib().amm_comm_destroy(self.h))
+        self.has_comm = False
 
     def comm_allreduce(self, tensor):
         _chk(lib().amm_comm_allreduce(self.h, _ptr(tensor), tensor.numel()))

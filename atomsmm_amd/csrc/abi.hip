@@ -560,6 +560,10 @@ int amm_comm_init(amm_ctx *ctx, const char *rccl_path, const uint8_t id[AMM_COMM
     }
     return amm_comm_init_impl(ctx, rccl_path, id, rank, world);
 }
+int amm_comm_destroy(amm_ctx *ctx) {
+    if (!ctx) return 1;
+    return amm_comm_destroy_impl(ctx);
+}
 int amm_comm_stats(amm_ctx *ctx, int64_t out[2]) {
     if (!ctx || !out) return 1;
     out[0] = ctx->comm_calls;

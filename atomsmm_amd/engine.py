@@ -1224,10 +1224,29 @@ class Engine:
         round trips per outer step (measured 480 us/step of host time).  torch.distributed only carries the 128-byte id."""
         box = [None]
         if self.rank == 0:
-            box[0] = self.ctx.comm_unique_id()
+            try:
+                box[0] = self.ctx.comm_unique_id()
+            except Exception as exc:        # e.g. librccl cannot be bound: every rank then keeps torch.distributed
+                box[0] = 'failed: %s' % exc
         dist.broadcast_object_list(box, src=0)
-        self.ctx.comm_init(box[0])
-        self._native_comm = True
+        ok = isinstance(box[0], (bytes, bytearray))
+        if ok:
+            try:
+                self.ctx.comm_init(box[0])
+            except Exception as exc:
+                ok = False
+                box[0] = 'failed: %s' % exc
+        # all ranks or none: a rank without the communicator would leave the others waiting in the first collective
+        flag = self.torch.tensor([1 if ok else 0], device=self.ctx.torch_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            self._native_comm = True
+        else:
+            import warnings
+            warnings.warn('library-owned RCCL communicator not available (%s): collectives stay in torch.distributed'
+                          % (box[0] if not ok else 'another rank failed'))
+            if ok:
+                self.ctx.comm_destroy()
 
     def _run(self, ops, repeat):
         if not self._coll:

@@ -135,6 +135,8 @@ int amm_set_slice(amm_ctx *ctx, int32_t rank, int32_t world);
 #define AMM_COMM_ID_BYTES 128
 int amm_comm_unique_id(const char *rccl_path, uint8_t id[AMM_COMM_ID_BYTES]);
 int amm_comm_init(amm_ctx *ctx, const char *rccl_path, const uint8_t id[AMM_COMM_ID_BYTES], int32_t rank, int32_t world);
+/* releases the communicator (amm_destroy does it too); collective, like ncclCommDestroy */
+int amm_comm_destroy(amm_ctx *ctx);
 /* in-place sum over ranks of count doubles in device memory, on the context's stream */
 int amm_comm_allreduce(amm_ctx *ctx, double *d_buf, int64_t count);
 /* Exchange of owner-computed force slices by ALL-GATHER instead of all-reduce (1/world of the bytes, no additions).
