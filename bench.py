@@ -198,7 +198,8 @@ def main():
                                    % (n, case['box'][0], 'DampedSmoothedForce(2.9/nm, 1.0, 0.9)' if args.outer == 'damped'
                                       else 'PME NonbondedForce (rc 1.0, switch 0.9, tol 5e-4: direct + reciprocal space)'),
                        'atoms': n, 'loops': list(loops), 'outer_step_fs': dt_fs, 'relax_steps': relaxed,
-                       'parallelism': 'atom-decomposition x%d, all-reduce of group force buffers' % world if world > 1 else 'single GPU',
+                       'parallelism': ('atom decomposition x%d, %s' % (world, 'all-gather of owner-computed force slices (RCCL, library-owned communicator)'
+                                                                     if getattr(eng, '_native_comm', False) else 'collectives through torch.distributed')) if world > 1 else 'single GPU',
                        'temperature_K_end': round(T_end, 1)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': None,
