@@ -469,6 +469,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                             }
                             m_pass &= ~m_excl;
                         }
+                        if (m_pass == 0ull) continue;        // wave-uniform: no candidate of this half chunk is in range of atom t
                         const unsigned long long m_near = m_pass & __builtin_amdgcn_ballot_w64(r2 < rnear2);
                         const int np_ = __popcll(m_pass), nn_ = __popcll(m_near);
                         const int cnt = c2[t] & 0xffff, cntf = (int)((unsigned)c2[t] >> 16);
