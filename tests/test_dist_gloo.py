@@ -128,3 +128,79 @@ def test_engine_collectives_under_gloo():
     assert out[0]['f1'] == out[1]['f1'] and out[0]['f2'] == out[1]['f2']
     assert out[0]['n_runs'] == out[1]['n_runs'] and out[0]['n_runs'] >= 6     # near+outer EVALs at the step boundary share a segment
     assert not any(out[0]['sliced'])
+
+
+def _engine_gather_job(rank, world):
+    """As _engine_job, with a recording backend that offers the exchange buffer: groups of one pair force exchange
+    their slices by all-gather (host-driven here: the op list is cut after each of their EVALs, the engine gathers the
+    chunks over gloo and calls exchange_finish); nothing is all-reduced for them."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import backend as B
+    from atomsmm_amd import engine as E
+    from atomsmm_amd import openmm, unit
+    from atomsmm_amd.testing import system_from_arrays
+    from fake_backend import RecordingContext
+
+    class GatherContext(RecordingContext):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.exchange, self.gather_groups, self.finishes, self.pending = None, set(), 0, False
+
+        def bind_exchange(self, tensor):
+            self.exchange = tensor
+
+        def group_set_exchange(self, group, mode):
+            assert mode == B.EXCHANGE_GATHER
+            self.gather_groups.add(group)
+
+        def run_ops(self, ops, repeat=1):
+            super().run_ops(ops, repeat)
+            assert not self.pending, 'a new segment although the previous exchange was not finished'
+            evals = [k for k, o in enumerate(ops) if o.op == B.OP_EVAL and o.a in self.gather_groups]
+            assert evals in ([], [len(ops) - 1]) and (repeat == 1 or not evals)   # an exchanged EVAL ends its segment
+            if evals:          # the pair kernel's part: this rank's chunk of the exchange buffer
+                per = (self.n + self.world - 1) // self.world
+                self.exchange[self.rank * per * 3:(self.rank + 1) * per * 3] = float(self.rank + 1)
+                self.pending = True
+
+        def exchange_finish(self):
+            assert self.pending
+            self.pending = False
+            self.finishes += 1
+
+    made = []
+    E._context_factory = lambda *a, **k: made.append(GatherContext(*a, **k)) or made[-1]
+    d = np.load(os.path.join(root, 'tests', 'golden', 'q-SPC-FW.npz'))
+    case = {k: d[k] for k in d.files}
+    system = system_from_arrays(case, nonbondedMethod='CutoffPeriodic')
+    respa = atomsmm.RESPASystem(system, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
+    nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+    f = atomsmm.DampedSmoothedForce(2.9 / unit.nanometers, 1.0 * unit.nanometers, 0.9 * unit.nanometers).importFrom(nb)
+    f.setForceGroup(2)
+    f.addTo(respa)
+    integ = atomsmm.RespaPropagator([4, 2, 1]).integrator(4 * unit.femtoseconds)
+    ctx = openmm.Context(respa, integ)
+    ctx.setPositions(case['positions'])
+    eng = ctx._engine
+    eng._buffer('f1').fill_(float(rank + 1))
+    integ.step(2)
+    rec = made[-1]
+    per = (rec.n + world - 1) // world
+    chunks = [float(rec.exchange[r * per * 3]) for r in range(world)]
+    return dict(gather=sorted(rec.gather_groups), finishes=rec.finishes, chunks=chunks, f1=float(eng._buffers['f1'][0, 0]),
+                pending=rec.pending, n_runs=len(rec.runs))
+
+
+def test_engine_all_gather_exchange_under_gloo():
+    out = run_ranks(_engine_gather_job, world=2)
+    for r in (0, 1):
+        assert out[r]['gather'] == [1, 2]                  # near and outer force: one pair force each
+        assert out[r]['finishes'] == 5 + 3                 # f1: 3 + 2 evaluations, f2: 2 + 1 (two steps)
+        assert out[r]['chunks'] == [1.0, 2.0]              # every rank holds every rank's chunk
+        assert out[r]['f1'] == float(r + 1)                # no all-reduce touched the group buffers
+        assert not out[r]['pending']
+    assert out[0]['n_runs'] == out[1]['n_runs']
