@@ -164,6 +164,11 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     PairForce *pf = new PairForce();
     pf->desc = *desc;
     pf->n = ctx->n;
+    if (ctx->n >= (1 << 26)) {      // the traversal addresses the sorted copies with 32-bit byte offsets (32 B per slot)
+        amm_set_error("amm_pair_create: more than 2^26 atoms are not supported");
+        delete pf;
+        return 1;
+    }
     if (amm_pair_build_consts(*desc, pf->pc)) {
         delete pf;
         return 1;

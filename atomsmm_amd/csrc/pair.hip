@@ -695,8 +695,10 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, Pa
             double2 lj[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                pj[u] = A.posq_s[js[u]];
-                lj[u] = A.lj_s[js[u]];
+                // 32-bit byte offsets from the (scalar) array bases: one shift per load instead of a 64-bit index
+                // extension and shift-add (slots < 2^26, checked when the force is created)
+                pj[u] = *reinterpret_cast<const double4 *>(reinterpret_cast<const char *>(A.posq_s) + ((unsigned)js[u] << 5));
+                lj[u] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.lj_s) + ((unsigned)js[u] << 4));
             }
             // the guest's candidates are the FRONT part of the row (walked first): once every row of this wavefront is
             // past its front part, the trips skip the guest arithmetic (its contribution there is an exact zero)
