@@ -67,7 +67,7 @@ __device__ __forceinline__ void amm_erfc_exp(double x, const double *tab, double
     int k = (int)(x * AMM_ERFCX_INVH);
     k = k > AMM_ERFCX_NI - 1 ? AMM_ERFCX_NI - 1 : k;
     const double t = x - ((double)k + 0.5) * AMM_ERFCX_H;
-    const double *cf = tab + k * AMM_ERFCX_NC;
+    const double *cf = tab + __mul24(k, AMM_ERFCX_NC);      // 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate)
     double p = cf[AMM_ERFCX_NC - 1];
 #pragma unroll
     for (int m = AMM_ERFCX_NC - 2; m >= 0; --m) p = fma(p, t, cf[m]);
