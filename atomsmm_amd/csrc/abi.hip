@@ -807,8 +807,16 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
             if (ctx->fuse_inner && !no_dual && op.op == AMM_OP_EVAL && k + 1 < n_ops && ops[k + 1].op == AMM_OP_EVAL && op.a >= 0 &&
                 op.a < AMM_MAX_GROUPS && ops[k + 1].a >= 0 && ops[k + 1].a < AMM_MAX_GROUPS && op.a != ops[k + 1].a) {
                 GroupDef &g1 = ctx->groups[op.a], &g2 = ctx->groups[ops[k + 1].a];
-                if (g1.forces.size() == 1 && g2.forces.size() == 1 && g1.slot >= 0 && g2.slot >= 0 && ctx->slots[g1.slot] &&
-                    ctx->slots[g2.slot] && ctx->forces[g1.forces[0]].type == 1 && ctx->forces[g2.forces[0]].type == 1) {
+                // further members of the two groups (bond-list terms, reciprocal space of a PME outer force) are added after
+                // the shared pass; they must not be pair forces themselves
+                auto tail_ok = [&](const GroupDef &g) {
+                    for (size_t j = 1; j < g.forces.size(); ++j)
+                        if (ctx->forces[g.forces[j]].type == 1) return false;
+                    return true;
+                };
+                if (!g1.forces.empty() && !g2.forces.empty() && tail_ok(g1) && tail_ok(g2) && g1.slot >= 0 && g2.slot >= 0 &&
+                    ctx->slots[g1.slot] && ctx->slots[g2.slot] && ctx->forces[g1.forces[0]].type == 1 &&
+                    ctx->forces[g2.forces[0]].type == 1) {
                     PairForce *pa = ctx->forces[g1.forces[0]].pair, *pb = ctx->forces[g2.forces[0]].pair;
                     PairForce *guest = pa->host == pb ? pa : (pb->host == pa ? pb : nullptr);
                     if (guest) {
@@ -817,6 +825,9 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                         if (g1.exchange == g2.exchange && amm_pair_can_eval_dual(ctx, guest, host)) {
                             if (amm_pair_eval_impl(ctx, host, ctx->d_x, fh, 0, nullptr, guest, fg, 0, g1.exchange)) return 1;
                             if (exchange_left_to_host(ctx, rep == repeat - 1 && k + 1 == n_ops - 1)) return 1;
+                            for (const GroupDef *g : {&g1, &g2})
+                                for (size_t j = 1; j < g->forces.size(); ++j)
+                                    if (force_eval_dispatch(ctx, g->forces[j], ctx->d_x, ctx->slots[g->slot], 1, nullptr)) return 1;
                             k += 1;
                             continue;
                         }

@@ -1269,6 +1269,7 @@ bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host) {
     if ((guest->desc.flags & AMM_GUARD_RC0) || (host->desc.flags & AMM_GUARD_RC0)) return false;
     if ((guest->desc.flags | host->desc.flags) & (AMM_GROUP_LJ | AMM_GROUP_Q)) return false;
     if (!(guest->desc.rc <= host->desc.rc)) return false;
+    if (guest->pc.Kc != host->pc.Kc) return false;          // the pass forms Kc q_i q_j once, with the host's constant
     const size_t n = (size_t)ctx->n;
     std::vector<double> a(n), b(n);
     const double *ga[3] = {guest->d_q, guest->d_hsig, guest->d_seps2}, *ha[3] = {host->d_q, host->d_hsig, host->d_seps2};
