@@ -35,6 +35,8 @@ _SAFE_FUNCS = {name: getattr(math, name) for name in ('sqrt', 'exp', 'log', 'sin
 _SAFE_FUNCS.update(step=lambda x: 1.0 if x >= 0 else 0.0, delta=lambda x: 1.0 if x == 0 else 0.0,
                    select=lambda c, a, b: a if c != 0 else b, min=min, max=max, abs=abs)
 ALLREDUCE = 'allreduce'
+_AUX_FORCE = re.compile(r'_f[0-9]*_')      # auxiliary buffers of multi-force expressions (integrators.py:134-145)
+_NO_ALIAS = os.environ.get('AMM_NO_ALIAS') is not None      # tuning knob (A/B)
 _context_factory = B.HipContext   # the only backend; tests of the host logic substitute a call recorder
 
 
@@ -841,6 +843,9 @@ class Engine:
         self._mirror.pop(name, None)
 
     def get_per_dof(self, name):
+        src = self._mirror.get(name)
+        if src is not None and _AUX_FORCE.fullmatch(name) and src in self._buffers and not _NO_ALIAS:
+            self._buffer(name).copy_(self._buffers[src])        # its copy op may have been dropped (_drop_dead_copies)
         return [mm.Vec3(*row) for row in self._buffer(name).cpu().numpy().tolist()]
 
     def set_per_dof(self, name, values):
@@ -1017,7 +1022,7 @@ class Engine:
             pc += 1
         self._static_exprs = False
         finals = {name: env[name] for name in integ._gnames}
-        return self._pair_up_evals(ops), valid, finals, dict(self._mirror_work)
+        return self._drop_dead_copies(self._pair_up_evals(ops)), valid, finals, dict(self._mirror_work)
 
     def _pair_up_evals(self, ops):
         """RESPA evaluates the near force (group 1) and, one kick later, the outer force (group 2) at the same positions
@@ -1117,7 +1122,52 @@ class Engine:
         integ = self.integrator
         if name not in integ._pnames and name not in ('x', 'v'):
             raise NotImplementedError('unknown per-DOF symbol in step program: ' + name)
+        # `_f2_` while it mirrors f2 (`_f2_ <- f2`, integrators.py:139-144, and no evaluation of group 2 since): read the
+        # group's buffer itself, so that the copy has no reader left and can be dropped (_drop_dead_copies)
+        src = self._mirror_work.get(name)
+        if src is not None and _AUX_FORCE.fullmatch(name) and not _NO_ALIAS:
+            g = 'all' if src == 'f' else int(src[1:])
+            if g in self._group_defs:
+                return self._group_defs[g][1]
         return self._slot(name)
+
+    def _drop_dead_copies(self, ops):
+        """Remove COPY ops into the integrator's auxiliary force buffers (`_f2_ <- f2`) that no later op reads before the
+        buffer is written again -- the program is cyclic, so the search wraps around.  get_per_dof materialises such a
+        buffer from the force it mirrors when the user asks for it."""
+        if _NO_ALIAS:
+            return ops
+        aux = {slot for name, slot in self._slots.items() if _AUX_FORCE.fullmatch(name)}
+        if not aux:
+            return ops
+
+        def reads(op, slot):
+            if isinstance(op, tuple):
+                return op[1] == slot
+            if op.op == B.OP_KICK:
+                return slot in (op.a, op.b)
+            if op.op == B.OP_COPY:
+                return op.b == slot
+            if op.op == B.OP_COMBINE:
+                return slot in (op.b, op.c)
+            return op.op in (B.OP_EXPR,)            # expression programs may read any buffer
+
+        def writes(op, slot):
+            return not isinstance(op, tuple) and op.op in (B.OP_COPY, B.OP_COMBINE) and op.a == slot
+
+        keep = [True] * len(ops)
+        for k, op in enumerate(ops):
+            if isinstance(op, tuple) or op.op != B.OP_COPY or op.a not in aux:
+                continue
+            dead = True
+            for j in list(range(k + 1, len(ops))) + list(range(0, k)):
+                if reads(ops[j], op.a):
+                    dead = False
+                    break
+                if writes(ops[j], op.a):
+                    break
+            keep[k] = not dead
+        return [op for op, kept in zip(ops, keep) if kept]
 
     def _emit_per_dof(self, target, expr, env, ops, valid):
         text = expr.replace(' ', '')
