@@ -1126,9 +1126,7 @@ class Engine:
         # group's buffer itself, so that the copy has no reader left and can be dropped (_drop_dead_copies)
         src = self._mirror_work.get(name)
         if src is not None and _AUX_FORCE.fullmatch(name) and not _NO_ALIAS:
-            g = 'all' if src == 'f' else int(src[1:])
-            if g in self._group_defs:
-                return self._group_defs[g][1]
+            return self._define_group('all' if src == 'f' else int(src[1:]))[1]
         return self._slot(name)
 
     def _drop_dead_copies(self, ops):
