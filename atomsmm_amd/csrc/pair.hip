@@ -712,6 +712,20 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, Pa
                 bool pass = ok[u] && (r2 < c.rc2);
                 if (GUARD) pass = pass && (r2 <= guard2);          // step(rc0 - r)
                 const double r2s = pass ? r2 : 1.0;
+                // the guest first: it needs only what both share (1/r, the LJ and Coulomb pieces); the host's own part (its
+                // table coefficients, exp, switch) is kept behind a scheduling barrier so that it is not live across the
+                // guest block -- 142 -> see the kernel table in DESIGN.md for the register count
+                if (GFAM >= 0) {
+                    if (guest_trip) {
+                        double eg, frg;
+                        amm_pair_math<GFAM, 0, false, false>(gc, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, eg, frg, s_tab);
+                        frg = (pass && r2 < gc.rc2) ? frg : 0.0;
+                        gx += frg * dx;
+                        gy += frg * dy;
+                        gz += frg * dz;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 double e, fr;
                 amm_pair_math<FAM, CMODE, false, EN, GROUPED>(c, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, e, fr, s_tab);
                 fr = pass ? fr : 0.0;
@@ -719,14 +733,6 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, Pa
                 fy += fr * dy;
                 fz += fr * dz;
                 if (EN) esum += pass ? e : 0.0;
-                if (GFAM >= 0 && guest_trip) {
-                    double eg, frg;
-                    amm_pair_math<GFAM, 0, false, false>(gc, r2s, qi * pj[u].w, li.x + lj[u].x, li.y * lj[u].y, eg, frg, s_tab);
-                    frg = (pass && r2 < gc.rc2) ? frg : 0.0;
-                    gx += frg * dx;
-                    gy += frg * dy;
-                    gz += frg * dz;
-                }
             }
         }
     }
