@@ -330,7 +330,8 @@ struct PosLds {
 // same numbers in the same order, so still bit-identical to k_bonded, with each term computed once instead of once per
 // atom and a dependency chain of one term instead of the atom's whole record list (a water: 1 bond + 1 angle path per
 // iteration instead of 2 + 2).
-template <int G, bool BATH, bool TERMS>
+// HONLY: the set holds harmonic bonds and angles only (a flexible water model): the other kinds' code is compiled out.
+template <int G, bool BATH, bool TERMS, bool HONLY>
 __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
     __shared__ double s_x[3][256];
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
         f[0] = f[1] = f[2] = 0.0;
         auto do_rec = [&](const int4 al, const double4 q) {
             const long long code = __double_as_longlong(q.w);
-            const int kind = (int)(code & 7), role = (int)((code >> 3) & 3), periodic = (int)((code >> 5) & 1);
+            const int kind = HONLY ? (int)(code & 1) : (int)(code & 7), role = (int)((code >> 3) & 3), periodic = (int)((code >> 5) & 1);
             const int ix[4] = {al.x, al.y, al.z, al.w};
             const double p[3] = {q.x, q.y, q.z};
             double fo[4][3], e;
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
                 const int ix[4] = {my_tl.x, my_tl.y, my_tl.z, my_tl.w};
                 const double p[3] = {my_tq.x, my_tq.y, my_tq.z};
                 double e;
-                bonded_term_forces(A, pos, ix, p, (int)(code & 7), (int)((code >> 5) & 1), fo, e);
+                bonded_term_forces(A, pos, ix, p, HONLY ? (int)(code & 1) : (int)(code & 7), (int)((code >> 5) & 1), fo, e);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -790,7 +791,13 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     C.term_q = bs->d_term_q;
     C.atom_recs = bs->d_atom_recs;
     if (bath) ctx->expr_counter += (unsigned long long)niter;      // one BATH op per iteration, as the unfused sequence counts
-#define AMM_LAUNCH_INNER(GG, BB, TT) hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT>), grid, block, 0, ctx->stream, A, C)
+    bool honly = true;
+    for (int kd = 2; kd < 8; ++kd) honly = honly && bs->n_terms[kd] == 0;
+#define AMM_LAUNCH_INNER(GG, BB, TT)                                                                          \
+    do {                                                                                                        \
+        if (honly) hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT, true>), grid, block, 0, ctx->stream, A, C);   \
+        else hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT, false>), grid, block, 0, ctx->stream, A, C);         \
+    } while (0)
     if (bath) {
         if (G == 4) { if (terms) AMM_LAUNCH_INNER(4, true, true); else AMM_LAUNCH_INNER(4, true, false); }
         else { if (terms) AMM_LAUNCH_INNER(8, true, true); else AMM_LAUNCH_INNER(8, true, false); }
