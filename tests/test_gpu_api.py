@@ -539,3 +539,26 @@ def test_AlchemicalRespaSystem_with_softcore(phenol):              # tests/test_
     assert [force.getCollectiveVariableName(i) for i in range(force.getNumCollectiveVariables())] == ['E%d' % i for i in range(6)]
     assert values == pytest.approx([0.0, -10.071581499620784, -19.66450283710424, -28.284595753200428, -35.004158250494505,
                                     -37.9416812137183])
+
+
+def test_alchemical_respa_trajectory_fused_equals_unfused(phenol):
+    """AlchemicalRespaSystem over a PME system, RESPA [2,2,1]: the near force (Kc = 138.935456637, systems.py:572) and the
+    NonbondedForce (OpenMM's 138.935456) share a neighbour list but must NOT share a pass (the pass forms Kc q_i q_j once);
+    groups 1 and 2 hold several members each.  Every fusion of amm_run_ops on == off, bit for bit."""
+    system, positions, topology, solute = _phenol_system(phenol)
+    results = []
+    for fuse in (True, False):
+        alch = atomsmm.AlchemicalRespaSystem(system, 7 * unit.angstroms, 5 * unit.angstroms, solute,
+                                             coupling_function='lambda^4*(5-4*lambda)')
+        integrator = atomsmm.RespaPropagator([2, 2, 1]).integrator(2 * unit.femtoseconds)
+        context = openmm.Context(alch, integrator)
+        context._engine.ctx.set_fuse_inner(fuse)
+        context.setParameter('lambda', 0.5)
+        context.setParameter('respa_switch', 1)
+        context.setPositions(positions)
+        context.setVelocitiesToTemperature(300 * unit.kelvin, 11)
+        integrator.step(4)
+        st = context.getState(getPositions=True, getVelocities=True)
+        results.append((st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    assert np.isfinite(results[0][0]).all()
