@@ -562,3 +562,25 @@ def test_alchemical_respa_trajectory_fused_equals_unfused(phenol):
         results.append((st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value))
     assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
     assert np.isfinite(results[0][0]).all()
+
+
+def test_pme_respa_trajectory_fused_equals_unfused(spcfw):
+    """RESPASystem over a PME water box, RESPA [4,2,1]: group 2 holds the NonbondedForce's pair force, its exclusion terms
+    and the reciprocal space; the near force rides on the pair force's pass (dual evaluation) and the other members are
+    added afterwards -- every fusion of amm_run_ops on == off, bit for bit, list rebuilds included."""
+    system = system_from_arrays(spcfw, nonbondedMethod='PME')
+    results = []
+    for fuse in (True, False):
+        respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+        integrator = atomsmm.RespaPropagator([4, 2, 1]).integrator(4 * unit.femtoseconds)
+        context = openmm.Context(respa, integrator)
+        context._engine.ctx.set_fuse_inner(fuse)
+        context.setPositions(spcfw['positions'] * unit.nanometers)
+        context.setVelocitiesToTemperature(300 * unit.kelvin, 5)
+        integrator.step(25)
+        st = context.getState(getPositions=True, getVelocities=True)
+        eng = context._engine
+        results.append((st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value,
+                        eng.ctx.pair_stats(eng.pair_force_ids(2)[0])['n_builds']))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    assert results[0][2] == results[1][2] and results[0][2] >= 2          # the list was rebuilt on the way
