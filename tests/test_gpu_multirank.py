@@ -141,3 +141,74 @@ def test_library_owned_rccl_communicator(pme):
     # reciprocal-space terms and is all-reduced on its own
     assert out['comm']['doubles'] == (3 * 3 + 2) * 9000, out['comm']
     assert out['comm']['calls'] == (2 * 3 + 1 if not pme else 3 * 3 + 2), out['comm']
+
+
+def test_exchange_chunks_of_five_uneven_slices():
+    """The all-gather exchange without any collective library: five contexts in ONE process stand for ranks 0..4 of a
+    world of 5 (1536 atoms: slices of 308, 308, 308, 308, 304 slots).  Every 'rank' evaluates the near and the outer
+    force of its slice in one pass into its chunk of its exchange buffer (no communicator: the EVAL leaves the exchange
+    to the host), the chunks are copied between the buffers as an all-gather would, amm_exchange_finish spreads them:
+    every rank then holds the forces of a single-context evaluation, bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from atomsmm_amd import backend as B
+    from atomsmm_amd.testing import tip3p_box
+    from test_gpu_abi_parity import near, hip_pair, dev, O
+    c = tip3p_box(8)
+    n = len(c['positions'])
+    assert n == 1536
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+    world = 5
+    per = (n + world - 1) // world
+    E = B.OP_EVAL
+
+    def make(rank, w):
+        ctx = B.HipContext(n, c['box'], rank=rank, world=w)
+        fn = hip_pair(B, ctx, dn, c)
+        ff = hip_pair(B, ctx, dd, c)
+        ctx.pair_share_list(fn, ff)
+        x, v, m = dev(c['positions']), dev(c['velocities']), dev(c['mass'])
+        f = [torch.zeros((n, 3), dtype=torch.float64, device='cuda') for _ in range(3)]
+        ctx.bind_state(x, v, m)
+        for slot, buf in enumerate(f):
+            ctx.bind_buffer(slot, buf)
+        ctx.group_define(1, 1, [fn])
+        ctx.group_define(2, 2, [ff])
+        return ctx, f, (x, v, m)
+
+    ref, fref, keep_ref = make(0, 1)
+    ref.run_ops([B.Op(E, 1, 0, 0, 0.0), B.Op(E, 2, 0, 0, 0.0)], 1)
+    ref.check()
+    ranks = []
+    for r in range(world):
+        ctx, f, keep = make(r, world)
+        xchg = torch.full((world * 2 * per * 3,), float('nan'), dtype=torch.float64, device='cuda')
+        ctx.bind_exchange(xchg)
+        ctx.group_set_exchange(1, B.EXCHANGE_GATHER)
+        ctx.group_set_exchange(2, B.EXCHANGE_GATHER)
+        ctx.run_ops([B.Op(E, 1, 0, 0, 0.0), B.Op(E, 2, 0, 0, 0.0)], 1)       # dual pass: chunk = [2][per][3]
+        ranks.append((ctx, f, xchg, keep))
+    chunk = 2 * per * 3
+    for r, (ctx, f, xchg, keep) in enumerate(ranks):           # the all-gather, by hand
+        for q, other in enumerate(ranks):
+            if q != r:
+                xchg[q * chunk:(q + 1) * chunk].copy_(other[2][q * chunk:(q + 1) * chunk])
+    for ctx, f, xchg, keep in ranks:
+        ctx.exchange_finish()
+        ctx.check()
+        assert torch.equal(f[1], fref[1]) and torch.equal(f[2], fref[2])
+        with pytest.raises(B.HipError):
+            ctx.exchange_finish()                               # nothing is waiting any more
+    # a single (not dual) exchanged evaluation uses chunks of [per][3]
+    ctx, f, xchg, keep = ranks[2]
+    f[1].zero_()
+    ctx.run_ops([B.Op(E, 1, 0, 0, 0.0)], 1)
+    lo = 2 * per * 3
+    mine = xchg[lo:lo + per * 3].clone()
+    assert torch.isfinite(mine).all() and torch.count_nonzero(mine) > 0
+    with pytest.raises(B.HipError):                             # the previous exchange still waits for its finish
+        ctx.run_ops([B.Op(E, 1, 0, 0, 0.0)], 1)
+    for ctx, f, xchg, keep in ranks:
+        ctx.close()
+    ref.close()
