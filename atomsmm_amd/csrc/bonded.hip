@@ -390,6 +390,14 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
     }
     const int gbase = (int)threadIdx.x - l;
     PosLds pos{&s_x[0][gbase], &s_x[1][gbase], &s_x[2][gbase]};
+    // TERMS: where the atom's first four records sit in s_out (element index of the x component)
+    const int rec_n = (int)(my_recs >> 60);
+    int rec_at[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int rcode = (int)((my_recs >> (5 * t)) & 31ull);
+        rec_at[t] = 3 * (rcode >> 3) * 256 + gbase + (rcode & 7);
+    }
     for (int it = 0; it < C.niter; ++it) {
         {
 #pragma clang fp contract(off)
@@ -447,21 +455,31 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
                 bonded_term_forces(A, pos, ix, p, HONLY ? (int)(code & 1) : (int)(code & 7), (int)((code >> 5) & 1), fo, e);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < (HONLY ? 3 : 4); ++r)          // bonds and angles have no fourth atom
 #pragma unroll
                 for (int xx = 0; xx < 3; ++xx) s_out[TERMS ? r * 3 + xx : 0][TERMS ? threadIdx.x : 0] = fo[r][xx];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int nr = (int)(my_recs >> 60);
-            unsigned long long rr = my_recs;
-            for (int t = 0; t < nr; ++t) {
-                const int rcode = (int)(rr & 31ull);
-                rr >>= 5;
-                const int src = gbase + (rcode & 7), row = 3 * (rcode >> 3);
-                f[0] += s_out[TERMS ? row : 0][TERMS ? src : 0];
-                f[1] += s_out[TERMS ? row + 1 : 0][TERMS ? src : 0];
-                f[2] += s_out[TERMS ? row + 2 : 0][TERMS ? src : 0];
+            // the atom's records in order: the first four from the table decoded before the loop, the rest from the word
+            const double *so = &s_out[0][0];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < rec_n) {
+                    f[0] += so[TERMS ? rec_at[t] : 0];
+                    f[1] += so[TERMS ? rec_at[t] + 256 : 0];
+                    f[2] += so[TERMS ? rec_at[t] + 512 : 0];
+                }
+            if (rec_n > 4) {
+                unsigned long long rr = my_recs >> 20;
+                for (int t = 4; t < rec_n; ++t) {
+                    const int rcode = (int)(rr & 31ull);
+                    rr >>= 5;
+                    const int src = gbase + (rcode & 7), row = 3 * (rcode >> 3);
+                    f[0] += s_out[TERMS ? row : 0][TERMS ? src : 0];
+                    f[1] += s_out[TERMS ? row + 1 : 0][TERMS ? src : 0];
+                    f[2] += s_out[TERMS ? row + 2 : 0][TERMS ? src : 0];
+                }
             }
         } else
         // ONE inlined copy of the term code (it covers every bond-list kind: unrolling this loop over a register
