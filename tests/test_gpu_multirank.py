@@ -212,3 +212,56 @@ def test_exchange_chunks_of_five_uneven_slices():
     for ctx, f, xchg, keep in ranks:
         ctx.close()
     ref.close()
+
+
+def test_exchange_with_empty_slices_on_a_tiny_box():
+    """More ranks than work: 24 atoms over a world of 8 with 4 atoms per slice would leave nothing empty, so 16 ranks' worth
+    is emulated with per = 2 (ranks 12..15 own no atom).  Small box: the minimum-image (RINT) list build.  Same hand-made
+    all-gather as above; every rank, the empty ones included, ends with the single-context force, bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from atomsmm_amd import backend as B
+    from atomsmm_amd.testing import tip3p_box
+    from test_gpu_abi_parity import near, hip_pair, dev
+    c = tip3p_box(2)
+    n = len(c['positions'])
+    assert n == 24
+    dn = near('force-switch', 0.3, 0.25)
+    world = 16
+    per = (n + world - 1) // world
+    assert per == 2 and (world - 1) * per >= n            # the last ranks are empty
+    E = B.OP_EVAL
+
+    def make(rank, w):
+        ctx = B.HipContext(n, c['box'], rank=rank, world=w)
+        fn = hip_pair(B, ctx, dn, c)
+        x, v, m = dev(c['positions']), dev(c['velocities']), dev(c['mass'])
+        f = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+        ctx.bind_state(x, v, m)
+        ctx.bind_buffer(1, f)
+        ctx.group_define(1, 1, [fn])
+        return ctx, f, (x, v, m)
+
+    ref, fref, keep_ref = make(0, 1)
+    ref.run_ops([B.Op(E, 1, 0, 0, 0.0)], 1)
+    ref.check()
+    assert float(fref.abs().max()) > 0.0
+    ranks = []
+    for r in range(world):
+        ctx, f, keep = make(r, world)
+        xchg = torch.zeros(world * 2 * per * 3, dtype=torch.float64, device='cuda')
+        ctx.bind_exchange(xchg)
+        ctx.group_set_exchange(1, B.EXCHANGE_GATHER)
+        ctx.run_ops([B.Op(E, 1, 0, 0, 0.0)], 1)
+        ranks.append((ctx, f, xchg, keep))
+    chunk = per * 3                                       # a single evaluation: chunks of [per][3]
+    for r, (ctx, f, xchg, keep) in enumerate(ranks):
+        for q, other in enumerate(ranks):
+            if q != r:
+                xchg[q * chunk:(q + 1) * chunk].copy_(other[2][q * chunk:(q + 1) * chunk])
+    for ctx, f, xchg, keep in ranks:
+        ctx.exchange_finish()
+        ctx.check()
+        assert torch.equal(f, fref)
+        ctx.close()
+    ref.close()
