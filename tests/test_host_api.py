@@ -557,3 +557,69 @@ def test_sin_r_program_structure():
     assert 'v2_0 <- z*v2_0 + sqrt(kT*(1 - z*z)/mass)*gaussian; mass = Q2; z = exp(-(0.25*dt)*friction)' in lines
     iso = atomsmm.MassiveIsokineticPropagator(300 * unit.kelvin, 10 * unit.femtoseconds, 1, forceDependent=False)
     assert set(iso.perDofVariables) == {'v1_0', 'v2_0', 'H'} and unit.md_value(iso.perDofVariables['v1_0']) == pytest.approx(100.0)
+
+
+# ------------------------------------------------------------------------------------------------ drop-in import surface
+def test_alias_packages_resolve_to_the_native_implementation():
+    """`import atomsmm`, `from simtk import openmm, unit`, `from simtk.openmm import app`: the reference's import lines
+    (/root/reference/tests/test_respa_forces.py:3-8, src/atomsmm/__init__.py:3-43)."""
+    import importlib
+    import simtk
+    from simtk import openmm as mm2, unit as unit2
+    from simtk.openmm import app as app2
+    import atomsmm as alias
+    import atomsmm_amd
+    assert mm2 is atomsmm_amd.openmm and unit2 is atomsmm_amd.unit and app2 is atomsmm_amd.openmm.app
+    assert importlib.import_module('simtk.openmm.app') is app2 and simtk.openmm is mm2
+    assert alias.RespaPropagator is atomsmm_amd.RespaPropagator and alias.forces is atomsmm_amd.forces
+    assert importlib.import_module('atomsmm.propagators') is atomsmm_amd.propagators
+    for name in atomsmm_amd.__all__:
+        assert getattr(alias, name) is getattr(atomsmm_amd, name)
+    assert mm2.app.PME == app2.PME and app2.HBonds is not None
+
+
+@pytest.mark.parametrize('case', ['q-SPC-FW', 'hydroxyethylaminoanthraquinone-in-water', 'emim_BCN4_Jiung2014', 'phenol-in-water'])
+def test_pdbfile_and_forcefield_reproduce_the_fixtures(case):
+    """app.PDBFile + app.ForceField.describe on the reference's data files give the committed .npz arrays exactly."""
+    import os
+    from conftest import GOLDEN, load_case
+    from atomsmm_amd.openmm import app as A
+    pdb = A.PDBFile(os.path.join(GOLDEN, 'data', case + '.pdb'))
+    d = A.ForceField(os.path.join(GOLDEN, 'data', case + '.xml')).describe(pdb.topology)
+    ref = load_case(case)
+    assert np.array_equal(np.array([list(v) for v in pdb.positions._value]), ref['positions'])
+    assert np.array_equal(np.array(list(pdb.topology.getUnitCellDimensions()._value)), ref['box'])
+    assert [a.name for a in pdb.topology.atoms()] == list(ref['atomname'])
+    assert [a.residue.name for a in pdb.topology.atoms()] == list(ref['resname'])
+    for key in ('charge', 'sigma', 'epsilon', 'mass', 'bonds', 'bond_r0', 'bond_k', 'angles', 'angle_theta0', 'angle_k',
+                'torsions', 'torsion_n', 'torsion_phase', 'torsion_k', 'exc_pairs', 'exc_chargeprod', 'exc_sigma', 'exc_epsilon'):
+        assert np.array_equal(d[key], ref[key]), key
+
+
+def test_create_system_options():
+    """createSystem's keyword arguments as the reference's tests use them (tests/test_systems.py:14-19,
+    tests/test_propagators.py:14-17, tests/test_respa_forces.py:58-61)."""
+    import os
+    from conftest import GOLDEN
+    from atomsmm_amd.openmm import app as A
+    pdb = A.PDBFile(os.path.join(GOLDEN, 'data', 'q-SPC-FW.pdb'))
+    ff = A.ForceField(os.path.join(GOLDEN, 'data', 'q-SPC-FW.xml'))
+    rigid = ff.createSystem(pdb.topology, nonbondedMethod=A.CutoffPeriodic)
+    assert rigid.getNumConstraints() == 1536 and isinstance(rigid.getForce(rigid.getNumForces() - 1), openmm.CMMotionRemover)
+    assert sum(f.getNumBonds() for f in rigid.getForces() if isinstance(f, openmm.HarmonicBondForce)) == 0
+    flexible = ff.createSystem(pdb.topology, nonbondedMethod=A.PME, nonbondedCutoff=10 * unit.angstroms, rigidWater=False,
+                               constraints=None, removeCMMotion=False)
+    assert flexible.getNumConstraints() == 0
+    nb = flexible.getForce(atomsmm.findNonbondedForce(flexible))
+    assert nb.getNonbondedMethod() == openmm.NonbondedForce.PME and nb.getCutoffDistance() == 1.0 * unit.nanometers
+    assert nb.getNumExceptions() == 1536 and flexible.getForce(0).getNumBonds() == 1024 and flexible.getForce(1).getNumAngles() == 512
+    box = flexible.getDefaultPeriodicBoxVectors()
+    assert [float(unit.md_value(box[k])[k]) for k in range(3)] == [2.5, 2.5, 2.5]
+    emim_pdb = A.PDBFile(os.path.join(GOLDEN, 'data', 'emim_BCN4_Jiung2014.pdb'))
+    emim = A.ForceField(os.path.join(GOLDEN, 'data', 'emim_BCN4_Jiung2014.xml'))
+    hbonds = emim.createSystem(emim_pdb.topology, nonbondedMethod=A.PME, constraints=A.HBonds, removeCMMotion=True)
+    free = emim.createSystem(emim_pdb.topology, nonbondedMethod=A.PME, constraints=None, removeCMMotion=False)
+    n_h_bonds = hbonds.getNumConstraints()
+    assert n_h_bonds > 0 and free.getForce(0).getNumBonds() - hbonds.getForce(0).getNumBonds() == n_h_bonds
+    with pytest.raises(ValueError):
+        A.ForceField(os.path.join(GOLDEN, 'data', 'q-SPC-FW.xml')).createSystem(emim_pdb.topology)
