@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libatomsmm_hip.so')
+LIB_PATH = os.environ.get('AMM_LIB') or os.path.join(HERE, 'libatomsmm_hip.so')      # AMM_LIB: an experimental build (kernel tuning)
 
 NEAR_NONE, NEAR_SHIFT, NEAR_FSWITCH, DAMPED, NONBONDED, SOFTCORE, LJ_VIRIAL = range(7)
 GUARD_RC0, COULOMB_EWALD, COULOMB_RF, SWITCH, NO_SHIFT, GROUP_LJ, GROUP_Q = 1, 2, 4, 8, 16, 32, 64

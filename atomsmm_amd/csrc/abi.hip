@@ -169,7 +169,7 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
         delete pf;
         return 1;
     }
-    if (amm_pair_build_consts(*desc, pf->pc)) {
+    if (amm_pair_build_consts(*desc, pf->pc) || amm_pair_build_table(pf)) {
         delete pf;
         return 1;
     }
@@ -221,6 +221,10 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     AMM_HIP(hipMalloc(&pf->d_cell_count, sizeof(int) * (nc + 1)));
     AMM_HIP(hipMemset(pf->d_cell_count, 0, sizeof(int) * (nc + 1)));
     AMM_HIP(hipMalloc(&pf->d_cell_start, sizeof(int) * (nc + 1)));
+    AMM_HIP(hipMalloc(&pf->d_cell_count_lj, sizeof(int) * (nc + 1)));
+    AMM_HIP(hipMemset(pf->d_cell_count_lj, 0, sizeof(int) * (nc + 1)));
+    AMM_HIP(hipMalloc(&pf->d_cell_start_lj, sizeof(int) * (nc + 1)));
+    AMM_HIP(hipMalloc(&pf->d_cls, sizeof(int) * n));
     AMM_HIP(hipMalloc(&pf->d_perm, sizeof(int) * n));
     AMM_HIP(hipMalloc(&pf->d_inv_perm, sizeof(int) * n));
     AMM_HIP(hipMalloc(&pf->d_posq_s, sizeof(double4) * n));
@@ -347,6 +351,10 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
     AMM_HIP(hipMemcpy(pf->d_q, h_q, sizeof(double) * n, hipMemcpyHostToDevice));
     AMM_HIP(hipMemcpy(pf->d_hsig, hs.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     AMM_HIP(hipMemcpy(pf->d_seps2, se.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    // class of each atom for the traversal order: 1 = no Lennard-Jones site (its rows skip the LJ arithmetic)
+    std::vector<int> cls(n);
+    for (int i = 0; i < n; ++i) cls[i] = h_eps[i] == 0.0 ? 1 : 0;
+    AMM_HIP(hipMemcpy(pf->d_cls, cls.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     // dual evaluation needs bitwise equal parameters on guest and host: re-check after any change
     pf->dual_ok = -1;
     for (auto &fo : ctx->forces)

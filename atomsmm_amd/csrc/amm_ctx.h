@@ -23,6 +23,14 @@ void amm_set_error(const std::string &msg);
         }                                                                                        \
     } while (0)
 
+// Radial Coulomb table of a pair force (pair_tab.h): abscissa w = r^2 * scale, interval = (hi32(w) >> 13) - base.
+struct PairTab {
+    double scale, r2min;                // r2 < r2min: below the table (analytic path)
+    int baseA, nA;                      // zone A (w < 1): interval = (hi32(w) >> 13) - baseA, nA intervals
+    int shiftB, rawB_minus_nA, halfB;   // zone B (w >= 1): interval = (hi32(w) >> shiftB) - rawB_minus_nA
+    int nint;                           // all intervals; 0: the family has no table
+};
+
 // Constants of one pair force, precomputed on the host and passed to kernels by value.
 struct PairConsts {
     int family, flags, degree, cmode;   // cmode: 0 plain coulomb, 1 ewald(erfc), 2 reaction field
@@ -32,6 +40,7 @@ struct PairConsts {
     double b, f12c, f6c, f1c;           // force-switch (forces.py:559-563)
     double sw_den, inv_sw_dr;           // DAMPED: rc^d - rs^d ; NONBONDED: 1/(rc - rswitch)
     double inv_sw_den, rswitch_d;       // DAMPED: 1/(rc^d - rs^d), rs^d
+    PairTab tab;
 };
 
 struct Box {
@@ -89,6 +98,11 @@ struct PairForce {
     int parts = 1;                 // wavefronts per cell in the list-build kernel
     double *d_epart = nullptr;
     int n_epart = 0;
+    double *d_tab = nullptr;       // radial Coulomb table: pc.tab.nint x 6 doubles (pair_tab.h)
+    double tab_error = 0;          // largest relative interpolation error found when the table was built
+    int *d_cls = nullptr;          // per atom (original order): 1 = no Lennard-Jones site (eps = 0) -- sorted behind the others in its cell
+    int *d_cell_count_lj = nullptr, *d_cell_start_lj = nullptr;   // per cell: atoms WITH a Lennard-Jones site (count, exclusive scan)
+    int *d_row_order = nullptr;    // traversal order of the slice's rows: rows with a Lennard-Jones site first (wave-uniform LJ skip)
     bool built = false;
     int64_t n_evals = 0;
     // profiling
@@ -210,6 +224,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
                        int exchange = 0);
 bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host);
 int amm_pair_free(PairForce *pf);
+int amm_pair_build_table(PairForce *pf);
 int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate,
                          double *d_energy);
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);

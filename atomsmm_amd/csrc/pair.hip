@@ -20,6 +20,7 @@
 #include "amm_ctx.h"
 #include "device_utils.h"
 #include "pair_math.h"
+#include "pair_tab.h"
 
 // ------------------------------------------------------------------------------------------------
 // host: constants
@@ -95,7 +96,7 @@ __global__ void k_check_displacement(int n, const double *__restrict__ pos, cons
 // the last block turns the counts into the exclusive scan start[0..ncell] (count <- 0) and records the fullest cell
 __global__ void __launch_bounds__(256) k_cell_assign(int n, const double *__restrict__ pos, Box box, CellGrid g, int *cell_of,
                               int *count, int *start, int *members, int capc, double *xref, int *flags, int *ticket,
-                              int which, int force) {
+                              int which, int force, const int *__restrict__ cls, int *count_lj, int *start_lj) {
     if (!force && !flags[which]) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -111,6 +112,7 @@ __global__ void __launch_bounds__(256) k_cell_assign(int n, const double *__rest
         int cell = (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
         cell_of[i] = cell;
         const int rank = atomicAdd(&count[cell], 1);
+        if (!cls[i]) atomicAdd(&count_lj[cell], 1);       // atoms with a Lennard-Jones site: first in their cell, first in row_order
         if (members) {
             if (rank < capc) members[(size_t)cell * capc + rank] = i;
             else flags[7] = 1;            // reported by amm_check: the density grew beyond the member tables
@@ -119,6 +121,8 @@ __global__ void __launch_bounds__(256) k_cell_assign(int n, const double *__rest
     if (!amm_last_block(ticket)) return;
     const int fullest = amm_block_scan_counts(g.ncell, count, start);
     if (threadIdx.x == 0) flags[6] = fullest;
+    __syncthreads();
+    amm_block_scan_counts(g.ncell, count_lj, start_lj);
 }
 
 // rebuild: one wavefront per cell ranks the cell's members by atom index -> deterministic order whatever the atomics
@@ -132,7 +136,9 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
                                                           const double *__restrict__ pos, Box box, float4 *pos4f_s,
                                                           int *inv_perm, const int *flags, int which, int force,
                                                           const double *__restrict__ q, const double *__restrict__ hsig,
-                                                          const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s) {
+                                                          const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s,
+                                                          const int *__restrict__ cls, const int *__restrict__ start_lj,
+                                                          int *row_order, int s_begin, int s_end, int *n_lj_out) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (!force && !flags[which]) {
         if (posq_s && gid < n) {
@@ -153,10 +159,47 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
     const int b = start[wave];
     const int cnt = min(start[wave + 1] - b, capc);
     const int *mem = members + (size_t)wave * capc;
-    for (int a = lane; a < cnt; a += 64) {
-        const int me = mem[a];
+    // traversal order of the rank's rows (row_order): the slice's atoms WITH a Lennard-Jones site first, in slot order,
+    // then the others.  ga / gi = number of such atoms in the slots below; the slice's own offsets come from the cell
+    // that holds s_begin / s_end (binary search in the cell starts: only ranks of a multi-GPU run have s_begin > 0)
+    const int lj_before = start_lj[wave], lj_here = start_lj[wave + 1] - lj_before;
+    int ga0 = 0, ga1 = start_lj[ncell];
+    if (row_order && (s_begin > 0 || s_end < n)) {
+        int bounds[2] = {s_begin, s_end};
+        int ga[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int lo = 0, hi = ncell;                    // cell c with start[c] <= slot < start[c + 1] (slot == n: beyond the last)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (start[mid] <= bounds[e]) lo = mid;
+                else hi = mid;
+            }
+            const int o = bounds[e] - start[lo];
+            ga[e] = bounds[e] >= n ? start_lj[ncell] : start_lj[lo] + min(o, start_lj[lo + 1] - start_lj[lo]);
+        }
+        ga0 = ga[0];
+        ga1 = ga[1];
+    }
+    const int gi0 = s_begin - ga0;
+    if (row_order && wave == 0 && lane == 0) n_lj_out[0] = ga1 - ga0;
+    for (int a0 = 0; a0 < cnt; a0 += 64) {
+        const int a = a0 + lane;
+        const int me = a < cnt ? mem[a] : 0;
+        // sort key: class (atoms with a Lennard-Jones site first), then atom index -> deterministic whatever the atomics did
+        const int key = a < cnt ? (me | (cls[me] << 30)) : 0x7fffffff;
         int rank = 0;
-        for (int k = 0; k < cnt; ++k) rank += mem[k] < me;
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+            const int kk = k0 + lane;
+            int okey = 0x7fffffff;
+            if (kk < cnt) {
+                const int other = mem[kk];
+                okey = other | (cls[other] << 30);
+            }
+            const int nk = min(64, cnt - k0);
+            for (int jj = 0; jj < nk; ++jj) rank += __builtin_amdgcn_readlane(okey, jj) < key;
+        }
+        if (a >= cnt) continue;
         const int sl = b + rank;
         perm[sl] = me;
         double4 pd;
@@ -170,6 +213,11 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
         p.w = 0.f;
         pos4f_s[sl] = p;
         inv_perm[me] = sl;
+        if (row_order && sl >= s_begin && sl < s_end) {
+            const bool has_lj = rank < lj_here;
+            const int ga = lj_before + (has_lj ? rank : lj_here);          // atoms with a site in the slots below sl
+            row_order[has_lj ? ga - ga0 : (ga1 - ga0) + (sl - ga) - gi0] = sl;
+        }
         if (posq_s) {
             pd.w = q[me];
             posq_s[sl] = pd;
@@ -652,7 +700,7 @@ struct PairArgs {
 
 
 __device__ double amm_erfcx_table_dev[AMM_ERFCX_NI * AMM_ERFCX_NC];
-static bool g_erfcx_uploaded = false;
+static bool g_erfcx_uploaded[64] = {false};   // per device: the table is a __device__ symbol of each device's code object
 
 // GFAM >= 0: the guest force of a shared list (RESPA near force, same particles, shorter cutoff) is evaluated on the
 // same pass into its own buffer: geometry, gathers, 1/r and the LJ / Coulomb pieces are common, so the guest costs a
@@ -847,6 +895,325 @@ static int launch_pair_dual(dim3 grid, dim3 block, hipStream_t st, int gfam, con
     return launch_pair_dual_u<FAM, CMODE, 2>(grid, block, st, gfam, A, c, gc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2'/K3': force-only traversal with the Coulomb part read from the radial table of pair_tab.h.
+//   * per pair: geometry (3 sub + r^2), the table look-up (2 integer ops for the interval, 5 fma) and three fma to
+//     accumulate -- no 1/sqrt, erfc, exp or switching polynomial; the Lennard-Jones part (analytic, amm_lj_force) only in
+//     wavefronts that hold a row with eps_i != 0 (rows are traversed in `row_order`: those rows first, so that all but one
+//     wavefront are uniform); for TIP3P that is one row in three;
+//   * rows whose atom is farther than `margin` from every face of the box skip the minimum-image arithmetic (wave-uniform);
+//   * persistent wavefronts: the grid is sized to the chip (blocks per CU from the occupancy query), each block stages the
+//     table(s) in LDS once and its wavefronts walk tasks (= 64 >> lpa_shift rows) with a stride; tasks are dealt so that
+//     the blocks of one XCD (blockIdx & 7, MI355X_MICROARCH.md) own one contiguous eighth of the cell-sorted rows: the
+//     j-records an XCD gathers are then one slab of the box, which its 4 MiB L2 holds;
+//   * pairs closer than the table reaches take amm_pair_math under a wave-uniform branch (never in a liquid; lattice
+//     starts and tests do meet them).
+struct TabArgs {
+    const double *host_tab, *guest_tab;   // nint x 6 doubles each (device)
+    int host_bytes, guest_bytes;
+    int need_erfcx;                       // the analytic path of an erfc family needs the erfcx table in LDS
+    double margin;
+    const int *row_order;                 // [nslice] sorted slots in traversal order, or null (slot order)
+    const int *n_lj;                      // device: rows at the head of row_order that have a Lennard-Jones site (null: all)
+    int ntask, nslice;
+};
+
+template <int FAM, int CMODE, int GFAM, bool INTERIOR, bool LJ>
+__device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairConsts &c, const PairConsts &gc,
+                                                 const char *tabh, const char *tabg, const double *s_erfcx, const double4 pi,
+                                                 const double2 li, const int *row, int nfront, int nn, int sub, int lpa, int s,
+                                                 double &fx, double &fy, double &fz, double &gx, double &gy, double &gz) {
+    constexpr int UNR = 2;
+    const double qi = c.Kc * pi.w;
+    const int back = A.cap - 1 + nfront;
+    const int step = UNR * lpa;
+    // Software pipeline, two trips deep: while trip t computes, the j-records of trip t + 1 are in flight (issued at the top of
+    // the iteration) and so are the row entries of trip t + 2.  With half the arithmetic per pair of the analytic kernel the
+    // wavefront must overlap its own memory latency -- there are too few wavefronts per SIMD (registers) to leave it to them.
+    auto entry = [&](int k) { return k < nn ? row[k < nfront ? k : back - k] : s; };
+    auto fetch = [&](int j, double4 &p, double2 &l) {
+        p = *reinterpret_cast<const double4 *>(reinterpret_cast<const char *>(A.posq_s) + ((unsigned)j << 5));
+        if (LJ) l = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.lj_s) + ((unsigned)j << 4));
+    };
+    // one trip: UNR entries per lane, records already in registers.  Straight-line code for all entries (their dependent
+    // chains -- table look-up, Horner steps, the Newton steps of 1/r -- interleave); pairs closer than a table reaches are
+    // left out here and redone analytically below, in one rare branch that recomputes their geometry.
+    auto geometry = [&](const double4 &pjv, double &dx, double &dy, double &dz) {
+        dx = pi.x - pjv.x;
+        dy = pi.y - pjv.y;
+        dz = pi.z - pjv.z;
+        if (!INTERIOR) {
+            dx = amm_min_image(dx, A.box.L[0], A.box.invL[0]);
+            dy = amm_min_image(dy, A.box.L[1], A.box.invL[1]);
+            dz = amm_min_image(dz, A.box.L[2], A.box.invL[2]);
+        }
+        return dx * dx + dy * dy + dz * dz;
+    };
+    auto process = [&](const double4 (&pj)[UNR], const double2 (&lj)[UNR], const int (&jc)[UNR], int k0) {
+        const bool guest_trip = GFAM >= 0 && __builtin_amdgcn_ballot_w64(k0 < nfront) != 0ull;
+        bool any_low = false;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const bool ok = k0 + u * lpa < nn;
+            double dx, dy, dz;
+            const double r2 = geometry(pj[u], dx, dy, dz);
+            const bool pass = ok && (r2 < c.rc2);
+            const double qq = qi * pj[u].w;
+            double fr = qq * amm_tab_eval(tabh, c.tab, r2);
+            double frg = 0.0;
+            if (GFAM >= 0) {
+                if (guest_trip) frg = qq * amm_tab_eval(tabg, gc.tab, r2);
+            }
+            if (LJ) {
+                const double sig = li.x + lj[u].x, eps4 = li.y * lj[u].y;
+                const LJCommon L = amm_lj_common(r2, sig, eps4);   // lanes out of range (r2 = 0 on padding) are selected away below
+                fr += amm_lj_force<FAM, CMODE>(c, L, sig, eps4);
+                if (GFAM >= 0) {
+                    if (guest_trip) frg += amm_lj_force<GFAM, 0>(gc, L, sig, eps4);
+                }
+            }
+            const bool gpass = GFAM >= 0 && pass && (r2 < gc.rc2);
+            const bool low = pass && (r2 < c.tab.r2min), glow = gpass && (r2 < gc.tab.r2min);
+            any_low = any_low || low || glow;
+            fr = (pass && !low) ? fr : 0.0;
+            fx += fr * dx;
+            fy += fr * dy;
+            fz += fr * dz;
+            if (GFAM >= 0) {
+                if (guest_trip) {
+                    frg = (gpass && !glow) ? frg : 0.0;
+                    gx += frg * dx;
+                    gy += frg * dy;
+                    gz += frg * dz;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {     // closer than a table reaches: analytic (never in a liquid)
+            for (int u = 0; u < UNR; ++u) {
+                double dx, dy, dz;
+                const double r2 = geometry(pj[u], dx, dy, dz);
+                const bool pass = (k0 + u * lpa < nn) && (r2 < c.rc2);
+                const bool low = pass && (r2 < c.tab.r2min), glow = GFAM >= 0 && pass && (r2 < gc.rc2) && (r2 < gc.tab.r2min);
+                const double qq = qi * pj[u].w;
+                const double2 lx = A.lj_s[jc[u]];
+                const double sg = li.x + lx.x, e4 = li.y * lx.y;
+                double e_, fr_;
+                amm_pair_math<FAM, CMODE, false, false>(c, low ? r2 : 1.0, qq, sg, e4, e_, fr_, s_erfcx);
+                fr_ = low ? fr_ : 0.0;
+                fx += fr_ * dx;
+                fy += fr_ * dy;
+                fz += fr_ * dz;
+                if (GFAM >= 0) {
+                    amm_pair_math<GFAM, 0, false, false>(gc, glow ? r2 : 1.0, qq, sg, e4, e_, fr_, s_erfcx);
+                    fr_ = glow ? fr_ : 0.0;
+                    gx += fr_ * dx;
+                    gy += fr_ * dy;
+                    gz += fr_ * dz;
+                }
+            }
+        }
+    };
+    // two register sets (a / b) alternate, so that no copy -- which would have to wait for the load -- sits between a
+    // fetch and its use one iteration later
+    int ja[UNR], jb[UNR];
+    double4 pa[UNR], pb[UNR];
+    double2 la[UNR], lb[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        ja[u] = entry(sub + u * lpa);
+        jb[u] = entry(sub + u * lpa + step);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) fetch(ja[u], pa[u], la[u]);
+    for (int k0 = sub; k0 < nn; k0 += 2 * step) {
+        int jc[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            fetch(jb[u], pb[u], lb[u]);                 // records of trip k0 + step
+            jc[u] = ja[u];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) ja[u] = entry(k0 + u * lpa + 2 * step);   // entries of trip k0 + 2 step
+        process(pa, la, jc, k0);
+        if (k0 + step >= nn) break;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            fetch(ja[u], pa[u], la[u]);                 // records of trip k0 + 2 step
+            jc[u] = jb[u];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) jb[u] = entry(k0 + u * lpa + 3 * step);
+        process(pb, lb, jc, k0 + step);
+    }
+}
+
+template <int FAM, int CMODE, int GFAM, int BS>
+__global__ void __launch_bounds__(BS) k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
+    extern __shared__ __align__(16) char s_lds[];
+    // stage the table(s): 16-byte pieces, coalesced
+    for (int o = threadIdx.x * 16; o < T.host_bytes; o += BS * 16)
+        *reinterpret_cast<double2 *>(s_lds + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.host_tab) + o);
+    const char *tabh = s_lds, *tabg = s_lds + T.host_bytes;
+    if (GFAM >= 0)
+        for (int o = threadIdx.x * 16; o < T.guest_bytes; o += BS * 16)
+            *reinterpret_cast<double2 *>(s_lds + T.host_bytes + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T.guest_tab) + o);
+    double *s_erfcx = reinterpret_cast<double *>(s_lds + T.host_bytes + (GFAM >= 0 ? T.guest_bytes : 0));
+    if (T.need_erfcx)
+        for (int k = threadIdx.x; k < AMM_ERFCX_NI * AMM_ERFCX_NC; k += BS) s_erfcx[k] = amm_erfcx_table_dev[k];
+    __syncthreads();
+
+    constexpr int WPB = BS / 64;
+    const int lane = threadIdx.x & 63;
+    const int lpa = 1 << A.lpa_shift;
+    const int sub = lane & (lpa - 1);
+    // Tasks: one wavefront's worth of rows (rpw = 64 >> lpa_shift), drawn from two pools -- rows with a Lennard-Jones site
+    // (the first n_lj entries of row_order; about twice the arithmetic per pair) and rows without.  Each XCD
+    // (blockIdx & 7) owns one contiguous eighth of either pool.
+    const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
+    const int rpw = 64 >> A.lpa_shift;
+    const int n_lj = T.n_lj ? min(*T.n_lj, T.nslice) : T.nslice;
+    const int t_lj = (n_lj + rpw - 1) / rpw, t_h = (T.nslice - n_lj + rpw - 1) / rpw;
+    const int per_lj = (t_lj + 7) >> 3, per_h = (t_h + 7) >> 3;
+    const int lj0 = min(xcd * per_lj, t_lj), nlj_x = min(lj0 + per_lj, t_lj) - lj0;
+    const int h0 = min(xcd * per_h, t_h), nh_x = min(h0 + per_h, t_h) - h0;
+    const int ntask_x = nlj_x + nh_x;
+    // static deal: position p of the XCD's task sequence goes to wavefront p mod nwx.  The sequence interleaves the two
+    // pools in proportion (position p is a Lennard-Jones task iff floor((p + 1) nlj / n) > floor(p nlj / n)), so every
+    // wavefront meets the same mix whatever the stride.  (A ticket counter costs more than it balances: the returning
+    // atomic sits in front of the task's first loads in the in-order vmcnt queue.)
+    for (int p = (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); p < ntask_x; p += nwx) {
+        const int before = (int)(((long long)p * nlj_x) / ntask_x), upto = (int)(((long long)(p + 1) * nlj_x) / ntask_x);
+        const bool lj_pool = upto > before;
+        const int task = lj_pool ? before : nlj_x + (p - upto);
+        const int a = lj_pool ? (lj0 + task) * rpw + (lane >> A.lpa_shift) : n_lj + (h0 + task - nlj_x) * rpw + (lane >> A.lpa_shift);
+        const bool valid = lj_pool ? a < n_lj : a < T.nslice;
+        int s = A.s_begin;
+        double4 pi = make_double4(0.0, 0.0, 0.0, 0.0);
+        double2 li = make_double2(0.0, 0.0);
+        int nfront = 0, nn = 0;
+        const int *row = A.nl;
+        if (valid) {
+            s = T.row_order ? T.row_order[a] : A.s_begin + a;
+            const int ra = s - A.s_begin;
+            pi = A.posq_s[s];
+            li = A.lj_s[s];
+            nfront = A.nnb[ra];
+            nn = A.nnb_total ? A.nnb_total[ra] : nfront;
+            row = A.nl + (size_t)ra * A.cap;
+        }
+        const bool edge = valid && !(pi.x >= T.margin && pi.x <= A.box.L[0] - T.margin && pi.y >= T.margin && pi.y <= A.box.L[1] - T.margin &&
+                                     pi.z >= T.margin && pi.z <= A.box.L[2] - T.margin);
+        const bool interior = __builtin_amdgcn_ballot_w64(edge) == 0ull;
+        const bool any_lj = __builtin_amdgcn_ballot_w64(valid && li.y != 0.0) != 0ull;
+        double fx = 0.0, fy = 0.0, fz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+        if (interior) {
+            if (any_lj) amm_walk_row_tab<FAM, CMODE, GFAM, true, true>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
+            else amm_walk_row_tab<FAM, CMODE, GFAM, true, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
+        } else {
+            if (any_lj) amm_walk_row_tab<FAM, CMODE, GFAM, false, true>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
+            else amm_walk_row_tab<FAM, CMODE, GFAM, false, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
+        }
+        for (int off = lpa >> 1; off > 0; off >>= 1) {
+            fx += __shfl_xor(fx, off);
+            fy += __shfl_xor(fy, off);
+            fz += __shfl_xor(fz, off);
+            if (GFAM >= 0) {
+                gx += __shfl_xor(gx, off);
+                gy += __shfl_xor(gy, off);
+                gz += __shfl_xor(gz, off);
+            }
+        }
+        if (valid && sub == 0) {
+            const int i = A.sorted_out ? s - A.s_begin : A.perm[s];
+            if (GFAM >= 0) {
+                if (A.gaccumulate) {
+                    A.gforce[3 * i] += gx;
+                    A.gforce[3 * i + 1] += gy;
+                    A.gforce[3 * i + 2] += gz;
+                } else {
+                    A.gforce[3 * i] = gx;
+                    A.gforce[3 * i + 1] = gy;
+                    A.gforce[3 * i + 2] = gz;
+                }
+            }
+            if (A.accumulate) {
+                A.force[3 * i] += fx;
+                A.force[3 * i + 1] += fy;
+                A.force[3 * i + 2] += fz;
+            } else {
+                A.force[3 * i] = fx;
+                A.force[3 * i + 1] = fy;
+                A.force[3 * i + 2] = fz;
+            }
+        }
+    }
+}
+
+static int g_num_cu = 0;
+
+// one instantiation: dynamic LDS attribute + blocks per CU (cached), persistent grid (a multiple of 8 blocks)
+template <int FAM, int CMODE, int GFAM, int BS>
+static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts &c, const PairConsts &gc, TabArgs &T) {
+    static int bpc = -1, lds_set = 0;
+    const int lds = T.host_bytes + (GFAM >= 0 ? T.guest_bytes : 0) + AMM_ERFCX_NI * AMM_ERFCX_NC * 8;
+    auto kern = k_pair_tab<FAM, CMODE, GFAM, BS>;
+    if (lds > lds_set) {
+        AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        lds_set = lds;
+        bpc = -1;
+    }
+    if (bpc < 0) {
+        int nb = 0;
+        AMM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BS, (size_t)lds));
+        if (nb < 1) {
+            amm_set_error("tabulated pair kernel does not fit on a CU (LDS)");
+            return 1;
+        }
+        bpc = nb;
+    }
+    if (!g_num_cu) {
+        int dev = 0;
+        AMM_HIP(hipGetDevice(&dev));
+        AMM_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    constexpr int WPB = BS / 64;
+    long nblk = std::min((long)g_num_cu * bpc, ((long)T.ntask + WPB - 1) / WPB);
+    nblk = std::max(8L, (nblk + 7) / 8 * 8);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, st, A, c, gc, T);
+    return 0;
+}
+
+// block sizes (wavefronts per block a multiple of 4: an uneven deal over the 4 SIMDs strands registers).  Alone: 512 threads
+// (2 per SIMD; 2 blocks per CU with <= 128 VGPRs) or 768 (3 per SIMD, 1 block); with a guest: 1024 or 768.  AMM_TAB_BS /
+// AMM_TAB_DUAL_BS override for tuning.
+static int tab_block_size(bool dual) {
+    static int bs[2] = {-1, -1};
+    if (bs[dual] < 0) {
+        const char *e = getenv(dual ? "AMM_TAB_DUAL_BS" : "AMM_TAB_BS");
+        bs[dual] = e ? atoi(e) : (dual ? 768 : 512);
+    }
+    return bs[dual];
+}
+
+template <int FAM, int CMODE, int GFAM>
+static int launch_pair_tab_g(hipStream_t st, const PairArgs &A, const PairConsts &c, const PairConsts &gc, TabArgs &T) {
+    const int bs = tab_block_size(GFAM >= 0);
+    if (bs == 1024) return launch_pair_tab_i<FAM, CMODE, GFAM, 1024>(st, A, c, gc, T);
+    if (bs == 768) return launch_pair_tab_i<FAM, CMODE, GFAM, 768>(st, A, c, gc, T);
+    return launch_pair_tab_i<FAM, CMODE, GFAM, 512>(st, A, c, gc, T);
+}
+
+template <int FAM, int CMODE>
+static int launch_pair_tab(hipStream_t st, int gfam, const PairArgs &A, const PairConsts &c, const PairConsts &gc, TabArgs &T) {
+    switch (gfam) {
+    case -1: return launch_pair_tab_g<FAM, CMODE, -1>(st, A, c, gc, T);
+    case AMM_NEAR_NONE: return launch_pair_tab_g<FAM, CMODE, AMM_NEAR_NONE>(st, A, c, gc, T);
+    case AMM_NEAR_SHIFT: return launch_pair_tab_g<FAM, CMODE, AMM_NEAR_SHIFT>(st, A, c, gc, T);
+    case AMM_NEAR_FSWITCH: return launch_pair_tab_g<FAM, CMODE, AMM_NEAR_FSWITCH>(st, A, c, gc, T);
+    default: amm_set_error("dual evaluation: unsupported guest family"); return 1;
+    }
+}
+
 // deterministic single-block reduction: *out += scale * sum(part[0..n))
 __global__ void k_reduce_add(const double *__restrict__ part, int n, double scale, double *out) {
     __shared__ double sh[256];
@@ -909,7 +1276,7 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
     const int which = direct ? 0 : 4;
     hipLaunchKernelGGL(k_cell_assign, dim3(nb), dim3(256), 0, st, n, d_pos, ctx->box, pf->grid, pf->d_cell_of,
                        pf->d_cell_count, pf->d_cell_start, pf->d_cell_members, pf->capc, direct ? pf->d_xref : pf->d_xref_out,
-                       pf->d_flags, pf->d_ticket, which, force);
+                       pf->d_flags, pf->d_ticket, which, force, pf->d_cls, pf->d_cell_count_lj, pf->d_cell_start_lj);
     if (!pf->d_cell_members) return 0;         // sizing pass of the first build: only the counts were wanted
     // gather_for: the sorted fp64 copies of the evaluation that follows ride on the same launch
     PairForce *gf = gather_for;
@@ -917,7 +1284,8 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
     hipLaunchKernelGGL(k_cell_sort_gather, dim3((unsigned)((sort_threads + 255) / 256)), dim3(256), 0, st, pf->grid.ncell, n,
                        pf->d_cell_start, pf->d_cell_members, pf->capc, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s,
                        pf->d_inv_perm, pf->d_flags, which, force, gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr,
-                       gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr, gf ? gf->d_lj_s : (double2 *)nullptr);
+                       gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr, gf ? gf->d_lj_s : (double2 *)nullptr,
+                       pf->d_cls, pf->d_cell_start_lj, pf->d_row_order, pf->s_begin, pf->s_end, pf->d_flags + 3);
     const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
@@ -993,6 +1361,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     AMM_HIP(hipMalloc(&pf->d_nnb_near, sizeof(int) * ns));
     AMM_HIP(hipMalloc(&pf->d_nnb_out, sizeof(int) * ns));
     AMM_HIP(hipMalloc(&pf->d_nnb_scratch, sizeof(int) * ns));
+    AMM_HIP(hipMalloc(&pf->d_row_order, sizeof(int) * ns));
     // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding, but not beyond 16 lanes: longer
     // strides waste the tail of every row (measured on 1/8 slices of C3, scripts/probe_slices.py: dual pass 63.6 us
     // with 16 lanes, 71.9 us with 64)
@@ -1096,9 +1465,9 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
-    if (!g_erfcx_uploaded) {
+    if (!g_erfcx_uploaded[ctx->device & 63]) {
         AMM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(amm_erfcx_table_dev), amm_erfcx_table_host, sizeof(amm_erfcx_table_host)));
-        g_erfcx_uploaded = true;
+        g_erfcx_uploaded[ctx->device & 63] = true;
     }
     // the neighbour list may belong to another, longer-ranged pair force (amm_pair_share_list)
     PairForce *L = pf->host ? pf->host : pf;
@@ -1195,7 +1564,45 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             AMM_HIP(hipEventRecord(e0, st));
         }
         dim3 grid(nblk), block(256);
-        if (guest) {
+        static int use_tab = -1;
+        if (use_tab < 0) {
+            const char *e = getenv("AMM_TAB");
+            use_tab = e ? atoi(e) : 1;
+        }
+        // force-only, unguarded, ungrouped evaluations of the tabulated families: the kernel of pair_tab.h
+        const bool tab_ok = use_tab && !en && !guard && !(pf->pc.flags & (AMM_GROUP_LJ | AMM_GROUP_Q)) && pf->pc.tab.nint > 0 && pf->d_tab &&
+                            pf->pc.sign == 1.0 && (!guest || (guest->pc.tab.nint > 0 && guest->d_tab && guest->pc.sign == 1.0));
+        if (tab_ok) {
+            TabArgs T;
+            T.host_tab = pf->d_tab;
+            T.host_bytes = pf->pc.tab.nint * AMM_TAB_STRIDE;
+            T.guest_tab = guest ? guest->d_tab : nullptr;
+            T.guest_bytes = guest ? guest->pc.tab.nint * AMM_TAB_STRIDE : 0;
+            T.need_erfcx = 1;
+            T.margin = L->rlist_build + L->skin + 1e-6;
+            T.row_order = L->d_row_order;
+            T.n_lj = L->d_row_order ? L->d_flags + 3 : nullptr;
+            T.nslice = nslice;
+            T.ntask = (int)((threads + 63) / 64);
+            const int gfam = guest ? guest->desc.family : -1;
+            const PairConsts &gpc = guest ? guest->pc : pf->pc;
+            int rc_ = 0;
+            switch (pf->desc.family) {
+            case AMM_NEAR_NONE: rc_ = launch_pair_tab<AMM_NEAR_NONE, 0>(st, gfam, A, pf->pc, gpc, T); break;
+            case AMM_NEAR_SHIFT: rc_ = launch_pair_tab<AMM_NEAR_SHIFT, 0>(st, gfam, A, pf->pc, gpc, T); break;
+            case AMM_NEAR_FSWITCH: rc_ = launch_pair_tab<AMM_NEAR_FSWITCH, 0>(st, gfam, A, pf->pc, gpc, T); break;
+            case AMM_DAMPED:
+                if (pf->pc.degree == 1) rc_ = launch_pair_tab<AMM_DAMPED, 1>(st, gfam, A, pf->pc, gpc, T);
+                else rc_ = launch_pair_tab<AMM_DAMPED, 0>(st, gfam, A, pf->pc, gpc, T);
+                break;
+            default:
+                if (pf->pc.cmode == 1) rc_ = launch_pair_tab<AMM_NONBONDED, 1>(st, gfam, A, pf->pc, gpc, T);
+                else if (pf->pc.cmode == 2) rc_ = launch_pair_tab<AMM_NONBONDED, 2>(st, gfam, A, pf->pc, gpc, T);
+                else rc_ = launch_pair_tab<AMM_NONBONDED, 0>(st, gfam, A, pf->pc, gpc, T);
+            }
+            if (rc_) return 1;
+            if (guest) guest->n_evals++;
+        } else if (guest) {
             int rc_ = 0;
             // DAMPED: CMODE 1 = the degree-1 specialisation (built-in switch in r: no power loop, no int -> double per pair)
             if (pf->desc.family == AMM_DAMPED && pf->pc.degree == 1) rc_ = launch_pair_dual<AMM_DAMPED, 1>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
@@ -1288,11 +1695,27 @@ bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host) {
     return true;
 }
 
+// radial Coulomb table of the force-only traversal (pair_tab.h): built from the descriptor alone, once per pair force
+int amm_pair_build_table(PairForce *pf) {
+    std::vector<double> coef;
+    pf->tab_error = amm_build_coulomb_table(pf->pc, coef);
+    if (pf->d_tab) {
+        (void)hipFree(pf->d_tab);
+        pf->d_tab = nullptr;
+    }
+    if (pf->pc.tab.nint > 0) {
+        AMM_HIP(hipMalloc(&pf->d_tab, sizeof(double) * coef.size()));
+        AMM_HIP(hipMemcpy(pf->d_tab, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
 int amm_pair_free(PairForce *pf) {
     void *ptrs[] = {pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_excl_ptr, pf->d_excl_idx, pf->d_cell_of, pf->d_cell_count,
                     pf->d_cell_start, pf->d_cell_members, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
                     pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near, pf->d_nl_out, pf->d_nnb_out,
-                    pf->d_nnb_scratch, pf->d_xref_out, pf->d_ticket};
+                    pf->d_nnb_scratch, pf->d_xref_out, pf->d_ticket, pf->d_tab, pf->d_cls, pf->d_cell_count_lj, pf->d_cell_start_lj,
+                    pf->d_row_order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);

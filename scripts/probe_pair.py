@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Static timing of the pair kernels at C3 size through the C-ABI (kernel tuning harness).
+
+    python scripts/probe_pair.py --make-config            # relax the lattice start with the product library, save positions
+    [AMM_LIB=atomsmm_amd/exp/lib_X.so] python scripts/probe_pair.py [--reps 50]
+
+The positions are fixed (a relaxed liquid configuration, scripts/_cache/c3_relaxed.npz), so an experimental build whose
+arithmetic is deliberately wrong (a look-up removed, a gather short-circuited) still walks the same lists.  Prints the
+average duration (HIP events on the launch stream, amm_profile_enable) of the stand-alone near evaluation, of the outer
+force alone and of the dual pass (near + outer in one traversal), and of a forced list rebuild.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CACHE = os.path.join(ROOT, 'scripts', '_cache', 'c3_relaxed.npz')
+
+
+def make_config(out):
+    import torch
+    import bench
+    sim, case = bench.build_simulation(32, (4, 2, 1), 4.0)
+    bench.relax(sim, torch)
+    sim.step(100)
+    eng = sim.context._engine
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    np.savez_compressed(out, positions=eng.x.cpu().numpy(), velocities=eng.v.cpu().numpy())
+    print('saved', out, 'T =', bench.temperature(eng, torch))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--make-config', action='store_true')
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'c3_relaxed.npz'))
+    ap.add_argument('--reps', type=int, default=50)
+    ap.add_argument('--skin', type=float, default=-1.0)
+    ap.add_argument('--outer', choices=['damped', 'ewald'], default='damped')
+    args = ap.parse_args()
+    if args.make_config:
+        return make_config(args.out)
+    import torch
+    from atomsmm_amd import backend as B
+    from atomsmm_amd.testing import tip3p_box
+    c = tip3p_box(32)
+    n = len(c['positions'])
+    if os.path.exists(CACHE):
+        c['positions'] = np.load(CACHE)['positions']
+    else:
+        print('warning: no relaxed configuration (%s): timing the lattice start' % CACHE)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device='cuda')   # noqa: E731
+    ctx = B.HipContext(n, c['box'])
+    dn = B.pair_desc(B.NEAR_FSWITCH, 0.7, rc0=0.7, rs0=0.5)
+    if args.outer == 'damped':
+        dd = B.pair_desc(B.DAMPED, 1.0, rswitch=0.9, alpha=2.9, degree=1)
+    else:
+        dd = B.pair_desc(B.NONBONDED, 1.0, rswitch=0.9, alpha=2.628260884878466, flags=B.COULOMB_EWALD | B.SWITCH)
+    fn = ctx.pair_create(dn, c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'], skin=args.skin)
+    ff = ctx.pair_create(dd, c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'], skin=args.skin)
+    ctx.pair_share_list(fn, ff)
+    x, v, m = dev(c['positions']), dev(np.zeros((n, 3))), dev(c['mass'])
+    f = [torch.zeros((n, 3), dtype=torch.float64, device='cuda') for _ in range(4)]
+    ctx.bind_state(x, v, m)
+    for slot, buf in enumerate(f):
+        ctx.bind_buffer(slot, buf)
+    ctx.group_define(1, 1, [fn])
+    ctx.group_define(2, 2, [ff])
+    E = B.OP_EVAL
+    near_only = [B.Op(E, 1, 0, 0, 0.0)]
+    far_only = [B.Op(E, 2, 0, 0, 0.0)]
+    dual = [B.Op(E, 1, 0, 0, 0.0), B.Op(E, 2, 0, 0, 0.0)]
+    ctx.run_ops(dual, 2)
+    ctx.check()
+    torch.cuda.synchronize()
+    res = {}
+    for label, ops, fid in (('near', near_only, fn), ('far', far_only, ff), ('dual', dual, ff)):
+        ctx.run_ops(ops, 3)
+        ctx.profile_enable(True, only=fid)
+        ctx.run_ops(ops, args.reps)
+        torch.cuda.synchronize()
+        cnt, ms = ctx.profile_read(fid)
+        ctx.profile_enable(False)
+        res[label] = ms / max(cnt, 1) * 1e3
+    st = ctx.pair_stats(ff)
+    print('lib=%s  near %.1f us  far %.1f us  dual %.1f us   (list pairs near/far: %d / %d, lanes/atom %d)' % (
+        os.path.basename(os.environ.get('AMM_LIB', 'product')), res['near'], res['far'], res['dual'],
+        ctx.pair_stats(fn)['n_list_pairs'], st['n_list_pairs'], st['lanes_per_atom']))
+    fsum = [float(b.abs().sum()) for b in f[1:3]]
+    print('   checksum |f1| = %.10e  |f2| = %.10e' % tuple(fsum))
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -79,13 +79,12 @@ def test_pair_families_vs_oracle_and_goldens(spcfw, goldens, name):
     assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
     if gid:
         assert e == pytest.approx(goldens[gid]['value'], rel=1e-6)
-    # force-only launch (no energy) gives the same forces bit for bit
+    # the force-only launch (no energy) is a different kernel -- its Coulomb part comes from the radial table of
+    # csrc/pair_tab.h (relative interpolation error < 1e-14) -- and must give the same forces, also against the oracle
     f2 = torch.empty((n, 3), dtype=torch.float64, device='cuda')
     ctx.force_eval(fid, dev(c['positions']), f2)
-    if d.family != O.NEAR_FSWITCH:
-        assert np.abs(f2.cpu().numpy() - f).max() <= 1e-12 * np.abs(f).max()
-    else:
-        assert np.array_equal(f2.cpu().numpy(), f)
+    assert np.abs(f2.cpu().numpy() - f).max() <= 1e-12 * np.abs(f).max()
+    assert np.abs(f2.cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
     ctx.close()
 
 
