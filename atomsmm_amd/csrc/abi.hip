@@ -592,12 +592,20 @@ int amm_comm_allreduce(amm_ctx *ctx, double *d_buf, int64_t count) {
 }
 
 int amm_expr_seed(amm_ctx *ctx, uint64_t seed) {
+    if (!ctx) {
+        amm_set_error("amm_expr_seed: null context");
+        return 1;
+    }
     ctx->expr_seed = seed;
     ctx->expr_counter = 0;
     return 0;
 }
 
 int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass) {
+    if (!ctx || !d_x || !d_v || !d_mass) {
+        amm_set_error("amm_bind_state: null argument");
+        return 1;
+    }
     ctx->d_x = d_x;
     ctx->d_v = d_v;
     ctx->d_mass = d_mass;
@@ -614,10 +622,19 @@ int amm_bind_buffer(amm_ctx *ctx, int32_t slot, double *d_buf) {
     return 0;
 }
 int amm_group_define(amm_ctx *ctx, int32_t group, int32_t slot, const int32_t *force_ids, int32_t n_forces) {
+    if (!ctx || (n_forces > 0 && !force_ids) || n_forces < 0) {
+        amm_set_error("amm_group_define: null argument");
+        return 1;
+    }
     if (group < 0 || group >= AMM_MAX_GROUPS || slot < 0 || slot >= AMM_MAX_SLOTS) {
         amm_set_error("amm_group_define: group/slot out of range");
         return 1;
     }
+    for (int32_t k = 0; k < n_forces; ++k)
+        if (force_ids[k] < 0 || force_ids[k] >= (int32_t)ctx->forces.size()) {
+            amm_set_error("amm_group_define: unknown force id");
+            return 1;
+        }
     ctx->groups[group].slot = slot;
     ctx->groups[group].forces.assign(force_ids, force_ids + n_forces);
     return 0;
@@ -664,6 +681,34 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
     int f0_slot = -1;
     double *user_f0 = nullptr;
     bool swapped = false;
+    // Every exit -- also the early `return 1` of a failed launch, an unbound buffer or a failed collective -- must leave the
+    // context bound to the CALLER's buffers: the fused inner iteration ping-pongs d_x / d_v / the group-0 slot onto the
+    // library's alt_* buffers.  On the error path the state held in the alt buffers is copied back on a best-effort basis.
+    struct RestoreBindings {
+        amm_ctx *ctx;
+        double *ux, *uv;
+        double *&uf0;
+        int &slot;
+        bool &swapped;
+        bool done = false;
+        void restore(bool copy_back) {
+            if (done) return;
+            done = true;
+            if (slot < 0) return;
+            if (swapped && copy_back) {
+                const size_t bytes = sizeof(double) * 3 * (size_t)ctx->n;
+                (void)hipMemcpyAsync(ux, ctx->d_x, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+                (void)hipMemcpyAsync(uv, ctx->d_v, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+                (void)hipMemcpyAsync(uf0, ctx->slots[slot], bytes, hipMemcpyDeviceToDevice, ctx->stream);
+            }
+            ctx->d_x = ux;
+            ctx->d_v = uv;
+            ctx->slots[slot] = uf0;
+            ctx->slots[AMM_SLOT_X] = ux;
+            ctx->slots[AMM_SLOT_V] = uv;
+        }
+        ~RestoreBindings() { restore(true); }
+    } bindings{ctx, user_x, user_v, user_f0, f0_slot, swapped};
     // kicks that close one repetition of the program ride on the first inner-loop launch of the next (as further
     // "preceding kicks"): same order, same arithmetic, two launches less per outer step
     std::vector<amm_op> deferred;
@@ -961,13 +1006,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
         AMM_HIP(hipMemcpyAsync(user_v, ctx->d_v, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         AMM_HIP(hipMemcpyAsync(user_f0, ctx->slots[f0_slot], bytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (f0_slot >= 0) {
-        ctx->d_x = user_x;
-        ctx->d_v = user_v;
-        ctx->slots[f0_slot] = user_f0;
-        ctx->slots[AMM_SLOT_X] = user_x;
-        ctx->slots[AMM_SLOT_V] = user_v;
-    }
+    bindings.restore(false);        // the copies above were checked; only the pointers are left to rebind
     return 0;
 }
 
@@ -998,6 +1037,20 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     }
     return 0;
 }
+
+int amm_pair_count_within(amm_ctx *ctx, int32_t force_id, const double *d_pos, double r_within, int64_t *count) {
+    PairForce *pf = get_pair(ctx, force_id);
+    if (!pf || !d_pos || !count) {
+        amm_set_error("amm_pair_count_within: null argument or not a pair force");
+        return 1;
+    }
+    long long c = 0;
+    if (amm_pair_count_within_impl(ctx, pf, d_pos, r_within, &c)) return 1;
+    *count = (int64_t)c;
+    return 0;
+}
+
+const char *amm_kernel_revision(void) { return amm_kernel_revision_impl(); }
 
 int amm_set_outer_skin(amm_ctx *ctx, double skin_out) {
     ctx->skin_out = skin_out;

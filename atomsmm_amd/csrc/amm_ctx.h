@@ -225,6 +225,8 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
 bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host);
 int amm_pair_free(PairForce *pf);
 int amm_pair_build_table(PairForce *pf);
+int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double r_within, long long *count);
+const char *amm_kernel_revision_impl();
 int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate,
                          double *d_energy);
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);

@@ -1695,6 +1695,65 @@ bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host) {
     return true;
 }
 
+// measurement helper: directed list entries within r_within of the CURRENT sorted positions (fp64, minimum image)
+__global__ void __launch_bounds__(256) k_count_within(PairArgs A, double r2w, int nslice, unsigned long long *out) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = tid >> A.lpa_shift, sub = tid & ((1 << A.lpa_shift) - 1);
+    unsigned long long cnt = 0;
+    if (a < nslice) {
+        const int s = A.s_begin + a;
+        const double4 pi = A.posq_s[s];
+        const int nfront = A.nnb[a], nn = A.nnb_total ? A.nnb_total[a] : nfront;
+        const int *row = A.nl + (size_t)a * A.cap;
+        const int back = A.cap - 1 + nfront;
+        for (int k = sub; k < nn; k += 1 << A.lpa_shift) {
+            const double4 pj = A.posq_s[row[k < nfront ? k : back - k]];
+            const double dx = amm_min_image(pi.x - pj.x, A.box.L[0], A.box.invL[0]);
+            const double dy = amm_min_image(pi.y - pj.y, A.box.L[1], A.box.invL[1]);
+            const double dz = amm_min_image(pi.z - pj.z, A.box.L[2], A.box.invL[2]);
+            cnt += (dx * dx + dy * dy + dz * dz < r2w) ? 1ull : 0ull;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, cnt);
+}
+
+int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double r_within, long long *count) {
+    PairForce *L = pf->host ? pf->host : pf;
+    if (!L->built) {
+        amm_set_error("amm_pair_count_within: evaluate the force once first (the neighbour rows do not exist yet)");
+        return 1;
+    }
+    hipStream_t st = ctx->stream;
+    const int n = pf->n;
+    hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, st, n, L->d_perm, d_pos, pf->d_q, pf->d_hsig,
+                       pf->d_seps2, ctx->box, pf->d_posq_s, pf->d_lj_s);
+    PairArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.s_begin = L->s_begin;
+    A.s_end = L->s_end;
+    A.lpa_shift = 3;
+    A.cap = L->cap;
+    A.nl = L->d_nl;
+    A.nnb = L->d_nnb_near;
+    A.nnb_total = (pf == L && L->rnear_build > 0) ? L->d_nnb : nullptr;
+    A.posq_s = pf->d_posq_s;
+    A.box = ctx->box;
+    const int nslice = L->s_end - L->s_begin;
+    unsigned long long *d_cnt = L->d_counters + 7;
+    AMM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+    if (nslice > 0)
+        hipLaunchKernelGGL(k_count_within, dim3((unsigned)(((long)nslice * 8 + 255) / 256)), dim3(256), 0, st, A, r_within * r_within, nslice, d_cnt);
+    unsigned long long h = 0;
+    AMM_HIP(hipMemcpyAsync(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+    AMM_HIP(hipStreamSynchronize(st));
+    *count = (long long)h;
+    return 0;
+}
+
+// bump when a pair-traversal kernel changes: stored measurements (profiles/*_traffic.json) are matched against it
+const char *amm_kernel_revision_impl() { return "r02-tab2"; }
+
 // radial Coulomb table of the force-only traversal (pair_tab.h): built from the descriptor alone, once per pair force
 int amm_pair_build_table(PairForce *pf) {
     std::vector<double> coef;

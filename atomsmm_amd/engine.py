@@ -156,6 +156,17 @@ class _Entry:
         self.depends = set()        # global parameters this entry's backend data depend on
 
 
+def slice_bounds(n_items, rank, world):
+    """[begin, end) of rank's contiguous slice of n_items cell-sorted slots: ceil(n / world) each, the same formula as the
+    HIP library (csrc/pair.hip first_build).  Atom decomposition: every rank holds all positions and
+    integrates all atoms redundantly; the pair work is split by these slices of the cell-sorted order with full neighbour
+    rows, so every force row has one producer and the exchange (all-gather of slices, or all-reduce of zero-filled
+    buffers) is exact and identical on all ranks."""
+    per = (n_items + world - 1) // world
+    begin = min(n_items, rank * per)
+    return begin, min(n_items, begin + per)
+
+
 class Engine:
     def __init__(self, system, integrator, properties):
         import torch
@@ -854,6 +865,35 @@ class Engine:
         self._mirror.pop(name, None)
 
     # ------------------------------------------------------------------------------- getState
+    def _check(self):
+        """amm_check on every rank TOGETHER: a neighbour-row overflow or a constraint failure is detected by the rank
+        that owns the row, and a rank that raised alone would leave its peers inside the next collective."""
+        if not self._coll:
+            return self.ctx.check()
+        err = None
+        try:
+            self.ctx.check()
+        except Exception as exc:       # noqa: BLE001 -- re-raised below, on every rank
+            err = exc
+        dist = self.torch.distributed
+        flag = self.torch.tensor([1 if err is not None else 0], dtype=self.torch.int32,
+                                 device=self.x.device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if err is not None:
+            raise err
+        if int(flag.item()):
+            raise B.HipError('another rank reported a failed check (neighbour-row overflow or constraint failure)')
+
+    def broadcast_from_rank0(self, array):
+        """A host array every rank must hold bit for bit (e.g. randomly drawn velocities): rank 0's copy wins."""
+        if not self._coll:
+            return array
+        dist = self.torch.distributed
+        t = self.torch.as_tensor(np.ascontiguousarray(array, dtype=np.float64),
+                                 device=self.x.device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.broadcast(t, src=0)
+        return t.cpu().numpy()
+
     def _allreduce(self, tensor):
         if self._coll:
             if self._native_comm:
@@ -882,7 +922,7 @@ class Engine:
                     self.ctx.pme_set_sliced(entry.recip, False)
                     self.ctx.force_eval(entry.recip, self.x, fb, accumulate=True, energy=e_bond)
                     self.ctx.pme_set_sliced(entry.recip, getattr(entry, 'recip_sliced', False))
-            self.ctx.check()
+            self._check()
             if self._coll:
                 self._allreduce(fp)
                 if want_energy:
@@ -923,7 +963,10 @@ class Engine:
         members = [e for e in self.entries if (e.group == g if g != 'all' else True)]
         pair_ids = [pid for e in members for pid in e.pair_ids]
         terms = [t for e in members for t in e.terms]
-        reduced = self._coll and bool(pair_ids)
+        # multi-rank: a group is evaluated slice-wise and all-reduced as soon as it holds a pair force OR a reciprocal-space
+        # force -- the "sliced" switch lives on the PME object, so it must mean the same in every group that evaluates it
+        has_recip = any(e.recip is not None and (g == 'all' or e.recip_group == g) for e in self.entries)
+        reduced = self._coll and (bool(pair_ids) or has_recip)
         gather = reduced and self._gather and g != 'all' and len(pair_ids) == 1 and not terms and not any(
             e.recip is not None and e.recip_group == g for e in self.entries)
         ids = list(pair_ids)
@@ -961,12 +1004,12 @@ class Engine:
         if self._has_constraints:
             self.ctx.run_ops([B.Op(B.OP_SAVE_REF, 0, 0, 0, 0.0), B.Op(B.OP_CONSTRAIN_X, 0, 0, 0, 0.0)], 1)
             self._invalidate_forces()
-            self.ctx.check()
+            self._check()
 
     def apply_velocity_constraints(self):
         if self._has_constraints:
             self.ctx.run_ops([B.Op(B.OP_CONSTRAIN_V, 0, 0, 0, 0.0)], 1)
-            self.ctx.check()
+            self._check()
 
     def _eval(self, expr, env):
         return float(eval(expr.replace('^', '**'), {'__builtins__': {}}, env))
@@ -1296,20 +1339,23 @@ class Engine:
             if ok:
                 self.ctx.comm_destroy()
 
-    def _run(self, ops, repeat):
+    def _run(self, ops, repeat, cache=True):
+        """cache=False: `ops` is a throw-away list (the interpreted path flushes a fresh one several times per step); its
+        plan is not kept -- the cache is keyed by the list's identity and would otherwise grow without bound."""
         if not self._coll:
             self.ctx.run_ops([op for op in ops if not isinstance(op, tuple)], repeat)
             return
         if self._native_comm:
-            native = self._native_ops.get(id(ops))
+            native = self._native_ops.get(id(ops)) if cache else None
             if native is None or native[0] is not ops:
                 native = (ops, [B.Op(B.OP_ALLREDUCE, op[1], 0, 0, 0.0) if isinstance(op, tuple) else op for op in ops])
-                self._native_ops[id(ops)] = native
+                if cache:
+                    self._native_ops[id(ops)] = native
             self.ctx.run_ops(native[1], repeat)
             return
         # collectives driven from here (torch.distributed): the op list is cut after every all-reduce marker and after
         # every EVAL of an all-gather group (the library leaves the rank's chunk in the exchange buffer and waits)
-        plan = self._native_ops.get(id(ops))
+        plan = self._native_ops.get(id(ops)) if cache else None
         if plan is None or plan[0] is not ops:
             segments, current = [], []
             for op in ops:
@@ -1322,7 +1368,8 @@ class Engine:
                         segments.append((current, ('gather', None)))
                         current = []
             plan = (ops, segments, current)
-            self._native_ops[id(ops)] = plan
+            if cache:
+                self._native_ops[id(ops)] = plan
         _, segments, tail = plan
         inv = {slot: name for name, slot in self._slots.items()}
         for _ in range(repeat):
@@ -1419,7 +1466,7 @@ class Engine:
 
             def flush():
                 if ops:
-                    self._run(list(ops), 1)
+                    self._run(list(ops), 1, cache=False)
                     del ops[:]
 
             def resolve(name):
@@ -1491,7 +1538,7 @@ class Engine:
             for k, name in enumerate(integ._gnames):
                 integ._gvalues[k] = env[name]
             self.time += integ._dt
-        self.ctx.check()
+        self._check()
 
     def step(self, n):
         integ = self.integrator
@@ -1526,7 +1573,7 @@ class Engine:
                 integ._gvalues[integ._gnames.index(name)] = value
             remaining -= count
             self.time += count * integ._dt
-        self.ctx.check()
+        self._check()
 
     # measurement helpers (bench / tests)
     def pair_force_ids(self, group):

@@ -895,6 +895,9 @@ class Context:
         kT = _unit.BOLTZMANN_CONSTANT_kB._value * T
         v = rng.normal(size=(len(m), 3)) * np.sqrt(kT / np.where(m > 0, m, 1.0))[:, None]
         v[m <= 0] = 0.0
+        # multi-rank runs integrate every atom on every rank: all ranks must hold the SAME velocities, also when no seed
+        # was given (each process would draw its own from OS entropy) -- rank 0's draw is broadcast
+        v = self._engine.broadcast_from_rank0(v)
         self._engine.set_velocities(v)
         self._engine.apply_velocity_constraints()     # as OpenMM does after drawing the velocities
 

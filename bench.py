@@ -34,7 +34,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
 FP64_VECTOR_PEAK_TF = 78.6     # public datasheet value; not in the container's guide
 BYTES_PER_ATOM = 72            # fp64: read x,y,z + q,sigma,eps, write Fx,Fy,Fz
+BYTES_PER_ATOM_DUAL = 96       # dual pass: the same read set, two force arrays written
 FLOP_PER_PAIR_NEAR = 60        # force-switch near, force only
+FLOP_PER_PAIR_FAR = 80         # DampedSmoothedForce (erfc + exp), force only
+FP64_SUSTAINED_TF = 60.7       # measured: v_fma_f64, 8 wavefronts per SIMD, 2.16 ns per wave-instruction per SIMD (DVFS clock)
+TRAFFIC_FILE = 'r02_traffic.json'
 KB = 0.0083144626181532
 
 
@@ -160,15 +164,17 @@ def main():
     near_id = eng.pair_force_ids(1)[0]
     far_id = eng.pair_force_ids(2)[0]
     st0 = {fid: eng.ctx.pair_stats(fid) for fid in (near_id, far_id)}
-    # HIP events around every launch of the near kernel (the roofline kernel), on the launch stream; the far kernel is
-    # left untimed here (each timed launch costs two event packets of stream time; its duration is in profiles/)
-    eng.ctx.profile_enable(True, only=near_id)
+    # HIP events around every pair-kernel launch, on the launch stream: the stand-alone near evaluation (the kernel the
+    # metric names) under the near force's id, the dual pass (outer + near force in one traversal: the dominant kernel)
+    # under the outer force's id
+    eng.ctx.profile_enable(True)
     fence()
     t0 = time.perf_counter()
     simulation.step(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     n_near, ms_near = eng.ctx.profile_read(near_id)
+    n_dual, ms_dual = eng.ctx.profile_read(far_id)
     eng.ctx.profile_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -178,16 +184,45 @@ def main():
     T_end = temperature(eng, torch)
     ms_per_step = elapsed / args.steps * 1e3
     ns_day = dt_fs * 1e-6 * 86400.0 / (elapsed / args.steps)
+    # pairs actually inside the cutoffs at the final configuration: one counting launch per force over the neighbour rows
+    # (fp64, outside the timed region); directed entries / 2 = pairs counted once (this rank's slice of the rows)
+    pairs_near = eng.ctx.pair_count_within(near_id, eng.x, 0.7) / 2
+    pairs_far = eng.ctx.pair_count_within(far_id, eng.x, 1.0) / 2
 
     if rank == 0:
+        from atomsmm_amd import backend
         t_near = ms_near / max(n_near, 1) * 1e-3          # s per launch (this rank's slice)
+        t_dual = ms_dual / max(n_dual, 1) * 1e-3
         atoms_per_launch = st1[near_id]['n_slice_atoms']
-        alg_bytes = BYTES_PER_ATOM * atoms_per_launch
-        achieved = alg_bytes / t_near / 1e9
-        # directed in-cutoff pairs ~ list pairs * (rc/rlist)^3 ; algorithmic pairs counted once per (i,j)
         near_stats = st1[near_id]
-        pairs_once = 0.5 * near_stats['n_list_pairs'] * (0.7 / near_stats['rlist']) ** 3
-        fp64_tf = FLOP_PER_PAIR_NEAR * pairs_once / t_near / 1e12
+        flop_dual = FLOP_PER_PAIR_FAR * pairs_far + FLOP_PER_PAIR_NEAR * pairs_near
+        # HBM traffic from the PMC passes (rocprofv3 cannot run inside this process: scripts/measure_round.sh makes them on
+        # this same command and commits the summary); quoted only while the kernels are the ones it was measured on
+        traffic = {}
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', TRAFFIC_FILE)
+        if world == 1 and args.nside == 32 and os.path.exists(tfile):
+            try:
+                stored = json.load(open(tfile))
+                if stored.get('kernel_revision') == backend.kernel_revision():
+                    traffic = stored
+            except Exception:
+                pass
+
+        def roofline(kernel, seconds, launches, alg_bytes, flops, tag):
+            achieved = alg_bytes / max(seconds, 1e-12) / 1e9
+            tf = flops / max(seconds, 1e-12) / 1e12
+            entry = {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic.get(tag, {}).get('hbm_bytes_per_launch'),
+                     'kernel': kernel, 'avg_launch_us': round(seconds * 1e6, 2), 'launches': launches,
+                     'algorithmic_bytes_per_launch': alg_bytes, 'fp64_tflops': round(tf, 3),
+                     'fp64_frac_of_vector_peak': round(tf / FP64_VECTOR_PEAK_TF, 4),
+                     'note': 'FP64-VALU / latency bound, not HBM bound (SURVEY.md 8d); fp64 fraction against the %.1f TF datasheet peak '
+                             '(a bare v_fma_f64 loop sustains %.1f TF on this chip: scripts/micro/fp64_rate.hip)'
+                             % (FP64_VECTOR_PEAK_TF, FP64_SUSTAINED_TF)}
+            if entry['traffic'] is not None:
+                entry['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, kernels %s)' % (
+                    TRAFFIC_FILE, traffic.get('kernel_revision'))
+            return entry
         result = {
             'metric': 'ns/day on 100k-atom TIP3P RESPA box; near-nonbonded HBM GB/s vs 8 TB/s peak',
             'value': round(ns_day, 3), 'unit': 'ns/day', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -201,30 +236,25 @@ def main():
                        'parallelism': ('atom decomposition x%d, %s' % (world, 'all-gather of owner-computed force slices (RCCL, library-owned communicator)'
                                                                      if getattr(eng, '_native_comm', False) else 'collectives through torch.distributed')) if world > 1 else 'single GPU',
                        'temperature_K_end': round(T_end, 1)},
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': None,
-                         'kernel': 'k_pair_nlist<NEAR_FSWITCH> (group-1 near force, force only)',
-                         'avg_launch_us': round(t_near * 1e6, 2), 'launches': n_near,
-                         'algorithmic_bytes_per_launch': alg_bytes,
-                         'note': 'FP64-VALU/latency bound, not HBM bound (SURVEY.md 8d): %.2f TFLOP/s fp64 = %.3f of %.1f TF vector peak '
-                                 'at 60 flop per in-cutoff pair' % (fp64_tf, fp64_tf / FP64_VECTOR_PEAK_TF, FP64_VECTOR_PEAK_TF)},
+            # the kernel the metric names: the stand-alone near-force traversal (group 1, force only)
+            'roofline': roofline('k_pair_tab<NEAR_FSWITCH> (group-1 near force, force only)', t_near, n_near,
+                                 BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_NEAR * pairs_near, 'near'),
+            # the dominant kernel of the step: outer force + near force of the shared list in one traversal (one read set,
+            # two force arrays: 96 B per atom)
+            'roofline_dominant': roofline('k_pair_tab<%s, guest NEAR_FSWITCH> (outer + near force in one pass)'
+                                          % ('DAMPED' if args.outer == 'damped' else 'NONBONDED/Ewald'), t_dual, n_dual,
+                                          BYTES_PER_ATOM_DUAL * atoms_per_launch, flop_dual, 'dual'),
             'detail': {'near_kernel_us': round(t_near * 1e6, 2), 'near_launches': n_near,
+                       'dual_kernel_us': round(t_dual * 1e6, 2), 'dual_launches': n_dual,
                        'near_list_prunes_in_timed_region': st1[near_id]['n_builds'] - st0[near_id]['n_builds'],
                        'far_list_prunes_in_timed_region': st1[far_id]['n_builds'] - st0[far_id]['n_builds'],
                        'outer_list_builds_in_timed_region': st1[far_id]['n_outer_builds'] - st0[far_id]['n_outer_builds'],
                        'outer_rlist_nm': st1[far_id]['rlist_outer'], 'shared_list': bool(near_stats['shares_list']),
                        'near_lanes_per_atom': near_stats['lanes_per_atom'], 'near_rlist_nm': near_stats['rlist'],
-                       'near_list_pairs': near_stats['n_list_pairs'], 'fp64_tflops_near': round(fp64_tf, 3)},
+                       'near_list_pairs': near_stats['n_list_pairs'], 'far_list_pairs': st1[far_id]['n_list_pairs'],
+                       'pairs_within_0.7nm_counted': int(pairs_near), 'pairs_within_1.0nm_counted': int(pairs_far),
+                       'kernel_revision': backend.kernel_revision()},
         }
-        # HBM traffic of the near kernel from the PMC passes (rocprofv3 cannot run inside this process; the passes
-        # are made with scripts/pmc_summary.py on this same command and committed under profiles/)
-        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
-        if world == 1 and args.nside == 32 and os.path.exists(tfile):
-            try:
-                result['roofline']['traffic'] = json.load(open(tfile))['near']['hbm_bytes_per_launch']
-                result['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)'
-            except Exception:
-                pass
         if world == 1 and not args.no_cpu_baseline and args.outer == 'damped':
             try:
                 result['cpu_baseline'] = cpu_baseline(args.nside, loops, dt_fs)

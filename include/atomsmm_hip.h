@@ -267,6 +267,13 @@ typedef struct {
     double rlist_outer;
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
+/* Measurement helper (bench.py): the number of directed list entries of this force with r < r_within at d_pos, counted in
+ * fp64 by one launch over the neighbour rows (an evaluation must have built them).  Half of it is the number of pairs the
+ * reference's expression is evaluated for when r_within is the force's cutoff (forces.py:659-661).  Synchronises. */
+int amm_pair_count_within(amm_ctx *ctx, int32_t force_id, const double *d_pos, double r_within, int64_t *count);
+/* Revision tag of the pair-traversal kernels: measurements kept under profiles/ carry it, and bench.py drops a stored
+ * figure (the PMC traffic) once the kernels it was measured on have changed. */
+const char *amm_kernel_revision(void);
 /* HIP-event timing of the dominant kernel (pair traversal) on the context stream. */
 /* on = 1: HIP events around every pair-kernel launch; on = -(force_id + 1): only around that force's launches
  * (two event packets per timed launch cost ~4 us of stream time each: time what you report); 0: off. */

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from atomsmm_amd.parallel import AtomDecomposition, slice_bounds
+from atomsmm_amd.engine import slice_bounds
 
 
 def _free_port():
@@ -58,14 +58,14 @@ def _slice_forces_job(rank, world):
     full = O.pair_eval(desc, d['positions'], d['box'], d['charge'], d['sigma'], d['epsilon'], d['exc_pairs'])[1]
     # a deterministic "cell-sorted" order shared by all ranks (here: sorted by z then index)
     order = np.lexsort((np.arange(n), np.floor(d['positions'][:, 2] / 0.4)))
-    dec = AtomDecomposition(n)
-    mine = dec.owned(order)
+    begin, end = slice_bounds(n, rank, world)
+    mine = order[begin:end]
     buf = np.zeros((n, 3))
     buf[mine] = full[mine]                   # owner-computes: full neighbour rows for my atoms, zeros elsewhere
     t = torch.from_numpy(buf)
-    dec.reduce_forces(t)
+    dist.all_reduce(t)
     e = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dec.reduce_scalar(e)
+    dist.all_reduce(e)
     return dict(n_mine=len(mine), equal=bool(np.array_equal(t.numpy(), full)), esum=e.item(),
                 digest=float(np.abs(t.numpy()).sum()))
 
@@ -204,3 +204,54 @@ def test_engine_all_gather_exchange_under_gloo():
         assert out[r]['f1'] == float(r + 1)                # no all-reduce touched the group buffers
         assert not out[r]['pending']
     assert out[0]['n_runs'] == out[1]['n_runs']
+
+
+def _consistency_job(rank, world):
+    """Unseeded setVelocitiesToTemperature and a rank-local failed check under a real process group."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import backend as B
+    from atomsmm_amd import engine as E
+    from atomsmm_amd import openmm, unit
+    from atomsmm_amd.testing import system_from_arrays
+    from fake_backend import RecordingContext
+
+    class FailingOnRank1(RecordingContext):
+        fail = False
+
+        def check(self):
+            if self.fail and self.rank == 1:
+                raise B.HipError('neighbour row overflow (rank-local)')
+
+    made = []
+    E._context_factory = lambda *a, **k: made.append(FailingOnRank1(*a, **k)) or made[-1]
+    d = np.load(os.path.join(root, 'tests', 'golden', 'q-SPC-FW.npz'))
+    case = {k: d[k] for k in d.files}
+    system = system_from_arrays(case, nonbondedMethod='CutoffPeriodic')
+    respa = atomsmm.RESPASystem(system, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
+    integ = atomsmm.RespaPropagator([2, 1, 1]).integrator(1 * unit.femtoseconds)
+    ctx = openmm.Context(respa, integ)
+    ctx.setPositions(case['positions'])
+    ctx.setVelocitiesToTemperature(300 * unit.kelvin)             # no seed: every process would draw its own
+    v = ctx._engine.v.numpy().copy()
+    gathered = [torch.zeros_like(torch.from_numpy(v)) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(v))
+    same = all(bool(torch.equal(g, gathered[0])) for g in gathered)
+    integ.step(1)                                                 # healthy step: no rank raises
+    made[-1].fail = True
+    raised = None
+    try:
+        integ.step(1)
+    except B.HipError as exc:
+        raised = str(exc)
+    return dict(same=same, nonzero=bool(np.abs(v).max() > 0), raised=raised)
+
+
+def test_unseeded_velocities_and_failed_checks_are_collective():
+    out = run_ranks(_consistency_job, world=2)
+    assert out[0]['same'] and out[1]['same'] and out[0]['nonzero']
+    assert 'rank-local' in out[1]['raised']                       # the rank that detected it
+    assert 'another rank' in out[0]['raised']                     # its peer raises too instead of hanging in the next collective
