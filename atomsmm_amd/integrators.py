@@ -282,71 +282,77 @@ class ExtendedSystemVariable(object):
 
 
 class AdiabaticDynamicsIntegrator(_AtomsMM_Integrator):
-    """Adiabatic Free Energy Dynamics (integrators.py:747-860): over one step of size 2 n dt,
-    [kick lambda ; atoms over dt ; kick lambda]^n ; lambda move + bath ; [...]^n, where "atoms over dt" is the program of
-    `custom_integrator` with dt rewritten to dt/(2n) and the kicks use deriv(energy, lambda)."""
+    """Adiabatic Free Energy Dynamics (interface of integrators.py:747-860).  One step of size 2 n dt is
+
+        [ kick lambda ; atoms over dt ; kick lambda ]^n     lambda move + bath     [ ... ]^n
+
+    where "atoms over dt" replays the program of `custom_integrator` with every `dt` rewritten to (dt/(2n)) and the kicks
+    of the extended variables use deriv(energy, lambda).  The emitted program for RespaPropagator([2,1]), n = 2, is the
+    44-step capture of SURVEY.md Appendix C.4 (tests/test_host_api.py)."""
+
+    _SKIPPED_GLOBALS = frozenset(('mvv', 'NDOF'))       # owned by _AtomsMM_Integrator itself
+    _SKIPPED_PER_DOF = frozenset(('ndof',))
 
     def __init__(self, custom_integrator, nsteps, variables):
         super().__init__(2 * nsteps * custom_integrator.getStepSize())
-        self._variables = variables
-        if nsteps > 1:
-            self._counter = '_nsteps_counter'
+        self._variables = list(variables)
+        self._nsteps = int(nsteps)
+        self._counter = '_nsteps_counter' if self._nsteps > 1 else None
+        if self._counter:
             self.addGlobalVariable(self._counter, 0)
         for variable in self._variables:
             variable.add_global_variables(self)
-        self._import_variables_and_initializer(custom_integrator)
+        self._adopt_state_of(custom_integrator)
+        # the inner program, captured once: (step kind, variable, expression with dt -> dt/(2n))
+        substep = '(dt/{})'.format(2 * self._nsteps)
+        self._inner_program = [(kind, name, re.sub(r'\bdt\b', substep, text))
+                               for kind, name, text in (custom_integrator.getComputationStep(k)
+                                                        for k in range(custom_integrator.getNumComputations()))]
         self.addUpdateContextState()
-        self._add_physical_steps(custom_integrator, nsteps)
+        self._emit_half()
         for variable in self._variables:
             variable.add_integration_steps(self)
-        self._add_physical_steps(custom_integrator, nsteps)
+        self._emit_half()
 
-    def _add_physical_steps(self, integrator, nsteps):
-        if nsteps > 1:
+    def _emit_half(self):
+        """[kick ; inner program ; kick] repeated n times (a while-loop over the counter when n > 1)."""
+        if self._counter:
             self.addComputeGlobal(self._counter, '0')
-            self.beginWhileBlock('{} < {}'.format(self._counter, nsteps))
-        for variable in self._variables:
-            variable.update_velocity(self, 2 * nsteps)
-        self._import_computations(integrator, nsteps)
-        for variable in self._variables:
-            variable.update_velocity(self, 2 * nsteps)
-        if nsteps > 1:
+            self.beginWhileBlock('{} < {}'.format(self._counter, self._nsteps))
+        self._kick_variables()
+        self._replay_inner_program()
+        self._kick_variables()
+        if self._counter:
             self.addComputeGlobal(self._counter, '{} + 1'.format(self._counter))
             self.endBlock()
 
-    def _import_computations(self, integrator, nsteps):
-        C = openmm.CustomIntegrator
-        for index in range(integrator.getNumComputations()):
-            computation, variable, expression = integrator.getComputationStep(index)
-            expression = re.sub(r'\bdt\b', '(dt/{})'.format(2 * nsteps), expression)
-            if computation == C.ComputeGlobal:
-                self.addComputeGlobal(variable, expression)
-            elif computation == C.ComputePerDof:
-                self.addComputePerDof(variable, expression)
-            elif computation == C.ComputeSum:
-                self.addComputeSum(variable, expression)
-            elif computation == C.ConstrainPositions:
-                self.addConstrainPositions()
-            elif computation == C.ConstrainVelocities:
-                self.addConstrainVelocities()
-            elif computation == C.UpdateContextState:
-                self.addUpdateContextState()
-            elif computation == C.IfBlock:
-                self.beginIfBlock(expression)
-            elif computation == C.WhileBlock:
-                self.beginWhileBlock(expression)
-            elif computation == C.EndBlock:
-                self.endBlock()
+    def _kick_variables(self):
+        for variable in self._variables:
+            variable.update_velocity(self, 2 * self._nsteps)
 
-    def _import_variables_and_initializer(self, integrator):
-        for index in range(integrator.getNumGlobalVariables()):
-            name = integrator.getGlobalVariableName(index)
-            if name not in ('mvv', 'NDOF'):
-                self.addGlobalVariable(name, integrator.getGlobalVariable(index))
-        self._imported_per_dof = {}
-        for index in range(integrator.getNumPerDofVariables()):
-            name = integrator.getPerDofVariableName(index)
-            if name != 'ndof':
+    def _replay_inner_program(self):
+        C = openmm.CustomIntegrator
+        emit = {C.ComputeGlobal: lambda name, text: self.addComputeGlobal(name, text),
+                C.ComputePerDof: lambda name, text: self.addComputePerDof(name, text),
+                C.ComputeSum: lambda name, text: self.addComputeSum(name, text),
+                C.ConstrainPositions: lambda name, text: self.addConstrainPositions(),
+                C.ConstrainVelocities: lambda name, text: self.addConstrainVelocities(),
+                C.UpdateContextState: lambda name, text: self.addUpdateContextState(),
+                C.IfBlock: lambda name, text: self.beginIfBlock(text),
+                C.WhileBlock: lambda name, text: self.beginWhileBlock(text),
+                C.EndBlock: lambda name, text: self.endBlock()}
+        for kind, name, text in self._inner_program:
+            emit[kind](name, text)
+
+    def _adopt_state_of(self, integrator):
+        """Globals, per-DOF variables and the initialisation hook of the wrapped integrator become this one's."""
+        for k in range(integrator.getNumGlobalVariables()):
+            name = integrator.getGlobalVariableName(k)
+            if name not in self._SKIPPED_GLOBALS:
+                self.addGlobalVariable(name, integrator.getGlobalVariable(k))
+        for k in range(integrator.getNumPerDofVariables()):
+            name = integrator.getPerDofVariableName(k)
+            if name not in self._SKIPPED_PER_DOF:
                 self.addPerDofVariable(name, 0)
         self._inner_initialize = getattr(type(integrator), 'initialize', None)
 

@@ -20,6 +20,38 @@ from . import unit
 from .utils import InputError, kB
 
 
+def play(integrator, template, **values):
+    """Append the steps a program template describes.  One step per line, `{name}` fields filled from `values`:
+
+        dof v <- v + ({h}*dt)*{F}/m        per-DOF computation          global X <- gaussian        global computation
+        sum mvv <- m*v*v                    sum over the DOFs            while V <= 0.0 / if ... / end    blocks
+        constrain positions / constrain velocities
+
+    The contract with the reference is the emitted program TEXT (tests/golden/goldens.json:
+    programs); the propagators below state that text as templates instead of as call sequences."""
+    for raw in template.strip().splitlines():
+        line = raw.strip().format(**values)
+        if not line:
+            continue
+        word, _, rest = line.partition(' ')
+        if word in ('dof', 'global', 'sum'):
+            name, _, expression = rest.partition(' <- ')
+            {'dof': integrator.addComputePerDof, 'global': integrator.addComputeGlobal,
+             'sum': integrator.addComputeSum}[word](name.strip(), expression.strip())
+        elif word == 'while':
+            integrator.beginWhileBlock(rest)
+        elif word == 'if':
+            integrator.beginIfBlock(rest)
+        elif line == 'end':
+            integrator.endBlock()
+        elif line == 'constrain positions':
+            integrator.addConstrainPositions()
+        elif line == 'constrain velocities':
+            integrator.addConstrainVelocities()
+        else:
+            raise ValueError('unknown step in program template: ' + line)
+
+
 class Propagator:
     """Base class: global / per-DOF variable tables and `integrator(stepSize)` (propagators.py:24-75)."""
 
@@ -131,8 +163,16 @@ class SuzukiYoshidaPropagator(Propagator):
 
 
 class TranslationPropagator(Propagator):
-    """x <- x + (fraction*dt)*v ; the constrained variant saves x0, constrains positions and rebuilds
-    v from the displacement (propagators.py:229-252)."""
+    """The move x <- x + (fraction*dt)*v.  With constraints the start is kept in x0, the positions are constrained and the
+    velocity is rebuilt from the displacement actually made (interface of propagators.py:229-252)."""
+
+    FREE = 'dof x <- x + ({h}*dt)*v'
+    CONSTRAINED = """
+        dof x0 <- x
+        dof x <- x + ({h}*dt)*v
+        constrain positions
+        dof v <- (x - x0)/({h}*dt)
+    """
 
     def __init__(self, constrained=True):
         super().__init__()
@@ -141,98 +181,69 @@ class TranslationPropagator(Propagator):
             self.perDofVariables['x0'] = 0
 
     def addSteps(self, integrator, fraction=1.0, force='f'):
-        if self.constrained:
-            integrator.addComputePerDof('x0', 'x')
-        integrator.addComputePerDof('x', 'x + ({}*dt)*v'.format(fraction))
-        if self.constrained:
-            integrator.addConstrainPositions()
-            integrator.addComputePerDof('v', '(x - x0)/({}*dt)'.format(fraction))
+        play(integrator, self.CONSTRAINED if self.constrained else self.FREE, h=fraction)
 
 
 class VelocityBoostPropagator(Propagator):
-    """v <- v + (fraction*dt)*force/m (+ velocity constraints)  (propagators.py:255-273)."""
+    """The kick v <- v + (fraction*dt)*force/m, followed by velocity constraints when asked (propagators.py:255-273)."""
 
     def __init__(self, constrained=True):
         super().__init__()
         self.constrained = constrained
 
     def addSteps(self, integrator, fraction=1.0, force='f'):
-        integrator.addComputePerDof('v', 'v + ({}*dt)*{}/m'.format(fraction, force))
-        if self.constrained:
-            integrator.addConstrainVelocities()
+        play(integrator, 'dof v <- v + ({h}*dt)*{F}/m' + ('\nconstrain velocities' if self.constrained else ''),
+             h=fraction, F=force)
 
 
 class RespaPropagator(Propagator):
-    """rRESPA with N force groups; group 0 in the innermost loop (propagators.py:830-973).
+    """rRESPA over N force groups, group 0 innermost (interface of propagators.py:830-973).
 
-    loops[k] = iterations of level k per iteration of level k+1.  Level k kicks with force expression
-    f0, f1, f2-f1, f3-f2, ... (the near force is *subtracted inside the integrator*).  Optional
-    `core` (between two half moves) and `shell` {level: propagator} baths; keyword flags
+    loops[k] = iterations of level k per iteration of level k + 1.  Level k kicks with the force expression f0, f1, f2-f1,
+    f3-f2, ...: the shorter-ranged force is subtracted inside the integrator.  `core`: a propagator placed between two half
+    moves at the bottom of the recursion; `shell`: {level: propagator} wrapped around the kicks of a level.  Keyword flags:
     has_memory (default False, as in the reference's code), use_respa_switch, blitz.
-    """
+
+    The whole program is one recursion (`_level`): level k is  [shell] kick/2 . (level k-1)^n_k . kick/2 [shell], and below
+    level 0 sits the move (split around `core`).  The emitted text is pinned by the captures of SURVEY.md 3.2 / App. C."""
 
     def __init__(self, loops, move=None, boost=None, core=None, shell=None, **kwargs):
         super().__init__()
         self.loops = loops
         self.N = len(loops)
-        self.move = move if move is not None else TranslationPropagator(constrained=False)
-        self.boost = boost if boost is not None else VelocityBoostPropagator(constrained=False)
+        self.move = move or TranslationPropagator(constrained=False)
+        self.boost = boost or VelocityBoostPropagator(constrained=False)
         self.core = core
-        if shell is None:
-            self.shell = dict()
-        elif set(shell.keys()).issubset(range(self.N)):
-            self.shell = shell
-        else:
-            raise InputError('invalid key(s) in RespaPropagator \'shell\' argument')
-        for member in [self.move, self.boost, self.core] + list(self.shell.values()):
-            if member is not None:
-                self.absorbVariables(member)
-        for level, n in enumerate(loops):
-            if n > 1:
-                self.globalVariables['n{}RESPA'.format(level)] = 0
-        self.expr = ['f{}'.format(level) for level in range(self.N)]
-        for level in range(2, self.N):
-            self.expr[level] += '-f{}'.format(level - 1)
-        self.force = list(self.expr)
+        self.shell = dict(shell or {})
+        if not set(self.shell) <= set(range(self.N)):
+            raise InputError("invalid key(s) in RespaPropagator 'shell' argument")
+        for part in (self.move, self.boost, self.core, *self.shell.values()):
+            if part is not None:
+                self.absorbVariables(part)
+        self.globalVariables.update({'n%dRESPA' % k: 0 for k, n in enumerate(loops) if n > 1})
+        # force expression per level: f0, f1, f2-f1, ...; with memory, fm_k holds level k's force through the inner loops
+        # (added to level 0's kicks, subtracted from level k's closing kick)
+        self.expr = ['f%d' % k if k < 2 else 'f%d-f%d' % (k, k - 1) for k in range(self.N)]
         self._has_memory = kwargs.pop('has_memory', False)
+        kick = list(self.expr)
         if self._has_memory:
-            for level in range(1, self.N):
-                self.perDofVariables['fm{}'.format(level)] = 0.0
-                self.force[0] += '+fm{}'.format(level)
-                self.force[level] += '-fm{}'.format(level)
-        self.force = ['({})'.format(f) for f in self.force]
+            for k in range(1, self.N):
+                self.perDofVariables['fm%d' % k] = 0.0
+                kick[0] += '+fm%d' % k
+                kick[k] += '-fm%d' % k
+        self.force = ['(%s)' % text for text in kick]
         self._use_respa_switch = kwargs.pop('use_respa_switch', False)
         self._blitz = kwargs.pop('blitz', False)
 
     def addSteps(self, integrator, fraction=1.0, force='f'):
         if self._use_respa_switch:
-            integrator.addComputeGlobal('respa_switch', '1')
-        self._addSubsteps(integrator, self.N - 1, fraction)
+            play(integrator, 'global respa_switch <- 1')
+        self._level(integrator, self.N - 1, fraction)
         if self._use_respa_switch:
-            integrator.addComputeGlobal('respa_switch', '0')
+            play(integrator, 'global respa_switch <- 0')
 
-    def _internalSplitting(self, integrator, timescale, fraction, shell):
-        remembered = self._has_memory and timescale > 0
-        if self._blitz:
-            if remembered:
-                integrator.addComputePerDof('F{}'.format(timescale), 'f{}'.format(timescale))
-            else:
-                self.boost.addSteps(integrator, fraction, self.force[timescale])
-            self._addSubsteps(integrator, timescale - 1, fraction)
-            return
-        if shell:
-            shell.addSteps(integrator, 0.5 * fraction, self.force[timescale])
-        if remembered:
-            integrator.addComputePerDof('fm{}'.format(timescale), self.expr[timescale])
-        else:
-            self.boost.addSteps(integrator, 0.5 * fraction, self.force[timescale])
-        self._addSubsteps(integrator, timescale - 1, fraction)
-        self.boost.addSteps(integrator, 0.5 * fraction, self.force[timescale])
-        if shell:
-            shell.addSteps(integrator, 0.5 * fraction, self.force[timescale])
-
-    def _addSubsteps(self, integrator, timescale, fraction):
-        if timescale < 0:
+    def _level(self, integrator, k, fraction):
+        if k < 0:                                   # below the innermost force: the move, split around the core bath
             if self.core is None:
                 self.move.addSteps(integrator, fraction)
             else:
@@ -240,108 +251,133 @@ class RespaPropagator(Propagator):
                 self.core.addSteps(integrator, fraction)
                 self.move.addSteps(integrator, 0.5 * fraction)
             return
-        n = self.loops[timescale]
-        counter = 'n{}RESPA'.format(timescale)
+        n, counter = self.loops[k], 'n%dRESPA' % k
         if n > 1:
-            integrator.addComputeGlobal(counter, '0')
-            integrator.beginWhileBlock('{} < {}'.format(counter, n))
-        self._internalSplitting(integrator, timescale, fraction / n, self.shell.get(timescale, None))
+            play(integrator, 'global {c} <- 0\nwhile {c} < {n}', c=counter, n=n)
+        self._iteration(integrator, k, fraction / n)
         if n > 1:
-            integrator.addComputeGlobal(counter, '{} + 1'.format(counter))
-            integrator.endBlock()
+            play(integrator, 'global {c} <- {c} + 1\nend', c=counter)
+
+    def _iteration(self, integrator, k, h):
+        """One iteration of level k over the fraction h of the step."""
+        remembered = self._has_memory and k > 0
+        if self._blitz:                             # one full kick up front, no closing kick
+            if remembered:
+                integrator.addComputePerDof('F%d' % k, 'f%d' % k)
+            else:
+                self.boost.addSteps(integrator, h, self.force[k])
+            return self._level(integrator, k - 1, h)
+        bath = self.shell.get(k)
+        if bath:
+            bath.addSteps(integrator, 0.5 * h, self.force[k])
+        if remembered:                              # the opening half kick is carried by the inner kicks through fm_k
+            integrator.addComputePerDof('fm%d' % k, self.expr[k])
+        else:
+            self.boost.addSteps(integrator, 0.5 * h, self.force[k])
+        self._level(integrator, k - 1, h)
+        self.boost.addSteps(integrator, 0.5 * h, self.force[k])
+        if bath:
+            bath.addSteps(integrator, 0.5 * h, self.force[k])
 
 
 class MultipleTimeScalePropagator(RespaPropagator):
-    """RESPA with a bath placed by `scheme` in {middle, blitz, xi-respa, xo-respa, side}; the bath may be
-    factorised by `nres` (SplitPropagator) and `nsy` (Suzuki-Yoshida)  (propagators.py:976-1042)."""
+    """RESPA with a bath whose place is named by `scheme` (interface of propagators.py:976-1042):
+    'middle' -- between the two half moves of the innermost loop; 'blitz' -- the same, with RespaPropagator's blitz flag;
+    'xi-respa' / 'xo-respa' -- around the kicks of the innermost / outermost level; 'side' -- around those of level `location`.
+    `nres` splits the bath into that many sub-steps, `nsy` applies a Suzuki-Yoshida factorisation on top."""
 
     def __init__(self, loops, move=None, boost=None, bath=None, **kwargs):
         scheme = kwargs.pop('scheme', 'middle')
         location = kwargs.pop('location', 0)
-        nres = kwargs.pop('nres', 1)
-        nsy = kwargs.pop('nsy', 1)
-        if nres > 1:
-            bath = SplitPropagator(bath, nres)
-        if nsy > 1:
-            bath = SuzukiYoshidaPropagator(bath, nsy)
-        if scheme == 'middle':
-            super().__init__(loops, move=move, boost=boost, core=bath, **kwargs)
-        elif scheme == 'blitz':
-            super().__init__(loops, move=move, boost=boost, core=bath, blitz=True, **kwargs)
-        elif scheme in ('xi-respa', 'xo-respa', 'side'):
-            level = {'side': location, 'xi-respa': 0, 'xo-respa': len(loops) - 1}[scheme]
-            super().__init__(loops, move=move, boost=boost, shell={level: bath}, **kwargs)
+        nres, nsy = kwargs.pop('nres', 1), kwargs.pop('nsy', 1)
+        bath = SplitPropagator(bath, nres) if nres > 1 else bath
+        bath = SuzukiYoshidaPropagator(bath, nsy) if nsy > 1 else bath
+        shell_level = {'xi-respa': 0, 'xo-respa': len(loops) - 1, 'side': location}
+        if scheme in ('middle', 'blitz'):
+            placement = dict(core=bath, blitz=True) if scheme == 'blitz' else dict(core=bath)
+        elif scheme in shell_level:
+            placement = dict(shell={shell_level[scheme]: bath})
         else:
             raise InputError('wrong value of scheme parameter')
+        placement.update(kwargs)
+        super().__init__(loops, move=move, boost=boost, **placement)
 
 
 class VelocityVerletPropagator(Propagator):
-    """Velocity Verlet with constraints (propagators.py:1108-1133)."""
+    """Velocity Verlet with constraints: half kick, constrained move, velocity from the displacement plus the second half
+    kick, velocity constraints (interface of propagators.py:1108-1133)."""
+
+    PROGRAM = """
+        dof v <- v+0.5*Dt*f/m; Dt={h}*dt
+        dof x0 <- x
+        dof x <- x+Dt*v; Dt={h}*dt
+        constrain positions
+        dof v <- (x-x0)/Dt+0.5*Dt*f/m; Dt={h}*dt
+        constrain velocities
+    """
 
     def __init__(self):
         super().__init__()
         self.perDofVariables['x0'] = 0
 
     def addSteps(self, integrator, fraction=1.0, force='f'):
-        Dt = '; Dt=%s*dt' % fraction
-        integrator.addComputePerDof('v', 'v+0.5*Dt*f/m' + Dt)
-        integrator.addComputePerDof('x0', 'x')
-        integrator.addComputePerDof('x', 'x+Dt*v' + Dt)
-        integrator.addConstrainPositions()
-        integrator.addComputePerDof('v', '(x-x0)/Dt+0.5*Dt*f/m' + Dt)
-        integrator.addConstrainVelocities()
+        play(integrator, self.PROGRAM, h=fraction)
 
 
 class UnconstrainedVelocityVerletPropagator(Propagator):
-    """Velocity Verlet without constraints (propagators.py:1136-1153)."""
+    """Velocity Verlet without constraints (interface of propagators.py:1136-1153)."""
+
+    PROGRAM = """
+        dof v <- v+0.5*{h}*dt*f/m
+        dof x <- x+{h}*dt*v
+        dof v <- v+0.5*{h}*dt*f/m
+    """
 
     def addSteps(self, integrator, fraction=1.0, force='f'):
-        integrator.addComputePerDof('v', 'v+0.5*{}*dt*f/m'.format(fraction))
-        integrator.addComputePerDof('x', 'x+{}*dt*v'.format(fraction))
-        integrator.addComputePerDof('v', 'v+0.5*{}*dt*f/m'.format(fraction))
+        play(integrator, self.PROGRAM, h=fraction)
 
 
 class VelocityRescalingPropagator(Propagator):
-    """Stochastic velocity rescaling of Bussi, Donadio and Parrinello (propagators.py:1156-1227): a gamma-distributed
-    sum of squared Gaussians by Marsaglia-Tsang rejection in the global variables, then `v <- vscaling*v`."""
+    """Stochastic velocity rescaling of Bussi, Donadio and Parrinello (interface of propagators.py:1156-1227).  The sum of
+    dof - 1 squared Gaussians is drawn as a gamma variate by Marsaglia-Tsang rejection (shape `a`, constants d = a - 1/3 and
+    c = 1/sqrt(9 d)) held in global variables -- plus one more squared Gaussian when dof - 1 is odd -- and the velocities
+    are scaled by the factor of the paper's Eq. (A7)."""
+
+    GAMMA_VARIATE = """
+        global ready <- 0
+        while ready < 0.5
+            global X <- gaussian
+            global V <- 1+{c}*X
+            while V <= 0.0
+                global X <- gaussian
+                global V <- 1+{c}*X
+            end
+            global V <- V^3
+            global U <- random
+            global ready <- step(1-0.0331*X^4-U)
+            if ready < 0.5
+                global ready <- step(0.5*X^2+{d}*(1-V+log(V))-log(U))
+            end
+        end
+    """
+    RESCALE = ('dof v <- vscaling*v; vscaling = sqrt(A+C*B*(gaussian^2+sumRs)+2*sqrt(C*B*A)*gaussian); C = {kT}/mvv; B = 1-A; '
+               'A = exp(-dt*{rate}); sumRs = {twice_d}*V{extra}')
 
     def __init__(self, temperature, degreesOfFreedom, timeScale):
         super().__init__()
         self.tau = unit.md_value(timeScale)
         self.dof = degreesOfFreedom
         self.kT = unit.md_value(kB * temperature)
-        for name in ('V', 'X', 'U', 'ready'):
-            self.globalVariables[name] = 0
+        self.globalVariables.update(V=0, X=0, U=0, ready=0)
 
     def addSteps(self, integrator, fraction=1.0, force='f'):
-        a = (self.dof - 2 + self.dof % 2) / 2
-        d = a - 1 / 3
-        c = 1 / math.sqrt(9 * d)
-        integrator.addComputeGlobal('ready', '0')
-        integrator.beginWhileBlock('ready < 0.5')
-        integrator.addComputeGlobal('X', 'gaussian')
-        integrator.addComputeGlobal('V', '1+%s*X' % c)
-        integrator.beginWhileBlock('V <= 0.0')
-        integrator.addComputeGlobal('X', 'gaussian')
-        integrator.addComputeGlobal('V', '1+%s*X' % c)
-        integrator.endBlock()
-        integrator.addComputeGlobal('V', 'V^3')
-        integrator.addComputeGlobal('U', 'random')
-        integrator.addComputeGlobal('ready', 'step(1-0.0331*X^4-U)')
-        integrator.beginIfBlock('ready < 0.5')
-        integrator.addComputeGlobal('ready', 'step(0.5*X^2+%s*(1-V+log(V))-log(U))' % d)
-        integrator.endBlock()
-        integrator.endBlock()
-        odd = self.dof % 2 == 1
-        if odd:
-            integrator.addComputeGlobal('X', 'gaussian')
-        pieces = ['vscaling*v',
-                  'vscaling = sqrt(A+C*B*(gaussian^2+sumRs)+2*sqrt(C*B*A)*gaussian)',
-                  'C = %s/mvv' % self.kT,
-                  'B = 1-A',
-                  'A = exp(-dt*%s)' % (fraction / self.tau),
-                  'sumRs = %s*V' % (2 * d) + ('+X^2' if odd else '')]
-        integrator.addComputePerDof('v', '; '.join(pieces))
+        one_more = self.dof % 2 == 1
+        shape = (self.dof - 2 + self.dof % 2) / 2
+        d = shape - 1 / 3
+        play(integrator, self.GAMMA_VARIATE, c=1 / math.sqrt(9 * d), d=d)
+        if one_more:
+            play(integrator, 'global X <- gaussian')
+        play(integrator, self.RESCALE, kT=self.kT, rate=fraction / self.tau, twice_d=2 * d, extra='+X^2' if one_more else '')
 
 
 class NoseHooverPropagator(Propagator):

@@ -519,55 +519,57 @@ class AlchemicalRespaSystem(openmm.System):
 
 
 class AlchemicalSoftcoreCVForce(object):
-    """The softcore solute-solvent energy at a grid of coupling-parameter values, each in its own force group of a
-    private System / Context (systems.py:412-470): the collective variables E0, E1, ... used for reweighting."""
+    """Collective variables E0, E1, ... for reweighting: the softcore solute-solvent energy at every value of a grid of
+    coupling parameters (interface of systems.py:412-470).  One private System holds a clone of the alchemical softcore
+    force per grid point, with the coupling parameter frozen into its expression, each clone in the force group that
+    carries its index; a private Context on the caller's platform evaluates them group by group."""
+
+    _EXPRESSION = ('4*lambda*epsilon*x*(x - 1); x = 1/((r/sigma)^6 + 0.5*(1-lambda)); lambda = {}; '
+                   'sigma = 0.5*(sigma1 + sigma2); epsilon = sqrt(epsilon1*epsilon2)')
 
     def __init__(self, alchemical_system, grid):
-        self._system = openmm.System()
-        for i in range(alchemical_system.getNumParticles()):
-            self._system.addParticle(alchemical_system.getParticleMass(i))
-        self._system.setDefaultPeriodicBoxVectors(*alchemical_system.getDefaultPeriodicBoxVectors())
+        template = alchemical_system._alchemical_vdw_force
+        self._grid = list(grid)
         self._context = None
-        self._numForces = len(grid)
-        original = alchemical_system._alchemical_vdw_force
-        for index, value in enumerate(grid):
-            ljsoft = '4*lambda*epsilon*x*(x - 1)'
-            ljsoft += '; x = 1/((r/sigma)^6 + 0.5*(1-lambda))'
-            ljsoft += '; lambda = {}'.format(value)
-            ljsoft += '; sigma = 0.5*(sigma1 + sigma2)'
-            ljsoft += '; epsilon = sqrt(epsilon1*epsilon2)'
-            force = openmm.CustomNonbondedForce(ljsoft)
-            force.setNonbondedMethod(original.getNonbondedMethod())
-            for parameter in ['sigma', 'epsilon']:
-                force.addPerParticleParameter(parameter)
-            for i in range(original.getNumParticles()):
-                _, sigma, epsilon = original.getParticleParameters(i)
-                force.addParticle((sigma, epsilon))
-            for i in range(original.getNumExclusions()):
-                force.addExclusion(*original.getExclusionParticles(i))
-            force.setCutoffDistance(original.getCutoffDistance())
-            force.setUseSwitchingFunction(original.getUseSwitchingFunction())
-            force.setSwitchingDistance(original.getSwitchingDistance())
-            if value != 0.0:
-                force.setUseLongRangeCorrection(original.getUseLongRangeCorrection())
-            for i in range(original.getNumInteractionGroups()):
-                force.addInteractionGroup(*original.getInteractionGroupParameters(i))
-            force.setForceGroup(index)
-            self._system.addForce(force)
+        self._system = openmm.System()
+        for mass in (alchemical_system.getParticleMass(k) for k in range(alchemical_system.getNumParticles())):
+            self._system.addParticle(mass)
+        self._system.setDefaultPeriodicBoxVectors(*alchemical_system.getDefaultPeriodicBoxVectors())
+        lj = [template.getParticleParameters(k)[1:] for k in range(template.getNumParticles())]
+        exclusions = [template.getExclusionParticles(k) for k in range(template.getNumExclusions())]
+        groups = [template.getInteractionGroupParameters(k) for k in range(template.getNumInteractionGroups())]
+        for group, coupling in enumerate(self._grid):
+            self._system.addForce(self._clone(template, coupling, group, lj, exclusions, groups))
+
+    def _clone(self, template, coupling, group, lj, exclusions, interaction_groups):
+        force = openmm.CustomNonbondedForce(self._EXPRESSION.format(coupling))
+        force.addPerParticleParameter('sigma')
+        force.addPerParticleParameter('epsilon')
+        for sigma_epsilon in lj:
+            force.addParticle(tuple(sigma_epsilon))
+        for pair in exclusions:
+            force.addExclusion(*pair)
+        for sets in interaction_groups:
+            force.addInteractionGroup(*sets)
+        force.setNonbondedMethod(template.getNonbondedMethod())
+        force.setCutoffDistance(template.getCutoffDistance())
+        force.setUseSwitchingFunction(template.getUseSwitchingFunction())
+        force.setSwitchingDistance(template.getSwitchingDistance())
+        # a fully decoupled solute has no dispersion tail to correct
+        force.setUseLongRangeCorrection(template.getUseLongRangeCorrection() and coupling != 0.0)
+        force.setForceGroup(group)
+        return force
 
     def getNumCollectiveVariables(self):
-        return self._numForces
+        return len(self._grid)
 
     def getCollectiveVariableName(self, index):
-        return 'E{}'.format(index)
+        return 'E%d' % index
 
     def getCollectiveVariableValues(self, context):
         import numpy as np
         if self._context is None:
             self._context = openmm.Context(self._system, openmm.CustomIntegrator(0), context.getPlatform())
         self._context.setState(context.getState(getPositions=True))
-        energy = np.empty(self._numForces)
-        for index in range(self._numForces):
-            state = self._context.getState(getEnergy=True, groups=set([index]))
-            energy[index] = md_value(state.getPotentialEnergy())
-        return energy
+        return np.array([md_value(self._context.getState(getEnergy=True, groups={g}).getPotentialEnergy())
+                         for g in range(len(self._grid))])

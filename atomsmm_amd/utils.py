@@ -65,55 +65,46 @@ def exceptionOffsetParameters(force):
     return _offset_parameters(force, force.getNumExceptionParameterOffsets(), force.getExceptionParameterOffset)
 
 
+_REPORTED_AS = ('NonbondedForce', 'CustomNonbondedForce', 'CustomBondForce', 'HarmonicBondForce', 'HarmonicAngleForce',
+                'PeriodicTorsionForce')
+
+
+def _energy_label(force, openmm):
+    """OpenMM hands back plain base-class proxies from System.getForces(), so AtomsMM's subclasses are reported under the
+    name of their OpenMM base class (tests/test_systems.py:63-79); the direct space of a NonbondedForce is 'Real-Space'."""
+    label = type(force).__name__
+    for base_name in _REPORTED_AS:
+        if isinstance(force, getattr(openmm, base_name)):
+            label = base_name
+    return 'Real-Space' if label == 'NonbondedForce' else label
+
+
 def splitPotentialEnergy(system, topology, positions, **globals):
-    """Potential energy split per Force object (utils.py:118-186): every force of a deep copy of the
-    system gets its own group (a NonbondedForce's reciprocal space a separate one), one getState per
-    group, keys 'ClassName', 'ClassName(k)', 'Real-Space', 'Reciprocal-Space', 'Total'."""
+    """Potential energy per Force object (interface of utils.py:118-186): in a deep copy of the system every force gets a
+    force group of its own -- the reciprocal space of a NonbondedForce one more -- and each group is evaluated by itself.
+    Keys: 'ClassName' for the first force of a kind and 'ClassName(k)' for the k-th further one, 'Real-Space' /
+    'Reciprocal-Space' for a NonbondedForce, and 'Total'.  Keyword arguments set global Context parameters first."""
     openmm = _openmm()
-    syscopy = deepcopy(system)
-    forces = syscopy.getForces()
-    index = 0
-    for force in forces:
-        force.setForceGroup(index)
-        index += 1
+    work = deepcopy(system)
+    plan = []                                   # (label, group) in evaluation order
+    repeats = {}
+    next_group = 0
+    for force in work.getForces():
+        label = _energy_label(force, openmm)
+        k = repeats[label] = repeats.get(label, -1) + 1
+        suffix = '' if k == 0 else '(%d)' % k
+        force.setForceGroup(next_group)
+        plan.append((label + suffix, next_group))
+        next_group += 1
         if isinstance(force, openmm.NonbondedForce):
-            force.setReciprocalSpaceForceGroup(index)
-            index += 1
-    platform = openmm.Platform.getPlatformByName('HIP')
-    integrator = openmm.VerletIntegrator(0.0)
-    simulation = openmm.app.Simulation(topology, syscopy, integrator, platform)
+            force.setReciprocalSpaceForceGroup(next_group)
+            plan.append(('Reciprocal-Space' + suffix, next_group))
+            next_group += 1
+    simulation = openmm.app.Simulation(topology, work, openmm.VerletIntegrator(0.0), openmm.Platform.getPlatformByName('HIP'))
     simulation.context.setPositions(positions)
-    for parameter, value in globals.items():
-        simulation.context.setParameter(parameter, value)
-    seen = dict()
-    energy = dict()
-    index = 0
-    for force in forces:
-        state = simulation.context.getState(getEnergy=True, groups=set([index]))
-        # OpenMM hands back plain base-class proxies from System.getForces(), so AtomsMM subclasses are
-        # reported under their OpenMM base-class name (tests/test_systems.py:63-79)
-        name = force.__class__.__name__
-        for base in (openmm.NonbondedForce, openmm.CustomNonbondedForce, openmm.CustomBondForce,
-                     openmm.HarmonicBondForce, openmm.HarmonicAngleForce, openmm.PeriodicTorsionForce):
-            if isinstance(force, base):
-                name = base.__name__
-        if name == 'NonbondedForce':
-            name = 'Real-Space'
-        new = name not in seen
-        if new:
-            seen[name] = 0
-            energy[name] = state.getPotentialEnergy()
-        else:
-            seen[name] += 1
-            energy['%s(%d)' % (name, seen[name])] = state.getPotentialEnergy()
-        index += 1
-        if isinstance(force, openmm.NonbondedForce):
-            state = simulation.context.getState(getEnergy=True, groups=set([index]))
-            if new:
-                energy['Reciprocal-Space'] = state.getPotentialEnergy()
-            else:
-                energy['%s(%d)' % ('Reciprocal-Space', seen[name])] = state.getPotentialEnergy()
-            index += 1
+    for name, value in globals.items():
+        simulation.context.setParameter(name, value)
+    energy = {label: simulation.context.getState(getEnergy=True, groups={group}).getPotentialEnergy() for label, group in plan}
     energy['Total'] = sum(energy.values(), 0.0 * unit.kilojoules_per_mole)
     return energy
 
