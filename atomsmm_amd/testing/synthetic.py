@@ -138,3 +138,119 @@ def system_from_arrays(c, nonbondedMethod='CutoffPeriodic', cutoff=1.0, switch=N
     nb.setUseDispersionCorrection(dispersionCorrection)
     system.addForce(nb)
     return system
+
+
+def _zigzag_block(n_atoms, per_row, origin, dx=0.124, dy=0.042, row_gap=0.45):
+    """n_atoms on a serpentine of zig-zag rows (bond 0.15 nm inside a row, rows and layers row_gap apart): a compact,
+    self-avoiding bonded chain whose non-bonded neighbours are never closer than row_gap."""
+    rows = (n_atoms + per_row - 1) // per_row
+    side = int(np.ceil(np.sqrt(rows)))
+    pos = np.empty((n_atoms, 3))
+    for k in range(n_atoms):
+        row, col = divmod(k, per_row)
+        layer, line = divmod(row, side)
+        if layer % 2:
+            line = side - 1 - line                  # layers snake back so that consecutive rows stay neighbours
+        c = col if row % 2 == 0 else per_row - 1 - col
+        pos[k] = (c * dx, line * row_gap + (dy if c % 2 else -dy), layer * row_gap)
+    return pos + np.asarray(origin)
+
+
+def solvated_chain(nside=44, n_chain=3000, n_solute=30, seed=SEED, density=33.368):
+    """C5 of BASELINE.json: a box of flexible TIP3P waters (nside^3 lattice sites; 44 -> 13.67 nm) holding a
+    bonded `n_chain`-atom chain -- harmonic bonds and angles, periodic torsions, 1-2 / 1-3 exclusions and scaled 1-4
+    exceptions (coulomb14 0.8333, lj14 0.5), alternating charges -- and an uncharged `n_solute`-atom solute meant to be
+    coupled through lambda_vdw.  Waters that overlap either are removed (about 83 000 remain at nside = 44, ~252 000 atoms).
+    Bond lengths and angles of the chain are at their equilibrium values in the generated geometry.  Atom order: waters
+    (O, H, H), chain, solute.  Keys as tip3p_box plus torsions, the exception parameters, 'chain' and 'solute' index arrays."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    w = tip3p_box(nside, seed, density)
+    L = float(w['box'][0])
+    per_row = 30 if n_chain >= 900 else 10
+    rows = (n_chain + per_row - 1) // per_row
+    side = int(np.ceil(np.sqrt(rows)))
+    block = np.array([per_row * 0.124, side * 0.45, max(1, (rows + side - 1) // side) * 0.45])
+    chain = _zigzag_block(n_chain, per_row, 0.5 * (L - block) + np.array([-0.2 * L, 0.0, 0.0]))
+    solute = _zigzag_block(n_solute, 10, np.array([0.72 * L, 0.5 * L, 0.5 * L]))
+    guests = np.concatenate([chain, solute]) % L
+    # drop the waters that overlap the chain or the solute
+    tree = cKDTree(guests, boxsize=L)
+    wpos = w['positions'] % L
+    near = tree.query_ball_point(wpos, r=0.30, return_length=True) > 0
+    keep_mol = ~near.reshape(-1, 3).any(axis=1)
+    nmol = int(keep_mol.sum())
+    keep_atoms = np.repeat(keep_mol, 3)
+    nw = 3 * nmol
+    pos = np.concatenate([w['positions'][keep_atoms], chain, solute])
+    n = len(pos)
+    ic = nw + np.arange(n_chain)
+    isol = nw + n_chain + np.arange(n_solute)
+    charge = np.concatenate([np.tile([-0.834, 0.417, 0.417], nmol), np.tile([0.2, -0.2], (n_chain + 1) // 2)[:n_chain], np.zeros(n_solute)])
+    charge[ic[-1]] -= charge[ic].sum()                      # neutral chain whatever its length
+    sigma = np.concatenate([np.tile([0.315075, 1.0, 1.0], nmol), np.tile([0.33, 0.30], (n_chain + 1) // 2)[:n_chain], np.full(n_solute, 0.34)])
+    epsilon = np.concatenate([np.tile([0.635968, 0.0, 0.0], nmol), np.tile([0.40, 0.25], (n_chain + 1) // 2)[:n_chain], np.full(n_solute, 0.36)])
+    mass = np.concatenate([np.tile([15.9994, 1.008, 1.008], nmol), np.full(n_chain + n_solute, 12.011)])
+    o = 3 * np.arange(nmol, dtype=np.int64)
+    bonds = [np.stack([o, o + 1], 1), np.stack([o, o + 2], 1)]
+    bond_r0 = [np.full(2 * nmol, 0.09572)]
+    bond_k = [np.full(2 * nmol, 462750.4)]
+    angles = [np.stack([o + 1, o, o + 2], 1)]
+    angle_t0 = [np.full(nmol, 1.82421813)]
+    angle_k = [np.full(nmol, 836.8)]
+    torsions = []
+    exc = [np.stack([o, o + 1], 1), np.stack([o, o + 2], 1), np.stack([o + 1, o + 2], 1)]
+    exc_qq = [np.zeros(3 * nmol)]
+    exc_sig = [np.concatenate([np.full(2 * nmol, 0.5 * (0.315075 + 1.0)), np.full(nmol, 1.0)])]
+    exc_eps = [np.zeros(3 * nmol)]
+    for idx in (ic, isol):
+        m = len(idx)
+        p = pos[idx]
+        b = np.stack([idx[:-1], idx[1:]], 1)
+        bonds.append(b)
+        bond_r0.append(np.linalg.norm(p[1:] - p[:-1], axis=1))
+        bond_k.append(np.full(m - 1, 250000.0))
+        u, v = p[:-2] - p[1:-1], p[2:] - p[1:-1]
+        cosang = (u * v).sum(1) / (np.linalg.norm(u, axis=1) * np.linalg.norm(v, axis=1))
+        angles.append(np.stack([idx[:-2], idx[1:-1], idx[2:]], 1))
+        angle_t0.append(np.arccos(np.clip(cosang, -1.0, 1.0)))
+        angle_k.append(np.full(m - 2, 400.0))
+        torsions.append(np.stack([idx[:-3], idx[1:-2], idx[2:-1], idx[3:]], 1))
+        for gap, scale_q, scale_e in ((1, 0.0, 0.0), (2, 0.0, 0.0), (3, 0.8333, 0.5)):       # 1-2, 1-3 excluded; 1-4 scaled
+            i, j = idx[:-gap], idx[gap:]
+            exc.append(np.stack([i, j], 1))
+            exc_qq.append(scale_q * charge[i] * charge[j])
+            exc_sig.append(0.5 * (sigma[i] + sigma[j]))
+            exc_eps.append(scale_e * np.sqrt(epsilon[i] * epsilon[j]))
+    tors = np.concatenate(torsions).astype(np.int32)
+    kT = 0.0083144626181532 * 300.0
+    vel = rng.normal(size=(n, 3)) * np.sqrt(kT / mass)[:, None]
+    residue = np.concatenate([np.repeat(np.arange(nmol), 3), np.full(n_chain, nmol), np.full(n_solute, nmol + 1)]).astype(np.int32)
+    return dict(positions=pos, box=np.full(3, L), charge=charge, sigma=sigma, epsilon=epsilon, mass=mass,
+                bonds=np.concatenate(bonds).astype(np.int32), bond_r0=np.concatenate(bond_r0), bond_k=np.concatenate(bond_k),
+                angles=np.concatenate(angles).astype(np.int32), angle_theta0=np.concatenate(angle_t0), angle_k=np.concatenate(angle_k),
+                torsions=tors, torsion_n=np.full(len(tors), 3, dtype=np.int32), torsion_phase=np.zeros(len(tors)),
+                torsion_k=np.full(len(tors), 1.0),
+                exc_pairs=np.concatenate(exc).astype(np.int32), exc_chargeprod=np.concatenate(exc_qq),
+                exc_sigma=np.concatenate(exc_sig), exc_epsilon=np.concatenate(exc_eps), velocities=vel, residue=residue,
+                chain=ic.astype(np.int32), solute=isol.astype(np.int32), n_waters=nmol)
+
+
+def build_c5_system(case, outer='damped'):
+    """The System of config C5 from a solvated_chain() case, through the AtomsMM-shaped API only:
+    SolvationSystem (softcore solute-solvent force with the global parameter lambda_vdw, systems.py:240-315) ->
+    RESPASystem(0.7, 0.5) (near force in group 1, exceptions as NonbondedExceptionsForce-type bonds in group 0,
+    systems.py:62-95) -> the outer NonbondedForce replaced by DampedSmoothedForce(2.9/nm, 1.0, 0.9) in group 2 (the
+    composition recipe of SURVEY.md 8d C1/C3) unless outer == 'pme'."""
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import unit
+    method = 'PME' if outer == 'pme' else 'CutoffPeriodic'
+    system = system_from_arrays(case, nonbondedMethod=method, cutoff=1.0, switch=0.9)
+    solvated = atomsmm.SolvationSystem(system, set(int(i) for i in case['solute']))
+    respa = atomsmm.RESPASystem(solvated, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
+    if outer != 'pme':
+        nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+        force = atomsmm.DampedSmoothedForce(2.9 / unit.nanometers, 1.0 * unit.nanometers, 0.9 * unit.nanometers).importFrom(nb)
+        force.setForceGroup(2)
+        force.addTo(respa)
+    return respa

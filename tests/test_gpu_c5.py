@@ -1,0 +1,90 @@
+"""Config C5 of BASELINE.json: a solvated bonded chain with 1-4 exceptions (NonbondedExceptionsForce in
+group 0), RESPA near / outer split and one AFED extended variable lambda_vdw that couples a 30-atom solute through the
+softcore force of SolvationSystem -- at the full ~250 000 atoms for the static checks, and at a 4 233-atom instance of the
+same generator for the step-by-step comparison of the AFED program with its oracle-driven evaluation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+import atomsmm_amd as atomsmm  # noqa: E402
+from atomsmm_amd import openmm, unit  # noqa: E402
+from atomsmm_amd.testing import build_c5_system, solvated_chain  # noqa: E402
+from oracle import oracle as O  # noqa: E402  (checker only)
+from oracle.afed_cpu import AfedCPU  # noqa: E402
+
+
+def group_forces(context, group):
+    st = context.getState(getForces=True, getEnergy=True, groups={group})
+    return st.getPotentialEnergy()._value, st.getForces(asNumpy=True)._value
+
+
+def check_groups(case, context, ref, lam):
+    e0, f0 = group_forces(context, 0)
+    r0e, r0f = ref.group_energy_forces(0)
+    lrc = O.softcore_lrc(case['sigma'], case['epsilon'], ref.codes, case['box'], 1.0, 0.9, lam)
+    assert e0 == pytest.approx(r0e + lrc, rel=1e-9)
+    assert np.abs(f0 - r0f).max() <= 1e-9 * np.abs(r0f).max()
+    for g in (1, 2):
+        e, f = group_forces(context, g)
+        re_, rf = ref.group_energy_forces(g)
+        assert e == pytest.approx(re_, rel=1e-10)
+        assert np.abs(f - rf).max() <= 1e-9 * np.abs(rf).max()
+    d = context._engine.energy_derivative('lambda_vdw')
+    assert d == pytest.approx(ref.dE_dlambda(), rel=2e-6)
+
+
+def test_c5_groups_and_afed_steps_vs_oracle_small():
+    """4 233 atoms: per-group energies and forces, deriv(energy, lambda_vdw), then 3 AFED steps (RESPA [2,2,1] inside,
+    n = 2 sub-steps, Nose-Hoover bath on lambda) against the oracle-driven evaluation of the same program."""
+    case = solvated_chain(nside=12, n_chain=300, n_solute=30)
+    respa = build_c5_system(case)
+    inner = atomsmm.RespaPropagator([2, 2, 1]).integrator(1 * unit.femtoseconds)
+    var = atomsmm.ExtendedSystemVariable('lambda_vdw', 50, 2.5, 20 * unit.femtoseconds)
+    integrator = atomsmm.AdiabaticDynamicsIntegrator(inner, 2, [var])
+    context = openmm.Context(respa, integrator)
+    context.setPositions(case['positions'] * unit.nanometers)
+    context.setVelocities(case['velocities'])
+    context.setParameter('lambda_vdw', 0.8)
+    ref = AfedCPU(case, loops=(2, 2, 1), dt=0.001, nsteps=2, mass=50.0, kT=2.5, tau=0.02, lam=0.8, v_lam=0.0)
+    check_groups(case, context, ref, 0.8)
+    integrator.step(0)                                              # runs the (random) initialisation hook ...
+    integrator.setGlobalVariableByName('_v_lambda_vdw', 0.05)       # ... which these known starting values replace
+    integrator.setGlobalVariableByName('_v_eta_lambda_vdw', 0.0)
+    ref.v_lam = 0.05
+    for _ in range(3):
+        integrator.step(1)
+        ref.step(1)
+        x = context.getState(getPositions=True).getPositions(asNumpy=True)._value
+        assert np.abs(x - ref.x).max() < 1e-9
+        assert context.getParameter('lambda_vdw') == pytest.approx(ref.lam, abs=1e-9)
+        assert integrator.getGlobalVariableByName('_v_lambda_vdw') == pytest.approx(ref.v_lam, rel=1e-6, abs=1e-9)
+    assert abs(ref.lam - 0.8) > 1e-4                                  # lambda did move
+
+
+def test_c5_full_size_groups_and_afed():
+    """~249 000 atoms (82 015 waters + the 3 000-atom chain + the solute): per-group energies and forces and
+    deriv(energy, lambda_vdw) vs the oracle; then AFED steps: lambda moves and stays within its walls, the Context
+    parameter follows the extended variable, nothing overflows (amm_check) and the energies stay finite."""
+    case = solvated_chain()
+    n = len(case['positions'])
+    assert n > 245000 and len(case['chain']) == 3000 and len(case['solute']) == 30
+    respa = build_c5_system(case)
+    inner = atomsmm.RespaPropagator([4, 2, 1]).integrator(1 * unit.femtoseconds)
+    var = atomsmm.ExtendedSystemVariable('lambda_vdw', 50, 2.5, 20 * unit.femtoseconds)
+    integrator = atomsmm.AdiabaticDynamicsIntegrator(inner, 2, [var])
+    integrator.setRandomNumberSeed(7)
+    context = openmm.Context(respa, integrator)
+    context.setPositions(case['positions'] * unit.nanometers)
+    context.setVelocities(case['velocities'])
+    context.setParameter('lambda_vdw', 0.6)
+    ref = AfedCPU(case, lam=0.6)
+    check_groups(case, context, ref, 0.6)
+    seen = []
+    for _ in range(4):
+        integrator.step(2)
+        seen.append(context.getParameter('lambda_vdw'))
+    assert all(0.0 <= v <= 1.0 for v in seen) and max(seen) - min(seen) > 1e-5, seen
+    st = context.getState(getEnergy=True)
+    assert np.isfinite(st.getPotentialEnergy()._value) and np.isfinite(st.getKineticEnergy()._value)
