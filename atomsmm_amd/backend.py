@@ -137,9 +137,10 @@ def lib():
         L.amm_bath_define.argtypes = [vp, C.c_double, C.c_double, ip]
         L.amm_expr_eval.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp]
         for name in EXPORTS:
-            if name not in ('amm_last_error',):
+            if name not in ('amm_last_error', 'amm_kernel_revision'):
                 getattr(L, name).restype = C.c_int
         L.amm_last_error.restype = C.c_char_p
+        L.amm_kernel_revision.restype = C.c_char_p
         _LIB = L
     return _LIB
 

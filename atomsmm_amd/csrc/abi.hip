@@ -288,6 +288,10 @@ int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id) {
         amm_set_error("amm_pair_share_list: invalid host/guest combination");
         return 1;
     }
+    if (g->d_member || h->d_member) {
+        amm_set_error("amm_pair_share_list: an interaction-group force keeps its own (filtered) neighbour list");
+        return 1;
+    }
     if (g->built || h->built) {
         amm_set_error("amm_pair_share_list must be called before the first force evaluation");
         return 1;
@@ -351,6 +355,19 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
     AMM_HIP(hipMemcpy(pf->d_q, h_q, sizeof(double) * n, hipMemcpyHostToDevice));
     AMM_HIP(hipMemcpy(pf->d_hsig, hs.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     AMM_HIP(hipMemcpy(pf->d_seps2, se.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    // interaction-group forces carry the set code of every atom (0 none, 1, 2) in place of a parameter: q for SOFTCORE and
+    // AMM_GROUP_LJ (product 2 = a (set 1, set 2) pair), sigma for AMM_GROUP_Q (sigma/2 holds the code).  The neighbour list
+    // of such a force keeps only the pairs with code_i * code_j == 2: every other entry would be evaluated to an exact zero.
+    {
+        const bool by_q = pf->desc.family == AMM_SOFTCORE || (pf->desc.flags & AMM_GROUP_LJ);
+        const bool by_sigma = (pf->desc.flags & AMM_GROUP_Q) != 0;
+        if (by_q || by_sigma) {
+            std::vector<float> member(n);
+            for (int i = 0; i < n; ++i) member[i] = (float)(by_q ? h_q[i] : 0.5 * h_sigma[i]);
+            if (!pf->d_member) AMM_HIP(hipMalloc(&pf->d_member, sizeof(float) * n));
+            AMM_HIP(hipMemcpy(pf->d_member, member.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+        }
+    }
     // class of each atom for the traversal order: 1 = no Lennard-Jones site (its rows skip the LJ arithmetic)
     std::vector<int> cls(n);
     for (int i = 0; i < n; ++i) cls[i] = h_eps[i] == 0.0 ? 1 : 0;

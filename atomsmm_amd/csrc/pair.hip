@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
                                                           const double *__restrict__ q, const double *__restrict__ hsig,
                                                           const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s,
                                                           const int *__restrict__ cls, const int *__restrict__ start_lj,
-                                                          int *row_order, int s_begin, int s_end, int *n_lj_out) {
+                                                          int *row_order, int s_begin, int s_end, int *n_lj_out, const float *__restrict__ member) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (!force && !flags[which]) {
         if (posq_s && gid < n) {
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
         p.x = (float)pd.x;
         p.y = (float)pd.y;
         p.z = (float)pd.z;
-        p.w = 0.f;
+        p.w = member ? member[me] : 0.f;       // set code of an interaction-group force (the build keeps (1, 2) pairs only)
         pos4f_s[sl] = p;
         inv_perm[me] = sl;
         if (row_order && sl >= s_begin && sl < s_end) {
@@ -260,7 +260,7 @@ __global__ void k_gather_f32(int n, const int *__restrict__ perm, const double *
     p.x = (float)wrap1(pos[3 * i], box.L[0], box.invL[0]);
     p.y = (float)wrap1(pos[3 * i + 1], box.L[1], box.invL[1]);
     p.z = (float)wrap1(pos[3 * i + 2], box.L[2], box.invL[2]);
-    p.w = 0.f;
+    p.w = pos4f_s[s].w;                        // the set code travels with the slot (same permutation)
     pos4f_s[s] = p;
     if (inv_perm) inv_perm[i] = s;
 }
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                               const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2, float rnear2,
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
                               int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
-                              unsigned long long *counters, int *ticket, int which, int force) {
+                              unsigned long long *counters, int *ticket, int which, int force, int filtered) {
     if (!force && !flags[which]) return;
     __shared__ int s_rstart[4][64];
     __shared__ int s_rpref[4][64];
@@ -452,10 +452,11 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
             // per i-atom scalars: coordinates and the two running row lengths packed into one register
             // (front | back << 16; rows are shorter than 65536 -- checked on the host); the kernel lives on the
             // scalar-register budget, 8 atoms x 4 registers
-            float px[AMM_BATCH], py[AMM_BATCH], pz[AMM_BATCH];
+            float px[AMM_BATCH], py[AMM_BATCH], pz[AMM_BATCH], pw[AMM_BATCH];
             int c2[AMM_BATCH];
 #pragma unroll
             for (int t = 0; t < AMM_BATCH; ++t) {
+                pw[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.w), t));
                 px[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.x), t));
                 py[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.y), t));
                 pz[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.z), t));
@@ -504,6 +505,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                         // lane masks live in scalar registers: ballots of plain compares, combined with scalar logic
                         unsigned long long m_pass = __builtin_amdgcn_ballot_w64(r2 < rlist2);
                         if (RINT) m_pass &= __builtin_amdgcn_ballot_w64(js[u] >= 0);
+                        if (filtered) m_pass &= __builtin_amdgcn_ballot_w64(pw[t] * cand[u].w == 2.0f);   // (set 1, set 2) pairs only
                         if (special) {       // wave-uniform branch, scalar loop over the atom's exclusions
                             const int st = tb + t;
                             unsigned long long m_excl = __builtin_amdgcn_ballot_w64(js[u] == st);
@@ -1285,7 +1287,7 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
                        pf->d_cell_start, pf->d_cell_members, pf->capc, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s,
                        pf->d_inv_perm, pf->d_flags, which, force, gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr,
                        gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr, gf ? gf->d_lj_s : (double2 *)nullptr,
-                       pf->d_cls, pf->d_cell_start_lj, pf->d_row_order, pf->s_begin, pf->s_end, pf->d_flags + 3);
+                       pf->d_cls, pf->d_cell_start_lj, pf->d_row_order, pf->s_begin, pf->s_end, pf->d_flags + 3, pf->d_member);
     const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
@@ -1304,7 +1306,7 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
                        pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
                        pf->d_excl_idx, cap, nl, nnb, nnb_near, pf->d_flags, pf->d_blockstats, pf->d_counters,      \
-                       pf->d_ticket + 1, which, force)
+                       pf->d_ticket + 1, which, force, pf->d_member ? 1 : 0)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
         else AMM_LAUNCH_BUILD(true, false);
@@ -1774,7 +1776,7 @@ int amm_pair_free(PairForce *pf) {
                     pf->d_cell_start, pf->d_cell_members, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
                     pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near, pf->d_nl_out, pf->d_nnb_out,
                     pf->d_nnb_scratch, pf->d_xref_out, pf->d_ticket, pf->d_tab, pf->d_cls, pf->d_cell_count_lj, pf->d_cell_start_lj,
-                    pf->d_row_order};
+                    pf->d_row_order, pf->d_member};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);

@@ -40,7 +40,7 @@ _NO_ALIAS = os.environ.get('AMM_NO_ALIAS') is not None      # tuning knob (A/B)
 _context_factory = B.HipContext   # the only backend; tests of the host logic substitute a call recorder
 
 
-def custom_long_range_correction(u, sigma, eps, box, rc, rswitch, codes=None):
+def custom_long_range_correction(u, sigma, eps, box, rc, rswitch, codes=None, pairs=None):
     """Long-range correction of a CustomNonbondedForce as OpenMM defines it [recalled; pinned by tests/test_systems.py:39
     (interaction group, met to 2e-8) and tests/test_computers.py:31 (no groups)]: with I(s, e) = int_rc^inf u r^2 dr +
     int_rs^rc (1 - S) u r^2 dr for a pair of mixed parameters (s, e),
@@ -77,35 +77,44 @@ def custom_long_range_correction(u, sigma, eps, box, rc, rswitch, codes=None):
             out += refine(shell) * (rc - rswitch)
         return out
 
-    def classes(members):
-        table = {}
-        for i in members:
-            table[(sigma[i], eps[i])] = table.get((sigma[i], eps[i]), 0) + 1
-        return table
-
-    total = 0.0
-    if codes is not None:
-        for (s1, e1), n1 in classes(np.where(codes == 1.0)[0]).items():
-            for (s2, e2), n2 in classes(np.where(codes == 2.0)[0]).items():
-                s, e = 0.5 * (s1 + s2), math.sqrt(e1 * e2)
-                if e != 0.0 and s > 0.0:
-                    total += n1 * n2 * integral(s, e)
-    else:
-        table = list(classes(range(n)).items())
-        for a, ((s1, e1), n1) in enumerate(table):
-            for (s2, e2), n2 in table[a:]:
-                s, e = 0.5 * (s1 + s2), math.sqrt(e1 * e2)
-                if e != 0.0 and s > 0.0:
-                    total += (n1 * (n1 + 1) / 2 if (s1, e1) == (s2, e2) else n1 * n2) * integral(s, e)
+    if pairs is None:
+        pairs = lrc_class_pairs(sigma, eps, codes)
+    total = sum(weight * integral(s, e) for s, e, weight in pairs)
     return 2.0 * math.pi * n * n / float(np.prod(box)) * total / (n * (n + 1) / 2.0)
 
 
-def softcore_long_range_correction(sigma, eps, codes, box, rc, rswitch, lam):
+def lrc_class_pairs(sigma, eps, codes=None):
+    """[(sigma_ij, eps_ij, number of pairs)] over the classes of equal (sigma, epsilon) -- the part of a long-range
+    correction that depends on the per-particle parameters only (a 250 000-atom system has a handful of classes): the
+    softcore force's correction is re-evaluated at every change of lambda, and twice per deriv(energy, lambda)."""
+    table = np.stack([np.asarray(sigma, dtype=np.float64), np.asarray(eps, dtype=np.float64)], axis=1)
+
+    def classes(members):
+        values, counts = np.unique(table[members], axis=0, return_counts=True)
+        return [(float(s_), float(e_), int(c_)) for (s_, e_), c_ in zip(values, counts)]
+    out = []
+    if codes is not None:
+        for s1, e1, n1 in classes(np.where(np.asarray(codes) == 1.0)[0]):
+            for s2, e2, n2 in classes(np.where(np.asarray(codes) == 2.0)[0]):
+                s, e = 0.5 * (s1 + s2), math.sqrt(e1 * e2)
+                if e != 0.0 and s > 0.0:
+                    out.append((s, e, n1 * n2))
+    else:
+        every = classes(np.arange(len(table)))
+        for a, (s1, e1, n1) in enumerate(every):
+            for s2, e2, n2 in every[a:]:
+                s, e = 0.5 * (s1 + s2), math.sqrt(e1 * e2)
+                if e != 0.0 and s > 0.0:
+                    out.append((s, e, n1 * (n1 + 1) / 2 if (s1, e1) == (s2, e2) else n1 * n2))
+    return out
+
+
+def softcore_long_range_correction(sigma, eps, codes, box, rc, rswitch, lam, pairs=None):
     """SolvationSystem's softcore force (systems.py:266-272): u = 4 lambda eps (1-x)/x^2, x = (r/sigma)^6 + (1-lambda)/2."""
     def u(r, s, e):
         x = (r / s) ** 6 + 0.5 * (1.0 - lam)
         return 4.0 * lam * e * (1.0 - x) / (x * x)
-    return custom_long_range_correction(u, sigma, eps, box, rc, rswitch, codes)
+    return custom_long_range_correction(u, sigma, eps, box, rc, rswitch, codes, pairs)
 
 
 def dispersion_correction(sigma, eps, box, rc, rswitch=None):
@@ -298,6 +307,9 @@ class Engine:
     def _pair_create(self, desc, q, sigma, eps, excl):
         pid = self.ctx.pair_create(desc, q, sigma, eps, excl, skin=self.skin)
         key = np.sort(np.sort(np.asarray(excl, dtype=np.int64).reshape(-1, 2), axis=1), axis=0).tobytes()
+        # interaction-group forces keep a list of their own: it holds the (set 1, set 2) pairs only
+        if desc.family == B.SOFTCORE or desc.flags & (B.GROUP_LJ | B.GROUP_Q):
+            key = ('group', pid)
         self._pair_info[pid] = (float(desc.rc), key)
         return pid
 
@@ -684,11 +696,18 @@ class Engine:
         entry.pair_ids.append(pid)
         use_lrc = force.getUseLongRangeCorrection()
 
+        class_pairs = {}        # the (sigma, eps) classes depend on the offset parameters only, not on lambda
+
         def constant(parameters):
             if not use_lrc:
                 return 0.0
-            p = self._effective(base, scales, names, parameters)
-            value = softcore_long_range_correction(p[:, 1], p[:, 2], codes, self.box, rc, rswitch, parameters[lam_name])
+            key = tuple(parameters[name] for name in names)
+            if key not in class_pairs:
+                p = self._effective(base, scales, names, parameters)
+                class_pairs.clear()
+                class_pairs[key] = (lrc_class_pairs(p[:, 1], p[:, 2], codes), p[:, 1], p[:, 2])
+            pairs, sig_, eps_ = class_pairs[key]
+            value = softcore_long_range_correction(sig_, eps_, codes, self.box, rc, rswitch, parameters[lam_name], pairs)
             return value * (parameters[scale_name] if scale_name else 1.0)
 
         entry.constant = constant(self.parameters)

@@ -68,6 +68,28 @@ def build_simulation(nside, loops, dt_fs, outer_kind='damped', skin=None):
     return simulation, case
 
 
+def build_simulation_c5(loops, dt_fs, afed_substeps=2, skin=None):
+    """Config C5: ~249 000 atoms -- 82 015 flexible TIP3P waters, a 3 000-atom bonded chain with 1-4 exceptions
+    (NonbondedExceptionsForce in group 0) and a 30-atom solute coupled by the AFED extended variable lambda_vdw;
+    AdiabaticDynamicsIntegrator(RespaPropagator(loops).integrator(dt), n) -> one step covers 2 n dt."""
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import openmm, unit
+    from atomsmm_amd.openmm import app
+    from atomsmm_amd.testing import build_c5_system, solvated_chain
+    case = solvated_chain()
+    respa = build_c5_system(case)
+    inner = atomsmm.RespaPropagator(list(loops)).integrator(dt_fs * unit.femtoseconds)
+    variable = atomsmm.ExtendedSystemVariable('lambda_vdw', 50, 2.5, 20 * unit.femtoseconds)
+    integrator = atomsmm.AdiabaticDynamicsIntegrator(inner, afed_substeps, [variable])
+    integrator.setRandomNumberSeed(7)
+    simulation = app.Simulation(app.Topology(len(case['positions'])), respa, integrator, openmm.Platform.getPlatformByName('HIP'),
+                                {'Skin': str(skin)} if skin is not None else None)
+    simulation.context.setPositions(case['positions'] * unit.nanometers)
+    simulation.context.setVelocities(case['velocities'])
+    simulation.context.setParameter('lambda_vdw', 0.6)
+    return simulation, case
+
+
 def temperature(engine, torch):
     out = torch.zeros(1, dtype=torch.float64, device=engine.x.device)
     engine.ctx.mvv(engine.v, engine.mass, out)
@@ -112,6 +134,8 @@ def main():
     ap.add_argument('--nside', type=int, default=32, help='waters per box edge (32 -> 98 304 atoms)')
     ap.add_argument('--outer', choices=['damped', 'pme'], default='damped',
                     help="group-2 force: DampedSmoothedForce (headline, SURVEY 8d C3 i) or the PME NonbondedForce (C3 ii)")
+    ap.add_argument('--config', choices=['c3', 'c5'], default='c3',
+                    help='c3: the headline 98 304-atom TIP3P RESPA box; c5: ~249 000-atom solvated chain, RESPA + exceptions + AFED (2 fs inner step)')
     ap.add_argument('--skin', type=float, default=None, help='Verlet buffer in nm (default: the library default, 0.1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-relax', action='store_true')
@@ -148,7 +172,14 @@ def main():
 
     loops, dt_fs = (4, 2, 1), 4.0
     t_setup = time.perf_counter()
-    simulation, case = build_simulation(args.nside, loops, dt_fs, args.outer, args.skin)
+    if args.config == 'c5':
+        # AFED wraps the RESPA integrator: one integrator step = 2 n = 4 RESPA steps of 2 fs (the chain's bonds are stiff)
+        inner_fs, substeps = 2.0, 2
+        simulation, case = build_simulation_c5(loops, inner_fs, substeps, args.skin)
+        dt_fs = 2 * substeps * inner_fs
+        args.no_cpu_baseline = True
+    else:
+        simulation, case = build_simulation(args.nside, loops, dt_fs, args.outer, args.skin)
     eng = simulation.context._engine
     n = eng.n
     log('system built in %.1f s: %d atoms' % (time.perf_counter() - t_setup, n))
@@ -200,7 +231,7 @@ def main():
         # this same command and commits the summary); quoted only while the kernels are the ones it was measured on
         traffic = {}
         tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', TRAFFIC_FILE)
-        if world == 1 and args.nside == 32 and os.path.exists(tfile):
+        if world == 1 and args.nside == 32 and args.config == 'c3' and os.path.exists(tfile):
             try:
                 stored = json.load(open(tfile))
                 if stored.get('kernel_revision') == backend.kernel_revision():
@@ -228,10 +259,14 @@ def main():
             'value': round(ns_day, 3), 'unit': 'ns/day', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'C3: %d-atom flexible TIP3P box (L = %.3f nm), RESPASystem(0.7, 0.5, force-switch) + '
-                                   '%s outer force, RespaPropagator([4,2,1]), 4 fs outer step'
-                                   % (n, case['box'][0], 'DampedSmoothedForce(2.9/nm, 1.0, 0.9)' if args.outer == 'damped'
-                                      else 'PME NonbondedForce (rc 1.0, switch 0.9, tol 5e-4: direct + reciprocal space)'),
+            'config': {'workload': ('C5: %d atoms (%d TIP3P waters + 3000-atom bonded chain with 1-4 exceptions + 30-atom solute, L = %.3f nm), '
+                                    'SolvationSystem -> RESPASystem(0.7, 0.5) + DampedSmoothedForce outer force, AdiabaticDynamicsIntegrator('
+                                    'RespaPropagator([4,2,1]) at 2 fs, n = 2, lambda_vdw): 8 fs per step' % (n, case['n_waters'], case['box'][0]))
+                       if args.config == 'c5' else
+                       'C3: %d-atom flexible TIP3P box (L = %.3f nm), RESPASystem(0.7, 0.5, force-switch) + '
+                       '%s outer force, RespaPropagator([4,2,1]), 4 fs outer step'
+                       % (n, case['box'][0], 'DampedSmoothedForce(2.9/nm, 1.0, 0.9)' if args.outer == 'damped'
+                          else 'PME NonbondedForce (rc 1.0, switch 0.9, tol 5e-4: direct + reciprocal space)'),
                        'atoms': n, 'loops': list(loops), 'outer_step_fs': dt_fs, 'relax_steps': relaxed,
                        'parallelism': ('atom decomposition x%d, %s' % (world, 'all-gather of owner-computed force slices (RCCL, library-owned communicator)'
                                                                      if getattr(eng, '_native_comm', False) else 'collectives through torch.distributed')) if world > 1 else 'single GPU',
