@@ -175,7 +175,10 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     }
     const int n = ctx->n;
     double Lmin = std::min(ctx->box.L[0], std::min(ctx->box.L[1], ctx->box.L[2]));
-    if (skin < 0) skin = 0.1;
+    // default Verlet buffer: 0.1 nm on one GPU (C3: list build 0.58 x 320 us per step against +30 % pair work at 0.2 nm);
+    // a rank's slice makes the pair kernels 2 - 5 x cheaper but the rebuild only 1.6 - 2 x (scripts/probe_pair.py --world N),
+    // so the optimum moves to a larger buffer: 0.15 nm for 2 ranks, 0.2 nm beyond
+    if (skin < 0) skin = ctx->world >= 4 ? 0.2 : (ctx->world >= 2 ? 0.15 : 0.1);
     skin = std::min(skin, std::max(0.0, 0.5 * Lmin - desc->rc) * 0.999);
     pf->skin = skin;
     pf->rlist = desc->rc + skin;

@@ -39,6 +39,8 @@ def main():
     ap.add_argument('--reps', type=int, default=50)
     ap.add_argument('--skin', type=float, default=-1.0)
     ap.add_argument('--outer', choices=['damped', 'ewald'], default='damped')
+    ap.add_argument('--world', type=int, default=1, help='emulate rank --rank of this many ranks (its slice of the rows, no collectives)')
+    ap.add_argument('--rank', type=int, default=0)
     args = ap.parse_args()
     if args.make_config:
         return make_config(args.out)
@@ -52,7 +54,7 @@ def main():
     else:
         print('warning: no relaxed configuration (%s): timing the lattice start' % CACHE)
     dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device='cuda')   # noqa: E731
-    ctx = B.HipContext(n, c['box'])
+    ctx = B.HipContext(n, c['box'], rank=args.rank, world=args.world)
     dn = B.pair_desc(B.NEAR_FSWITCH, 0.7, rc0=0.7, rs0=0.5)
     if args.outer == 'damped':
         dd = B.pair_desc(B.DAMPED, 1.0, rswitch=0.9, alpha=2.9, degree=1)
@@ -84,6 +86,32 @@ def main():
         cnt, ms = ctx.profile_read(fid)
         ctx.profile_enable(False)
         res[label] = ms / max(cnt, 1) * 1e3
+    # wall time of a whole evaluation (list check + sorted copies + kernel) and of one with a forced list rebuild: a uniform
+    # shift beyond skin / 2 triggers the rebuild and keeps the geometry
+    def wall(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / reps
+
+    def moved(ops):
+        x.add_(1e-7)                  # positions "changed": the displacement check and the sorted copies run again
+        ctx.set_positions_changed() if hasattr(ctx, 'set_positions_changed') else None
+        ctx.run_ops(ops, 1)
+
+    def rebuilt(ops):
+        x.add_(0.06)
+        ctx.run_ops(ops, 1)
+    w_near = wall(lambda: ctx.run_ops(near_only, 1))
+    w_dual = wall(lambda: ctx.run_ops(dual, 1))
+    w_rebuild = wall(lambda: rebuilt(near_only))
+    print('   world %d rank %d: evaluation wall time near %.1f us, dual %.1f us; with a list rebuild %.1f us (rebuild alone ~%.1f us)' % (
+        args.world, args.rank, w_near, w_dual, w_rebuild, w_rebuild - w_near))
     st = ctx.pair_stats(ff)
     print('lib=%s  near %.1f us  far %.1f us  dual %.1f us   (list pairs near/far: %d / %d, lanes/atom %d)' % (
         os.path.basename(os.environ.get('AMM_LIB', 'product')), res['near'], res['far'], res['dual'],

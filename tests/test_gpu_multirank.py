@@ -265,3 +265,90 @@ def test_exchange_with_empty_slices_on_a_tiny_box():
         assert torch.equal(f, fref)
         ctx.close()
     ref.close()
+
+
+def test_c3_size_eight_slices_all_gather_bit_identical(monkeypatch):
+    """Config C4 of BASELINE.json at full size, emulated on one GPU: eight contexts stand for the ranks of a world of 8 over
+    the 98 304-atom TIP3P box (slices of 12 288 cell-sorted slots, 16 lanes per atom, rows traversed in each slice's own
+    row_order).  Each 'rank' runs the dual pass (near + outer force) on its slice into its chunk of the exchange buffer, the
+    chunks are copied as an all-gather would, amm_exchange_finish unsorts them: every rank then holds the single-context
+    forces bit for bit -- before and after a displacement that makes every rank rebuild its part of the list.  (A rank's
+    slice is walked with 16 lanes per atom, the whole box on one GPU with 8: the single-context reference is pinned to 16
+    as well, since the number of partial sums per row fixes the summation order; against the 8-lane walk the forces agree
+    to 1e-12 of the largest, checked too.)"""
+    monkeypatch.setenv('AMM_LPA', '16')
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from atomsmm_amd import backend as B
+    from atomsmm_amd.testing import tip3p_box
+    from test_gpu_abi_parity import near, hip_pair, dev, O
+    c = tip3p_box(32)
+    n = len(c['positions'])
+    assert n == 98304
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+    world = 8
+    per = (n + world - 1) // world
+    E = B.OP_EVAL
+    dual = [B.Op(E, 1, 0, 0, 0.0), B.Op(E, 2, 0, 0, 0.0)]
+
+    def make(rank, w):
+        ctx = B.HipContext(n, c['box'], rank=rank, world=w)
+        fn = hip_pair(B, ctx, dn, c)
+        ff = hip_pair(B, ctx, dd, c)
+        ctx.pair_share_list(fn, ff)
+        x, v, m = dev(c['positions']), dev(c['velocities']), dev(c['mass'])
+        f = [torch.zeros((n, 3), dtype=torch.float64, device='cuda') for _ in range(3)]
+        ctx.bind_state(x, v, m)
+        for slot, buf in enumerate(f):
+            ctx.bind_buffer(slot, buf)
+        ctx.group_define(1, 1, [fn])
+        ctx.group_define(2, 2, [ff])
+        return ctx, f, x, (v, m), ff
+
+    ref, fref, xref, keep_ref, ff_ref = make(0, 1)
+    monkeypatch.delenv('AMM_LPA')
+    ref8, fref8, xref8, keep_ref8, ff_ref8 = make(0, 1)           # the product's single-GPU walk: 8 lanes per atom
+    ref8.run_ops(dual, 1)
+    ref8.check()
+    assert ref8.pair_stats(ff_ref8)['lanes_per_atom'] == 8
+    monkeypatch.setenv('AMM_LPA', '16')
+    ranks = []
+    for r in range(world):
+        ctx, f, x, keep, ff = make(r, world)
+        xchg = torch.full((world * 2 * per * 3,), float('nan'), dtype=torch.float64, device='cuda')
+        ctx.bind_exchange(xchg)
+        ctx.group_set_exchange(1, B.EXCHANGE_GATHER)
+        ctx.group_set_exchange(2, B.EXCHANGE_GATHER)
+        ranks.append((ctx, f, xchg, x, keep, ff))
+    chunk = 2 * per * 3
+    rng = np.random.default_rng(3)
+    shift = torch.as_tensor(rng.normal(0.0, 0.04, (n, 3)), device='cuda')        # beyond skin / 2 for many atoms: rebuild
+    for stage in range(2):
+        ref.run_ops(dual, 1)
+        ref.check()
+        for ctx, f, xchg, x, keep, ff in ranks:
+            ctx.run_ops(dual, 1)
+        for r, (ctx, f, xchg, x, keep, ff) in enumerate(ranks):                # the all-gather, by hand
+            for q, other in enumerate(ranks):
+                if q != r:
+                    xchg[q * chunk:(q + 1) * chunk].copy_(other[2][q * chunk:(q + 1) * chunk])
+        slices = 0
+        for ctx, f, xchg, x, keep, ff in ranks:
+            ctx.exchange_finish()
+            ctx.check()
+            assert torch.equal(f[1], fref[1]) and torch.equal(f[2], fref[2])
+            st = ctx.pair_stats(ff)
+            assert st['lanes_per_atom'] == 16 and st['n_builds'] == stage + 1
+            slices += st['n_slice_atoms']
+        assert slices == n and ref.pair_stats(ff_ref)['n_builds'] == stage + 1
+        if stage == 0:
+            for k in (1, 2):
+                assert (fref[k] - fref8[k]).abs().max() <= 1e-12 * fref8[k].abs().max()
+            ref8.close()
+        xref.add_(shift)
+        for ctx, f, xchg, x, keep, ff in ranks:
+            x.add_(shift)
+    for ctx, f, xchg, x, keep, ff in ranks:
+        ctx.close()
+    ref.close()
