@@ -181,7 +181,10 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     if (skin < 0) skin = ctx->world >= 4 ? 0.2 : (ctx->world >= 2 ? 0.15 : 0.1);
     skin = std::min(skin, std::max(0.0, 0.5 * Lmin - desc->rc) * 0.999);
     pf->skin = skin;
-    pf->rlist = desc->rc + skin;
+    // a force guarded by step(rc0 - r) (the discount of FarNonbondedForce, forces.py:714; group 31 of RESPASystem) vanishes
+    // beyond rc0 whatever its nominal cutoff: its list needs to reach rc0 only
+    const double reach = ((desc->flags & AMM_GUARD_RC0) && desc->rc0 > 0.0) ? std::min(desc->rc, desc->rc0) : desc->rc;
+    pf->rlist = reach + skin;
     pf->rlist_build = pf->rlist + 2e-4;   // fp32 build: positions carry ~1e-6 nm rounding, superset is harmless
     // outer buffer: large enough that the cell-based build is rare (hydrogens consume 0.05 nm in ~2 outer steps)
     // default: single list (skin_out = skin).  Measured at C3: the prune pass costs about as much as a cell build
@@ -189,7 +192,7 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     double skin_out = ctx->skin_out > 0 ? ctx->skin_out : skin;
     skin_out = std::max(skin, std::min(skin_out, std::max(0.0, 0.5 * Lmin - desc->rc) * 0.999));
     pf->skin_out = skin_out;
-    pf->rlist_out_build = desc->rc + skin_out + 2e-4;
+    pf->rlist_out_build = reach + skin_out + 2e-4;
     if (amm_pair_setup_grid(ctx, pf)) {
         delete pf;
         return 1;
@@ -376,9 +379,9 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
     for (int i = 0; i < n; ++i) cls[i] = h_eps[i] == 0.0 ? 1 : 0;
     AMM_HIP(hipMemcpy(pf->d_cls, cls.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     // dual evaluation needs bitwise equal parameters on guest and host: re-check after any change
-    pf->dual_ok = -1;
+    pf->dual_ok = pf->fuse_ok = -1;
     for (auto &fo : ctx->forces)
-        if (fo.type == 1 && fo.pair->host == pf) fo.pair->dual_ok = -1;
+        if (fo.type == 1 && fo.pair->host == pf) fo.pair->dual_ok = fo.pair->fuse_ok = -1;
     return 0;
 }
 
@@ -929,8 +932,40 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     if (exchange_left_to_host(ctx, rep == repeat - 1 && k == n_ops - 1)) return 1;
                     break;
                 }
-                for (size_t j = 0; j < g.forces.size(); ++j)
-                    if (force_eval_dispatch(ctx, g.forces[j], ctx->d_x, buf, j > 0, nullptr)) return 1;
+                // FarNonbondedForce (forces.py:710-724) = total + discount, two forces of one group: when the discount
+                // (guarded near force, sign -1) shares the total's neighbour list, both are evaluated in ONE traversal that
+                // accumulates into the same buffer (the reference, and OpenMM, run two passes)
+                std::vector<char> done(g.forces.size(), 0);
+                bool first = true;
+                for (size_t j = 0; j < g.forces.size(); ++j) {
+                    if (done[j]) continue;
+                    ForceObj &fj = ctx->forces[g.forces[j]];
+                    if (fj.type == 1) {
+                        size_t partner = g.forces.size();
+                        for (size_t i = 0; i < g.forces.size() && partner == g.forces.size(); ++i)
+                            if (i != j && !done[i] && ctx->forces[g.forces[i]].type == 1 &&
+                                amm_pair_can_fuse_discount(ctx, ctx->forces[g.forces[i]].pair, fj.pair)) partner = i;
+                        if (partner < g.forces.size()) {
+                            if (amm_pair_eval_impl(ctx, fj.pair, ctx->d_x, buf, first ? 0 : 1, nullptr, ctx->forces[g.forces[partner]].pair, buf, 1, 0)) return 1;
+                            done[j] = done[partner] = 1;
+                            first = false;
+                            continue;
+                        }
+                        // the discount itself comes later in the list: let its host pick it up
+                        bool is_discount = false;
+                        for (size_t i = 0; i < g.forces.size(); ++i)
+                            if (i != j && !done[i] && ctx->forces[g.forces[i]].type == 1 && amm_pair_can_fuse_discount(ctx, fj.pair, ctx->forces[g.forces[i]].pair)) is_discount = true;
+                        if (is_discount) continue;
+                    }
+                    if (force_eval_dispatch(ctx, g.forces[j], ctx->d_x, buf, first ? 0 : 1, nullptr)) return 1;
+                    done[j] = 1;
+                    first = false;
+                }
+                for (size_t j = 0; j < g.forces.size(); ++j)      // (a discount whose host was consumed by another pairing)
+                    if (!done[j]) {
+                        if (force_eval_dispatch(ctx, g.forces[j], ctx->d_x, buf, first ? 0 : 1, nullptr)) return 1;
+                        first = false;
+                    }
             } break;
             case AMM_OP_KICK: {
                 double *fa = (op.a >= 0 && op.a < AMM_MAX_SLOTS) ? ctx->slots[op.a] : nullptr;

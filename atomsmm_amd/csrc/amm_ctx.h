@@ -84,6 +84,7 @@ struct PairForce {
     int cap_out = 0;
     bool dual = false;             // outer list + prune (skin_out > skin) or a single list built from the cells
     PairForce *host = nullptr;     // owner of the neighbour list this force traverses (nullptr: its own)
+    int fuse_ok = -1;              // cached amm_pair_can_fuse_discount(this, host) (reset by set_params)
     int dual_ok = -1;              // cached amm_pair_can_eval_dual(this, host): -1 unknown, 0 no, 1 yes (reset by set_params)
     double rnear_build = 0;        // list radius of the guest force sharing this list (front part of each row)
     int *d_flags = nullptr;        // [0] need prune [1] overflow [2] max inner row [4] need outer build [5] max outer row
@@ -224,6 +225,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
                        double *d_energy, PairForce *guest = nullptr, double *g_force = nullptr, int g_accumulate = 0,
                        int exchange = 0);
 bool amm_pair_can_eval_dual(amm_ctx *ctx, PairForce *guest, PairForce *host);
+bool amm_pair_can_fuse_discount(amm_ctx *ctx, PairForce *guest, PairForce *host);
 int amm_pair_free(PairForce *pf);
 int amm_pair_build_table(PairForce *pf);
 int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double r_within, long long *count);

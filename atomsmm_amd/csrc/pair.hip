@@ -698,6 +698,7 @@ struct PairArgs {
     double *gforce;    // dual evaluation: force buffer of the guest force that shares this list (same particles)
     int gaccumulate;
     int sorted_out;    // exchange by all-gather: rows go to force[3 (s - s_begin)] (this rank's chunk of the exchange buffer)
+    int gsame;         // the guest accumulates into the SAME rows as the host (fused FarNonbondedForce): one store of the sum
 };
 
 
@@ -983,7 +984,7 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
             fz += fr * dz;
             if (GFAM >= 0) {
                 if (guest_trip) {
-                    frg = (gpass && !glow) ? frg : 0.0;
+                    frg = (gpass && !glow) ? frg * gc.sign : 0.0;     // the table and amm_lj_force carry no sign (the discount: -1)
                     gx += frg * dx;
                     gy += frg * dy;
                     gz += frg * dz;
@@ -1128,7 +1129,11 @@ __global__ void __launch_bounds__(BS) k_pair_tab(PairArgs A, PairConsts c, PairC
         if (valid && sub == 0) {
             const int i = A.sorted_out ? s - A.s_begin : A.perm[s];
             if (GFAM >= 0) {
-                if (A.gaccumulate) {
+                if (A.gsame) {             // fused total + discount: one row, one store
+                    fx += gx;
+                    fy += gy;
+                    fz += gz;
+                } else if (A.gaccumulate) {
                     A.gforce[3 * i] += gx;
                     A.gforce[3 * i + 1] += gy;
                     A.gforce[3 * i + 2] += gz;
@@ -1540,6 +1545,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         A.box = ctx->box;
         A.gforce = gout;
         A.gaccumulate = g_accumulate;
+        A.gsame = (guest && g_force == d_force && !exchange) ? 1 : 0;
         A.sorted_out = exchange ? 1 : 0;
         const long threads = (long)nslice << A.lpa_shift;
         const int nblk = (int)((threads + 255) / 256);
@@ -1573,7 +1579,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         }
         // force-only, unguarded, ungrouped evaluations of the tabulated families: the kernel of pair_tab.h
         const bool tab_ok = use_tab && !en && !guard && !(pf->pc.flags & (AMM_GROUP_LJ | AMM_GROUP_Q)) && pf->pc.tab.nint > 0 && pf->d_tab &&
-                            pf->pc.sign == 1.0 && (!guest || (guest->pc.tab.nint > 0 && guest->d_tab && guest->pc.sign == 1.0));
+                            pf->pc.sign == 1.0 && (!guest || (guest->pc.tab.nint > 0 && guest->d_tab));
         if (tab_ok) {
             TabArgs T;
             T.host_tab = pf->d_tab;
@@ -1587,7 +1593,8 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             T.nslice = nslice;
             T.ntask = (int)((threads + 63) / 64);
             const int gfam = guest ? guest->desc.family : -1;
-            const PairConsts &gpc = guest ? guest->pc : pf->pc;
+            PairConsts gpc = guest ? guest->pc : pf->pc;
+            if (guest && (guest->desc.flags & AMM_GUARD_RC0)) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);   // step(rc0 - r)
             int rc_ = 0;
             switch (pf->desc.family) {
             case AMM_NEAR_NONE: rc_ = launch_pair_tab<AMM_NEAR_NONE, 0>(st, gfam, A, pf->pc, gpc, T); break;
@@ -1605,6 +1612,10 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             if (rc_) return 1;
             if (guest) guest->n_evals++;
         } else if (guest) {
+            if (A.gsame || (guest->desc.flags & AMM_GUARD_RC0) || guest->pc.sign != 1.0) {
+                amm_set_error("dual evaluation of a guarded / signed guest needs the tabulated kernel (AMM_TAB=0?)");
+                return 1;
+            }
             int rc_ = 0;
             // DAMPED: CMODE 1 = the degree-1 specialisation (built-in switch in r: no power loop, no int -> double per pair)
             if (pf->desc.family == AMM_DAMPED && pf->pc.degree == 1) rc_ = launch_pair_dual<AMM_DAMPED, 1>(grid, block, st, guest->desc.family, A, pf->pc, guest->pc);
@@ -1769,6 +1780,35 @@ int amm_pair_build_table(PairForce *pf) {
         AMM_HIP(hipMemcpy(pf->d_tab, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
     }
     return 0;
+}
+
+// Can `guest` -- a guarded near force such as the discount of FarNonbondedForce -- ride on the pass of its list owner
+// `host`, accumulating into the same buffer?  As amm_pair_can_eval_dual, with the guard allowed (it becomes the guest's
+// cutoff) and any sign; needs the tabulated kernel on both.
+bool amm_pair_can_fuse_discount(amm_ctx *ctx, PairForce *guest, PairForce *host) {
+    if (!guest || !host || guest->host != host || host->host) return false;
+    if (!(guest->desc.flags & AMM_GUARD_RC0)) return false;
+    if (guest->fuse_ok >= 0) return guest->fuse_ok == 1;
+    guest->fuse_ok = 0;
+    const char *e = getenv("AMM_TAB");
+    if (e && atoi(e) == 0) return false;
+    const int gf = guest->desc.family, hf = host->desc.family;
+    if (!(gf == AMM_NEAR_NONE || gf == AMM_NEAR_SHIFT || gf == AMM_NEAR_FSWITCH)) return false;
+    if (!(hf == AMM_DAMPED || hf == AMM_NONBONDED)) return false;
+    if ((host->desc.flags & AMM_GUARD_RC0) || host->pc.sign != 1.0) return false;
+    if ((guest->desc.flags | host->desc.flags) & (AMM_GROUP_LJ | AMM_GROUP_Q)) return false;
+    if (!(guest->pc.tab.nint > 0 && guest->d_tab && host->pc.tab.nint > 0 && host->d_tab)) return false;
+    if (guest->pc.Kc != host->pc.Kc) return false;
+    const size_t n = (size_t)ctx->n;
+    std::vector<double> a(n), b(n);
+    const double *ga[3] = {guest->d_q, guest->d_hsig, guest->d_seps2}, *ha[3] = {host->d_q, host->d_hsig, host->d_seps2};
+    for (int k = 0; k < 3; ++k) {
+        if (hipMemcpy(a.data(), ga[k], sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (hipMemcpy(b.data(), ha[k], sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (std::memcmp(a.data(), b.data(), sizeof(double) * n) != 0) return false;
+    }
+    guest->fuse_ok = 1;
+    return true;
 }
 
 int amm_pair_free(PairForce *pf) {

@@ -310,7 +310,10 @@ class Engine:
         # interaction-group forces keep a list of their own: it holds the (set 1, set 2) pairs only
         if desc.family == B.SOFTCORE or desc.flags & (B.GROUP_LJ | B.GROUP_Q):
             key = ('group', pid)
-        self._pair_info[pid] = (float(desc.rc), key)
+        # a force guarded by step(rc0 - r) reaches rc0 only (the discount of FarNonbondedForce): it can then walk the front part
+        # of the total force's rows, and be evaluated on the total's pass
+        reach = min(float(desc.rc), float(desc.rc0)) if (desc.flags & B.GUARD_RC0 and desc.rc0 > 0) else float(desc.rc)
+        self._pair_info[pid] = (reach, key)
         return pid
 
     def _share_lists(self):

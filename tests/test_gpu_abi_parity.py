@@ -370,11 +370,12 @@ def test_atom_decomposition_slices_sum_to_full(spcfw):
     d = near('force-switch', 0.7, 0.5)
     pos = dev(c['positions'])
     ctx = B.HipContext(n, c['box'])
-    e_full, f_full = eval_force(ctx, hip_pair(B, ctx, d, c), pos, n)
+    # the same Verlet buffer on both sides (its default grows with the number of ranks): same rows, same summation order
+    e_full, f_full = eval_force(ctx, hip_pair(B, ctx, d, c, skin=0.1), pos, n)
     parts, es = [], []
     for r in range(2):
         cr = B.HipContext(n, c['box'], rank=r, world=2)
-        e, f = eval_force(cr, hip_pair(B, cr, d, c), pos, n)
+        e, f = eval_force(cr, hip_pair(B, cr, d, c, skin=0.1), pos, n)
         parts.append(f); es.append(e)
         assert cr.pair_stats(0)['n_slice_atoms'] == n // 2
         cr.close()

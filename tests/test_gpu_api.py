@@ -175,6 +175,37 @@ def test_far_plus_near_equals_total(spcfw, method):
         assert potential / potential.unit == pytest.approx(refpot / refpot.unit)
 
 
+@pytest.mark.parametrize('method', ['CutoffPeriodic', 'PME'])
+def test_far_force_is_one_traversal(spcfw, method):
+    """FarNonbondedForce = total + discount (forces.py:710-724): the reference -- and OpenMM -- run two passes; here the
+    discount (a near force guarded by step(rc0 - r), sign -1) shares the total's neighbour list and is evaluated ON the
+    total's pass, accumulating into the same force rows.  One kernel launch under the total's id, none under the
+    discount's, and the same forces as the separate (energy-carrying, analytic) evaluations of the two."""
+    system, positions, topology = create_system(spcfw, nonbondedMethod=method, flexible=False)
+    nbforce = atomsmm.hijackForce(system, atomsmm.findNonbondedForce(system))
+    inner = atomsmm.NearNonbondedForce(7.0 * unit.angstroms, 6.5 * unit.angstroms, 'force-switch')
+    inner.importFrom(nbforce).addTo(system)
+    outer = atomsmm.FarNonbondedForce(inner, 10 * unit.angstroms, 9.5 * unit.angstroms).setForceGroup(2)
+    outer.importFrom(nbforce).addTo(system)
+    integrator = openmm.CustomIntegrator(0.001)
+    integrator.addComputePerDof('v', 'v + dt*f2/m')          # a force-only evaluation of group 2
+    context = openmm.Context(system, integrator)
+    context.setPositions(positions)
+    eng = context._engine
+    ids = eng.pair_force_ids(2)
+    assert len(ids) == 2
+    total, discount = ids
+    eng.ctx.profile_enable(True)
+    integrator.step(1)
+    launches = {pid: eng.ctx.profile_read(pid)[0] for pid in ids}
+    eng.ctx.profile_enable(False)
+    assert launches == {total: 1, discount: 0}
+    assert eng.ctx.pair_stats(discount)['shares_list'] == 1 and eng.ctx.pair_stats(discount)['n_evals'] == 1
+    fused = eng._buffers['f2'].cpu().numpy().copy()
+    separate = context.getState(getForces=True, groups={2}).getForces(asNumpy=True)._value
+    assert np.abs(fused - separate).max() <= 1e-11 * np.abs(separate).max()
+
+
 def test_forces_from_getState_match_oracle(spcfw):
     c = spcfw
     system, positions, topology = create_system(c, nonbondedMethod='CutoffPeriodic', switch=0.9)
