@@ -577,7 +577,28 @@ int amm_bath_define(amm_ctx *ctx, double z, double kT, int32_t *bath_id) {
         amm_set_error("amm_bath_define: need 0 <= z <= 1 and kT >= 0");
         return 1;
     }
-    ctx->baths.push_back(BathDef{z, kT});
+    BathDef b;
+    b.z = z;
+    b.kT = kT;
+    ctx->baths.push_back(b);
+    *bath_id = (int32_t)ctx->baths.size() - 1;
+    return 0;
+}
+
+int amm_bath_define_nhl(amm_ctx *ctx, double h, double z, double kT, double Q, double friction, int32_t slot, int32_t *bath_id) {
+    if (!ctx || !bath_id || !(z >= 0.0 && z <= 1.0) || !(kT >= 0.0) || !(Q > 0.0) || !(friction > 0.0) || slot < 0 || slot >= AMM_SLOT_X) {
+        amm_set_error("amm_bath_define_nhl: need 0 <= z <= 1, kT >= 0, Q > 0, friction > 0 and a per-DOF buffer slot");
+        return 1;
+    }
+    BathDef b;
+    b.z = z;
+    b.kT = kT;
+    b.kind = 1;
+    b.h = h;
+    b.Q = Q;
+    b.friction = friction;
+    b.slot = slot;
+    ctx->baths.push_back(b);
     *bath_id = (int32_t)ctx->baths.size() - 1;
     return 0;
 }

@@ -157,8 +157,14 @@ struct ExprDef {
 };
 
 // native bath step of Langevin-type integrators: v <- z v + sqrt(kT (1 - z^2) / m) * gaussian  (propagators.py:727-741)
+// kind 1 (Nose-Hoover-Langevin, NHL_R_Integrator: propagators.py:1362-1449 as MassiveNoseHooverLangevin emits it): the
+// three per-DOF steps  v <- v exp(-h w) ; w <- z w + sqrt(kT (1 - z^2)/Q) gaussian + (m v^2 - kT)(1 - z)/(Q friction) ;
+// v <- v exp(-h w)  with the thermostat velocity w of each DOF in the per-DOF buffer `slot`.
 struct BathDef {
     double z, kT;
+    int kind = 0;                  // 0 Ornstein-Uhlenbeck, 1 Nose-Hoover-Langevin
+    double h = 0, Q = 0, friction = 0;
+    int slot = -1;
 };
 
 struct GroupDef {

@@ -305,6 +305,9 @@ struct CompArgs {
     double c1, d, c2;
     // BATH: kick ; move(d) ; Ornstein-Uhlenbeck step ; move(d2) ; forces ; kick  (Langevin_R 'middle' scheme)
     double d2, bath_z, bath_kT;
+    int bath_kind;                  // 0 Ornstein-Uhlenbeck, 1 Nose-Hoover-Langevin (thermostat velocities in bath_w)
+    double bath_h, bath_Q, bath_friction;
+    double *bath_w;
     unsigned long long seed, counter0;
     PreKick pre[AMM_MAX_PRE];
     // displacement watchers: neighbour lists whose rebuild trigger this kernel evaluates for the positions it
@@ -347,6 +350,13 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
         x[j] = C.x[3 * a + j];
         v[j] = C.v[3 * a + j];
         f[j] = C.f0[3 * a + j];
+    }
+    double w[3] = {0.0, 0.0, 0.0};       // thermostat velocities of a Nose-Hoover-Langevin bath
+    if (BATH) {
+        if (C.bath_kind == 1) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) w[j] = C.bath_w[3 * a + j];
+        }
     }
     const double rm = 1.0 / m;
     const bool rok = (__double_as_longlong(m) & 0xFFFFFFFFFFFFFll) != 0xFFFFFFFFFFFFFll && m > 1e-200 && m < 1e200;
@@ -414,7 +424,11 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
             // the same amm_ou_step / random stream as a separate AMM_OP_BATH launch of this iteration would use
             const unsigned long long counter = (1ull << 63) | (C.counter0 + (unsigned long long)it + 1ull);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) v[j] = amm_ou_step(v[j], m, C.bath_z, C.bath_kT, amm_gaussian(C.seed, counter, (unsigned)(3 * a + j)));
+            for (int j = 0; j < 3; ++j) {
+                const double g = amm_gaussian(C.seed, counter, (unsigned)(3 * a + j));
+                if (C.bath_kind == 1) amm_nhl_step(v[j], w[j], m, C.bath_h, C.bath_z, C.bath_kT, C.bath_Q, C.bath_friction, g);
+                else v[j] = amm_ou_step(v[j], m, C.bath_z, C.bath_kT, g);
+            }
             {
 #pragma clang fp contract(off)
 #pragma unroll
@@ -507,9 +521,15 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
             C.v[3 * a + j] = v[j];
             C.f0[3 * a + j] = f[j];
         }
-        for (int w = 0; w < C.nwatch; ++w) {
-            const double dx = x[0] - C.wref[w][3 * a], dy = x[1] - C.wref[w][3 * a + 1], dz = x[2] - C.wref[w][3 * a + 2];
-            if (!(dx * dx + dy * dy + dz * dz <= C.wthr2[w])) C.wflags[w][0] = 1;   // benign race (NaN also triggers)
+        if (BATH) {
+            if (C.bath_kind == 1) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) C.bath_w[3 * a + j] = w[j];
+            }
+        }
+        for (int q = 0; q < C.nwatch; ++q) {
+            const double dx = x[0] - C.wref[q][3 * a], dy = x[1] - C.wref[q][3 * a + 1], dz = x[2] - C.wref[q][3 * a + 2];
+            if (!(dx * dx + dy * dy + dz * dz <= C.wthr2[q])) C.wflags[q][0] = 1;   // benign race (NaN also triggers)
         }
     }
 }
@@ -801,6 +821,15 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     C.d2 = d2;
     C.bath_z = bath ? bath->z : 1.0;
     C.bath_kT = bath ? bath->kT : 0.0;
+    C.bath_kind = bath ? bath->kind : 0;
+    C.bath_h = bath ? bath->h : 0.0;
+    C.bath_Q = bath ? bath->Q : 1.0;
+    C.bath_friction = bath ? bath->friction : 1.0;
+    C.bath_w = (bath && bath->kind == 1 && bath->slot >= 0 && bath->slot < AMM_MAX_SLOTS) ? ctx->slots[bath->slot] : nullptr;
+    if (bath && bath->kind == 1 && !C.bath_w) {
+        amm_set_error("Nose-Hoover-Langevin bath: the thermostat-velocity buffer is not bound");
+        return 1;
+    }
     C.seed = ctx->expr_seed;
     C.counter0 = ctx->expr_counter;
     static const bool no_terms = getenv("AMM_NO_TERM_LANES") != nullptr;     // tuning knob (A/B)

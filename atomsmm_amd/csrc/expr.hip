@@ -98,8 +98,28 @@ __global__ void k_bath_ou(int n3, double *v, const double *__restrict__ mass, do
     v[dof] = amm_ou_step(v[dof], mass[dof / 3], z, kT, amm_gaussian(seed, counter, (unsigned)dof));
 }
 
+__global__ void k_bath_nhl(int n3, double *v, double *w, const double *__restrict__ mass, BathDef b, unsigned long long seed,
+                           unsigned long long counter) {
+    const int dof = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dof >= n3) return;
+    double vv = v[dof], ww = w[dof];
+    amm_nhl_step(vv, ww, mass[dof / 3], b.h, b.z, b.kT, b.Q, b.friction, amm_gaussian(seed, counter, (unsigned)dof));
+    v[dof] = vv;
+    w[dof] = ww;
+}
+
 int amm_bath_impl(amm_ctx *ctx, const BathDef &bath, double *d_v, unsigned long long counter) {
     const int n3 = 3 * ctx->n;
+    if (bath.kind == 1) {
+        double *w = (bath.slot >= 0 && bath.slot < AMM_MAX_SLOTS) ? ctx->slots[bath.slot] : nullptr;
+        if (!w) {
+            amm_set_error("Nose-Hoover-Langevin bath: the thermostat-velocity buffer is not bound");
+            return 1;
+        }
+        hipLaunchKernelGGL(k_bath_nhl, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_v, w, ctx->d_mass, bath, ctx->expr_seed, counter);
+        AMM_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_bath_ou, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_v, ctx->d_mass, bath.z, bath.kT,
                        ctx->expr_seed, counter);
     AMM_HIP(hipGetLastError());

@@ -72,6 +72,19 @@ __device__ __forceinline__ double amm_ou_step(double v, double m, double z, doub
     return zv + noise;
 }
 
+// Nose-Hoover-Langevin step of one DOF, in the operation order of the reference's three expressions
+// (`v*exp(-(h)*v2)`, `z*v2 + sqrt(kT*(1 - z*z)/mass)*gaussian + force*(1 - z)/(mass*friction)` with force = m*v^2 - kT and
+// mass = Q2, then the scaling again): shared by the stand-alone kernel and the inner-loop kernel
+__device__ __forceinline__ void amm_nhl_step(double &v, double &w, double m, double h, double z, double kT, double Q, double friction,
+                                             double g) {
+#pragma clang fp contract(off)
+    v = v * exp(-h * w);
+    const double force = m * v * v - kT;
+    const double amp = sqrt(kT * (1.0 - z * z) / Q);
+    w = z * w + amp * g + force * (1.0 - z) / (Q * friction);
+    v = v * exp(-h * w);
+}
+
 // one copy per kernel, called (not inlined): the interpreter is ~2 k instructions
 static __device__ __noinline__ double expr_run(const ExprProg &P, int dof) {
     double st[AMM_EXPR_STACK], loc[AMM_EXPR_LOCALS];

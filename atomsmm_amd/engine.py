@@ -1071,6 +1071,10 @@ class Engine:
                         raise NotImplementedError('step programs that change Context parameters (%s) are not supported' % target)
                 env[target] = value
             elif kind == C.ComputePerDof:
+                skip = self._emit_native_bath_block(steps, pc, env, ops)
+                if skip:
+                    pc += skip
+                    continue
                 self._emit_per_dof(target, expr, env, ops, valid)
             elif kind == C.ComputeSum:
                 raise NotImplementedError('ComputeSum steps (thermostat propagators) are outside this round\'s scope')
@@ -1088,6 +1092,36 @@ class Engine:
         self._static_exprs = False
         finals = {name: env[name] for name in integ._gnames}
         return self._drop_dead_copies(self._pair_up_evals(ops)), valid, finals, dict(self._mirror_work)
+
+    _NHL_SCALE = re.compile(r'v\*exp\(-\((.+)\*dt\)\*(\w+)\)')
+    _NHL_UPDATE = re.compile(r'z\*(\w+)\+sqrt\(kT\*\(1-z\*z\)/mass\)\*gaussian\+force\*\(1-z\)/\(mass\*friction\);force=m\*v\^2-kT;'
+                             r'mass=(\w+);z=exp\(-\((.+)\*dt\)\*friction\)')
+
+    def _emit_native_bath_block(self, steps, pc, env, ops):
+        """The three per-DOF steps of a Nose-Hoover-Langevin bath (NHL_R_Integrator, integrators.py:272-330:
+        `v <- v*exp(-(h*dt)*v2)` ; `v2 <- z*v2 + sqrt(kT*(1 - z*z)/mass)*gaussian + force*(1 - z)/(mass*friction); ...` ;
+        `v <- v*exp(-(h*dt)*v2)`) become ONE native bath op, which the inner-loop kernel carries between its two half moves
+        like the Ornstein-Uhlenbeck step of Langevin_R.  Returns the number of program steps consumed (0: not such a block)."""
+        C = mm.CustomIntegrator
+        if pc + 2 >= len(steps) or any(steps[pc + k][0] != C.ComputePerDof for k in range(3)):
+            return 0
+        (_, t0, e0), (_, t1, e1), (_, t2, e2) = steps[pc:pc + 3]
+        a, b, c = self._NHL_SCALE.fullmatch(e0.replace(' ', '')), self._NHL_UPDATE.fullmatch(e1.replace(' ', '')), \
+            self._NHL_SCALE.fullmatch(e2.replace(' ', ''))
+        if not (a and b and c and t0 == 'v' and t2 == 'v' and e0 == e2):
+            return 0
+        w = a.group(2)
+        if not (t1 == w and b.group(1) == w and w in self.integrator._pnames and b.group(2) in env and 'kT' in env and 'friction' in env):
+            return 0
+        h = self._eval(a.group(1), env) * env['dt']
+        z = math.exp(-(self._eval(b.group(3), env) * env['dt']) * env['friction'])
+        key = ('nhl', h, z, float(env['kT']), float(env[b.group(2)]), float(env['friction']), w)
+        if key not in self._expr_ids:
+            self._expr_ids[key] = self.ctx.bath_define_nhl(h, z, float(env['kT']), float(env[b.group(2)]), float(env['friction']),
+                                                           self._slot(w))
+        ops.append(B.Op(B.OP_BATH, self._expr_ids[key], B.SLOT_V, 0, 0.0))
+        self._mirror_work.pop(w, None)
+        return 3
 
     def _pair_up_evals(self, ops):
         """RESPA evaluates the near force (group 1) and, one kick later, the outer force (group 2) at the same positions

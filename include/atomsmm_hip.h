@@ -235,6 +235,11 @@ int amm_expr_define(amm_ctx *ctx, const int32_t *code, int32_t n_code, const dou
 int amm_expr_seed(amm_ctx *ctx, uint64_t seed);
 /* z = exp(-gamma * fraction * dt), kT in kJ/mol: the constants of one Ornstein-Uhlenbeck bath step for AMM_OP_BATH. */
 int amm_bath_define(amm_ctx *ctx, double z, double kT, int32_t *bath_id);
+/* The Nose-Hoover-Langevin bath block of NHL_R_Integrator (integrators.py:272-330; MassiveNoseHooverLangevinPropagator,
+ * propagators.py:1362-1449) as ONE AMM_OP_BATH: v <- v exp(-h w) ; w <- z w + sqrt(kT (1 - z^2)/Q) gaussian +
+ * (m v^2 - kT)(1 - z)/(Q friction) ; v <- v exp(-h w), with the per-DOF thermostat velocities w in buffer slot `slot`
+ * (h = fraction * dt of the two scalings, z = exp(-2 h friction)). */
+int amm_bath_define_nhl(amm_ctx *ctx, double h, double z, double kT, double Q, double friction, int32_t slot, int32_t *bath_id);
 
 int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass);
 #define AMM_MAX_SLOTS 64

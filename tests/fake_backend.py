@@ -76,6 +76,11 @@ class RecordingContext:
         self.baths.append((z, kT))
         return len(self.baths) - 1
 
+    def bath_define_nhl(self, h, z, kT, Q, friction, slot):
+        self.baths = getattr(self, 'baths', [])
+        self.baths.append(('nhl', h, z, kT, Q, friction, slot))
+        return len(self.baths) - 1
+
     def expr_seed(self, seed):
         self.calls.append(('expr_seed', seed))
 

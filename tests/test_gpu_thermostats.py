@@ -444,3 +444,61 @@ def test_adiabatic_free_energy_dynamics_runs(heaq):
     st = context.getState(getEnergy=True)
     assert np.isfinite(st.getPotentialEnergy()._value) and np.isfinite(st.getKineticEnergy()._value)
     assert integrator.getGlobalVariableByName('_v_lambda_vdw') != 0.0
+
+
+def test_native_nhl_bath_vs_numpy():
+    """AMM_OP_BATH of kind Nose-Hoover-Langevin (amm_bath_define_nhl): the three per-DOF steps of NHL_R_Integrator's bath block
+    (integrators.py:272-330) -- v <- v exp(-h w); w <- z w + sqrt(kT (1 - z^2)/Q) gaussian + (m v^2 - kT)(1 - z)/(Q friction);
+    v <- v exp(-h w) -- against numpy on the same Philox stream."""
+    rng = np.random.default_rng(6)
+    n = 3000
+    ctx = B.HipContext(n, np.array([3.0, 3.0, 3.0]))
+    v0, w0 = rng.normal(0, 0.5, (n, 3)), rng.normal(0, 50.0, (n, 3))
+    mass = rng.choice([1.008, 15.9994], n)
+    x, v, w = dev(rng.uniform(0, 3, (n, 3))), dev(v0), dev(w0)
+    ctx.bind_state(x, v, dev(mass))
+    ctx.bind_buffer(5, w)
+    h, friction, kT, Q = 0.000125, 20.0, 2.494, 2.494e-4
+    z = float(np.exp(-2 * h * friction))
+    bid = ctx.bath_define_nhl(h, z, kT, Q, friction, 5)
+    ctx.expr_seed(777)
+    ctx.run_ops([B.Op(B.OP_BATH, bid, B.SLOT_V, 0, 0.0)] * 2, 1)
+    ctx.check()
+    rv, rw = v0.copy(), w0.copy()
+    m = mass[:, None]
+    for k in (1, 2):
+        u1, u2 = XO.uniforms(3 * n, 0, 777, (1 << 63) | k)
+        g = (np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586476925 * u2)).reshape(n, 3)
+        rv = rv * np.exp(-h * rw)
+        rw = z * rw + np.sqrt(kT * (1.0 - z * z) / Q) * g + (m * rv * rv - kT) * (1.0 - z) / (Q * friction)
+        rv = rv * np.exp(-h * rw)
+    assert np.abs(v.cpu().numpy() - rv).max() < 1e-13 and np.abs(w.cpu().numpy() - rw).max() < 1e-10
+    ctx.close()
+
+
+def test_nhl_bath_inside_the_inner_loop_kernel_is_bit_identical(spcfw):
+    """NHL_R: the inner-loop kernel carries the Nose-Hoover-Langevin block between its two half moves for all n0 iterations;
+    the trajectory and the thermostat velocities are bit-identical to the op-by-op execution (same amm_nhl_step, same counters)."""
+    c = spcfw
+    out = []
+    for fuse in (True, False):
+        system = system_from_arrays(c, nonbondedMethod='CutoffPeriodic')
+        respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+        nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+        outer = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9 * unit.angstroms).importFrom(nb)
+        outer.setForceGroup(2)
+        outer.addTo(respa)
+        integrator = atomsmm.NHL_R_Integrator(2 * unit.femtoseconds, [4, 2, 1], 300 * unit.kelvin, 10 * unit.femtoseconds, 5 / unit.picoseconds)
+        integrator.setRandomNumberSeed(99)
+        context = openmm.Context(respa, integrator)
+        context._engine.ctx.set_fuse_inner(fuse)
+        context.setPositions(c['positions'] * unit.nanometers)
+        context.setVelocitiesToTemperature(300 * unit.kelvin, 3)
+        integrator.step(12)
+        assert context._engine._interpreted is False
+        st = context.getState(getPositions=True, getVelocities=True)
+        v2 = np.array([list(row) for row in integrator.getPerDofVariableByName('v2')])
+        out.append((st.getPositions(asNumpy=True)._value.copy(), st.getVelocities(asNumpy=True)._value.copy(), v2))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert np.abs(out[0][0] - c['positions']).max() > 1e-3 and np.abs(out[0][2]).max() > 0
