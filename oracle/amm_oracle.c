@@ -296,6 +296,113 @@ long ammo_pair_eval(const ammo_pair_desc *d, int n, const double *pos, const dou
     return pair_eval_n2(d, n, pos, box, q, sigma, eps, excl_ptr, excl_idx, energy, f);
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * CPU BASELINE (bench.py cpu_baseline leg only): Verlet neighbour list, OpenMP.  The traversal above re-walks the
+ * 27-cell stencil and searches the exclusion list at every evaluation -- fine for a checker, not what a CPU engine
+ * does.  This port builds a full (both-direction) list of non-excluded neighbours within rlist once per skin/2 of
+ * displacement and walks it with the same ammo_pair_kernel arithmetic; same results (checked by the tests), the cost
+ * profile of a production CPU code.  list: nbr_ptr[n+1], nbr_idx[]; returns the number of entries or -1. */
+long ammo_nlist_build(int n, const double *pos, const double *box, double rlist, const int *excl_ptr, const int *excl_idx,
+                      long capacity, long *nbr_ptr, int *nbr_idx) {
+    int nc[3];
+    double cw[3];
+    for (int k = 0; k < 3; k++) {
+        nc[k] = (int)floor(box[k] / rlist);
+        if (nc[k] < 3) return -1;
+        cw[k] = box[k] / nc[k];
+    }
+    int ncell = nc[0] * nc[1] * nc[2];
+    int *cell_of = (int *)malloc(sizeof(int) * n);
+    int *start = (int *)calloc(ncell + 1, sizeof(int));
+    int *order = (int *)malloc(sizeof(int) * n);
+    double *wp = (double *)malloc(sizeof(double) * 3 * n);
+    for (int i = 0; i < n; i++) {
+        int c[3];
+        for (int k = 0; k < 3; k++) {
+            double x = pos[3 * i + k] - box[k] * floor(pos[3 * i + k] / box[k]);
+            if (x >= box[k]) x -= box[k];
+            wp[3 * i + k] = x;
+            c[k] = (int)(x / cw[k]);
+            if (c[k] >= nc[k]) c[k] = nc[k] - 1;
+        }
+        cell_of[i] = (c[2] * nc[1] + c[1]) * nc[0] + c[0];
+        start[cell_of[i] + 1]++;
+    }
+    for (int c = 0; c < ncell; c++) start[c + 1] += start[c];
+    int *fill = (int *)malloc(sizeof(int) * ncell);
+    memcpy(fill, start, sizeof(int) * ncell);
+    for (int i = 0; i < n; i++) order[fill[cell_of[i]]++] = i;
+    free(fill);
+    const double rl2 = rlist * rlist;
+    /* pass 1: counts; pass 2: fill (rows in atom order, so that the traversal streams the list) */
+    for (int pass = 0; pass < 2; pass++) {
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int i = 0; i < n; i++) {
+            int c = cell_of[i];
+            int cx = c % nc[0], cy = (c / nc[0]) % nc[1], cz = c / (nc[0] * nc[1]);
+            double xi = wp[3 * i], yi = wp[3 * i + 1], zi = wp[3 * i + 2];
+            long count = 0, base = pass ? nbr_ptr[i] : 0;
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        int c2 = (((cz + dz + nc[2]) % nc[2]) * nc[1] + (cy + dy + nc[1]) % nc[1]) * nc[0] + (cx + dx + nc[0]) % nc[0];
+                        for (int b2 = start[c2]; b2 < start[c2 + 1]; b2++) {
+                            int j = order[b2];
+                            if (j == i) continue;
+                            double ddx = min_image(xi - wp[3 * j], box[0]);
+                            double ddy = min_image(yi - wp[3 * j + 1], box[1]);
+                            double ddz = min_image(zi - wp[3 * j + 2], box[2]);
+                            if (ddx * ddx + ddy * ddy + ddz * ddz >= rl2) continue;
+                            if (is_excluded(excl_ptr, excl_idx, i, j)) continue;
+                            if (pass) nbr_idx[base + count] = j;
+                            count++;
+                        }
+                    }
+            if (!pass) nbr_ptr[i + 1] = count;
+        }
+        if (!pass) {
+            nbr_ptr[0] = 0;
+            for (int i = 0; i < n; i++) nbr_ptr[i + 1] += nbr_ptr[i];
+            if (nbr_ptr[n] > capacity) {
+                free(cell_of); free(start); free(order); free(wp);
+                return -2 - nbr_ptr[n];      /* caller reallocates: needs -(ret + 2) entries */
+            }
+        }
+    }
+    free(cell_of); free(start); free(order); free(wp);
+    return nbr_ptr[n];
+}
+
+long ammo_pair_eval_nlist(const ammo_pair_desc *d, int n, const double *pos, const double *box, const double *q,
+                          const double *sigma, const double *eps, const long *nbr_ptr, const int *nbr_idx, double *energy,
+                          double *f) {
+    const double rc2 = d->rc * d->rc;
+    double etot = 0.0;
+    long npairs = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : etot, npairs)
+    for (int i = 0; i < n; i++) {
+        const double xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2], qi = q[i], si = sigma[i], ei_ = eps[i];
+        double fx = 0, fy = 0, fz = 0, ei = 0;
+        for (long k = nbr_ptr[i]; k < nbr_ptr[i + 1]; k++) {
+            const int j = nbr_idx[k];
+            const double ddx = min_image(xi - pos[3 * j], box[0]);
+            const double ddy = min_image(yi - pos[3 * j + 1], box[1]);
+            const double ddz = min_image(zi - pos[3 * j + 2], box[2]);
+            const double r2 = ddx * ddx + ddy * ddy + ddz * ddz;
+            if (r2 >= rc2) continue;
+            double e, fr;
+            ammo_pair_kernel(d, r2, qi * q[j], 0.5 * (si + sigma[j]), sqrt(ei_ * eps[j]), &e, &fr);
+            ei += e;
+            npairs++;
+            fx += fr * ddx; fy += fr * ddy; fz += fr * ddz;
+        }
+        etot += 0.5 * ei;
+        if (f) { f[3 * i] += fx; f[3 * i + 1] += fy; f[3 * i + 2] += fz; }
+    }
+    if (energy) *energy = etot;
+    return npairs / 2;
+}
+
 void ammo_ewald_exclusion(int npairs, const int *pairs, const double *pos, const double *box,
                           const double *q, double alpha, double Kc, double *energy, double *f) {
     double etot = 0.0;

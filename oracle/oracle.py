@@ -120,6 +120,53 @@ def pair_eval(d, pos, box, q, sigma, eps, excl_pairs=None, want_forces=True, use
     return en.value, f, npairs
 
 
+class VerletList:
+    """CPU BASELINE helper (bench.py cpu_baseline leg): full neighbour list within rc + skin, rebuilt when an atom has moved
+    more than skin / 2 since the last build (oracle/amm_oracle.c: ammo_nlist_build / ammo_pair_eval_nlist)."""
+
+    def __init__(self, n, box, rlist, skin, csr):
+        self.n, self.box, self.rlist, self.skin, self.csr = n, np.ascontiguousarray(box, dtype=np.float64), rlist, skin, csr
+        self.ptr = np.zeros(n + 1, dtype=np.int64)
+        self.idx = np.zeros(1, dtype=np.int32)
+        self.xref = None
+        self.builds = 0
+
+    def _build(self, pos):
+        L = lib()
+        L.ammo_nlist_build.restype = C.c_long
+        ptr, idx = self.csr if self.csr is not None else (None, None)
+        ptrp = ptr.ctypes.data_as(C.POINTER(C.c_int)) if ptr is not None else None
+        idxp = idx.ctypes.data_as(C.POINTER(C.c_int)) if idx is not None else None
+        while True:
+            r = L.ammo_nlist_build(self.n, pos.ctypes.data_as(C.POINTER(C.c_double)), self.box.ctypes.data_as(C.POINTER(C.c_double)),
+                                   C.c_double(self.rlist), ptrp, idxp, C.c_long(len(self.idx)),
+                                   self.ptr.ctypes.data_as(C.POINTER(C.c_long)), self.idx.ctypes.data_as(C.POINTER(C.c_int)))
+            if r >= 0:
+                break
+            if r == -1:
+                raise RuntimeError('oracle: the neighbour-list build needs >= 3 cells per axis')
+            self.idx = np.zeros(int(1.2 * (-(r + 2))) + 1024, dtype=np.int32)
+        self.xref = pos.copy()
+        self.builds += 1
+
+    def update(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        if self.xref is None or np.max(np.sum((pos - self.xref) ** 2, axis=1)) > (0.5 * self.skin) ** 2:
+            self._build(pos)
+
+    def eval(self, d, pos, q, sigma, eps, want_forces=True):
+        pos_, pp = _d(pos)
+        q_, qp = _d(q); s_, sp = _d(sigma); e_, ep = _d(eps)
+        en = C.c_double(0.0)
+        f = np.zeros((self.n, 3)) if want_forces else None
+        L = lib()
+        L.ammo_pair_eval_nlist.restype = C.c_long
+        npairs = L.ammo_pair_eval_nlist(C.byref(d), self.n, pp, self.box.ctypes.data_as(C.POINTER(C.c_double)), qp, sp, ep,
+                                        self.ptr.ctypes.data_as(C.POINTER(C.c_long)), self.idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                        C.byref(en), f.ctypes.data_as(C.POINTER(C.c_double)) if want_forces else None)
+        return en.value, f, npairs
+
+
 def pair_kernel(d, r2, qq, sig, eps):
     e, fr = C.c_double(), C.c_double()
     lib().ammo_pair_kernel(C.byref(d), r2, qq, sig, eps, C.byref(e), C.byref(fr))

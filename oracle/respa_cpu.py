@@ -12,7 +12,7 @@ from . import oracle as O
 
 
 class RespaCPU:
-    def __init__(self, case, rc_in=0.7, rs_in=0.5, rc=1.0, rs=0.9, alpha=2.9, loops=(4, 2, 1), dt=0.004):
+    def __init__(self, case, rc_in=0.7, rs_in=0.5, rc=1.0, rs=0.9, alpha=2.9, loops=(4, 2, 1), dt=0.004, verlet_skin=None):
         self.c = case
         self.loops, self.dt = loops, dt
         n = len(case['positions'])
@@ -24,6 +24,11 @@ class RespaCPU:
         self.m = np.ascontiguousarray(case['mass'], dtype=np.float64)
         self.F = {}
         self.evals = {0: 0, 1: 0, 2: 0}
+        # verlet_skin: the CPU-baseline mode -- Verlet lists (one per cutoff) instead of a 27-cell walk per evaluation
+        self.lists = None
+        if verlet_skin:
+            self.lists = {1: O.VerletList(n, case['box'], rc_in + verlet_skin, verlet_skin, self.csr),
+                          2: O.VerletList(n, case['box'], rc + verlet_skin, verlet_skin, self.csr)}
 
     def f(self, g):
         c = self.c
@@ -34,6 +39,10 @@ class RespaCPU:
                              O.harmonic_angles(c['angles'], c['angle_theta0'], c['angle_k'], self.x, c['box'])[1])
             else:
                 d = self.dn if g == 1 else self.dd
+                if self.lists is not None:
+                    self.lists[g].update(self.x)
+                    self.F[g] = self.lists[g].eval(d, self.x, c['charge'], c['sigma'], c['epsilon'])[1]
+                    return self.F[g]
                 cells = min(c['box']) / d.rc >= 3.0       # the 27-cell stencil needs >= 3 cells per axis
                 self.F[g] = O.pair_eval(d, self.x, c['box'], c['charge'], c['sigma'], c['epsilon'], use_cells=cells,
                                         csr=self.csr)[1]

@@ -256,3 +256,19 @@ def test_step_primitives():
     O.move(x, v, 0.125)
     assert np.array_equal(x, x0 + 0.125 * v)
     assert O.mvv(v, m) == pytest.approx((m[:, None] * v * v).sum(), rel=1e-14)
+
+
+def test_verlet_list_port_equals_the_cell_walk():
+    """The CPU-baseline mode of the oracle (Verlet lists, bench.py's cpu_baseline leg) gives the forces and the RESPA
+    trajectory of the checker's 27-cell walk: same ammo_pair_kernel, same pairs."""
+    from atomsmm_amd.testing import tip3p_box
+    from oracle.respa_cpu import RespaCPU
+    case = tip3p_box(12)
+    walk = RespaCPU(case, dt=0.002)
+    lists = RespaCPU(case, dt=0.002, verlet_skin=0.1)
+    for g in (1, 2):
+        assert np.abs(walk.f(g) - lists.f(g)).max() <= 1e-12 * np.abs(walk.f(g)).max()
+    walk.step(2)
+    lists.step(2)
+    assert np.abs(walk.x - lists.x).max() < 1e-13
+    assert lists.lists[2].builds >= 1
