@@ -35,7 +35,7 @@ EXPORTS = [
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read', 'amm_pair_count_within', 'amm_kernel_revision',
-    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_bath_define_nhl', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
+    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_bath_define_nhl', 'amm_bath_define_sin', 'amm_iso_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
     'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_destroy', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
 ]
 
@@ -136,6 +136,8 @@ def lib():
         L.amm_pair_energy_derivative.argtypes = [vp, C.c_int32, vp, vp]
         L.amm_bath_define.argtypes = [vp, C.c_double, C.c_double, ip]
         L.amm_bath_define_nhl.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, ip]
+        L.amm_bath_define_sin.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, ip]
+        L.amm_iso_define.argtypes = [vp, C.c_int32, C.c_double, C.c_double, C.c_int32]
         L.amm_expr_eval.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp]
         for name in EXPORTS:
             if name not in ('amm_last_error', 'amm_kernel_revision'):
@@ -318,6 +320,14 @@ class HipContext:
         bid = C.c_int32(-1)
         _chk(lib().amm_bath_define_nhl(self.h, float(h), float(z), float(kT), float(Q), float(friction), int(slot), C.byref(bid)))
         return bid.value
+
+    def bath_define_sin(self, h, z, kT, Q2, friction, slot_v2):
+        bid = C.c_int32(-1)
+        _chk(lib().amm_bath_define_sin(self.h, float(h), float(z), float(kT), float(Q2), float(friction), int(slot_v2), C.byref(bid)))
+        return bid.value
+
+    def iso_define(self, on, LkT=0.0, Q1=0.0, slot_v1=-1):
+        _chk(lib().amm_iso_define(self.h, int(bool(on)), float(LkT), float(Q1), int(slot_v1)))
 
     def expr_seed(self, seed):
         _chk(lib().amm_expr_seed(self.h, int(seed) & (2 ** 64 - 1)))

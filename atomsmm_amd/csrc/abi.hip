@@ -603,6 +603,36 @@ int amm_bath_define_nhl(amm_ctx *ctx, double h, double z, double kT, double Q, d
     return 0;
 }
 
+int amm_bath_define_sin(amm_ctx *ctx, double h, double z, double kT, double Q2, double friction, int32_t slot_v2, int32_t *bath_id) {
+    if (!ctx || !bath_id || !(z >= 0.0 && z <= 1.0) || !(kT >= 0.0) || !(Q2 > 0.0) || !(friction > 0.0) || slot_v2 < 0 || slot_v2 >= AMM_SLOT_X) {
+        amm_set_error("amm_bath_define_sin: need 0 <= z <= 1, kT >= 0, Q2 > 0, friction > 0 and a per-DOF buffer slot");
+        return 1;
+    }
+    BathDef b;
+    b.z = z;
+    b.kT = kT;
+    b.kind = 2;
+    b.h = h;
+    b.Q = Q2;
+    b.friction = friction;
+    b.slot = slot_v2;
+    ctx->baths.push_back(b);
+    *bath_id = (int32_t)ctx->baths.size() - 1;
+    return 0;
+}
+
+int amm_iso_define(amm_ctx *ctx, int32_t on, double LkT, double Q1, int32_t slot_v1) {
+    if (!ctx || (on && (!(LkT > 0.0) || !(Q1 > 0.0) || slot_v1 < 0 || slot_v1 >= AMM_SLOT_X))) {
+        amm_set_error("amm_iso_define: need LkT > 0, Q1 > 0 and a per-DOF buffer slot");
+        return 1;
+    }
+    ctx->iso.on = on != 0;
+    ctx->iso.LkT = LkT;
+    ctx->iso.Q1 = Q1;
+    ctx->iso.slot = slot_v1;
+    return 0;
+}
+
 int amm_comm_unique_id(const char *rccl_path, uint8_t id[AMM_COMM_ID_BYTES]) {
     if (!id) {
         amm_set_error("amm_comm_unique_id: null output");
@@ -867,7 +897,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 if (!deferred.empty() && flush_deferred()) return 1;      // no fused launch to ride on
             }
             // fused inner RESPA iteration: KICK(c1, fg) ; MOVE(d) ; EVAL(g) ; KICK(c2, fg) with g = one bond-list set
-            if (ctx->fuse_inner && op.op == AMM_OP_KICK && op.b < 0 && k + 3 < n_ops && ops[k + 1].op == AMM_OP_MOVE &&
+            if (ctx->fuse_inner && !ctx->iso.on && op.op == AMM_OP_KICK && op.b < 0 && k + 3 < n_ops && ops[k + 1].op == AMM_OP_MOVE &&
                 ops[k + 2].op == AMM_OP_EVAL && ops[k + 3].op == AMM_OP_KICK && ops[k + 3].b < 0 && ops[k + 3].a == op.a &&
                 ops[k + 2].a >= 0 && ops[k + 2].a < AMM_MAX_GROUPS) {
                 GroupDef &g = ctx->groups[ops[k + 2].a];

@@ -160,10 +160,22 @@ struct ExprDef {
 // kind 1 (Nose-Hoover-Langevin, NHL_R_Integrator: propagators.py:1362-1449 as MassiveNoseHooverLangevin emits it): the
 // three per-DOF steps  v <- v exp(-h w) ; w <- z w + sqrt(kT (1 - z^2)/Q) gaussian + (m v^2 - kT)(1 - z)/(Q friction) ;
 // v <- v exp(-h w)  with the thermostat velocity w of each DOF in the per-DOF buffer `slot`.
+// kind 2 (stochastic-isokinetic, SIN_R_Integrator with L = 1: propagators.py:276-355, 1045-1105): v1 <- v1 exp(-h v2) ;
+// isokinetic rescale of (v, v1) ; v2 <- z v2 + sqrt(kT (1 - z^2)/Q2) gaussian + (Q1 v1^2 - kT)(1 - z)/(Q2 friction) ;
+// v1 <- v1 exp(-h v2) ; rescale -- thermostat velocities v1 in the context's isokinetic slot, v2 in `slot`.
 struct BathDef {
     double z, kT;
-    int kind = 0;                  // 0 Ornstein-Uhlenbeck, 1 Nose-Hoover-Langevin
+    int kind = 0;                  // 0 Ornstein-Uhlenbeck, 1 Nose-Hoover-Langevin, 2 stochastic-isokinetic
     double h = 0, Q = 0, friction = 0;
+    int slot = -1;
+};
+
+// Isokinetic mode of a context (SIN(R), L = 1): every AMM_OP_KICK is the isokinetic kick
+//   v <- v cosh(z) + sqrt(LkT/m) sinh(z), z = coef F / sqrt(m LkT) ;  H = sqrt(LkT / (m v^2 + Q1 v1^2 / 2)) ; v <- H v ; v1 <- H v1
+// with the per-DOF thermostat velocity v1 in buffer `slot` (MassiveIsokineticPropagator, propagators.py:276-355).
+struct IsoDef {
+    bool on = false;
+    double LkT = 0, Q1 = 0;
     int slot = -1;
 };
 
@@ -201,7 +213,8 @@ struct amm_ctx {
     double *d_fscratch = nullptr;  // [n][3] force sink of amm_pair_energy_derivative
     ConstraintSet *constraints = nullptr;   // distance constraints of the System (AMM_OP_CONSTRAIN_*)
     std::vector<ExprDef> exprs;    // registered per-DOF expressions (AMM_OP_EXPR)
-    std::vector<BathDef> baths;    // registered Ornstein-Uhlenbeck baths (AMM_OP_BATH)
+    std::vector<BathDef> baths;    // registered baths (AMM_OP_BATH)
+    IsoDef iso;                    // isokinetic mode: what AMM_OP_KICK means (amm_iso_define)
     unsigned long long expr_seed = 0, expr_counter = 0;
     // ping-pong partners of x, v and the group-0 force buffer for the fused inner RESPA iteration
     double *alt_x = nullptr, *alt_v = nullptr, *alt_f = nullptr;
@@ -244,6 +257,7 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
                               const double *const *pre_b, const double *pre_coef, const int *pre_plus, double c1, double d,
                               double c2, int niter, const BathDef *bath = nullptr, double d2 = 0.0);
 int amm_bath_impl(amm_ctx *ctx, const BathDef &bath, double *d_v, unsigned long long counter);
+int amm_isokick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef);
 int amm_constraints_create_impl(amm_ctx *ctx, const int32_t *h_pairs, const double *h_dist, int n_cons, double tol,
                                 ConstraintSet **out);
 int amm_constraints_save_reference(amm_ctx *ctx, ConstraintSet *cs, const double *d_x);

@@ -305,7 +305,10 @@ struct CompArgs {
     double c1, d, c2;
     // BATH: kick ; move(d) ; Ornstein-Uhlenbeck step ; move(d2) ; forces ; kick  (Langevin_R 'middle' scheme)
     double d2, bath_z, bath_kT;
-    int bath_kind;                  // 0 Ornstein-Uhlenbeck, 1 Nose-Hoover-Langevin (thermostat velocities in bath_w)
+    int iso;                        // isokinetic mode (SIN(R)): kicks are amm_iso_kick on (v, v1), v1 in iso_v1
+    double iso_LkT, iso_Q1;
+    double *iso_v1;
+    int bath_kind;                  // 0 Ornstein-Uhlenbeck, 1 Nose-Hoover-Langevin, 2 stochastic-isokinetic (thermostat velocities in bath_w)
     double bath_h, bath_Q, bath_friction;
     double *bath_w;
     unsigned long long seed, counter0;
@@ -351,12 +354,17 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
         v[j] = C.v[3 * a + j];
         f[j] = C.f0[3 * a + j];
     }
-    double w[3] = {0.0, 0.0, 0.0};       // thermostat velocities of a Nose-Hoover-Langevin bath
+    double w[3] = {0.0, 0.0, 0.0};       // thermostat velocities of a Nose-Hoover-Langevin / stochastic-isokinetic bath
+    double u1[3] = {0.0, 0.0, 0.0};      // isokinetic mode: the thermostat velocity coupled to each velocity component
     if (BATH) {
-        if (C.bath_kind == 1) {
+        if (C.bath_kind >= 1) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) w[j] = C.bath_w[3 * a + j];
         }
+    }
+    if (C.iso) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) u1[j] = C.iso_v1[3 * a + j];
     }
     const double rm = 1.0 / m;
     const bool rok = (__double_as_longlong(m) & 0xFFFFFFFFFFFFFll) != 0xFFFFFFFFFFFFFll && m > 1e-200 && m < 1e200;
@@ -368,6 +376,10 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
             for (int j = 0; j < 3; ++j) {
                 double ff = pk.a[3 * a + j];
                 if (pk.b) ff = pk.plus ? ff + pk.b[3 * a + j] : ff - pk.b[3 * a + j];
+                if (C.iso) {
+                    amm_iso_kick(v[j], u1[j], ff, m, pk.coef, C.iso_LkT, C.iso_Q1);
+                    continue;
+                }
                 const double num = pk.coef * ff;
                 const double dv = amm_div_mass(num, m, rm, rok);
                 v[j] = v[j] + dv;
@@ -413,9 +425,13 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const double num = C.c1 * f[j];
-                const double dv = amm_div_mass(num, m, rm, rok);
-                v[j] = v[j] + dv;
+                if (C.iso) {
+                    amm_iso_kick(v[j], u1[j], f[j], m, C.c1, C.iso_LkT, C.iso_Q1);
+                } else {
+                    const double num = C.c1 * f[j];
+                    const double dv = amm_div_mass(num, m, rm, rok);
+                    v[j] = v[j] + dv;
+                }
                 const double dx = C.d * v[j];
                 x[j] = x[j] + dx;
             }
@@ -426,7 +442,8 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const double g = amm_gaussian(C.seed, counter, (unsigned)(3 * a + j));
-                if (C.bath_kind == 1) amm_nhl_step(v[j], w[j], m, C.bath_h, C.bath_z, C.bath_kT, C.bath_Q, C.bath_friction, g);
+                if (C.bath_kind == 2) amm_sin_bath_step(v[j], u1[j], w[j], m, C.bath_h, C.bath_z, C.bath_kT, C.bath_Q, C.bath_friction, C.iso_Q1, C.iso_LkT, g);
+                else if (C.bath_kind == 1) amm_nhl_step(v[j], w[j], m, C.bath_h, C.bath_z, C.bath_kT, C.bath_Q, C.bath_friction, g);
                 else v[j] = amm_ou_step(v[j], m, C.bath_z, C.bath_kT, g);
             }
             {
@@ -508,6 +525,10 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
+                if (C.iso) {
+                    amm_iso_kick(v[j], u1[j], f[j], m, C.c2, C.iso_LkT, C.iso_Q1);
+                    continue;
+                }
                 const double num = C.c2 * f[j];
                 const double dv = amm_div_mass(num, m, rm, rok);
                 v[j] = v[j] + dv;
@@ -522,10 +543,14 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
             C.f0[3 * a + j] = f[j];
         }
         if (BATH) {
-            if (C.bath_kind == 1) {
+            if (C.bath_kind >= 1) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) C.bath_w[3 * a + j] = w[j];
             }
+        }
+        if (C.iso) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) C.iso_v1[3 * a + j] = u1[j];
         }
         for (int q = 0; q < C.nwatch; ++q) {
             const double dx = x[0] - C.wref[q][3 * a], dy = x[1] - C.wref[q][3 * a + 1], dz = x[2] - C.wref[q][3 * a + 2];
@@ -825,9 +850,17 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     C.bath_h = bath ? bath->h : 0.0;
     C.bath_Q = bath ? bath->Q : 1.0;
     C.bath_friction = bath ? bath->friction : 1.0;
-    C.bath_w = (bath && bath->kind == 1 && bath->slot >= 0 && bath->slot < AMM_MAX_SLOTS) ? ctx->slots[bath->slot] : nullptr;
-    if (bath && bath->kind == 1 && !C.bath_w) {
-        amm_set_error("Nose-Hoover-Langevin bath: the thermostat-velocity buffer is not bound");
+    C.bath_w = (bath && bath->kind >= 1 && bath->slot >= 0 && bath->slot < AMM_MAX_SLOTS) ? ctx->slots[bath->slot] : nullptr;
+    if (bath && bath->kind >= 1 && !C.bath_w) {
+        amm_set_error("Nose-Hoover-Langevin / stochastic-isokinetic bath: the thermostat-velocity buffer is not bound");
+        return 1;
+    }
+    C.iso = ctx->iso.on ? 1 : 0;
+    C.iso_LkT = ctx->iso.LkT;
+    C.iso_Q1 = ctx->iso.Q1;
+    C.iso_v1 = (ctx->iso.on && ctx->iso.slot >= 0 && ctx->iso.slot < AMM_MAX_SLOTS) ? ctx->slots[ctx->iso.slot] : nullptr;
+    if ((ctx->iso.on && !C.iso_v1) || (bath && bath->kind == 2 && !ctx->iso.on)) {
+        amm_set_error("isokinetic mode: the thermostat-velocity buffer is not bound (or a stochastic-isokinetic bath without the mode)");
         return 1;
     }
     C.seed = ctx->expr_seed;

@@ -108,8 +108,57 @@ __global__ void k_bath_nhl(int n3, double *v, double *w, const double *__restric
     w[dof] = ww;
 }
 
+__global__ void k_bath_sin(int n3, double *v, double *v1, double *v2, const double *__restrict__ mass, BathDef b, double Q1, double LkT,
+                           unsigned long long seed, unsigned long long counter) {
+    const int dof = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dof >= n3) return;
+    double vv = v[dof], a = v1[dof], c = v2[dof];
+    amm_sin_bath_step(vv, a, c, mass[dof / 3], b.h, b.z, b.kT, b.Q, b.friction, Q1, LkT, amm_gaussian(seed, counter, (unsigned)dof));
+    v[dof] = vv;
+    v1[dof] = a;
+    v2[dof] = c;
+}
+
+// isokinetic kick outside the inner-loop kernel (amm_kick_impl dispatches here when the context is in isokinetic mode)
+__global__ void k_isokick(int n3, double *v, double *v1, const double *__restrict__ f, const double *__restrict__ f2, int plus,
+                          const double *__restrict__ mass, double coef, double LkT, double Q1) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    double ff = f[t];
+    if (f2) ff = plus ? ff + f2[t] : ff - f2[t];
+    double vv = v[t], a = v1[t];
+    amm_iso_kick(vv, a, ff, mass[t / 3], coef, LkT, Q1);
+    v[t] = vv;
+    v1[t] = a;
+}
+
+int amm_isokick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef) {
+    double *v1 = (ctx->iso.slot >= 0 && ctx->iso.slot < AMM_MAX_SLOTS) ? ctx->slots[ctx->iso.slot] : nullptr;
+    if (!v1) {
+        amm_set_error("isokinetic kick: the thermostat-velocity buffer is not bound");
+        return 1;
+    }
+    const int n3 = 3 * ctx->n;
+    hipLaunchKernelGGL(k_isokick, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_v, v1, d_f, d_f2, plus, d_mass, coef,
+                       ctx->iso.LkT, ctx->iso.Q1);
+    AMM_HIP(hipGetLastError());
+    return 0;
+}
+
 int amm_bath_impl(amm_ctx *ctx, const BathDef &bath, double *d_v, unsigned long long counter) {
     const int n3 = 3 * ctx->n;
+    if (bath.kind == 2) {
+        double *v2 = (bath.slot >= 0 && bath.slot < AMM_MAX_SLOTS) ? ctx->slots[bath.slot] : nullptr;
+        double *v1 = (ctx->iso.on && ctx->iso.slot >= 0 && ctx->iso.slot < AMM_MAX_SLOTS) ? ctx->slots[ctx->iso.slot] : nullptr;
+        if (!v1 || !v2) {
+            amm_set_error("stochastic-isokinetic bath: isokinetic mode is off or a thermostat-velocity buffer is not bound");
+            return 1;
+        }
+        hipLaunchKernelGGL(k_bath_sin, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_v, v1, v2, ctx->d_mass, bath, ctx->iso.Q1,
+                           ctx->iso.LkT, ctx->expr_seed, counter);
+        AMM_HIP(hipGetLastError());
+        return 0;
+    }
     if (bath.kind == 1) {
         double *w = (bath.slot >= 0 && bath.slot < AMM_MAX_SLOTS) ? ctx->slots[bath.slot] : nullptr;
         if (!w) {

@@ -85,6 +85,32 @@ __device__ __forceinline__ void amm_nhl_step(double &v, double &w, double m, dou
     v = v * exp(-h * w);
 }
 
+// Stochastic-isokinetic pieces (SIN(R), L = 1), in the operation order of the reference's expressions
+//   `v*cosh(z) + sqrt(LkT/m)*sinh(z); z = (c*dt)*(F)/sqrt(m*LkT)` ; `H <- sqrt(LkT/(m*v^2 + 0.5*Q1*(v1_0^2)))` ; `v <- H*v` ;
+//   `v1_0 <- H*v1_0` (propagators.py:300-355), shared by the stand-alone kernels and the inner-loop kernel
+__device__ __forceinline__ void amm_iso_rescale(double &v, double &v1, double m, double LkT, double Q1) {
+#pragma clang fp contract(off)
+    const double H = sqrt(LkT / (m * (v * v) + (0.5 * Q1) * (v1 * v1)));
+    v = H * v;
+    v1 = H * v1;
+}
+__device__ __forceinline__ void amm_iso_kick(double &v, double &v1, double F, double m, double coef, double LkT, double Q1) {
+#pragma clang fp contract(off)
+    const double z = (coef * F) / sqrt(m * LkT);
+    v = v * cosh(z) + sqrt(LkT / m) * sinh(z);
+    amm_iso_rescale(v, v1, m, LkT, Q1);
+}
+__device__ __forceinline__ void amm_sin_bath_step(double &v, double &v1, double &v2, double m, double h, double z, double kT, double Q2,
+                                                  double friction, double Q1, double LkT, double g) {
+#pragma clang fp contract(off)
+    v1 = v1 * exp(-h * v2);
+    amm_iso_rescale(v, v1, m, LkT, Q1);
+    const double force = Q1 * (v1 * v1) - kT;
+    v2 = z * v2 + sqrt(kT * (1.0 - z * z) / Q2) * g + force * (1.0 - z) / (Q2 * friction);
+    v1 = v1 * exp(-h * v2);
+    amm_iso_rescale(v, v1, m, LkT, Q1);
+}
+
 // one copy per kernel, called (not inlined): the interpreter is ~2 k instructions
 static __device__ __noinline__ double expr_run(const ExprProg &P, int dof) {
     double st[AMM_EXPR_STACK], loc[AMM_EXPR_LOCALS];

@@ -51,6 +51,7 @@ __global__ void k_mvv(int n, const double *__restrict__ v, const double *__restr
 }
 
 int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef) {
+    if (ctx->iso.on) return amm_isokick_impl(ctx, d_v, d_f, d_f2, plus, d_mass, coef);      // SIN(R): every kick is isokinetic
     const int n3 = 3 * ctx->n;
     hipLaunchKernelGGL(k_kick, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, d_v, d_f, d_f2, plus, d_mass, coef);
     AMM_HIP(hipGetLastError());

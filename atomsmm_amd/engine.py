@@ -229,6 +229,8 @@ class Engine:
         self.parameters = {}
         self.entries = []
         self.skin = float(properties.get('Skin', -1.0))
+        if float(properties.get('OuterSkin', -1.0)) > 0:       # dual Verlet list: cell-built outer list pruned to the inner one
+            self.ctx.set_outer_skin(float(properties['OuterSkin']))
         self._pair_info = {}
         for force in system.getForces():
             self._translate(force)
@@ -1056,6 +1058,7 @@ class Engine:
         valid = dict(self._valid)
         self._mirror_work = dict(self._mirror)
         self._static_exprs = True
+        self._iso_found, self._plain_kick = None, False      # isokinetic (SIN(R)) kicks recognised / ordinary kicks emitted
         ops = [B.Op(B.OP_SAVE_REF, 0, 0, 0, 0.0)] if self._has_constraints else []
         pc = 0
         guard = 0
@@ -1071,7 +1074,7 @@ class Engine:
                         raise NotImplementedError('step programs that change Context parameters (%s) are not supported' % target)
                 env[target] = value
             elif kind == C.ComputePerDof:
-                skip = self._emit_native_bath_block(steps, pc, env, ops)
+                skip = self._emit_native_bath_block(steps, pc, env, ops) or self._emit_native_iso_block(steps, pc, env, ops, valid)
                 if skip:
                     pc += skip
                     continue
@@ -1090,6 +1093,17 @@ class Engine:
                     pc = match[pc] - 1
             pc += 1
         self._static_exprs = False
+        if self._iso_found and self._plain_kick:
+            # isokinetic AND ordinary kicks in one program: the context-wide isokinetic mode cannot serve both -- run the
+            # isokinetic ones as general expressions
+            self._no_native_iso = True
+            return self._compile()
+        if hasattr(self.ctx, 'iso_define'):
+            if self._iso_found:
+                LkT, Q1, v1 = self._iso_found
+                self.ctx.iso_define(True, LkT, Q1, self._slot(v1))
+            else:
+                self.ctx.iso_define(False)
         finals = {name: env[name] for name in integ._gnames}
         return self._drop_dead_copies(self._pair_up_evals(ops)), valid, finals, dict(self._mirror_work)
 
@@ -1122,6 +1136,77 @@ class Engine:
         ops.append(B.Op(B.OP_BATH, self._expr_ids[key], B.SLOT_V, 0, 0.0))
         self._mirror_work.pop(w, None)
         return 3
+
+    _ISO_KICK = re.compile(r'v\*cosh\(z\)\+sqrt\(LkT/m\)\*sinh\(z\);z=(.+)/sqrt\(m\*LkT\)')
+    _ISO_H = re.compile(r'sqrt\(LkT/\(m\*v\^2\+0\.5\*Q1\*\((\w+)\^2\)\)\)')
+    _SIN_SCALE = re.compile(r'(\w+)\*exp\(-\((.+)\*dt\)\*(\w+)\)')
+    _SIN_UPDATE = re.compile(r'z\*(\w+)\+sqrt\(kT\*\(1-z\*z\)/mass\)\*gaussian\+force\*\(1-z\)/\(mass\*friction\);force=Q1\*(\w+)\^2-kT;'
+                             r'mass=(\w+);z=exp\(-\((.+)\*dt\)\*friction\)')
+
+    def _iso_rescale_at(self, steps, pc, env):
+        """`H <- sqrt(LkT/(m*v^2 + 0.5*Q1*(v1^2)))` ; `v <- H*v` ; `v1 <- H*v1` at steps[pc:pc+3] (SIN(R) with L = 1,
+        propagators.py:300-320): the name of v1, or None."""
+        C = mm.CustomIntegrator
+        if pc + 2 >= len(steps) or any(steps[pc + k][0] != C.ComputePerDof for k in range(3)):
+            return None
+        (_, t0, e0), (_, t1, e1), (_, t2, e2) = steps[pc:pc + 3]
+        m = self._ISO_H.fullmatch(e0.replace(' ', ''))
+        if not (m and t0 == 'H' and t1 == 'v' and e1.replace(' ', '') == 'H*v' and t2 == m.group(1) and
+                e2.replace(' ', '') == 'H*' + m.group(1) and m.group(1) in self.integrator._pnames and 'LkT' in env and 'Q1' in env):
+            return None
+        found = (float(env['LkT']), float(env['Q1']), m.group(1))
+        if self._iso_found not in (None, found):
+            return None
+        return m.group(1)
+
+    def _emit_native_iso_block(self, steps, pc, env, ops, valid):
+        """SIN(R) with one thermostat per DOF (SIN_R_Integrator, integrators.py:358-416).  (a) The isokinetic kick --
+        `v <- v*cosh(z) + sqrt(LkT/m)*sinh(z); z = (c*dt)*(F)/sqrt(m*LkT)` followed by the rescale triple -- becomes an ordinary
+        KICK op of a context in isokinetic mode (amm_iso_define); (b) the bath block between the two half moves -- `v1 <-
+        v1*exp(-(h*dt)*v2)`, rescale, the Ornstein-Uhlenbeck-like update of v2 driven by Q1*v1^2 - kT, the scaling and the rescale
+        again -- becomes ONE native bath op.  Returns the number of program steps consumed (0: neither)."""
+        if getattr(self, '_no_native_iso', False) or not hasattr(self.ctx, 'iso_define'):
+            return 0
+        C = mm.CustomIntegrator
+        kind, target, expr = steps[pc]
+        text = expr.replace(' ', '')
+        kick = self._ISO_KICK.fullmatch(text) if target == 'v' else None
+        if kick:
+            v1 = self._iso_rescale_at(steps, pc + 1, env)
+            parts = self._split_leading_group(kick.group(1))
+            terms = self._signed_terms(parts[1]) if parts else None
+            if not (v1 and terms and len(terms) <= 2 and terms[0][0] == 1):
+                return 0
+            coef = self._eval(parts[0], env)
+            a = self._force_ref(terms[0][1], ops, valid)
+            b, plus = -1, 0
+            if len(terms) == 2:
+                b = self._force_ref(terms[1][1], ops, valid)
+                plus = 1 if terms[1][0] == 1 else 0
+            ops.append(B.Op(B.OP_KICK, a, b, plus, coef))
+            self._iso_found = (float(env['LkT']), float(env['Q1']), v1)
+            return 4
+        scale = self._SIN_SCALE.fullmatch(text)
+        if scale and scale.group(1) == target and pc + 8 < len(steps):
+            v1, v2 = target, scale.group(3)
+            if self._iso_rescale_at(steps, pc + 1, env) != v1 or self._iso_rescale_at(steps, pc + 6, env) != v1:
+                return 0
+            (k4, t4, e4), (k5, t5, e5) = steps[pc + 4], steps[pc + 5]
+            upd = self._SIN_UPDATE.fullmatch(e4.replace(' ', '')) if k4 == C.ComputePerDof else None
+            if not (upd and t4 == v2 and upd.group(1) == v2 and upd.group(2) == v1 and k5 == C.ComputePerDof and t5 == v1 and e5 == expr and
+                    v2 in self.integrator._pnames and upd.group(3) in env and 'kT' in env and 'friction' in env):
+                return 0
+            h = self._eval(scale.group(2), env) * env['dt']
+            z = math.exp(-(self._eval(upd.group(4), env) * env['dt']) * env['friction'])
+            key = ('sin', h, z, float(env['kT']), float(env[upd.group(3)]), float(env['friction']), v2)
+            if key not in self._expr_ids:
+                self._expr_ids[key] = self.ctx.bath_define_sin(h, z, float(env['kT']), float(env[upd.group(3)]), float(env['friction']),
+                                                               self._slot(v2))
+            ops.append(B.Op(B.OP_BATH, self._expr_ids[key], B.SLOT_V, 0, 0.0))
+            self._iso_found = (float(env['LkT']), float(env['Q1']), v1)
+            self._slot(v1)
+            return 9
+        return 0
 
     def _pair_up_evals(self, ops):
         """RESPA evaluates the near force (group 1) and, one kick later, the outer force (group 2) at the same positions
@@ -1283,6 +1368,7 @@ class Engine:
                         b = self._force_ref(terms[1][1], ops, valid)
                         plus = 1 if terms[1][0] == 1 else 0
                     ops.append(B.Op(B.OP_KICK, a, b, plus, coef))
+                    self._plain_kick = True
                     return
         # move: x <- x + (coef)*v
         if target == 'x' and text.startswith('x+') and text.endswith('*v'):

@@ -42,7 +42,7 @@ TRAFFIC_FILE = 'r02_traffic.json'
 KB = 0.0083144626181532
 
 
-def build_simulation(nside, loops, dt_fs, outer_kind='damped', skin=None):
+def build_simulation(nside, loops, dt_fs, outer_kind='damped', skin=None, outer_skin=None):
     import atomsmm_amd as atomsmm
     from atomsmm_amd import openmm, unit
     from atomsmm_amd.openmm import app
@@ -62,7 +62,8 @@ def build_simulation(nside, loops, dt_fs, outer_kind='damped', skin=None):
     integrator = atomsmm.RespaPropagator(list(loops)).integrator(dt_fs * unit.femtoseconds)
     simulation = app.Simulation(app.Topology(len(case['positions'])), respa, integrator,
                                 openmm.Platform.getPlatformByName('HIP'),
-                                {'Skin': str(skin)} if skin is not None else None)
+                                dict(([('Skin', str(skin))] if skin is not None else []) +
+                                     ([('OuterSkin', str(outer_skin))] if outer_skin is not None else [])) or None)
     simulation.context.setPositions(case['positions'] * unit.nanometers)
     simulation.context.setVelocities(case['velocities'])
     return simulation, case
@@ -139,6 +140,7 @@ def main():
                     help="group-2 force: DampedSmoothedForce (headline, SURVEY 8d C3 i) or the PME NonbondedForce (C3 ii)")
     ap.add_argument('--config', choices=['c3', 'c5'], default='c3',
                     help='c3: the headline 98 304-atom TIP3P RESPA box; c5: ~249 000-atom solvated chain, RESPA + exceptions + AFED (2 fs inner step)')
+    ap.add_argument('--outer-skin', type=float, default=None, help='dual Verlet list: buffer of the cell-built outer list in nm (default: single list)')
     ap.add_argument('--skin', type=float, default=None, help='Verlet buffer in nm (default: the library default, 0.1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-relax', action='store_true')
@@ -182,7 +184,7 @@ def main():
         dt_fs = 2 * substeps * inner_fs
         args.no_cpu_baseline = True
     else:
-        simulation, case = build_simulation(args.nside, loops, dt_fs, args.outer, args.skin)
+        simulation, case = build_simulation(args.nside, loops, dt_fs, args.outer, args.skin, args.outer_skin)
     eng = simulation.context._engine
     n = eng.n
     log('system built in %.1f s: %d atoms' % (time.perf_counter() - t_setup, n))

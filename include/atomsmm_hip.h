@@ -240,6 +240,14 @@ int amm_bath_define(amm_ctx *ctx, double z, double kT, int32_t *bath_id);
  * (m v^2 - kT)(1 - z)/(Q friction) ; v <- v exp(-h w), with the per-DOF thermostat velocities w in buffer slot `slot`
  * (h = fraction * dt of the two scalings, z = exp(-2 h friction)). */
 int amm_bath_define_nhl(amm_ctx *ctx, double h, double z, double kT, double Q, double friction, int32_t slot, int32_t *bath_id);
+/* SIN(R) with L = 1 (SIN_R_Integrator, integrators.py:358-416; MassiveIsokineticPropagator / SIN_R_Propagator,
+ * propagators.py:276-355, 1045-1105).  amm_iso_define(on = 1) puts the context in isokinetic mode: every AMM_OP_KICK becomes
+ *   v <- v cosh(z) + sqrt(LkT/m) sinh(z), z = coef F / sqrt(m LkT) ; H = sqrt(LkT/(m v^2 + Q1 v1^2/2)) ; v <- H v ; v1 <- H v1
+ * with the per-DOF thermostat velocities v1 in buffer slot `slot_v1`.  amm_bath_define_sin registers the bath block between
+ * the two half moves -- v1 <- v1 exp(-h v2) ; rescale ; v2 <- z v2 + sqrt(kT (1 - z^2)/Q2) gaussian + (Q1 v1^2 - kT)(1 - z)/
+ * (Q2 friction) ; v1 <- v1 exp(-h v2) ; rescale -- as ONE AMM_OP_BATH (v2 in slot_v2; needs the isokinetic mode). */
+int amm_iso_define(amm_ctx *ctx, int32_t on, double LkT, double Q1, int32_t slot_v1);
+int amm_bath_define_sin(amm_ctx *ctx, double h, double z, double kT, double Q2, double friction, int32_t slot_v2, int32_t *bath_id);
 
 int amm_bind_state(amm_ctx *ctx, double *d_x, double *d_v, const double *d_mass);
 #define AMM_MAX_SLOTS 64

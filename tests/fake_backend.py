@@ -81,6 +81,14 @@ class RecordingContext:
         self.baths.append(('nhl', h, z, kT, Q, friction, slot))
         return len(self.baths) - 1
 
+    def bath_define_sin(self, h, z, kT, Q2, friction, slot_v2):
+        self.baths = getattr(self, 'baths', [])
+        self.baths.append(('sin', h, z, kT, Q2, friction, slot_v2))
+        return len(self.baths) - 1
+
+    def iso_define(self, on, LkT=0.0, Q1=0.0, slot_v1=-1):
+        self.calls.append(('iso_define', bool(on), LkT, Q1, slot_v1))
+
     def expr_seed(self, seed):
         self.calls.append(('expr_seed', seed))
 

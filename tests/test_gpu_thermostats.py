@@ -502,3 +502,87 @@ def test_nhl_bath_inside_the_inner_loop_kernel_is_bit_identical(spcfw):
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
     assert np.abs(out[0][0] - c['positions']).max() > 1e-3 and np.abs(out[0][2]).max() > 0
+
+
+def test_native_isokinetic_kick_and_sin_bath_vs_numpy():
+    """Isokinetic mode (amm_iso_define): AMM_OP_KICK is v <- v cosh(z) + sqrt(LkT/m) sinh(z), z = coef F/sqrt(m LkT), followed by
+    the rescale H = sqrt(LkT/(m v^2 + Q1 v1^2/2)) of (v, v1); the stochastic-isokinetic bath op (amm_bath_define_sin) is
+    v1 <- v1 exp(-h v2); rescale; v2 <- z v2 + sqrt(kT (1 - z^2)/Q2) gaussian + (Q1 v1^2 - kT)(1 - z)/(Q2 friction);
+    v1 <- v1 exp(-h v2); rescale (SIN_R_Integrator with L = 1, propagators.py:276-355, 1045-1105) -- against numpy."""
+    rng = np.random.default_rng(8)
+    n = 2000
+    ctx = B.HipContext(n, np.array([3.0, 3.0, 3.0]))
+    mass = rng.choice([1.008, 15.9994], n)
+    kT, Q1, Q2, friction, h = 2.494, 2.494e-4, 2.494e-4, 20.0, 0.000125
+    LkT = kT
+    v1_0 = rng.normal(0, np.sqrt(kT / Q1), (n, 3))
+    v0 = rng.normal(0, 1.0, (n, 3))
+    scale = np.sqrt(LkT / (mass[:, None] * v0 ** 2 + 0.5 * Q1 * v1_0 ** 2))          # start on the isokinetic surface
+    v0, v1_0 = scale * v0, scale * v1_0
+    v2_0 = rng.normal(0, np.sqrt(kT / Q2), (n, 3))
+    force = rng.normal(0, 500.0, (n, 3))
+    x, v, f, v1, v2 = dev(rng.uniform(0, 3, (n, 3))), dev(v0), dev(force), dev(v1_0), dev(v2_0)
+    ctx.bind_state(x, v, dev(mass))
+    ctx.bind_buffer(0, f)
+    ctx.bind_buffer(4, v1)
+    ctx.bind_buffer(5, v2)
+    ctx.iso_define(True, LkT, Q1, 4)
+    z = float(np.exp(-2 * h * friction))
+    bid = ctx.bath_define_sin(h, z, kT, Q2, friction, 5)
+    ctx.expr_seed(31337)
+    coef = 0.00025
+    ctx.run_ops([B.Op(B.OP_KICK, 0, -1, 0, coef), B.Op(B.OP_BATH, bid, B.SLOT_V, 0, 0.0), B.Op(B.OP_KICK, 0, -1, 0, coef)], 1)
+    ctx.check()
+    m = mass[:, None]
+
+    def rescale(a, b):
+        H = np.sqrt(LkT / (m * a * a + 0.5 * Q1 * b * b))
+        return H * a, H * b
+
+    def kick(a, b):
+        zz = coef * force / np.sqrt(m * LkT)
+        return rescale(a * np.cosh(zz) + np.sqrt(LkT / m) * np.sinh(zz), b)
+    rv, r1 = kick(v0, v1_0)
+    u1, u2 = XO.uniforms(3 * n, 0, 31337, (1 << 63) | 1)
+    g = (np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586476925 * u2)).reshape(n, 3)
+    r1 = r1 * np.exp(-h * v2_0)
+    rv, r1 = rescale(rv, r1)
+    r2 = z * v2_0 + np.sqrt(kT * (1 - z * z) / Q2) * g + (Q1 * r1 * r1 - kT) * (1 - z) / (Q2 * friction)
+    r1 = r1 * np.exp(-h * r2)
+    rv, r1 = rescale(rv, r1)
+    rv, r1 = kick(rv, r1)
+    assert np.abs(v.cpu().numpy() - rv).max() < 1e-12 * np.abs(rv).max()
+    assert np.abs(v1.cpu().numpy() - r1).max() < 1e-12 * np.abs(r1).max()
+    assert np.abs(v2.cpu().numpy() - r2).max() < 1e-12 * np.abs(r2).max()
+    lhs = m * v.cpu().numpy() ** 2 + 0.5 * Q1 * v1.cpu().numpy() ** 2
+    assert np.abs(lhs / LkT - 1.0).max() < 1e-13
+    ctx.iso_define(False)
+    ctx.close()
+
+
+def test_sin_r_inside_the_inner_loop_kernel_is_bit_identical(spcfw):
+    """SIN_R (L = 1): isokinetic kicks and the stochastic-isokinetic bath carried by the inner-loop kernel (thermostat velocities
+    v1, v2 in registers across the n0 iterations) give the op-by-op trajectory bit for bit."""
+    c = spcfw
+    out = []
+    for fuse in (True, False):
+        system = system_from_arrays(c, nonbondedMethod='CutoffPeriodic')
+        respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+        nb = atomsmm.hijackForce(respa, atomsmm.findNonbondedForce(respa))
+        outer = atomsmm.DampedSmoothedForce(0.29 / unit.angstroms, 10 * unit.angstroms, 9 * unit.angstroms).importFrom(nb)
+        outer.setForceGroup(2)
+        outer.addTo(respa)
+        integrator = atomsmm.SIN_R_Integrator(2 * unit.femtoseconds, [4, 2, 1], 300 * unit.kelvin, 10 * unit.femtoseconds, 5 / unit.picoseconds)
+        integrator.setRandomNumberSeed(99)
+        context = openmm.Context(respa, integrator)
+        context._engine.ctx.set_fuse_inner(fuse)
+        context.setPositions(c['positions'] * unit.nanometers)
+        context.setVelocitiesToTemperature(300 * unit.kelvin, 3)
+        integrator.step(12)
+        assert context._engine._interpreted is False
+        st = context.getState(getPositions=True, getVelocities=True)
+        extra = [np.array([list(row) for row in integrator.getPerDofVariableByName(name)]) for name in ('v1_0', 'v2_0')]
+        out.append([st.getPositions(asNumpy=True)._value.copy(), st.getVelocities(asNumpy=True)._value.copy()] + extra)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert np.abs(out[0][0] - c['positions']).max() > 1e-3
