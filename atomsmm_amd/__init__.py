@@ -35,7 +35,7 @@ from .propagators import (MassiveNoseHooverPropagator, NoseHooverPropagator, Orn
                           GenericBoostPropagator, GenericScalingPropagator, MassiveIsokineticPropagator,
                           SIN_R_Propagator, MassiveGeneralizedGaussianMomentPropagator, NoseHooverChainPropagator,
                           NoseHooverLangevinPropagator)
-from .systems import AlchemicalRespaSystem, ComputingSystem, RESPASystem, SolvationSystem  # noqa: F401
+from .systems import AlchemicalRespaSystem, AlchemicalSystem, ComputingSystem, RESPASystem, SolvationSystem  # noqa: F401
 from .computers import PressureComputer  # noqa: F401
 from .utils import InputError  # noqa: F401
 from .utils import countDegreesOfFreedom  # noqa: F401
@@ -57,6 +57,6 @@ __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPro
                    'MassiveIsokineticPropagator', 'SIN_R_Propagator', 'MassiveGeneralizedGaussianMomentPropagator',
                    'NoseHooverChainPropagator', 'NoseHooverLangevinPropagator']
 __systems__ = ['RESPASystem', 'SolvationSystem', 'ComputingSystem', 'PressureComputer',
-               'AlchemicalRespaSystem']
+               'AlchemicalRespaSystem', 'AlchemicalSystem']
 __utils__ = ['countDegreesOfFreedom', 'evaluateForce', 'findNonbondedForce', 'hijackForce', 'splitPotentialEnergy']
 __all__ = __forces__ + __integrators__ + __propagators__ + __systems__ + __utils__

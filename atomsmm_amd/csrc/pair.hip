@@ -991,6 +991,7 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
                 }
             }
         }
+#ifndef AMM_EXP_NOFALLBACK
         if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {     // closer than a table reaches: analytic (never in a liquid)
             for (int u = 0; u < UNR; ++u) {
                 double dx, dy, dz;
@@ -1015,6 +1016,7 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
                 }
             }
         }
+#endif
     };
     // two register sets (a / b) alternate, so that no copy -- which would have to wait for the load -- sits between a
     // fetch and its use one iteration later
@@ -1050,8 +1052,12 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
     }
 }
 
+#ifndef AMM_TAB_WAVES_PER_EU
+#define AMM_TAB_WAVES_PER_EU 1
+#endif
 template <int FAM, int CMODE, int GFAM, int BS>
-__global__ void __launch_bounds__(BS) k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_TAB_WAVES_PER_EU)))
+k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
     extern __shared__ __align__(16) char s_lds[];
     // stage the table(s): 16-byte pieces, coalesced
     for (int o = threadIdx.x * 16; o < T.host_bytes; o += BS * 16)
@@ -1076,9 +1082,21 @@ __global__ void __launch_bounds__(BS) k_pair_tab(PairArgs A, PairConsts c, PairC
     const int rpw = 64 >> A.lpa_shift;
     const int n_lj = T.n_lj ? min(*T.n_lj, T.nslice) : T.nslice;
     const int t_lj = (n_lj + rpw - 1) / rpw, t_h = (T.nslice - n_lj + rpw - 1) / rpw;
-    const int per_lj = (t_lj + 7) >> 3, per_h = (t_h + 7) >> 3;
-    const int lj0 = min(xcd * per_lj, t_lj), nlj_x = min(lj0 + per_lj, t_lj) - lj0;
-    const int h0 = min(xcd * per_h, t_h), nh_x = min(h0 + per_h, t_h) - h0;
+    // Each pool is cut into 16 chunks of consecutive tasks (consecutive cell-sorted rows: slabs of the box); XCD x owns chunks
+    // x and x + 8.  One contiguous eighth per XCD would give the two XCDs at the ends of the sorted order the slabs at the box
+    // faces, where every row needs the minimum-image arithmetic (+ 25 % instructions): with two slabs each, every XCD holds at
+    // most one face slab, and its gathers still come from 2 x (0.62 + 2.2) nm of the box -- within its 4 MiB of L2.
+    const int per_lj = (t_lj + 15) >> 4, per_h = (t_h + 15) >> 4;
+    auto chunk = [](int which, int per, int total, int &first, int &count) {
+        first = min(which * per, total);
+        count = min(first + per, total) - first;
+    };
+    int lj_a, nlj_a, lj_b, nlj_b, h_a, nh_a, h_b, nh_b;
+    chunk(xcd, per_lj, t_lj, lj_a, nlj_a);
+    chunk(xcd + 8, per_lj, t_lj, lj_b, nlj_b);
+    chunk(xcd, per_h, t_h, h_a, nh_a);
+    chunk(xcd + 8, per_h, t_h, h_b, nh_b);
+    const int nlj_x = nlj_a + nlj_b, nh_x = nh_a + nh_b;
     const int ntask_x = nlj_x + nh_x;
     // static deal: position p of the XCD's task sequence goes to wavefront p mod nwx.  The sequence interleaves the two
     // pools in proportion (position p is a Lennard-Jones task iff floor((p + 1) nlj / n) > floor(p nlj / n)), so every
@@ -1087,8 +1105,9 @@ __global__ void __launch_bounds__(BS) k_pair_tab(PairArgs A, PairConsts c, PairC
     for (int p = (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); p < ntask_x; p += nwx) {
         const int before = (int)(((long long)p * nlj_x) / ntask_x), upto = (int)(((long long)(p + 1) * nlj_x) / ntask_x);
         const bool lj_pool = upto > before;
-        const int task = lj_pool ? before : nlj_x + (p - upto);
-        const int a = lj_pool ? (lj0 + task) * rpw + (lane >> A.lpa_shift) : n_lj + (h0 + task - nlj_x) * rpw + (lane >> A.lpa_shift);
+        const int local = lj_pool ? before : p - upto;                    // index within the XCD's share of its pool
+        const int task = lj_pool ? (local < nlj_a ? lj_a + local : lj_b + (local - nlj_a)) : (local < nh_a ? h_a + local : h_b + (local - nh_a));
+        const int a = (lj_pool ? 0 : n_lj) + task * rpw + (lane >> A.lpa_shift);
         const bool valid = lj_pool ? a < n_lj : a < T.nslice;
         int s = A.s_begin;
         double4 pi = make_double4(0.0, 0.0, 0.0, 0.0);
@@ -1109,6 +1128,12 @@ __global__ void __launch_bounds__(BS) k_pair_tab(PairArgs A, PairConsts c, PairC
         const bool interior = __builtin_amdgcn_ballot_w64(edge) == 0ull;
         const bool any_lj = __builtin_amdgcn_ballot_w64(valid && li.y != 0.0) != 0ull;
         double fx = 0.0, fy = 0.0, fz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+#ifdef AMM_EXP_NOLJ
+        // experiment: as if no row had a Lennard-Jones site (wrong forces, same lists): the register budget and speed of a
+        // kernel that holds only the LJ-free loop
+        if (interior) amm_walk_row_tab<FAM, CMODE, GFAM, true, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
+        else amm_walk_row_tab<FAM, CMODE, GFAM, false, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
+#else
         if (interior) {
             if (any_lj) amm_walk_row_tab<FAM, CMODE, GFAM, true, true>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
             else amm_walk_row_tab<FAM, CMODE, GFAM, true, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
@@ -1116,6 +1141,7 @@ __global__ void __launch_bounds__(BS) k_pair_tab(PairArgs A, PairConsts c, PairC
             if (any_lj) amm_walk_row_tab<FAM, CMODE, GFAM, false, true>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
             else amm_walk_row_tab<FAM, CMODE, GFAM, false, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
         }
+#endif
         for (int off = lpa >> 1; off > 0; off >>= 1) {
             fx += __shfl_xor(fx, off);
             fy += __shfl_xor(fy, off);

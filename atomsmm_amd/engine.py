@@ -464,6 +464,10 @@ class Engine:
         if lam:
             entry.update = update
             entry.depends = set(lam)
+            # parameters whose offsets touch the charges only: the energy is a quadratic form of them
+            entry.quadratic_in = {nm for nm in lam
+                                  if not (nm in names and np.any(scales[names.index(nm)][:, 1:]))
+                                  and not (nm in enames and np.any(escales[enames.index(nm)][:, 1:]))}
 
     def _descriptor_of(self, force):
         desc = getattr(force, '_amm', None)
@@ -501,7 +505,7 @@ class Engine:
             return self._translate_softcore(force, entry, d)
         if d['family'] == 'lj-virial':
             return self._translate_lj_virial(force, entry)
-        if d['family'] == 'lj' or d.get('noshift') or d.get('scale_name') or force.getNumInteractionGroups() > 0:
+        if d['family'] == 'lj' or d.get('noshift') or d.get('scale_name') or d.get('scale_text') or force.getNumInteractionGroups() > 0:
             return self._translate_alchemical_pair(force, entry, d)
         if force.getNumInteractionGroups() > 0:
             raise NotImplementedError('interaction groups are supported for the softcore solute-solvent force only')
@@ -548,7 +552,10 @@ class Engine:
             raise NotImplementedError('alchemical pair force with parameter offsets')
         if force.getNonbondedMethod() != force.CutoffPeriodic:
             raise InputError('the HIP path evaluates CutoffPeriodic CustomNonbondedForces only')
-        p = np.array(force._particles, dtype=np.float64).reshape(n, -1)[:, :3]
+        p = np.array(force._particles, dtype=np.float64).reshape(n, -1)
+        if p.shape[1] == 2:                            # per-particle (sigma, epsilon) only: AlchemicalSystem (systems.py:378-379)
+            p = np.concatenate([np.zeros((n, 1)), p], axis=1)
+        p = p[:, :3]
         q = p[:, 0].copy()
         ngroups = force.getNumInteractionGroups()
         flags, Kc = 0, d.get('Kc', B.KC)
@@ -576,11 +583,18 @@ class Engine:
         rc = force._cutoff
         rswitch = force._switch if force.getUseSwitchingFunction() else None
         scale_name = d.get('scale_name')
+        scale_text = d.get('scale_text')
+        scale_symbols = X.symbols(scale_text) if scale_text else set()
+        for name in scale_symbols:
+            if name not in self.parameters:          # e.g. the reference's `linear` coupling leaves two_pi undefined
+                raise mm.OpenMMException('Unknown variable in expression: ' + name)
 
         def scale(parameters):
             value = d.get('sign', 1.0)
             if scale_name:
                 value *= parameters[scale_name]
+            if scale_text:
+                value *= X.eval_global(scale_text, {k: parameters[k] for k in scale_symbols})
             if outer is not None:
                 value *= outer(parameters)
             return value
@@ -616,7 +630,7 @@ class Engine:
             lrc = custom_long_range_correction(lambda r, s_, e_: 4.0 * e_ * ((s_ / r) ** 12 - (s_ / r) ** 6), p[:, 1], p[:, 2],
                                                self.box, rc, rswitch, codes)
         entry.constant = lrc * scale(self.parameters)
-        depends = set(outer_depends) | ({scale_name} if scale_name else set())
+        depends = set(outer_depends) | ({scale_name} if scale_name else set()) | scale_symbols
         if depends:
             def update(parameters, changed):
                 if not (depends & changed):
@@ -1550,14 +1564,43 @@ class Engine:
             raise NotImplementedError('deriv(%s, ...): only deriv(energy, parameter) is supported' % what)
         return self.energy_derivative(name)
 
+    def _energy_of(self, entries):
+        """Potential energy of a subset of the translated forces (pair + bond-list + reciprocal-space terms + constants)."""
+        torch = self.torch
+        e_pair = torch.zeros(1, dtype=torch.float64, device=self.x.device)
+        e_bond = torch.zeros(1, dtype=torch.float64, device=self.x.device)
+        fp, fb = self._fwork.zero_(), self._fwork2.zero_()
+        const = 0.0
+        for entry in entries:
+            for pid in entry.pair_ids:
+                self.ctx.force_eval(pid, self.x, fp, accumulate=True, energy=e_pair)
+            if entry.bonded_id is not None:
+                self.ctx.force_eval(entry.bonded_id, self.x, fb, accumulate=True, energy=e_bond)
+            if entry.recip is not None:
+                self.ctx.pme_set_sliced(entry.recip, False)
+                self.ctx.force_eval(entry.recip, self.x, fb, accumulate=True, energy=e_bond)
+                self.ctx.pme_set_sliced(entry.recip, getattr(entry, 'recip_sliced', False))
+            const += entry.constant
+        self._check()
+        if self._coll:
+            self._allreduce(e_pair)
+        return e_pair.item() + e_bond.item() + const
+
     def energy_derivative(self, name):
         """deriv(energy, name): d(total potential energy)/d(global parameter) at the current positions
-        (ExtendedSystemVariable.update_velocity, integrators.py:735-737).  Supported for the lambda of softcore pair
-        forces (pair kernel in derivative mode + the long-range correction's derivative)."""
+        (ExtendedSystemVariable.update_velocity, integrators.py:735-737).
+
+        * lambda of a softcore pair force: the pair kernel in derivative mode + the long-range correction's derivative;
+        * an overall coupling factor (AlchemicalSystem's `linear` / `spline` / `art` / custom couplings, systems.py:349-365):
+          the factor's derivative times the energy at unit coupling;
+        * parameter offsets of a NonbondedForce (SolvationSystem's `lambda_coul`, systems.py:289-308): the energy is a
+          quadratic form of the charges, so the central difference over a whole unit of lambda is exact; offsets that act
+          on sigma / epsilon (`use_softcore=False`, systems.py:309-312) take a small central step instead (O(h^2))."""
         if name not in self.parameters:
             raise mm.OpenMMException('deriv(energy, %s): no such Context parameter' % name)
         torch = self.torch
         total = 0.0
+        by_difference = []
         for entry in self.entries:
             sc = entry.softcore
             if sc is not None and sc['lambda_name'] == name:
@@ -1571,7 +1614,30 @@ class Engine:
                 dn[name] -= h
                 total += out.item() + (sc['constant'](up) - sc['constant'](dn)) / (2 * h)
             elif name in getattr(entry, 'depends', ()):
-                raise NotImplementedError('deriv(energy, %s): only softcore pair forces provide parameter derivatives' % name)
+                if entry.update is None:
+                    raise NotImplementedError('deriv(energy, %s): the force that depends on it cannot be re-parameterised' % name)
+                by_difference.append(entry)
+        if by_difference:
+            exact = all(getattr(e, 'quadratic_in', None) and name in e.quadratic_in for e in by_difference)
+            here = self.parameters[name]
+            h = 1.0 if exact else 1e-4
+            lo = here - h
+            if not exact and lo < 0.0 <= here:
+                lo = here                      # sqrt(epsilon) offsets are not analytic below zero: one-sided step
+            values, rebuilt = [], False
+            for point in (here + h, lo, here):
+                trial = dict(self.parameters)
+                trial[name] = point
+                for entry in by_difference:
+                    result = entry.update(trial, {name})
+                    rebuilt = rebuilt or (result and result != 'values')
+                if point != here:
+                    values.append(self._energy_of(by_difference))
+            if rebuilt:
+                self._group_defs.clear()
+                self._programs.clear()
+            self._invalidate_forces()
+            total += (values[0] - values[1]) / (here + h - lo)
         return total
 
     # ------------------------------------------------------------------------------- general step programs

@@ -86,6 +86,14 @@ def describe_energy(energy, global_parameters=None):
     if not parts:
         return None
     head = parts[0].replace(' ', '')
+    # `U_name; U_name = <expression>; ...` (AlchemicalSystem, systems.py:345-365): the head is an alias of a definition
+    if re.fullmatch(r'[A-Za-z_]\w*', head):
+        for k, part in enumerate(parts[1:], start=1):
+            lhs, _, rhs = part.partition('=')
+            if lhs.strip() == head and rhs:
+                parts = [rhs.strip()] + parts[1:k] + parts[k + 1:]
+                head = parts[0].replace(' ', '')
+                break
     sign, guard = 1.0, False
     for _ in range(3):
         if head.startswith('-step(rc0-r)*(') and head.endswith(')'):
@@ -155,6 +163,12 @@ def describe_energy(energy, global_parameters=None):
                 desc['lambda_value'] = fixed          # AlchemicalSoftcoreCVForce: `lambda = 0.4` among the definitions
         elif head == '4*epsilon*x*(x-1)' and 'x=(sigma/r)^6' in aux:
             desc.update(family='lj')                                   # systems.py:749: the collective variable
+        elif re.fullmatch(r'4\*\((.+)\)\*epsilon\*x\*\(x-1\)', head) and 'x=(sigma/r)^6' in aux:
+            # Lennard-Jones times a coupling function of the global parameters (AlchemicalSystem, systems.py:353-365):
+            # the factor and the definitions it needs are handed to the engine as text
+            factor = re.fullmatch(r'4\*\((.+)\)\*epsilon\*x\*\(x-1\)', head).group(1)
+            keep = [a for a in aux if a.split('=')[0] not in ('x', 'sigma', 'epsilon')]
+            desc.update(family='lj', scale_text=';'.join([factor] + keep))
         elif re.fullmatch(r'4\*epsilon\*x\*\(x-1\)\+' + num + r'\*chargeprod/r', head) and 'x=(sigma/r)^6' in aux:
             desc.update(family='ljc', Kc=float(re.fullmatch(r'4\*epsilon\*x\*\(x-1\)\+' + num + r'\*chargeprod/r', head).group(1)))
         else:

@@ -849,6 +849,11 @@ class State:
     def getTime(self):
         return Quantity(self._t, _unit.picosecond)
 
+    def getEnergyParameterDerivatives(self):
+        if getattr(self, '_derivatives', None) is None:
+            raise OpenMMException('Invoked getEnergyParameterDerivatives() on a State which does not contain parameter derivatives.')
+        return dict(self._derivatives)
+
 
 def _as_array(values, n, what):
     v = md_value(values)
@@ -959,14 +964,23 @@ class Context:
         return [groups[r] for r in sorted(groups)]
 
     def getState(self, getPositions=False, getVelocities=False, getForces=False, getEnergy=False,
-                 getParameters=False, enforcePeriodicBox=False, groups=-1):
+                 getParameters=False, enforcePeriodicBox=False, groups=-1, getParameterDerivatives=False):
         if isinstance(groups, (set, list, tuple, frozenset)):
             mask = 0
             for g in groups:
                 mask |= 1 << int(g)
         else:
             mask = int(groups) & 0xFFFFFFFF
-        return self._engine.get_state(getPositions, getVelocities, getForces, getEnergy, mask)
+        state = self._engine.get_state(getPositions, getVelocities, getForces, getEnergy, mask)
+        if getParameterDerivatives:
+            # the parameters some force asked for with addEnergyParameterDerivative (e.g. AlchemicalSystem, systems.py:390)
+            names = []
+            for force in self._system.getForces():
+                for name in getattr(force, '_derivs', ()):
+                    if name not in names:
+                        names.append(name)
+            state._derivatives = {name: self._engine.energy_derivative(name) for name in names}
+        return state
 
     def reinitialize(self, preserveState=False):
         self._engine.reinitialize(preserveState)

@@ -10,8 +10,8 @@ Given a System, it re-groups the nonbonded interactions for RESPA integration:
 
 The integrator forms the slow force as f2 - f1 (propagators.py:917-919).  Each custom force built
 here also carries the structured descriptor the HIP engine consumes (see atomsmm_amd.forces).
-Alchemical inputs (CustomNonbondedForces named U_linear/U_spline/U_art/U_general, systems.py:83-95)
-are outside this round's scope.
+RESPA splitting of AlchemicalSystem's coupling force (CustomNonbondedForces named U_linear/U_spline/U_art/U_general,
+systems.py:83-95) is not built: the constructor refuses such inputs.
 """
 import copy
 import itertools
@@ -185,6 +185,76 @@ class SolvationSystem(openmm.System):
             nonbonded.addGlobalParameter('lambda_vdw', 1.0)
             for index, (sigma, epsilon) in lj_parameters.items():
                 nonbonded.addParticleParameterOffset('lambda_vdw', index, 0.0, sigma, epsilon)
+
+
+class AlchemicalSystem(openmm.System):
+    """`atomsmm.systems.AlchemicalSystem(system, atoms, coupling='softcore', group=0, use_lrc=False)` (reference:
+    src/atomsmm/systems.py:318-410): a System prepared for solvation free-energy calculations with one coupling
+    parameter, `lambda_vdw`.
+
+    * the Lennard-Jones interactions between the solute `atoms` and everything else move to a CustomNonbondedForce over
+      that interaction group (force group `group`, per-particle parameters `sigma` and `epsilon`, lambda_vdw registered as
+      an energy parameter derivative).  `coupling` selects its energy: `softcore` (Beutler et al. 1994), or
+      Lennard-Jones times ((gt0-gt1)*S + gt1) with S(lambda_vdw) = `linear` / `art` (Abrams, Rosso & Tuckerman 2006) /
+      `spline` / any other text, taken as the function itself.  The emitted strings are the reference's, including its
+      `linear` variant that names `two_pi` without defining it (a Context then refuses it, as OpenMM does);
+    * the solute atoms lose charge and epsilon in the NonbondedForce (charge 0, sigma 1, epsilon 0);
+    * every solute-solute pair that is not an exception yet becomes one, with the combined original parameters, and is
+      excluded from the coupling force.
+    """
+
+    _COUPLINGS = {'linear': 'lambda_vdw - sin(two_pi*lambda_vdw)/two_pi',
+                  'spline': 'lambda_vdw^3*(10 - 15*lambda_vdw + 6*lambda_vdw^2)',
+                  'art': 'lambda_vdw - sin(two_pi*lambda_vdw)/two_pi; two_pi = 6.28318530717958'}
+
+    @classmethod
+    def _energy_text(cls, coupling):
+        mixing = '; sigma = 0.5*(sigma1 + sigma2); epsilon = sqrt(epsilon1*epsilon2)'
+        if coupling == 'softcore':
+            return ('U_softcore; U_softcore = 4*lambda_vdw*epsilon*(1 - x)/x^2'
+                    '; x = (r/sigma)^6 + 0.5*(1 - lambda_vdw)') + mixing
+        label = 'U_{}'.format(coupling) if coupling in cls._COUPLINGS else 'U_general'
+        return ('{0}; {0} = 4*((gt0-gt1)*S + gt1)*epsilon*x*(x - 1); x = (sigma/r)^6; gt0 = step(lambda_vdw)'
+                '; gt1 = step(lambda_vdw-1); S = {1}').format(label, cls._COUPLINGS.get(coupling, coupling)) + mixing
+
+    def __init__(self, system, atoms, coupling='softcore', group=0, use_lrc=False):
+        openmm.System.__init__(self)
+        self._copy_from(system)
+        nonbonded = self.getForce(utils.findNonbondedForce(self))
+        solute = sorted(set(int(i) for i in atoms))
+        everyone = range(nonbonded.getNumParticles())
+        pair_force = openmm.CustomNonbondedForce(self._energy_text(coupling))
+        free_space = nonbonded.getNonbondedMethod() == openmm.NonbondedForce.NoCutoff
+        pair_force.setNonbondedMethod(pair_force.NoCutoff if free_space else pair_force.CutoffPeriodic)
+        pair_force.setCutoffDistance(nonbonded.getCutoffDistance())
+        pair_force.setUseSwitchingFunction(nonbonded.getUseSwitchingFunction())
+        pair_force.setSwitchingDistance(nonbonded.getSwitchingDistance())
+        pair_force.setUseLongRangeCorrection(use_lrc)
+        pair_force.addGlobalParameter('lambda_vdw', 1.0)
+        for name in ('sigma', 'epsilon'):
+            pair_force.addPerParticleParameter(name)
+        original = {}
+        for index in everyone:
+            charge, sigma, epsilon = nonbonded.getParticleParameters(index)
+            pair_force.addParticle([sigma, epsilon])
+            original[index] = (charge, sigma, epsilon)
+        known = set()
+        for index in range(nonbonded.getNumExceptions()):
+            i, j = nonbonded.getExceptionParameters(index)[:2]
+            pair_force.addExclusion(i, j)
+            known.add(frozenset((i, j)))
+        pair_force.addInteractionGroup(set(solute), set(everyone) - set(solute))
+        pair_force.setForceGroup(group)
+        pair_force.addEnergyParameterDerivative('lambda_vdw')
+        self.addForce(pair_force)
+        for index in solute:
+            nonbonded.setParticleParameters(index, 0.0, 1.0, 0.0)
+        for i, j in itertools.combinations(solute, 2):
+            if frozenset((i, j)) in known:
+                continue
+            (q1, sig1, eps1), (q2, sig2, eps2) = original[i], original[j]
+            nonbonded.addException(i, j, q1 * q2, (sig1 + sig2) / 2, (eps1 * eps2).sqrt())
+            pair_force.addExclusion(i, j)          # both forces keep the same number of excluded pairs
 
 
 class _AtomsMM_System(openmm.System):

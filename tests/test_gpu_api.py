@@ -380,6 +380,97 @@ def test_SolvationSystem_with_lj_parameter_scaling(heaq):          # tests/test_
                         'Reciprocal-Space': -76436.3982762784, 'Total': -15273.024197108643})
 
 
+def test_AlchemicalSystem_softcore_meets_the_SolvationSystem_literal(heaq):
+    """AlchemicalSystem (systems.py:318-410) with the softcore coupling and the long-range correction: its coupling force is
+    SolvationSystem's softcore force -- same expression, interaction group and exclusions -- so at lambda_vdw = 0.5 it
+    must return the literal the reference's test holds for that force (tests/test_systems.py:28-42)."""
+    system, positions, topology, solute = _heaq_system(heaq)
+    alchemical_system = atomsmm.AlchemicalSystem(system, solute, group=5, use_lrc=True)
+    components = atomsmm.splitPotentialEnergy(alchemical_system, topology, positions, lambda_vdw=0.5)
+    assert components['CustomNonbondedForce'] / components['CustomNonbondedForce'].unit == pytest.approx(-64.67189605331785)
+    # the solute carries no charge any more: the rest is SolvationSystem at lambda_coul = 0
+    reference = atomsmm.splitPotentialEnergy(atomsmm.SolvationSystem(system, solute), topology, positions,
+                                             lambda_vdw=0.5, lambda_coul=0.0)
+    for term in ('Real-Space', 'Reciprocal-Space', 'HarmonicBondForce', 'Total'):
+        assert components[term]._value == pytest.approx(reference[term]._value, rel=1e-12), term
+
+
+@pytest.mark.parametrize('coupling', ['spline', 'art', 'lambda_vdw^2'])
+def test_AlchemicalSystem_coupling_functions(heaq, coupling):
+    """Lennard-Jones times ((gt0-gt1)*S + gt1) (systems.py:353-365): the energy of the coupling force is S(lambda) times the
+    solute-solvent Lennard-Jones energy -- which is the softcore force at lambda = 1, pinned to the oracle elsewhere -- and
+    deriv(energy, lambda_vdw) is S'(lambda) times it."""
+    system, positions, topology, solute = _heaq_system(heaq)
+    S = {'spline': lambda x: x ** 3 * (10 - 15 * x + 6 * x * x), 'art': lambda x: x - np.sin(2 * np.pi * x) / (2 * np.pi),
+         'lambda_vdw^2': lambda x: x * x}[coupling]
+    dS = {'spline': lambda x: 30 * x * x * (1 - x) ** 2, 'art': lambda x: 1 - np.cos(2 * np.pi * x),
+          'lambda_vdw^2': lambda x: 2 * x}[coupling]
+
+    def coupling_energy(sys_, lam):
+        context = openmm.Context(sys_, openmm.VerletIntegrator(0.0))
+        context.setPositions(positions)
+        context.setParameter('lambda_vdw', lam)
+        return context, context.getState(getEnergy=True, groups={7}).getPotentialEnergy()._value
+
+    _, full = coupling_energy(atomsmm.AlchemicalSystem(system, solute, coupling='softcore', group=7), 1.0)
+    codes = np.where(heaq['resname'] == 'aaa', 1.0, 2.0)
+    d = O.desc(O.SOFTCORE, rc=1.0, rswitch=0.9, alpha=1.0, flags=O.SWITCH, Kc=1.0)
+    nb = system.getForce(atomsmm.findNonbondedForce(system))
+    excl = [nb.getExceptionParameters(k)[:2] for k in range(nb.getNumExceptions())]
+    ref = O.pair_eval(d, heaq['positions'], heaq['box'], codes, heaq['sigma'], heaq['epsilon'], excl, want_forces=False)[0]
+    assert full == pytest.approx(ref, rel=1e-11)
+    alch = atomsmm.AlchemicalSystem(system, solute, coupling=coupling, group=7)
+    for lam in (0.0, 0.3, 0.8, 1.0, 1.4):
+        context, value = coupling_energy(alch, lam)
+        factor = 0.0 if lam < 0 else (1.0 if lam >= 1 else S(lam))
+        assert value == pytest.approx(factor * full, rel=1e-12, abs=1e-10), lam
+        if 0 < lam < 1:
+            derivatives = context.getState(getParameterDerivatives=True).getEnergyParameterDerivatives()
+            assert derivatives['lambda_vdw'] == pytest.approx(dS(lam) * full, rel=1e-6), lam
+
+
+def test_energy_derivative_of_charge_offsets(heaq):
+    """deriv(energy, lambda_coul) for SolvationSystem's charge offsets (systems.py:289-308): the energy is a quadratic form of
+    the charges, so a unit central step is exact.  Checked (i) against the same difference quotient taken through the public
+    API at another step, on PME; (ii) against the oracle's pair energies at lambda +- 1 on the reaction-field system, whose
+    lambda-dependent part is the direct-space sum alone."""
+    system, positions, topology, solute = _heaq_system(heaq)
+    solv = atomsmm.SolvationSystem(system, solute)
+    context = openmm.Context(solv, openmm.VerletIntegrator(0.0))
+    context.setPositions(positions)
+    context.setParameter('lambda_coul', 0.35)
+    d = context._engine.energy_derivative('lambda_coul')
+    assert context.getParameter('lambda_coul') == 0.35
+    e = []
+    for lam in (0.6, 0.1, 0.35):
+        context.setParameter('lambda_coul', lam)
+        e.append(context.getState(getEnergy=True).getPotentialEnergy()._value)
+    assert d == pytest.approx((e[0] - e[1]) / 0.5, rel=1e-9)
+    assert context._engine.energy_derivative('lambda_coul') == pytest.approx(d, rel=1e-12)     # state restored: same answer again
+    # reaction field: against the oracle
+    rf_system, _, _ = create_system(heaq, nonbondedMethod='CutoffPeriodic', cutoff=1.0, switch=0.9)
+    rf = atomsmm.SolvationSystem(rf_system, solute)
+    context = openmm.Context(rf, openmm.VerletIntegrator(0.0))
+    context.setPositions(positions)
+    lam = 0.35
+    context.setParameter('lambda_coul', lam)
+    d = context._engine.energy_derivative('lambda_coul')
+    nb = rf.getForce(atomsmm.findNonbondedForce(rf))
+    excl = [nb.getExceptionParameters(k)[:2] for k in range(nb.getNumExceptions())]
+    sig = heaq['sigma'].copy()
+    eps = heaq['epsilon'].copy()
+    member = heaq['resname'] == 'aaa'
+    sig[member], eps[member] = 0.0, 0.0
+    eps_rf = nb.getReactionFieldDielectric()
+    krf, crf = (eps_rf - 1) / (2 * eps_rf + 1), 3 * eps_rf / (2 * eps_rf + 1)
+    dd = O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, flags=O.SWITCH | O.COULOMB_RF, krf=krf, crf=crf)
+    ref = []
+    for point in (lam + 1.0, lam - 1.0):
+        q = np.where(member, point * heaq['charge'], heaq['charge'])
+        ref.append(O.pair_eval(dd, heaq['positions'], heaq['box'], q, sig, eps, excl, want_forces=False)[0])
+    assert d == pytest.approx((ref[0] - ref[1]) / 2.0, rel=1e-9)
+
+
 def test_RESPASystem_on_SolvationSystem(heaq):                     # tests/test_systems.py:61-80
     system, positions, topology, solute = _heaq_system(heaq)
     solvation_system = atomsmm.SolvationSystem(system, solute)

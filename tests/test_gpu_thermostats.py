@@ -416,8 +416,14 @@ def test_energy_parameter_derivative_of_softcore_force(heaq):
             ref.append(O.pair_eval(dd, h['positions'], h['box'], codes, h['sigma'], h['epsilon'], h['exc_pairs'], want_forces=False)[0] +
                        O.softcore_lrc(h['sigma'], h['epsilon'], codes, h['box'], 1.0, 0.9, lam + sgn * eps_))
         assert d == pytest.approx((ref[0] - ref[1]) / (2 * eps_), rel=2e-6)
-    with pytest.raises(NotImplementedError):
-        context._engine.energy_derivative('lambda_coul')       # charge offsets: no derivative kernels
+    # charge offsets: exact unit-step difference of a quadratic form (tests/test_gpu_api.py checks it against the oracle)
+    context.setParameter('lambda_coul', 0.5)
+    d = context._engine.energy_derivative('lambda_coul')
+    e = []
+    for point in (0.75, 0.25):
+        context.setParameter('lambda_coul', point)
+        e.append(context.getState(getEnergy=True).getPotentialEnergy()._value)
+    assert d == pytest.approx((e[0] - e[1]) / 0.5, rel=1e-9)
 
 
 def test_adiabatic_free_energy_dynamics_runs(heaq):

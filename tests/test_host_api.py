@@ -625,3 +625,57 @@ def test_create_system_options():
     assert n_h_bonds > 0 and free.getForce(0).getNumBonds() - hbonds.getForce(0).getNumBonds() == n_h_bonds
     with pytest.raises(ValueError):
         A.ForceField(os.path.join(GOLDEN, 'data', 'q-SPC-FW.xml')).createSystem(emim_pdb.topology)
+
+
+# ------------------------------------------------------------------------------------ AlchemicalSystem (systems.py:318-410)
+def test_alchemical_system_structure_and_coupling_translation(heaq, recorder):
+    system = system_from_arrays(heaq, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
+    solute = set(int(i) for i in np.where(heaq['resname'] == 'aaa')[0])
+    alch = atomsmm.AlchemicalSystem(system, solute, group=3, use_lrc=True)
+    nb = alch.getForce(atomsmm.findNonbondedForce(alch))
+    pair = [f for f in alch.getForces() if isinstance(f, openmm.CustomNonbondedForce)]
+    assert len(pair) == 1 and pair[0].getForceGroup() == 3 and pair[0].getUseLongRangeCorrection()
+    text = pair[0].getEnergyFunction()
+    assert text == ('U_softcore; U_softcore = 4*lambda_vdw*epsilon*(1 - x)/x^2; x = (r/sigma)^6 + 0.5*(1 - lambda_vdw)'
+                    '; sigma = 0.5*(sigma1 + sigma2); epsilon = sqrt(epsilon1*epsilon2)')
+    assert [pair[0].getPerParticleParameterName(k) for k in range(2)] == ['sigma', 'epsilon']
+    assert pair[0].getNumExclusions() == nb.getNumExceptions() and pair[0].getNumInteractionGroups() == 1
+    for i in solute:
+        q, s, e = nb.getParticleParameters(i)
+        assert (q._value, s._value, e._value) == (0.0, 1.0, 0.0)
+    assert nb.getNumParticleParameterOffsets() == 0            # no lambda_coul: the solute charges are simply gone
+    d = F.describe_energy(text)
+    assert d['family'] == 'softcore' and d['lambda_name'] == 'lambda_vdw'
+    ctx = openmm.Context(alch, openmm.VerletIntegrator(0.0))
+    sc = [p for p in recorder[-1].pairs if p['family'] == B.SOFTCORE]
+    assert len(sc) == 1 and np.array_equal(sc[0]['q'], np.where(heaq['resname'] == 'aaa', 1.0, 2.0))
+    assert np.array_equal(sc[0]['sigma'], heaq['sigma'])      # two per-particle columns, mapped by name
+    ctx.setParameter('lambda_vdw', 0.25)
+    assert ('pair_set_lambda', sc[0]['id'], 0.25) in recorder[-1].calls
+
+    # Lennard-Jones times a coupling function: the factor goes to the backend as the overall scale of a plain LJ pair force
+    spline = atomsmm.AlchemicalSystem(system, solute, coupling='spline')
+    text = [f for f in spline.getForces() if isinstance(f, openmm.CustomNonbondedForce)][0].getEnergyFunction()
+    assert text.startswith('U_spline; U_spline = 4*((gt0-gt1)*S + gt1)*epsilon*x*(x - 1); x = (sigma/r)^6; gt0 = step(lambda_vdw)'
+                           '; gt1 = step(lambda_vdw-1); S = lambda_vdw^3*(10 - 15*lambda_vdw + 6*lambda_vdw^2)')
+    d = F.describe_energy(text)
+    assert d['family'] == 'lj' and 'S=lambda_vdw^3' in d['scale_text']
+    ctx = openmm.Context(spline, openmm.VerletIntegrator(0.0))
+    rec = recorder[-1]
+    lj = [p for p in rec.pairs if p['family'] == B.NONBONDED and p['flags'] & B.GROUP_LJ]
+    assert len(lj) == 1 and lj[0]['sign'] == 1.0
+    ctx.setParameter('lambda_vdw', 0.5)
+    assert ('pair_set_scale', lj[0]['id'], 0.5) in rec.calls         # S(1/2) = 1/2
+    ctx.setParameter('lambda_vdw', 1.5)
+    assert ('pair_set_scale', lj[0]['id'], 1.0) in rec.calls         # beyond the end point: fully coupled
+    custom = atomsmm.AlchemicalSystem(system, solute, coupling='lambda_vdw^2')
+    assert 'U_general = ' in [f for f in custom.getForces() if isinstance(f, openmm.CustomNonbondedForce)][0].getEnergyFunction()
+    ctx = openmm.Context(custom, openmm.VerletIntegrator(0.0))
+    ctx.setParameter('lambda_vdw', 0.5)
+    assert any(c[0] == 'pair_set_scale' and c[2] == 0.25 for c in recorder[-1].calls)
+    # the reference's `linear` text leaves two_pi undefined (systems.py:359): no Context can be made of it
+    with pytest.raises(openmm.OpenMMException):
+        openmm.Context(atomsmm.AlchemicalSystem(system, solute, coupling='linear'), openmm.VerletIntegrator(0.0))
+    # RESPA splitting of the coupling force (systems.py:83-95) is not built
+    with pytest.raises(NotImplementedError):
+        atomsmm.RESPASystem(spline, 7 * unit.angstroms, 5 * unit.angstroms)
