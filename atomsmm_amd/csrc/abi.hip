@@ -238,8 +238,8 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     AMM_HIP(hipMalloc(&pf->d_pos4f_s, sizeof(float4) * n));
     AMM_HIP(hipMalloc(&pf->d_xref, sizeof(double) * 3 * n));
     AMM_HIP(hipMalloc(&pf->d_xref_out, sizeof(double) * 3 * n));
-    AMM_HIP(hipMalloc(&pf->d_flags, sizeof(int) * 8));
-    AMM_HIP(hipMemset(pf->d_flags, 0, sizeof(int) * 8));
+    AMM_HIP(hipMalloc(&pf->d_flags, sizeof(int) * 16));
+    AMM_HIP(hipMemset(pf->d_flags, 0, sizeof(int) * 16));
     AMM_HIP(hipMalloc(&pf->d_ticket, sizeof(int) * 4));
     AMM_HIP(hipMemset(pf->d_ticket, 0, sizeof(int) * 4));
     AMM_HIP(hipMalloc(&pf->d_counters, sizeof(unsigned long long) * 8));

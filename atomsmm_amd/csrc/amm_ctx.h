@@ -103,6 +103,8 @@ struct PairForce {
     double tab_error = 0;          // largest relative interpolation error found when the table was built
     int *d_cls = nullptr;          // per atom (original order): 1 = no Lennard-Jones site (eps = 0) -- sorted behind the others in its cell
     int *d_cell_count_lj = nullptr, *d_cell_start_lj = nullptr;   // per cell: atoms WITH a Lennard-Jones site (count, exclusive scan)
+    int active_cap = 0;            // rows the pair kernels' grid covers when d_active is walked
+    int *d_active = nullptr;       // filtered lists: slice-relative rows that hold entries (their number: flags[8])
     float *d_member = nullptr;     // interaction-group forces: set code of each atom (0 none, 1, 2); the list keeps only (1, 2) pairs
     int *d_row_order = nullptr;    // traversal order of the slice's rows: rows with a Lennard-Jones site first (wave-uniform LJ skip)
     bool built = false;

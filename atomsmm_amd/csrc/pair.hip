@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
     }
     const int gi0 = s_begin - ga0;
     if (row_order && wave == 0 && lane == 0) n_lj_out[0] = ga1 - ga0;
+    if (wave == 0 && lane == 0) n_lj_out[5] = 0;      // flags[8]: rows with entries of a filtered list, counted by the build that follows
     for (int a0 = 0; a0 < cnt; a0 += 64) {
         const int a = a0 + lane;
         const int me = a < cnt ? mem[a] : 0;
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                               const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2, float rnear2,
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
                               int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
-                              unsigned long long *counters, int *ticket, int which, int force, int filtered) {
+                              unsigned long long *counters, int *ticket, int which, int force, int filtered, int *active, int active_cap) {
     if (!force && !flags[which]) return;
     __shared__ int s_rstart[4][64];
     __shared__ int s_rpref[4][64];
@@ -555,6 +556,19 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                 wnear += (unsigned long long)count;
                 wmax = max(wmax, total_nb);
             }
+            // filtered lists (interaction groups): most rows are empty -- the rows that hold entries are collected (any order:
+            // a row has one producer whatever its place in the walk) so that the pair kernels visit only those; flags[8] counts
+            if (!COUNT_ONLY && active) {
+                const bool holds = lane < nt && count + countf > 0 && count + countf <= cap;
+                const unsigned long long m_act = __builtin_amdgcn_ballot_w64(holds);
+                if (m_act != 0ull) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&flags[8], __popcll(m_act));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (lane == 0 && base + __popcll(m_act) > active_cap) flags[1] = 1;   // more rows than the pair kernels' grid covers
+                    if (holds) active[base + __popcll(m_act & below)] = tb + lane - s_begin;
+                }
+            }
         }
     }
     // per-block (sum, max) of the list lengths -> blockstats; the last block reduces them.  (One same-address
@@ -699,6 +713,8 @@ struct PairArgs {
     int gaccumulate;
     int sorted_out;    // exchange by all-gather: rows go to force[3 (s - s_begin)] (this rank's chunk of the exchange buffer)
     int gsame;         // the guest accumulates into the SAME rows as the host (fused FarNonbondedForce): one store of the sum
+    const int *active;     // filtered lists: the rows that hold entries (slice-relative) ...
+    const int *n_active;   // ... and their number (device); null: every row of the slice is walked
 };
 
 
@@ -712,10 +728,15 @@ template <int FAM, int CMODE, bool GUARD, bool EN, int UNR, int GFAM, bool GROUP
 __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, PairConsts gc) {
     const int lpa = 1 << A.lpa_shift;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int a = tid >> A.lpa_shift;
+    int a = tid >> A.lpa_shift;
     const int sub = tid & (lpa - 1);
+    bool listed = true;
+    if (A.active) {        // only the rows that hold entries; the caller has zeroed the others' outputs
+        listed = a < *A.n_active;
+        a = listed ? A.active[a] : 0;
+    }
     const int s = A.s_begin + a;
-    const bool valid = s < A.s_end;
+    const bool valid = listed && s < A.s_end;
     constexpr bool NEEDS_ERFC = (FAM == AMM_DAMPED) || (FAM == AMM_NONBONDED && CMODE == 1);
     __shared__ double s_tab[NEEDS_ERFC ? AMM_ERFCX_NI * AMM_ERFCX_NC : 1];
     if (NEEDS_ERFC) {
@@ -1337,7 +1358,7 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
                        pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
                        pf->d_excl_idx, cap, nl, nnb, nnb_near, pf->d_flags, pf->d_blockstats, pf->d_counters,      \
-                       pf->d_ticket + 1, which, force, pf->d_member ? 1 : 0)
+                       pf->d_ticket + 1, which, force, pf->d_member ? 1 : 0, direct ? pf->d_active : (int *)nullptr, pf->active_cap)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
         else AMM_LAUNCH_BUILD(true, false);
@@ -1395,6 +1416,8 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     AMM_HIP(hipMalloc(&pf->d_nnb_out, sizeof(int) * ns));
     AMM_HIP(hipMalloc(&pf->d_nnb_scratch, sizeof(int) * ns));
     AMM_HIP(hipMalloc(&pf->d_row_order, sizeof(int) * ns));
+    if (pf->d_member && !(pf->skin_out > pf->skin * (1 + 1e-9))) AMM_HIP(hipMalloc(&pf->d_active, sizeof(int) * ns));
+    pf->active_cap = (int)ns;
     // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding, but not beyond 16 lanes: longer
     // strides waste the tail of every row (measured on 1/8 slices of C3, scripts/probe_slices.py: dual pass 63.6 us
     // with 16 lanes, 71.9 us with 64)
@@ -1454,6 +1477,14 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         }
         AMM_HIP(hipMalloc(&pf->d_nl, sizeof(int) * ns * pf->cap));
         if (cell_build_chain(ctx, pf, d_pos, 1, false, true)) return 1;
+    }
+    if (pf->d_active) {
+        // rows that hold entries: the pair kernels' grid covers twice the first build's number (+ 64); more than that later on
+        // is reported by amm_check like a row overflow
+        int f16[16];
+        AMM_HIP(hipMemcpyAsync(f16, pf->d_flags, sizeof(f16), hipMemcpyDeviceToHost, ctx->stream));
+        AMM_HIP(hipStreamSynchronize(ctx->stream));
+        pf->active_cap = (int)std::min<size_t>(ns, (size_t)2 * f16[8] + 64);
     }
     pf->built = true;
     return 0;
@@ -1573,7 +1604,20 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         A.gaccumulate = g_accumulate;
         A.gsame = (guest && g_force == d_force && !exchange) ? 1 : 0;
         A.sorted_out = exchange ? 1 : 0;
-        const long threads = (long)nslice << A.lpa_shift;
+        A.active = nullptr;
+        A.n_active = nullptr;
+        int rows = nslice;
+        if (L->d_active && !exchange && !guest) {
+            // interaction-group force: walk the rows that hold entries, the others' forces are zero.  Those rows are few and
+            // either long (a solute atom against all the solvent around it) or a handful of entries: a whole wavefront each
+            A.active = L->d_active;
+            A.n_active = L->d_flags + 8;
+            if (!accumulate && ctx->world == 1) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, st));
+            A.accumulate = 1;
+            A.lpa_shift = 6;
+            rows = std::min(nslice, L->active_cap);
+        }
+        const long threads = (long)rows << A.lpa_shift;
         const int nblk = (int)((threads + 255) / 256);
         const bool en = d_energy != nullptr;
         if (en && nblk > pf->n_epart) {
@@ -1791,7 +1835,7 @@ int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos,
 }
 
 // bump when a pair-traversal kernel changes: stored measurements (profiles/*_traffic.json) are matched against it
-const char *amm_kernel_revision_impl() { return "r02-tab2"; }
+const char *amm_kernel_revision_impl() { return "r02-tab3"; }
 
 // radial Coulomb table of the force-only traversal (pair_tab.h): built from the descriptor alone, once per pair force
 int amm_pair_build_table(PairForce *pf) {
@@ -1842,7 +1886,7 @@ int amm_pair_free(PairForce *pf) {
                     pf->d_cell_start, pf->d_cell_members, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
                     pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near, pf->d_nl_out, pf->d_nnb_out,
                     pf->d_nnb_scratch, pf->d_xref_out, pf->d_ticket, pf->d_tab, pf->d_cls, pf->d_cell_count_lj, pf->d_cell_start_lj,
-                    pf->d_row_order, pf->d_member};
+                    pf->d_row_order, pf->d_member, pf->d_active};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);

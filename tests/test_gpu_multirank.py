@@ -33,7 +33,9 @@ def _simulate(nsteps, pme=False):
         outer.setForceGroup(2)
         outer.addTo(respa)
     integrator = atomsmm.RespaPropagator([4, 2, 1]).integrator(2 * unit.femtoseconds)
-    sim = app.Simulation(app.Topology(), respa, integrator, openmm.Platform.getPlatformByName('HIP'))
+    # equal Verlet buffers on both sides of the comparison: the default grows with the number of ranks, and another buffer means
+    # other (masked) entries between the same pairs in a row, i.e. another order of the partial sums
+    sim = app.Simulation(app.Topology(), respa, integrator, openmm.Platform.getPlatformByName('HIP'), {'Skin': '0.1'})
     sim.context.setPositions(c['positions'] * unit.nanometers)
     sim.context.setVelocities(c['velocities'])
     e0 = sim.context.getState(getEnergy=True).getPotentialEnergy()._value
@@ -165,8 +167,8 @@ def test_exchange_chunks_of_five_uneven_slices():
 
     def make(rank, w):
         ctx = B.HipContext(n, c['box'], rank=rank, world=w)
-        fn = hip_pair(B, ctx, dn, c)
-        ff = hip_pair(B, ctx, dd, c)
+        fn = hip_pair(B, ctx, dn, c, skin=0.1)         # equal buffers on both sides: the default grows with the world
+        ff = hip_pair(B, ctx, dd, c, skin=0.1)
         ctx.pair_share_list(fn, ff)
         x, v, m = dev(c['positions']), dev(c['velocities']), dev(c['mass'])
         f = [torch.zeros((n, 3), dtype=torch.float64, device='cuda') for _ in range(3)]
@@ -234,7 +236,7 @@ def test_exchange_with_empty_slices_on_a_tiny_box():
 
     def make(rank, w):
         ctx = B.HipContext(n, c['box'], rank=rank, world=w)
-        fn = hip_pair(B, ctx, dn, c)
+        fn = hip_pair(B, ctx, dn, c, skin=0.1)         # equal buffers on both sides: the default grows with the world
         x, v, m = dev(c['positions']), dev(c['velocities']), dev(c['mass'])
         f = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
         ctx.bind_state(x, v, m)
@@ -294,8 +296,8 @@ def test_c3_size_eight_slices_all_gather_bit_identical(monkeypatch):
 
     def make(rank, w):
         ctx = B.HipContext(n, c['box'], rank=rank, world=w)
-        fn = hip_pair(B, ctx, dn, c)
-        ff = hip_pair(B, ctx, dd, c)
+        fn = hip_pair(B, ctx, dn, c, skin=0.1)         # equal buffers on both sides: the default grows with the world
+        ff = hip_pair(B, ctx, dd, c, skin=0.1)
         ctx.pair_share_list(fn, ff)
         x, v, m = dev(c['positions']), dev(c['velocities']), dev(c['mass'])
         f = [torch.zeros((n, 3), dtype=torch.float64, device='cuda') for _ in range(3)]
