@@ -407,8 +407,9 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
             if (lane >= off) incl += v;
         }
         const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int prefv = incl - rlen;           // exclusive prefix (lane r: first stream index of run r); lanes >= nr hold `total`
         s_rstart[w][lane] = rstart;
-        s_rpref[w][lane] = incl - rlen;          // exclusive prefix; lanes >= nr hold `total`
+        s_rpref[w][lane] = prefv;
         s_rshift[w][0][lane] = rsx;
         s_rshift[w][1][lane] = rsy;
         s_rshift[w][2][lane] = rsz;
@@ -465,24 +466,34 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
             }
             // Row layout: entries with r < rnear fill the row from the front, the others from the back, so a
             // shorter-ranged force sharing this list walks only the front part.
+            int r0 = 0;                                   // run that holds stream index cb (wave-uniform, only ever advances)
             for (int cb = 0; cb < total; cb += AMM_BCHUNK) {
                 float4 cand[2];
                 int js[2];
                 bool inr = false;
+                // run of every lane's candidate: r0 + the number of run boundaries at or below its stream index.  The few
+                // boundaries inside a chunk are read from the prefix register with scalar lane selects -- a per-lane
+                // binary search of the LDS copy was six dependent LDS round trips per half chunk
+                while (r0 + 1 < nr && __builtin_amdgcn_readlane(prefv, r0 + 1) <= cb) ++r0;
+                int ru[2] = {r0, r0};
+                for (int k = r0 + 1; k < nr; ++k) {
+                    const int first = __builtin_amdgcn_readlane(prefv, k);
+                    if (first >= cb + AMM_BCHUNK) break;
+                    ru[0] += (cb + lane) >= first;
+                    ru[1] += (cb + 64 + lane) >= first;
+                }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int idx = cb + u * 64 + lane;
                     const bool in = idx < total;
-                    int r = 0;
-#pragma unroll
-                    for (int step = 32; step > 0; step >>= 1)
-                        if (s_rpref[w][r + step] <= idx) r += step;
+                    const int r = ru[u];
                     const int slot = in ? s_rstart[w][r] + idx - s_rpref[w][r] : 0;
                     float4 q = pos4f_s[slot];
                     if (!RINT) {             // image shift; lanes beyond the stream are parked far away
-                        q.x = in ? q.x + s_rshift[w][0][r] : FAR;
-                        q.y = in ? q.y + s_rshift[w][1][r] : FAR;
-                        q.z = in ? q.z + s_rshift[w][2][r] : FAR;
+                        const float sx = s_rshift[w][0][r], sy = s_rshift[w][1][r], sz = s_rshift[w][2][r];
+                        q.x = in ? q.x + sx : FAR;
+                        q.y = in ? q.y + sy : FAR;
+                        q.z = in ? q.z + sz : FAR;
                     }
                     cand[u] = q;
                     js[u] = in ? slot : -1;
@@ -1103,21 +1114,13 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
     const int rpw = 64 >> A.lpa_shift;
     const int n_lj = T.n_lj ? min(*T.n_lj, T.nslice) : T.nslice;
     const int t_lj = (n_lj + rpw - 1) / rpw, t_h = (T.nslice - n_lj + rpw - 1) / rpw;
-    // Each pool is cut into 16 chunks of consecutive tasks (consecutive cell-sorted rows: slabs of the box); XCD x owns chunks
-    // x and x + 8.  One contiguous eighth per XCD would give the two XCDs at the ends of the sorted order the slabs at the box
-    // faces, where every row needs the minimum-image arithmetic (+ 25 % instructions): with two slabs each, every XCD holds at
-    // most one face slab, and its gathers still come from 2 x (0.62 + 2.2) nm of the box -- within its 4 MiB of L2.
-    const int per_lj = (t_lj + 15) >> 4, per_h = (t_h + 15) >> 4;
-    auto chunk = [](int which, int per, int total, int &first, int &count) {
-        first = min(which * per, total);
-        count = min(first + per, total) - first;
-    };
-    int lj_a, nlj_a, lj_b, nlj_b, h_a, nh_a, h_b, nh_b;
-    chunk(xcd, per_lj, t_lj, lj_a, nlj_a);
-    chunk(xcd + 8, per_lj, t_lj, lj_b, nlj_b);
-    chunk(xcd, per_h, t_h, h_a, nh_a);
-    chunk(xcd + 8, per_h, t_h, h_b, nh_b);
-    const int nlj_x = nlj_a + nlj_b, nh_x = nh_a + nh_b;
+    // one contiguous eighth of either pool per XCD: consecutive cell-sorted rows, i.e. a slab of the box, whose gathers (the
+    // slab + one list radius either side: 3.4 MB at 249k atoms, 2 MB at 98k) stay in the XCD's 4 MiB of L2.  (Two thinner
+    // slabs per XCD -- to spread the face slabs, whose rows all need the minimum image -- gained nothing at 98k atoms and
+    // overflowed the L2 at 249k.)
+    const int per_lj = (t_lj + 7) >> 3, per_h = (t_h + 7) >> 3;
+    const int lj0 = min(xcd * per_lj, t_lj), nlj_x = min(lj0 + per_lj, t_lj) - lj0;
+    const int h0 = min(xcd * per_h, t_h), nh_x = min(h0 + per_h, t_h) - h0;
     const int ntask_x = nlj_x + nh_x;
     // static deal: position p of the XCD's task sequence goes to wavefront p mod nwx.  The sequence interleaves the two
     // pools in proportion (position p is a Lennard-Jones task iff floor((p + 1) nlj / n) > floor(p nlj / n)), so every
@@ -1126,9 +1129,8 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
     for (int p = (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); p < ntask_x; p += nwx) {
         const int before = (int)(((long long)p * nlj_x) / ntask_x), upto = (int)(((long long)(p + 1) * nlj_x) / ntask_x);
         const bool lj_pool = upto > before;
-        const int local = lj_pool ? before : p - upto;                    // index within the XCD's share of its pool
-        const int task = lj_pool ? (local < nlj_a ? lj_a + local : lj_b + (local - nlj_a)) : (local < nh_a ? h_a + local : h_b + (local - nh_a));
-        const int a = (lj_pool ? 0 : n_lj) + task * rpw + (lane >> A.lpa_shift);
+        const int task = lj_pool ? before : nlj_x + (p - upto);
+        const int a = lj_pool ? (lj0 + task) * rpw + (lane >> A.lpa_shift) : n_lj + (h0 + task - nlj_x) * rpw + (lane >> A.lpa_shift);
         const bool valid = lj_pool ? a < n_lj : a < T.nslice;
         int s = A.s_begin;
         double4 pi = make_double4(0.0, 0.0, 0.0, 0.0);
@@ -1421,7 +1423,10 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding, but not beyond 16 lanes: longer
     // strides waste the tail of every row (measured on 1/8 slices of C3, scripts/probe_slices.py: dual pass 63.6 us
     // with 16 lanes, 71.9 us with 64)
-    int lpa = 1;
+    // never below 8: a wavefront's trip count is the maximum over its rows, and with 16 rows of 4 lanes the spread of the row
+    // lengths costs more than the shorter tails save (249k atoms, dual pass: 837 us with 4 lanes, 657 with 8, 643 with 16;
+    // 98k atoms: 229 us with 8, 240 with 16)
+    int lpa = 8;
     while (lpa < 16 && (long)nslice * lpa < 64L * 1024 * 8) lpa <<= 1;
     if (const char *e = getenv("AMM_LPA")) lpa = atoi(e);
     pf->lpa = lpa;
@@ -1835,7 +1840,7 @@ int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos,
 }
 
 // bump when a pair-traversal kernel changes: stored measurements (profiles/*_traffic.json) are matched against it
-const char *amm_kernel_revision_impl() { return "r02-tab3"; }
+const char *amm_kernel_revision_impl() { return "r02-tab4"; }
 
 // radial Coulomb table of the force-only traversal (pair_tab.h): built from the descriptor alone, once per pair force
 int amm_pair_build_table(PairForce *pf) {

@@ -717,20 +717,23 @@ class Engine:
 
         class_pairs = {}        # the (sigma, eps) classes depend on the offset parameters only, not on lambda
 
-        def quadrature(parameters, lam_value):
+        def classes_of(parameters):
             key = tuple(parameters[name] for name in names)
             if key not in class_pairs:
                 p = self._effective(base, scales, names, parameters)
                 class_pairs.clear()
                 class_pairs[key] = [lrc_class_pairs(p[:, 1], p[:, 2], codes), p[:, 1], p[:, 2], None]
-            return class_pairs[key], softcore_long_range_correction(
-                class_pairs[key][1], class_pairs[key][2], codes, self.box, rc, rswitch, lam_value, class_pairs[key][0])
+            return class_pairs[key]
+
+        def quadrature(parameters, lam_value):
+            record = classes_of(parameters)
+            return record, softcore_long_range_correction(record[1], record[2], codes, self.box, rc, rswitch, lam_value, record[0])
 
         def on_unit_interval(parameters):
             """The correction as a function of lambda on [0, 1] (it is analytic there): a Chebyshev interpolant through 24 of
             the quadrature's values, made once per set of offset parameters -- an AFED step asks for the correction and
             its lambda-derivative some twenty times, at 0.4 ms of host quadrature each otherwise."""
-            record, _ = quadrature(parameters, 1.0)
+            record = classes_of(parameters)
             if record[3] is None:
                 series = np.polynomial.Chebyshev.interpolate(
                     lambda nodes: np.array([quadrature(parameters, float(x))[1] for x in nodes]), 23, domain=[0.0, 1.0])

@@ -9,6 +9,7 @@ global expressions are evaluated on the host.  `gaussian` / `uniform` are ONE dr
 freedom, as in OpenMM (every occurrence inside one expression sees the same value).
 """
 import ast
+import functools
 import math
 import re
 
@@ -46,7 +47,10 @@ def _name(node_id):
     return node_id[:-len('__kw')] if node_id.endswith('__kw') else node_id
 
 
+@functools.lru_cache(maxsize=4096)
 def _parse(text):
+    """Syntax tree of one expression; cached (a host-walked step program evaluates the same few dozen texts every step;
+    nothing that walks the tree modifies it)."""
     try:
         tree = ast.parse(_KEYWORD.sub(r'\1__kw', text).replace('^', '**'), mode='eval').body
         for node in ast.walk(tree):
