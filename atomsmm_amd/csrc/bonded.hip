@@ -337,7 +337,8 @@ struct PosLds {
 // atom and a dependency chain of one term instead of the atom's whole record list (a water: 1 bond + 1 angle path per
 // iteration instead of 2 + 2).
 // HONLY: the set holds harmonic bonds and angles only (a flexible water model): the other kinds' code is compiled out.
-template <int G, bool BATH, bool TERMS, bool HONLY>
+// ISO: the isokinetic mode of SIN(R) exists in the kernel (its extra registers and tests are compiled out otherwise).
+template <int G, bool BATH, bool TERMS, bool HONLY, bool ISO>
 __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
     __shared__ double s_x[3][256];
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,7 +363,7 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
             for (int j = 0; j < 3; ++j) w[j] = C.bath_w[3 * a + j];
         }
     }
-    if (C.iso) {
+    if (ISO && C.iso) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) u1[j] = C.iso_v1[3 * a + j];
     }
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
             for (int j = 0; j < 3; ++j) {
                 double ff = pk.a[3 * a + j];
                 if (pk.b) ff = pk.plus ? ff + pk.b[3 * a + j] : ff - pk.b[3 * a + j];
-                if (C.iso) {
+                if (ISO && C.iso) {
                     amm_iso_kick(v[j], u1[j], ff, m, pk.coef, C.iso_LkT, C.iso_Q1);
                     continue;
                 }
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                if (C.iso) {
+                if (ISO && C.iso) {
                     amm_iso_kick(v[j], u1[j], f[j], m, C.c1, C.iso_LkT, C.iso_Q1);
                 } else {
                     const double num = C.c1 * f[j];
@@ -442,7 +443,7 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const double g = amm_gaussian(C.seed, counter, (unsigned)(3 * a + j));
-                if (C.bath_kind == 2) amm_sin_bath_step(v[j], u1[j], w[j], m, C.bath_h, C.bath_z, C.bath_kT, C.bath_Q, C.bath_friction, C.iso_Q1, C.iso_LkT, g);
+                if (ISO && C.bath_kind == 2) amm_sin_bath_step(v[j], u1[j], w[j], m, C.bath_h, C.bath_z, C.bath_kT, C.bath_Q, C.bath_friction, C.iso_Q1, C.iso_LkT, g);
                 else if (C.bath_kind == 1) amm_nhl_step(v[j], w[j], m, C.bath_h, C.bath_z, C.bath_kT, C.bath_Q, C.bath_friction, g);
                 else v[j] = amm_ou_step(v[j], m, C.bath_z, C.bath_kT, g);
             }
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                if (C.iso) {
+                if (ISO && C.iso) {
                     amm_iso_kick(v[j], u1[j], f[j], m, C.c2, C.iso_LkT, C.iso_Q1);
                     continue;
                 }
@@ -548,7 +549,7 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
                 for (int j = 0; j < 3; ++j) C.bath_w[3 * a + j] = w[j];
             }
         }
-        if (C.iso) {
+        if (ISO && C.iso) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) C.iso_v1[3 * a + j] = u1[j];
         }
@@ -875,8 +876,13 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     for (int kd = 2; kd < 8; ++kd) honly = honly && bs->n_terms[kd] == 0;
 #define AMM_LAUNCH_INNER(GG, BB, TT)                                                                          \
     do {                                                                                                        \
-        if (honly) hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT, true>), grid, block, 0, ctx->stream, A, C);   \
-        else hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT, false>), grid, block, 0, ctx->stream, A, C);         \
+        if (C.iso) {                                                                                            \
+            if (honly) hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT, true, true>), grid, block, 0, ctx->stream, A, C);    \
+            else hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT, false, true>), grid, block, 0, ctx->stream, A, C);        \
+        } else {                                                                                                \
+            if (honly) hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT, true, false>), grid, block, 0, ctx->stream, A, C);   \
+            else hipLaunchKernelGGL((k_inner_lanes<GG, BB, TT, false, false>), grid, block, 0, ctx->stream, A, C);       \
+        }                                                                                                       \
     } while (0)
     if (bath) {
         if (G == 4) { if (terms) AMM_LAUNCH_INNER(4, true, true); else AMM_LAUNCH_INNER(4, true, false); }
