@@ -31,7 +31,7 @@ NPAR = {BOND_HARMONIC: 2, ANGLE_HARMONIC: 2, BOND_LJC: 3, BOND_NEAR: 3, TORSION_
 EXPORTS = [
     'amm_abi_version', 'amm_last_error', 'amm_create', 'amm_destroy', 'amm_set_stream', 'amm_set_slice',
     'amm_synchronize', 'amm_check', 'amm_pair_create', 'amm_pair_set_params', 'amm_pair_share_list', 'amm_bonded_create',
-    'amm_bonded_add_terms', 'amm_bonded_finalize', 'amm_bonded_set_sliced', 'amm_force_eval', 'amm_kick',
+    'amm_bonded_add_terms', 'amm_bonded_finalize', 'amm_bonded_set_sliced', 'amm_bonded_release', 'amm_force_eval', 'amm_kick',
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read', 'amm_pair_count_within', 'amm_kernel_revision',
@@ -108,6 +108,7 @@ def lib():
         L.amm_bonded_add_terms.argtypes = [vp, C.c_int32, C.c_int32, ip, dp, C.c_int32, C.c_int32, C.POINTER(PairDesc)]
         L.amm_bonded_finalize.argtypes = [vp, C.c_int32]
         L.amm_bonded_set_sliced.argtypes = [vp, C.c_int32, C.c_int32]
+        L.amm_bonded_release.argtypes = [vp, C.c_int32]
         L.amm_force_eval.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
         L.amm_kick.argtypes = [vp, vp, vp, vp, C.c_int32, vp, C.c_double]
         L.amm_move.argtypes = [vp, vp, vp, C.c_double]
@@ -250,6 +251,10 @@ class HipContext:
         _chk(lib().amm_bonded_finalize(self.h, fid))
         if sliced:
             _chk(lib().amm_bonded_set_sliced(self.h, fid, 1))
+
+    def bonded_release(self, fid):
+        """Free a bond-list set that has been replaced (its id is retired)."""
+        _chk(lib().amm_bonded_release(self.h, fid))
 
     def pme_create(self, alpha, grid, q, Kc=KC):
         """Reciprocal space of a PME / Ewald NonbondedForce (smooth PME, order 5) on a grid[0] x grid[1] x grid[2] mesh."""

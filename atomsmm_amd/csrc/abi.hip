@@ -466,9 +466,30 @@ int amm_bonded_set_sliced(amm_ctx *ctx, int32_t force_id, int32_t on) {
     return 0;
 }
 
+// A bond-list set that the host has replaced (parameter offsets rebuild the exception terms, groups are merged anew): its
+// device arrays are freed and the id stays retired -- ids are positions in the force table and are never reused.
+int amm_bonded_release(amm_ctx *ctx, int32_t force_id) {
+    BondedSet *bs = get_bonded(ctx, force_id);
+    if (!bs) return 1;
+    AMM_HIP(hipStreamSynchronize(ctx->stream));            // nothing in flight may still read it
+    for (int g = 0; g < AMM_MAX_GROUPS; ++g) {
+        std::vector<int> &m = ctx->groups[g].forces;
+        m.erase(std::remove(m.begin(), m.end(), (int)force_id), m.end());
+    }
+    amm_bonded_free(bs);
+    delete bs;
+    ctx->forces[force_id].bonded = nullptr;
+    ctx->forces[force_id].type = 0;
+    return 0;
+}
+
 static int force_eval_dispatch(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *d_force, int32_t accumulate,
                                double *d_energy) {
     ForceObj &f = ctx->forces[force_id];
+    if (f.type == 0) {
+        amm_set_error("evaluation of a released force id");
+        return 1;
+    }
     if (f.type == 1) return amm_pair_eval_impl(ctx, f.pair, d_pos, d_force, accumulate, d_energy);
     if (f.type == 3) return amm_pme_eval_impl(ctx, f.pme, d_pos, d_force, accumulate, d_energy);
     return amm_bonded_eval_impl(ctx, f.bonded, d_pos, d_force, accumulate, d_energy);

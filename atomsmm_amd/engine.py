@@ -240,6 +240,7 @@ class Engine:
         self._arena_free = []
         self._arena_contiguous = True
         self._group_defs = {}
+        self._group_bonded = []     # merged bond-list sets made by _define_group
         self._valid = {}
         self._interpreted = None    # None: undecided; True: general (host-walked) step programs
         self._static_exprs = False
@@ -340,6 +341,20 @@ class Engine:
     def _finish_entry(self, entry):
         if entry.terms:
             entry.bonded_id = self._make_bonded(entry.terms, sliced=False)
+
+    def _replace_bonded(self, entry, terms):
+        """New bond-list set of a force whose terms changed; the set it replaces is freed (amm_bonded_release)."""
+        old = entry.bonded_id
+        entry.bonded_id = self._make_bonded(terms, sliced=False) if terms else None
+        if old is not None:
+            self.ctx.bonded_release(old)
+
+    def _forget_groups(self):
+        """Group definitions are stale (bond-list terms were rebuilt): drop them and free the merged sets they owned."""
+        for bid in self._group_bonded:
+            self.ctx.bonded_release(bid)
+        del self._group_bonded[:]
+        self._group_defs.clear()
 
     def _make_bonded(self, terms, sliced):
         bid = self.ctx.bonded_create()
@@ -445,7 +460,7 @@ class Engine:
             if entry.recip is not None:
                 self.ctx.pme_set_charges(entry.recip, p[:, 0])
             entry.terms = bonded_terms(parameters)
-            entry.bonded_id = self._make_bonded(entry.terms, sliced=False) if entry.terms else None
+            self._replace_bonded(entry, entry.terms)
             entry.constant = constant(parameters)
             return True
 
@@ -831,7 +846,7 @@ class Engine:
                 if not (lam & changed):
                     return False
                 entry.terms = terms(parameters)
-                entry.bonded_id = self._make_bonded(entry.terms, sliced=False)
+                self._replace_bonded(entry, entry.terms)
                 return True
             entry.update = update
             entry.depends = set(lam)
@@ -862,7 +877,7 @@ class Engine:
                 if result:
                     dirty = True
                     if result != 'values':
-                        self._group_defs.clear()       # bond-list terms were rebuilt
+                        self._forget_groups()       # bond-list terms were rebuilt
         if dirty:
             self._programs.clear()
             self._invalidate_forces()
@@ -883,7 +898,7 @@ class Engine:
             result = reload()
             if result:
                 if result != 'values':
-                    self._group_defs.clear()
+                    self._forget_groups()
                 self._programs.clear()
                 self._invalidate_forces()
 
@@ -1043,6 +1058,7 @@ class Engine:
         ids = list(pair_ids)
         if terms:
             ids.append(self._make_bonded(terms, sliced=reduced))
+            self._group_bonded.append(ids[-1])
         for e in self.entries:
             if e.recip is not None and (g == 'all' or e.recip_group == g):
                 e.recip_sliced = reduced
@@ -1663,7 +1679,7 @@ class Engine:
                 if point != here:
                     values.append(self._energy_of(by_difference))
             if rebuilt:
-                self._group_defs.clear()
+                self._forget_groups()
                 self._programs.clear()
             self._invalidate_forces()
             total += (values[0] - values[1]) / (here + h - lo)

@@ -189,6 +189,10 @@ int amm_bonded_add_terms(amm_ctx *ctx, int32_t force_id, int32_t kind, const int
 int amm_bonded_finalize(amm_ctx *ctx, int32_t force_id);
 /* world > 1: evaluate only this rank's block of atoms (use for bonded sets living in an all-reduced group). */
 int amm_bonded_set_sliced(amm_ctx *ctx, int32_t force_id, int32_t on);
+/* Free a bond-list set the host has replaced: Context.setParameter on a parameter offset rebuilds the exception terms of the
+ * NonbondedForce (forces.py:292-309, systems.py:303-311), which OpenMM does in place.  The id is retired (never reused) and
+ * leaves every group definition. */
+int amm_bonded_release(amm_ctx *ctx, int32_t force_id);
 
 /* Reciprocal space of a NonbondedForce with nonbondedMethod PME / Ewald, as RESPASystem and FarNonbondedForce
  * keep it in group 2 with the source force's Ewald tolerance / PME parameters (systems.py:74-75,

@@ -51,6 +51,10 @@ class RecordingContext:
     def bonded_finalize(self, fid, sliced=False):
         [b for b in self.bonded if b['id'] == fid][0]['sliced'] = sliced
 
+    def bonded_release(self, fid):
+        self.calls.append(('bonded_release', fid))
+        self.bonded = [b for b in self.bonded if b['id'] != fid]
+
     def pme_create(self, alpha, grid, q, Kc=138.935456):
         fid = self._new()
         self.pme = getattr(self, 'pme', [])

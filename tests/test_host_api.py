@@ -376,6 +376,14 @@ def test_parameter_offsets_update_backend(heaq, recorder):
     assert ctx.getParameter('lambda_coul') == 0.5
     with pytest.raises(openmm.OpenMMException):
         ctx.setParameter('nope', 1.0)
+    # the bond-list sets that a parameter change replaces are freed: the number of live sets does not grow
+    # (the plain system: its NonbondedForce keeps the exceptions, whose terms are rebuilt with the charges)
+    ctx = openmm.Context(system, openmm.VerletIntegrator(0.0))
+    rec = recorder[-1]
+    live = len(rec.bonded)
+    for value in (0.25, 0.75, 0.5):
+        ctx.setParameter('lambda_coul', value)
+    assert len(rec.bonded) == live and sum(c[0] == 'bonded_release' for c in rec.calls) >= 3
 
 
 def test_distributed_markers(spcfw, recorder, monkeypatch):
