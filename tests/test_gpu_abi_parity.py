@@ -233,6 +233,56 @@ def test_group_flags_vs_oracle(heaq):
     ctx.close()
 
 
+def test_filtered_list_follows_a_moving_solute_and_reports_overflow():
+    """Interaction-group forces walk only the rows that hold entries (collected by the list build, a whole wavefront per row):
+    (i) after the solute has moved through the solvent -- lists rebuilt, another set of rows -- energy and forces still equal
+    the oracle's; (ii) the grid of the pair kernel covers twice the rows of the first build (+ 64): a solute that starts
+    beyond the list radius of every solvent atom (no row at all) and then lands among them exceeds that, and amm_check says
+    so instead of dropping rows."""
+    B = _backend()
+    from atomsmm_amd.testing import tip3p_box
+    c = tip3p_box(8)                       # 1536 atoms, L = 2.48 nm
+    n = len(c['positions'])
+    rng = np.random.default_rng(5)
+    codes = np.full(n, 2.0)
+    codes[:3] = 1.0                        # one water is the solute
+    sigma = np.where(c['sigma'] > 0, c['sigma'], 0.1)
+    eps = np.full(n, 0.5)
+    desc = B.pair_desc(B.SOFTCORE, 0.9, rswitch=0.8, alpha=0.7, flags=B.SWITCH, Kc=1.0)
+    d = O.desc(O.SOFTCORE, rc=0.9, rswitch=0.8, alpha=0.7, flags=O.SWITCH, Kc=1.0)
+    ctx = B.HipContext(n, c['box'])
+    fid = ctx.pair_create(desc, codes, sigma, eps, c['exc_pairs'])
+    x = c['positions'].copy()
+    for hop in range(4):
+        pos = dev(x)
+        e, f = eval_force(ctx, fid, pos, n)
+        e_ref, f_ref, _ = O.pair_eval(d, x, c['box'], codes, sigma, eps, c['exc_pairs'])
+        assert e == pytest.approx(e_ref, rel=1e-10), hop
+        assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max(), hop
+        assert np.count_nonzero(np.abs(f).sum(axis=1)) < n // 2          # most rows are empty and were never visited
+        x[:3] += rng.uniform(0.3, 0.9, 3)                                    # the solute hops (beyond the Verlet buffer)
+    ctx.close()
+    # overflow of the active-row grid: solvent = the atoms of one corner only, the solute starts far from it
+    corner = np.all(c['positions'] < 0.9, axis=1)
+    codes = np.where(corner, 2.0, 0.0)
+    codes[n - 3:] = 1.0
+    assert not corner[n - 3:].any() and corner.sum() > 70
+    x = c['positions'].copy()
+    x[n - 3:] += np.array([1.69, 1.69, 1.69]) - x[n - 3]                     # the point farthest from the cube and its images: 1.37 nm
+    far = np.linalg.norm((x[corner][:, None, :] - x[None, n - 3:, :] + 0.5 * c['box']) % c['box'] - 0.5 * c['box'], axis=2).min()
+    assert far > 1.05
+    ctx = B.HipContext(n, c['box'])
+    fid = ctx.pair_create(desc, codes, sigma, eps, c['exc_pairs'], skin=0.1)
+    e, f = eval_force(ctx, fid, dev(x), n)
+    assert e == 0.0 and not f.any()
+    x[n - 3:] += np.array([0.45, 0.45, 0.45]) - x[n - 3]                     # into the corner
+    out = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+    ctx.force_eval(fid, dev(x), out)
+    with pytest.raises(B.HipError):
+        ctx.check()
+    ctx.close()
+
+
 def test_bonded_terms_vs_oracle(heaq, goldens):
     B = _backend()
     h = heaq
