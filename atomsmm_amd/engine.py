@@ -241,6 +241,8 @@ class Engine:
         self._arena_contiguous = True
         self._group_defs = {}
         self._group_bonded = []     # merged bond-list sets made by _define_group
+        self._deriv_cache = {}      # deriv(energy, name) at the current positions and parameters (host-walked programs)
+        self._pending = None        # device scalars that deferred globals wait for: (buffer, number in use)
         self._valid = {}
         self._interpreted = None    # None: undecided; True: general (host-walked) step programs
         self._static_exprs = False
@@ -855,6 +857,7 @@ class Engine:
     def _invalidate_forces(self):
         for g in self._valid:
             self._valid[g] = False
+        self._deriv_cache.clear()
 
     def set_positions(self, arr):
         self.x.copy_(self.torch.as_tensor(arr, device=self.x.device))
@@ -1084,6 +1087,7 @@ class Engine:
             ops.append(B.Op(B.OP_CONSTRAIN_X, 0, 0, 0, 0.0))
             for g in valid:
                 valid[g] = False
+            self._deriv_cache.clear()
         else:
             ops.append(B.Op(B.OP_CONSTRAIN_V, 0, 0, 0, 0.0))
 
@@ -1440,6 +1444,7 @@ class Engine:
                 ops.append(B.Op(B.OP_MOVE, 0, 0, 0, self._eval(parts[0], env)))
                 for g in valid:
                     valid[g] = False
+                self._deriv_cache.clear()
                 return
         # copies / differences of buffers: `_f2_ <- f2`, `fm1 <- f1`, `fm2 <- f2-f1`, `x0 <- x`
         if target not in ('x', 'v'):
@@ -1502,6 +1507,7 @@ class Engine:
             if target == 'x':
                 for g in valid:
                     valid[g] = False
+                self._deriv_cache.clear()
             return
         raise NotImplementedError('per-DOF computation outside the RESPA hot path: {} <- {}'.format(target, expr))
 
@@ -1685,6 +1691,53 @@ class Engine:
             total += (values[0] - values[1]) / (here + h - lo)
         return total
 
+    def _deriv_deferred(self, what, name, settle):
+        """deriv(energy, name) of a host-walked program without waiting for the GPU: the softcore pair kernel in derivative
+        mode leaves its sum in the next free slot of the pending buffer and the value is handed on as a deferred global
+        (expr.Deferred); the same positions and parameters give the same object again (a RESPA block ends and the next one
+        begins with the same derivative).  Forces that need difference quotients take the waiting path."""
+        if what != 'energy':
+            raise NotImplementedError('deriv(%s, ...): only deriv(energy, parameter) is supported' % what)
+        if name in self._deriv_cache:
+            return self._deriv_cache[name]
+        if name not in self.parameters:
+            raise mm.OpenMMException('deriv(energy, %s): no such Context parameter' % name)
+        if any(e.softcore is None and name in getattr(e, 'depends', ()) for e in self.entries):
+            settle()
+            value = self.energy_derivative(name)
+        else:
+            if self._pending is None:
+                self._pending = [self.torch.zeros(64, dtype=self.torch.float64, device=self.x.device), 0]
+            value = 0.0
+            for entry in self.entries:
+                sc = entry.softcore
+                if sc is not None and sc['lambda_name'] == name:
+                    if self._pending[1] >= 64:
+                        settle()
+                    slot = self._pending[1]
+                    self._pending[1] += 1
+                    self.ctx.pair_energy_derivative(sc['pid'], self.x, self._pending[0][slot:slot + 1])
+                    value = value + X.Deferred(sc['constant_derivative'](self.parameters), {slot: 1.0})
+        self._deriv_cache[name] = value
+        return value
+
+    def _settle(self, containers):
+        """Read the pending device scalars (one synchronising copy; summed over the ranks first) and turn every deferred
+        global in `containers` (dicts / lists) into its number."""
+        if self._pending is None or self._pending[1] == 0:
+            return
+        buf, used = self._pending
+        if self._coll:
+            self._allreduce(buf)
+        values = buf[:used].cpu().numpy()
+        for box in containers + [self._deriv_cache]:
+            keys = range(len(box)) if isinstance(box, list) else list(box)
+            for k in keys:
+                if isinstance(box[k], X.Deferred):
+                    box[k] = box[k].resolve(values)
+        buf.zero_()
+        self._pending[1] = 0
+
     # ------------------------------------------------------------------------------- general step programs
     def _step_interpreted(self, n):
         """Programs with data-dependent globals (ComputeSum results, random numbers) or per-DOF expressions beyond kick /
@@ -1707,12 +1760,32 @@ class Engine:
             self._host_rng = np.random.default_rng(integ.getRandomNumberSeed())
         seed = int(integ.getRandomNumberSeed()) & (2 ** 64 - 1)
         total = torch.zeros(1, dtype=torch.float64, device=self.x.device)
-        for _ in range(int(n)):
+        try:
+            self._walk_program(int(n), steps, match, seed, total)
+        finally:
+            self._settle([integ._gvalues])         # no deferred global outlives the call
+        self._check()
+
+    def _walk_program(self, n, steps, match, seed, total):
+        torch = self.torch
+        integ = self.integrator
+        C = mm.CustomIntegrator
+        for _ in range(n):
             env = dict(_SAFE_FUNCS)
             env.update(self.parameters)
             env.update(zip(integ._gnames, integ._gvalues))
             env['dt'] = integ._dt
-            env['__deriv__'] = lambda what, name: self._deriv(what, name)
+
+            def settle():
+                self._settle([env, integ._gvalues])
+
+            def deferred_in(text):
+                """Does the expression name a global whose number is still on the device?"""
+                if self._pending is None or self._pending[1] == 0:
+                    return False
+                return any(isinstance(env.get(name), X.Deferred) for name in X.symbols(text))
+
+            env['__deriv__'] = lambda what, name: self._deriv_deferred(what, name, settle)
             valid = self._valid
             self._mirror_work = self._mirror
             ops = [B.Op(B.OP_SAVE_REF, 0, 0, 0, 0.0)] if self._has_constraints else []
@@ -1743,14 +1816,26 @@ class Engine:
                 if kind == C.ComputeGlobal:
                     if 'deriv(' in expr:
                         flush()                                   # the derivative is taken at the current positions
-                    value = X.eval_global(expr, env, self._host_rng)
+                    rng_state = self._host_rng.bit_generator.state
+                    try:
+                        value = X.eval_global(expr, env, self._host_rng)
+                    except X.NeedsValue:                          # more than sums and multiples of a deferred global
+                        self._host_rng.bit_generator.state = rng_state
+                        settle()
+                        value = X.eval_global(expr, env, self._host_rng)
                     if target in self.parameters and target not in integ._gnames:
+                        if isinstance(value, X.Deferred):         # a Context parameter needs its number
+                            env[target] = value
+                            settle()
+                            value = env[target]
                         if value != self.parameters[target]:
                             flush()
                             self.set_parameter(target, value)     # an extended-system variable (AFED): forces change
                             valid = self._valid
                     env[target] = value
                 elif kind in (C.ComputePerDof, C.ComputeSum):
+                    if deferred_in(expr):
+                        settle()
                     done = False
                     if kind == C.ComputePerDof:
                         try:
@@ -1775,6 +1860,7 @@ class Engine:
                             if target == 'x':
                                 for g in valid:
                                     valid[g] = False
+                                self._deriv_cache.clear()
                         else:
                             self.ctx.expr_eval(prog.code, prog.consts, gvals, seed, self._expr_counter, total=total)
                             env[target] = total.item()          # device -> host (synchronises)
@@ -1783,6 +1869,8 @@ class Engine:
                 elif kind == C.UpdateContextState:
                     pass
                 elif kind in (C.IfBlock, C.WhileBlock):
+                    if deferred_in(expr):
+                        settle()
                     if not self._condition(expr, env):
                         pc = match[pc]
                 elif kind == C.EndBlock:
@@ -1793,7 +1881,6 @@ class Engine:
             for k, name in enumerate(integ._gnames):
                 integ._gvalues[k] = env[name]
             self.time += integ._dt
-        self._check()
 
     def step(self, n):
         integ = self.integrator

@@ -26,6 +26,73 @@ class ExpressionError(ValueError):
     pass
 
 
+class NeedsValue(Exception):
+    """A deferred global was used where its number is needed (anything but sums and multiples)."""
+
+
+class Deferred:
+    """A global of a host-walked step program whose number waits on device results: const + sum_k coef[k] * slot[k],
+    slot[k] being scalars that kernels already enqueued will leave in a device buffer (deriv(energy, lambda) of an AFED
+    program, integrators.py:735-737: the extended variable's velocity collects them, nothing else reads it until lambda itself
+    moves).  Sums and multiples keep the form, so the host does not wait for the GPU at every deriv(); any other use raises
+    NeedsValue and the engine reads the buffer once."""
+    __slots__ = ('const', 'terms')
+
+    def __init__(self, const=0.0, terms=None):
+        self.const, self.terms = float(const), dict(terms or {})
+
+    def _combined(self, other, sign):
+        if isinstance(other, Deferred):
+            terms = dict(self.terms)
+            for k, c in other.terms.items():
+                terms[k] = terms.get(k, 0.0) + sign * c
+            return Deferred(self.const + sign * other.const, terms)
+        return Deferred(self.const + sign * float(other), self.terms)
+
+    def _scaled(self, factor):
+        if isinstance(factor, Deferred):
+            raise NeedsValue()
+        factor = float(factor)
+        return Deferred(self.const * factor, {k: c * factor for k, c in self.terms.items()})
+
+    def __add__(self, other):
+        return self._combined(other, 1.0)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return self._combined(other, -1.0)
+
+    def __rsub__(self, other):
+        return self._scaled(-1.0)._combined(other, 1.0)
+
+    def __neg__(self):
+        return self._scaled(-1.0)
+
+    def __pos__(self):
+        return self
+
+    def __mul__(self, other):
+        return self._scaled(other)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        if isinstance(other, Deferred):
+            raise NeedsValue()
+        return self._scaled(1.0 / float(other))
+
+    def _needs_value(self, *args):
+        raise NeedsValue()
+
+    __rtruediv__ = __pow__ = __rpow__ = __float__ = __abs__ = __bool__ = _needs_value
+    __lt__ = __le__ = __gt__ = __ge__ = __eq__ = __ne__ = _needs_value
+    __hash__ = None
+
+    def resolve(self, values):
+        return self.const + sum(c * float(values[k]) for k, c in self.terms.items())
+
+
 def split_definitions(text):
     """'a*v; a = exp(-g*dt); g = 2' -> ('a*v', {'a': 'exp(-g*dt)', 'g': '2'})."""
     parts = [p.strip() for p in text.split(';') if p.strip()]
@@ -178,7 +245,7 @@ def eval_global(text, env, rng=None):
                 draws[key] = float(rng.standard_normal()) if key == 'gaussian' else float(rng.random())
             return draws[key]
         if name in env:
-            return float(env[name])
+            return env[name] if isinstance(env[name], Deferred) else float(env[name])
         raise ExpressionError('unknown symbol in global expression: ' + name)
 
     def ev(node):
@@ -206,7 +273,8 @@ def eval_global(text, env, rng=None):
             # deriv(energy, parameter): supplied by the engine (force kernels), integrators.py:735
             if '__deriv__' not in env:
                 raise ExpressionError('deriv() is not available in this context')
-            return float(env['__deriv__'](node.args[0].id, node.args[1].id))
+            value = env['__deriv__'](node.args[0].id, node.args[1].id)
+            return value if isinstance(value, Deferred) else float(value)
         if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id in _HOST_FUNCS and not node.keywords:
             return float(_HOST_FUNCS[node.func.id](*[ev(a) for a in node.args]))
         raise ExpressionError('unsupported syntax in expression: ' + ast.dump(node))
@@ -214,6 +282,7 @@ def eval_global(text, env, rng=None):
     return ev(_parse(main))
 
 
+@functools.lru_cache(maxsize=4096)
 def symbols(text):
     """Names referenced by an expression (auxiliary definitions expanded, their own names removed)."""
     main, defs = split_definitions(text)
@@ -222,4 +291,4 @@ def symbols(text):
         for node in ast.walk(_parse(part)):
             if isinstance(node, ast.Name):
                 found.add(node.id)
-    return found - set(defs) - set(_HOST_FUNCS)
+    return frozenset(found - set(defs) - set(_HOST_FUNCS))

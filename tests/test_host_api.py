@@ -687,3 +687,26 @@ def test_alchemical_system_structure_and_coupling_translation(heaq, recorder):
     # RESPA splitting of the coupling force (systems.py:83-95) is not built
     with pytest.raises(NotImplementedError):
         atomsmm.RESPASystem(spline, 7 * unit.angstroms, 5 * unit.angstroms)
+
+
+def test_deferred_globals_keep_sums_and_multiples_only():
+    """expr.Deferred: a global that waits on device scalars stays a linear form under +, -, * number, / number (what AFED's
+    velocity update of the extended variable does with deriv(energy, lambda), integrators.py:735-737); anything else asks
+    for the number (NeedsValue) -- the engine then reads the device buffer once and evaluates again."""
+    from atomsmm_amd import expr as X
+    d = X.Deferred(1.5, {0: 2.0})
+    env = {'v': 0.25, 'dt': 0.004, 'm': 50.0, '__deriv__': lambda what, name: d}
+    out = X.eval_global('v - 0.5*(dt/4)*deriv(energy,lambda_vdw)/m', env)
+    assert isinstance(out, X.Deferred)
+    assert out.resolve([3.0]) == pytest.approx(0.25 - 0.5 * 0.001 * (1.5 + 2.0 * 3.0) / 50.0, rel=1e-15)
+    env['v'] = out
+    again = X.eval_global('lam + 0.5*dt*v - v*2 + (-v)', dict(env, lam=0.6))
+    assert again.resolve([3.0]) == pytest.approx(0.6 + (0.002 - 3.0) * out.resolve([3.0]), rel=1e-14)
+    other = X.Deferred(0.0, {1: 1.0})
+    both = X.eval_global('v + w', dict(env, w=other))
+    assert both.resolve([3.0, 7.0]) == pytest.approx(out.resolve([3.0]) + 7.0)
+    for text in ('v^2', 'exp(-dt*v)', 'step(v)', 'select(step(v),2,0)-v', '1/v', 'v*v', 'max(v, 0)', 'abs(v)'):
+        with pytest.raises(X.NeedsValue):
+            X.eval_global(text, env)
+    with pytest.raises(X.NeedsValue):
+        float(out)
