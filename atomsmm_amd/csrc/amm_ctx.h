@@ -139,6 +139,13 @@ struct BondedSet {
     int4 *d_term_l = nullptr;                 // [ncomp*G] atoms of the term as component slots (x < 0: no term)
     double4 *d_term_q = nullptr;              // [ncomp*G] parameters + kind/periodic code
     unsigned long long *d_atom_recs = nullptr; // [n] the atom's records as (term slot | role << 3) in 5-bit fields, count in bits 60..63
+    // term-parallel evaluation of large sets (force only): every term once, its per-role forces parked in d_tf, every atom
+    // then adds up its records from there in record order -- the numbers and the order of k_bonded
+    int n_gterms = 0;
+    int4 *d_gt_a = nullptr;        // [n_gterms] atoms of the term
+    double4 *d_gt_q = nullptr;     // [n_gterms] parameters + kind/periodic code
+    int *d_rec_src = nullptr;      // [nref] term * 4 + role of each (atom, term) record
+    double *d_tf = nullptr;        // [n_gterms][4][3]
     double *d_epart = nullptr;
     int n_epart = 0;
 };

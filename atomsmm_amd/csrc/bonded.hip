@@ -239,6 +239,47 @@ __global__ void __launch_bounds__(256) k_bonded(BondedArgs A) {
     }
 }
 
+// Term-parallel evaluation (force only) for sets with many terms -- a solvated chain, a protein: one thread per TERM runs
+// bonded_term_forces once (k_bonded runs it once per atom of the term, and its wavefronts mix all the kinds; terms are stored
+// kind by kind, so these wavefronts are uniform) and parks the forces of the term's roles; one thread per atom then adds up
+// its records from there in record order: the same numbers in the same order as k_bonded, bit for bit.
+__global__ void __launch_bounds__(256) k_terms_eval(BondedArgs A, int nterms, const int4 *__restrict__ gt_a,
+                                                    const double4 *__restrict__ gt_q, double *__restrict__ tf) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nterms) return;
+    const int4 at = gt_a[t];
+    const double4 q = gt_q[t];
+    const long long code = __double_as_longlong(q.w);
+    const int kind = (int)(code & 7), periodic = (int)((code >> 5) & 1);
+    const int ix[4] = {at.x, at.y, at.z, at.w};
+    const double p[3] = {q.x, q.y, q.z};
+    double fo[4][3], e;
+    PosPlain pos{A.pos};
+    bonded_term_forces(A, pos, ix, p, kind, periodic, fo, e);
+    double *out = tf + (size_t)t * 12;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) out[3 * r + x] = fo[r][x];
+}
+
+__global__ void __launch_bounds__(256) k_terms_gather(BondedArgs A, const int *__restrict__ rec_src, const double *__restrict__ tf) {
+    const int i = A.row_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.row_end) return;
+    double f[3] = {0.0, 0.0, 0.0};
+    const int rb = A.ref_ptr[i], re = A.ref_ptr[i + 1];
+    for (int r = rb; r < re; ++r) {
+        const double *src = tf + (size_t)rec_src[r] * 3;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) f[x] += src[x];
+    }
+    if (A.accumulate) {
+        A.force[3 * i] += f[0]; A.force[3 * i + 1] += f[1]; A.force[3 * i + 2] += f[2];
+    } else {
+        A.force[3 * i] = f[0]; A.force[3 * i + 1] = f[1]; A.force[3 * i + 2] = f[2];
+    }
+}
+
 // Fused inner RESPA iteration (propagators.py:940-973, innermost level):
 //     v <- v + c1*f0/m ;  x <- x + d*v ;  f0 <- bonded(x) ;  v <- v + c2*f0/m
 // in ONE launch.  Each thread advances its own atom and, redundantly, the few atoms it shares bond-list terms
@@ -587,12 +628,15 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
     const size_t nref = (size_t)cnt[n];
     std::vector<int4> rec_a(nref);
     std::vector<double4> rec_q(nref);
+    std::vector<int> rec_src(nref);
     std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+    int gterm = 0;
     for (int kind = 0; kind < 8; ++kind)
-        for (int t = 0; t < bs->n_terms[kind]; ++t)
+        for (int t = 0; t < bs->n_terms[kind]; ++t, ++gterm)
             for (int r = 0; r < kArity[kind]; ++r) {
                 const int a = bs->h_idx[kind][t * kArity[kind] + r];
                 const size_t slot = (size_t)fill[a]++;
+                rec_src[slot] = gterm * 4 + r;
                 int at[4] = {-1, -1, -1, -1};
                 for (int k = 0; k < kArity[kind]; ++k) at[k] = bs->h_idx[kind][t * kArity[kind] + k];
                 rec_a[slot] = make_int4(at[0], at[1], at[2], at[3]);
@@ -704,6 +748,34 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
     AMM_HIP(hipMemcpy(bs->d_comp_atoms, comp_atoms.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     AMM_HIP(hipMalloc(&bs->d_rec_l, sizeof(int4) * std::max<size_t>(nref, 1)));
     if (nref) AMM_HIP(hipMemcpy(bs->d_rec_l, rec_l.data(), sizeof(int4) * nref, hipMemcpyHostToDevice));
+    // term tables of the term-parallel evaluation: worth two launches from a few thousand terms on
+    static const int terms_from = getenv("AMM_TERMS_FROM") ? atoi(getenv("AMM_TERMS_FROM")) : 8192;
+    bs->n_gterms = 0;
+    if (gterm >= terms_from) {
+        std::vector<int4> gt_a((size_t)gterm);
+        std::vector<double4> gt_q((size_t)gterm);
+        int g = 0;
+        for (int kind = 0; kind < 8; ++kind)
+            for (int t = 0; t < bs->n_terms[kind]; ++t, ++g) {
+                int at[4] = {-1, -1, -1, -1};
+                for (int k = 0; k < kArity[kind]; ++k) at[k] = bs->h_idx[kind][(size_t)t * kArity[kind] + k];
+                double pr[3] = {0.0, 0.0, 0.0};
+                for (int k = 0; k < kNpar[kind]; ++k) pr[k] = bs->h_par[kind][(size_t)t * kNpar[kind] + k];
+                const long long code = (long long)kind | ((long long)(bs->periodic[kind] ? 1 : 0) << 5);
+                double w;
+                std::memcpy(&w, &code, sizeof(w));
+                gt_a[g] = make_int4(at[0], at[1], at[2], at[3]);
+                gt_q[g] = make_double4(pr[0], pr[1], pr[2], w);
+            }
+        AMM_HIP(hipMalloc(&bs->d_gt_a, sizeof(int4) * (size_t)gterm));
+        AMM_HIP(hipMalloc(&bs->d_gt_q, sizeof(double4) * (size_t)gterm));
+        AMM_HIP(hipMalloc(&bs->d_rec_src, sizeof(int) * nref));
+        AMM_HIP(hipMalloc(&bs->d_tf, sizeof(double) * 12 * (size_t)gterm));
+        AMM_HIP(hipMemcpy(bs->d_gt_a, gt_a.data(), sizeof(int4) * (size_t)gterm, hipMemcpyHostToDevice));
+        AMM_HIP(hipMemcpy(bs->d_gt_q, gt_q.data(), sizeof(double4) * (size_t)gterm, hipMemcpyHostToDevice));
+        AMM_HIP(hipMemcpy(bs->d_rec_src, rec_src.data(), sizeof(int) * nref, hipMemcpyHostToDevice));
+        bs->n_gterms = gterm;
+    }
     AMM_HIP(hipMalloc(&bs->d_ref_ptr, sizeof(int) * (n + 1)));
     AMM_HIP(hipMemcpy(bs->d_ref_ptr, cnt.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
     AMM_HIP(hipMalloc(&bs->d_rec_a, sizeof(int4) * std::max<size_t>(nref, 1)));
@@ -751,6 +823,14 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
     A.Kc_ljc = bs->ljc_Kc;
     const int rows = A.row_end - A.row_begin;
     const int nblk = std::max(1, (rows + 255) / 256);
+    if (bs->n_gterms > 0 && !d_energy) {
+        // every term once (all of them on every rank: they are cheap next to the pair forces), then the atoms of the rank's rows
+        hipLaunchKernelGGL(k_terms_eval, dim3((bs->n_gterms + 255) / 256), dim3(256), 0, ctx->stream, A, bs->n_gterms, bs->d_gt_a,
+                           bs->d_gt_q, bs->d_tf);
+        hipLaunchKernelGGL(k_terms_gather, dim3(nblk), dim3(256), 0, ctx->stream, A, bs->d_rec_src, bs->d_tf);
+        AMM_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_bonded, dim3(nblk), dim3(256), 0, ctx->stream, A);
     AMM_HIP(hipGetLastError());
     if (d_energy) return amm_reduce_add(ctx, bs->d_epart, nblk, 1.0, d_energy);
@@ -901,6 +981,8 @@ int amm_bonded_free(BondedSet *bs) {
     if (bs->d_rec_a) (void)hipFree(bs->d_rec_a);
     if (bs->d_rec_q) (void)hipFree(bs->d_rec_q);
     if (bs->d_rec_l) (void)hipFree(bs->d_rec_l);
+    for (void *ptr : {(void *)bs->d_gt_a, (void *)bs->d_gt_q, (void *)bs->d_rec_src, (void *)bs->d_tf})
+        if (ptr) (void)hipFree(ptr);
     if (bs->d_term_l) (void)hipFree(bs->d_term_l);
     if (bs->d_term_q) (void)hipFree(bs->d_term_q);
     if (bs->d_atom_recs) (void)hipFree(bs->d_atom_recs);

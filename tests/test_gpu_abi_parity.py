@@ -334,6 +334,42 @@ def test_bonded_terms_vs_oracle(heaq, goldens):
     ctx.close()
 
 
+def test_term_parallel_bond_lists_equal_the_record_walk_bit_for_bit(heaq):
+    """Sets with many terms are evaluated term by term (k_terms_eval + k_terms_gather) when only forces are asked for, and
+    by the per-atom record walk (k_bonded) when the energy is wanted too: same bonded_term_forces, same order of an atom's
+    records => the same bits.  Every kind of term at once (harmonic bonds and angles, periodic torsions, periodic LJC
+    exception bonds), each four times so that the set is past the switch-over (8192 terms)."""
+    B = _backend()
+    h = heaq
+    n = len(h['positions'])
+    ctx = B.HipContext(n, h['box'])
+    pos = dev(h['positions'])
+    kinds = [(B.BOND_HARMONIC, h['bonds'], np.stack([h['bond_r0'], h['bond_k']], 1), False),
+             (B.ANGLE_HARMONIC, h['angles'], np.stack([h['angle_theta0'], h['angle_k']], 1), False),
+             (B.TORSION_PERIODIC, h['torsions'], np.stack([h['torsion_n'].astype(float), h['torsion_phase'], h['torsion_k']], 1), False),
+             (B.BOND_LJC, h['exc_pairs'], np.stack([h['exc_chargeprod'], h['exc_sigma'], h['exc_epsilon']], 1), True)]
+    copies = 1 + 8192 // sum(len(k[1]) for k in kinds)
+    bid = ctx.bonded_create()
+    for kind, idx, par, periodic in kinds:
+        ctx.bonded_add_terms(bid, kind, np.tile(idx, (copies, 1)), np.tile(par, (copies, 1)), periodic=periodic)
+    ctx.bonded_finalize(bid)
+    assert copies * sum(len(k[1]) for k in kinds) >= 8192
+    walk_e, walk = eval_force(ctx, bid, pos, n)                         # with the energy: k_bonded
+    by_term = torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda')
+    ctx.force_eval(bid, pos, by_term, accumulate=False)
+    ctx.check()
+    assert np.array_equal(by_term.cpu().numpy(), walk)
+    by_term.fill_(1.0)
+    ctx.force_eval(bid, pos, by_term, accumulate=True)                  # accumulating form
+    assert np.array_equal(by_term.cpu().numpy(), 1.0 + walk)
+    ref = (O.harmonic_bonds(h['bonds'], h['bond_r0'], h['bond_k'], h['positions'], h['box'])[1] +
+           O.harmonic_angles(h['angles'], h['angle_theta0'], h['angle_k'], h['positions'], h['box'])[1] +
+           O.periodic_torsions(h['torsions'], h['torsion_n'], h['torsion_phase'], h['torsion_k'], h['positions'], h['box'])[1] +
+           O.ljc_bonds(h['exc_pairs'], h['exc_chargeprod'], h['exc_sigma'], h['exc_epsilon'], h['positions'], h['box'], periodic=True)[1])
+    assert np.abs(walk - copies * ref).max() <= 1e-10 * np.abs(copies * ref).max()
+    ctx.close()
+
+
 def test_solvation_respa_golden_G9(heaq, goldens):
     from helpers import solvation_respa_inputs
     B = _backend()
