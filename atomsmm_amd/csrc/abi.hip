@@ -240,8 +240,8 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     AMM_HIP(hipMalloc(&pf->d_xref_out, sizeof(double) * 3 * n));
     AMM_HIP(hipMalloc(&pf->d_flags, sizeof(int) * 16));
     AMM_HIP(hipMemset(pf->d_flags, 0, sizeof(int) * 16));
-    AMM_HIP(hipMalloc(&pf->d_ticket, sizeof(int) * 4));
-    AMM_HIP(hipMemset(pf->d_ticket, 0, sizeof(int) * 4));
+    AMM_HIP(hipMalloc(&pf->d_ticket, sizeof(int) * 4 * AMM_TICKET_INTS));
+    AMM_HIP(hipMemset(pf->d_ticket, 0, sizeof(int) * 4 * AMM_TICKET_INTS));
     AMM_HIP(hipMalloc(&pf->d_counters, sizeof(unsigned long long) * 8));
     AMM_HIP(hipMemset(pf->d_counters, 0, sizeof(unsigned long long) * 8));
     ForceObj fo;

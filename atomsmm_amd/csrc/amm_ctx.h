@@ -103,6 +103,7 @@ struct PairForce {
     double tab_error = 0;          // largest relative interpolation error found when the table was built
     int *d_cls = nullptr;          // per atom (original order): 1 = no Lennard-Jones site (eps = 0) -- sorted behind the others in its cell
     int *d_cell_count_lj = nullptr, *d_cell_start_lj = nullptr;   // per cell: atoms WITH a Lennard-Jones site (count, exclusive scan)
+    int *d_cell_sets = nullptr;    // interaction-group forces: per cell, which of the two sets have atoms in it (bit 0 / bit 1)
     int active_cap = 0;            // rows the pair kernels' grid covers when d_active is walked
     int *d_active = nullptr;       // filtered lists: slice-relative rows that hold entries (their number: flags[8])
     float *d_member = nullptr;     // interaction-group forces: set code of each atom (0 none, 1, 2); the list keeps only (1, 2) pairs
@@ -113,6 +114,10 @@ struct PairForce {
     std::vector<hipEvent_t> ev;    // pairs (start, stop)
     size_t ev_used = 0;
 };
+
+#ifndef AMM_TICKET_INTS
+#define AMM_TICKET_INTS 64      // ints per last-block ticket (device_utils.h: amm_last_block)
+#endif
 
 struct BondedSet {
     // host staging

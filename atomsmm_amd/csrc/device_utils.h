@@ -9,14 +9,34 @@
 // waiting for the writes to be acknowledged (s_waitcnt 0) then orders them before the ticket.  A __threadfence()
 // here would instead write back each XCD's whole dirty L2 -- including the list being built -- once per block
 // (measured: 2.6x on the build kernel).
+// `ticket` points at AMM_TICKET_INTS ints.  Big grids draw in two levels -- 32 classes (blockIdx & 31), then the master
+// among the last block of each class -- because same-address device-scope atomics serialise at a few ns each: 15 000 blocks
+// that have nothing else to do (the culled build of an interaction-group list) spent 0.2 ms queueing for one counter.
+#ifndef AMM_TICKET_INTS
+#define AMM_TICKET_INTS 64
+#endif
 __device__ __forceinline__ bool amm_last_block(int *ticket) {
     __shared__ int s_last;
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t = atomicAdd(ticket, 1);
-        s_last = (t == (int)gridDim.x - 1);
-        if (s_last) *ticket = 0;        // every other block has already drawn: safe to re-arm
+        const int nb = (int)gridDim.x;
+        if (nb < 1024) {
+            const int t = atomicAdd(ticket, 1);
+            s_last = (t == nb - 1);
+            if (s_last) *ticket = 0;        // every other block has already drawn: safe to re-arm
+        } else {
+            const int k = (int)(blockIdx.x & 31u);
+            const int of_class = (nb - k + 31) >> 5;             // blocks b < nb with b & 31 == k
+            s_last = 0;
+            if (atomicAdd(&ticket[1 + k], 1) == of_class - 1) {
+                ticket[1 + k] = 0;
+                if (atomicAdd(ticket, 1) == 31) {
+                    *ticket = 0;
+                    s_last = 1;
+                }
+            }
+        }
     }
     __syncthreads();
     return s_last != 0;

@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
                                                           const double *__restrict__ q, const double *__restrict__ hsig,
                                                           const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s,
                                                           const int *__restrict__ cls, const int *__restrict__ start_lj,
-                                                          int *row_order, int s_begin, int s_end, int *n_lj_out, const float *__restrict__ member) {
+                                                          int *row_order, int s_begin, int s_end, int *n_lj_out, const float *__restrict__ member,
+                                                          int *cell_sets) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (!force && !flags[which]) {
         if (posq_s && gid < n) {
@@ -184,9 +185,14 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
     const int gi0 = s_begin - ga0;
     if (row_order && wave == 0 && lane == 0) n_lj_out[0] = ga1 - ga0;
     if (wave == 0 && lane == 0) n_lj_out[5] = 0;      // flags[8]: rows with entries of a filtered list, counted by the build that follows
+    int sets_here = 0;                                // interaction-group force: which of the two sets have atoms in this cell
     for (int a0 = 0; a0 < cnt; a0 += 64) {
         const int a = a0 + lane;
         const int me = a < cnt ? mem[a] : 0;
+        if (cell_sets) {
+            const float code = a < cnt ? member[me] : 0.f;
+            sets_here |= (__builtin_amdgcn_ballot_w64(code == 1.0f) != 0ull ? 1 : 0) | (__builtin_amdgcn_ballot_w64(code == 2.0f) != 0ull ? 2 : 0);
+        }
         // sort key: class (atoms with a Lennard-Jones site first), then atom index -> deterministic whatever the atomics did
         const int key = a < cnt ? (me | (cls[me] << 30)) : 0x7fffffff;
         int rank = 0;
@@ -225,6 +231,7 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
             lj_s[sl] = make_double2(hsig[me], seps2[me]);
         }
     }
+    if (cell_sets && lane == 0) cell_sets[wave] = sets_here;
 }
 
 // sorted copies of positions (wrapped) and parameters; run before every evaluation
@@ -348,7 +355,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                               const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2, float rnear2,
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
                               int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
-                              unsigned long long *counters, int *ticket, int which, int force, int filtered, int *active, int active_cap) {
+                              unsigned long long *counters, int *ticket, int which, int force, int filtered, int *active, int active_cap, const int *__restrict__ cell_sets) {
     if (!force && !flags[which]) return;
     __shared__ int s_rstart[4][64];
     __shared__ int s_rpref[4][64];
@@ -373,7 +380,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
         const int cx = c % ncx, cy = (c / ncx) % ncy, cz = c / (ncx * ncy);
         // ---- run table: lane r describes run r = (oz, oy, seg) ----
         const int nry = g.nstencil[1], nr = g.nstencil[2] * nry * 2;
-        int rstart = 0, rlen = 0;
+        int rstart = 0, rlen = 0, near_sets = 0;
         float rsx = 0.f, rsy = 0.f, rsz = 0.f;
         if (lane < nr) {
             const int seg = lane & 1, oy = (lane >> 1) % nry, oz = (lane >> 1) / nry;
@@ -399,6 +406,22 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                 rstart = cell_start[row + c0];
                 rlen = cell_start[row + c1 + 1] - rstart;
                 rsx = (float)(seg == 0 ? xsa : xsb) * box.L[0];
+                if (cell_sets)
+                    for (int cc = c0; cc <= c1; ++cc) near_sets |= cell_sets[row + cc];
+            }
+        }
+        if (cell_sets) {
+            // interaction-group list: a cell whose atoms have no partner of the other set anywhere in the stencil gets empty rows
+            // without walking the stream (a 30-atom solute in 249k atoms: 98 % of the wavefronts end here)
+            const int home = cell_sets[c];
+            const bool any1 = __builtin_amdgcn_ballot_w64((near_sets & 1) != 0) != 0ull, any2 = __builtin_amdgcn_ballot_w64((near_sets & 2) != 0) != 0ull;
+            if (!(((home & 1) && any2) || ((home & 2) && any1))) {
+                if (!COUNT_ONLY)
+                    for (int a = a_begin + lane; a < a_end; a += 64) {
+                        nnb[a - s_begin] = 0;
+                        nnb_near[a - s_begin] = 0;
+                    }
+                a_end = a_begin;              // the batch loop below has nothing to do
             }
         }
         int incl = rlen;
@@ -1341,7 +1364,8 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
                        pf->d_cell_start, pf->d_cell_members, pf->capc, pf->d_perm, d_pos, ctx->box, pf->d_pos4f_s,
                        pf->d_inv_perm, pf->d_flags, which, force, gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr,
                        gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr, gf ? gf->d_lj_s : (double2 *)nullptr,
-                       pf->d_cls, pf->d_cell_start_lj, pf->d_row_order, pf->s_begin, pf->s_end, pf->d_flags + 3, pf->d_member);
+                       pf->d_cls, pf->d_cell_start_lj, pf->d_row_order, pf->s_begin, pf->s_end, pf->d_flags + 3, pf->d_member,
+                       pf->d_cell_sets);
     const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
@@ -1360,7 +1384,7 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
                        pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
                        pf->d_excl_idx, cap, nl, nnb, nnb_near, pf->d_flags, pf->d_blockstats, pf->d_counters,      \
-                       pf->d_ticket + 1, which, force, pf->d_member ? 1 : 0, direct ? pf->d_active : (int *)nullptr, pf->active_cap)
+                       pf->d_ticket + AMM_TICKET_INTS, which, force, pf->d_member ? 1 : 0, direct ? pf->d_active : (int *)nullptr, pf->active_cap, pf->d_cell_sets)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
         else AMM_LAUNCH_BUILD(true, false);
@@ -1439,6 +1463,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         AMM_HIP(hipStreamSynchronize(ctx->stream));
         pf->capc = 2 * flags[6] + 16;
         AMM_HIP(hipMalloc(&pf->d_cell_members, sizeof(int) * (size_t)pf->grid.ncell * pf->capc));
+        if (pf->d_member) AMM_HIP(hipMalloc(&pf->d_cell_sets, sizeof(int) * (size_t)pf->grid.ncell));
         // waves per cell: enough that even the fullest cell's share is one batch per wave (a second batch walks the
         // whole candidate stream again; measured at C3: 315 us with 4 parts, 331 us with the 3 that the mean suggests)
         pf->parts = std::max(1, std::min(8, (int)std::ceil(1.15 * flags[6] / AMM_BATCH)));
@@ -1891,7 +1916,7 @@ int amm_pair_free(PairForce *pf) {
                     pf->d_cell_start, pf->d_cell_members, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
                     pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near, pf->d_nl_out, pf->d_nnb_out,
                     pf->d_nnb_scratch, pf->d_xref_out, pf->d_ticket, pf->d_tab, pf->d_cls, pf->d_cell_count_lj, pf->d_cell_start_lj,
-                    pf->d_row_order, pf->d_member, pf->d_active};
+                    pf->d_row_order, pf->d_member, pf->d_active, pf->d_cell_sets};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);

@@ -443,8 +443,8 @@ int amm_pme_create_impl(amm_ctx *ctx, double alpha, const int *K, double Kc, con
         AMM_HIP(hipMemset(pm->d_bin_count, 0, sizeof(int) * pm->nbins));
         AMM_HIP(hipMalloc(&pm->d_bin_start, sizeof(int) * (pm->nbins + 1)));
         AMM_HIP(hipMalloc(&pm->d_bin_fill, sizeof(int) * pm->nbins));
-        AMM_HIP(hipMalloc(&pm->d_ticket, sizeof(int) * 2));
-        AMM_HIP(hipMemset(pm->d_ticket, 0, sizeof(int) * 2));
+        AMM_HIP(hipMalloc(&pm->d_ticket, sizeof(int) * 2 * AMM_TICKET_INTS));
+        AMM_HIP(hipMemset(pm->d_ticket, 0, sizeof(int) * 2 * AMM_TICKET_INTS));
         AMM_HIP(hipMalloc(&pm->d_stage, sizeof(long long) * (size_t)pm->nbins * PME_TVOL));
     }
     pm->n_epart = (int)((mc + 255) / 256);
