@@ -130,8 +130,14 @@ int amm_check(amm_ctx *ctx) {
     for (size_t id = 0; id < ctx->forces.size(); ++id) {
         PairForce *pf = ctx->forces[id].pair;
         if (!pf || !pf->built) continue;
-        int flags[8];
+        int flags[16];
         AMM_HIP(hipMemcpy(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        if (pf->d_active && flags[8] > pf->active_cap) {
+            amm_set_error("interaction-group list of pair force " + std::to_string(id) + ": " + std::to_string(flags[8]) +
+                          " rows hold entries > the " + std::to_string(pf->active_cap) +
+                          " the traversal covers (more than twice the first build's); forces since the last rebuild are incomplete");
+            return 2;
+        }
         if (flags[7]) {
             amm_set_error("cell list overflow in pair force " + std::to_string(id) + ": a cell holds " + std::to_string(flags[6]) +
                           " atoms > capacity " + std::to_string(pf->capc) + " (local density more than doubled since the first build)");
