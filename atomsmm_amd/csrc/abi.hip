@@ -61,6 +61,7 @@ int amm_create(int32_t n_atoms, const double h_box[3], int32_t device, void *str
     ctx->n = n_atoms;
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
+    if (const char *e = getenv("AMM_SITE_TRIPS")) ctx->site_trips = atoi(e) != 0;
     for (int k = 0; k < 3; ++k) {
         ctx->box.L[k] = h_box[k];
         ctx->box.invL[k] = 1.0 / h_box[k];

@@ -103,6 +103,7 @@ struct PairForce {
     double tab_error = 0;          // largest relative interpolation error found when the table was built
     int *d_cls = nullptr;          // per atom (original order): 1 = no Lennard-Jones site (eps = 0) -- sorted behind the others in its cell
     int *d_cell_count_lj = nullptr, *d_cell_start_lj = nullptr;   // per cell: atoms WITH a Lennard-Jones site (count, exclusive scan)
+    int *d_nnb_lj = nullptr;       // per row: how many of its entries are partners with a Lennard-Jones site (front | back << 16): they come first on either side
     int *d_cell_sets = nullptr;    // interaction-group forces: per cell, which of the two sets have atoms in it (bit 0 / bit 1)
     int active_cap = 0;            // rows the pair kernels' grid covers when d_active is walked
     int *d_active = nullptr;       // filtered lists: slice-relative rows that hold entries (their number: flags[8])
@@ -233,6 +234,10 @@ struct amm_ctx {
     // ping-pong partners of x, v and the group-0 force buffer for the fused inner RESPA iteration
     double *alt_x = nullptr, *alt_v = nullptr, *alt_f = nullptr;
     bool fuse_inner = true;
+    // cut the force-only pair traversal into stretches with / without Lennard-Jones arithmetic (pair.hip).  A row's order of
+    // summation then depends on the rows that share its wavefront: results agree to rounding, not bit for bit, between two
+    // decompositions.  AMM_SITE_TRIPS=0 (read when the context is created) switches it off -- what the bit-identity tests do.
+    bool site_trips = true;
     long pos_epoch = 0;            // bumped whenever the positions may have changed (see amm_pair_eval_impl)
     PairForce *prechecked[2] = {nullptr, nullptr};   // lists whose displacement trigger the last integration kernel evaluated
     int n_prechecked = 0;

@@ -355,11 +355,12 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                               const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2, float rnear2,
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
                               int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
-                              unsigned long long *counters, int *ticket, int which, int force, int filtered, int *active, int active_cap, const int *__restrict__ cell_sets) {
+                              unsigned long long *counters, int *ticket, int which, int force, int filtered, int *active, int active_cap, const int *__restrict__ cell_sets,
+                              const int *__restrict__ cell_start_lj, int *nnb_lj) {
     if (!force && !flags[which]) return;
-    __shared__ int s_rstart[4][64];
-    __shared__ int s_rpref[4][64];
-    __shared__ float s_rshift[4][3][64];
+    __shared__ int s_rstart[4][128];
+    __shared__ int s_rpref[4][128];
+    __shared__ float s_rshift[4][3][128];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int c = wave / parts, part = wave - c * parts;
@@ -378,36 +379,34 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
     if (a_begin < a_end) {
         const int ncx = g.nc[0], ncy = g.nc[1], ncz = g.nc[2];
         const int cx = c % ncx, cy = (c / ncx) % ncy, cz = c / (ncx * ncy);
-        // ---- run table: lane r describes run r = (oz, oy, seg) ----
-        const int nry = g.nstencil[1], nr = g.nstencil[2] * nry * 2;
-        int rstart = 0, rlen = 0, near_sets = 0;
-        float rsx = 0.f, rsy = 0.f, rsz = 0.f;
-        if (lane < nr) {
-            const int seg = lane & 1, oy = (lane >> 1) % nry, oz = (lane >> 1) / nry;
-            int nz = ncz < 2 * g.h[2] + 1 ? oz : cz - g.h[2] + oz;
-            rsz = nz < 0 ? -box.L[2] : (nz >= ncz ? box.L[2] : 0.f);
-            nz = nz < 0 ? nz + ncz : (nz >= ncz ? nz - ncz : nz);
-            int ny = ncy < 2 * g.h[1] + 1 ? oy : cy - g.h[1] + oy;
-            rsy = ny < 0 ? -box.L[1] : (ny >= ncy ? box.L[1] : 0.f);
-            ny = ny < 0 ? ny + ncy : (ny >= ncy ? ny - ncy : ny);
-            // x runs: [xa0,xa1] and [xb0,xb1] (second may be empty) with their periodic image (-1, 0, +1)
-            int xa0, xa1, xb0 = 0, xb1 = -1, xsa = 0, xsb = 0;
-            if (ncx < 2 * g.h[0] + 1) {       // stencil would wrap onto itself: visit every cell once (RINT build)
-                xa0 = 0; xa1 = ncx - 1;
-            } else {
-                const int x0 = cx - g.h[0], x1 = cx + g.h[0];
-                if (x0 < 0) { xa0 = x0 + ncx; xa1 = ncx - 1; xb0 = 0; xb1 = x1; xsa = -1; }
-                else if (x1 >= ncx) { xa0 = x0; xa1 = ncx - 1; xb0 = 0; xb1 = x1 - ncx; xsb = 1; }
-                else { xa0 = x0; xa1 = x1; }
-            }
-            const int c0 = seg == 0 ? xa0 : xb0, c1 = seg == 0 ? xa1 : xb1;
-            if (c1 >= c0) {
-                const int row = (nz * ncy + ny) * ncx;
-                rstart = cell_start[row + c0];
-                rlen = cell_start[row + c1 + 1] - rstart;
-                rsx = (float)(seg == 0 ? xsa : xsb) * box.L[0];
-                if (cell_sets)
-                    for (int cc = c0; cc <= c1; ++cc) near_sets |= cell_sets[row + cc];
+        // ---- cell table: a lane describes the stencil cells e = lane and lane + 64 (<= 125), e = (oz, oy, ox), x fastest ----
+        // A cell's atoms are stored with the Lennard-Jones sites first (k_cell_sort_gather), so the candidates are walked as TWO
+        // streams: the sites of all the stencil's cells, then the rest.  A row therefore comes out with the partners that have a
+        // site first on either side (front: r < rnear; back: the others), and the traversal can keep the Lennard-Jones
+        // arithmetic to the trips that need it -- in water one pair in nine.
+        const int nsx = g.nstencil[0], nsy = g.nstencil[1], ne = nsx * nsy * g.nstencil[2];
+        int ecs[2] = {0, 0}, elj[2] = {0, 0}, ecn[2] = {0, 0}, near_sets = 0;
+        float esx[2] = {0.f, 0.f}, esy[2] = {0.f, 0.f}, esz[2] = {0.f, 0.f};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int e = lane + 64 * hh;
+            if (e < ne) {
+                const int ox = e % nsx, oy = (e / nsx) % nsy, oz = e / (nsx * nsy);
+                // fewer cells than the stencil is wide: visit every cell once (RINT build, minimum image in the test)
+                int nz = ncz < 2 * g.h[2] + 1 ? oz : cz - g.h[2] + oz;
+                esz[hh] = nz < 0 ? -box.L[2] : (nz >= ncz ? box.L[2] : 0.f);
+                nz = nz < 0 ? nz + ncz : (nz >= ncz ? nz - ncz : nz);
+                int ny = ncy < 2 * g.h[1] + 1 ? oy : cy - g.h[1] + oy;
+                esy[hh] = ny < 0 ? -box.L[1] : (ny >= ncy ? box.L[1] : 0.f);
+                ny = ny < 0 ? ny + ncy : (ny >= ncy ? ny - ncy : ny);
+                int nx = ncx < 2 * g.h[0] + 1 ? ox : cx - g.h[0] + ox;
+                esx[hh] = nx < 0 ? -box.L[0] : (nx >= ncx ? box.L[0] : 0.f);
+                nx = nx < 0 ? nx + ncx : (nx >= ncx ? nx - ncx : nx);
+                const int cc = (nz * ncy + ny) * ncx + nx;
+                ecs[hh] = cell_start[cc];
+                ecn[hh] = cell_start[cc + 1] - ecs[hh];
+                elj[hh] = cell_start_lj[cc + 1] - cell_start_lj[cc];
+                if (cell_sets) near_sets |= cell_sets[cc];
             }
         }
         if (cell_sets) {
@@ -420,26 +419,11 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                     for (int a = a_begin + lane; a < a_end; a += 64) {
                         nnb[a - s_begin] = 0;
                         nnb_near[a - s_begin] = 0;
+                        if (nnb_lj) nnb_lj[a - s_begin] = 0;
                     }
                 a_end = a_begin;              // the batch loop below has nothing to do
             }
         }
-        int incl = rlen;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        const int prefv = incl - rlen;           // exclusive prefix (lane r: first stream index of run r); lanes >= nr hold `total`
-        s_rstart[w][lane] = rstart;
-        s_rpref[w][lane] = prefv;
-        s_rshift[w][0][lane] = rsx;
-        s_rshift[w][1][lane] = rsy;
-        s_rshift[w][2][lane] = rsz;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
         for (int tb = a_begin; tb < a_end; tb += AMM_BATCH) {
             const int nt = min(AMM_BATCH, a_end - tb);
             float4 my = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -478,7 +462,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
             // (front | back << 16; rows are shorter than 65536 -- checked on the host); the kernel lives on the
             // scalar-register budget, 8 atoms x 4 registers
             float px[AMM_BATCH], py[AMM_BATCH], pz[AMM_BATCH], pw[AMM_BATCH];
-            int c2[AMM_BATCH];
+            int c2[AMM_BATCH], c2_sites[AMM_BATCH];
 #pragma unroll
             for (int t = 0; t < AMM_BATCH; ++t) {
                 pw[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.w), t));
@@ -486,30 +470,51 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                 py[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.y), t));
                 pz[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.z), t));
                 c2[t] = 0;
+                c2_sites[t] = 0;
             }
             // Row layout: entries with r < rnear fill the row from the front, the others from the back, so a
             // shorter-ranged force sharing this list walks only the front part.
-            int r0 = 0;                                   // run that holds stream index cb (wave-uniform, only ever advances)
+            for (int phase = 0; phase < 2; ++phase) {
+            // ---- candidate stream of this phase: the pieces (sites / the rest) of the stencil's cells, concatenated ----
+            int total;
+            {
+                int len[2], inc[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    len[hh] = phase ? ecn[hh] - elj[hh] : elj[hh];
+                    inc[hh] = len[hh];
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int v = __shfl_up(inc[hh], off);
+                        if (lane >= off) inc[hh] += v;
+                    }
+                }
+                const int lower = __builtin_amdgcn_readlane(inc[0], 63);
+                total = lower + __builtin_amdgcn_readlane(inc[1], 63);
+                __builtin_amdgcn_wave_barrier();                 // the previous phase's look-ups are done
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    s_rstart[w][lane + 64 * hh] = ecs[hh] + (phase ? elj[hh] : 0);
+                    s_rpref[w][lane + 64 * hh] = (hh ? lower : 0) + inc[hh] - len[hh];    // exclusive prefix; cells beyond the stencil: `total`
+                    s_rshift[w][0][lane + 64 * hh] = esx[hh];
+                    s_rshift[w][1][lane + 64 * hh] = esy[hh];
+                    s_rshift[w][2][lane + 64 * hh] = esz[hh];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             for (int cb = 0; cb < total; cb += AMM_BCHUNK) {
                 float4 cand[2];
                 int js[2];
                 bool inr = false;
-                // run of every lane's candidate: r0 + the number of run boundaries at or below its stream index.  The few
-                // boundaries inside a chunk are read from the prefix register with scalar lane selects -- a per-lane
-                // binary search of the LDS copy was six dependent LDS round trips per half chunk
-                while (r0 + 1 < nr && __builtin_amdgcn_readlane(prefv, r0 + 1) <= cb) ++r0;
-                int ru[2] = {r0, r0};
-                for (int k = r0 + 1; k < nr; ++k) {
-                    const int first = __builtin_amdgcn_readlane(prefv, k);
-                    if (first >= cb + AMM_BCHUNK) break;
-                    ru[0] += (cb + lane) >= first;
-                    ru[1] += (cb + 64 + lane) >= first;
-                }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int idx = cb + u * 64 + lane;
                     const bool in = idx < total;
-                    const int r = ru[u];
+                    int r = 0;                   // piece of the lane's candidate: the last one that starts at or below its stream index
+#pragma unroll
+                    for (int step = 64; step > 0; step >>= 1)
+                        if (s_rpref[w][r + step] <= idx) r += step;
                     const int slot = in ? s_rstart[w][r] + idx - s_rpref[w][r] : 0;
                     float4 q = pos4f_s[slot];
                     if (!RINT) {             // image shift; lanes beyond the stream are parked far away
@@ -572,11 +577,17 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                     }
                 }
             }
-            int count = 0, countf = 0;
+            if (phase == 0) {        // so far the row holds partners with a Lennard-Jones site only: remember how many, per side
+#pragma unroll
+                for (int t = 0; t < AMM_BATCH; ++t) c2_sites[t] = c2[t];
+            }
+            }      // phase
+            int count = 0, countf = 0, sites = 0;
 #pragma unroll
             for (int t = 0; t < AMM_BATCH; ++t) {
                 count = (lane == t) ? (c2[t] & 0xffff) : count;
                 countf = (lane == t) ? (int)((unsigned)c2[t] >> 16) : countf;
+                sites = (lane == t) ? c2_sites[t] : sites;
             }
             if (lane < nt) {
                 const int total_nb = count + countf;
@@ -584,6 +595,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                     const bool over = total_nb > cap;      // rows that overflow are flagged; amm_check() raises
                     nnb[tb + lane - s_begin] = over ? 0 : total_nb;
                     nnb_near[tb + lane - s_begin] = over ? 0 : count;
+                    if (nnb_lj) nnb_lj[tb + lane - s_begin] = over ? 0 : sites;      // front | back << 16
                     if (over) flags[1] = 1;
                 }
                 wsum += (unsigned long long)total_nb;
@@ -974,13 +986,20 @@ struct TabArgs {
     const int *row_order;                 // [nslice] sorted slots in traversal order, or null (slot order)
     const int *n_lj;                      // device: rows at the head of row_order that have a Lennard-Jones site (null: all)
     int ntask, nslice;
+    const int *nnb_lj;                    // per row: entries that are partners WITH a site (front | back << 16), first on either side; null: unknown
+    const int *nnb_all;                   // per row: total length (also when only the front part is walked: the stretches are cut the same way)
 };
 
 template <int FAM, int CMODE, int GFAM, bool INTERIOR, bool LJ>
 __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairConsts &c, const PairConsts &gc,
                                                  const char *tabh, const char *tabg, const double *s_erfcx, const double4 pi,
                                                  const double2 li, const int *row, int nfront, int nn, int sub, int lpa, int s,
-                                                 double &fx, double &fy, double &fz, double &gx, double &gy, double &gz) {
+                                                 double &fx, double &fy, double &fz, double &gx, double &gy, double &gz,
+                                                 int kstart = 0, int kend = 0x7fffffff, int kcut = 0x7fffffff, int kgap = 0) {
+    // The walk visits the row positions [kstart, kend), jumping over [kcut, kcut + kgap): one or two stretches of the rows.  All
+    // four are wave-uniform multiples of the trip length and live in scalar registers (the trips are counted by a scalar): the
+    // kernel gives the stretches whose partners may have a Lennard-Jones site to the walk with that arithmetic and the rest to
+    // the walk without.
     constexpr int UNR = 2;
     const double qi = c.Kc * pi.w;
     const int back = A.cap - 1 + nfront;
@@ -988,7 +1007,12 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
     // Software pipeline, two trips deep: while trip t computes, the j-records of trip t + 1 are in flight (issued at the top of
     // the iteration) and so are the row entries of trip t + 2.  With half the arithmetic per pair of the analytic kernel the
     // wavefront must overlap its own memory latency -- there are too few wavefronts per SIMD (registers) to leave it to them.
-    auto entry = [&](int k) { return k < nn ? row[k < nfront ? k : back - k] : s; };
+    auto entry = [&](int kb, int k) { return (kb < kend && k < nn) ? row[k < nfront ? k : back - k] : s; };      // kb: the trip's first position (scalar)
+    auto next_trip = [&](int kb) {
+        const int n = kb + step;
+        return __builtin_amdgcn_readfirstlane(n == kcut ? n + kgap : n);
+    };
+    auto any_left = [&](int kb) { return kb < kend && __builtin_amdgcn_ballot_w64(kb + sub < nn) != 0ull; };
     auto fetch = [&](int j, double4 &p, double2 &l) {
         p = *reinterpret_cast<const double4 *>(reinterpret_cast<const char *>(A.posq_s) + ((unsigned)j << 5));
         if (LJ) l = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.lj_s) + ((unsigned)j << 4));
@@ -1078,32 +1102,37 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
     int ja[UNR], jb[UNR];
     double4 pa[UNR], pb[UNR];
     double2 la[UNR], lb[UNR];
+    int ka = __builtin_amdgcn_readfirstlane(kstart == kcut ? kstart + kgap : kstart), kb = next_trip(ka);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-        ja[u] = entry(sub + u * lpa);
-        jb[u] = entry(sub + u * lpa + step);
+        ja[u] = entry(ka, ka + sub + u * lpa);
+        jb[u] = entry(kb, kb + sub + u * lpa);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) fetch(ja[u], pa[u], la[u]);
-    for (int k0 = sub; k0 < nn; k0 += 2 * step) {
+    while (any_left(ka)) {
         int jc[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            fetch(jb[u], pb[u], lb[u]);                 // records of trip k0 + step
+            fetch(jb[u], pb[u], lb[u]);                 // records of the next trip
             jc[u] = ja[u];
         }
+        const int kc = next_trip(kb);
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) ja[u] = entry(k0 + u * lpa + 2 * step);   // entries of trip k0 + 2 step
-        process(pa, la, jc, k0);
-        if (k0 + step >= nn) break;
+        for (int u = 0; u < UNR; ++u) ja[u] = entry(kc, kc + sub + u * lpa);   // entries of the trip after that
+        process(pa, la, jc, ka + sub);
+        if (!any_left(kb)) break;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            fetch(ja[u], pa[u], la[u]);                 // records of trip k0 + 2 step
+            fetch(ja[u], pa[u], la[u]);
             jc[u] = jb[u];
         }
+        const int kd = next_trip(kc);
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) jb[u] = entry(k0 + u * lpa + 3 * step);
-        process(pb, lb, jc, k0 + step);
+        for (int u = 0; u < UNR; ++u) jb[u] = entry(kd, kd + sub + u * lpa);
+        process(pb, lb, jc, kb + sub);
+        ka = kc;
+        kb = kd;
     }
 }
 
@@ -1158,7 +1187,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
         int s = A.s_begin;
         double4 pi = make_double4(0.0, 0.0, 0.0, 0.0);
         double2 li = make_double2(0.0, 0.0);
-        int nfront = 0, nn = 0;
+        int nfront = 0, nn = 0, ntot = 0, sites_front = 0x7fffffff, sites_back = 0x7fffffff;
         const int *row = A.nl;
         if (valid) {
             s = T.row_order ? T.row_order[a] : A.s_begin + a;
@@ -1168,26 +1197,70 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
             nfront = A.nnb[ra];
             nn = A.nnb_total ? A.nnb_total[ra] : nfront;
             row = A.nl + (size_t)ra * A.cap;
+            if (T.nnb_lj) {
+                const int sites = T.nnb_lj[ra];
+                sites_front = sites & 0xffff;
+                sites_back = (int)((unsigned)sites >> 16);
+                ntot = T.nnb_all[ra];
+            }
         }
         const bool edge = valid && !(pi.x >= T.margin && pi.x <= A.box.L[0] - T.margin && pi.y >= T.margin && pi.y <= A.box.L[1] - T.margin &&
                                      pi.z >= T.margin && pi.z <= A.box.L[2] - T.margin);
         const bool interior = __builtin_amdgcn_ballot_w64(edge) == 0ull;
         const bool any_lj = __builtin_amdgcn_ballot_w64(valid && li.y != 0.0) != 0ull;
         double fx = 0.0, fy = 0.0, fz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-#ifdef AMM_EXP_NOLJ
-        // experiment: as if no row had a Lennard-Jones site (wrong forces, same lists): the register budget and speed of a
-        // kernel that holds only the LJ-free loop
-        if (interior) amm_walk_row_tab<FAM, CMODE, GFAM, true, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
-        else amm_walk_row_tab<FAM, CMODE, GFAM, false, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
-#else
-        if (interior) {
-            if (any_lj) amm_walk_row_tab<FAM, CMODE, GFAM, true, true>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
-            else amm_walk_row_tab<FAM, CMODE, GFAM, true, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
-        } else {
-            if (any_lj) amm_walk_row_tab<FAM, CMODE, GFAM, false, true>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
-            else amm_walk_row_tab<FAM, CMODE, GFAM, false, false>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz);
+#define AMM_WALK(IN, LJF, KS, KE, KC, KG) amm_walk_row_tab<FAM, CMODE, GFAM, IN, LJF>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz, KS, KE, KC, KG)
+#define AMM_STRETCHES(LJF, KS, KE, KC, KG)                                                        \
+        do {                                                                                      \
+            if ((KE) > (KS) && __builtin_amdgcn_ballot_w64(valid && nn > (KS)) != 0ull) {         \
+                if (interior) AMM_WALK(true, LJF, KS, KE, KC, KG);                                \
+                else AMM_WALK(false, LJF, KS, KE, KC, KG);                                        \
+            }                                                                                     \
+        } while (0)
+        // The build files the partners that have a Lennard-Jones site first on either side of a row, so only the first trips of the
+        // front part and of the back part need the Lennard-Jones arithmetic (water: one pair in nine).  Cut at trip boundaries:
+        // [0, f1) and [b0, b1) go to ONE walk with that arithmetic (it jumps from f1 to b0), [f1, b0) and [b1, ...) to one
+        // walk without.  Tasks without a site take the second walk only, lists without the counts the first only.
+        const int all = 0x7fffffff;
+        int lj_end = 0, lj_cut = all, lj_gap = 0;              // walk with the Lennard-Jones part: [0, lj_end) less [lj_cut, lj_cut + lj_gap)
+        int pl_start = 0, pl_end = all, pl_cut = all, pl_gap = 0;
+        if (any_lj && !T.nnb_lj) {
+            lj_end = all;
+            pl_end = 0;
+        } else if (any_lj) {
+            const int trip_len = 2 << A.lpa_shift;
+            const bool mine = valid && li.y != 0.0;
+            // (from the row's full length even when only its front part is walked: the near force alone and as the guest of the
+            // outer force's pass then add up a row in the same order -- bit for bit)
+            const bool back = mine && ntot > nfront && sites_back > 0;
+            int f1 = mine ? min(sites_front, nfront) : 0, b0 = back ? nfront : all, b1 = back ? nfront + sites_back : 0;
+            for (int off = 32; off > 0; off >>= 1) {
+                f1 = max(f1, __shfl_xor(f1, off));
+                b0 = min(b0, __shfl_xor(b0, off));
+                b1 = max(b1, __shfl_xor(b1, off));
+            }
+            f1 = __builtin_amdgcn_readfirstlane((f1 + trip_len - 1) / trip_len * trip_len);
+            b0 = __builtin_amdgcn_readfirstlane(b0 == all ? all : b0 / trip_len * trip_len);
+            b1 = __builtin_amdgcn_readfirstlane((b1 + trip_len - 1) / trip_len * trip_len);
+            if (b1 <= b0) {                       // no partner with a site in any back part (or only front parts are walked)
+                lj_end = f1;
+                pl_start = f1;
+            } else if (f1 >= b0) {                // the two stretches touch
+                lj_end = b1;
+                pl_start = b1;
+            } else {
+                lj_end = b1;
+                lj_cut = f1;
+                lj_gap = b0 - f1;
+                pl_start = f1;
+                pl_cut = b0;
+                pl_gap = b1 - b0;
+            }
         }
-#endif
+        AMM_STRETCHES(true, 0, lj_end, lj_cut, lj_gap);
+        AMM_STRETCHES(false, pl_start, pl_end, pl_cut, pl_gap);
+#undef AMM_STRETCHES
+#undef AMM_WALK
         for (int off = lpa >> 1; off > 0; off >>= 1) {
             fx += __shfl_xor(fx, off);
             fy += __shfl_xor(fy, off);
@@ -1384,7 +1457,8 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
                        pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
                        pf->d_excl_idx, cap, nl, nnb, nnb_near, pf->d_flags, pf->d_blockstats, pf->d_counters,      \
-                       pf->d_ticket + AMM_TICKET_INTS, which, force, pf->d_member ? 1 : 0, direct ? pf->d_active : (int *)nullptr, pf->active_cap, pf->d_cell_sets)
+                       pf->d_ticket + AMM_TICKET_INTS, which, force, pf->d_member ? 1 : 0, direct ? pf->d_active : (int *)nullptr, pf->active_cap, pf->d_cell_sets,        \
+                       pf->d_cell_start_lj, direct ? pf->d_nnb_lj : (int *)nullptr)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
         else AMM_LAUNCH_BUILD(true, false);
@@ -1442,6 +1516,8 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     AMM_HIP(hipMalloc(&pf->d_nnb_out, sizeof(int) * ns));
     AMM_HIP(hipMalloc(&pf->d_nnb_scratch, sizeof(int) * ns));
     AMM_HIP(hipMalloc(&pf->d_row_order, sizeof(int) * ns));
+    AMM_HIP(hipMalloc(&pf->d_nnb_lj, sizeof(int) * ns));
+    AMM_HIP(hipMemset(pf->d_nnb_lj, 0, sizeof(int) * ns));
     if (pf->d_member && !(pf->skin_out > pf->skin * (1 + 1e-9))) AMM_HIP(hipMalloc(&pf->d_active, sizeof(int) * ns));
     pf->active_cap = (int)ns;
     // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding, but not beyond 16 lanes: longer
@@ -1692,6 +1768,8 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             T.n_lj = L->d_row_order ? L->d_flags + 3 : nullptr;
             T.nslice = nslice;
             T.ntask = (int)((threads + 63) / 64);
+            T.nnb_lj = (ctx->site_trips && !L->dual) ? L->d_nnb_lj : nullptr;    // the prune of a two-level list does not keep the counts
+            T.nnb_all = L->d_nnb;
             const int gfam = guest ? guest->desc.family : -1;
             PairConsts gpc = guest ? guest->pc : pf->pc;
             if (guest && (guest->desc.flags & AMM_GUARD_RC0)) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);   // step(rc0 - r)
@@ -1865,7 +1943,7 @@ int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos,
 }
 
 // bump when a pair-traversal kernel changes: stored measurements (profiles/*_traffic.json) are matched against it
-const char *amm_kernel_revision_impl() { return "r02-tab4"; }
+const char *amm_kernel_revision_impl() { return "r02-tab5"; }
 
 // radial Coulomb table of the force-only traversal (pair_tab.h): built from the descriptor alone, once per pair force
 int amm_pair_build_table(PairForce *pf) {
@@ -1916,7 +1994,7 @@ int amm_pair_free(PairForce *pf) {
                     pf->d_cell_start, pf->d_cell_members, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
                     pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near, pf->d_nl_out, pf->d_nnb_out,
                     pf->d_nnb_scratch, pf->d_xref_out, pf->d_ticket, pf->d_tab, pf->d_cls, pf->d_cell_count_lj, pf->d_cell_start_lj,
-                    pf->d_row_order, pf->d_member, pf->d_active, pf->d_cell_sets};
+                    pf->d_row_order, pf->d_member, pf->d_active, pf->d_cell_sets, pf->d_nnb_lj};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);
