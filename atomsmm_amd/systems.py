@@ -357,155 +357,166 @@ class AlchemicalRespaSystem(openmm.System):
 
     Kc = 138.935456637          # systems.py:572 (the other classes use 138.935456)
 
+    _MIXING = '; chargeprod = charge1*charge2; sigma = 0.5*(sigma1 + sigma2); epsilon = sqrt(epsilon1*epsilon2)'
+    _PAIR_PARAMETERS = ('chargeprod', 'sigma', 'epsilon')
+
     def __init__(self, system, rcutIn, rswitchIn, alchemical_atoms=[], coupling_parameter='lambda',
                  coupling_function='lambda', middle_scale=True, coulomb_scaling=False, lambda_coul=0,
                  use_softcore=False, split_alchemical=True):
         openmm.System.__init__(self)
         self._copy_from(system)
-        Kc = self.Kc
         self._parameter, self._middle_scale, self._use_softcore = coupling_parameter, middle_scale, use_softcore
         self._coulomb_scaling = coulomb_scaling
         self._solute_charges = {}
         self._lambda_coul = 0
-        solute_atoms = set(int(i) for i in alchemical_atoms)
-        solvent_atoms = set(range(self.getNumParticles())) - solute_atoms
-        rci, rsi = md_value(rcutIn), md_value(rswitchIn)
-        fsp = self._force_switched_potential(rci, rsi, Kc)
-        mixing_rules = '; chargeprod = charge1*charge2; sigma = 0.5*(sigma1 + sigma2); epsilon = sqrt(epsilon1*epsilon2)'
-        outer_group = 2 if middle_scale else 1
-        nonbonded = None
+        self._inner_cutoff = rcutIn
+        solute = set(int(i) for i in alchemical_atoms)
+        solvent = set(range(self.getNumParticles())) - solute
+        rc, rs = md_value(rcutIn), md_value(rswitchIn)
+        outer = 2 if middle_scale else 1
+        switched = self._force_switched_potential(rc, rs, self.Kc)
+        guarded = 'step({}-r)*U; U = {}'.format(rc, switched)
+
+        # 1. the NonbondedForce keeps the solvent; everything else goes to group 0
+        original = None
         for force in self.getForces():
-            if isinstance(force, openmm.NonbondedForce):
-                nonbonded = copy.deepcopy(force)
-                force.setForceGroup(outer_group)
-                force.setReciprocalSpaceForceGroup(outer_group)
-                for i in solute_atoms:
-                    self._solute_charges[i] = force.getParticleParameters(i)[0]
-                    force.setParticleParameters(i, 0.0, 1.0, 0.0)
-                have = set()
-                for index in range(force.getNumExceptions()):
-                    i, j = nonbonded.getExceptionParameters(index)[:2]
-                    if i in solute_atoms and j in solute_atoms:
-                        have.add(frozenset((i, j)))
-                        force.setExceptionParameters(index, i, j, 0.0, 1.0, 0.0)
-                for i, j in itertools.combinations(sorted(solute_atoms), 2):
-                    if frozenset((i, j)) not in have:
-                        force.addException(i, j, 0.0, 1.0, 0.0)
-                        q1, sig1, eps1 = nonbonded.getParticleParameters(i)
-                        q2, sig2, eps2 = nonbonded.getParticleParameters(j)
-                        nonbonded.addException(i, j, q1 * q2, (sig1 + sig2) / 2, (eps1 * eps2).sqrt())
-                if middle_scale:
-                    near_force = openmm.CustomNonbondedForce(fsp + mixing_rules)
-                    self._import_from_nonbonded(near_force, force)
-                    near_force.setCutoffDistance(rcutIn)
-                    near_force.setUseSwitchingFunction(False)
-                    near_force.setUseLongRangeCorrection(False)
-                    near_force.addGlobalParameter('respa_switch', 0)
-                    near_force.setForceGroup(1)
-                    self.addForce(near_force)
-                    exceptions = openmm.CustomBondForce('step({}-r)*U; U = {}'.format(rci, fsp))
-                    exceptions.addGlobalParameter('respa_switch', 0)
-                    for parameter in ['chargeprod', 'sigma', 'epsilon']:
-                        exceptions.addPerBondParameter(parameter)
-                    for index in range(force.getNumExceptions()):
-                        i, j, chargeprod, sigma, epsilon = force.getExceptionParameters(index)
-                        if md_value(chargeprod) != 0.0 or md_value(epsilon) != 0.0:
-                            exceptions.addBond(i, j, (chargeprod, sigma, epsilon))
-                    if exceptions.getNumBonds() > 0:
-                        exceptions.setForceGroup(1)
-                        self.addForce(exceptions)
-                self._nonbonded_force = force
-            else:
+            if not isinstance(force, openmm.NonbondedForce):
                 force.setForceGroup(0)
-        if not solute_atoms or nonbonded is None:
+                continue
+            original = copy.deepcopy(force)
+            self._strip_solute(force, original, solute, outer)
+            if middle_scale:
+                self.addForce(self._switched_pair_force(switched, force, group=1))
+                self._add_if_any(self._pair_bonds(guarded, 1, ((i, j, q, s_, e) for i, j, q, s_, e in self._exceptions(force)
+                                                                    if md_value(q) != 0.0 or md_value(e) != 0.0)))
+            self._nonbonded_force = force
+        if not solute or original is None:
             return
-        full_range = openmm.CustomBondForce('4*epsilon*x*(x - 1) + {}*chargeprod/r; x = (sigma/r)^6'.format(Kc))
-        full_range.setForceGroup(outer_group)
-        intrasolute_forces = [full_range]
+
+        # 2. solute-solute pairs: cutoff-less LJC bonds, and their short-ranged copy
+        inside = [(i, j, q, s_, e) for i, j, q, s_, e in self._exceptions(original) if i in solute and j in solute]
+        ljc = '4*epsilon*x*(x - 1) + {}*chargeprod/r; x = (sigma/r)^6'.format(self.Kc)
+        self.addForce(self._pair_bonds(ljc, outer, inside, switchable=False))
         if middle_scale:
-            short_range = openmm.CustomBondForce('step({}-r)*U; U = {}'.format(rci, fsp))
-            short_range.addGlobalParameter('respa_switch', 0)
-            short_range.setForceGroup(1)
-            intrasolute_forces.append(short_range)
-        for force in intrasolute_forces:
-            for parameter in ['chargeprod', 'sigma', 'epsilon']:
-                force.addPerBondParameter(parameter)
-            self.addForce(force)
-        for index in range(nonbonded.getNumExceptions()):
-            i, j, chargeprod, sigma, epsilon = nonbonded.getExceptionParameters(index)
-            if i in solute_atoms and j in solute_atoms:
-                for force in intrasolute_forces:
-                    force.addBond(i, j, (chargeprod, sigma, epsilon))
+            self.addForce(self._pair_bonds(guarded, 1, inside))
+
+        # 3. short-ranged solute-solvent electrostatics (particles keep the ORIGINAL charges until
+        #    reset_coulomb_scaling_factor rescales the solute's, systems.py:698-708)
         if coulomb_scaling and middle_scale:
-            # short-ranged part of the solute-solvent electrostatics; its particles are imported with the ORIGINAL charges
-            # and only reset_coulomb_scaling_factor rescales the solute's (systems.py:698-708)
-            fsep = self._force_switched_eletrostatic_potential(rci, rsi, Kc)
-            short_range = openmm.CustomNonbondedForce(fsep + mixing_rules)
-            self._import_from_nonbonded(short_range, nonbonded)
-            short_range.setCutoffDistance(rcutIn)
-            short_range.setUseSwitchingFunction(False)
-            short_range.setUseLongRangeCorrection(False)
-            short_range.addGlobalParameter('respa_switch', 0)
-            short_range.setForceGroup(1)
-            short_range.addInteractionGroup(solute_atoms, solvent_atoms)
-            self.addForce(short_range)
-            self._fsep_force = short_range
+            text = self._force_switched_eletrostatic_potential(rc, rs, self.Kc)
+            self._fsep_force = self._switched_pair_force(text, original, group=1, sets=(solute, solvent))
+            self.addForce(self._fsep_force)
+
+        # 4. solute-solvent Lennard-Jones: softcore, or a collective variable times the coupling function
         if use_softcore:
             ljsoft = '4*{0}*epsilon*x*(x - 1); x = 1/((r/sigma)^6 + 0.5*(1-{0}))'.format(coupling_parameter)
-            full_range = openmm.CustomNonbondedForce(ljsoft + mixing_rules)
-            self._import_from_nonbonded(full_range, nonbonded, import_globals=True)
-            full_range.addInteractionGroup(solute_atoms, solvent_atoms)
-            full_range.addGlobalParameter(coupling_parameter, 1.0)
-            full_range.addEnergyParameterDerivative(coupling_parameter)
-            full_range.setForceGroup(outer_group)
-            self.addForce(full_range)
-            self._alchemical_vdw_force = full_range
+            softcore = self._outer_pair_force(ljsoft, original, (solute, solvent))
+            softcore.addGlobalParameter(coupling_parameter, 1.0)
+            softcore.addEnergyParameterDerivative(coupling_parameter)
+            softcore.setForceGroup(outer)
+            self.addForce(softcore)
+            self._alchemical_vdw_force = softcore
             if middle_scale:
-                short_range = copy.deepcopy(full_range)
-                short_range.setEnergyFunction('respa_switch*{}'.format(ljsoft) + mixing_rules)
-                short_range.addGlobalParameter('respa_switch', 0)
-                short_range.setForceGroup(1)
-                self.addForce(short_range)
+                self.addForce(self._switched_copy(softcore, ljsoft))
         else:
-            potential = '((gt0-gt1)*S + gt1)*alchemical_vdw_energy'
-            potential += '; gt0 = step({})'.format(coupling_parameter)
-            potential += '; gt1 = step({}-1)'.format(coupling_parameter)
-            potential += '; S = {}'.format(coupling_function)
-            cv_force = openmm.CustomCVForce(potential)
-            cv_force.addGlobalParameter(coupling_parameter, 1.0)
-            cv_force.addEnergyParameterDerivative(coupling_parameter)
+            coupling = ('((gt0-gt1)*S + gt1)*alchemical_vdw_energy; gt0 = step({0}); gt1 = step({0}-1); S = {1}'
+                        .format(coupling_parameter, coupling_function))
             lj = '4*epsilon*x*(x - 1); x = (sigma/r)^6'
-            full_range = openmm.CustomNonbondedForce(lj + mixing_rules)
-            self._import_from_nonbonded(full_range, nonbonded, import_globals=True)
-            full_range.addInteractionGroup(solute_atoms, solvent_atoms)
-            full_range_cv_force = copy.deepcopy(cv_force)
-            full_range_cv_force.addCollectiveVariable('alchemical_vdw_energy', full_range)
-            full_range_cv_force.setForceGroup(outer_group)
-            self.addForce(full_range_cv_force)
-            self._alchemical_vdw_force = full_range_cv_force
+            energy = self._outer_pair_force(lj, original, (solute, solvent))
+            self._alchemical_vdw_force = self._coupled(coupling, coupling_parameter, energy, outer)
+            self.addForce(self._alchemical_vdw_force)
             if middle_scale and split_alchemical:
-                fsljp = self._force_switched_potential(rci, rsi, 0.0)
-                short_range = openmm.CustomNonbondedForce(fsljp + mixing_rules)
-                self._import_from_nonbonded(short_range, nonbonded)
-                short_range.setCutoffDistance(rcutIn)
-                short_range.setUseSwitchingFunction(False)
-                short_range.setUseLongRangeCorrection(False)
-                short_range.addGlobalParameter('respa_switch', 0)
-                short_range.addInteractionGroup(solute_atoms, solvent_atoms)
-                cv_force.addCollectiveVariable('alchemical_vdw_energy', short_range)
-                cv_force.setForceGroup(1)
-                self.addForce(cv_force)
+                near_energy = self._switched_pair_force(self._force_switched_potential(rc, rs, 0.0), original, group=None,
+                                                        sets=(solute, solvent))
+                self.addForce(self._coupled(coupling, coupling_parameter, near_energy, 1))
             elif middle_scale:
-                short_range = copy.deepcopy(full_range)
-                short_range.setEnergyFunction('respa_switch*{}'.format(lj) + mixing_rules)
-                short_range.addGlobalParameter('respa_switch', 0)
-                short_range.setForceGroup(1)
-                self.addForce(short_range)
+                self.addForce(self._switched_copy(energy, lj))
 
         # stored as zero and reset only if a different value was passed (systems.py:781-783): with the default the
         # force-switched electrostatic force keeps the solute's full charges, as in the reference
         self._lambda_coul = 0
         self.reset_coulomb_scaling_factor(lambda_coul)
+
+    # ---- pieces of the constructor -------------------------------------------------------------------------------
+    @staticmethod
+    def _exceptions(force):
+        return [force.getExceptionParameters(k) for k in range(force.getNumExceptions())]
+
+    def _strip_solute(self, force, original, solute, group):
+        """The solute leaves the NonbondedForce: parameters (0, 1, 0), every solute-solute pair an exclusion; `original`
+        (a copy made before) receives the missing solute-solute pairs as exceptions with the combined parameters."""
+        force.setForceGroup(group)
+        force.setReciprocalSpaceForceGroup(group)
+        for i in solute:
+            self._solute_charges[i] = force.getParticleParameters(i)[0]
+            force.setParticleParameters(i, 0.0, 1.0, 0.0)
+        listed = set()
+        for index, (i, j) in enumerate(e[:2] for e in self._exceptions(original)):
+            if i in solute and j in solute:
+                listed.add(frozenset((i, j)))
+                force.setExceptionParameters(index, i, j, 0.0, 1.0, 0.0)
+        for i, j in itertools.combinations(sorted(solute), 2):
+            if frozenset((i, j)) in listed:
+                continue
+            force.addException(i, j, 0.0, 1.0, 0.0)
+            (q1, sig1, eps1), (q2, sig2, eps2) = original.getParticleParameters(i), original.getParticleParameters(j)
+            original.addException(i, j, q1 * q2, (sig1 + sig2) / 2, (eps1 * eps2).sqrt())
+
+    def _switched_pair_force(self, expression, source, group, sets=None):
+        """CustomNonbondedForce of the middle time scale: cutoff rcutIn, no built-in switch or correction, gated by the
+        global parameter respa_switch; optionally restricted to an interaction group."""
+        force = openmm.CustomNonbondedForce(expression + self._MIXING)
+        self._import_from_nonbonded(force, source)
+        force.setCutoffDistance(self._inner_cutoff)
+        force.setUseSwitchingFunction(False)
+        force.setUseLongRangeCorrection(False)
+        force.addGlobalParameter('respa_switch', 0)
+        if group is not None:
+            force.setForceGroup(group)
+        if sets is not None:
+            force.addInteractionGroup(*sets)
+        return force
+
+    def _outer_pair_force(self, expression, source, sets):
+        """CustomNonbondedForce over the (solute, solvent) group with the cutoff, switch and correction of the NonbondedForce."""
+        force = openmm.CustomNonbondedForce(expression + self._MIXING)
+        self._import_from_nonbonded(force, source, import_globals=True)
+        force.addInteractionGroup(*sets)
+        return force
+
+    def _switched_copy(self, force, expression):
+        """Copy of an outer pair force for group 1: the same particles and settings, its energy times respa_switch."""
+        twin = copy.deepcopy(force)
+        twin.setEnergyFunction('respa_switch*{}'.format(expression) + self._MIXING)
+        twin.addGlobalParameter('respa_switch', 0)
+        twin.setForceGroup(1)
+        return twin
+
+    def _pair_bonds(self, expression, group, pairs, switchable=True):
+        """CustomBondForce with (chargeprod, sigma, epsilon) per bond over `pairs` = (i, j, chargeprod, sigma, epsilon)."""
+        force = openmm.CustomBondForce(expression)
+        if switchable:
+            force.addGlobalParameter('respa_switch', 0)
+        for name in self._PAIR_PARAMETERS:
+            force.addPerBondParameter(name)
+        for i, j, chargeprod, sigma, epsilon in pairs:
+            force.addBond(i, j, (chargeprod, sigma, epsilon))
+        force.setForceGroup(group)
+        return force
+
+    def _add_if_any(self, bond_force):
+        if bond_force.getNumBonds() > 0:
+            self.addForce(bond_force)
+
+    @staticmethod
+    def _coupled(text, parameter, energy_force, group):
+        """CustomCVForce `coupling(parameter) * alchemical_vdw_energy` over one pair force."""
+        force = openmm.CustomCVForce(text)
+        force.addGlobalParameter(parameter, 1.0)
+        force.addEnergyParameterDerivative(parameter)
+        force.addCollectiveVariable('alchemical_vdw_energy', energy_force)
+        force.setForceGroup(group)
+        return force
 
     def get_alchemical_vdw_force(self, parameter_values=[1]):
         if self._use_softcore:
