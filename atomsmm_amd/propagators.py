@@ -391,20 +391,29 @@ class NoseHooverPropagator(Propagator):
         for name in ('vscaling', 'p_eta', 'n_NH'):
             self.globalVariables[name] = 0
 
+    HEAD = """
+        global p_eta <- p_eta + ({half}*dt)*(mvv - LkT)
+        global vscaling <- exp(-({h}*dt)*p_eta/Q)
+    """
+    LOOP = """
+        global n_NH <- 1
+        while n_NH < {n}
+        global p_eta <- p_eta + ({h}*dt)*(vscaling^2*mvv - LkT)
+        global vscaling <- vscaling*exp(-({h}*dt)*p_eta/Q)
+        global n_NH <- n_NH + 1
+        end
+    """
+    TAIL = """
+        global p_eta <- p_eta + ({half}*dt)*(vscaling^2*mvv - LkT)
+        dof v <- vscaling*v
+    """
+
     def addSteps(self, integrator, fraction=1.0, force='f'):
-        n = self.nloops
-        subfrac = fraction / n
-        integrator.addComputeGlobal('p_eta', 'p_eta + ({}*dt)*(mvv - LkT)'.format(0.5 * subfrac))
-        integrator.addComputeGlobal('vscaling', 'exp(-({}*dt)*p_eta/Q)'.format(subfrac))
-        if n > 2:
-            integrator.addComputeGlobal('n_NH', '1')
-            integrator.beginWhileBlock('n_NH < {}'.format(n))
-            integrator.addComputeGlobal('p_eta', 'p_eta + ({}*dt)*(vscaling^2*mvv - LkT)'.format(subfrac))
-            integrator.addComputeGlobal('vscaling', 'vscaling*exp(-({}*dt)*p_eta/Q)'.format(subfrac))
-            integrator.addComputeGlobal('n_NH', 'n_NH + 1')
-            integrator.endBlock()
-        integrator.addComputeGlobal('p_eta', 'p_eta + ({}*dt)*(vscaling^2*mvv - LkT)'.format(0.5 * subfrac))
-        integrator.addComputePerDof('v', 'vscaling*v')
+        h = fraction / self.nloops
+        play(integrator, self.HEAD, h=h, half=0.5 * h)
+        if self.nloops > 2:            # as the reference emits it (propagators.py:1258: no inner pass for two loops)
+            play(integrator, self.LOOP, h=h, n=self.nloops)
+        play(integrator, self.TAIL, half=0.5 * h)
 
 
 class MassiveNoseHooverPropagator(Propagator):
@@ -418,17 +427,20 @@ class MassiveNoseHooverPropagator(Propagator):
         self.globalVariables['nMNH'] = 0
         self.perDofVariables['p_eta'] = 0
 
+    BODY = """
+        dof p_eta <- p_eta + ({half}*dt)*(m*v^2 - kT)
+        dof v <- v*exp(-({h}*dt)*p_eta/Q)
+        dof p_eta <- p_eta + ({half}*dt)*(m*v^2 - kT)
+    """
+
     def addSteps(self, integrator, fraction=1.0, force='f'):
-        subfrac = fraction / self.nloops
-        if self.nloops > 1:
-            integrator.addComputeGlobal('nMNH', '0')
-            integrator.beginWhileBlock('nMNH < {}'.format(self.nloops))
-        integrator.addComputePerDof('p_eta', 'p_eta + ({}*dt)*(m*v^2 - kT)'.format(0.5 * subfrac))
-        integrator.addComputePerDof('v', 'v*exp(-({}*dt)*p_eta/Q)'.format(subfrac))
-        integrator.addComputePerDof('p_eta', 'p_eta + ({}*dt)*(m*v^2 - kT)'.format(0.5 * subfrac))
-        if self.nloops > 1:
-            integrator.addComputeGlobal('nMNH', 'nMNH + 1')
-            integrator.endBlock()
+        h = fraction / self.nloops
+        repeated = self.nloops > 1
+        if repeated:
+            play(integrator, 'global nMNH <- 0\nwhile nMNH < {n}', n=self.nloops)
+        play(integrator, self.BODY, h=h, half=0.5 * h)
+        if repeated:
+            play(integrator, 'global nMNH <- nMNH + 1\nend')
 
 
 class MassiveGeneralizedGaussianMomentPropagator(Propagator):
@@ -446,25 +458,22 @@ class MassiveGeneralizedGaussianMomentPropagator(Propagator):
         self.perDofVariables['p1'] = 0
         self.perDofVariables['p2'] = 0
 
+    BODY = """
+        dof p1 <- p1 + ({half}*dt)*(m*v^2 - kT)
+        dof p2 <- p2 + ({half}*dt)*(m^2*v^4/3 - kT^2)
+        dof v <- v2*{scale};v2 = v1/sqrt(1 + 2*v1^2*alpha*{h}*dt);alpha = p2/(3*m*Q2);v1 = v*{scale}
+        dof p2 <- p2 + ({half}*dt)*(m^2*v^4/3 - kT^2)
+        dof p1 <- p1 + ({half}*dt)*(m*v^2 - kT)
+    """
+
     def addSteps(self, integrator, fraction=1.0, force='f'):
-        subfrac = fraction / self.nloops
-        half = subfrac / 2
-        boost1 = 'p1 + ({}*dt)*(m*v^2 - kT)'.format(half)
-        boost2 = 'p2 + ({}*dt)*(m^2*v^4/3 - kT^2)'.format(half)
-        scaling = 'exp(-{}*dt*(p1/Q1 + kT*p2/Q2))'.format(half)
-        velocity = ['v2*{}'.format(scaling), 'v2 = v1/sqrt(1 + 2*v1^2*alpha*{}*dt)'.format(subfrac), 'alpha = p2/(3*m*Q2)',
-                    'v1 = v*{}'.format(scaling)]
-        if self.nloops > 1:
-            integrator.addComputeGlobal('nGGM', '0')
-            integrator.beginWhileBlock('nGGM < {}'.format(self.nloops))
-        integrator.addComputePerDof('p1', boost1)
-        integrator.addComputePerDof('p2', boost2)
-        integrator.addComputePerDof('v', ';'.join(velocity))
-        integrator.addComputePerDof('p2', boost2)
-        integrator.addComputePerDof('p1', boost1)
-        if self.nloops > 1:
-            integrator.addComputeGlobal('nGGM', 'nGGM + 1')
-            integrator.endBlock()
+        h = fraction / self.nloops
+        repeated = self.nloops > 1
+        if repeated:
+            play(integrator, 'global nGGM <- 0\nwhile nGGM < {n}', n=self.nloops)
+        play(integrator, self.BODY, h=h, half=h / 2, scale='exp(-{}*dt*(p1/Q1 + kT*p2/Q2))'.format(h / 2))
+        if repeated:
+            play(integrator, 'global nGGM <- nGGM + 1\nend')
 
 
 class _TwoStageGlobalThermostat(Propagator):
