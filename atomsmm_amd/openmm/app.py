@@ -502,5 +502,67 @@ class Simulation:
         self.reporters = []
 
     def step(self, steps):
-        self.integrator.step(steps)
-        self.currentStep += steps
+        """Advance by `steps`, serving `self.reporters` with OpenMM's reporter protocol: `describeNextReport(simulation)` ->
+        (steps until the next report, positions?, velocities?, forces?, energies?[, wrap?]) and `report(simulation, state)`."""
+        remaining = int(steps)
+        while remaining > 0:
+            plans = [(reporter, reporter.describeNextReport(self)) for reporter in self.reporters]
+            due = [plan[0] for _, plan in plans if 0 < plan[0] <= remaining]
+            stride = min(due) if due else remaining
+            self.integrator.step(stride)
+            self.currentStep += stride
+            remaining -= stride
+            reporting = [(reporter, plan) for reporter, plan in plans if plan[0] == stride]
+            if reporting:
+                wants = [any(plan[k] for _, plan in reporting) for k in range(1, 5)]
+                state = self.context.getState(getPositions=wants[0], getVelocities=wants[1], getForces=wants[2],
+                                              getEnergy=wants[3], getParameters=True)
+                for reporter, _ in reporting:
+                    reporter.report(self, state)
+
+
+class StateDataReporter:
+    """app.StateDataReporter(file, reportInterval, step=..., time=..., potentialEnergy=..., kineticEnergy=..., totalEnergy=...,
+    temperature=..., volume=..., density=..., speed=..., separator=','): the columns of OpenMM's reporter that a script of
+    the reference typically asks for, written as separated text (units: ps, kJ/mol, K, nm^3, g/mL, ns/day)."""
+
+    def __init__(self, file, reportInterval, step=False, time=False, potentialEnergy=False, kineticEnergy=False,
+                 totalEnergy=False, temperature=False, volume=False, density=False, speed=False, separator=',', **ignored):
+        self._out = open(file, 'w') if isinstance(file, str) else file
+        self._interval = int(reportInterval)
+        self._columns = [name for name, on in (('Step', step), ('Time (ps)', time), ('Potential Energy (kJ/mole)', potentialEnergy),
+                                               ('Kinetic Energy (kJ/mole)', kineticEnergy), ('Total Energy (kJ/mole)', totalEnergy),
+                                               ('Temperature (K)', temperature), ('Box Volume (nm^3)', volume),
+                                               ('Density (g/mL)', density), ('Speed (ns/day)', speed)) if on]
+        self._separator = separator
+        self._started = None
+
+    def describeNextReport(self, simulation):
+        steps = self._interval - simulation.currentStep % self._interval
+        return (steps, False, False, False, True)
+
+    def report(self, simulation, state):
+        import time as _time
+        system = simulation.system
+        if self._started is None:
+            print('#"' + ('"' + self._separator + '"').join(self._columns) + '"', file=self._out)
+            self._started = (_time.time(), state.getTime().value_in_unit(_unit.picoseconds))
+            masses = [system.getParticleMass(i).value_in_unit(_unit.dalton) for i in range(system.getNumParticles())]
+            self._mass = sum(masses)
+            self._dof = 3 * sum(1 for m in masses if m > 0) - system.getNumConstraints()
+            if any(type(force).__name__ == 'CMMotionRemover' for force in system.getForces()):
+                self._dof -= 3
+        pe = state.getPotentialEnergy().value_in_unit(_unit.kilojoules_per_mole)
+        ke = state.getKineticEnergy().value_in_unit(_unit.kilojoules_per_mole)
+        box = state.getPeriodicBoxVectors()
+        volume = (box[0][0] * box[1][1] * box[2][2]).value_in_unit(_unit.nanometers ** 3)
+        now, t_ps = _time.time(), state.getTime().value_in_unit(_unit.picoseconds)
+        elapsed = now - self._started[0]
+        values = {'Step': simulation.currentStep, 'Time (ps)': t_ps, 'Potential Energy (kJ/mole)': pe,
+                  'Kinetic Energy (kJ/mole)': ke, 'Total Energy (kJ/mole)': pe + ke,
+                  'Temperature (K)': 2.0 * ke / (self._dof * 8.3144626e-3),
+                  'Box Volume (nm^3)': volume, 'Density (g/mL)': self._mass / volume / 602.214076,
+                  'Speed (ns/day)': (t_ps - self._started[1]) * 86.4 / elapsed if elapsed > 0 else 0.0}
+        print(self._separator.join(str(values[name]) for name in self._columns), file=self._out)
+        if hasattr(self._out, 'flush'):
+            self._out.flush()

@@ -735,3 +735,41 @@ def test_softcore_force_classes(heaq, recorder):
     both.importFrom(system2.getForce(atomsmm.findNonbondedForce(system2))).addTo(system2)
     with pytest.raises(atomsmm.InputError):
         openmm.Context(system2, openmm.VerletIntegrator(0.0))
+
+
+def test_simulation_serves_reporters(spcfw, recorder):
+    """app.Simulation.step follows OpenMM's reporter protocol (describeNextReport / report), so scripts that attach reporters
+    keep working: reports land on the right steps whatever the chunks step() is called in; app.StateDataReporter writes
+    the requested columns."""
+    import io
+    system = system_from_arrays(spcfw, nonbondedMethod='CutoffPeriodic')
+    respa = atomsmm.RESPASystem(system, 7 * unit.angstroms, 5 * unit.angstroms)
+    integrator = atomsmm.RespaPropagator([2, 2, 1]).integrator(1 * unit.femtoseconds)
+    simulation = app.Simulation(app.Topology(), respa, integrator, openmm.Platform.getPlatformByName('HIP'))
+    simulation.context.setPositions(spcfw['positions'] * unit.nanometers)
+
+    class Probe:
+        def __init__(self, every):
+            self.every, self.seen = every, []
+
+        def describeNextReport(self, simulation):
+            return (self.every - simulation.currentStep % self.every, True, False, False, False)
+
+        def report(self, simulation, state):
+            self.seen.append(simulation.currentStep)
+            assert state.getPositions(asNumpy=True)._value.shape == (len(spcfw['positions']), 3)
+
+    three, five = Probe(3), Probe(5)
+    text = io.StringIO()
+    simulation.reporters += [three, five, app.StateDataReporter(text, 4, step=True, time=True, potentialEnergy=True,
+                                                                temperature=True, volume=True, density=True, speed=True)]
+    for chunk in (1, 6, 2, 7):
+        simulation.step(chunk)
+    assert simulation.currentStep == 16
+    assert three.seen == [3, 6, 9, 12, 15] and five.seen == [5, 10, 15]
+    lines = text.getvalue().strip().splitlines()
+    assert lines[0].startswith('#"Step","Time (ps)","Potential Energy (kJ/mole)","Temperature (K)"')
+    assert [int(line.split(',')[0]) for line in lines[1:]] == [4, 8, 12, 16]
+    assert float(lines[-1].split(',')[1]) == pytest.approx(0.016)
+    density = float(lines[-1].split(',')[5])
+    assert 0.9 < density < 1.1               # q-SPC/Fw water
