@@ -447,6 +447,80 @@ def test_neighbour_list_rebuild_and_reuse(spcfw, outer_skin):
     ctx.close()
 
 
+@pytest.mark.parametrize('seed', [11, 12, 13, 14, 15, 16])
+def test_random_boxes_and_site_mixes_vs_oracle(seed):
+    """Randomised configurations for the list build and both traversals: non-cubic boxes down to the size where a
+    dimension holds fewer cells than the stencil is wide (minimum-image build), fractions of atoms with a Lennard-Jones site
+    from none to all (the build walks sites and the rest as two streams; the force-only kernel cuts its tasks by them),
+    random exclusions between near neighbours, the near force alone and as the guest of a damped outer force's pass.  Both
+    the energy-carrying and the force-only (tabulated) kernel against the oracle, the in-cutoff pair count against numpy,
+    before and after a random displacement that triggers a rebuild."""
+    B = _backend()
+    rng = np.random.default_rng(seed)
+    box = rng.uniform(2.3, 4.6, 3)
+    if seed % 3 == 0:
+        box[rng.integers(3)] = rng.uniform(2.05, 2.25)               # fewer than five cells along one axis
+    n = int(rng.integers(700, 2600))
+    # jittered lattice: liquid-like density without overlaps
+    m = int(np.ceil(n ** (1 / 3)))
+    grid = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing='ij'), -1).reshape(-1, 3)[rng.permutation(m ** 3)[:n]]
+    pos = (grid + 0.5 + rng.uniform(-0.28, 0.28, (n, 3))) / m * box
+    site_fraction = [0.0, 0.1, 1 / 3, 0.5, 0.8, 1.0][seed % 6]
+    has_site = rng.random(n) < site_fraction
+    q = rng.normal(0.0, 0.4, n)
+    q -= q.mean()
+    sigma = np.where(has_site, rng.uniform(0.25, 0.34, n), 0.1)
+    eps = np.where(has_site, rng.uniform(0.2, 0.9, n), 0.0)
+    # exclusions: some of the closest pairs
+    d2 = ((pos[:, None, :] - pos[None, :, :] + 0.5 * box) % box - 0.5 * box)
+    d2 = (d2 ** 2).sum(-1)
+    close = np.argwhere(np.triu(d2 < 0.2 ** 2, 1))
+    excl = close[rng.random(len(close)) < 0.5]
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+    ctx = B.HipContext(n, box)
+    case = dict(charge=q, sigma=sigma, epsilon=eps, exc_pairs=excl)
+    fn = hip_pair(B, ctx, dn, case, skin=0.1)
+    ff = hip_pair(B, ctx, dd, case, skin=0.1)
+    ctx.pair_share_list(fn, ff)
+    for stage in range(2):
+        x = dev(pos)
+        refs = {fid: O.pair_eval(d, pos, box, q, sigma, eps, excl) for fid, d in ((fn, dn), (ff, dd))}
+        for fid in (fn, ff):
+            e, f = eval_force(ctx, fid, x, n)                                   # energy-carrying kernel
+            e_ref, f_ref, _ = refs[fid]
+            scale = max(np.abs(f_ref).max(), 1.0)
+            assert e == pytest.approx(e_ref, rel=1e-10, abs=1e-9)
+            assert np.abs(f - f_ref).max() <= 1e-9 * scale
+            only = torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda')
+            ctx.force_eval(fid, x, only, accumulate=False)                      # force-only kernel (tabulated)
+            ctx.check()
+            assert np.abs(only.cpu().numpy() - f_ref).max() <= 1e-9 * scale
+        # dual pass through the op interface: both forces in one traversal
+        bufs = [torch.zeros((n, 3), dtype=torch.float64, device='cuda') for _ in range(3)]
+        ctx.bind_state(x, dev(np.zeros((n, 3))), dev(np.ones(n)))
+        for slot, buf in enumerate(bufs):
+            ctx.bind_buffer(slot, buf)
+        ctx.group_define(1, 1, [fn])
+        ctx.group_define(2, 2, [ff])
+        ctx.run_ops([B.Op(B.OP_EVAL, 1, 0, 0, 0.0), B.Op(B.OP_EVAL, 2, 0, 0, 0.0)], 1)
+        ctx.check()
+        for slot, fid in ((1, fn), (2, ff)):
+            f_ref = refs[fid][1]
+            assert np.abs(bufs[slot].cpu().numpy() - f_ref).max() <= 1e-9 * max(np.abs(f_ref).max(), 1.0)
+        within = ctx.pair_count_within(ff, x, 1.0)
+        dist2 = ((pos[:, None, :] - pos[None, :, :] + 0.5 * box) % box - 0.5 * box)
+        dist2 = (dist2 ** 2).sum(-1)
+        mask = dist2 < 1.0
+        np.fill_diagonal(mask, False)
+        mask[excl[:, 0], excl[:, 1]] = False
+        mask[excl[:, 1], excl[:, 0]] = False
+        assert within == int(mask.sum())
+        assert ctx.pair_stats(ff)['n_builds'] == stage + 1
+        pos = pos + rng.normal(0.0, 0.05, pos.shape)                            # beyond skin / 2 for many atoms
+    ctx.close()
+
+
 def test_atom_decomposition_slices_sum_to_full(spcfw):
     """amm_set_slice: two 'ranks' (two contexts on one GPU) each compute their i-slice; the sum of the
     two buffers (what the RCCL all-reduce does) equals the single-rank forces bit for bit."""
