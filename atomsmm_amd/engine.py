@@ -1060,8 +1060,14 @@ class Engine:
             e.recip is not None and e.recip_group == g for e in self.entries)
         ids = list(pair_ids)
         if terms:
-            ids.append(self._make_bonded(terms, sliced=reduced))
-            self._group_bonded.append(ids[-1])
+            merged = self._make_bonded(terms, sliced=reduced)
+            self._group_bonded.append(merged)
+            # the first member of a group writes the buffer, the others add to it: an interaction-group force touches a few rows
+            # only (it would have to clear the rest first), so the bond lists go first in its group
+            if any(e.softcore is not None for e in members):
+                ids.insert(0, merged)
+            else:
+                ids.append(merged)
         for e in self.entries:
             if e.recip is not None and (g == 'all' or e.recip_group == g):
                 e.recip_sliced = reduced
