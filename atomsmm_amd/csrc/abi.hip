@@ -989,6 +989,32 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     }
                 }
             }
+            // a run of plain kicks, then (maybe) a move: one launch (same arithmetic per degree of freedom, same order)
+            if (ctx->fuse_inner && !ctx->iso.on && op.op == AMM_OP_KICK) {
+                const double *fa[4], *fb[4];
+                int plus[4], nk = 0;
+                double coef[4];
+                int j = k;
+                while (j < n_ops && nk < 4 && ops[j].op == AMM_OP_KICK) {
+                    const amm_op &kick = ops[j];
+                    const double *a_ = (kick.a >= 0 && kick.a < AMM_MAX_SLOTS) ? ctx->slots[kick.a] : nullptr;
+                    const double *b_ = (kick.b >= 0 && kick.b < AMM_MAX_SLOTS) ? ctx->slots[kick.b] : nullptr;
+                    if (!a_ || (kick.b >= 0 && !b_)) break;                 // left to the plain path, which reports it
+                    fa[nk] = a_;
+                    fb[nk] = b_;
+                    plus[nk] = kick.c;
+                    coef[nk] = kick.coef;
+                    ++nk;
+                    ++j;
+                }
+                const bool moves = j < n_ops && ops[j].op == AMM_OP_MOVE;
+                if (nk == j - k && (nk >= 2 || (nk == 1 && moves))) {
+                    if (amm_kicks_move_impl(ctx, fa, fb, plus, coef, nk, moves ? 1 : 0, moves ? ops[j].coef : 0.0)) return 1;
+                    if (moves) ctx->pos_epoch++;
+                    k = j - (moves ? 0 : 1);
+                    continue;
+                }
+            }
             switch (op.op) {
             case AMM_OP_EVAL: {
                 if (op.a < 0 || op.a >= AMM_MAX_GROUPS || ctx->groups[op.a].slot < 0) {

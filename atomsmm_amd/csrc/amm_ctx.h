@@ -272,6 +272,8 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
                          double *d_energy);
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
 int amm_bonded_free(BondedSet *bs);
+int amm_kicks_move_impl(amm_ctx *ctx, const double *const *fa, const double *const *fb, const int *plus, const double *coef, int nk,
+                        int with_move, double dcoef);
 int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v, double *f0, int npre, const double *const *pre_a,
                               const double *const *pre_b, const double *pre_coef, const int *pre_plus, double c1, double d,
                               double c2, int niter, const BathDef *bath = nullptr, double d2 = 0.0);

@@ -31,6 +31,54 @@ __global__ void k_move(int n3, double *__restrict__ x, const double *__restrict_
     x[t] = x[t] + dx;
 }
 
+// up to four kicks and a move in one launch: the same operations per degree of freedom, in the same order, as the separate
+// kernels (v <- v + (c*f)/m ... ; x <- x + d*v) -- programs outside the one-launch inner loop (a pair force in the innermost
+// group) spend a tenth of their step in these 5 us launches otherwise
+struct KickList {
+    const double *f[4], *f2[4];
+    int plus[4];
+    double coef[4];
+    int n;
+};
+__global__ void k_kicks_move(int n3, double *__restrict__ x, double *__restrict__ v, KickList K, const double *__restrict__ mass,
+                             int with_move, double dcoef) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    double vt = v[t];
+    const double m = mass[t / 3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < K.n) {
+            double ff = K.f[k][t];
+            if (K.f2[k]) ff = K.plus[k] ? ff + K.f2[k][t] : ff - K.f2[k][t];
+            const double num = K.coef[k] * ff;
+            const double dv = num / m;
+            vt = vt + dv;
+        }
+    }
+    v[t] = vt;
+    if (with_move) {
+        const double dx = dcoef * vt;
+        x[t] = x[t] + dx;
+    }
+}
+int amm_kicks_move_impl(amm_ctx *ctx, const double *const *fa, const double *const *fb, const int *plus, const double *coef, int nk,
+                        int with_move, double dcoef) {
+    KickList K;
+    K.n = nk;
+    for (int k = 0; k < 4; ++k) {
+        K.f[k] = k < nk ? fa[k] : nullptr;
+        K.f2[k] = k < nk ? fb[k] : nullptr;
+        K.plus[k] = k < nk ? plus[k] : 0;
+        K.coef[k] = k < nk ? coef[k] : 0.0;
+    }
+    const int n3 = 3 * ctx->n;
+    hipLaunchKernelGGL(k_kicks_move, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->d_x, ctx->d_v, K, ctx->d_mass,
+                       with_move, dcoef);
+    AMM_HIP(hipGetLastError());
+    return 0;
+}
+
 // dst <- a + coef*b   (`fm2 <- f2-f1`, propagators.py:951)
 __global__ void k_combine(int n3, double *__restrict__ dst, const double *__restrict__ a, const double *__restrict__ b, double coef) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
