@@ -1245,9 +1245,9 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
             if (b1 <= b0) {                       // no partner with a site in any back part (or only front parts are walked)
                 lj_end = f1;
                 pl_start = f1;
-            } else if (f1 >= b0) {                // the two stretches touch
-                lj_end = b1;
-                pl_start = b1;
+            } else if (f1 >= b0) {                // the two stretches touch or overlap (rows of very different lengths in one wavefront)
+                lj_end = max(f1, b1);       // (b1 alone would leave a long front part's partners to the walk without: tests seed 31)
+                pl_start = lj_end;
             } else {
                 lj_end = b1;
                 lj_cut = f1;

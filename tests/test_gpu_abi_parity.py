@@ -447,7 +447,7 @@ def test_neighbour_list_rebuild_and_reuse(spcfw, outer_skin):
     ctx.close()
 
 
-@pytest.mark.parametrize('seed', [11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize('seed', [11, 12, 13, 14, 15, 16, 21, 22, 23, 31, 32])
 def test_random_boxes_and_site_mixes_vs_oracle(seed):
     """Randomised configurations for the list build and both traversals: non-cubic boxes down to the size where a
     dimension holds fewer cells than the stencil is wide (minimum-image build), fractions of atoms with a Lennard-Jones site
@@ -467,6 +467,29 @@ def test_random_boxes_and_site_mixes_vs_oracle(seed):
     pos = (grid + 0.5 + rng.uniform(-0.28, 0.28, (n, 3))) / m * box
     site_fraction = [0.0, 0.1, 1 / 3, 0.5, 0.8, 1.0][seed % 6]
     has_site = rng.random(n) < site_fraction
+    if seed > 30:
+        # a tight ball of atoms with a site + a few isolated ones in a gas of atoms without: a wavefront then holds a row whose
+        # partners with a site all sit in a long front part and none in the back, next to rows with short front parts and a
+        # couple of such partners in the back (the two stretches with Lennard-Jones arithmetic overlap)
+        has_site = np.zeros(n, bool)
+        ball = rng.choice(n, 70, replace=False)
+        centre = pos[ball[0]].copy()
+        placed = []
+        while len(placed) < len(ball):
+            trial = centre + rng.normal(0.0, 0.2, 3)
+            if np.linalg.norm(trial - centre) < 0.36 and all(np.linalg.norm(trial - p_) > 0.11 for p_ in placed):
+                placed.append(trial)
+        pos[ball] = np.array(placed)
+        has_site[ball] = True
+        far_away = np.linalg.norm((pos - centre + 0.5 * box) % box - 0.5 * box, axis=1) > 1.25
+        has_site[rng.choice(np.where(far_away)[0], 40, replace=False)] = True
+    elif seed > 20:
+        # gradients:    elif seed > 20:
+        # gradients: the density falls by a factor of ~6 along x and the atoms with a site crowd at one end of y, so that the
+        # rows that share a wavefront differ widely in length and in their numbers of partners with a site
+        u = pos[:, 0] / box[0]
+        pos[:, 0] = box[0] * (0.35 * u + 0.65 * u ** 3)
+        has_site = rng.random(n) < np.clip(1.2 - 1.6 * pos[:, 1] / box[1], 0.02, 0.98)
     q = rng.normal(0.0, 0.4, n)
     q -= q.mean()
     sigma = np.where(has_site, rng.uniform(0.25, 0.34, n), 0.1)
