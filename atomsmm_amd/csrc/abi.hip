@@ -385,6 +385,15 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
     std::vector<int> cls(n);
     for (int i = 0; i < n; ++i) cls[i] = h_eps[i] == 0.0 ? 1 : 0;
     AMM_HIP(hipMemcpy(pf->d_cls, cls.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    if (cls != pf->h_cls) {
+        // another set of atoms has a site (an epsilon offset crossed zero): the list's order within the cells and the rows' site
+        // counts were made for the old one -- rebuild at the next evaluation; guests re-check that their sites are the owner's
+        if (!pf->h_cls.empty() && pf->built) pf->force_rebuild = true;
+        pf->h_cls = cls;
+        pf->sites_match = -1;
+        for (auto &fo : ctx->forces)
+            if (fo.type == 1 && fo.pair->host == pf) fo.pair->sites_match = -1;
+    }
     // dual evaluation needs bitwise equal parameters on guest and host: re-check after any change
     pf->dual_ok = pf->fuse_ok = -1;
     for (auto &fo : ctx->forces)

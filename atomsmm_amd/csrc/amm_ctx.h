@@ -103,6 +103,9 @@ struct PairForce {
     double tab_error = 0;          // largest relative interpolation error found when the table was built
     int *d_cls = nullptr;          // per atom (original order): 1 = no Lennard-Jones site (eps = 0) -- sorted behind the others in its cell
     int *d_cell_count_lj = nullptr, *d_cell_start_lj = nullptr;   // per cell: atoms WITH a Lennard-Jones site (count, exclusive scan)
+    std::vector<int> h_cls;        // host copy of d_cls: a change of the site pattern (parameter offsets on epsilon) asks for a rebuild
+    bool force_rebuild = false;    // the rows' site counts and traversal order were made for another site pattern
+    int sites_match = -1;          // a guest may use its list owner's site counts only if both have sites on the same atoms (-1: unknown)
     int *d_nnb_lj = nullptr;       // per row: how many of its entries are partners with a Lennard-Jones site (front | back << 16): they come first on either side
     int *d_cell_sets = nullptr;    // interaction-group forces: per cell, which of the two sets have atoms in it (bit 0 / bit 1)
     int active_cap = 0;            // rows the pair kernels' grid covers when d_active is walked

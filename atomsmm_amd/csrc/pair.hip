@@ -1644,7 +1644,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     bool gathered = false;
     if (!L->built) {
         if (first_build(ctx, L, d_pos)) return 1;
-    } else if (L->checked_epoch == ctx->pos_epoch && L->checked_pos == d_pos) {
+    } else if (L->checked_epoch == ctx->pos_epoch && L->checked_pos == d_pos && !L->force_rebuild) {
         // positions unchanged since this list was last checked (e.g. the far force right after the near force
         // that shares the list): nothing to do
     } else {
@@ -1652,11 +1652,13 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         if (!(L->pre_epoch == ctx->pos_epoch && L->pre_pos == d_pos && !L->dual))   // else: the integration kernel already checked
             hipLaunchKernelGGL(k_check_displacement, dim3(nb), dim3(256), 0, st, n, d_pos, L->d_xref,
                                L->dual ? L->d_xref_out : L->d_xref, thr_in * thr_in, thr_out * thr_out, L->d_flags);
+        const int forced = L->force_rebuild ? 1 : 0;       // the site pattern changed (amm_pair_set_params)
+        L->force_rebuild = false;
         if (L->dual) {
-            if (cell_build_chain(ctx, L, d_pos, 0, false, false)) return 1;
-            if (prune_chain(ctx, L, d_pos, 0, false)) return 1;
+            if (cell_build_chain(ctx, L, d_pos, forced, false, false)) return 1;
+            if (prune_chain(ctx, L, d_pos, forced, false)) return 1;
         } else {
-            if (cell_build_chain(ctx, L, d_pos, 0, false, true, pf)) return 1;
+            if (cell_build_chain(ctx, L, d_pos, forced, false, true, pf)) return 1;
             gathered = true;
         }
     }
@@ -1768,7 +1770,14 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             T.n_lj = L->d_row_order ? L->d_flags + 3 : nullptr;
             T.nslice = nslice;
             T.ntask = (int)((threads + 63) / 64);
-            T.nnb_lj = (ctx->site_trips && !L->dual) ? L->d_nnb_lj : nullptr;    // the prune of a two-level list does not keep the counts
+            // the rows' site counts are the list owner's: a guest may cut its walk by them only if it has its sites on the same atoms
+            if (pf->sites_match < 0) pf->sites_match = (pf == L || pf->h_cls == L->h_cls) ? 1 : 0;
+            bool sites_ok = pf->sites_match == 1;
+            if (guest) {
+                if (guest->sites_match < 0) guest->sites_match = (guest == L || guest->h_cls == L->h_cls) ? 1 : 0;
+                sites_ok = sites_ok && guest->sites_match == 1;
+            }
+            T.nnb_lj = (ctx->site_trips && !L->dual && sites_ok) ? L->d_nnb_lj : nullptr;    // (the prune of a two-level list does not keep the counts)
             T.nnb_all = L->d_nnb;
             const int gfam = guest ? guest->desc.family : -1;
             PairConsts gpc = guest ? guest->pc : pf->pc;

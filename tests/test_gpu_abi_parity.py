@@ -544,6 +544,56 @@ def test_random_boxes_and_site_mixes_vs_oracle(seed):
     ctx.close()
 
 
+def test_site_pattern_change_rebuilds_the_rows(spcfw):
+    """Parameter offsets on epsilon can give an atom a Lennard-Jones site it did not have (SolvationSystem with
+    use_softcore=False at lambda_vdw = 0 -> 0.5, systems.py:309-312).  The rows' order and site counts were made for the old
+    pattern: amm_pair_set_params asks for a rebuild, and a guest whose sites differ from its list owner's does not use the
+    owner's counts.  Force-only evaluations (the kernel that cuts its walk by those counts) against the oracle, at fixed
+    positions, before and after the change."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    x = dev(c['positions'])
+    rng = np.random.default_rng(8)
+    hydrogens = np.where(c['epsilon'] == 0.0)[0]
+    assert len(hydrogens) > n // 2
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+    ctx = B.HipContext(n, c['box'])
+    fn = hip_pair(B, ctx, dn, c, skin=0.1)
+    ff = hip_pair(B, ctx, dd, c, skin=0.1)
+    ctx.pair_share_list(fn, ff)
+
+    def force_only(fid):
+        out = torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda')
+        ctx.force_eval(fid, x, out, accumulate=False)
+        ctx.check()
+        return out.cpu().numpy()
+
+    def check(fid, d, sigma, eps):
+        f_ref = O.pair_eval(d, c['positions'], c['box'], c['charge'], sigma, eps, c['exc_pairs'])[1]
+        assert np.abs(force_only(fid) - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+
+    check(ff, dd, c['sigma'], c['epsilon'])
+    check(fn, dn, c['sigma'], c['epsilon'])
+    builds = ctx.pair_stats(ff)['n_builds']
+    # half of the hydrogens get a (small) site on BOTH forces: same positions, another site pattern
+    chosen = rng.choice(hydrogens, len(hydrogens) // 2, replace=False)
+    sigma2, eps2 = c['sigma'].copy(), c['epsilon'].copy()
+    sigma2[chosen], eps2[chosen] = 0.12, 0.08
+    ctx.pair_set_params(ff, c['charge'], sigma2, eps2)
+    ctx.pair_set_params(fn, c['charge'], sigma2, eps2)
+    check(ff, dd, sigma2, eps2)
+    check(fn, dn, sigma2, eps2)
+    assert ctx.pair_stats(ff)['n_builds'] == builds + 1
+    # now only the guest changes back: its sites differ from the owner's, whose counts it must not use
+    ctx.pair_set_params(fn, c['charge'], c['sigma'], c['epsilon'])
+    check(fn, dn, c['sigma'], c['epsilon'])
+    check(ff, dd, sigma2, eps2)
+    assert ctx.pair_stats(ff)['n_builds'] == builds + 1
+    ctx.close()
+
+
 def test_atom_decomposition_slices_sum_to_full(spcfw):
     """amm_set_slice: two 'ranks' (two contexts on one GPU) each compute their i-slice; the sum of the
     two buffers (what the RCCL all-reduce does) equals the single-rank forces bit for bit."""
