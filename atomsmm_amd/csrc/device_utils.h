@@ -50,6 +50,81 @@ __device__ __forceinline__ void amm_st_l2(unsigned long long *p, unsigned long l
 }
 
 
+// Two histograms in one word -- count[c] = atoms of cell c (low 16 bits) | those of them with a Lennard-Jones site << 16 -- and
+// both exclusive scans in one sweep: start[0..ncell] and start_hi[0..ncell]; count <- 0; returns the largest cell count.
+// (One atomic per atom and one pass over the counts instead of two of each.)
+__device__ __forceinline__ int amm_block_scan_packed(int ncell, int *count, int *start, int *start_hi) {
+    __shared__ int part[256];
+    __shared__ int part_hi[256];
+    __shared__ int s_most[256];
+    const int t = threadIdx.x;
+    const int per = (ncell + 255) / 256;
+    const int c0 = min(t * per, ncell), c1 = min(c0 + per, ncell);
+    constexpr int KEEP = 32;
+    int keep[KEEP];
+    const bool kept = per <= KEEP;
+    int sum = 0, sum_hi = 0, most = 0;
+    if (kept) {
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) keep[j] = (c0 + j < c1) ? amm_ld_l2(&count[c0 + j]) : 0;
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) {
+            sum += keep[j] & 0xffff;
+            sum_hi += (int)((unsigned)keep[j] >> 16);
+            most = max(most, keep[j] & 0xffff);
+        }
+    } else {
+        for (int c = c0; c < c1; ++c) {
+            const int v = amm_ld_l2(&count[c]);
+            sum += v & 0xffff;
+            sum_hi += (int)((unsigned)v >> 16);
+            most = max(most, v & 0xffff);
+        }
+    }
+    part[t] = sum;
+    part_hi[t] = sum_hi;
+    s_most[t] = most;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int add = t >= off ? part[t - off] : 0, add_hi = t >= off ? part_hi[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        part_hi[t] += add_hi;
+        __syncthreads();
+    }
+    int run = part[t] - sum, run_hi = part_hi[t] - sum_hi;
+    if (kept) {
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j)
+            if (c0 + j < c1) {
+                start[c0 + j] = run;
+                start_hi[c0 + j] = run_hi;
+                count[c0 + j] = 0;
+                run += keep[j] & 0xffff;
+                run_hi += (int)((unsigned)keep[j] >> 16);
+            }
+    } else {
+        for (int c = c0; c < c1; ++c) {
+            const int v = amm_ld_l2(&count[c]);
+            start[c] = run;
+            start_hi[c] = run_hi;
+            count[c] = 0;
+            run += v & 0xffff;
+            run_hi += (int)((unsigned)v >> 16);
+        }
+    }
+    if (t == 255) {
+        start[ncell] = part[255];
+        start_hi[ncell] = part_hi[255];
+    }
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) s_most[t] = max(s_most[t], s_most[t + off]);
+        __syncthreads();
+    }
+    return s_most[0];
+}
+
 // run by ONE 256-thread block (the last block of the histogram kernel): exclusive scan of count[0..ncell) ->
 // start[0..ncell], count <- 0 (fill <- start when given); returns the largest count.  Thread t scans the contiguous segment [t*per, (t+1)*per).
 __device__ __forceinline__ int amm_block_scan_counts(int ncell, int *count, int *start, int *fill = nullptr) {

@@ -111,18 +111,17 @@ __global__ void __launch_bounds__(256) k_cell_assign(int n, const double *__rest
         }
         int cell = (c[2] * g.nc[1] + c[1]) * g.nc[0] + c[0];
         cell_of[i] = cell;
-        const int rank = atomicAdd(&count[cell], 1);
-        if (!cls[i]) atomicAdd(&count_lj[cell], 1);       // atoms with a Lennard-Jones site: first in their cell, first in row_order
+        // one counter per cell: atoms (low 16 bits; the member tables hold far fewer) | those with a Lennard-Jones site << 16 (they
+        // come first in their cell and in row_order)
+        const int rank = atomicAdd(&count[cell], cls[i] ? 1 : 0x10001) & 0xffff;
         if (members) {
             if (rank < capc) members[(size_t)cell * capc + rank] = i;
             else flags[7] = 1;            // reported by amm_check: the density grew beyond the member tables
         }
     }
     if (!amm_last_block(ticket)) return;
-    const int fullest = amm_block_scan_counts(g.ncell, count, start);
+    const int fullest = amm_block_scan_packed(g.ncell, count, start, start_lj);
     if (threadIdx.x == 0) flags[6] = fullest;
-    __syncthreads();
-    amm_block_scan_counts(g.ncell, count_lj, start_lj);
 }
 
 // rebuild: one wavefront per cell ranks the cell's members by atom index -> deterministic order whatever the atomics
