@@ -804,6 +804,12 @@ def test_c2_full_size_lj_fluid(adj):
     assert e == pytest.approx(e_ref, rel=1e-10)
     assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
     assert np.abs(f.sum(0)).max() <= 1e-8 * np.abs(f).max()
+    # the force-only launch is the kernel bench.py times (tabulated Coulomb, persistent grid): at full size too it must meet the
+    # ORACLE's forces, not only its energy-carrying sibling
+    f_only = torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda')
+    ctx.force_eval(fid, dev(c['positions']), f_only)
+    ctx.check()
+    assert np.abs(f_only.cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
     shifted = c['positions'] + np.array([0.61, -7.3, 23.9]) * c['box']
     e2, f2 = eval_force(ctx, fid, dev(shifted), n)
     assert e2 == pytest.approx(e, rel=1e-11)
@@ -856,6 +862,19 @@ def test_c3_full_size_tip3p_respa():
         assert e == pytest.approx(e_ref, rel=1e-10)
         assert np.abs(fo - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
         assert np.abs(fo.sum(0)).max() <= 1e-8 * np.abs(fo).max()
+        # force-only launch of the same force = the traversal kernel bench.py times, against the oracle at full size
+        f_only = torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda')
+        ctx.force_eval(fid, pos, f_only)
+        ctx.check()
+        assert np.abs(f_only.cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    # the dual pass (outer + near force of the shared list in ONE traversal: the dominant kernel of the bench) through the op
+    # list, against the oracle's forces of both
+    x.copy_(pos)
+    ctx.run_ops([B.Op(B.OP_EVAL, 1, 0, 0, 0.0), B.Op(B.OP_EVAL, 2, 0, 0, 0.0)], 1)
+    ctx.check()
+    for key, slot in (('near', 1), ('far', 2)):
+        f_ref = ref[key][1]
+        assert np.abs(f[slot].cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
     # one outer step as RespaPropagator([4,2,1]) emits it at 2 fs, steady-state form
     dt = 0.002
     E, K, M, C_ = B.OP_EVAL, B.OP_KICK, B.OP_MOVE, B.OP_COPY

@@ -31,6 +31,11 @@ def check_groups(case, context, ref, lam):
         re_, rf = ref.group_energy_forces(g)
         assert e == pytest.approx(re_, rel=1e-10)
         assert np.abs(f - rf).max() <= 1e-9 * np.abs(rf).max()
+        # without the energy the pair forces take the force-only traversal (the kernel the step program runs)
+        f_only = context.getState(getForces=True, groups={g}).getForces(asNumpy=True)._value
+        assert np.abs(f_only - rf).max() <= 1e-9 * np.abs(rf).max()
+    f_only = context.getState(getForces=True, groups={0}).getForces(asNumpy=True)._value
+    assert np.abs(f_only - r0f).max() <= 1e-9 * np.abs(r0f).max()
     d = context._engine.energy_derivative('lambda_vdw')
     assert d == pytest.approx(ref.dE_dlambda(), rel=2e-6)
 

@@ -2,8 +2,10 @@
 addConstrainVelocities (propagators.py:246-252, 272-273, 1126-1133).
 
 Parity status: UNPINNED against the reference (its constrained dynamic tests, tests/test_propagators.py:37-48, need
-OpenMM's random velocities and its own SETTLE/CCMA round-off); checked here: the solver against a numpy restatement of
-the same iteration, constraint satisfaction, and energy conservation of constrained dynamics."""
+OpenMM's random velocities and its own SETTLE/CCMA round-off); checked here: the solver against oracle/constraints_oracle.py --
+the constraint equations solved by Newton's method on the multipliers, by the closed form of SETTLE (what OpenMM's Reference
+platform uses for water) and by a dense linear solve for the velocities: three routes that share nothing with the kernel's
+Gauss-Seidel sweep --, constraint satisfaction, and energy conservation of constrained dynamics."""
 import numpy as np
 import pytest
 
@@ -14,6 +16,7 @@ import atomsmm_amd as atomsmm  # noqa: E402
 from atomsmm_amd import backend as B  # noqa: E402
 from atomsmm_amd import openmm, unit  # noqa: E402
 from atomsmm_amd.testing import system_from_arrays  # noqa: E402
+from oracle import constraints_oracle as CO  # noqa: E402  (checker only)
 
 KB = unit.BOLTZMANN_CONSTANT_kB._value        # kB*NA in kJ/mol/K as the unit module defines it
 
@@ -80,12 +83,78 @@ def test_shake_and_rattle_through_the_abi():
         loc = shake_numpy(moved[idx], x0[idx], mass[idx], [(0, 1), (0, 2), (1, 2)], [r_oh, r_oh, r_hh], 1e-7)
         ref[idx] = loc
     assert np.abs(got - ref).max() < 1e-12
+    # the definition itself (oracle/constraints_oracle.py): Newton on the multipliers and analytic SETTLE; the kernel stops at
+    # |r^2 - d^2| < 2 tol d^2, i.e. within tol * d of the exact solution
+    v_in = None
+    for k in range(0, nmol, 7):
+        idx = [3 * k, 3 * k + 1, 3 * k + 2]
+        exact = CO.shake_exact(moved[idx], x0[idx], mass[idx], [(0, 1), (0, 2), (1, 2)], [r_oh, r_oh, r_hh])
+        closed = CO.settle(x0[idx], moved[idx], mass[3 * k], mass[3 * k + 1], r_oh, r_hh)
+        assert np.abs(closed - exact).max() < 1e-13
+        assert np.abs(got[idx] - exact).max() < 4e-8
     # SHAKE conserves each molecule's centre of mass; RATTLE leaves no velocity along the bonds
     com = lambda a: (a.reshape(nmol, 3, 3) * mass.reshape(nmol, 3, 1)).sum(1)      # noqa: E731
     assert np.abs(com(got) - com(moved)).max() < 1e-12
     w = v.cpu().numpy()
     rel = ((got[pairs[:, 0]] - got[pairs[:, 1]]) * (w[pairs[:, 0]] - w[pairs[:, 1]])).sum(1)
     assert np.abs(rel / dist ** 2).max() < 2e-7
+    ctx.close()
+
+
+def test_tight_tolerance_meets_the_exact_solutions():
+    """At a solver tolerance of 1e-13 the kernels' Gauss-Seidel sweeps must land on the exact solutions of the constraint
+    equations (oracle/constraints_oracle.py): positions against Newton-on-multipliers and analytic SETTLE (rigid water) and
+    against Newton alone for an X-H3 group with unequal masses (4 atoms, 3 constraints: the CCMA case of OpenMM's Reference
+    platform); velocities against the dense linear solve."""
+    rng = np.random.default_rng(11)
+    nw, ng = 64, 32
+    r_oh, r_hh, r_ch = 0.09572, 0.15139, 0.109
+    xs, ms, pairs, dist, clusters = [], [], [], [], []
+    for k in range(nw):
+        o = rng.uniform(0, 4, 3)
+        a = rng.normal(size=3); a /= np.linalg.norm(a)
+        b = np.cross(a, rng.normal(size=3)); b /= np.linalg.norm(b)
+        half = np.arcsin(0.5 * r_hh / r_oh)
+        base = len(xs)
+        xs += [o, o + r_oh * (np.cos(half) * a + np.sin(half) * b), o + r_oh * (np.cos(half) * a - np.sin(half) * b)]
+        ms += [15.9994, 1.008, 1.008]
+        loc = [(0, 1), (0, 2), (1, 2)]
+        pairs += [(base + i, base + j) for i, j in loc]
+        dist += [r_oh, r_oh, r_hh]
+        clusters.append((list(range(base, base + 3)), loc, [r_oh, r_oh, r_hh], True))
+    for k in range(ng):
+        c = rng.uniform(0, 4, 3)
+        base = len(xs)
+        xs.append(c)
+        ms.append(12.011)
+        for h in range(3):
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            xs.append(c + r_ch * d)
+            ms.append(1.008 + 0.5 * h)
+        loc = [(0, 1), (0, 2), (0, 3)]
+        pairs += [(base + i, base + j) for i, j in loc]
+        dist += [r_ch] * 3
+        clusters.append((list(range(base, base + 4)), loc, [r_ch] * 3, False))
+    x0 = np.array(xs)
+    mass = np.array(ms)
+    n = len(x0)
+    moved = x0 + rng.normal(0, 0.003, (n, 3))
+    vel = rng.normal(0, 0.5, (n, 3))
+    ctx = B.HipContext(n, np.array([4.0, 4.0, 4.0]))
+    x, v = dev(x0), dev(vel)
+    ctx.bind_state(x, v, dev(mass))
+    ctx.constraints_create(np.array(pairs, dtype=np.int32), np.array(dist), 1e-13)
+    ctx.run_ops([B.Op(B.OP_SAVE_REF, 0, 0, 0, 0.0)], 1)
+    x.copy_(dev(moved))
+    ctx.run_ops([B.Op(B.OP_CONSTRAIN_X, 0, 0, 0, 0.0), B.Op(B.OP_CONSTRAIN_V, 0, 0, 0, 0.0)], 1)
+    ctx.check()
+    got, w = x.cpu().numpy(), v.cpu().numpy()
+    for idx, loc, d, water in clusters:
+        exact = CO.shake_exact(moved[idx], x0[idx], mass[idx], loc, d)
+        assert np.abs(got[idx] - exact).max() < 1e-13
+        if water:
+            assert np.abs(CO.settle(x0[idx], moved[idx], mass[idx[0]], mass[idx[1]], d[0], d[2]) - got[idx]).max() < 1e-13
+        assert np.abs(w[idx] - CO.rattle_exact(got[idx], vel[idx], mass[idx], loc)).max() < 1e-11
     ctx.close()
 
 

@@ -365,3 +365,92 @@ def test_c3_size_eight_slices_all_gather_bit_identical(monkeypatch):
     for ctx, f, xchg, x, keep, ff in ranks:
         ctx.close()
     ref.close()
+
+
+def _simulate_c5(nsteps):
+    """The 4 233-atom instance of config C5 (solvated chain with 1-4 exceptions + softcore solute + AFED variable): per-group
+    forces, deriv(energy, lambda_vdw), then AFED steps through the host-walked program (interaction-group force, term-parallel
+    / sliced bond lists, the derivative's reduction over ranks, deferred globals)."""
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import openmm, unit
+    from atomsmm_amd.testing import build_c5_system, solvated_chain
+    case = solvated_chain(nside=12, n_chain=300, n_solute=30)
+    respa = build_c5_system(case)
+    inner = atomsmm.RespaPropagator([2, 2, 1]).integrator(1 * unit.femtoseconds)
+    var = atomsmm.ExtendedSystemVariable('lambda_vdw', 50, 2.5, 20 * unit.femtoseconds)
+    integrator = atomsmm.AdiabaticDynamicsIntegrator(inner, 2, [var])
+    context = openmm.Context(respa, integrator, openmm.Platform.getPlatformByName('HIP'), {'Skin': '0.1'})
+    context.setPositions(case['positions'] * unit.nanometers)
+    context.setVelocities(case['velocities'])
+    context.setParameter('lambda_vdw', 0.8)
+    eng = context._engine
+    out = dict(world=eng.world, n=len(case['positions']))
+    for g in (0, 1, 2):
+        st = context.getState(getForces=True, getEnergy=True, groups={g})
+        out['e%d' % g] = st.getPotentialEnergy()._value
+        out['f%d' % g] = st.getForces(asNumpy=True)._value
+        out['fo%d' % g] = context.getState(getForces=True, groups={g}).getForces(asNumpy=True)._value     # force-only kernels
+    out['dEdl'] = eng.energy_derivative('lambda_vdw')
+    integrator.step(0)
+    integrator.setGlobalVariableByName('_v_lambda_vdw', 0.05)
+    integrator.setGlobalVariableByName('_v_eta_lambda_vdw', 0.0)
+    integrator.step(nsteps)
+    st = context.getState(getPositions=True, getVelocities=True)
+    out['x'] = st.getPositions(asNumpy=True)._value
+    out['v'] = st.getVelocities(asNumpy=True)._value
+    out['lam'] = context.getParameter('lambda_vdw')
+    out['v_lam'] = integrator.getGlobalVariableByName('_v_lambda_vdw')
+    return out
+
+
+def _worker_c5(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ret[rank] = _simulate_c5(2)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c5_four_ranks_match_single_rank():
+    """Config C5's path on several ranks: four processes share the card over gloo, each evaluates the
+    pair rows / bond-list terms of its slice; group energies, forces (energy-carrying and force-only kernels) and
+    deriv(energy, lambda_vdw) after the reductions equal the single-rank values to rounding (the all-reduce adds the
+    ranks' partial sums in another order than one rank does), and two AFED steps end in the same state on every rank."""
+    import torch.multiprocessing as mp
+    single = _simulate_c5(2)
+    assert single['world'] == 1 and single['n'] == 4233
+    world = 4
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as manager:
+        ret = manager.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_c5, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+        stuck = [p for p in procs if p.is_alive()]
+        for p in stuck:
+            p.kill()
+        assert not stuck, 'a rank did not finish within 240 s'
+        assert all(p.exitcode == 0 for p in procs)
+        out = dict(ret)
+    for r in range(world):
+        o = out[r]
+        assert o['world'] == world
+        for g in (0, 1, 2):
+            scale = np.abs(single['f%d' % g]).max()
+            assert o['e%d' % g] == pytest.approx(single['e%d' % g], rel=1e-11)
+            assert np.abs(o['f%d' % g] - single['f%d' % g]).max() <= 1e-11 * scale
+            assert np.abs(o['fo%d' % g] - single['fo%d' % g]).max() <= 1e-11 * scale
+        assert o['dEdl'] == pytest.approx(single['dEdl'], rel=1e-10)
+        assert np.abs(o['x'] - single['x']).max() < 1e-11
+        assert np.abs(o['v'] - single['v']).max() < 1e-9
+        assert o['lam'] == pytest.approx(single['lam'], abs=1e-12)
+        assert o['v_lam'] == pytest.approx(single['v_lam'], rel=1e-9, abs=1e-12)
+        # every rank holds the same state, bit for bit (no rank-dependent arithmetic after the reductions)
+        assert np.array_equal(o['x'], out[0]['x']) and np.array_equal(o['v'], out[0]['v'])

@@ -272,3 +272,35 @@ def test_verlet_list_port_equals_the_cell_walk():
     lists.step(2)
     assert np.abs(walk.x - lists.x).max() < 1e-13
     assert lists.lists[2].builds >= 1
+
+
+def test_constraint_oracle_routes_agree():
+    """oracle/constraints_oracle.py: the closed form of SETTLE, Newton's method on the multipliers and the dense velocity solve are
+    three derivations of the constraint equations' definition; they must agree with each other to round-off, satisfy the
+    constraints, conserve the centre of mass and (velocities) leave nothing along the bonds."""
+    from oracle import constraints_oracle as CO
+    rng = np.random.default_rng(5)
+    r_oh, r_hh = 0.09572, 0.15139
+    m = np.array([15.9994, 1.008, 1.008])
+    loc = [(0, 1), (0, 2), (1, 2)]
+    for _ in range(100):
+        o = rng.uniform(0, 5, 3)
+        a = rng.normal(size=3); a /= np.linalg.norm(a)
+        b = np.cross(a, rng.normal(size=3)); b /= np.linalg.norm(b)
+        half = np.arcsin(0.5 * r_hh / r_oh)
+        x0 = np.stack([o, o + r_oh * (np.cos(half) * a + np.sin(half) * b), o + r_oh * (np.cos(half) * a - np.sin(half) * b)])
+        x1 = x0 + rng.normal(0, 0.005, (3, 3))
+        ys = CO.shake_exact(x1, x0, m, loc, [r_oh, r_oh, r_hh])
+        yt = CO.settle(x0, x1, m[0], m[1], r_oh, r_hh)
+        assert np.abs(ys - yt).max() < 1e-13
+        for (i, j), d in zip(loc, [r_oh, r_oh, r_hh]):
+            assert abs(np.linalg.norm(yt[i] - yt[j]) - d) < 1e-14
+        assert np.abs((m[:, None] * (yt - x1)).sum(0)).max() < 1e-12
+        # the displacement is a mass-weighted combination of the REFERENCE bond vectors: no torque about them
+        torque = sum(np.cross(x0[k], m[k] * (yt[k] - x1[k])) for k in range(3))
+        assert np.abs(torque).max() < 1e-11
+        v = rng.normal(0, 0.5, (3, 3))
+        w = CO.rattle_exact(yt, v, m, loc)
+        for i, j in loc:
+            assert abs((w[i] - w[j]) @ (yt[i] - yt[j])) < 1e-14
+        assert np.abs((m[:, None] * (w - v)).sum(0)).max() < 1e-12
