@@ -37,6 +37,7 @@ EXPORTS = [
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read', 'amm_pair_count_within', 'amm_kernel_revision',
     'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_bath_define_nhl', 'amm_bath_define_sin', 'amm_iso_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
     'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_destroy', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
+    'amm_set_option', 'amm_exchange_per',
 ]
 
 
@@ -55,8 +56,14 @@ class PairStats(C.Structure):
     _fields_ = [('n_builds', C.c_int64), ('n_evals', C.c_int64), ('n_list_pairs', C.c_int64),
                 ('n_slice_atoms', C.c_int64), ('capacity', C.c_int32), ('max_neighbors', C.c_int32),
                 ('lanes_per_atom', C.c_int32), ('n_cells', C.c_int32), ('rlist', C.c_double),
-                ('shares_list', C.c_int32), ('pad_', C.c_int32), ('n_outer_builds', C.c_int64),
-                ('n_outer_pairs', C.c_int64), ('rlist_outer', C.c_double)]
+                ('shares_list', C.c_int32), ('list_kind', C.c_int32), ('n_outer_builds', C.c_int64),
+                ('n_outer_pairs', C.c_int64), ('rlist_outer', C.c_double), ('tab_error', C.c_double),
+                ('has_table', C.c_int32), ('pad2_', C.c_int32)]
+
+
+def slice_per(n, world):
+    """Slots of the cell-sorted order per rank: whole molecules of three (csrc/amm_ctx.h: amm_slice_per)."""
+    return 3 * (((n + 2) // 3 + world - 1) // world)
 
 
 def pair_desc(family, rc, rc0=0.0, rs0=0.0, rswitch=0.0, alpha=0.0, degree=1, flags=0, sign=1.0, Kc=KC,
@@ -139,6 +146,8 @@ def lib():
         L.amm_bath_define_nhl.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, ip]
         L.amm_bath_define_sin.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, ip]
         L.amm_iso_define.argtypes = [vp, C.c_int32, C.c_double, C.c_double, C.c_int32]
+        L.amm_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+        L.amm_exchange_per.argtypes = [vp, ip]
         L.amm_expr_eval.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp]
         for name in EXPORTS:
             if name not in ('amm_last_error', 'amm_kernel_revision'):
@@ -378,7 +387,7 @@ class HipContext:
         _chk(lib().amm_group_set_exchange(self.h, int(group), int(mode)))
 
     def bind_exchange(self, tensor):
-        """Exchange buffer of the all-gather mode: world * 2 * ceil(n/world) * 3 doubles, owned by the caller."""
+        """Exchange buffer of the all-gather mode: world * 2 * exchange_per() * 3 doubles, owned by the caller."""
         self._keep.append(tensor)
         _chk(lib().amm_bind_exchange(self.h, _ptr(tensor), tensor.numel()))
 
@@ -391,6 +400,16 @@ class HipContext:
 
     def set_outer_skin(self, skin_out):
         _chk(lib().amm_set_outer_skin(self.h, float(skin_out)))
+
+    def set_option(self, name, value):
+        """Tuning / test option of the context (include/atomsmm_hip.h: amm_set_option); set before the first evaluation."""
+        _chk(lib().amm_set_option(self.h, name.encode(), float(value)))
+
+    def exchange_per(self):
+        """Slots of the cell-sorted order per rank (whole molecules of three): chunk geometry of the exchange buffer."""
+        per = C.c_int32(0)
+        _chk(lib().amm_exchange_per(self.h, C.byref(per)))
+        return per.value
 
     def set_fuse_inner(self, on=True):
         _chk(lib().amm_set_fuse_inner(self.h, int(bool(on))))

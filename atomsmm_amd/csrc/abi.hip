@@ -5,8 +5,13 @@
 #include <numeric>
 
 #include "amm_ctx.h"
+#include "cluster.h"
 
 int amm_pair_setup_grid(amm_ctx *ctx, PairForce *pf);
+static bool amm_family_allows_cluster(int family, int flags) {
+    const bool tab_family = family == AMM_NEAR_NONE || family == AMM_NEAR_SHIFT || family == AMM_NEAR_FSWITCH || family == AMM_DAMPED || family == AMM_NONBONDED;
+    return tab_family && !(flags & (AMM_GROUP_LJ | AMM_GROUP_Q));
+}
 int amm_bonded_arity(int kind);
 int amm_bonded_npar(int kind);
 
@@ -61,7 +66,6 @@ int amm_create(int32_t n_atoms, const double h_box[3], int32_t device, void *str
     ctx->n = n_atoms;
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
-    if (const char *e = getenv("AMM_SITE_TRIPS")) ctx->site_trips = atoi(e) != 0;
     for (int k = 0; k < 3; ++k) {
         ctx->box.L[k] = h_box[k];
         ctx->box.invL[k] = 1.0 / h_box[k];
@@ -130,6 +134,21 @@ int amm_check(amm_ctx *ctx) {
     }
     for (size_t id = 0; id < ctx->forces.size(); ++id) {
         PairForce *pf = ctx->forces[id].pair;
+        if (pf && pf->cl && pf->cl->built) {
+            int cf[8];
+            AMM_HIP(hipMemcpy(cf, pf->cl->d_flags, sizeof(cf), hipMemcpyDeviceToHost));
+            if (cf[7]) {
+                amm_set_error("molecule-row list of pair force " + std::to_string(id) + ": a cell holds more molecules than its table (" +
+                              std::to_string(pf->cl->capc) + ") or a molecule stretched beyond " + std::to_string(pf->cl->rext) +
+                              " nm from its first atom; forces since the last rebuild may be incomplete");
+                return 2;
+            }
+            if (cf[1]) {
+                amm_set_error("molecule-row list overflow in pair force " + std::to_string(id) + ": " + std::to_string(cf[2]) +
+                              " partners > capacity " + std::to_string(pf->cl->cap) + "; forces since the last rebuild are incomplete");
+                return 2;
+            }
+        }
         if (!pf || !pf->built) continue;
         int flags[16];
         AMM_HIP(hipMemcpy(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
@@ -226,6 +245,8 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
         idx[fill[j]++] = i;
     }
     if (upload(&pf->d_excl_ptr, ptr.data(), ptr.size()) || upload(&pf->d_excl_idx, idx.data(), idx.size())) return 1;
+    // water-like systems take molecule rows on the force-only hot path (cluster.h)
+    pf->cluster_ok = amm_family_allows_cluster(desc->family, desc->flags) && amm_cluster_qualifies(n, ptr, idx);
     AMM_HIP(hipMalloc(&pf->d_q, sizeof(double) * n));
     AMM_HIP(hipMalloc(&pf->d_hsig, sizeof(double) * n));
     AMM_HIP(hipMalloc(&pf->d_seps2, sizeof(double) * n));
@@ -276,6 +297,10 @@ int amm_pair_set_scale(amm_ctx *ctx, int32_t force_id, double scale) {
     if (!pf) return 1;
     pf->desc.sign = scale;
     pf->pc.sign = scale;
+    // the pairings cached for the one-pass evaluations depend on the sign (host sign == 1): decide them again
+    pf->dual_ok = pf->fuse_ok = -1;
+    for (auto &fo : ctx->forces)
+        if (fo.type == 1 && fo.pair->host == pf) fo.pair->dual_ok = fo.pair->fuse_ok = -1;
     return 0;
 }
 
@@ -389,6 +414,7 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
         // another set of atoms has a site (an epsilon offset crossed zero): the list's order within the cells and the rows' site
         // counts were made for the old one -- rebuild at the next evaluation; guests re-check that their sites are the owner's
         if (!pf->h_cls.empty() && pf->built) pf->force_rebuild = true;
+        if (!pf->h_cls.empty() && pf->cl) pf->force_rebuild_c = true;
         pf->h_cls = cls;
         pf->sites_match = -1;
         for (auto &fo : ctx->forces)
@@ -836,7 +862,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
         deferred.clear();
         return 0;
     };
-    static const bool no_defer = getenv("AMM_NO_DEFER") != nullptr;      // tuning knob (A/B)
+    const bool no_defer = ctx->opt_no_defer != 0;      // tuning option (A/B)
     for (int rep = 0; rep < repeat; ++rep)
         for (int k = 0; k < n_ops; ++k) {
             const amm_op &op = ops[k];
@@ -922,9 +948,9 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                                                           bathed ? &ctx->baths[ops[start + 2].a] : nullptr,
                                                           bathed ? ops[start + 3].coef : 0.0)) return 1;
                             ctx->pos_epoch++;
-                            for (int w = 0; w < ctx->n_prechecked; ++w) {
-                                ctx->prechecked[w]->pre_epoch = ctx->pos_epoch;
-                                ctx->prechecked[w]->pre_pos = ctx->d_x;
+                            for (int w = 0; w < ctx->n_watched; ++w) {
+                                *ctx->watched[w].pre_epoch = ctx->pos_epoch;
+                                *ctx->watched[w].pre_pos = ctx->d_x;
                             }
                             k = q - 1;
                             continue;
@@ -967,7 +993,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 }
             }
             // EVAL(ga) ; EVAL(gb) of a guest pair force and the owner of its list, same positions: one pass for both
-            static const bool no_dual = getenv("AMM_NO_DUAL") != nullptr;     // tuning knob
+            const bool no_dual = ctx->opt_no_dual != 0;     // tuning option
             if (ctx->fuse_inner && !no_dual && op.op == AMM_OP_EVAL && k + 1 < n_ops && ops[k + 1].op == AMM_OP_EVAL && op.a >= 0 &&
                 op.a < AMM_MAX_GROUPS && ops[k + 1].a >= 0 && ops[k + 1].a < AMM_MAX_GROUPS && op.a != ops[k + 1].a) {
                 GroupDef &g1 = ctx->groups[op.a], &g2 = ctx->groups[ops[k + 1].a];
@@ -1192,6 +1218,25 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     out->rlist = pf->rlist;
     out->n_slice_atoms = L->s_end - L->s_begin;
     out->shares_list = pf->host ? 1 : 0;
+    out->list_kind = L->last_kind;
+    out->tab_error = pf->tab_error;
+    out->has_table = (pf->pc.tab.nint > 0 && pf->d_tab) ? 1 : 0;
+    if (L->last_kind == 1 && L->cl && L->cl->built) {
+        ClusterList *cl = L->cl;
+        int flags[8];
+        unsigned long long cnt[8];
+        AMM_HIP(hipMemcpy(flags, cl->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        AMM_HIP(hipMemcpy(cnt, cl->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+        out->capacity = cl->cap;
+        out->lanes_per_atom = cl->lpa;
+        out->n_cells = cl->grid.ncell;
+        out->n_slice_atoms = 3 * (int64_t)(cl->c_end - cl->c_begin);
+        out->n_builds = (int64_t)cnt[0];
+        out->n_list_pairs = 9 * (int64_t)(pf->host ? cnt[2] : cnt[1]);      // atom pairs evaluated: nine per molecule-pair entry
+        out->max_neighbors = flags[2];
+        out->rlist_outer = L->desc.rc + L->skin;
+        return 0;
+    }
     if (L->built) {
         int flags[8];
         unsigned long long cnt[8];
@@ -1214,7 +1259,10 @@ int amm_pair_count_within(amm_ctx *ctx, int32_t force_id, const double *d_pos, d
         return 1;
     }
     long long c = 0;
-    if (amm_pair_count_within_impl(ctx, pf, d_pos, r_within, &c)) return 1;
+    PairForce *Lw = pf->host ? pf->host : pf;
+    if (Lw->last_kind == 1 && Lw->cl && Lw->cl->built) {
+        if (amm_cluster_count_within_impl(ctx, pf, d_pos, r_within, &c)) return 1;
+    } else if (amm_pair_count_within_impl(ctx, pf, d_pos, r_within, &c)) return 1;
     *count = (int64_t)c;
     return 0;
 }
@@ -1223,6 +1271,39 @@ const char *amm_kernel_revision(void) { return amm_kernel_revision_impl(); }
 
 int amm_set_outer_skin(amm_ctx *ctx, double skin_out) {
     ctx->skin_out = skin_out;
+    return 0;
+}
+
+int amm_set_option(amm_ctx *ctx, const char *name, double value) {
+    if (!ctx || !name) {
+        amm_set_error("amm_set_option: null argument");
+        return 1;
+    }
+    const std::string k(name);
+    const int v = (int)value;
+    if (k == "cluster") ctx->opt_cluster = v;
+    else if (k == "tab") ctx->opt_tab = v;
+    else if (k == "site_trips") ctx->site_trips = v != 0;
+    else if (k == "lanes_per_row") ctx->opt_lpa = v;
+    else if (k == "build_parts") ctx->opt_parts = v;
+    else if (k == "unroll") ctx->opt_unroll = v;
+    else if (k == "dual_unroll") ctx->opt_dual_unroll = v;
+    else if (k == "tab_block") ctx->opt_tab_bs = v;
+    else if (k == "tab_dual_block") ctx->opt_tab_dual_bs = v;
+    else if (k == "no_dual") ctx->opt_no_dual = v;
+    else if (k == "no_defer") ctx->opt_no_defer = v;
+    else if (k == "terms_from") ctx->opt_terms_from = v;
+    else if (k == "no_term_lanes") ctx->opt_no_term_lanes = v;
+    else {
+        amm_set_error("amm_set_option: unknown option '" + k + "'");
+        return 1;
+    }
+    return 0;
+}
+
+int amm_exchange_per(amm_ctx *ctx, int32_t *per) {
+    if (!ctx || !per) return 1;
+    *per = amm_slice_per(ctx->n, ctx->world);
     return 0;
 }
 

@@ -55,8 +55,14 @@ struct CellGrid {
     double cw[3], inv_cw[3];
 };
 
+struct ClusterList;   // cluster.h: molecule-row list of the force-only traversal
+
 struct PairForce {
     amm_pair_desc desc;
+    ClusterList *cl = nullptr;     // molecule rows (built on the first force-only evaluation of a qualifying force; list owners only)
+    bool cluster_ok = false;       // every atom sits in a three-atom molecule whose three pairs are the force's only exclusions
+    bool force_rebuild_c = false;  // the molecule rows carry site bits of another site pattern
+    int last_kind = 0;             // list walked by the last evaluation: 0 per-atom rows, 1 molecule rows (statistics)
     PairConsts pc;
     int n = 0;
     int id = -1;                   // force id within the context
@@ -213,8 +219,31 @@ struct PendingExchange {
     double *force = nullptr, *gforce = nullptr;
 };
 
+// a neighbour list whose displacement trigger the kernel that moves the atoms evaluates (saves the check launch)
+struct ListWatch {
+    const double *xref = nullptr;
+    double thr2 = 0;
+    int *flags = nullptr;
+    long *pre_epoch = nullptr;
+    const double **pre_pos = nullptr;
+};
+
+// slots per rank of the cell-sorted order: whole molecules of three (the molecule rows slice by molecule)
+static inline int amm_slice_per(int n, int world) {
+    const int nc = (n + 2) / 3;
+    return 3 * ((nc + world - 1) / world);
+}
+
 struct amm_ctx {
     int n = 0;
+    // tuning / test options (amm_set_option): never read from the environment, so that a stray variable cannot change the
+    // order of summation of a production run
+    int opt_cluster = 1;           // molecule rows for qualifying forces (0: per-atom rows everywhere)
+    int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
+    int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
+    int opt_no_dual = 0, opt_no_defer = 0, opt_terms_from = 8192, opt_no_term_lanes = 0;
+    ListWatch watched[2];
+    int n_watched = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     Box box;
@@ -242,8 +271,6 @@ struct amm_ctx {
     // decompositions.  AMM_SITE_TRIPS=0 (read when the context is created) switches it off -- what the bit-identity tests do.
     bool site_trips = true;
     long pos_epoch = 0;            // bumped whenever the positions may have changed (see amm_pair_eval_impl)
-    PairForce *prechecked[2] = {nullptr, nullptr};   // lists whose displacement trigger the last integration kernel evaluated
-    int n_prechecked = 0;
     double skin_out = -1.0;        // outer Verlet buffer for pair forces created afterwards (<= 0: default)
     void *comm = nullptr;          // ncclComm_t of the library's own communicator (comm.hip), or none
     double *d_xchg = nullptr;      // caller-owned exchange buffer (amm_bind_exchange): world chunks of 2 x ceil(n/world) x 3 doubles

@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "amm_ctx.h"
+#include "cluster.h"
 #include "expr_vm.h"
 #include "pair_math.h"
 
@@ -749,7 +750,7 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
     AMM_HIP(hipMalloc(&bs->d_rec_l, sizeof(int4) * std::max<size_t>(nref, 1)));
     if (nref) AMM_HIP(hipMemcpy(bs->d_rec_l, rec_l.data(), sizeof(int4) * nref, hipMemcpyHostToDevice));
     // term tables of the term-parallel evaluation: worth two launches from a few thousand terms on
-    static const int terms_from = getenv("AMM_TERMS_FROM") ? atoi(getenv("AMM_TERMS_FROM")) : 8192;
+    const int terms_from = ctx->opt_terms_from;
     bs->n_gterms = 0;
     if (gterm >= terms_from) {
         std::vector<int4> gt_a((size_t)gterm);
@@ -896,21 +897,29 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     C.f0 = f0;
     C.mass = ctx->d_mass;
     C.nwatch = 0;
-    ctx->n_prechecked = 0;
+    ctx->n_watched = 0;
     {
-        // single-list owners with a built list (dual lists keep their two-threshold check kernel)
-        std::vector<PairForce *> owners;
+        // lists whose rebuild trigger this launch evaluates: the molecule rows first (the hot path's), then single per-atom lists
+        auto watch = [&](const double *xref, double skin, int *flags, long *pre_epoch, const double **pre_pos) {
+            if (C.nwatch >= 2) return;
+            C.wref[C.nwatch] = xref;
+            C.wthr2[C.nwatch] = 0.25 * skin * skin;
+            C.wflags[C.nwatch] = flags;
+            ListWatch &w = ctx->watched[C.nwatch];
+            w.xref = xref;
+            w.thr2 = C.wthr2[C.nwatch];
+            w.flags = flags;
+            w.pre_epoch = pre_epoch;
+            w.pre_pos = pre_pos;
+            C.nwatch++;
+        };
         for (auto &fo : ctx->forces)
-            if (fo.type == 1 && fo.pair->built && !fo.pair->host && !fo.pair->dual) owners.push_back(fo.pair);
-        if (owners.size() <= 2)
-            for (PairForce *L : owners) {
-                C.wref[C.nwatch] = L->d_xref;
-                C.wthr2[C.nwatch] = 0.25 * L->skin * L->skin;
-                C.wflags[C.nwatch] = L->d_flags;
-                ctx->prechecked[C.nwatch] = L;
-                C.nwatch++;
-            }
-        ctx->n_prechecked = C.nwatch;
+            if (fo.type == 1 && fo.pair->cl && fo.pair->cl->built && fo.pair->last_kind == 1)
+                watch(fo.pair->cl->d_xref, fo.pair->cl->skin, fo.pair->cl->d_flags, &fo.pair->cl->pre_epoch, &fo.pair->cl->pre_pos);
+        for (auto &fo : ctx->forces)
+            if (fo.type == 1 && fo.pair->built && !fo.pair->host && !fo.pair->dual && !(fo.pair->cl && fo.pair->last_kind == 1))
+                watch(fo.pair->d_xref, fo.pair->skin, fo.pair->d_flags, &fo.pair->pre_epoch, &fo.pair->pre_pos);
+        ctx->n_watched = C.nwatch;
     }
     C.c1 = c1;
     C.d = d;
@@ -946,7 +955,7 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     }
     C.seed = ctx->expr_seed;
     C.counter0 = ctx->expr_counter;
-    static const bool no_terms = getenv("AMM_NO_TERM_LANES") != nullptr;     // tuning knob (A/B)
+    const bool no_terms = ctx->opt_no_term_lanes != 0;     // tuning option (A/B)
     const bool terms = bs->terms_ok && !no_terms;
     C.term_l = bs->d_term_l;
     C.term_q = bs->d_term_q;

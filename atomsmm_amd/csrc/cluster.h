@@ -1,0 +1,50 @@
+// atomsmm_amd/csrc/cluster.h -- molecule-row ("cluster") neighbour lists of the force-only pair traversal (gfx950).
+//
+// When every atom of a pair force belongs to a three-atom molecule whose three intramolecular pairs are its only exclusions
+// (a water box: the reference's exceptions -> exclusions, forces.py:310-312), the hot path keeps ONE neighbour row per
+// MOLECULE instead of one per atom: an entry names a partner molecule, and the traversal evaluates the nine atom pairs of
+// the two molecules from registers (this is the "i-tile" of BASELINE.json's north_star, three atoms tall).  Against per-atom rows:
+//   * a ninth of the row entries (list build writes, index stream, row bookkeeping per pair);
+//   * a third of the j-record gathers per pair, one periodic image per molecule pair instead of nine;
+//   * the Lennard-Jones arithmetic exactly where two sites meet (O-O: one pair in nine), with no ordering of the rows by
+//     site class -- so a row's order of summation depends on the row alone again (bit-identical between decompositions);
+//   * exclusions need no look-up at all: a molecule is not its own neighbour.
+// Price: a molecule pair is listed as soon as ANY of its nine atom pairs is within the list radius, so somewhat fewer of the
+// evaluated pairs lie inside the cutoff (measured in DESIGN.md).  Energy evaluations, guarded / grouped / softcore / virial
+// forces and systems that do not qualify keep the per-atom rows of pair.hip (built only when such an evaluation asks).
+#pragma once
+#include "amm_ctx.h"
+
+struct ClusterList {
+    int nc = 0;                    // molecules (clusters of 3 atoms: 3m, 3m+1, 3m+2)
+    bool built = false;
+    CellGrid grid;
+    int capc = 0;                  // members per cell in the cell tables
+    int parts = 1;                 // wavefronts per cell in the build
+    double rext = 0;               // bound on the distance of a molecule's atoms from its first atom (cells, interior margin)
+    double rlist_build = 0, rnear_build = 0, skin = 0;
+    int *d_cell_count = nullptr, *d_cell_start = nullptr, *d_cell_members = nullptr;
+    int *d_cperm = nullptr;        // sorted cluster -> molecule
+    int *d_aperm = nullptr;        // sorted atom slot (3 c + a) -> atom (3 m + a): what k_unsort and the stores index with
+    float4 *d_pos4f = nullptr;     // [3 nc] fp32 positions at the last build, molecules kept whole; .w: atom 0 extent, atom 1 site bits
+    double *d_xref = nullptr;      // [n][3] positions at the last build (displacement trigger)
+    int c_begin = 0, c_end = 0;    // this rank's slice of the sorted clusters
+    int cap = 0;                   // entries per row
+    int lpa = 8;                   // lanes per row in the traversal
+    int *d_nl = nullptr, *d_nnb = nullptr, *d_nnb_near = nullptr;
+    int *d_flags = nullptr;        // [0] rebuild wanted [1] row overflow [2] longest row [6] fullest cell [7] cell table / extent overflow
+    unsigned long long *d_counters = nullptr;    // [0] builds [1] entries [2] front entries [7] scratch (count_within)
+    unsigned long long *d_blockstats = nullptr;
+    int *d_ticket = nullptr;
+    long checked_epoch = -1, pre_epoch = -1;
+    const double *checked_pos = nullptr, *pre_pos = nullptr;
+    bool per_pair_image = false;   // small box: the periodic image is chosen per atom pair, not per molecule pair
+};
+
+// does the force qualify?  (host; exclusion CSR in original indices)
+bool amm_cluster_qualifies(int n, const std::vector<int> &excl_ptr, const std::vector<int> &excl_idx);
+// the force-only evaluation of `pf` (and of `guest` on the same pass) over molecule rows; same contract as amm_pair_eval_impl
+int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, PairForce *guest,
+                          double *g_force, int g_accumulate, int exchange);
+int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double r_within, long long *count);
+int amm_cluster_free(ClusterList *cl);

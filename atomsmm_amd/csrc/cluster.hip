@@ -1,0 +1,1183 @@
+// atomsmm_amd/csrc/cluster.hip -- molecule-row neighbour lists and their force-only traversal (gfx950, fp64).  See cluster.h.
+//
+// Takes over, for water-like systems, what OpenMM's neighbour search + per-pair evaluation do for the reference's
+// CustomNonbondedForce / NonbondedForce objects on the RESPA hot path (forces.py:448-455, 539-567, 655-670, 710-724;
+// systems.py:71-77): same pairs (exclusions = the three pairs inside each molecule), same per-pair arithmetic as pair.hip's
+// tabulated kernel (pair_tab.h), another decomposition of the work.
+//
+// Data layout in HBM (per list owner; cluster c = sorted molecule, slot 3 c + a = its atom a):
+//   cperm[c]             molecule index of sorted cluster c (cell-sorted by the molecule's first atom; within a cell by index)
+//   pos4f[3 c + a]       fp32 position at the last build, molecule kept whole (image of its first atom); .w of atom 0: extent
+//                        (largest distance of an atom from the first), .w of atom 1: bit b set = atom b has a Lennard-Jones site
+//   posq_s / lj_s[3c+a]  fp64 sorted copies (x, y, z, q) and (sigma/2, 2 sqrt(eps)), refreshed before every evaluation
+//   nl[row cap + k]      int32 entry = partner cluster | site bits of the partner << 29; partners whose closest atom pair is within
+//                        the GUEST force's list radius fill the row from the front, the others from the back
+// Work decomposition of the traversal: lpa (8) lanes share one row; a lane takes one partner molecule per trip, fetches its three
+// records (96 contiguous bytes) once and evaluates the nine atom pairs against the row's three atoms held in registers; the 9 (+ 9
+// for the guest force) partial force components are combined over the lanes with wavefront shuffles at the end of the row.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "amm_ctx.h"
+#include "cluster.h"
+#include "device_utils.h"
+#include "pair_math.h"
+#include "pair_tab.h"
+
+__device__ double amm_erfcx_table_dev_c[AMM_ERFCX_NI * AMM_ERFCX_NC];
+static bool g_erfcx_uploaded_c[64] = {false};
+
+// ------------------------------------------------------------------------------------------------ qualification (host)
+bool amm_cluster_qualifies(int n, const std::vector<int> &ptr, const std::vector<int> &idx) {
+    if (n < 3 || n % 3 != 0) return false;
+    for (int i = 0; i < n; ++i) {
+        if (ptr[i + 1] - ptr[i] != 2) return false;
+        const int m = i / 3, a = i - 3 * m;
+        const int p0 = 3 * m + (a == 0 ? 1 : 0), p1 = 3 * m + (a == 2 ? 1 : 2);
+        const int e0 = idx[ptr[i]], e1 = idx[ptr[i] + 1];
+        if (!((e0 == p0 && e1 == p1) || (e0 == p1 && e1 == p0))) return false;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ cell list of molecules
+__device__ __forceinline__ double cwrap1(double x, double L, double invL) {
+    double w = x - L * floor(x * invL);
+    if (w >= L) w -= L;
+    if (w < 0.0) w = 0.0;
+    return w;
+}
+
+__global__ void k_ccheck_displacement(int n, const double *__restrict__ pos, const double *__restrict__ xref, double thr2, int *flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double dx = pos[3 * i] - xref[3 * i], dy = pos[3 * i + 1] - xref[3 * i + 1], dz = pos[3 * i + 2] - xref[3 * i + 2];
+    if (!(dx * dx + dy * dy + dz * dz <= thr2)) flags[0] = 1;        // benign race; NaN also triggers
+}
+
+// cell of every molecule (by its first atom) + per-cell counts; the arrival rank places the molecule in the cell's member table;
+// the last block scans the counts (device_utils.h).  members == nullptr: sizing pass (counts only).
+__global__ void __launch_bounds__(256) k_cassign(int nc, const double *__restrict__ pos, Box box, CellGrid g, int *count, int *start,
+                                                 int *members, int capc, double *xref, int *flags, int *ticket, int force) {
+    if (!force && !flags[0]) return;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nc) {
+        int cidx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double w = cwrap1(pos[9 * m + k], box.L[k], box.invL[k]);
+            const int ck = (w == w) ? (int)(w * g.inv_cw[k]) : 0;          // NaN-safe
+            cidx[k] = ck >= g.nc[k] ? g.nc[k] - 1 : (ck < 0 ? 0 : ck);
+        }
+        if (xref) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) xref[9 * m + k] = pos[9 * m + k];
+        }
+        const int cell = (cidx[2] * g.nc[1] + cidx[1]) * g.nc[0] + cidx[0];
+        const int rank = atomicAdd(&count[cell], 1);
+        if (members) {
+            if (rank < capc) members[(size_t)cell * capc + rank] = m;
+            else flags[7] = 1;
+        }
+    }
+    if (!amm_last_block(ticket)) return;
+    const int fullest = amm_block_scan_counts(g.ncell, count, start);
+    if (threadIdx.x == 0) flags[6] = fullest;
+}
+
+// sorted fp64 copies of one molecule (kept whole: every atom takes the image of the first)
+__device__ __forceinline__ void cgather_one(int c, int m, const double *__restrict__ pos, Box box, const double *__restrict__ q,
+                                            const double *__restrict__ hsig, const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s) {
+    double sh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sh[k] = cwrap1(pos[9 * m + k], box.L[k], box.invL[k]) - pos[9 * m + k];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int i = 3 * m + a;
+        double4 p;
+        p.x = pos[3 * i] + sh[0];
+        p.y = pos[3 * i + 1] + sh[1];
+        p.z = pos[3 * i + 2] + sh[2];
+        p.w = q[i];
+        posq_s[3 * c + a] = p;
+        lj_s[3 * c + a] = make_double2(hsig[i], seps2[i]);
+    }
+}
+
+// rebuild: one wavefront per cell ranks the cell's molecules by index (deterministic whatever the atomics did), writes the
+// permutation, the fp32 copies with extent and site bits, and the fp64 sorted copies of the evaluation that follows.
+// No rebuild: only those fp64 copies.
+__global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const int *__restrict__ start, const int *__restrict__ members,
+                                                      int capc, int *cperm, int *aperm, const double *__restrict__ pos, Box box,
+                                                      float4 *pos4f, const int *flags, int *wflags, int force, const double *__restrict__ q,
+                                                      const double *__restrict__ hsig, const double *__restrict__ seps2, double4 *posq_s,
+                                                      double2 *lj_s, float rext, const double *__restrict__ site_eps) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!force && !flags[0]) {
+        if (posq_s && gid < nc) cgather_one(gid, cperm[gid], pos, box, q, hsig, seps2, posq_s, lj_s);
+        return;
+    }
+    const int wave = gid >> 6, lane = threadIdx.x & 63;
+    if (wave >= ncell) return;
+    const int b = start[wave];
+    const int cnt = min(start[wave + 1] - b, capc);
+    const int *mem = members + (size_t)wave * capc;
+    for (int a0 = 0; a0 < cnt; a0 += 64) {
+        const int a = a0 + lane;
+        const int me = a < cnt ? mem[a] : 0x7fffffff;
+        int rank = 0;
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+            const int kk = k0 + lane;
+            const int other = kk < cnt ? mem[kk] : 0x7fffffff;
+            const int nk = min(64, cnt - k0);
+            for (int jj = 0; jj < nk; ++jj) rank += __builtin_amdgcn_readlane(other, jj) < me;
+        }
+        if (a >= cnt) continue;
+        const int sl = b + rank;
+        cperm[sl] = me;
+        double sh[3], p0[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p0[k] = pos[9 * me + k];
+            sh[k] = cwrap1(p0[k], box.L[k], box.invL[k]) - p0[k];
+        }
+        float ext2 = 0.f;
+        int sites = 0;
+        float4 pf[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int i = 3 * me + t;
+            aperm[3 * sl + t] = i;
+            const double x = pos[3 * i] + sh[0], y = pos[3 * i + 1] + sh[1], z = pos[3 * i + 2] + sh[2];
+            pf[t] = make_float4((float)x, (float)y, (float)z, 0.f);
+            const float dx = pf[t].x - pf[0].x, dy = pf[t].y - pf[0].y, dz = pf[t].z - pf[0].z;
+            ext2 = fmaxf(ext2, dx * dx + dy * dy + dz * dz);
+            if (site_eps[i] != 0.0) sites |= 1 << t;        // the LIST OWNER's site pattern (a guest must share it: checked by the caller)
+            if (posq_s) {
+                posq_s[3 * sl + t] = make_double4(x, y, z, q[i]);
+                lj_s[3 * sl + t] = make_double2(hsig[i], seps2[i]);
+            }
+        }
+        const float ext = sqrtf(ext2) * 1.000001f + 1e-6f;
+        if (!(ext <= rext)) wflags[7] = 1;               // a molecule stretched beyond the bound the cells were sized for
+        pf[0].w = ext;
+        pf[1].w = __int_as_float(sites);
+        pos4f[3 * sl] = pf[0];
+        pos4f[3 * sl + 1] = pf[1];
+        pos4f[3 * sl + 2] = pf[2];
+    }
+}
+
+struct CBoxF {
+    float L[3], invL[3];
+};
+
+// ------------------------------------------------------------------------------------------------ list build
+// One wavefront per (cell, part); a batch of CB_BATCH row molecules lives in scalar registers.  Two passes over the candidates:
+//   1. the stencil's molecules are walked as ONE concatenated stream (lane = candidate; piece table + binary search as in
+//      pair.hip's build) and tested by their FIRST atoms against a sphere that is guaranteed to contain every partner
+//      (|x0_i - x0_j| < rlist + ext_i + ext_j): 10 instructions per 64 candidates and row molecule; the survivors (a sixth of
+//      the stream) are queued in LDS, per row molecule;
+//   2. the queue is drained with all 64 lanes busy: three records per candidate, the nine atom-pair distances, the smallest
+//      decides (< rlist: listed; < rnear: front part), ordered ballot compaction into the row.
+// The old per-atom build spent 42 instructions per 64 ATOM-pair tests, mostly compaction; here the compaction is paid per
+// MOLECULE pair and only for a stream that is already 80 % hits.
+#define CB_BATCH 4
+#define CB_QCAP 448
+
+__device__ void cfinish_build_block(int *flags, unsigned long long *counters, const unsigned long long *blockstats, int nblocks, int count_only) {
+    __shared__ unsigned long long sh_sum[256], sh_max[256], sh_near[256];
+    unsigned long long sum = 0, mx = 0, nr = 0;
+    for (int b0 = threadIdx.x; b0 < nblocks; b0 += 8 * 256) {
+        unsigned long long v[8][3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = b0 + j * 256;
+            const bool in = b < nblocks;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[j][q] = in ? amm_ld_l2(&blockstats[3 * (in ? b : 0) + q]) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sum += v[j][0];
+            mx = max(mx, v[j][1]);
+            nr += v[j][2];
+        }
+    }
+    sh_sum[threadIdx.x] = sum;
+    sh_max[threadIdx.x] = mx;
+    sh_near[threadIdx.x] = nr;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            sh_sum[threadIdx.x] += sh_sum[threadIdx.x + off];
+            sh_near[threadIdx.x] += sh_near[threadIdx.x + off];
+            sh_max[threadIdx.x] = max(sh_max[threadIdx.x], sh_max[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        flags[2] = (int)sh_max[0];
+        counters[1] = sh_sum[0];
+        counters[2] = sh_near[0];
+        if (!count_only) {
+            flags[0] = 0;
+            counters[0] += 1;
+        }
+    }
+}
+
+template <bool COUNT_ONLY, bool RINT>
+__global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int parts, const int *__restrict__ cell_start,
+                                                const float4 *__restrict__ pos4f, CBoxF box, CellGrid g, float rlist, float rnear2, int cap,
+                                                int *nl, int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
+                                                unsigned long long *counters, int *ticket, int force) {
+    if (!force && !flags[0]) return;
+    __shared__ int s_rstart[4][128];
+    __shared__ int s_rpref[4][128];
+    __shared__ float s_rshift[4][3][128];
+    __shared__ int s_q[4][CB_BATCH][CB_QCAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int c = wave / parts, part = wave - c * parts;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    (void)below;
+    const float FAR = 1.0e9f;
+    const float rlist2 = rlist * rlist;
+    unsigned long long wsum = 0, wnear = 0;
+    int wmax = 0;
+    int a_begin = 0, a_end = 0;
+    if (c < g.ncell) {
+        const int cb0 = __builtin_amdgcn_readfirstlane(cell_start[c]), cb1 = __builtin_amdgcn_readfirstlane(cell_start[c + 1]);
+        const int per = (cb1 - cb0 + parts - 1) / parts;
+        a_begin = max(cb0 + part * per, c_begin);
+        a_end = min(min(cb0 + (part + 1) * per, cb1), c_end);
+    }
+    if (a_begin < a_end) {
+        const int ncx = g.nc[0], ncy = g.nc[1], ncz = g.nc[2];
+        const int cx = c % ncx, cy = (c / ncx) % ncy, cz = c / (ncx * ncy);
+        // ---- piece table: a lane describes the stencil cells e = lane and lane + 64 (<= 125), x fastest ----
+        const int nsx = g.nstencil[0], nsy = g.nstencil[1], ne = nsx * nsy * g.nstencil[2];
+        int total;
+        {
+            int ecs[2] = {0, 0}, len[2] = {0, 0}, inc[2];
+            float esx[2] = {0.f, 0.f}, esy[2] = {0.f, 0.f}, esz[2] = {0.f, 0.f};
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int e = lane + 64 * hh;
+                if (e < ne) {
+                    const int ox = e % nsx, oy = (e / nsx) % nsy, oz = e / (nsx * nsy);
+                    int nz = ncz < 2 * g.h[2] + 1 ? oz : cz - g.h[2] + oz;
+                    esz[hh] = nz < 0 ? -box.L[2] : (nz >= ncz ? box.L[2] : 0.f);
+                    nz = nz < 0 ? nz + ncz : (nz >= ncz ? nz - ncz : nz);
+                    int ny = ncy < 2 * g.h[1] + 1 ? oy : cy - g.h[1] + oy;
+                    esy[hh] = ny < 0 ? -box.L[1] : (ny >= ncy ? box.L[1] : 0.f);
+                    ny = ny < 0 ? ny + ncy : (ny >= ncy ? ny - ncy : ny);
+                    int nx = ncx < 2 * g.h[0] + 1 ? ox : cx - g.h[0] + ox;
+                    esx[hh] = nx < 0 ? -box.L[0] : (nx >= ncx ? box.L[0] : 0.f);
+                    nx = nx < 0 ? nx + ncx : (nx >= ncx ? nx - ncx : nx);
+                    const int cc = (nz * ncy + ny) * ncx + nx;
+                    ecs[hh] = cell_start[cc];
+                    len[hh] = cell_start[cc + 1] - ecs[hh];
+                }
+                inc[hh] = len[hh];
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(inc[hh], off);
+                    if (lane >= off) inc[hh] += v;
+                }
+            }
+            const int lower = __builtin_amdgcn_readlane(inc[0], 63);
+            total = lower + __builtin_amdgcn_readlane(inc[1], 63);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                s_rstart[w][lane + 64 * hh] = ecs[hh];
+                s_rpref[w][lane + 64 * hh] = (hh ? lower : 0) + inc[hh] - len[hh];       // exclusive prefix; beyond the stencil: `total`
+                s_rshift[w][0][lane + 64 * hh] = esx[hh];
+                s_rshift[w][1][lane + 64 * hh] = esy[hh];
+                s_rshift[w][2][lane + 64 * hh] = esz[hh];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        for (int tb = a_begin; tb < a_end; tb += CB_BATCH) {
+            const int nt = min(CB_BATCH, a_end - tb);
+            // the batch's atoms: lane 3 t + a holds atom a of row molecule t; scalars by readlane
+            float4 my = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < 3 * nt) my = pos4f[3 * tb + lane];
+            float px[CB_BATCH][3], py[CB_BATCH][3], pz[CB_BATCH][3], plim[CB_BATCH];
+            int c2[CB_BATCH], qn[CB_BATCH];
+#pragma unroll
+            for (int t = 0; t < CB_BATCH; ++t) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    px[t][a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.x), 3 * t + a));
+                    py[t][a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.y), 3 * t + a));
+                    pz[t][a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.z), 3 * t + a));
+                }
+                plim[t] = rlist + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.w), 3 * t));
+                c2[t] = 0;
+                qn[t] = 0;
+            }
+            // ---- pass 2: drain the queues (all lanes busy): nine distances, the smallest decides ----
+            auto drain = [&]() {
+#pragma unroll
+                for (int t = 0; t < CB_BATCH; ++t) {
+                    if (t >= nt) break;
+                    const int nq = qn[t];
+                    int *row_out = nl + (size_t)(tb + t - c_begin) * cap;
+                    for (int base = 0; base < nq; base += 64) {
+                        const int k = base + lane;
+                        const bool v = k < nq;
+                        const int slot = v ? s_q[w][t][k] : tb + t;
+                        float4 A[3];
+                        A[0] = pos4f[3 * slot];
+                        A[1] = pos4f[3 * slot + 1];
+                        A[2] = pos4f[3 * slot + 2];
+                        const int sites = __float_as_int(A[1].w);
+                        if (!RINT) {          // one periodic image per molecule pair, from the first atoms
+                            const float sx = box.L[0] * rintf((A[0].x - px[t][0]) * box.invL[0]);
+                            const float sy = box.L[1] * rintf((A[0].y - py[t][0]) * box.invL[1]);
+                            const float sz = box.L[2] * rintf((A[0].z - pz[t][0]) * box.invL[2]);
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) {
+                                A[b].x -= sx;
+                                A[b].y -= sy;
+                                A[b].z -= sz;
+                            }
+                        }
+                        float m2 = 3.0e38f;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) {
+                                float dx = px[t][a] - A[b].x, dy = py[t][a] - A[b].y, dz = pz[t][a] - A[b].z;
+                                if (RINT) {
+                                    dx -= box.L[0] * rintf(dx * box.invL[0]);
+                                    dy -= box.L[1] * rintf(dy * box.invL[1]);
+                                    dz -= box.L[2] * rintf(dz * box.invL[2]);
+                                }
+                                m2 = fminf(m2, dx * dx + dy * dy + dz * dz);
+                            }
+                        const unsigned long long m_pass = __builtin_amdgcn_ballot_w64(v && m2 < rlist2);
+                        if (m_pass == 0ull) continue;
+                        const unsigned long long m_near = m_pass & __builtin_amdgcn_ballot_w64(m2 < rnear2);
+                        const int np_ = __popcll(m_pass), nn_ = __popcll(m_near);
+                        const int cnt = c2[t] & 0xffff, cntf = (int)((unsigned)c2[t] >> 16);
+                        if (!COUNT_ONLY) {
+                            const int mp = __builtin_amdgcn_mbcnt_hi((unsigned)(m_pass >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_pass, 0u));
+                            const int mn = __builtin_amdgcn_mbcnt_hi((unsigned)(m_near >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_near, 0u));
+                            const int pos_near = cnt + mn, pos_far = (cap - 1 - cntf) - (mp - mn);
+                            const bool is_near = (m_near >> lane) & 1ull;
+                            const int pos_in = is_near ? pos_near : pos_far;
+                            if (cnt + cntf + np_ <= cap) {
+                                if ((m_pass >> lane) & 1ull) row_out[pos_in] = slot | (sites << 29);
+                            }
+                        }
+                        c2[t] += nn_ + ((np_ - nn_) << 16);
+                    }
+                    qn[t] = 0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the queue reads are done before the next pass refills it
+                __builtin_amdgcn_wave_barrier();
+            };
+            // ---- pass 1: the candidate stream, first atoms only ----
+            for (int cb = 0; cb < total; cb += 128) {
+                float4 cand[2];
+                int js[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int idx = cb + u * 64 + lane;
+                    const bool in = idx < total;
+                    int r = 0;
+#pragma unroll
+                    for (int step = 64; step > 0; step >>= 1)
+                        if (s_rpref[w][r + step] <= idx) r += step;
+                    const int slot = in ? s_rstart[w][r] + idx - s_rpref[w][r] : 0;
+                    float4 q = pos4f[3 * slot];
+                    if (!RINT) {
+                        const float sx = s_rshift[w][0][r], sy = s_rshift[w][1][r], sz = s_rshift[w][2][r];
+                        q.x = in ? q.x + sx : FAR;
+                        q.y = in ? q.y + sy : FAR;
+                        q.z = in ? q.z + sz : FAR;
+                    }
+                    cand[u] = q;
+                    js[u] = in ? slot : -1;
+                }
+#pragma unroll
+                for (int t = 0; t < CB_BATCH; ++t) {
+                    if (t >= nt) break;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (cb + u * 64 >= total) continue;
+                        float dx = px[t][0] - cand[u].x, dy = py[t][0] - cand[u].y, dz = pz[t][0] - cand[u].z;
+                        if (RINT) {
+                            dx -= box.L[0] * rintf(dx * box.invL[0]);
+                            dy -= box.L[1] * rintf(dy * box.invL[1]);
+                            dz -= box.L[2] * rintf(dz * box.invL[2]);
+                        }
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        const float lim = plim[t] + cand[u].w;
+                        unsigned long long m = __builtin_amdgcn_ballot_w64(r2 < lim * lim && js[u] >= 0 && js[u] != tb + t);
+                        if (m == 0ull) continue;
+                        const int at = qn[t] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if ((m >> lane) & 1ull) s_q[w][t][at] = js[u];
+                        qn[t] += __popcll(m);
+                    }
+                }
+                int fullest = qn[0];
+#pragma unroll
+                for (int t = 1; t < CB_BATCH; ++t) fullest = max(fullest, qn[t]);
+                if (fullest > CB_QCAP - 128) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    drain();
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            drain();
+            int count = 0, countf = 0;
+#pragma unroll
+            for (int t = 0; t < CB_BATCH; ++t) {
+                count = (lane == t) ? (c2[t] & 0xffff) : count;
+                countf = (lane == t) ? (int)((unsigned)c2[t] >> 16) : countf;
+            }
+            if (lane < nt) {
+                const int total_nb = count + countf;
+                if (!COUNT_ONLY) {
+                    const bool over = total_nb > cap;
+                    nnb[tb + lane - c_begin] = over ? 0 : total_nb;
+                    nnb_near[tb + lane - c_begin] = over ? 0 : count;
+                    if (over) flags[1] = 1;
+                }
+                wsum += (unsigned long long)total_nb;
+                wnear += (unsigned long long)count;
+                wmax = max(wmax, total_nb);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        wsum += __shfl_xor(wsum, off);
+        wnear += __shfl_xor(wnear, off);
+        wmax = max(wmax, __shfl_xor(wmax, off));
+    }
+    __shared__ unsigned long long s_sum[4], s_near[4];
+    __shared__ int s_max[4];
+    if (lane == 0) {
+        s_sum[w] = wsum;
+        s_near[w] = wnear;
+        s_max[w] = wmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        amm_st_l2(&blockstats[3 * blockIdx.x], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        amm_st_l2(&blockstats[3 * blockIdx.x + 1], (unsigned long long)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+        amm_st_l2(&blockstats[3 * blockIdx.x + 2], s_near[0] + s_near[1] + s_near[2] + s_near[3]);
+    }
+    if (amm_last_block(ticket)) cfinish_build_block(flags, counters, blockstats, (int)gridDim.x, COUNT_ONLY ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------ traversal
+struct CPairArgs {
+    int c_begin, nrows, lpa_shift, cap;
+    const int *aperm;
+    const int *nl, *nnb, *nnb_total;
+    const double4 *posq;
+    const double2 *lj;
+    double *force, *gforce;
+    int accumulate, gaccumulate, gsame, sorted_out;
+    Box box;
+    const double *host_tab, *guest_tab;
+    int host_bytes, guest_bytes;
+    double margin;
+    int ntask;
+    int per_pair_image;
+};
+
+// IMG: 0 interior rows (no periodic image), 1 one image per molecule pair (from the first atoms), 2 minimum image per atom pair
+//
+// One trip = one partner molecule per lane = nine atom pairs, walked partner atom by partner atom (b outer, a inner): when the three
+// pairs of partner atom b are done its record is dead, and the same registers take the record of the NEXT trip's partner -- the
+// loads of trip t + 1 are in flight behind ~2 000 cycles of trip t's arithmetic without a second register set (the per-atom kernel
+// of pair.hip needs two sets and a two-deep pipeline because its trips are 2 pairs long).  Scheduling barriers between the b blocks
+// keep the compiler from interleaving all nine pairs (which costs 100 registers of temporaries and spills).
+template <int FAM, int CMODE, int GFAM, int IMG>
+__device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &c, const PairConsts &gc, const char *tabh, const char *tabg,
+                                          const double *s_erfcx, const double4 (&pi)[3], const double2 *li, int i_sites,
+                                          const int *row, int nfront, int nn, int sub, int lpa, int self, double (&f)[9], double (&g)[9]) {
+    // pi[a].w = Kc q_a (folded by the caller); li[a]: the row atoms' Lennard-Jones parameters in an LDS strip of the wavefront (only the
+    // rare pairs of two sites read them: 12 registers less)
+    const int back = A.cap - 1 + nfront;
+    // pairs closer than EITHER table reaches are left out of the main path and redone analytically (both forces) below
+    const double r2low = GFAM >= 0 ? fmax(c.tab.r2min, gc.tab.r2min) : c.tab.r2min;
+    auto entry = [&](int k) { return k < nn ? row[k < nfront ? k : back - k] : self; };
+    auto load_pos = [&](int e, int b) {
+        return *reinterpret_cast<const double4 *>(reinterpret_cast<const char *>(A.posq) + (size_t)((unsigned)e & 0x1fffffffu) * 96u + 32 * b);
+    };
+    auto load_lj = [&](int e, int b) {
+        // the Lennard-Jones record only of partner atoms that have a site in some entry of this trip (wave-uniform)
+        double2 l = make_double2(0.0, 0.0);
+        if (i_sites != 0 && __builtin_amdgcn_ballot_w64((((unsigned)e >> 29) >> b) & 1u) != 0ull)
+            l = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.lj) + (size_t)((unsigned)e & 0x1fffffffu) * 48u + 16 * b);
+        return l;
+    };
+    double4 pj[3];
+    double2 lj[3];
+    int k = sub;
+    int e = entry(k), en = entry(k + lpa);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        pj[b] = load_pos(e, b);
+        lj[b] = load_lj(e, b);
+    }
+    // One partner atom against the row's three atoms.  GT (the guest force takes part in this trip) is a compile-time
+    // variant of the whole block, and the Lennard-Jones branches come AFTER the Coulomb part of all three pairs: the three
+    // table look-ups (index arithmetic -> LDS -> five dependent fma) then sit in one basic block and overlap -- with a branch
+    // between the pairs (first version) every pair's chain ran on its own, LDS latency and all (330 cycles per 64 pairs).
+    auto block = [&](auto gt_tag, int b, bool ok, unsigned bits, double sx, double sy, double sz) {
+        constexpr bool GT = decltype(gt_tag)::value;
+        const double xb = pj[b].x - sx, yb = pj[b].y - sy, zb = pj[b].z - sz, qb = pj[b].w;
+        double dx[3], dy[3], dz[3], r2[3], fr[3], frg[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            dx[a] = pi[a].x - xb;
+            dy[a] = pi[a].y - yb;
+            dz[a] = pi[a].z - zb;
+            if (IMG == 2) {
+                dx[a] = amm_min_image(dx[a], A.box.L[0], A.box.invL[0]);
+                dy[a] = amm_min_image(dy[a], A.box.L[1], A.box.invL[1]);
+                dz[a] = amm_min_image(dz[a], A.box.L[2], A.box.invL[2]);
+            }
+            r2[a] = dx[a] * dx[a] + dy[a] * dy[a] + dz[a] * dz[a];
+        }
+        // table look-ups in two pinned stages: ALL index arithmetic and LDS reads of the three pairs (and of the guest's table)
+        // first, then the Horner chains -- the compiler left to itself waits for each pair's reads right behind them
+        // (s_waitcnt lgkmcnt(0) nine times per trip: 45 % of the issue slots used)
+        TabLookup th[3], tg[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            th[a] = amm_tab_fetch(tabh, c.tab, r2[a]);
+            if (GT) tg[a] = amm_tab_fetch(tabg, gc.tab, r2[a]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double qq = pi[a].w * qb;
+            fr[a] = qq * amm_tab_horner(th[a]);
+            frg[a] = GT ? qq * amm_tab_horner(tg[a]) : 0.0;
+        }
+        // Lennard-Jones part: only where two sites can meet (wave-uniform); the other lanes add an exact zero (eps4 = 0)
+        if (i_sites != 0 && __builtin_amdgcn_ballot_w64(ok && ((bits >> b) & 1u)) != 0ull) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if ((i_sites >> a) & 1) {
+                    const double2 la = li[64 * a];
+                    const double sig = la.x + lj[b].x, eps4 = la.y * lj[b].y;
+                    const LJCommon L = amm_lj_common(r2[a], sig, eps4);
+                    fr[a] += amm_lj_force<FAM, CMODE>(c, L, sig, eps4);
+                    if (GT) frg[a] += amm_lj_force<(GFAM >= 0 ? GFAM : FAM), 0>(gc, L, sig, eps4);
+                }
+        }
+        bool any_low = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const bool low = r2[a] < r2low;
+            const bool pass = ok && (r2[a] < c.rc2);
+            any_low = any_low || (pass && low);
+            const double fh = (pass && !low) ? fr[a] : 0.0;
+            f[3 * a] += fh * dx[a];
+            f[3 * a + 1] += fh * dy[a];
+            f[3 * a + 2] += fh * dz[a];
+            if (GT) {
+                const double fg = (pass && !low && (r2[a] < gc.rc2)) ? frg[a] * gc.sign : 0.0;
+                g[3 * a] += fg * dx[a];
+                g[3 * a + 1] += fg * dy[a];
+                g[3 * a + 2] += fg * dz[a];
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {       // closer than a table reaches: analytic, both forces (never in a liquid)
+            for (int a = 0; a < 3; ++a) {
+                const bool low = ok && (r2[a] < c.rc2) && (r2[a] < r2low);
+                const double qq = pi[a].w * qb;
+                const double2 lx = A.lj[3 * ((unsigned)e & 0x1fffffffu) + b];
+                const double2 la = li[64 * a];
+                const double sg = la.x + lx.x, e4 = la.y * lx.y;
+                double e_, fr_;
+                amm_pair_math<FAM, CMODE, false, false>(c, low ? r2[a] : 1.0, qq, sg, e4, e_, fr_, s_erfcx);
+                fr_ = low ? fr_ : 0.0;
+                f[3 * a] += fr_ * dx[a];
+                f[3 * a + 1] += fr_ * dy[a];
+                f[3 * a + 2] += fr_ * dz[a];
+                if (GFAM >= 0) {
+                    const bool glow = low && (r2[a] < gc.rc2);
+                    amm_pair_math<(GFAM >= 0 ? GFAM : FAM), 0, false, false>(gc, glow ? r2[a] : 1.0, qq, sg, e4, e_, fr_, s_erfcx);
+                    fr_ = glow ? fr_ : 0.0;        // (amm_pair_math carries the sign)
+                    g[3 * a] += fr_ * dx[a];
+                    g[3 * a + 1] += fr_ * dy[a];
+                    g[3 * a + 2] += fr_ * dz[a];
+                }
+            }
+        }
+    };
+    while (__builtin_amdgcn_ballot_w64(k < nn) != 0ull) {
+        const bool ok = k < nn;
+        const bool guest_trip = GFAM >= 0 && __builtin_amdgcn_ballot_w64(k < nfront) != 0ull;
+        const unsigned bits = (unsigned)e >> 29;
+        const int e2 = entry(k + 2 * lpa);           // the entry after next: its index is there when the next trip starts
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        if (IMG == 1) {
+            sx = A.box.L[0] * rint((pj[0].x - pi[0].x) * A.box.invL[0]);
+            sy = A.box.L[1] * rint((pj[0].y - pi[0].y) * A.box.invL[1]);
+            sz = A.box.L[2] * rint((pj[0].z - pi[0].z) * A.box.invL[2]);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (guest_trip) block(std::true_type{}, b, ok, bits, sx, sy, sz);
+            else block(std::false_type{}, b, ok, bits, sx, sy, sz);
+            // this partner atom's record is dead: its registers take the next trip's (the image shift of THIS trip is in sx, sy, sz)
+            pj[b] = load_pos(en, b);
+            lj[b] = load_lj(en, b);
+        }
+        e = en;
+        en = e2;
+        k += lpa;
+    }
+}
+
+#ifndef AMM_CBS_SINGLE
+#define AMM_CBS_SINGLE 512
+#endif
+#ifndef AMM_CBS_DUAL
+#define AMM_CBS_DUAL 512
+#endif
+#ifndef AMM_CTAB_WAVES_PER_EU
+#define AMM_CTAB_WAVES_PER_EU 1
+#endif
+template <int FAM, int CMODE, int GFAM, int BS>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_CTAB_WAVES_PER_EU)))
+k_cpair_tab(CPairArgs A, PairConsts c, PairConsts gc) {
+    extern __shared__ __align__(16) char s_lds[];
+    for (int o = threadIdx.x * 16; o < A.host_bytes; o += BS * 16)
+        *reinterpret_cast<double2 *>(s_lds + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.host_tab) + o);
+    const char *tabh = s_lds, *tabg = s_lds + A.host_bytes;
+    if (GFAM >= 0)
+        for (int o = threadIdx.x * 16; o < A.guest_bytes; o += BS * 16)
+            *reinterpret_cast<double2 *>(s_lds + A.host_bytes + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.guest_tab) + o);
+    double *s_erfcx = reinterpret_cast<double *>(s_lds + A.host_bytes + (GFAM >= 0 ? A.guest_bytes : 0));
+    for (int k = threadIdx.x; k < AMM_ERFCX_NI * AMM_ERFCX_NC; k += BS) s_erfcx[k] = amm_erfcx_table_dev_c[k];
+    // Lennard-Jones parameters of the rows' atoms: [wave][atom][lane] (read by the rare site-site pairs only)
+    double2 *s_li = reinterpret_cast<double2 *>(s_erfcx + AMM_ERFCX_NI * AMM_ERFCX_NC) + (threadIdx.x >> 6) * 192;
+    __syncthreads();
+
+    constexpr int WPB = BS / 64;
+    const int lane = threadIdx.x & 63;
+    const int lpa = 1 << A.lpa_shift;
+    const int sub = lane & (lpa - 1);
+    const int rpw = 64 >> A.lpa_shift;
+    // one contiguous eighth of the tasks per XCD (blockIdx & 7): consecutive cell-sorted rows = one slab of the box per L2
+    const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
+    const int per = (A.ntask + 7) >> 3;
+    const int t0 = min(xcd * per, A.ntask), t1 = min(t0 + per, A.ntask);
+    for (int task = t0 + (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); task < t1; task += nwx) {
+        const int a = task * rpw + (lane >> A.lpa_shift);
+        const bool valid = a < A.nrows;
+        const int cs = A.c_begin + (valid ? a : 0);
+        double4 pi[3];
+        int i_sites = 0;
+        __builtin_amdgcn_wave_barrier();                 // the previous task's reads of the strip are done
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            pi[t] = A.posq[3 * cs + t];
+            pi[t].w *= c.Kc;
+            const double2 l = A.lj[3 * cs + t];
+            s_li[64 * t + lane] = l;
+            if (__builtin_amdgcn_ballot_w64(valid && l.y != 0.0) != 0ull) i_sites |= 1 << t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double2 *li = s_li + lane;                 // li[64 a]
+        const int nfront = valid ? A.nnb[a] : 0;
+        const int nn = valid ? (A.nnb_total ? A.nnb_total[a] : nfront) : 0;
+        const int *row = A.nl + (size_t)(valid ? a : 0) * A.cap;
+        const bool edge = valid && !(pi[0].x >= A.margin && pi[0].x <= A.box.L[0] - A.margin && pi[0].y >= A.margin &&
+                                     pi[0].y <= A.box.L[1] - A.margin && pi[0].z >= A.margin && pi[0].z <= A.box.L[2] - A.margin);
+        const bool interior = __builtin_amdgcn_ballot_w64(edge) == 0ull;
+        double f[9], g[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[k] = g[k] = 0.0;
+        if (A.per_pair_image) cwalk_row<FAM, CMODE, GFAM, 2>(A, c, gc, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, g);
+        else if (interior) cwalk_row<FAM, CMODE, GFAM, 0>(A, c, gc, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, g);
+        else cwalk_row<FAM, CMODE, GFAM, 1>(A, c, gc, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, g);
+        for (int off = lpa >> 1; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                f[k] += __shfl_xor(f[k], off);
+                if (GFAM >= 0) g[k] += __shfl_xor(g[k], off);
+            }
+        }
+        if (valid && sub == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int i = A.sorted_out ? 3 * a + t : A.aperm[3 * cs + t];
+                double fx = f[3 * t], fy = f[3 * t + 1], fz = f[3 * t + 2];
+                if (GFAM >= 0) {
+                    if (A.gsame) {
+                        fx += g[3 * t];
+                        fy += g[3 * t + 1];
+                        fz += g[3 * t + 2];
+                    } else if (A.gaccumulate) {
+                        A.gforce[3 * i] += g[3 * t];
+                        A.gforce[3 * i + 1] += g[3 * t + 1];
+                        A.gforce[3 * i + 2] += g[3 * t + 2];
+                    } else {
+                        A.gforce[3 * i] = g[3 * t];
+                        A.gforce[3 * i + 1] = g[3 * t + 1];
+                        A.gforce[3 * i + 2] = g[3 * t + 2];
+                    }
+                }
+                if (A.accumulate) {
+                    A.force[3 * i] += fx;
+                    A.force[3 * i + 1] += fy;
+                    A.force[3 * i + 2] += fz;
+                } else {
+                    A.force[3 * i] = fx;
+                    A.force[3 * i + 1] = fy;
+                    A.force[3 * i + 2] = fz;
+                }
+            }
+        }
+    }
+}
+
+// per (device, kernel) launch configuration: dynamic LDS attribute + blocks per CU from the occupancy query
+struct CLaunchCfg {
+    int lds_set = 0, bpc = -1;
+};
+static int g_num_cu_c[64] = {0};
+
+template <int FAM, int CMODE, int GFAM>
+static int launch_cpair_i(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &gc) {
+    // 2 wavefronts per SIMD (187 / 256 registers with the look-ups of three pairs pinned ahead of their Horner chains): one block
+    // of 512; 8 rows per wavefront then deal 2 tasks to every wavefront at 98 304 atoms (768 threads: 1.33 -- a third idle)
+    constexpr int BS = GFAM >= 0 ? AMM_CBS_DUAL : AMM_CBS_SINGLE;
+    static CLaunchCfg cfg[64];
+    CLaunchCfg &k = cfg[ctx->device & 63];
+    const int lds = A.host_bytes + (GFAM >= 0 ? A.guest_bytes : 0) + AMM_ERFCX_NI * AMM_ERFCX_NC * 8 + (BS / 64) * 192 * 16;
+    auto kern = k_cpair_tab<FAM, CMODE, GFAM, BS>;
+    if (lds > k.lds_set) {
+        AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        k.lds_set = lds;
+        k.bpc = -1;
+    }
+    if (k.bpc < 0) {
+        int nb = 0;
+        AMM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BS, (size_t)lds));
+        if (nb < 1) {
+            amm_set_error("molecule-row pair kernel does not fit on a CU (LDS)");
+            return 1;
+        }
+        k.bpc = nb;
+    }
+    int &ncu = g_num_cu_c[ctx->device & 63];
+    if (!ncu) AMM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    constexpr int WPB = BS / 64;
+    long nblk = std::min((long)ncu * k.bpc, ((long)A.ntask + WPB - 1) / WPB);
+    nblk = std::max(8L, (nblk + 7) / 8 * 8);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, A, c, gc);
+    return 0;
+}
+
+template <int FAM, int CMODE>
+static int launch_cpair(amm_ctx *ctx, int gfam, const CPairArgs &A, const PairConsts &c, const PairConsts &gc) {
+    switch (gfam) {
+    case -1: return launch_cpair_i<FAM, CMODE, -1>(ctx, A, c, gc);
+    case AMM_NEAR_NONE: return launch_cpair_i<FAM, CMODE, AMM_NEAR_NONE>(ctx, A, c, gc);
+    case AMM_NEAR_SHIFT: return launch_cpair_i<FAM, CMODE, AMM_NEAR_SHIFT>(ctx, A, c, gc);
+    case AMM_NEAR_FSWITCH: return launch_cpair_i<FAM, CMODE, AMM_NEAR_FSWITCH>(ctx, A, c, gc);
+    default: amm_set_error("dual evaluation: unsupported guest family"); return 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host orchestration
+static int cluster_setup_grid(amm_ctx *ctx, ClusterList *cl, double rc) {
+    CellGrid &g = cl->grid;
+    g.ncell = 1;
+    const double reach = cl->rlist_build + 2.0 * cl->rext;     // first atoms of two listed molecules are closer than this
+    for (int k = 0; k < 3; ++k) {
+        const double L = ctx->box.L[k];
+        int nc = (int)floor(L / (0.5 * reach));
+        if (nc < 1) nc = 1;
+        if (nc > 512) nc = 512;
+        g.nc[k] = nc;
+        g.h[k] = 2;
+        g.nstencil[k] = nc >= 5 ? 5 : nc;
+        g.cw[k] = L / nc;
+        g.inv_cw[k] = nc / L;
+        g.ncell *= nc;
+        // one image per molecule pair is the nearest image of every atom pair within the cutoff only if rc + 2 rext < L / 2
+        if (!(rc + cl->skin + 2.0 * cl->rext < 0.5 * L * (1 - 1e-9))) cl->per_pair_image = true;
+    }
+    return 0;
+}
+
+static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const double *d_pos, int force, bool count_only, PairForce *gather_for) {
+    hipStream_t st = ctx->stream;
+    const int nc = cl->nc;
+    hipLaunchKernelGGL(k_cassign, dim3((nc + 255) / 256), dim3(256), 0, st, nc, d_pos, ctx->box, cl->grid, cl->d_cell_count, cl->d_cell_start,
+                       cl->d_cell_members, cl->capc, count_only ? (double *)nullptr : cl->d_xref, cl->d_flags, cl->d_ticket, force);
+    if (!cl->d_cell_members) return 0;
+    PairForce *gf = gather_for;
+    const long sort_threads = std::max((long)cl->grid.ncell * 64, gf ? (long)nc : 0L);
+    hipLaunchKernelGGL(k_csort_gather, dim3((unsigned)((sort_threads + 255) / 256)), dim3(256), 0, st, cl->grid.ncell, nc, cl->d_cell_start,
+                       cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags, cl->d_flags, force,
+                       gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr, gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr,
+                       gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2);
+    const long threads = (long)cl->grid.ncell * cl->parts * 64;
+    dim3 grid((unsigned)((threads + 255) / 256));
+    CBoxF bf;
+    for (int k = 0; k < 3; ++k) {
+        bf.L[k] = (float)ctx->box.L[k];
+        bf.invL[k] = (float)ctx->box.invL[k];
+    }
+    const float rl = (float)cl->rlist_build;
+    const float rn2 = cl->rnear_build > 0 ? (float)(cl->rnear_build * cl->rnear_build) : 3.0e38f;
+    const bool use_rint = cl->grid.nc[0] < 5 || cl->grid.nc[1] < 5 || cl->grid.nc[2] < 5;
+#define AMM_LAUNCH_CBUILD(CO, RI)                                                                                                   \
+    hipLaunchKernelGGL((k_cbuild<CO, RI>), grid, dim3(256), 0, st, cl->c_begin, cl->c_end, cl->parts, cl->d_cell_start, cl->d_pos4f, bf, \
+                       cl->grid, rl, rn2, cl->cap, cl->d_nl, cl->d_nnb, cl->d_nnb_near, cl->d_flags, cl->d_blockstats, cl->d_counters,   \
+                       cl->d_ticket + AMM_TICKET_INTS, force)
+    if (count_only) {
+        if (use_rint) AMM_LAUNCH_CBUILD(true, true);
+        else AMM_LAUNCH_CBUILD(true, false);
+    } else {
+        if (use_rint) AMM_LAUNCH_CBUILD(false, true);
+        else AMM_LAUNCH_CBUILD(false, false);
+    }
+#undef AMM_LAUNCH_CBUILD
+    AMM_HIP(hipGetLastError());
+    return 0;
+}
+
+// largest distance of an atom from the first atom of its molecule (host, first build only)
+static double cluster_extent_host(amm_ctx *ctx, const double *d_pos, int n) {
+    std::vector<double> x(3 * (size_t)n);
+    if (hipMemcpyAsync(x.data(), d_pos, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return -1.0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1.0;
+    double worst = 0.0;
+    for (int m = 0; m < n / 3; ++m)
+        for (int a = 1; a < 3; ++a) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double d = x[9 * (size_t)m + 3 * a + k] - x[9 * (size_t)m + k];
+                d2 += d * d;
+            }
+            worst = std::max(worst, d2);
+        }
+    return std::sqrt(worst);
+}
+
+static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) {
+    ClusterList *cl = new ClusterList();
+    L->cl = cl;
+    const int n = L->n, nc = n / 3;
+    cl->nc = nc;
+    cl->skin = L->skin;
+    cl->rlist_build = L->rlist_build;
+    cl->rnear_build = L->rnear_build;
+    const double ext = cluster_extent_host(ctx, d_pos, n);
+    if (!(ext >= 0.0) || !(ext == ext)) {
+        amm_set_error("molecule-row list: cannot read the positions (or NaN positions)");
+        return 1;
+    }
+    // bound on the molecules' extent: the cells and the interior margin are sized for it; a molecule that stretches beyond it
+    // is reported by amm_check (flags[7])
+    cl->rext = std::max(1.5 * ext, ext + 0.05);
+    if (cluster_setup_grid(ctx, cl, L->desc.rc)) return 1;
+    const int per = (nc + ctx->world - 1) / ctx->world;
+    cl->c_begin = std::min(nc, ctx->rank * per);
+    cl->c_end = std::min(nc, cl->c_begin + per);
+    const size_t ns = (size_t)std::max(cl->c_end - cl->c_begin, 1);
+    const int ncell = cl->grid.ncell;
+    AMM_HIP(hipMalloc(&cl->d_cell_count, sizeof(int) * (ncell + 1)));
+    AMM_HIP(hipMemset(cl->d_cell_count, 0, sizeof(int) * (ncell + 1)));
+    AMM_HIP(hipMalloc(&cl->d_cell_start, sizeof(int) * (ncell + 1)));
+    AMM_HIP(hipMalloc(&cl->d_cperm, sizeof(int) * nc));
+    AMM_HIP(hipMalloc(&cl->d_aperm, sizeof(int) * n));
+    AMM_HIP(hipMalloc(&cl->d_pos4f, sizeof(float4) * n));
+    AMM_HIP(hipMalloc(&cl->d_xref, sizeof(double) * 3 * (size_t)n));
+    AMM_HIP(hipMalloc(&cl->d_nnb, sizeof(int) * ns));
+    AMM_HIP(hipMalloc(&cl->d_nnb_near, sizeof(int) * ns));
+    AMM_HIP(hipMalloc(&cl->d_flags, sizeof(int) * 16));
+    AMM_HIP(hipMemset(cl->d_flags, 0, sizeof(int) * 16));
+    AMM_HIP(hipMalloc(&cl->d_ticket, sizeof(int) * 4 * AMM_TICKET_INTS));
+    AMM_HIP(hipMemset(cl->d_ticket, 0, sizeof(int) * 4 * AMM_TICKET_INTS));
+    AMM_HIP(hipMalloc(&cl->d_counters, sizeof(unsigned long long) * 8));
+    AMM_HIP(hipMemset(cl->d_counters, 0, sizeof(unsigned long long) * 8));
+    int lpa = 8;
+    if (ctx->opt_lpa > 0) lpa = ctx->opt_lpa;
+    cl->lpa = lpa;
+    int flags[8];
+    // member tables of the cell list: twice the fullest cell of the first configuration + 16
+    cl->capc = 0;
+    if (cluster_chain(ctx, L, cl, d_pos, 1, true, nullptr)) return 1;
+    AMM_HIP(hipMemcpyAsync(flags, cl->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    cl->capc = 2 * flags[6] + 16;
+    AMM_HIP(hipMalloc(&cl->d_cell_members, sizeof(int) * (size_t)ncell * cl->capc));
+    cl->parts = std::max(1, std::min(16, (int)std::ceil(1.15 * flags[6] / CB_BATCH)));
+    if (ctx->opt_parts > 0) cl->parts = std::max(1, std::min(16, ctx->opt_parts));
+    {
+        const long t1 = (long)ncell * cl->parts * 64;
+        AMM_HIP(hipMalloc(&cl->d_blockstats, sizeof(unsigned long long) * 3 * (size_t)((t1 + 255) / 256)));
+    }
+    // row capacity from the longest row of the whole box (a later rebuild can bring any row into this rank's slice)
+    cl->cap = 0;
+    {
+        const int cb = cl->c_begin, ce = cl->c_end;
+        cl->c_begin = 0;
+        cl->c_end = nc;
+        const int rc_count = cluster_chain(ctx, L, cl, d_pos, 1, true, nullptr);
+        cl->c_begin = cb;
+        cl->c_end = ce;
+        if (rc_count) return 1;
+    }
+    AMM_HIP(hipMemcpyAsync(flags, cl->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    if (flags[7]) {
+        amm_set_error("molecule-row list: cell table overflow at the first build");
+        return 1;
+    }
+    cl->cap = ((int)(flags[2] * 1.5) + 32 + 15) / 16 * 16;
+    if (cl->cap > 65535 || nc >= (1 << 29)) {
+        amm_set_error("molecule-row list: rows longer than 65535 entries or more than 2^29 molecules are not supported");
+        return 1;
+    }
+    AMM_HIP(hipMalloc(&cl->d_nl, sizeof(int) * ns * cl->cap));
+    if (cluster_chain(ctx, L, cl, d_pos, 1, false, nullptr)) return 1;
+    cl->built = true;
+    return 0;
+}
+
+int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, PairForce *guest,
+                          double *g_force, int g_accumulate, int exchange) {
+    hipStream_t st = ctx->stream;
+    const int n = pf->n;
+    if (!g_erfcx_uploaded_c[ctx->device & 63]) {
+        AMM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(amm_erfcx_table_dev_c), amm_erfcx_table_host, sizeof(amm_erfcx_table_host)));
+        g_erfcx_uploaded_c[ctx->device & 63] = true;
+    }
+    PairForce *L = pf->host ? pf->host : pf;
+    bool gathered = false;
+    if (!L->cl || !L->cl->built) {
+        if (L->cl) {
+            amm_set_error("molecule-row list: an earlier first build failed");
+            return 1;
+        }
+        if (cluster_first_build(ctx, L, d_pos)) return 1;
+    }
+    ClusterList *cl = L->cl;
+    if (cl->checked_epoch == ctx->pos_epoch && cl->checked_pos == d_pos && !L->force_rebuild_c) {
+        // positions unchanged since this list was last checked
+    } else {
+        if (!(cl->pre_epoch == ctx->pos_epoch && cl->pre_pos == d_pos))
+            hipLaunchKernelGGL(k_ccheck_displacement, dim3((n + 255) / 256), dim3(256), 0, st, n, d_pos, cl->d_xref, 0.25 * cl->skin * cl->skin,
+                               cl->d_flags);
+        const int forced = L->force_rebuild_c ? 1 : 0;
+        L->force_rebuild_c = false;
+        if (cluster_chain(ctx, L, cl, d_pos, forced, false, pf)) return 1;
+        gathered = true;
+    }
+    cl->checked_epoch = ctx->pos_epoch;
+    cl->checked_pos = d_pos;
+    if (!gathered)
+        hipLaunchKernelGGL(k_csort_gather, dim3((cl->nc + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start,
+                           cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0,
+                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2);     // flags[8] stays 0: copies only
+    const int nrows = cl->c_end - cl->c_begin;
+    const int per_c = (cl->nc + ctx->world - 1) / ctx->world, per = 3 * per_c, nf = guest ? 2 : 1;
+    double *out = d_force, *gout = g_force;
+    if (exchange) {
+        if (accumulate || g_accumulate) {
+            amm_set_error("exchanged evaluation: forces only, no accumulation");
+            return 1;
+        }
+        if (ctx->pending.active) {
+            amm_set_error("exchanged evaluation while the previous one still waits for amm_exchange_finish");
+            return 1;
+        }
+        if (!ctx->d_xchg || ctx->xchg_doubles < (long long)ctx->world * 2 * per * 3) {
+            amm_set_error("exchanged evaluation: bind an exchange buffer of world * 2 * per * 3 doubles, per = amm_exchange_per()");
+            return 1;
+        }
+        out = ctx->d_xchg + (size_t)ctx->rank * nf * per * 3;
+        gout = out + (size_t)per * 3;
+    } else {
+        if (!accumulate && ctx->world > 1) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, st));
+        if (guest && !g_accumulate && ctx->world > 1 && g_force != d_force) AMM_HIP(hipMemsetAsync(g_force, 0, sizeof(double) * 3 * (size_t)n, st));
+    }
+    if (nrows > 0) {
+        CPairArgs A;
+        A.c_begin = cl->c_begin;
+        A.nrows = nrows;
+        int sh = 0;
+        while ((1 << sh) < cl->lpa) ++sh;
+        A.lpa_shift = sh;
+        A.cap = cl->cap;
+        A.aperm = cl->d_aperm;
+        A.nl = cl->d_nl;
+        A.nnb = cl->d_nnb_near;
+        A.nnb_total = (pf == L && cl->rnear_build > 0) ? cl->d_nnb : nullptr;
+        if (pf == L && !(cl->rnear_build > 0)) {
+            A.nnb = cl->d_nnb;            // no guest radius: the whole row is its "front part"
+            A.nnb_total = nullptr;
+        }
+        A.posq = pf->d_posq_s;
+        A.lj = pf->d_lj_s;
+        A.force = out;
+        A.gforce = gout;
+        A.accumulate = accumulate;
+        A.gaccumulate = g_accumulate;
+        A.gsame = (guest && g_force == d_force && !exchange) ? 1 : 0;
+        A.sorted_out = exchange ? 1 : 0;
+        A.box = ctx->box;
+        A.host_tab = pf->d_tab;
+        A.host_bytes = pf->pc.tab.nint * AMM_TAB_STRIDE;
+        A.guest_tab = guest ? guest->d_tab : nullptr;
+        A.guest_bytes = guest ? guest->pc.tab.nint * AMM_TAB_STRIDE : 0;
+        A.margin = cl->rlist_build + cl->skin + 2.0 * cl->rext + 1e-6;
+        const int rpw = 64 >> A.lpa_shift;
+        A.ntask = (nrows + rpw - 1) / rpw;
+        A.per_pair_image = cl->per_pair_image ? 1 : 0;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = ctx->profile && (ctx->profile_only < 0 || ctx->profile_only == pf->id);
+        if (timed) {
+            if (pf->ev_used + 2 > pf->ev.size())
+                for (int k = 0; k < 64; ++k) {
+                    hipEvent_t ev;
+                    AMM_HIP(hipEventCreate(&ev));
+                    pf->ev.push_back(ev);
+                }
+            e0 = pf->ev[pf->ev_used++];
+            e1 = pf->ev[pf->ev_used++];
+            AMM_HIP(hipEventRecord(e0, st));
+        }
+        const int gfam = guest ? guest->desc.family : -1;
+        PairConsts gpc = guest ? guest->pc : pf->pc;
+        if (guest && (guest->desc.flags & AMM_GUARD_RC0)) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);      // step(rc0 - r)
+        int rc_ = 0;
+#ifdef AMM_CLUSTER_TUNE      // kernel tuning builds: the two instantiations of the bench only (compile time)
+        if (pf->desc.family == AMM_NEAR_FSWITCH) rc_ = launch_cpair_i<AMM_NEAR_FSWITCH, 0, -1>(ctx, A, pf->pc, gpc);
+        else if (gfam < 0) rc_ = launch_cpair_i<AMM_DAMPED, 1, -1>(ctx, A, pf->pc, gpc);
+        else rc_ = launch_cpair_i<AMM_DAMPED, 1, AMM_NEAR_FSWITCH>(ctx, A, pf->pc, gpc);
+#else
+        switch (pf->desc.family) {
+        case AMM_NEAR_NONE: rc_ = launch_cpair<AMM_NEAR_NONE, 0>(ctx, gfam, A, pf->pc, gpc); break;
+        case AMM_NEAR_SHIFT: rc_ = launch_cpair<AMM_NEAR_SHIFT, 0>(ctx, gfam, A, pf->pc, gpc); break;
+        case AMM_NEAR_FSWITCH: rc_ = launch_cpair<AMM_NEAR_FSWITCH, 0>(ctx, gfam, A, pf->pc, gpc); break;
+        case AMM_DAMPED:
+            if (pf->pc.degree == 1) rc_ = launch_cpair<AMM_DAMPED, 1>(ctx, gfam, A, pf->pc, gpc);
+            else rc_ = launch_cpair<AMM_DAMPED, 0>(ctx, gfam, A, pf->pc, gpc);
+            break;
+        default:
+            if (pf->pc.cmode == 1) rc_ = launch_cpair<AMM_NONBONDED, 1>(ctx, gfam, A, pf->pc, gpc);
+            else if (pf->pc.cmode == 2) rc_ = launch_cpair<AMM_NONBONDED, 2>(ctx, gfam, A, pf->pc, gpc);
+            else rc_ = launch_cpair<AMM_NONBONDED, 0>(ctx, gfam, A, pf->pc, gpc);
+        }
+#endif
+        if (rc_) return 1;
+        if (timed) AMM_HIP(hipEventRecord(e1, st));
+        AMM_HIP(hipGetLastError());
+        if (guest) guest->n_evals++;
+    }
+    pf->n_evals++;
+    if (exchange) {
+        PendingExchange &pe = ctx->pending;
+        pe.active = true;
+        pe.per = per;
+        pe.nf = nf;
+        pe.perm = cl->d_aperm;
+        pe.force = d_force;
+        pe.gforce = g_force;
+        if (ctx->comm) {
+            if (amm_comm_allgather_impl(ctx, ctx->d_xchg, (size_t)nf * per * 3)) return 1;
+            if (amm_exchange_finish_impl(ctx)) return 1;
+        }
+    }
+    return 0;
+}
+
+// measurement helper: directed ATOM-pair entries of the molecule rows within r_within of the current sorted positions
+__global__ void __launch_bounds__(256) k_ccount_within(CPairArgs A, double r2w, unsigned long long *out) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = tid >> 3, sub = tid & 7;
+    unsigned long long cnt = 0;
+    if (a < A.nrows) {
+        const int cs = A.c_begin + a;
+        const int nfront = A.nnb[a], nn = A.nnb_total ? A.nnb_total[a] : nfront;
+        const int *row = A.nl + (size_t)a * A.cap;
+        const int back = A.cap - 1 + nfront;
+        for (int k = sub; k < nn; k += 8) {
+            const unsigned j = (unsigned)row[k < nfront ? k : back - k] & 0x1fffffffu;
+            for (int t = 0; t < 3; ++t)
+                for (int b = 0; b < 3; ++b) {
+                    const double4 pi = A.posq[3 * cs + t], pj = A.posq[3 * j + b];
+                    const double dx = amm_min_image(pi.x - pj.x, A.box.L[0], A.box.invL[0]);
+                    const double dy = amm_min_image(pi.y - pj.y, A.box.L[1], A.box.invL[1]);
+                    const double dz = amm_min_image(pi.z - pj.z, A.box.L[2], A.box.invL[2]);
+                    cnt += (dx * dx + dy * dy + dz * dz < r2w) ? 1ull : 0ull;
+                }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, cnt);
+}
+
+int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double r_within, long long *count) {
+    PairForce *L = pf->host ? pf->host : pf;
+    ClusterList *cl = L->cl;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_csort_gather, dim3((cl->nc + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start, cl->d_cell_members,
+                       cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0, pf->d_q, pf->d_hsig,
+                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2);
+    CPairArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.c_begin = cl->c_begin;
+    A.nrows = cl->c_end - cl->c_begin;
+    A.cap = cl->cap;
+    A.nl = cl->d_nl;
+    A.nnb = (pf == L) ? cl->d_nnb : cl->d_nnb_near;
+    A.nnb_total = nullptr;
+    if (pf == L && cl->rnear_build > 0) {
+        A.nnb = cl->d_nnb_near;
+        A.nnb_total = cl->d_nnb;
+    }
+    A.posq = pf->d_posq_s;
+    A.box = ctx->box;
+    unsigned long long *d_cnt = cl->d_counters + 7;
+    AMM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+    if (A.nrows > 0)
+        hipLaunchKernelGGL(k_ccount_within, dim3((unsigned)(((long)A.nrows * 8 + 255) / 256)), dim3(256), 0, st, A, r_within * r_within, d_cnt);
+    unsigned long long h = 0;
+    AMM_HIP(hipMemcpyAsync(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+    AMM_HIP(hipStreamSynchronize(st));
+    *count = (long long)h;
+    return 0;
+}
+
+int amm_cluster_free(ClusterList *cl) {
+    void *ptrs[] = {cl->d_cell_count, cl->d_cell_start, cl->d_cell_members, cl->d_cperm, cl->d_aperm, cl->d_pos4f, cl->d_xref, cl->d_nl,
+                    cl->d_nnb, cl->d_nnb_near, cl->d_flags, cl->d_counters, cl->d_blockstats, cl->d_ticket};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete cl;
+    return 0;
+}

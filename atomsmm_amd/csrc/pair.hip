@@ -18,6 +18,7 @@
 #include <cstring>
 
 #include "amm_ctx.h"
+#include "cluster.h"
 #include "device_utils.h"
 #include "pair_math.h"
 #include "pair_tab.h"
@@ -909,14 +910,8 @@ static void launch_pair_u(dim3 grid, dim3 block, hipStream_t st, bool guard, boo
 
 // list entries per lane and trip.  2: the erfc families fit 128 VGPRs = 4 waves/SIMD (218 VGPRs = 2 waves at 4:
 // far kernel 295 -> 254 us at C3, near kernel unchanged); AMM_UNROLL / AMM_LPA are tuning knobs for experiments.
-static int pair_unroll() {
-    static int unr = -1;
-    if (unr < 0) {
-        const char *e = getenv("AMM_UNROLL");
-        unr = e ? atoi(e) : 2;
-    }
-    return unr;
-}
+static int g_opt_unroll = 2, g_opt_dual_unroll = 2, g_opt_tab_bs = 0, g_opt_tab_dual_bs = 0;     // copied from the context by every evaluation
+static int pair_unroll() { return g_opt_unroll; }
 
 template <int FAM, int CMODE>
 static void launch_pair(dim3 grid, dim3 block, hipStream_t st, bool guard, bool en, const PairArgs &A, const PairConsts &c) {
@@ -955,11 +950,7 @@ static void launch_pair_grouped(dim3 grid, dim3 block, hipStream_t st, bool guar
 template <int FAM, int CMODE>
 static int launch_pair_dual(dim3 grid, dim3 block, hipStream_t st, int gfam, const PairArgs &A, const PairConsts &c,
                             const PairConsts &gc) {
-    static int unr = -1;
-    if (unr < 0) {
-        const char *e = getenv("AMM_DUAL_UNROLL");
-        unr = e ? atoi(e) : 2;
-    }
+    const int unr = g_opt_dual_unroll;
     if (unr == 1) return launch_pair_dual_u<FAM, CMODE, 1>(grid, block, st, gfam, A, c, gc);
     return launch_pair_dual_u<FAM, CMODE, 2>(grid, block, st, gfam, A, c, gc);
 }
@@ -1338,12 +1329,8 @@ static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts
 // (2 per SIMD; 2 blocks per CU with <= 128 VGPRs) or 768 (3 per SIMD, 1 block); with a guest: 1024 or 768.  AMM_TAB_BS /
 // AMM_TAB_DUAL_BS override for tuning.
 static int tab_block_size(bool dual) {
-    static int bs[2] = {-1, -1};
-    if (bs[dual] < 0) {
-        const char *e = getenv(dual ? "AMM_TAB_DUAL_BS" : "AMM_TAB_BS");
-        bs[dual] = e ? atoi(e) : (dual ? 768 : 512);
-    }
-    return bs[dual];
+    const int opt = dual ? g_opt_tab_dual_bs : g_opt_tab_bs;
+    return opt > 0 ? opt : (dual ? 768 : 512);
 }
 
 template <int FAM, int CMODE, int GFAM>
@@ -1505,7 +1492,7 @@ static int prune_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int for
 static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     // slice of the sorted order owned by this rank
     const int n = pf->n;
-    const int per = (n + ctx->world - 1) / ctx->world;
+    const int per = amm_slice_per(n, ctx->world);
     pf->s_begin = std::min(n, ctx->rank * per);
     pf->s_end = std::min(n, pf->s_begin + per);
     const int nslice = pf->s_end - pf->s_begin;
@@ -1527,7 +1514,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     // 98k atoms: 229 us with 8, 240 with 16)
     int lpa = 8;
     while (lpa < 16 && (long)nslice * lpa < 64L * 1024 * 8) lpa <<= 1;
-    if (const char *e = getenv("AMM_LPA")) lpa = atoi(e);
+    if (ctx->opt_lpa > 0) lpa = ctx->opt_lpa;
     pf->lpa = lpa;
     int flags[8];
     {
@@ -1542,7 +1529,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         // waves per cell: enough that even the fullest cell's share is one batch per wave (a second batch walks the
         // whole candidate stream again; measured at C3: 315 us with 4 parts, 331 us with the 3 that the mean suggests)
         pf->parts = std::max(1, std::min(8, (int)std::ceil(1.15 * flags[6] / AMM_BATCH)));
-        if (const char *e = getenv("AMM_PARTS")) pf->parts = std::max(1, std::min(8, atoi(e)));
+        if (ctx->opt_parts > 0) pf->parts = std::max(1, std::min(8, ctx->opt_parts));
         const long t1 = (long)pf->grid.ncell * pf->parts * 64, t2 = (long)ns * 16;
         const size_t nblk = (size_t)((std::max(t1, t2) + 255) / 256);
         AMM_HIP(hipMalloc(&pf->d_blockstats, sizeof(unsigned long long) * 3 * nblk));
@@ -1570,9 +1557,25 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         AMM_HIP(hipMalloc(&pf->d_nl, sizeof(int) * ns * pf->cap));
         if (prune_chain(ctx, pf, d_pos, 1, false)) return 1;
     } else {
-        // single list: the cell sweep writes the traversed list directly
+        // single list: the cell sweep writes the traversed list directly.  The row capacity comes from the longest row of the
+        // WHOLE box, not of this rank's slice: the slices follow the cell-sorted order, so a later rebuild can bring rows into
+        // the slice that are far longer than any it held at first -- the rows of a filtered (interaction-group) list are a
+        // few hundred entries for a solute atom and a handful for the solvent (found by the four-rank test of config C5)
         pf->cap = 0;
-        if (cell_build_chain(ctx, pf, d_pos, 1, true, true)) return 1;
+        {
+            const int sb = pf->s_begin, se = pf->s_end;
+            int *const row_order = pf->d_row_order;
+            if (ctx->world > 1) {
+                pf->s_begin = 0;
+                pf->s_end = n;
+                pf->d_row_order = nullptr;        // sized for the slice: the sort kernel must not fill it for the whole box
+            }
+            const int rc_count = cell_build_chain(ctx, pf, d_pos, 1, true, true);
+            pf->s_begin = sb;
+            pf->s_end = se;
+            pf->d_row_order = row_order;
+            if (rc_count) return 1;
+        }
         AMM_HIP(hipMemcpyAsync(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
         AMM_HIP(hipStreamSynchronize(ctx->stream));
         pf->cap = ((int)(flags[2] * 1.5) + 32 + 15) / 16 * 16;
@@ -1590,6 +1593,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         AMM_HIP(hipMemcpyAsync(f16, pf->d_flags, sizeof(f16), hipMemcpyDeviceToHost, ctx->stream));
         AMM_HIP(hipStreamSynchronize(ctx->stream));
         pf->active_cap = (int)std::min<size_t>(ns, (size_t)2 * f16[8] + 64);
+        if (ctx->world > 1) pf->active_cap = (int)ns;      // a slice can come to hold any share of the rows with entries
     }
     pf->built = true;
     return 0;
@@ -1640,6 +1644,27 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     }
     // the neighbour list may belong to another, longer-ranged pair force (amm_pair_share_list)
     PairForce *L = pf->host ? pf->host : pf;
+    g_opt_unroll = ctx->opt_unroll;
+    g_opt_dual_unroll = ctx->opt_dual_unroll;
+    g_opt_tab_bs = ctx->opt_tab_bs;
+    g_opt_tab_dual_bs = ctx->opt_tab_dual_bs;
+    // force-only evaluations of a water-like system walk molecule rows (cluster.hip): the same test as `tab_ok` below, made
+    // before any per-atom list is touched -- that list is only built if an evaluation of the other kind asks for it
+    {
+        const bool guard0 = (pf->desc.flags & AMM_GUARD_RC0) != 0;
+        // (the rows carry the list owner's site bits: a force that walks them must have its sites on the same atoms)
+        if (pf->sites_match < 0) pf->sites_match = (pf == L || pf->h_cls == L->h_cls) ? 1 : 0;
+        if (guest && guest->sites_match < 0) guest->sites_match = (guest == L || guest->h_cls == L->h_cls) ? 1 : 0;
+        const bool cluster = ctx->opt_cluster && ctx->opt_tab && L->cluster_ok && pf->cluster_ok && !d_energy && !guard0 &&
+                             pf->sites_match == 1 && (!guest || guest->sites_match == 1) &&
+                             pf->pc.tab.nint > 0 && pf->d_tab && pf->pc.sign == 1.0 && !(L->skin_out > L->skin * (1 + 1e-9)) &&
+                             (!guest || (guest->cluster_ok && guest->pc.tab.nint > 0 && guest->d_tab));
+        if (cluster) {
+            L->last_kind = 1;
+            return amm_cluster_eval_impl(ctx, pf, d_pos, d_force, accumulate, guest, g_force, g_accumulate, exchange);
+        }
+        L->last_kind = 0;
+    }
     bool gathered = false;
     if (!L->built) {
         if (first_build(ctx, L, d_pos)) return 1;
@@ -1671,7 +1696,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     pf->lpa = L->lpa;
     pf->cap = L->cap;
     const int nslice = pf->s_end - pf->s_begin;
-    const int per = (n + ctx->world - 1) / ctx->world, nf = guest ? 2 : 1;
+    const int per = amm_slice_per(n, ctx->world), nf = guest ? 2 : 1;
     double *out = d_force, *gout = g_force;
     if (exchange) {
         if (accumulate || g_accumulate || d_energy) {
@@ -1749,11 +1774,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             AMM_HIP(hipEventRecord(e0, st));
         }
         dim3 grid(nblk), block(256);
-        static int use_tab = -1;
-        if (use_tab < 0) {
-            const char *e = getenv("AMM_TAB");
-            use_tab = e ? atoi(e) : 1;
-        }
+        const int use_tab = ctx->opt_tab;
         // force-only, unguarded, ungrouped evaluations of the tabulated families: the kernel of pair_tab.h
         const bool tab_ok = use_tab && !en && !guard && !(pf->pc.flags & (AMM_GROUP_LJ | AMM_GROUP_Q)) && pf->pc.tab.nint > 0 && pf->d_tab &&
                             pf->pc.sign == 1.0 && (!guest || (guest->pc.tab.nint > 0 && guest->d_tab));
@@ -1961,6 +1982,13 @@ int amm_pair_build_table(PairForce *pf) {
         (void)hipFree(pf->d_tab);
         pf->d_tab = nullptr;
     }
+    // The bound is enforced, not assumed: the refinement stops at the LDS budget (or at its finest level), and a narrow
+    // switching window or a high DAMPED degree can leave the table short of the arithmetic's accuracy.  Such a force keeps
+    // the analytic kernels (no table: `tab_ok` is false for it, and a guest without a table disables the one-pass forms).
+    if (pf->pc.tab.nint > 0 && !(pf->tab_error <= AMM_TAB_MAX_ERROR)) {
+        pf->pc.tab.nint = 0;
+        coef.clear();
+    }
     if (pf->pc.tab.nint > 0) {
         AMM_HIP(hipMalloc(&pf->d_tab, sizeof(double) * coef.size()));
         AMM_HIP(hipMemcpy(pf->d_tab, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
@@ -1976,8 +2004,7 @@ bool amm_pair_can_fuse_discount(amm_ctx *ctx, PairForce *guest, PairForce *host)
     if (!(guest->desc.flags & AMM_GUARD_RC0)) return false;
     if (guest->fuse_ok >= 0) return guest->fuse_ok == 1;
     guest->fuse_ok = 0;
-    const char *e = getenv("AMM_TAB");
-    if (e && atoi(e) == 0) return false;
+    if (!ctx->opt_tab) return false;
     const int gf = guest->desc.family, hf = host->desc.family;
     if (!(gf == AMM_NEAR_NONE || gf == AMM_NEAR_SHIFT || gf == AMM_NEAR_FSWITCH)) return false;
     if (!(hf == AMM_DAMPED || hf == AMM_NONBONDED)) return false;
@@ -2006,6 +2033,8 @@ int amm_pair_free(PairForce *pf) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);
+    if (pf->cl) amm_cluster_free(pf->cl);
+    pf->cl = nullptr;
     return 0;
 }
 

@@ -28,6 +28,7 @@
 #define AMM_TAB_SHIFT 13                 // hi32(w) >> 13 = exponent | top 7 mantissa bits
 #define AMM_TAB_PER_OCTAVE 128
 #define AMM_TAB_STRIDE 48                // bytes per interval: c0..c5
+#define AMM_TAB_MAX_ERROR 1e-13          // largest relative interpolation error a table may show at its check points
 
 // ------------------------------------------------------------------------------------------------ host: build
 // exact radial Coulomb force over r, per unit qq, in long double (the formulas of amm_pair_math, Coulomb terms only)
@@ -92,6 +93,8 @@ static inline void amm_tab_interval(const PairTab &T, int j, long double &lo, lo
 }
 
 static inline double amm_fit_coulomb_table(const PairConsts &pc, const PairTab &T, std::vector<double> &coef) {
+    // a force guarded by step(rc0 - r) is never looked up beyond rc0, whatever its nominal cutoff (the discount of FarNonbondedForce)
+    const double reach = ((pc.flags & AMM_GUARD_RC0) && pc.rc0 > 0.0) ? std::min(pc.rc, pc.rc0) : pc.rc;
     coef.assign((size_t)T.nint * 6, 0.0);
     long double nodes[6];
     for (int k = 0; k < 6; ++k) nodes[k] = cosl((2 * k + 1) * 3.14159265358979323846264338327950288L / 12.0L);
@@ -137,7 +140,7 @@ static inline double amm_fit_coulomb_table(const PairConsts &pc, const PairTab &
             double p = coef[(size_t)j * 6 + 5];
             for (int q = 4; q >= 0; --q) p = fma(p, t, coef[(size_t)j * 6 + q]);
             const long double r = sqrtl((centre + (long double)t) / (long double)T.scale);
-            if (r >= (long double)pc.rc) continue;
+            if (r >= (long double)reach) continue;
             const long double exact = amm_coul_radial_exact(pc, r);
             // where a switching function takes the force through zero the error is measured against the unswitched 1/r^3
             const long double denom = fmaxl(fabsl(exact), 1e-3L / (r * r * r));
@@ -168,7 +171,9 @@ static inline double amm_build_coulomb_table(PairConsts &pc, std::vector<double>
     T.r2min = ldexp(1.0, -octaves_below) / T.scale * (1.0 + 1e-12);
     T.baseA = (int)raw_index(ldexp(1.0, -octaves_below), AMM_TAB_SHIFT);
     T.nA = octaves_below * AMM_TAB_PER_OCTAVE;
-    const double wtop = pc.rc * pc.rc * T.scale * (1.0 + 1e-12);
+    // (a force guarded by step(rc0 - r) is looked up to rc0 only: its table ends there, whatever the nominal cutoff)
+    const double reach = ((pc.flags & AMM_GUARD_RC0) && pc.rc0 > 0.0) ? std::min(pc.rc, pc.rc0) : pc.rc;
+    const double wtop = reach * reach * T.scale * (1.0 + 1e-12);
     double worst = 0.0;
     for (int fine = 0; fine <= 6; ++fine) {        // refine the switching zone until the table is as good as the arithmetic
         T.shiftB = AMM_TAB_SHIFT - fine;
@@ -211,6 +216,36 @@ __device__ __forceinline__ double amm_tab_eval(const char *lds_tab, const PairTa
     p = fma(p, t, c23.x);
     p = fma(p, t, c01.y);
     return fma(p, t, c01.x);
+}
+
+// the same look-up in two halves, for kernels that pin the LDS reads of several pairs ahead of the arithmetic (cluster.hip)
+struct TabLookup {
+    double2 c01, c23, c45;
+    double t;
+};
+__device__ __forceinline__ TabLookup amm_tab_fetch(const char *lds_tab, const PairTab &T, double r2) {
+    const double w = r2 * T.scale;
+    const unsigned hi = (unsigned)__double2hiint(w);
+    const bool above = hi >= 0x3FF00000u;
+    const unsigned sh = above ? (unsigned)T.shiftB : (unsigned)AMM_TAB_SHIFT;
+    const unsigned raw = hi >> sh;
+    unsigned idx = raw - (unsigned)(above ? T.rawB_minus_nA : T.baseA);
+    idx = min(idx, (unsigned)(T.nint - 1));
+    const double centre = __hiloint2double((int)((raw << sh) | (unsigned)(above ? T.halfB : (1 << (AMM_TAB_SHIFT - 1)))), 0);
+    TabLookup L;
+    L.t = w - centre;
+    const double2 *cf = reinterpret_cast<const double2 *>(lds_tab + __umul24(idx, AMM_TAB_STRIDE));
+    L.c01 = cf[0];
+    L.c23 = cf[1];
+    L.c45 = cf[2];
+    return L;
+}
+__device__ __forceinline__ double amm_tab_horner(const TabLookup &L) {
+    double p = fma(L.c45.y, L.t, L.c45.x);
+    p = fma(p, L.t, L.c23.y);
+    p = fma(p, L.t, L.c23.x);
+    p = fma(p, L.t, L.c01.y);
+    return fma(p, L.t, L.c01.x);
 }
 
 // Lennard-Jones part of (-dE/dr)/r for mixed sig = (sigma_i + sigma_j)/2, eps4 = 4 sqrt(eps_i eps_j): the qq = 0 case of

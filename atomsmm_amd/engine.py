@@ -171,7 +171,7 @@ def slice_bounds(n_items, rank, world):
     integrates all atoms redundantly; the pair work is split by these slices of the cell-sorted order with full neighbour
     rows, so every force row has one producer and the exchange (all-gather of slices, or all-reduce of zero-filled
     buffers) is exact and identical on all ranks."""
-    per = (n_items + world - 1) // world
+    per = (n_items + world - 1) // world      # (bond-list sets: blocks of atom indices; the pair rows use backend.slice_per)
     begin = min(n_items, rank * per)
     return begin, min(n_items, begin + per)
 
@@ -219,7 +219,7 @@ class Engine:
         self._gather = self._coll and hasattr(self.ctx, 'bind_exchange') and os.environ.get('AMM_EXCHANGE', 'gather') == 'gather'
         self._gather_groups = set()
         if self._gather:
-            self._per = (n + self.world - 1) // self.world
+            self._per = B.slice_per(n, self.world)
             self._xchg = torch.zeros(self.world * 2 * self._per * 3, dtype=f64, device=dev)
             self.ctx.bind_exchange(self._xchg)
         self.x = torch.zeros((n, 3), dtype=f64, device=dev)
@@ -229,6 +229,10 @@ class Engine:
         self.parameters = {}
         self.entries = []
         self.skin = float(properties.get('Skin', -1.0))
+        # 'Option.<name>': tuning / test options of the library context (include/atomsmm_hip.h: amm_set_option)
+        for key, value in properties.items():
+            if key.startswith('Option.') and hasattr(self.ctx, 'set_option'):
+                self.ctx.set_option(key[len('Option.'):], float(value))
         if float(properties.get('OuterSkin', -1.0)) > 0:       # dual Verlet list: cell-built outer list pruned to the inner one
             self.ctx.set_outer_skin(float(properties['OuterSkin']))
         self._pair_info = {}

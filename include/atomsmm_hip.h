@@ -263,6 +263,14 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat);
 /* Dual Verlet list: an OUTER list (radius rc + skin_out, built from the cell list, rare) is PRUNED to the inner list
  * (rc + skin) that the traversal walks whenever an atom moved more than skin/2.  Applies to pair forces created later. */
 int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
+/* Tuning and test options of a context (set before the first evaluation; never read from the environment).  Names:
+ * "cluster" (1: molecule rows for water-like systems on the force-only path, 0: per-atom rows everywhere), "tab" (tabulated
+ * force-only kernels), "site_trips", "lanes_per_row", "build_parts", "unroll", "dual_unroll", "tab_block", "tab_dual_block",
+ * "no_dual", "no_defer", "terms_from", "no_term_lanes".  Unknown names are an error. */
+int amm_set_option(amm_ctx *ctx, const char *name, double value);
+/* slots of the cell-sorted order per rank (whole molecules of three: 3 ceil(ceil(n/3) / world)): the exchange buffer holds
+ * world x 2 x per x 3 doubles and a chunk of a single / dual evaluation is [1 or 2][per][3] */
+int amm_exchange_per(amm_ctx *ctx, int32_t *per);
 /* amm_run_ops fuses KICK;MOVE;EVAL(bond-list group);KICK into one launch (bit-identical results); 0 disables. */
 int amm_set_fuse_inner(amm_ctx *ctx, int32_t on);
 
@@ -278,10 +286,15 @@ typedef struct {
     int32_t n_cells;
     double rlist;
     int32_t shares_list;    /* 1 if this force traverses another force's list */
-    int32_t pad_;
+    int32_t list_kind;      /* rows walked by the last evaluation: 0 one per atom, 1 one per molecule (water-like systems,
+                               force-only evaluations: n_list_pairs then counts nine atom pairs per entry, capacity and
+                               max_neighbors are molecule partners per row, lanes_per_atom is lanes per row) */
     int64_t n_outer_builds; /* cell-based builds of the outer list (n_builds counts prunes of the inner list) */
     int64_t n_outer_pairs;
     double rlist_outer;
+    double tab_error;       /* largest relative interpolation error of the force's radial Coulomb table at its check points;
+                               0 without a table (analytic kernels: family without one, or a table that missed 1e-13) */
+    int32_t has_table, pad2_;
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
 /* Measurement helper (bench.py): the number of directed list entries of this force with r < r_within at d_pos, counted in

@@ -41,6 +41,8 @@ def main():
     ap.add_argument('--outer', choices=['damped', 'ewald'], default='damped')
     ap.add_argument('--world', type=int, default=1, help='emulate rank --rank of this many ranks (its slice of the rows, no collectives)')
     ap.add_argument('--rank', type=int, default=0)
+    ap.add_argument('--cluster', type=int, default=1, help='1: molecule rows (product default for water), 0: per-atom rows')
+    ap.add_argument('--option', action='append', default=[], help='name=value context option (amm_set_option), repeatable')
     args = ap.parse_args()
     if args.make_config:
         return make_config(args.out)
@@ -55,6 +57,10 @@ def main():
         print('warning: no relaxed configuration (%s): timing the lattice start' % CACHE)
     dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device='cuda')   # noqa: E731
     ctx = B.HipContext(n, c['box'], rank=args.rank, world=args.world)
+    ctx.set_option('cluster', args.cluster)
+    for item in args.option:
+        name, value = item.split('=')
+        ctx.set_option(name, float(value))
     dn = B.pair_desc(B.NEAR_FSWITCH, 0.7, rc0=0.7, rs0=0.5)
     if args.outer == 'damped':
         dd = B.pair_desc(B.DAMPED, 1.0, rswitch=0.9, alpha=2.9, degree=1)
@@ -113,9 +119,12 @@ def main():
     print('   world %d rank %d: evaluation wall time near %.1f us, dual %.1f us; with a list rebuild %.1f us (rebuild alone ~%.1f us)' % (
         args.world, args.rank, w_near, w_dual, w_rebuild, w_rebuild - w_near))
     st = ctx.pair_stats(ff)
-    print('lib=%s  near %.1f us  far %.1f us  dual %.1f us   (list pairs near/far: %d / %d, lanes/atom %d)' % (
+    print('lib=%s  near %.1f us  far %.1f us  dual %.1f us   (list pairs near/far: %d / %d, lanes/row %d, rows per %s)' % (
         os.path.basename(os.environ.get('AMM_LIB', 'product')), res['near'], res['far'], res['dual'],
-        ctx.pair_stats(fn)['n_list_pairs'], st['n_list_pairs'], st['lanes_per_atom']))
+        ctx.pair_stats(fn)['n_list_pairs'], st['n_list_pairs'], st['lanes_per_atom'], 'molecule' if st['list_kind'] else 'atom'))
+    within = (ctx.pair_count_within(fn, x, 0.7), ctx.pair_count_within(ff, x, 1.0))
+    print('   entries inside the cutoffs: near %d (%.1f %%)  outer %d (%.1f %%)' % (
+        within[0], 100.0 * within[0] / max(ctx.pair_stats(fn)['n_list_pairs'], 1), within[1], 100.0 * within[1] / max(st['n_list_pairs'], 1)))
     fsum = [float(b.abs().sum()) for b in f[1:3]]
     print('   checksum |f1| = %.10e  |f2| = %.10e' % tuple(fsum))
     ctx.close()

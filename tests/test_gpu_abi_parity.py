@@ -65,6 +65,38 @@ CASES = {
 }
 
 
+NARROW = {
+    # switching windows far narrower than the tested 0.2 / 0.05 nm, and a DAMPED degree above 1: the radial table's refinement may
+    # stop short of the arithmetic's accuracy: such a force must keep the analytic kernels, never a coarse table
+    'damped-2-narrow': O.desc(O.DAMPED, rc=1.0, rswitch=0.98, alpha=2.9, degree=2),
+    'damped-3': O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=3),
+    'near-fswitch-narrow': near('force-switch', 0.7, 0.68),
+    'near-none-narrow': near(None, 0.7, 0.69),
+}
+
+
+@pytest.mark.parametrize('name', sorted(NARROW))
+def test_narrow_switch_tables_meet_their_bound_or_are_not_used(spcfw, name):
+    B = _backend()
+    d = NARROW[name]
+    c = spcfw
+    n = len(c['positions'])
+    e_ref, f_ref, _ = O.pair_eval(d, c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])
+    ctx = B.HipContext(n, c['box'])
+    fid = hip_pair(B, ctx, d, c)
+    f2 = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+    ctx.force_eval(fid, dev(c['positions']), f2)           # force-only: the tabulated kernel IF the table is good enough
+    ctx.check()
+    st = ctx.pair_stats(fid)
+    assert (st['has_table'] == 1 and st['tab_error'] <= 1e-13) or st['has_table'] == 0
+    assert np.abs(f2.cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    e, f = eval_force(ctx, fid, dev(c['positions']), n)
+    # (the force-switch ENERGY is ill-conditioned in b = rs/(rc - rs) -- b = 34 here, cf. G3 with b = 19 --, its force is not)
+    assert e == pytest.approx(e_ref, rel=1e-6 if name == 'near-fswitch-narrow' else 1e-9)
+    assert np.abs(f2.cpu().numpy() - f).max() <= 1e-11 * np.abs(f).max()
+    ctx.close()
+
+
 @pytest.mark.parametrize('name', sorted(CASES))
 def test_pair_families_vs_oracle_and_goldens(spcfw, goldens, name):
     B = _backend()

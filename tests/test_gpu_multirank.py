@@ -13,13 +13,11 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
 
 
-@pytest.fixture(autouse=True)
-def _one_order_of_summation(monkeypatch):
-    """The force-only traversal cuts a wavefront's rows into stretches with / without Lennard-Jones arithmetic at positions taken
-    from all the rows of the wavefront: a row's partial sums then depend on its wave-mates, i.e. on the decomposition -- equal to
-    rounding, not bit for bit.  The bit-identity checks of this file run with the cutting off (read when a context is created;
-    spawned ranks inherit it); the C3-size test also compares against the product's default walk, to 1e-12."""
-    monkeypatch.setenv('AMM_SITE_TRIPS', '0')
+# Order of summation.  Water-like systems walk MOLECULE rows on the force-only path (csrc/cluster.hip): a row's partial sums depend
+# on the row alone, so any decomposition gives the same bits -- the product default is what these tests run.  The per-atom rows
+# (csrc/pair.hip: systems that do not qualify, and option "cluster" = 0) cut a wavefront's rows into stretches with / without
+# Lennard-Jones arithmetic at positions taken from all the rows of the wavefront; their bit-identity variants switch that off
+# with the context option "site_trips" (amm_set_option: an ABI option, not an environment variable).
 
 
 def _free_port():
@@ -154,9 +152,11 @@ def test_library_owned_rccl_communicator(pme):
     assert out['comm']['calls'] == (2 * 3 + 1 if not pme else 3 * 3 + 2), out['comm']
 
 
-def test_exchange_chunks_of_five_uneven_slices():
+@pytest.mark.parametrize('cluster', [1, 0])
+def test_exchange_chunks_of_five_uneven_slices(cluster):
     """The all-gather exchange without any collective library: five contexts in ONE process stand for ranks 0..4 of a
-    world of 5 (1536 atoms: slices of 308, 308, 308, 308, 304 slots).  Every 'rank' evaluates the near and the outer
+    world of 5 (1536 atoms = 512 molecules: slices of 309, 309, 309, 309, 300 slots -- whole molecules).  cluster = 1: molecule
+    rows (the product default for water); 0: per-atom rows with the stretch cutting off.  Every 'rank' evaluates the near and the outer
     force of its slice in one pass into its chunk of its exchange buffer (no communicator: the EVAL leaves the exchange
     to the host), the chunks are copied between the buffers as an all-gather would, amm_exchange_finish spreads them:
     every rank then holds the forces of a single-context evaluation, bit for bit."""
@@ -171,11 +171,15 @@ def test_exchange_chunks_of_five_uneven_slices():
     dn = near('force-switch', 0.7, 0.5)
     dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
     world = 5
-    per = (n + world - 1) // world
+    per = B.slice_per(n, world)
+    assert per == 309
     E = B.OP_EVAL
 
     def make(rank, w):
         ctx = B.HipContext(n, c['box'], rank=rank, world=w)
+        ctx.set_option('cluster', cluster)
+        ctx.set_option('site_trips', 0)
+        assert ctx.exchange_per() == (per if w == world else B.slice_per(n, w))
         fn = hip_pair(B, ctx, dn, c, skin=0.1)         # equal buffers on both sides: the default grows with the world
         ff = hip_pair(B, ctx, dd, c, skin=0.1)
         ctx.pair_share_list(fn, ff)
@@ -209,6 +213,7 @@ def test_exchange_chunks_of_five_uneven_slices():
         ctx.exchange_finish()
         ctx.check()
         assert torch.equal(f[1], fref[1]) and torch.equal(f[2], fref[2])
+        assert ctx.pair_stats(1)['list_kind'] == cluster
         with pytest.raises(B.HipError):
             ctx.exchange_finish()                               # nothing is waiting any more
     # a single (not dual) exchanged evaluation uses chunks of [per][3]
@@ -226,8 +231,8 @@ def test_exchange_chunks_of_five_uneven_slices():
 
 
 def test_exchange_with_empty_slices_on_a_tiny_box():
-    """More ranks than work: 24 atoms over a world of 8 with 4 atoms per slice would leave nothing empty, so 16 ranks' worth
-    is emulated with per = 2 (ranks 12..15 own no atom).  Small box: the minimum-image (RINT) list build.  Same hand-made
+    """More ranks than work: 24 atoms = 8 molecules over a world of 16: per = 3 slots (one molecule), ranks 8..15 own nothing.
+    Small box: the minimum-image (RINT) list build and the per-pair periodic image of the traversal.  Same hand-made
     all-gather as above; every rank, the empty ones included, ends with the single-context force, bit for bit."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -239,8 +244,8 @@ def test_exchange_with_empty_slices_on_a_tiny_box():
     assert n == 24
     dn = near('force-switch', 0.3, 0.25)
     world = 16
-    per = (n + world - 1) // world
-    assert per == 2 and (world - 1) * per >= n            # the last ranks are empty
+    per = B.slice_per(n, world)
+    assert per == 3 and (world - 1) * per >= n            # the last ranks are empty
     E = B.OP_EVAL
 
     def make(rank, w):
@@ -278,16 +283,17 @@ def test_exchange_with_empty_slices_on_a_tiny_box():
     ref.close()
 
 
-def test_c3_size_eight_slices_all_gather_bit_identical(monkeypatch):
+@pytest.mark.parametrize('cluster', [1, 0])
+def test_c3_size_eight_slices_all_gather_bit_identical(cluster):
     """Config C4 of BASELINE.json at full size, emulated on one GPU: eight contexts stand for the ranks of a world of 8 over
-    the 98 304-atom TIP3P box (slices of 12 288 cell-sorted slots, 16 lanes per atom, rows traversed in each slice's own
-    row_order).  Each 'rank' runs the dual pass (near + outer force) on its slice into its chunk of the exchange buffer, the
-    chunks are copied as an all-gather would, amm_exchange_finish unsorts them: every rank then holds the single-context
-    forces bit for bit -- before and after a displacement that makes every rank rebuild its part of the list.  (A rank's
-    slice is walked with 16 lanes per atom, the whole box on one GPU with 8: the single-context reference is pinned to 16
-    as well, since the number of partial sums per row fixes the summation order; against the 8-lane walk the forces agree
-    to 1e-12 of the largest, checked too.)"""
-    monkeypatch.setenv('AMM_LPA', '16')
+    the 98 304-atom TIP3P box (slices of 4 096 molecules of the cell-sorted order).  Each 'rank' runs the dual pass (near + outer
+    force) on its slice into its chunk of the exchange buffer, the chunks are copied as an all-gather would,
+    amm_exchange_finish unsorts them: every rank then holds the single-context forces bit for bit -- before and after a
+    displacement that makes every rank rebuild its part of the list.  cluster = 1: molecule rows, the product default (a row's
+    order of summation depends on the row alone).  cluster = 0: per-atom rows; there a slice is walked with 16 lanes per atom
+    and the whole box with 8, and the wavefront-wide stretch cutting couples a row's order to its wave-mates, so the reference
+    context is pinned to 16 lanes and the cutting is off on both sides (options of the ABI); against the product's own 8-lane
+    walk with the cutting on the forces agree to 1e-12 of the largest, checked too."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from atomsmm_amd import backend as B
@@ -299,12 +305,14 @@ def test_c3_size_eight_slices_all_gather_bit_identical(monkeypatch):
     dn = near('force-switch', 0.7, 0.5)
     dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
     world = 8
-    per = (n + world - 1) // world
+    per = B.slice_per(n, world)
     E = B.OP_EVAL
     dual = [B.Op(E, 1, 0, 0, 0.0), B.Op(E, 2, 0, 0, 0.0)]
 
-    def make(rank, w):
+    def make(rank, w, options):
         ctx = B.HipContext(n, c['box'], rank=rank, world=w)
+        for name, value in options.items():
+            ctx.set_option(name, value)
         fn = hip_pair(B, ctx, dn, c, skin=0.1)         # equal buffers on both sides: the default grows with the world
         ff = hip_pair(B, ctx, dd, c, skin=0.1)
         ctx.pair_share_list(fn, ff)
@@ -317,18 +325,15 @@ def test_c3_size_eight_slices_all_gather_bit_identical(monkeypatch):
         ctx.group_define(2, 2, [ff])
         return ctx, f, x, (v, m), ff
 
-    ref, fref, xref, keep_ref, ff_ref = make(0, 1)
-    monkeypatch.delenv('AMM_LPA')
-    monkeypatch.setenv('AMM_SITE_TRIPS', '1')
-    ref8, fref8, xref8, keep_ref8, ff_ref8 = make(0, 1)           # the product's single-GPU walk: 8 lanes per atom, stretches cut
+    pinned = {'cluster': cluster} if cluster else {'cluster': 0, 'lanes_per_row': 16, 'site_trips': 0}
+    ref, fref, xref, keep_ref, ff_ref = make(0, 1, pinned)
+    ref8, fref8, xref8, keep_ref8, ff_ref8 = make(0, 1, {'cluster': 0})      # the per-atom walk as shipped: 8 lanes, stretches cut
     ref8.run_ops(dual, 1)
     ref8.check()
-    assert ref8.pair_stats(ff_ref8)['lanes_per_atom'] == 8
-    monkeypatch.setenv('AMM_LPA', '16')
-    monkeypatch.setenv('AMM_SITE_TRIPS', '0')
+    assert ref8.pair_stats(ff_ref8)['lanes_per_atom'] == 8 and ref8.pair_stats(ff_ref8)['list_kind'] == 0
     ranks = []
     for r in range(world):
-        ctx, f, x, keep, ff = make(r, world)
+        ctx, f, x, keep, ff = make(r, world, pinned)
         xchg = torch.full((world * 2 * per * 3,), float('nan'), dtype=torch.float64, device='cuda')
         ctx.bind_exchange(xchg)
         ctx.group_set_exchange(1, B.EXCHANGE_GATHER)
@@ -336,7 +341,8 @@ def test_c3_size_eight_slices_all_gather_bit_identical(monkeypatch):
         ranks.append((ctx, f, xchg, x, keep, ff))
     chunk = 2 * per * 3
     rng = np.random.default_rng(3)
-    shift = torch.as_tensor(rng.normal(0.0, 0.04, (n, 3)), device='cuda')        # beyond skin / 2 for many atoms: rebuild
+    # whole molecules move (beyond skin / 2 for many of them: rebuild) and every atom a little on top
+    shift = torch.as_tensor(np.repeat(rng.normal(0.0, 0.04, (n // 3, 3)), 3, axis=0) + rng.normal(0.0, 0.004, (n, 3)), device='cuda')
     for stage in range(2):
         ref.run_ops(dual, 1)
         ref.check()
@@ -352,7 +358,7 @@ def test_c3_size_eight_slices_all_gather_bit_identical(monkeypatch):
             ctx.check()
             assert torch.equal(f[1], fref[1]) and torch.equal(f[2], fref[2])
             st = ctx.pair_stats(ff)
-            assert st['lanes_per_atom'] == 16 and st['n_builds'] == stage + 1
+            assert st['list_kind'] == cluster and st['lanes_per_atom'] == (8 if cluster else 16) and st['n_builds'] == stage + 1
             slices += st['n_slice_atoms']
         assert slices == n and ref.pair_stats(ff_ref)['n_builds'] == stage + 1
         if stage == 0:
