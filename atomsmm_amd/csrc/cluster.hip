@@ -182,13 +182,15 @@ struct CBoxF {
 //   1. the stencil's molecules are walked as ONE concatenated stream (lane = candidate; piece table + binary search as in
 //      pair.hip's build) and tested by their FIRST atoms against a sphere that is guaranteed to contain every partner
 //      (|x0_i - x0_j| < rlist + ext_i + ext_j): 10 instructions per 64 candidates and row molecule; the survivors (a sixth of
-//      the stream) are queued in LDS, per row molecule;
-//   2. the queue is drained with all 64 lanes busy: three records per candidate, the nine atom-pair distances, the smallest
+//      the stream) are queued in LDS, per row molecule (a ring of 256);
+//   2. as soon as a ring holds 64 it is drained with ALL 64 lanes busy: three records per candidate, the nine atom-pair distances, the smallest
 //      decides (< rlist: listed; < rnear: front part), ordered ballot compaction into the row.
 // The old per-atom build spent 42 instructions per 64 ATOM-pair tests, mostly compaction; here the compaction is paid per
 // MOLECULE pair and only for a stream that is already 80 % hits.
-#define CB_BATCH 4
-#define CB_QCAP 448
+#ifndef CB_BATCH
+#define CB_BATCH 8
+#endif
+#define CB_QCAP 256         // ring of survivors per row molecule: a power of two >= 63 + 128
 
 __device__ void cfinish_build_block(int *flags, unsigned long long *counters, const unsigned long long *blockstats, int nblocks, int count_only) {
     __shared__ unsigned long long sh_sum[256], sh_max[256], sh_near[256];
@@ -241,12 +243,10 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
     __shared__ int s_rstart[4][128];
     __shared__ int s_rpref[4][128];
     __shared__ float s_rshift[4][3][128];
-    __shared__ int s_q[4][CB_BATCH][CB_QCAP];
+    __shared__ int s_q[4][CB_BATCH][CB_QCAP];        // per row molecule: ring of survivors of the sphere test (sorted slots)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int c = wave / parts, part = wave - c * parts;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    (void)below;
     const float FAR = 1.0e9f;
     const float rlist2 = rlist * rlist;
     unsigned long long wsum = 0, wnear = 0;
@@ -307,89 +307,80 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
         }
         for (int tb = a_begin; tb < a_end; tb += CB_BATCH) {
             const int nt = min(CB_BATCH, a_end - tb);
-            // the batch's atoms: lane 3 t + a holds atom a of row molecule t; scalars by readlane
+            // the batch's atoms: lane 3 t + a holds atom a of row molecule t; the loops over t below are REAL loops (t is a scalar
+            // register): coordinates come by v_readlane, the per-row counters live in lane t of three registers -- one copy of the
+            // test and of the drain code whatever the batch size
             float4 my = make_float4(0.f, 0.f, 0.f, 0.f);
             if (lane < 3 * nt) my = pos4f[3 * tb + lane];
-            float px[CB_BATCH][3], py[CB_BATCH][3], pz[CB_BATCH][3], plim[CB_BATCH];
-            int c2[CB_BATCH], qn[CB_BATCH];
-#pragma unroll
-            for (int t = 0; t < CB_BATCH; ++t) {
+            int row_cnt = 0;          // lane t: entries of row t so far (front | back << 16)
+            int q_head = 0, q_cnt = 0;    // lane t: ring of row t (head index, entries waiting)
+            auto rl = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+            // ---- pass 2: 64 queued survivors of row t (n of them valid): nine distances, the smallest decides ----
+            auto drain = [&](int t, int n) {
+                const int head = __builtin_amdgcn_readlane(q_head, t);
+                const bool v0 = lane < n;
+                const int slot = v0 ? s_q[w][t][(head + lane) & (CB_QCAP - 1)] : tb + t;
+                const bool v = v0 && slot != tb + t;          // (a molecule is not its own partner)
+                float4 A[3];
+                A[0] = pos4f[3 * slot];
+                A[1] = pos4f[3 * slot + 1];
+                A[2] = pos4f[3 * slot + 2];
+                const int sites = __float_as_int(A[1].w);
+                float px[3], py[3], pz[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    px[t][a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.x), 3 * t + a));
-                    py[t][a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.y), 3 * t + a));
-                    pz[t][a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.z), 3 * t + a));
+                    px[a] = rl(my.x, 3 * t + a);
+                    py[a] = rl(my.y, 3 * t + a);
+                    pz[a] = rl(my.z, 3 * t + a);
                 }
-                plim[t] = rlist + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my.w), 3 * t));
-                c2[t] = 0;
-                qn[t] = 0;
-            }
-            // ---- pass 2: drain the queues (all lanes busy): nine distances, the smallest decides ----
-            auto drain = [&]() {
+                if (!RINT) {          // one periodic image per molecule pair, from the first atoms
+                    const float sx = box.L[0] * rintf((A[0].x - px[0]) * box.invL[0]);
+                    const float sy = box.L[1] * rintf((A[0].y - py[0]) * box.invL[1]);
+                    const float sz = box.L[2] * rintf((A[0].z - pz[0]) * box.invL[2]);
 #pragma unroll
-                for (int t = 0; t < CB_BATCH; ++t) {
-                    if (t >= nt) break;
-                    const int nq = qn[t];
-                    int *row_out = nl + (size_t)(tb + t - c_begin) * cap;
-                    for (int base = 0; base < nq; base += 64) {
-                        const int k = base + lane;
-                        const bool v = k < nq;
-                        const int slot = v ? s_q[w][t][k] : tb + t;
-                        float4 A[3];
-                        A[0] = pos4f[3 * slot];
-                        A[1] = pos4f[3 * slot + 1];
-                        A[2] = pos4f[3 * slot + 2];
-                        const int sites = __float_as_int(A[1].w);
-                        if (!RINT) {          // one periodic image per molecule pair, from the first atoms
-                            const float sx = box.L[0] * rintf((A[0].x - px[t][0]) * box.invL[0]);
-                            const float sy = box.L[1] * rintf((A[0].y - py[t][0]) * box.invL[1]);
-                            const float sz = box.L[2] * rintf((A[0].z - pz[t][0]) * box.invL[2]);
-#pragma unroll
-                            for (int b = 0; b < 3; ++b) {
-                                A[b].x -= sx;
-                                A[b].y -= sy;
-                                A[b].z -= sz;
-                            }
-                        }
-                        float m2 = 3.0e38f;
-#pragma unroll
-                        for (int a = 0; a < 3; ++a)
-#pragma unroll
-                            for (int b = 0; b < 3; ++b) {
-                                float dx = px[t][a] - A[b].x, dy = py[t][a] - A[b].y, dz = pz[t][a] - A[b].z;
-                                if (RINT) {
-                                    dx -= box.L[0] * rintf(dx * box.invL[0]);
-                                    dy -= box.L[1] * rintf(dy * box.invL[1]);
-                                    dz -= box.L[2] * rintf(dz * box.invL[2]);
-                                }
-                                m2 = fminf(m2, dx * dx + dy * dy + dz * dz);
-                            }
-                        const unsigned long long m_pass = __builtin_amdgcn_ballot_w64(v && m2 < rlist2);
-                        if (m_pass == 0ull) continue;
-                        const unsigned long long m_near = m_pass & __builtin_amdgcn_ballot_w64(m2 < rnear2);
-                        const int np_ = __popcll(m_pass), nn_ = __popcll(m_near);
-                        const int cnt = c2[t] & 0xffff, cntf = (int)((unsigned)c2[t] >> 16);
-                        if (!COUNT_ONLY) {
-                            const int mp = __builtin_amdgcn_mbcnt_hi((unsigned)(m_pass >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_pass, 0u));
-                            const int mn = __builtin_amdgcn_mbcnt_hi((unsigned)(m_near >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_near, 0u));
-                            const int pos_near = cnt + mn, pos_far = (cap - 1 - cntf) - (mp - mn);
-                            const bool is_near = (m_near >> lane) & 1ull;
-                            const int pos_in = is_near ? pos_near : pos_far;
-                            if (cnt + cntf + np_ <= cap) {
-                                if ((m_pass >> lane) & 1ull) row_out[pos_in] = slot | (sites << 29);
-                            }
-                        }
-                        c2[t] += nn_ + ((np_ - nn_) << 16);
+                    for (int b = 0; b < 3; ++b) {
+                        A[b].x -= sx;
+                        A[b].y -= sy;
+                        A[b].z -= sz;
                     }
-                    qn[t] = 0;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the queue reads are done before the next pass refills it
-                __builtin_amdgcn_wave_barrier();
+                float m2 = 3.0e38f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        float dx = px[a] - A[b].x, dy = py[a] - A[b].y, dz = pz[a] - A[b].z;
+                        if (RINT) {
+                            dx -= box.L[0] * rintf(dx * box.invL[0]);
+                            dy -= box.L[1] * rintf(dy * box.invL[1]);
+                            dz -= box.L[2] * rintf(dz * box.invL[2]);
+                        }
+                        m2 = fminf(m2, dx * dx + dy * dy + dz * dz);
+                    }
+                const unsigned long long m_pass = __builtin_amdgcn_ballot_w64(v && m2 < rlist2);
+                if (m_pass != 0ull) {
+                    const unsigned long long m_near = m_pass & __builtin_amdgcn_ballot_w64(m2 < rnear2);
+                    const int np_ = __popcll(m_pass), nn_ = __popcll(m_near);
+                    const int c2 = __builtin_amdgcn_readlane(row_cnt, t);
+                    const int cnt = c2 & 0xffff, cntf = (int)((unsigned)c2 >> 16);
+                    if (!COUNT_ONLY) {
+                        const int mp = __builtin_amdgcn_mbcnt_hi((unsigned)(m_pass >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_pass, 0u));
+                        const int mn = __builtin_amdgcn_mbcnt_hi((unsigned)(m_near >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_near, 0u));
+                        const int pos_near = cnt + mn, pos_far = (cap - 1 - cntf) - (mp - mn);
+                        const bool is_near = (m_near >> lane) & 1ull;
+                        if (cnt + cntf + np_ <= cap) {
+                            int *row_out = nl + (size_t)(tb + t - c_begin) * cap;
+                            if ((m_pass >> lane) & 1ull) row_out[is_near ? pos_near : pos_far] = slot | (sites << 29);
+                        }
+                    }
+                    row_cnt = lane == t ? c2 + nn_ + ((np_ - nn_) << 16) : row_cnt;
+                }
+                q_head = lane == t ? (head + n) & (CB_QCAP - 1) : q_head;
+                q_cnt = lane == t ? q_cnt - n : q_cnt;
             };
-            // ---- pass 1: the candidate stream, first atoms only ----
-            for (int cb = 0; cb < total; cb += 128) {
-                float4 cand[2];
-                int js[2];
+            // ---- pass 1: the candidate stream, first atoms only; a row's ring is drained in FULL chunks as soon as it holds 64 ----
+            // (the candidates of chunk pair i + 1 -- piece search in LDS, then a gather -- are fetched while pair i is tested)
+            auto fetch = [&](int cb, float4 (&cand)[2], int (&js)[2]) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int idx = cb + u * 64 + lane;
@@ -405,52 +396,67 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
                         q.x = in ? q.x + sx : FAR;
                         q.y = in ? q.y + sy : FAR;
                         q.z = in ? q.z + sz : FAR;
+                    } else if (!in) {
+                        q.w = -1.0e9f;            // beyond the stream: no sphere reaches it
                     }
                     cand[u] = q;
-                    js[u] = in ? slot : -1;
+                    js[u] = slot;
                 }
-#pragma unroll
-                for (int t = 0; t < CB_BATCH; ++t) {
-                    if (t >= nt) break;
+            };
+            float4 cand[2], cand_n[2];
+            int js[2], js_n[2];
+            fetch(0, cand, js);
+            for (int cb = 0; cb < total; cb += 128) {
+                if (cb + 128 < total) fetch(cb + 128, cand_n, js_n);
+                for (int t = 0; t < nt; ++t) {
+                    const float p0x = rl(my.x, 3 * t), p0y = rl(my.y, 3 * t), p0z = rl(my.z, 3 * t), plim = rlist + rl(my.w, 3 * t);
+                    int qn = __builtin_amdgcn_readlane(q_cnt, t);
+                    const int head = __builtin_amdgcn_readlane(q_head, t);
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         if (cb + u * 64 >= total) continue;
-                        float dx = px[t][0] - cand[u].x, dy = py[t][0] - cand[u].y, dz = pz[t][0] - cand[u].z;
+                        float dx = p0x - cand[u].x, dy = p0y - cand[u].y, dz = p0z - cand[u].z;
                         if (RINT) {
                             dx -= box.L[0] * rintf(dx * box.invL[0]);
                             dy -= box.L[1] * rintf(dy * box.invL[1]);
                             dz -= box.L[2] * rintf(dz * box.invL[2]);
                         }
                         const float r2 = dx * dx + dy * dy + dz * dz;
-                        const float lim = plim[t] + cand[u].w;
-                        unsigned long long m = __builtin_amdgcn_ballot_w64(r2 < lim * lim && js[u] >= 0 && js[u] != tb + t);
+                        const float lim = plim + cand[u].w;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(r2 < lim * lim && lim > 0.f);
                         if (m == 0ull) continue;
-                        const int at = qn[t] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        if ((m >> lane) & 1ull) s_q[w][t][at] = js[u];
-                        qn[t] += __popcll(m);
+                        const int at = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if ((m >> lane) & 1ull) s_q[w][t][(head + at) & (CB_QCAP - 1)] = js[u];
+                        qn += __popcll(m);
+                    }
+                    q_cnt = lane == t ? qn : q_cnt;
+                    if (qn >= 64) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        while (qn >= 64) {
+                            drain(t, 64);
+                            qn -= 64;
+                        }
                     }
                 }
-                int fullest = qn[0];
 #pragma unroll
-                for (int t = 1; t < CB_BATCH; ++t) fullest = max(fullest, qn[t]);
-                if (fullest > CB_QCAP - 128) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    drain();
+                for (int u = 0; u < 2; ++u) {
+                    cand[u] = cand_n[u];
+                    js[u] = js_n[u];
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            drain();
-            int count = 0, countf = 0;
-#pragma unroll
-            for (int t = 0; t < CB_BATCH; ++t) {
-                count = (lane == t) ? (c2[t] & 0xffff) : count;
-                countf = (lane == t) ? (int)((unsigned)c2[t] >> 16) : countf;
+            for (int t = 0; t < nt; ++t) {
+                const int n = __builtin_amdgcn_readlane(q_cnt, t);
+                if (n > 0) drain(t, n);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the ring reads are done before the next batch refills them
+            __builtin_amdgcn_wave_barrier();
             if (lane < nt) {
+                const int count = row_cnt & 0xffff, countf = (int)((unsigned)row_cnt >> 16);
                 const int total_nb = count + countf;
                 if (!COUNT_ONLY) {
                     const bool over = total_nb > cap;
@@ -922,7 +928,11 @@ static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) 
     AMM_HIP(hipMemset(cl->d_ticket, 0, sizeof(int) * 4 * AMM_TICKET_INTS));
     AMM_HIP(hipMalloc(&cl->d_counters, sizeof(unsigned long long) * 8));
     AMM_HIP(hipMemset(cl->d_counters, 0, sizeof(unsigned long long) * 8));
+    // lanes per row: 8 rows per wavefront on a whole box; a rank's slice has fewer rows than the persistent grid has wavefronts
+    // (256 CUs x 8), so rows are shared out over more lanes until every wavefront has one task (measured on slices of the
+    // 98 304-atom box, dual pass: 2 ranks 113 us with 8 lanes; 4 ranks 68 with 16 (107 with 8); 8 ranks 44 with 32 (105 with 8))
     int lpa = 8;
+    while (lpa < 64 && (long)(cl->c_end - cl->c_begin) * lpa < 64L * 2048) lpa <<= 1;
     if (ctx->opt_lpa > 0) lpa = ctx->opt_lpa;
     cl->lpa = lpa;
     int flags[8];
@@ -933,7 +943,9 @@ static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) 
     AMM_HIP(hipStreamSynchronize(ctx->stream));
     cl->capc = 2 * flags[6] + 16;
     AMM_HIP(hipMalloc(&cl->d_cell_members, sizeof(int) * (size_t)ncell * cl->capc));
-    cl->parts = std::max(1, std::min(16, (int)std::ceil(1.15 * flags[6] / CB_BATCH)));
+    // wavefronts per cell: one batch of CB_BATCH row molecules each at the MEAN cell occupancy (a wave walks the cell's whole
+    // candidate stream once per batch: sized by the fullest cell -- the first version -- most waves walked it for two molecules)
+    cl->parts = std::max(1, std::min(16, (int)std::ceil((double)nc / ncell / CB_BATCH)));
     if (ctx->opt_parts > 0) cl->parts = std::max(1, std::min(16, ctx->opt_parts));
     {
         const long t1 = (long)ncell * cl->parts * 64;

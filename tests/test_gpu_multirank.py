@@ -86,11 +86,11 @@ def test_two_ranks_match_single_rank_bit_for_bit(pme):
         for p in procs:
             p.start()
         for p in procs:
-            p.join(90)
+            p.join(240)
         stuck = [p for p in procs if p.is_alive()]
         for p in stuck:          # never leave a rank behind on the GPU box
             p.kill()
-        assert not stuck, 'a rank did not finish within 90 s'
+        assert not stuck, 'a rank did not finish within 240 s'
         assert all(p.exitcode == 0 for p in procs)
         out = dict(ret)
     for r in (0, 1):
@@ -134,10 +134,10 @@ def test_library_owned_rccl_communicator(pme):
         ret = manager.dict()
         p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret, pme))
         p.start()
-        p.join(120)
+        p.join(300)
         if p.is_alive():
             p.kill()
-            raise AssertionError('the RCCL rank did not finish within 120 s')
+            raise AssertionError('the RCCL rank did not finish within 300 s')
         assert p.exitcode == 0
         out = dict(ret)[0]
     assert out['native_comm'] and out['slice_atoms'] == 3000
@@ -325,7 +325,9 @@ def test_c3_size_eight_slices_all_gather_bit_identical(cluster):
         ctx.group_define(2, 2, [ff])
         return ctx, f, x, (v, m), ff
 
-    pinned = {'cluster': cluster} if cluster else {'cluster': 0, 'lanes_per_row': 16, 'site_trips': 0}
+    # (the number of lanes that share a row fixes the order of its partial sums: the library picks it from the number of rows a
+    # context owns -- 8 for the whole box, 32 for an eighth -- so both sides of a bit-for-bit comparison pin it)
+    pinned = {'cluster': 1, 'lanes_per_row': 8} if cluster else {'cluster': 0, 'lanes_per_row': 16, 'site_trips': 0}
     ref, fref, xref, keep_ref, ff_ref = make(0, 1, pinned)
     ref8, fref8, xref8, keep_ref8, ff_ref8 = make(0, 1, {'cluster': 0})      # the per-atom walk as shipped: 8 lanes, stretches cut
     ref8.run_ops(dual, 1)
