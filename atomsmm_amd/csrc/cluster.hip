@@ -498,11 +498,11 @@ struct CPairArgs {
     const int *nl, *nnb, *nnb_total;
     const double4 *posq;
     const double2 *lj;
-    double *force, *gforce;
-    int accumulate, gaccumulate, gsame, sorted_out;
+    double *force;
+    int accumulate, sorted_out;
     Box box;
-    const double *host_tab, *guest_tab;
-    int host_bytes, guest_bytes;
+    const double *host_tab;
+    int host_bytes;
     double margin;
     int ntask;
     int per_pair_image;
@@ -510,20 +510,25 @@ struct CPairArgs {
 
 // IMG: 0 interior rows (no periodic image), 1 one image per molecule pair (from the first atoms), 2 minimum image per atom pair
 //
-// One trip = one partner molecule per lane = nine atom pairs, walked partner atom by partner atom (b outer, a inner): when the three
-// pairs of partner atom b are done its record is dead, and the same registers take the record of the NEXT trip's partner -- the
-// loads of trip t + 1 are in flight behind ~2 000 cycles of trip t's arithmetic without a second register set (the per-atom kernel
-// of pair.hip needs two sets and a two-deep pipeline because its trips are 2 pairs long).  Scheduling barriers between the b blocks
-// keep the compiler from interleaving all nine pairs (which costs 100 registers of temporaries and spills).
-template <int FAM, int CMODE, int GFAM, int IMG>
-__device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &c, const PairConsts &gc, const char *tabh, const char *tabg,
-                                          const double *s_erfcx, const double4 (&pi)[3], const double2 *li, int i_sites,
-                                          const int *row, int nfront, int nn, int sub, int lpa, int self, double (&f)[9], double (&g)[9]) {
-    // pi[a].w = Kc q_a (folded by the caller); li[a]: the row atoms' Lennard-Jones parameters in an LDS strip of the wavefront (only the
-    // rare pairs of two sites read them: 12 registers less)
+// One trip = one partner molecule per lane = nine atom pairs, walked partner atom by partner atom (b outer, a inner).  Per partner
+// atom: geometry, index arithmetic and LDS reads of its three pairs are pinned AHEAD of the three Horner chains (a scheduling
+// barrier: left to itself the compiler waits for each pair's reads right behind them, s_waitcnt lgkmcnt(0) nine times per trip),
+// then the rare Lennard-Jones branch, then the accumulation.  When the three pairs of partner atom b are done its record is dead
+// and the same registers take the record of the NEXT trip's partner: the loads of trip t + 1 are in flight behind ~1 000 cycles
+// of arithmetic without a second register set.
+//
+// ONE force per launch.  The forms that evaluated the guest force of a shared list on the same walk (two radial tables, 18 more
+// accumulators) all spilled at 256 registers -- 72 to 436 bytes of scratch per lane, 200 us for DAMPED + near and 680 us for
+// Ewald-direct + near -- so the "dual pass" of molecule rows is two launches over the same rows: the outer force over the whole
+// rows, the near force over their front parts (140 + 63 us; the list check, the sorted copies and the rows are shared).
+template <int FAM, int CMODE, int IMG>
+__device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &c, const char *tabh, const double *s_erfcx,
+                                          const double4 (&pi)[3], const double2 *li, int i_sites, const int *row, int nfront, int nn,
+                                          int sub, int lpa, int self, double (&f)[9]) {
+    // pi[a].w = sign Kc q_a (folded by the caller); li[a]: the row atoms' Lennard-Jones parameters (2 sqrt(eps) times the sign) in an
+    // LDS strip of the wavefront (only the rare pairs of two sites read them: 12 registers less)
     const int back = A.cap - 1 + nfront;
-    // pairs closer than EITHER table reaches are left out of the main path and redone analytically (both forces) below
-    const double r2low = GFAM >= 0 ? fmax(c.tab.r2min, gc.tab.r2min) : c.tab.r2min;
+    const double r2low = c.tab.r2min;      // closer pairs are left out of the main path and redone analytically below
     auto entry = [&](int k) { return k < nn ? row[k < nfront ? k : back - k] : self; };
     auto load_pos = [&](int e, int b) {
         return *reinterpret_cast<const double4 *>(reinterpret_cast<const char *>(A.posq) + (size_t)((unsigned)e & 0x1fffffffu) * 96u + 32 * b);
@@ -544,98 +549,8 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
         pj[b] = load_pos(e, b);
         lj[b] = load_lj(e, b);
     }
-    // One partner atom against the row's three atoms.  GT (the guest force takes part in this trip) is a compile-time
-    // variant of the whole block, and the Lennard-Jones branches come AFTER the Coulomb part of all three pairs: the three
-    // table look-ups (index arithmetic -> LDS -> five dependent fma) then sit in one basic block and overlap -- with a branch
-    // between the pairs (first version) every pair's chain ran on its own, LDS latency and all (330 cycles per 64 pairs).
-    auto block = [&](auto gt_tag, int b, bool ok, unsigned bits, double sx, double sy, double sz) {
-        constexpr bool GT = decltype(gt_tag)::value;
-        const double xb = pj[b].x - sx, yb = pj[b].y - sy, zb = pj[b].z - sz, qb = pj[b].w;
-        double dx[3], dy[3], dz[3], r2[3], fr[3], frg[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            dx[a] = pi[a].x - xb;
-            dy[a] = pi[a].y - yb;
-            dz[a] = pi[a].z - zb;
-            if (IMG == 2) {
-                dx[a] = amm_min_image(dx[a], A.box.L[0], A.box.invL[0]);
-                dy[a] = amm_min_image(dy[a], A.box.L[1], A.box.invL[1]);
-                dz[a] = amm_min_image(dz[a], A.box.L[2], A.box.invL[2]);
-            }
-            r2[a] = dx[a] * dx[a] + dy[a] * dy[a] + dz[a] * dz[a];
-        }
-        // table look-ups in two pinned stages: ALL index arithmetic and LDS reads of the three pairs (and of the guest's table)
-        // first, then the Horner chains -- the compiler left to itself waits for each pair's reads right behind them
-        // (s_waitcnt lgkmcnt(0) nine times per trip: 45 % of the issue slots used)
-        TabLookup th[3], tg[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            th[a] = amm_tab_fetch(tabh, c.tab, r2[a]);
-            if (GT) tg[a] = amm_tab_fetch(tabg, gc.tab, r2[a]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double qq = pi[a].w * qb;
-            fr[a] = qq * amm_tab_horner(th[a]);
-            frg[a] = GT ? qq * amm_tab_horner(tg[a]) : 0.0;
-        }
-        // Lennard-Jones part: only where two sites can meet (wave-uniform); the other lanes add an exact zero (eps4 = 0)
-        if (i_sites != 0 && __builtin_amdgcn_ballot_w64(ok && ((bits >> b) & 1u)) != 0ull) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-                if ((i_sites >> a) & 1) {
-                    const double2 la = li[64 * a];
-                    const double sig = la.x + lj[b].x, eps4 = la.y * lj[b].y;
-                    const LJCommon L = amm_lj_common(r2[a], sig, eps4);
-                    fr[a] += amm_lj_force<FAM, CMODE>(c, L, sig, eps4);
-                    if (GT) frg[a] += amm_lj_force<(GFAM >= 0 ? GFAM : FAM), 0>(gc, L, sig, eps4);
-                }
-        }
-        bool any_low = false;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const bool low = r2[a] < r2low;
-            const bool pass = ok && (r2[a] < c.rc2);
-            any_low = any_low || (pass && low);
-            const double fh = (pass && !low) ? fr[a] : 0.0;
-            f[3 * a] += fh * dx[a];
-            f[3 * a + 1] += fh * dy[a];
-            f[3 * a + 2] += fh * dz[a];
-            if (GT) {
-                const double fg = (pass && !low && (r2[a] < gc.rc2)) ? frg[a] * gc.sign : 0.0;
-                g[3 * a] += fg * dx[a];
-                g[3 * a + 1] += fg * dy[a];
-                g[3 * a + 2] += fg * dz[a];
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {       // closer than a table reaches: analytic, both forces (never in a liquid)
-            for (int a = 0; a < 3; ++a) {
-                const bool low = ok && (r2[a] < c.rc2) && (r2[a] < r2low);
-                const double qq = pi[a].w * qb;
-                const double2 lx = A.lj[3 * ((unsigned)e & 0x1fffffffu) + b];
-                const double2 la = li[64 * a];
-                const double sg = la.x + lx.x, e4 = la.y * lx.y;
-                double e_, fr_;
-                amm_pair_math<FAM, CMODE, false, false>(c, low ? r2[a] : 1.0, qq, sg, e4, e_, fr_, s_erfcx);
-                fr_ = low ? fr_ : 0.0;
-                f[3 * a] += fr_ * dx[a];
-                f[3 * a + 1] += fr_ * dy[a];
-                f[3 * a + 2] += fr_ * dz[a];
-                if (GFAM >= 0) {
-                    const bool glow = low && (r2[a] < gc.rc2);
-                    amm_pair_math<(GFAM >= 0 ? GFAM : FAM), 0, false, false>(gc, glow ? r2[a] : 1.0, qq, sg, e4, e_, fr_, s_erfcx);
-                    fr_ = glow ? fr_ : 0.0;        // (amm_pair_math carries the sign)
-                    g[3 * a] += fr_ * dx[a];
-                    g[3 * a + 1] += fr_ * dy[a];
-                    g[3 * a + 2] += fr_ * dz[a];
-                }
-            }
-        }
-    };
     while (__builtin_amdgcn_ballot_w64(k < nn) != 0ull) {
         const bool ok = k < nn;
-        const bool guest_trip = GFAM >= 0 && __builtin_amdgcn_ballot_w64(k < nfront) != 0ull;
         const unsigned bits = (unsigned)e >> 29;
         const int e2 = entry(k + 2 * lpa);           // the entry after next: its index is there when the next trip starts
         double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -646,8 +561,61 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
         }
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-            if (guest_trip) block(std::true_type{}, b, ok, bits, sx, sy, sz);
-            else block(std::false_type{}, b, ok, bits, sx, sy, sz);
+            const double xb = pj[b].x - sx, yb = pj[b].y - sy, zb = pj[b].z - sz, qb = pj[b].w;
+            double dx[3], dy[3], dz[3], r2[3], fr[3];
+            TabLookup th[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                dx[a] = pi[a].x - xb;
+                dy[a] = pi[a].y - yb;
+                dz[a] = pi[a].z - zb;
+                if (IMG == 2) {
+                    dx[a] = amm_min_image(dx[a], A.box.L[0], A.box.invL[0]);
+                    dy[a] = amm_min_image(dy[a], A.box.L[1], A.box.invL[1]);
+                    dz[a] = amm_min_image(dz[a], A.box.L[2], A.box.invL[2]);
+                }
+                r2[a] = dx[a] * dx[a] + dy[a] * dy[a] + dz[a] * dz[a];
+                th[a] = amm_tab_fetch(tabh, c.tab, r2[a]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) fr[a] = (pi[a].w * qb) * amm_tab_horner(th[a]);
+            // Lennard-Jones part: only where two sites can meet (wave-uniform); the other lanes add an exact zero (eps4 = 0)
+            if (i_sites != 0 && __builtin_amdgcn_ballot_w64(ok && ((bits >> b) & 1u)) != 0ull) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if ((i_sites >> a) & 1) {
+                        const double2 la = li[64 * a];
+                        const double sig = la.x + lj[b].x, eps4 = la.y * lj[b].y;
+                        const LJCommon L = amm_lj_common(r2[a], sig, eps4);
+                        fr[a] += amm_lj_force<FAM, CMODE>(c, L, sig, eps4);
+                    }
+            }
+            bool any_low = false;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const bool low = r2[a] < r2low;
+                const bool pass = ok && (r2[a] < c.rc2);
+                any_low = any_low || (pass && low);
+                const double fh = (pass && !low) ? fr[a] : 0.0;
+                f[3 * a] += fh * dx[a];
+                f[3 * a + 1] += fh * dy[a];
+                f[3 * a + 2] += fh * dz[a];
+            }
+            if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {       // closer than the table reaches: analytic (never in a liquid)
+                for (int a = 0; a < 3; ++a) {
+                    const bool low = ok && (r2[a] < c.rc2) && (r2[a] < r2low);
+                    const double2 lx = A.lj[3 * ((unsigned)e & 0x1fffffffu) + b];
+                    const double2 la = li[64 * a];
+                    double e_, fr_;
+                    // (pi.w and la.y carry the sign already: the math runs with sign 1)
+                    amm_pair_math<FAM, CMODE, false, false>(c, low ? r2[a] : 1.0, pi[a].w * qb, la.x + lx.x, la.y * lx.y, e_, fr_, s_erfcx);
+                    fr_ = low ? fr_ : 0.0;
+                    f[3 * a] += fr_ * dx[a];
+                    f[3 * a + 1] += fr_ * dy[a];
+                    f[3 * a + 2] += fr_ * dz[a];
+                }
+            }
             // this partner atom's record is dead: its registers take the next trip's (the image shift of THIS trip is in sx, sy, sz)
             pj[b] = load_pos(en, b);
             lj[b] = load_lj(en, b);
@@ -661,23 +629,17 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
 #ifndef AMM_CBS_SINGLE
 #define AMM_CBS_SINGLE 512
 #endif
-#ifndef AMM_CBS_DUAL
-#define AMM_CBS_DUAL 512
-#endif
 #ifndef AMM_CTAB_WAVES_PER_EU
 #define AMM_CTAB_WAVES_PER_EU 1
 #endif
-template <int FAM, int CMODE, int GFAM, int BS>
+template <int FAM, int CMODE, int BS>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_CTAB_WAVES_PER_EU)))
-k_cpair_tab(CPairArgs A, PairConsts c, PairConsts gc) {
+k_cpair_tab(CPairArgs A, PairConsts c) {
     extern __shared__ __align__(16) char s_lds[];
     for (int o = threadIdx.x * 16; o < A.host_bytes; o += BS * 16)
         *reinterpret_cast<double2 *>(s_lds + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.host_tab) + o);
-    const char *tabh = s_lds, *tabg = s_lds + A.host_bytes;
-    if (GFAM >= 0)
-        for (int o = threadIdx.x * 16; o < A.guest_bytes; o += BS * 16)
-            *reinterpret_cast<double2 *>(s_lds + A.host_bytes + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.guest_tab) + o);
-    double *s_erfcx = reinterpret_cast<double *>(s_lds + A.host_bytes + (GFAM >= 0 ? A.guest_bytes : 0));
+    const char *tabh = s_lds;
+    double *s_erfcx = reinterpret_cast<double *>(s_lds + A.host_bytes);
     for (int k = threadIdx.x; k < AMM_ERFCX_NI * AMM_ERFCX_NC; k += BS) s_erfcx[k] = amm_erfcx_table_dev_c[k];
     // Lennard-Jones parameters of the rows' atoms: [wave][atom][lane] (read by the rare site-site pairs only)
     double2 *s_li = reinterpret_cast<double2 *>(s_erfcx + AMM_ERFCX_NI * AMM_ERFCX_NC) + (threadIdx.x >> 6) * 192;
@@ -688,6 +650,9 @@ k_cpair_tab(CPairArgs A, PairConsts c, PairConsts gc) {
     const int lpa = 1 << A.lpa_shift;
     const int sub = lane & (lpa - 1);
     const int rpw = 64 >> A.lpa_shift;
+    const double sign = c.sign;
+    PairConsts c1 = c;
+    c1.sign = 1.0;          // the sign travels with the row atoms' charges and epsilons (every family is linear in both)
     // one contiguous eighth of the tasks per XCD (blockIdx & 7): consecutive cell-sorted rows = one slab of the box per L2
     const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
     const int per = (A.ntask + 7) >> 3;
@@ -702,8 +667,9 @@ k_cpair_tab(CPairArgs A, PairConsts c, PairConsts gc) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             pi[t] = A.posq[3 * cs + t];
-            pi[t].w *= c.Kc;
-            const double2 l = A.lj[3 * cs + t];
+            pi[t].w *= c.Kc * sign;
+            double2 l = A.lj[3 * cs + t];
+            l.y *= sign;
             s_li[64 * t + lane] = l;
             if (__builtin_amdgcn_ballot_w64(valid && l.y != 0.0) != 0ull) i_sites |= 1 << t;
         }
@@ -717,47 +683,28 @@ k_cpair_tab(CPairArgs A, PairConsts c, PairConsts gc) {
         const bool edge = valid && !(pi[0].x >= A.margin && pi[0].x <= A.box.L[0] - A.margin && pi[0].y >= A.margin &&
                                      pi[0].y <= A.box.L[1] - A.margin && pi[0].z >= A.margin && pi[0].z <= A.box.L[2] - A.margin);
         const bool interior = __builtin_amdgcn_ballot_w64(edge) == 0ull;
-        double f[9], g[9];
+        double f[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) f[k] = g[k] = 0.0;
-        if (A.per_pair_image) cwalk_row<FAM, CMODE, GFAM, 2>(A, c, gc, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, g);
-        else if (interior) cwalk_row<FAM, CMODE, GFAM, 0>(A, c, gc, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, g);
-        else cwalk_row<FAM, CMODE, GFAM, 1>(A, c, gc, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, g);
+        for (int k = 0; k < 9; ++k) f[k] = 0.0;
+        if (A.per_pair_image) cwalk_row<FAM, CMODE, 2>(A, c1, tabh, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f);
+        else if (interior) cwalk_row<FAM, CMODE, 0>(A, c1, tabh, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f);
+        else cwalk_row<FAM, CMODE, 1>(A, c1, tabh, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f);
         for (int off = lpa >> 1; off > 0; off >>= 1) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                f[k] += __shfl_xor(f[k], off);
-                if (GFAM >= 0) g[k] += __shfl_xor(g[k], off);
-            }
+            for (int k = 0; k < 9; ++k) f[k] += __shfl_xor(f[k], off);
         }
         if (valid && sub == 0) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int i = A.sorted_out ? 3 * a + t : A.aperm[3 * cs + t];
-                double fx = f[3 * t], fy = f[3 * t + 1], fz = f[3 * t + 2];
-                if (GFAM >= 0) {
-                    if (A.gsame) {
-                        fx += g[3 * t];
-                        fy += g[3 * t + 1];
-                        fz += g[3 * t + 2];
-                    } else if (A.gaccumulate) {
-                        A.gforce[3 * i] += g[3 * t];
-                        A.gforce[3 * i + 1] += g[3 * t + 1];
-                        A.gforce[3 * i + 2] += g[3 * t + 2];
-                    } else {
-                        A.gforce[3 * i] = g[3 * t];
-                        A.gforce[3 * i + 1] = g[3 * t + 1];
-                        A.gforce[3 * i + 2] = g[3 * t + 2];
-                    }
-                }
                 if (A.accumulate) {
-                    A.force[3 * i] += fx;
-                    A.force[3 * i + 1] += fy;
-                    A.force[3 * i + 2] += fz;
+                    A.force[3 * i] += f[3 * t];
+                    A.force[3 * i + 1] += f[3 * t + 1];
+                    A.force[3 * i + 2] += f[3 * t + 2];
                 } else {
-                    A.force[3 * i] = fx;
-                    A.force[3 * i + 1] = fy;
-                    A.force[3 * i + 2] = fz;
+                    A.force[3 * i] = f[3 * t];
+                    A.force[3 * i + 1] = f[3 * t + 1];
+                    A.force[3 * i + 2] = f[3 * t + 2];
                 }
             }
         }
@@ -770,15 +717,15 @@ struct CLaunchCfg {
 };
 static int g_num_cu_c[64] = {0};
 
-template <int FAM, int CMODE, int GFAM>
-static int launch_cpair_i(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &gc) {
-    // 2 wavefronts per SIMD (187 / 256 registers with the look-ups of three pairs pinned ahead of their Horner chains): one block
+template <int FAM, int CMODE>
+static int launch_cpair_i(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c) {
+    // 2 wavefronts per SIMD (187 registers with the look-ups of three pairs pinned ahead of their Horner chains): one block
     // of 512; 8 rows per wavefront then deal 2 tasks to every wavefront at 98 304 atoms (768 threads: 1.33 -- a third idle)
-    constexpr int BS = GFAM >= 0 ? AMM_CBS_DUAL : AMM_CBS_SINGLE;
+    constexpr int BS = AMM_CBS_SINGLE;
     static CLaunchCfg cfg[64];
     CLaunchCfg &k = cfg[ctx->device & 63];
-    const int lds = A.host_bytes + (GFAM >= 0 ? A.guest_bytes : 0) + AMM_ERFCX_NI * AMM_ERFCX_NC * 8 + (BS / 64) * 192 * 16;
-    auto kern = k_cpair_tab<FAM, CMODE, GFAM, BS>;
+    const int lds = A.host_bytes + AMM_ERFCX_NI * AMM_ERFCX_NC * 8 + (BS / 64) * 192 * 16;
+    auto kern = k_cpair_tab<FAM, CMODE, BS>;
     if (lds > k.lds_set) {
         AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         k.lds_set = lds;
@@ -798,19 +745,28 @@ static int launch_cpair_i(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c,
     constexpr int WPB = BS / 64;
     long nblk = std::min((long)ncu * k.bpc, ((long)A.ntask + WPB - 1) / WPB);
     nblk = std::max(8L, (nblk + 7) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, A, c, gc);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, A, c);
     return 0;
 }
 
-template <int FAM, int CMODE>
-static int launch_cpair(amm_ctx *ctx, int gfam, const CPairArgs &A, const PairConsts &c, const PairConsts &gc) {
-    switch (gfam) {
-    case -1: return launch_cpair_i<FAM, CMODE, -1>(ctx, A, c, gc);
-    case AMM_NEAR_NONE: return launch_cpair_i<FAM, CMODE, AMM_NEAR_NONE>(ctx, A, c, gc);
-    case AMM_NEAR_SHIFT: return launch_cpair_i<FAM, CMODE, AMM_NEAR_SHIFT>(ctx, A, c, gc);
-    case AMM_NEAR_FSWITCH: return launch_cpair_i<FAM, CMODE, AMM_NEAR_FSWITCH>(ctx, A, c, gc);
-    default: amm_set_error("dual evaluation: unsupported guest family"); return 1;
+static int launch_cpair(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c) {
+#ifdef AMM_CLUSTER_TUNE      // kernel tuning builds: the two instantiations of the bench only (compile time)
+    if (c.family == AMM_NEAR_FSWITCH) return launch_cpair_i<AMM_NEAR_FSWITCH, 0>(ctx, A, c);
+    return launch_cpair_i<AMM_DAMPED, 1>(ctx, A, c);
+#else
+    switch (c.family) {
+    case AMM_NEAR_NONE: return launch_cpair_i<AMM_NEAR_NONE, 0>(ctx, A, c);
+    case AMM_NEAR_SHIFT: return launch_cpair_i<AMM_NEAR_SHIFT, 0>(ctx, A, c);
+    case AMM_NEAR_FSWITCH: return launch_cpair_i<AMM_NEAR_FSWITCH, 0>(ctx, A, c);
+    case AMM_DAMPED:
+        if (c.degree == 1) return launch_cpair_i<AMM_DAMPED, 1>(ctx, A, c);
+        return launch_cpair_i<AMM_DAMPED, 0>(ctx, A, c);
+    default:
+        if (c.cmode == 1) return launch_cpair_i<AMM_NONBONDED, 1>(ctx, A, c);
+        if (c.cmode == 2) return launch_cpair_i<AMM_NONBONDED, 2>(ctx, A, c);
+        return launch_cpair_i<AMM_NONBONDED, 0>(ctx, A, c);
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host orchestration
@@ -1055,16 +1011,11 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         A.posq = pf->d_posq_s;
         A.lj = pf->d_lj_s;
         A.force = out;
-        A.gforce = gout;
         A.accumulate = accumulate;
-        A.gaccumulate = g_accumulate;
-        A.gsame = (guest && g_force == d_force && !exchange) ? 1 : 0;
         A.sorted_out = exchange ? 1 : 0;
         A.box = ctx->box;
         A.host_tab = pf->d_tab;
         A.host_bytes = pf->pc.tab.nint * AMM_TAB_STRIDE;
-        A.guest_tab = guest ? guest->d_tab : nullptr;
-        A.guest_bytes = guest ? guest->pc.tab.nint * AMM_TAB_STRIDE : 0;
         A.margin = cl->rlist_build + cl->skin + 2.0 * cl->rext + 1e-6;
         const int rpw = 64 >> A.lpa_shift;
         A.ntask = (nrows + rpw - 1) / rpw;
@@ -1082,29 +1033,22 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             e1 = pf->ev[pf->ev_used++];
             AMM_HIP(hipEventRecord(e0, st));
         }
-        const int gfam = guest ? guest->desc.family : -1;
-        PairConsts gpc = guest ? guest->pc : pf->pc;
-        if (guest && (guest->desc.flags & AMM_GUARD_RC0)) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);      // step(rc0 - r)
-        int rc_ = 0;
-#ifdef AMM_CLUSTER_TUNE      // kernel tuning builds: the two instantiations of the bench only (compile time)
-        if (pf->desc.family == AMM_NEAR_FSWITCH) rc_ = launch_cpair_i<AMM_NEAR_FSWITCH, 0, -1>(ctx, A, pf->pc, gpc);
-        else if (gfam < 0) rc_ = launch_cpair_i<AMM_DAMPED, 1, -1>(ctx, A, pf->pc, gpc);
-        else rc_ = launch_cpair_i<AMM_DAMPED, 1, AMM_NEAR_FSWITCH>(ctx, A, pf->pc, gpc);
-#else
-        switch (pf->desc.family) {
-        case AMM_NEAR_NONE: rc_ = launch_cpair<AMM_NEAR_NONE, 0>(ctx, gfam, A, pf->pc, gpc); break;
-        case AMM_NEAR_SHIFT: rc_ = launch_cpair<AMM_NEAR_SHIFT, 0>(ctx, gfam, A, pf->pc, gpc); break;
-        case AMM_NEAR_FSWITCH: rc_ = launch_cpair<AMM_NEAR_FSWITCH, 0>(ctx, gfam, A, pf->pc, gpc); break;
-        case AMM_DAMPED:
-            if (pf->pc.degree == 1) rc_ = launch_cpair<AMM_DAMPED, 1>(ctx, gfam, A, pf->pc, gpc);
-            else rc_ = launch_cpair<AMM_DAMPED, 0>(ctx, gfam, A, pf->pc, gpc);
-            break;
-        default:
-            if (pf->pc.cmode == 1) rc_ = launch_cpair<AMM_NONBONDED, 1>(ctx, gfam, A, pf->pc, gpc);
-            else if (pf->pc.cmode == 2) rc_ = launch_cpair<AMM_NONBONDED, 2>(ctx, gfam, A, pf->pc, gpc);
-            else rc_ = launch_cpair<AMM_NONBONDED, 0>(ctx, gfam, A, pf->pc, gpc);
+        int rc_ = launch_cpair(ctx, A, pf->pc);
+        if (!rc_ && guest) {
+            // the guest force of the shared list (same particles, bitwise equal parameters: the host's sorted copies serve): a
+            // second launch over the FRONT parts of the same rows, into its own buffer -- or, for the discount of
+            // FarNonbondedForce, added to the host's (sign -1 and the step(rc0 - r) guard travel in its constants)
+            CPairArgs G = A;
+            G.nnb = cl->d_nnb_near;
+            G.nnb_total = nullptr;
+            G.force = gout;
+            G.accumulate = (g_force == d_force && !exchange) ? 1 : g_accumulate;
+            G.host_tab = guest->d_tab;
+            G.host_bytes = guest->pc.tab.nint * AMM_TAB_STRIDE;
+            PairConsts gpc = guest->pc;
+            if (guest->desc.flags & AMM_GUARD_RC0) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);      // step(rc0 - r)
+            rc_ = launch_cpair(ctx, G, gpc);
         }
-#endif
         if (rc_) return 1;
         if (timed) AMM_HIP(hipEventRecord(e1, st));
         AMM_HIP(hipGetLastError());

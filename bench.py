@@ -38,7 +38,7 @@ BYTES_PER_ATOM_DUAL = 96       # dual pass: the same read set, two force arrays 
 FLOP_PER_PAIR_NEAR = 60        # force-switch near, force only
 FLOP_PER_PAIR_FAR = 80         # DampedSmoothedForce (erfc + exp), force only
 FP64_SUSTAINED_TF = 60.7       # measured: v_fma_f64, 8 wavefronts per SIMD, 2.16 ns per wave-instruction per SIMD (DVFS clock)
-TRAFFIC_FILE = 'r02_traffic.json'
+TRAFFIC_FILE = 'r03_traffic.json'
 KB = 0.0083144626181532
 
 
@@ -115,23 +115,61 @@ def relax(simulation, torch, target=300.0, max_steps=1500, block=10, log=None):
     return done
 
 
-def cpu_baseline(nside, loops, dt_fs, sample_steps=10, state=None):
-    """The same system and step program on this host's cores: the CPU port of oracle/ (plain C, OpenMP, fp64) in its baseline
-    mode -- Verlet neighbour lists with a 0.1 nm buffer rebuilt on displacement, one force cache per group -- not the
-    27-cell walk the parity tests use as checker.  OpenMM is not installable here: this is a port, and labelled so.
-    `state` = (positions, velocities) at the end of the GPU run: the sample then continues the relaxed liquid the GPU was timed
-    on (and rebuilds its lists as often), not the lattice start."""
+def cpu_baseline(nside, loops, dt_fs, sample_steps=40, state=None):
+    """The same system and step program on this host's cores: oracle/cpu_port.c -- the whole RESPA step loop in C with OpenMP over
+    rows / molecules / atoms, one cell-sorted Verlet list (0.1 nm buffer, rebuilt on displacement) shared by the near and the
+    outer force, owner-computed full rows, one force cache per group (the outer force and the last near force of a step in one
+    traversal), first-touch allocation; the same arithmetic as oracle/amm_oracle.c (tests/test_oracle_golden.py).  OpenMM is not
+    installable here: this is a port, and labelled so.  `state` = (positions, velocities) at the end of the GPU run: the sample
+    then continues the relaxed liquid the GPU was timed on (and rebuilds its lists as often), not the lattice start."""
     from atomsmm_amd.testing import tip3p_box
-    from oracle import oracle as O
-    from oracle import respa_cpu
+    from oracle import cpu_port
     case = tip3p_box(nside)
     if state is not None:
         case = dict(case, positions=state[0], velocities=state[1])
-    sec, sim = respa_cpu.time_respa(case, warmup=1, steps=sample_steps, loops=tuple(loops), dt=dt_fs * 1e-3, verlet_skin=0.1)
-    return {'value': round(dt_fs * 1e-6 * 86400.0 / sec, 4), 'unit': 'ns/day', 'cores': int(O.num_threads()), 'kind': 'port',
-            'sample': '%d outer RESPA steps (after 1 warm-up) of the same %d-atom workload continued from the state the GPU run ended in, %.2f s/step, %d list builds; CPU port with '
-                      'Verlet lists + OpenMP (oracle/amm_oracle.c: ammo_nlist_build / ammo_pair_eval_nlist), not OpenMM'
-                      % (sample_steps, len(case['positions']), sec, sim.lists[2].builds)}
+    sec, st = cpu_port.time_port(case, warmup=3, steps=sample_steps, loops=tuple(loops), dt=dt_fs * 1e-3, skin=0.1)
+    return {'value': round(dt_fs * 1e-6 * 86400.0 / sec, 4), 'unit': 'ns/day', 'cores': cpu_port.threads(), 'kind': 'port',
+            'sample': '%d outer RESPA steps (after 3 warm-up) of the same %d-atom workload continued from the state the GPU run ended in, '
+                      '%.1f ms/step, %d list builds; CPU port in C + OpenMP (oracle/cpu_port.c: step loop, shared cell-sorted Verlet list, '
+                      'owner-computed rows), not OpenMM' % (sample_steps, len(case['positions']), sec * 1e3, st['builds'])}
+
+
+def launch_ranks(n):
+    """Self-launch: N child processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what
+    torch.distributed.run would do), rank 0's stdout relayed.  The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in out.decode().splitlines():        # the JSON line to stdout, library chatter (if any) to stderr
+        print(line, file=sys.stdout if line.lstrip().startswith('{') else sys.stderr, flush=True)
+    if any(codes):
+        raise SystemExit('bench.py: rank exit codes %s' % codes)
+
+
+def dry_run():
+    """AMM_BENCH_DRYRUN=1 (CPU tests of the launcher): the ranks rendezvous over gloo, all-reduce their rank numbers and rank 0
+    prints a line -- everything bench.py does around the GPU work, none of the GPU work."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({'dryrun': True, 'n_gpus': world, 'rank_sum': t.item()}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -149,7 +187,18 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-relax', action='store_true')
     ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--pme-steps', type=int, default=100,
+                    help='also time this many steps with the PME NonbondedForce as the outer force (what RESPASystem leaves in group 2 for a '
+                         'PME source, systems.py:74-75) and report them under detail.pme_outer; 0 skips it')
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), BEFORE anything touches
+    # the GPU -- this process only waits and relays rank 0's JSON line
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args.gpus)
+
+    if os.environ.get('AMM_BENCH_DRYRUN') == '1':
+        return dry_run()
 
     import torch
     import torch.distributed as dist
@@ -229,6 +278,30 @@ def main():
     pairs_near = eng.ctx.pair_count_within(near_id, eng.x, 0.7) / 2
     pairs_far = eng.ctx.pair_count_within(far_id, eng.x, 1.0) / 2
 
+    # the same box with the PME NonbondedForce as the outer force (what RESPASystem leaves in group 2 for a PME source,
+    # systems.py:74-75; SURVEY 8d C3 ii): continued from the state the headline run ended in, its own short timed region
+    pme_outer = None
+    if args.pme_steps > 0 and args.outer == 'damped' and args.config == 'c3':
+        from atomsmm_amd import unit
+        sim2, _ = build_simulation(args.nside, loops, dt_fs, 'pme', args.skin, args.outer_skin)
+        sim2.context.setPositions(eng.x.cpu().numpy() * unit.nanometers)
+        sim2.context.setVelocities(eng.v.cpu().numpy())
+        sim2.step(max(10, args.warmup // 2))
+        fence()
+        t1 = time.perf_counter()
+        sim2.step(args.pme_steps)
+        fence()
+        el2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el2], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = t.item()
+        pme_outer = {'ms_per_step': round(el2 / args.pme_steps * 1e3, 4), 'ns_day': round(dt_fs * 1e-6 * 86400.0 / (el2 / args.pme_steps), 2),
+                     'steps': args.pme_steps,
+                     'workload': 'the same box and RESPA split, outer force = PME NonbondedForce (rc 1.0, switch 0.9, Ewald tolerance 5e-4: '
+                                 'direct space + reciprocal space on an 80^3 mesh), continued from the final state of the headline run'}
+        del sim2
+
     if rank == 0:
         from atomsmm_amd import backend
         t_near = ms_near / max(n_near, 1) * 1e-3          # s per launch (this rank's slice)
@@ -248,7 +321,9 @@ def main():
             except Exception:
                 pass
 
-        def roofline(kernel, seconds, launches, alg_bytes, flops, tag):
+        kname = 'k_cpair_tab' if near_stats.get('list_kind') else 'k_pair_tab'
+
+        def roofline(kernel, seconds, launches, alg_bytes, flops, tag, npairs):
             achieved = alg_bytes / max(seconds, 1e-12) / 1e9
             tf = flops / max(seconds, 1e-12) / 1e12
             entry = {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -260,6 +335,14 @@ def main():
                              '(a bare v_fma_f64 loop sustains %.1f TF on this chip: scripts/micro/fp64_rate.hip)'
                              % (FP64_VECTOR_PEAK_TF, FP64_SUSTAINED_TF)}
             if entry['traffic'] is not None:
+                t_ = traffic.get(tag, {})
+                # FETCH_SIZE halves WIDE streaming reads on gfx950 (MI355X_MICROARCH.md); this kernel's reads are 32-byte gathers,
+                # for which the correction is uncalibrated: the truth lies between the raw and the doubled figure
+                entry['traffic_raw'] = int((t_.get('fetch_size_kb_avg', 0) + t_.get('write_size_kb_avg', 0)) * 1024)
+                entry['traffic_corrected'] = entry['traffic']
+                if t_.get('valu_insts_per_launch') and npairs:
+                    # lane-instructions (64 x SQ_INSTS_VALU) per in-cutoff pair counted once (the pass evaluates both directions)
+                    entry['valu_insts_per_pair'] = round(64.0 * t_['valu_insts_per_launch'] / npairs, 1)
                 entry['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, kernels %s)' % (
                     TRAFFIC_FILE, traffic.get('kernel_revision'))
             return entry
@@ -281,13 +364,13 @@ def main():
                                                                      if getattr(eng, '_native_comm', False) else 'collectives through torch.distributed')) if world > 1 else 'single GPU',
                        'temperature_K_end': round(T_end, 1)},
             # the kernel the metric names: the stand-alone near-force traversal (group 1, force only)
-            'roofline': roofline('k_pair_tab<NEAR_FSWITCH> (group-1 near force, force only)', t_near, n_near,
-                                 BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_NEAR * pairs_near, 'near'),
+            'roofline': roofline('%s<NEAR_FSWITCH> (group-1 near force, force only)' % kname, t_near, n_near,
+                                 BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_NEAR * pairs_near, 'near', pairs_near),
             # the dominant kernel of the step: outer force + near force of the shared list in one traversal (one read set,
             # two force arrays: 96 B per atom)
-            'roofline_dominant': roofline('k_pair_tab<%s, guest NEAR_FSWITCH> (outer + near force in one pass)'
-                                          % ('DAMPED' if args.outer == 'damped' else 'NONBONDED/Ewald'), t_dual, n_dual,
-                                          BYTES_PER_ATOM_DUAL * atoms_per_launch, flop_dual, 'dual'),
+            'roofline_dominant': roofline('%s<%s, guest NEAR_FSWITCH> (outer + near force in one pass)'
+                                          % (kname, 'DAMPED' if args.outer == 'damped' else 'NONBONDED/Ewald'), t_dual, n_dual,
+                                          BYTES_PER_ATOM_DUAL * atoms_per_launch, flop_dual, 'dual', pairs_far),
             'detail': {'near_kernel_us': round(t_near * 1e6, 2), 'near_launches': n_near,
                        'dual_kernel_us': round(t_dual * 1e6, 2), 'dual_launches': n_dual,
                        'near_list_prunes_in_timed_region': st1[near_id]['n_builds'] - st0[near_id]['n_builds'],
@@ -297,7 +380,8 @@ def main():
                        'near_lanes_per_atom': near_stats['lanes_per_atom'], 'near_rlist_nm': near_stats['rlist'],
                        'near_list_pairs': near_stats['n_list_pairs'], 'far_list_pairs': st1[far_id]['n_list_pairs'],
                        'pairs_within_0.7nm_counted': int(pairs_near), 'pairs_within_1.0nm_counted': int(pairs_far),
-                       'kernel_revision': backend.kernel_revision()},
+                       'kernel_revision': backend.kernel_revision(), 'rows': 'one per molecule' if near_stats.get('list_kind') else 'one per atom',
+                       'pme_outer': pme_outer},
         }
         if world == 1 and not args.no_cpu_baseline and args.outer == 'damped':
             try:

@@ -255,3 +255,22 @@ def test_unseeded_velocities_and_failed_checks_are_collective():
     assert out[0]['same'] and out[1]['same'] and out[0]['nonzero']
     assert 'rank-local' in out[1]['raised']                       # the rank that detected it
     assert 'another rank' in out[0]['raised']                     # its peer raises too instead of hanging in the next collective
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without torchrun (how the driver starts the 1-GPU run, and what a user types): the script must
+    start N ranks itself, before anything touches a GPU, and relay rank 0's single JSON line.  AMM_BENCH_DRYRUN=1 replaces the GPU
+    work by a gloo all-reduce of the rank numbers (there is no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AMM_BENCH_DRYRUN='1')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3', '--steps', '1', '--warmup', '0'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {'dryrun': True, 'n_gpus': 3, 'rank_sum': 6.0}

@@ -304,3 +304,22 @@ def test_constraint_oracle_routes_agree():
         for i, j in loc:
             assert abs((w[i] - w[j]) @ (yt[i] - yt[j])) < 1e-14
         assert np.abs((m[:, None] * (w - v)).sum(0)).max() < 1e-12
+
+
+def test_cpu_port_equals_the_oracle_driven_program():
+    """oracle/cpu_port.c (bench.py's cpu_baseline, kind "port") runs the RESPA step program entirely in C; it must give what the
+    oracle-driven program gives (oracle/respa_cpu.py over oracle/amm_oracle.c): same evaluation counts per group, positions and
+    velocities to round-off after two steps -- on the small-box (all-pairs list) and on the cell-grid list build."""
+    from atomsmm_amd.testing import tip3p_box
+    from oracle import cpu_port, respa_cpu
+    for nside, steps in ((8, 2), (20, 1)):
+        c = tip3p_box(nside)
+        a = respa_cpu.RespaCPU(c, dt=0.002, verlet_skin=0.1 if nside == 20 else None)
+        a.step(steps)
+        b = cpu_port.RespaPort(c, dt=0.002)
+        b.step(steps)
+        st = b.state()
+        assert st['evals'] == (a.evals[0], a.evals[1], a.evals[2])
+        assert np.abs(st['x'] - a.x).max() < 1e-13
+        assert np.abs(st['v'] - a.v).max() < 1e-10
+        b.close()
