@@ -1,6 +1,7 @@
 """CPU tests of the host side: the AtomsMM-shaped API (names, strings, step programs, errors) and the
 engine's translation / program unrolling, with a call recorder in place of the HIP library."""
 import copy
+import os
 import re
 
 import numpy as np
@@ -773,3 +774,59 @@ def test_simulation_serves_reporters(spcfw, recorder):
     assert float(lines[-1].split(',')[1]) == pytest.approx(0.016)
     density = float(lines[-1].split(',')[5])
     assert 0.9 < density < 1.1               # q-SPC/Fw water
+
+
+# ------------------------------------------------------------------------------------ reference-generated text fixtures
+# tests/golden/programs.json is written by scripts/capture_reference_text.py (build container only): the reference's own Python
+# layer run under a recording stand-in for simtk.  Every constructor expression is evaluated again here, against atomsmm_amd.
+def _captured():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'programs.json')) as fh:
+        return json.load(fh)
+
+
+def _numbers_to_12_digits(text):
+    import re
+
+    def norm(m):
+        return repr(float('%.12g' % float(m.group(0))))
+    return re.sub(r'(?<![A-Za-z_0-9])\d+\.?\d*(?:[eE][-+]?\d+)?', norm, text)
+
+
+@pytest.mark.parametrize('name', sorted(_captured()['programs']))
+def test_step_program_equals_the_reference_capture(name):
+    """Per-DOF variables, global variables (names, order and initial values) and every line of the emitted step program of each
+    propagator / integrator class the repository restates -- composition classes, RESPA and its schemes, velocity Verlet, the
+    thermostat propagators, Langevin_R / NHL_R / SIN_R, AFED -- against what the reference emits for the same constructor call."""
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import unit
+    g = _captured()['programs'][name]
+    integ = eval(g['ctor'], {'atomsmm': atomsmm, 'unit': unit})
+    assert [integ.getPerDofVariableName(i) for i in range(integ.getNumPerDofVariables())] == g['per_dof']
+    names = [integ.getGlobalVariableName(i) for i in range(integ.getNumGlobalVariables())]
+    assert names == g['globals']
+    for i, gname in enumerate(names):
+        assert integ.getGlobalVariable(i) == pytest.approx(g['global_values'][gname], rel=1e-9, abs=1e-300), gname
+    assert integ.pretty_steps() == g['steps']
+
+
+@pytest.mark.parametrize('name', sorted(_captured()['forces']))
+def test_energy_string_equals_the_reference_capture(name):
+    """forces.py:400-724: the energy expression after importFrom(nonbonded), literals compared to 12 digits (the capture's unit
+    stand-in and this package's unit module may differ in the last digit of a converted number)."""
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import openmm, unit
+    g = _captured()['forces'][name]
+    nb = openmm.NonbondedForce()
+    nb.setNonbondedMethod(nb.CutoffPeriodic)
+    nb.addParticle(0.5, 0.3, 0.7)
+    nb.addParticle(-0.5, 0.25, 0.2)
+    nb.addParticle(0.1, 0.2, 0.1)
+    nb.addException(0, 1, -0.1, 0.27, 0.3)
+    force = eval(g['ctor'], {'atomsmm': atomsmm, 'unit': unit})
+    force.importFrom(nb)
+    assert _numbers_to_12_digits(force.getEnergyFunction()) == _numbers_to_12_digits(g['energy'])
+    mine = {force.getGlobalParameterName(i): force.getGlobalParameterDefaultValue(i) for i in range(force.getNumGlobalParameters())}
+    assert set(mine) == set(g['globals'])
+    for key, value in g['globals'].items():
+        assert mine[key] == pytest.approx(value, rel=1e-12)
