@@ -1034,6 +1034,7 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             AMM_HIP(hipEventRecord(e0, st));
         }
         int rc_ = launch_cpair(ctx, A, pf->pc);
+        if (timed) AMM_HIP(hipEventRecord(e1, st));          // (the guest's launch below is timed under the guest's own id)
         if (!rc_ && guest) {
             // the guest force of the shared list (same particles, bitwise equal parameters: the host's sorted copies serve): a
             // second launch over the FRONT parts of the same rows, into its own buffer -- or, for the discount of
@@ -1047,10 +1048,23 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             G.host_bytes = guest->pc.tab.nint * AMM_TAB_STRIDE;
             PairConsts gpc = guest->pc;
             if (guest->desc.flags & AMM_GUARD_RC0) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);      // step(rc0 - r)
+            const bool gtimed = ctx->profile && (ctx->profile_only < 0 || ctx->profile_only == guest->id);
+            hipEvent_t g0 = nullptr, g1 = nullptr;
+            if (gtimed) {
+                if (guest->ev_used + 2 > guest->ev.size())
+                    for (int k = 0; k < 64; ++k) {
+                        hipEvent_t ev;
+                        AMM_HIP(hipEventCreate(&ev));
+                        guest->ev.push_back(ev);
+                    }
+                g0 = guest->ev[guest->ev_used++];
+                g1 = guest->ev[guest->ev_used++];
+                AMM_HIP(hipEventRecord(g0, st));
+            }
             rc_ = launch_cpair(ctx, G, gpc);
+            if (gtimed) AMM_HIP(hipEventRecord(g1, st));
         }
         if (rc_) return 1;
-        if (timed) AMM_HIP(hipEventRecord(e1, st));
         AMM_HIP(hipGetLastError());
         if (guest) guest->n_evals++;
     }

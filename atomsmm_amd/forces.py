@@ -454,17 +454,6 @@ class SoftcoreLennardJonesForce(_AtomsMM_CustomNonbondedForce):
                          **{parameter: 1.0})
 
 
-class SoftcoreForce(_AtomsMM_CustomNonbondedForce):
-    """Softened Lennard-Jones plus Coulomb scaled by `lambda_coul` (forces.py:761-792): the class and its energy text as the
-    reference states them; the HIP engine has no pair family for the combination (a Context of a System that holds it raises
-    InputError: expression not recognised) -- SolvationSystem expresses the same physics with the softcore force and charge offsets."""
-
-    def __init__(self, cutoff_distance, switch_distance=None):
-        super().__init__('4*lambda_vdw*epsilon*(1-x)/x^2 + Kc*lambda_coul*chargeprod/r;x = (r/sigma)^6 + 0.5*(1-lambda_vdw)',
-                         cutoff_distance, True, switch_distance,
-                         Kc=KC * unit.kilojoules_per_mole / unit.nanometer, lambda_vdw=1.0, lambda_coul=1.0)
-
-
 class NearForce(object):
     """Shared pieces of the near forces (forces.py:533-567)."""
 

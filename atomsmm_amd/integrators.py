@@ -23,17 +23,22 @@ _FUNCS = {'sqrt', 'exp', 'log', 'sin', 'cos', 'sec', 'csc', 'tan', 'cot', 'asin'
           'cosh', 'tanh', 'erf', 'erfc', 'min', 'max', 'abs', 'floor', 'ceil', 'step', 'delta', 'select', 'deriv'}
 
 
+def _is_force_symbol(name):
+    """`f` or `f<group>`: the per-DOF force symbols of a CustomIntegrator expression."""
+    return name == 'f' or (name[:1] == 'f' and name[1:].isdigit())
+
+
 class _AtomsMM_Integrator(openmm.CustomIntegrator):
     def __init__(self, stepSize):
         super().__init__(stepSize)
-        self.addGlobalVariable('mvv', 0.0)
-        self.addGlobalVariable('NDOF', 0.0)
+        # declaration order is contract (the captured programs list `mvv, NDOF` first and `ndof` as the first per-DOF variable)
+        for name in ('mvv', 'NDOF'):
+            self.addGlobalVariable(name, 0.0)
         self.addPerDofVariable('ndof', 0.0)
-        self._obsoleteKinetic = True
-        self._forceFinder = re.compile('^f[0-9]+$|^f$')
-        self._obsoleteContextState = True
-        self._random = np.random.RandomState()
-        self._uninitialized = True
+        # bookkeeping of the automatic insertions (integrators.py:106-147): is the stored sum(m v^2) older than v?  has this program
+        # already let the forces update the Context?  has step() run its one-time initialisation?
+        self._state = dict(mvv_stale=True, context_stale=True, first_step=True)
+        self._rng = np.random.RandomState()
 
     def __repr__(self):
         """Human-readable program, same layout as the reference's (integrators.py:38-86)."""
@@ -61,7 +66,7 @@ class _AtomsMM_Integrator(openmm.CustomIntegrator):
         return out
 
     def _normalVec(self):
-        return openmm.Vec3(self._random.normal(), self._random.normal(), self._random.normal())
+        return openmm.Vec3(self._rng.normal(), self._rng.normal(), self._rng.normal())
 
     def _required_variables(self, variable, expression):
         """Names an assignment `variable <- expression` reads (excluding names it defines itself)."""
@@ -80,17 +85,17 @@ class _AtomsMM_Integrator(openmm.CustomIntegrator):
         return sorted(used - defined)
 
     def _checkUpdate(self, requirements):
-        if self._obsoleteKinetic and 'mvv' in requirements:
+        if self._state['mvv_stale'] and 'mvv' in requirements:
             openmm.CustomIntegrator.addComputeSum(self, 'mvv', 'm*v*v')
-            self._obsoleteKinetic = False
-        if self._obsoleteContextState and any(self._forceFinder.match(s) for s in requirements):
+            self._state['mvv_stale'] = False
+        if self._state['context_stale'] and any(_is_force_symbol(s) for s in requirements):
             openmm.CustomIntegrator.addUpdateContextState(self)
-            self._obsoleteContextState = False
+            self._state['context_stale'] = False
 
     def addUpdateContextState(self):
-        if self._obsoleteContextState:
+        if self._state['context_stale']:
             openmm.CustomIntegrator.addUpdateContextState(self)
-            self._obsoleteContextState = False
+            self._state['context_stale'] = False
 
     def addComputeGlobal(self, variable, expression):
         if variable == 'mvv':
@@ -101,7 +106,7 @@ class _AtomsMM_Integrator(openmm.CustomIntegrator):
     def addComputePerDof(self, variable, expression):
         requirements = self._required_variables(variable, expression)
         self._checkUpdate(requirements)
-        forces = sorted(s for s in requirements if self._forceFinder.match(s))
+        forces = sorted(s for s in requirements if _is_force_symbol(s))
         if len(forces) > 1:
             # one force group per computation: stash all but the first in per-DOF buffers _f{k}_
             expression = re.sub(r'\bf([0-9]*)\b', '_f\\1_', expression)
@@ -114,22 +119,22 @@ class _AtomsMM_Integrator(openmm.CustomIntegrator):
             expression = re.sub(r'\b{}\b'.format(buffers[0]), forces[0], expression)
         index = openmm.CustomIntegrator.addComputePerDof(self, variable, expression)
         if variable == 'v':
-            self._obsoleteKinetic = True
+            self._state['mvv_stale'] = True
         return index
 
     def setRandomNumberSeed(self, seed):
-        self._random.seed(seed)
-        openmm.CustomIntegrator.setRandomNumberSeed(self, self._random.tomaxint() % 2 ** 31)
+        self._rng.seed(seed)
+        openmm.CustomIntegrator.setRandomNumberSeed(self, self._rng.tomaxint() % 2 ** 31)
 
     def step(self, steps):
-        if self._uninitialized:
+        if self._state['first_step']:
             if self._context is None:
                 raise openmm.OpenMMException('This Integrator is not bound to a context!')
             self._ndof = NDOF = 3 * self._context.getSystem().getNumParticles()
             self.setGlobalVariableByName('NDOF', NDOF)
             self._context._engine.fill_per_dof('ndof', float(NDOF))
             self.initialize()
-            self._uninitialized = False
+            self._state['first_step'] = False
         return openmm.CustomIntegrator.step(self, steps)
 
     def initialize(self):
@@ -231,15 +236,12 @@ class ExtendedSystemVariable(object):
         self._kTbym, self._v_eta, self._Q_eta, self._gamma = '_kTbym_' + name, '_v_eta_' + name, '_Q_eta_' + name, '_gamma_' + name
 
     def add_global_variables(self, integrator):
-        integrator.addGlobalVariable(self._v, 0.0)
-        integrator.addGlobalVariable(self._m, self._m_value)
-        if self._thermostat == 'Nose-Hoover':
-            integrator.addGlobalVariable(self._v_eta, 0.0)
-            integrator.addGlobalVariable(self._kT, self._kT_value)
-            integrator.addGlobalVariable(self._Q_eta, self._Q_eta_value)
-        elif self._thermostat == 'Langevin':
-            integrator.addGlobalVariable(self._kTbym, self._kT_value / self._m_value)
-            integrator.addGlobalVariable(self._gamma, self._gamma_value)
+        """Velocity and mass of the variable, then the bath's own globals -- in the reference's declaration order
+        (integrators.py:690-699: programs.json pins names and order)."""
+        bath = {'Nose-Hoover': [(self._v_eta, 0.0), (self._kT, self._kT_value), (self._Q_eta, self._Q_eta_value)],
+                'Langevin': [(self._kTbym, self._kT_value / self._m_value), (self._gamma, self._gamma_value)]}
+        for name, value in [(self._v, 0.0), (self._m, self._m_value)] + bath.get(self._thermostat, []):
+            integrator.addGlobalVariable(name, value)
 
     def _apply_boundary_conditions(self, integrator):
         above_lower = 'step({}-({}))'.format(self._x, self._lower_limit)
@@ -275,10 +277,10 @@ class ExtendedSystemVariable(object):
     def initialize(self, integrator):
         from .unit import md_value
         sigma_v = math.sqrt(md_value(self._kT_value) / md_value(self._m_value))
-        integrator.setGlobalVariableByName(self._v, sigma_v * integrator._random.normal())
+        integrator.setGlobalVariableByName(self._v, sigma_v * integrator._rng.normal())
         if self._thermostat == 'Nose-Hoover':
             sigma_v_eta = math.sqrt(md_value(self._kT_value) / md_value(self._Q_eta_value))
-            integrator.setGlobalVariableByName(self._v_eta, sigma_v_eta * integrator._random.normal())
+            integrator.setGlobalVariableByName(self._v_eta, sigma_v_eta * integrator._rng.normal())
 
 
 class AdiabaticDynamicsIntegrator(_AtomsMM_Integrator):

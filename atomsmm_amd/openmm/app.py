@@ -170,8 +170,11 @@ class Topology:
         return None if self._box is None else Quantity(list(self._box), _unit.nanometer)
 
     def setUnitCellDimensions(self, dimensions):
+        if dimensions is None:           # clears the cell
+            self._box = None
+            return
         d = md_value(dimensions)
-        self._box = None if dimensions is None else [Vec3(float(d[0]), 0, 0), Vec3(0, float(d[1]), 0), Vec3(0, 0, float(d[2]))]
+        self._box = [Vec3(float(d[0]), 0, 0), Vec3(0, float(d[1]), 0), Vec3(0, 0, float(d[2]))]
 
     def getUnitCellDimensions(self):
         return None if self._box is None else Quantity(Vec3(self._box[0][0], self._box[1][1], self._box[2][2]), _unit.nanometer)

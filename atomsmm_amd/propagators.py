@@ -556,16 +556,14 @@ class OrnsteinUhlenbeckPropagator(Propagator):
             (self.globalVariables if overall else self.perDofVariables)[velocity] = 0
 
     def addSteps(self, integrator, fraction=1.0, force='f'):
-        expression = 'z*{} + sqrt(kT*(1 - z*z)/mass)*gaussian'.format(self.velocity, self.mass)
+        # one assignment: the update, then its definitions (`force` only when a constant force acts during the step)
+        update = 'z*{} + sqrt(kT*(1 - z*z)/mass)*gaussian'.format(self.velocity)
+        definitions = ['mass = {}'.format(self.mass), 'z = exp(-({}*dt)*friction)'.format(fraction)]
         if self.force is not None:
-            expression += ' + force*(1 - z)/(mass*friction)'
-            expression += '; force = {}'.format(self.force)
-        expression += '; mass = {}'.format(self.mass)
-        expression += '; z = exp(-({}*dt)*friction)'.format(fraction)
-        if self.overall:
-            integrator.addComputeGlobal(self.velocity, expression)
-        else:
-            integrator.addComputePerDof(self.velocity, expression)
+            update += ' + force*(1 - z)/(mass*friction)'
+            definitions.insert(0, 'force = {}'.format(self.force))
+        add = integrator.addComputeGlobal if self.overall else integrator.addComputePerDof
+        add(self.velocity, '; '.join([update] + definitions))
 
 
 class MassiveIsokineticPropagator(Propagator):

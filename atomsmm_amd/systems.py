@@ -169,22 +169,21 @@ class SolvationSystem(openmm.System):
                 nonbonded.addException(i, j, q1 * q2, (sig1 + sig2) / 2, (eps1 * eps2).sqrt())
                 if softcore is not None:
                     softcore.addExclusion(i, j)
-        charges, lj_parameters = {}, {}
-        for index in sorted(solute_atoms):
-            charge, sigma, epsilon = nonbonded.getParticleParameters(index)
-            nonbonded.setParticleParameters(index, 0.0, 0.0, 0.0)
-            if md_value(charge) != 0.0:
-                charges[index] = charge
-            if md_value(epsilon) != 0.0:
-                lj_parameters[index] = (sigma, epsilon)
-        if charges:
-            nonbonded.addGlobalParameter('lambda_coul', 1.0)
-            for index, charge in charges.items():
-                nonbonded.addParticleParameterOffset('lambda_coul', index, charge, 0.0, 0.0)
-        if lj_parameters and not use_softcore:
-            nonbonded.addGlobalParameter('lambda_vdw', 1.0)
-            for index, (sigma, epsilon) in lj_parameters.items():
-                nonbonded.addParticleParameterOffset('lambda_vdw', index, 0.0, sigma, epsilon)
+        # the solute's own parameters become offsets scaled by lambda_coul / lambda_vdw (systems.py:289-312); the particle itself
+        # keeps (0, 0, 0).  Offsets are added charge-first, in atom order: the order OpenMM evaluates them in is contract.
+        scaled = {'lambda_coul': [], 'lambda_vdw': []}
+        for atom in sorted(solute_atoms):
+            q, sig, eps = nonbonded.getParticleParameters(atom)
+            nonbonded.setParticleParameters(atom, 0.0, 0.0, 0.0)
+            if md_value(q) != 0.0:
+                scaled['lambda_coul'].append((atom, q, 0.0, 0.0))
+            if md_value(eps) != 0.0 and not use_softcore:
+                scaled['lambda_vdw'].append((atom, 0.0, sig, eps))
+        for parameter in ('lambda_coul', 'lambda_vdw'):
+            if scaled[parameter]:
+                nonbonded.addGlobalParameter(parameter, 1.0)
+                for atom, q, sig, eps in scaled[parameter]:
+                    nonbonded.addParticleParameterOffset(parameter, atom, q, sig, eps)
 
 
 class AlchemicalSystem(openmm.System):
@@ -277,41 +276,50 @@ class ComputingSystem(_AtomsMM_System):
 
     def __init__(self, system):
         super().__init__(system, copyForces=False)
-        dispersionGroup, bondedGroup, coulombGroup = 0, 1, 2
-        self._dispersion, self._bonded, self._coulomb = 2 ** dispersionGroup, 2 ** bondedGroup, 2 ** coulombGroup
-        expression = '24*epsilon*(2*(sigma/r)^12-(sigma/r)^6)'
+        # force groups: 0 dispersion virial, 1 bond-stretching virial, 2 Coulomb (whose virial is its energy)
+        group = dict(dispersion=0, bonded=1, coulomb=2)
+        self._dispersion, self._bonded, self._coulomb = (1 << group[k] for k in ('dispersion', 'bonded', 'coulomb'))
+        lj_virial = '24*epsilon*(2*(sigma/r)^12-(sigma/r)^6)'
+
+        def lj_virial_forces(source):
+            """W_LJ of the pair interactions and of the exceptions, as energies of two custom forces (systems.py:894-905)."""
+            pairs = forces._AtomsMM_CustomNonbondedForce(lj_virial).importFrom(source)
+            bonds = forces._AtomsMM_CustomBondForce(lj_virial).importFrom(source, extract=False)
+            return [pairs] + ([bonds] if bonds.getNumBonds() > 0 else [])
+
+        def coulomb_only(source):
+            """The source force with every Lennard-Jones interaction switched off (sigma 1, epsilon 0)."""
+            for k in range(source.getNumParticles()):
+                source.setParticleParameters(k, source.getParticleParameters(k)[0], 1.0, 0.0)
+            for k in range(source.getNumExceptions()):
+                a, b, qq = source.getExceptionParameters(k)[:3]
+                source.setExceptionParameters(k, a, b, qq, 1.0, 0.0)
+            source.setReciprocalSpaceForceGroup(group['coulomb'])
+            return source
+
+        def stretching_virial(harmonic):
+            """-r dE/dr = -K r (r - r0) of every harmonic bond (systems.py:914)."""
+            out = openmm.CustomBondForce('-K*r*(r-r0)')
+            for name in ('r0', 'K'):
+                out.addPerBondParameter(name)
+            for k in range(harmonic.getNumBonds()):
+                a, b, r0, K = harmonic.getBondParameters(k)
+                out.addBond(a, b, [r0, K])
+            return out
+
         for force in system.getForces():
             if isinstance(force, openmm.NonbondedForce) and force.getNumParticles() > 0:
-                nonbonded = copy.deepcopy(force)
-                virial = forces._AtomsMM_CustomNonbondedForce(expression)
-                virial.importFrom(nonbonded)
-                virial.setForceGroup(dispersionGroup)
-                self.addForce(virial)
-                exceptions = forces._AtomsMM_CustomBondForce(expression)
-                exceptions.importFrom(nonbonded, extract=False)
-                if exceptions.getNumBonds() > 0:
-                    exceptions.setForceGroup(dispersionGroup)
-                    self.addForce(exceptions)
-                for index in range(nonbonded.getNumParticles()):
-                    charge = nonbonded.getParticleParameters(index)[0]
-                    nonbonded.setParticleParameters(index, charge, 1.0, 0.0)
-                for index in range(nonbonded.getNumExceptions()):
-                    i, j, chargeprod = nonbonded.getExceptionParameters(index)[:3]
-                    nonbonded.setExceptionParameters(index, i, j, chargeprod, 1.0, 0.0)
-                nonbonded.setForceGroup(coulombGroup)
-                nonbonded.setReciprocalSpaceForceGroup(coulombGroup)
-                self.addForce(nonbonded)
+                source = copy.deepcopy(force)
+                members = [(f, 'dispersion') for f in lj_virial_forces(source)] + [(coulomb_only(source), 'coulomb')]
             elif isinstance(force, openmm.HarmonicBondForce) and force.getNumBonds() > 0:
-                bondforce = openmm.CustomBondForce('-K*r*(r-r0)')
-                bondforce.addPerBondParameter('r0')
-                bondforce.addPerBondParameter('K')
-                for index in range(force.getNumBonds()):
-                    i, j, r0, K = force.getBondParameters(index)
-                    bondforce.addBond(i, j, [r0, K])
-                bondforce.setForceGroup(bondedGroup)
-                self.addForce(bondforce)
+                members = [(stretching_virial(force), 'bonded')]
             elif isinstance(force, openmm.CustomBondForce) and force.getNumBonds() > 0:
                 raise NotImplementedError('ComputingSystem: virial of a user CustomBondForce is not supported')
+            else:
+                members = []
+            for member, kind in members:
+                member.setForceGroup(group[kind])
+                self.addForce(member)
 
 
 class AlchemicalCoulombCVForce(object):

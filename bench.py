@@ -127,8 +127,11 @@ def cpu_baseline(nside, loops, dt_fs, sample_steps=40, state=None):
     case = tip3p_box(nside)
     if state is not None:
         case = dict(case, positions=state[0], velocities=state[1])
-    sec, st = cpu_port.time_port(case, warmup=3, steps=sample_steps, loops=tuple(loops), dt=dt_fs * 1e-3, skin=0.1)
-    return {'value': round(dt_fs * 1e-6 * 86400.0 / sec, 4), 'unit': 'ns/day', 'cores': cpu_port.threads(), 'kind': 'port',
+    kw = dict(loops=tuple(loops), dt=dt_fs * 1e-3, skin=0.1)
+    threads, timing = cpu_port.best_thread_count(case, **kw)       # the box's CPU quota, not its logical CPU count, decides
+    sec, st = cpu_port.time_port(case, warmup=3, steps=sample_steps, **kw)
+    return {'value': round(dt_fs * 1e-6 * 86400.0 / sec, 4), 'unit': 'ns/day', 'cores': threads, 'kind': 'port',
+            'thread_scan_ms_per_step': {str(t): round(v * 1e3, 1) for t, v in sorted(timing.items())},
             'sample': '%d outer RESPA steps (after 3 warm-up) of the same %d-atom workload continued from the state the GPU run ended in, '
                       '%.1f ms/step, %d list builds; CPU port in C + OpenMP (oracle/cpu_port.c: step loop, shared cell-sorted Verlet list, '
                       'owner-computed rows), not OpenMM' % (sample_steps, len(case['positions']), sec * 1e3, st['builds'])}
@@ -321,7 +324,9 @@ def main():
             except Exception:
                 pass
 
-        kname = 'k_cpair_tab' if near_stats.get('list_kind') else 'k_pair_tab'
+        molecule_rows = bool(near_stats.get('list_kind'))
+        kname = 'k_cpair_tab' if molecule_rows else 'k_pair_tab'
+        outer_name = 'DAMPED' if args.outer == 'damped' else 'NONBONDED/Ewald'
 
         def roofline(kernel, seconds, launches, alg_bytes, flops, tag, npairs):
             achieved = alg_bytes / max(seconds, 1e-12) / 1e9
@@ -363,16 +368,20 @@ def main():
                        'parallelism': ('atom decomposition x%d, %s' % (world, 'all-gather of owner-computed force slices (RCCL, library-owned communicator)'
                                                                      if getattr(eng, '_native_comm', False) else 'collectives through torch.distributed')) if world > 1 else 'single GPU',
                        'temperature_K_end': round(T_end, 1)},
-            # the kernel the metric names: the stand-alone near-force traversal (group 1, force only)
+            # the kernel the metric names: the near-force traversal (group 1, force only).  Molecule rows: the same kernel serves the
+            # stand-alone evaluation and the near force's launch of the step-boundary pass (front parts of the shared rows)
             'roofline': roofline('%s<NEAR_FSWITCH> (group-1 near force, force only)' % kname, t_near, n_near,
                                  BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_NEAR * pairs_near, 'near', pairs_near),
-            # the dominant kernel of the step: outer force + near force of the shared list in one traversal (one read set,
-            # two force arrays: 96 B per atom)
-            'roofline_dominant': roofline('%s<%s, guest NEAR_FSWITCH> (outer + near force in one pass)'
-                                          % (kname, 'DAMPED' if args.outer == 'damped' else 'NONBONDED/Ewald'), t_dual, n_dual,
-                                          BYTES_PER_ATOM_DUAL * atoms_per_launch, flop_dual, 'dual', pairs_far),
+            # the dominant kernel of the step: the outer force over the whole rows.  Molecule rows: one force per launch (72 B per
+            # atom); per-atom rows (--option cluster=0): outer + near force in one traversal (96 B per atom, both forces' flops)
+            'roofline_dominant': (roofline('%s<%s> (group-2 outer force, force only)' % (kname, outer_name), t_dual, n_dual,
+                                           BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_FAR * pairs_far, 'outer', pairs_far)
+                                  if molecule_rows else
+                                  roofline('%s<%s, guest NEAR_FSWITCH> (outer + near force in one pass)' % (kname, outer_name), t_dual, n_dual,
+                                           BYTES_PER_ATOM_DUAL * atoms_per_launch, flop_dual, 'dual', pairs_far)),
             'detail': {'near_kernel_us': round(t_near * 1e6, 2), 'near_launches': n_near,
-                       'dual_kernel_us': round(t_dual * 1e6, 2), 'dual_launches': n_dual,
+                       'outer_kernel_us' if molecule_rows else 'dual_kernel_us': round(t_dual * 1e6, 2), 'outer_launches' if molecule_rows else 'dual_launches': n_dual,
+                       'step_boundary_pass_us': round((t_dual + (t_near if molecule_rows else 0.0)) * 1e6, 2),
                        'near_list_prunes_in_timed_region': st1[near_id]['n_builds'] - st0[near_id]['n_builds'],
                        'far_list_prunes_in_timed_region': st1[far_id]['n_builds'] - st0[far_id]['n_builds'],
                        'outer_list_builds_in_timed_region': st1[far_id]['n_outer_builds'] - st0[far_id]['n_outer_builds'],

@@ -331,6 +331,7 @@ void port_get(const port_t *p, double *x, double *v, double *f0, double *f1, dou
 }
 
 int port_threads(void) { return omp_get_max_threads(); }
+void port_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 
 void port_destroy(port_t *p) {
     double *d[] = {p->x, p->v, p->m, p->q, p->hsig, p->seps2, p->f0, p->f1, p->f2, p->xref};

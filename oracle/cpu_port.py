@@ -25,6 +25,7 @@ def lib():
         L.port_get.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, C.POINTER(C.c_long)]
         L.port_destroy.argtypes = [C.c_void_p]
         L.port_threads.restype = C.c_int
+        L.port_set_threads.argtypes = [C.c_int]
         _LIB = L
     return _LIB
 
@@ -78,8 +79,32 @@ def threads():
     return int(lib().port_threads())
 
 
+def set_threads(n):
+    lib().port_set_threads(int(n))
+
+
+def best_thread_count(case, candidates=None, **kw):
+    """The thread count that runs the step fastest on this host (2 timed steps per candidate): a container's CPU quota can be far
+    below the number of logical CPUs it sees, and over-subscribed OpenMP threads run slower, not faster."""
+    ncpu = os.cpu_count() or 1
+    candidates = candidates or sorted(set(c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu))
+    sim = RespaPort(case, **kw)
+    sim.step(1)
+    timing = {}
+    for t in candidates:
+        set_threads(t)
+        sim.step(1)
+        t0 = time.perf_counter()
+        sim.step(2)
+        timing[t] = (time.perf_counter() - t0) / 2
+    sim.close()
+    best = min(timing, key=timing.get)
+    set_threads(best)
+    return best, timing
+
+
 def time_port(case, warmup=2, steps=20, **kw):
-    """Seconds per outer step on this host's cores."""
+    """Seconds per outer step on this host's cores (with the thread count set by set_threads / best_thread_count, or OpenMP's default)."""
     sim = RespaPort(case, **kw)
     sim.step(warmup)
     t0 = time.perf_counter()

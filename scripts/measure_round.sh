@@ -10,14 +10,16 @@ mkdir -p "$out"
 cd "$root"
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- python3 "$root/bench.py" --no-cpu-baseline > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- python3 "$root/bench.py" --no-cpu-baseline --pme-steps 0 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_rocprof.err"
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_fetch" -- python3 "$root/bench.py" --no-cpu-baseline --steps 150 --warmup 10 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_fetch" -- python3 "$root/bench.py" --no-cpu-baseline --pme-steps 0 --steps 150 --warmup 10 > /dev/null 2>&1
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -- python3 "$root/bench.py" --no-cpu-baseline --steps 150 --warmup 10 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -- python3 "$root/bench.py" --no-cpu-baseline --pme-steps 0 --steps 150 --warmup 10 > /dev/null 2>&1
 echo "write pass done"
+rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d "$out/${tag}_pmc_valu" -- python3 "$root/bench.py" --no-cpu-baseline --pme-steps 0 --steps 150 --warmup 10 > /dev/null 2>&1
+echo "valu pass done"
 cd "$root"
-python3 scripts/pmc_summary.py "$out/${tag}_pmc_summary.txt" --traffic-json "$out/${tag}_traffic.json" "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" > /dev/null
+python3 scripts/pmc_summary.py "$out/${tag}_pmc_summary.txt" --traffic-json "$out/${tag}_traffic.json" "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" "$out/${tag}_pmc_valu" > /dev/null
 cp "$out/${tag}_traffic.json" profiles/${tag}_traffic.json      # bench.py quotes the traffic measured on this box
 cp "$(find "$out/${tag}_stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_kernel_stats.csv"
 python3 bench.py > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"

@@ -31,21 +31,29 @@ def main():
     print('\n'.join(lines))
     if tj:
         res = {}
-        for tag, pats in (('near', ('k_pair_tab<2, 0, -1', 'k_pair_nlist<2')), ('dual', ('k_pair_tab<3, 1, 2', 'k_pair_nlist<3')),
-                          ('build', ('k_build_nlist<false',))):
+        for tag, pats in (('near', ('k_cpair_tab<2, 0', 'k_pair_tab<2, 0, -1', 'k_pair_nlist<2')),
+                          ('outer', ('k_cpair_tab<3, 1', 'k_cpair_tab<4, 1')),
+                          ('dual', ('k_pair_tab<3, 1, 2', 'k_pair_nlist<3')),
+                          ('build', ('k_cbuild<false', 'k_build_nlist<false'))):
             fe = [x for (cn, kn), v in acc.items() if cn == 'FETCH_SIZE' and any(p in kn for p in pats) for x in v]
             wr = [x for (cn, kn), v in acc.items() if cn == 'WRITE_SIZE' and any(p in kn for p in pats) for x in v]
+            iv = [x for (cn, kn), v in acc.items() if cn == 'SQ_INSTS_VALU' and any(p in kn for p in pats) for x in v]
             names = sorted(set(kn for (cn, kn) in acc if cn == 'FETCH_SIZE' and any(p in kn for p in pats)))
             if tag == 'build':      # only the launches that actually rebuilt (the others return at once)
                 fe = [x for x in fe if x > 100.0]
                 wr = [x for x in wr if x > 100.0]
+                iv = [x for x in iv if x > 1.0e5]
             if fe and wr:
                 f_kb, w_kb = sum(fe) / len(fe), sum(wr) / len(wr)
                 res[tag] = {'kernel': names[0].split('(')[0] if names else None, 'fetch_size_kb_avg': round(f_kb, 1),
                             'write_size_kb_avg': round(w_kb, 1), 'launches': len(fe),
                             'hbm_bytes_per_launch': int((2 * f_kb + w_kb) * 1024)}
-        res['note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py; '
-                       'hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of MI355X_MICROARCH.md)')
+                if iv:
+                    res[tag]['valu_insts_per_launch'] = int(sum(iv) / len(iv))
+        res['note'] = ('rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_INSTS_VALU in separate passes of bench.py; '
+                       'hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of MI355X_MICROARCH.md, stated for wide '
+                       'streaming reads: these kernels gather 32-byte records, so the truth lies between raw and corrected); '
+                       'valu_insts = wave-instructions per launch')
         try:        # the kernels these figures belong to: bench.py quotes them only while the library still reports this tag
             import os
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -175,12 +175,14 @@ def test_far_plus_near_equals_total(spcfw, method):
         assert potential / potential.unit == pytest.approx(refpot / refpot.unit)
 
 
+@pytest.mark.parametrize('rows', ['molecule', 'atom'])
 @pytest.mark.parametrize('method', ['CutoffPeriodic', 'PME'])
-def test_far_force_is_one_traversal(spcfw, method):
-    """FarNonbondedForce = total + discount (forces.py:710-724): the reference -- and OpenMM -- run two passes; here the
-    discount (a near force guarded by step(rc0 - r), sign -1) shares the total's neighbour list and is evaluated ON the
-    total's pass, accumulating into the same force rows.  One kernel launch under the total's id, none under the
-    discount's, and the same forces as the separate (energy-carrying, analytic) evaluations of the two."""
+def test_far_force_shares_one_list(spcfw, method, rows):
+    """FarNonbondedForce = total + discount (forces.py:710-724): the reference -- and OpenMM -- run two passes over two neighbour
+    lists; here the discount (a near force guarded by step(rc0 - r), sign -1) shares the total's neighbour list, its displacement
+    check and its sorted copies, and accumulates into the same force rows.  Per-atom rows (option cluster = 0): ONE kernel launch
+    for both, under the total's id.  Molecule rows (water, the default): one launch per force over the same rows -- the
+    discount's over their front parts.  Either way the forces equal the separate (energy-carrying, analytic) evaluations."""
     system, positions, topology = create_system(spcfw, nonbondedMethod=method, flexible=False)
     nbforce = atomsmm.hijackForce(system, atomsmm.findNonbondedForce(system))
     inner = atomsmm.NearNonbondedForce(7.0 * unit.angstroms, 6.5 * unit.angstroms, 'force-switch')
@@ -189,7 +191,8 @@ def test_far_force_is_one_traversal(spcfw, method):
     outer.importFrom(nbforce).addTo(system)
     integrator = openmm.CustomIntegrator(0.001)
     integrator.addComputePerDof('v', 'v + dt*f2/m')          # a force-only evaluation of group 2
-    context = openmm.Context(system, integrator)
+    context = openmm.Context(system, integrator, openmm.Platform.getPlatformByName('HIP'),
+                             {'Option.cluster': '1' if rows == 'molecule' else '0'})
     context.setPositions(positions)
     eng = context._engine
     ids = eng.pair_force_ids(2)
@@ -199,7 +202,8 @@ def test_far_force_is_one_traversal(spcfw, method):
     integrator.step(1)
     launches = {pid: eng.ctx.profile_read(pid)[0] for pid in ids}
     eng.ctx.profile_enable(False)
-    assert launches == {total: 1, discount: 0}
+    assert launches == {total: 1, discount: 1 if rows == 'molecule' else 0}
+    assert eng.ctx.pair_stats(total)['list_kind'] == (1 if rows == 'molecule' else 0)
     assert eng.ctx.pair_stats(discount)['shares_list'] == 1 and eng.ctx.pair_stats(discount)['n_evals'] == 1
     fused = eng._buffers['f2'].cpu().numpy().copy()
     separate = context.getState(getForces=True, groups={2}).getForces(asNumpy=True)._value

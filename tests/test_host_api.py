@@ -714,8 +714,7 @@ def test_deferred_globals_keep_sums_and_multiples_only():
 
 
 def test_softcore_force_classes(heaq, recorder):
-    """forces.py:727-792: SoftcoreLennardJonesForce over an interaction group is the softcore pair family; SoftcoreForce exists
-    with the reference's energy text, and a Context that holds it says what is missing."""
+    """forces.py:727-758: SoftcoreLennardJonesForce over an interaction group is the softcore pair family."""
     system = system_from_arrays(heaq, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
     nb = system.getForce(atomsmm.findNonbondedForce(system))
     solute = set(int(i) for i in np.where(heaq['resname'] == 'aaa')[0])
@@ -729,13 +728,9 @@ def test_softcore_force_classes(heaq, recorder):
     openmm.Context(system, openmm.VerletIntegrator(0.0)).setParameter('lambda_vdw', 0.5)
     sc = [p_ for p_ in recorder[-1].pairs if p_['family'] == B.SOFTCORE]
     assert len(sc) == 1 and ('pair_set_lambda', sc[0]['id'], 0.5) in recorder[-1].calls
-    both = atomsmm.SoftcoreForce(1.0 * unit.nanometers, 0.9 * unit.nanometers)
-    assert both.getEnergyFunction().startswith('4*lambda_vdw*epsilon*(1-x)/x^2 + Kc*lambda_coul*chargeprod/r;x = (r/sigma)^6 + 0.5*(1-lambda_vdw)')
-    assert both.getGlobalParameters()['lambda_coul'] == 1.0
-    system2 = system_from_arrays(heaq, nonbondedMethod='PME', cutoff=1.0, switch=0.9)
-    both.importFrom(system2.getForce(atomsmm.findNonbondedForce(system2))).addTo(system2)
-    with pytest.raises(atomsmm.InputError):
-        openmm.Context(system2, openmm.VerletIntegrator(0.0))
+    # (the reference's SoftcoreForce -- softcore Lennard-Jones plus scaled Coulomb in one expression, forces.py:761-792 -- is outside the
+    # hot path's scope and is not restated: a stub whose Context raised was dropped in round 3)
+    assert not hasattr(atomsmm, 'SoftcoreForce')
 
 
 def test_simulation_serves_reporters(spcfw, recorder):
