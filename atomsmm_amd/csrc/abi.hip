@@ -406,6 +406,23 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
             AMM_HIP(hipMemcpy(pf->d_member, member.data(), sizeof(float) * n, hipMemcpyHostToDevice));
         }
     }
+    // one Lennard-Jones site class?  (water: the oxygens) -- the molecule-row kernels then need no per-atom LJ records
+    {
+        pf->one_site_class = true;
+        bool seen = false;
+        for (int i = 0; i < n; ++i) {
+            if (h_eps[i] == 0.0) continue;
+            if (!seen) {
+                seen = true;
+                pf->site_hsig = hs[i];
+                pf->site_seps2 = se[i];
+            } else if (hs[i] != pf->site_hsig || se[i] != pf->site_seps2) {
+                pf->one_site_class = false;
+                break;
+            }
+        }
+        if (!seen) pf->site_hsig = pf->site_seps2 = 0.0;
+    }
     // class of each atom for the traversal order: 1 = no Lennard-Jones site (its rows skip the LJ arithmetic)
     std::vector<int> cls(n);
     for (int i = 0; i < n; ++i) cls[i] = h_eps[i] == 0.0 ? 1 : 0;

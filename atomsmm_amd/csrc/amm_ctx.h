@@ -62,6 +62,8 @@ struct PairForce {
     ClusterList *cl = nullptr;     // molecule rows (built on the first force-only evaluation of a qualifying force; list owners only)
     bool cluster_ok = false;       // every atom sits in a three-atom molecule whose three pairs are the force's only exclusions
     bool force_rebuild_c = false;  // the molecule rows carry site bits of another site pattern
+    bool one_site_class = false;   // all atoms with eps != 0 share ONE (sigma, eps): the molecule-row kernels carry them as constants
+    double site_hsig = 0, site_seps2 = 0;
     int last_kind = 0;             // list walked by the last evaluation: 0 per-atom rows, 1 molecule rows (statistics)
     PairConsts pc;
     int n = 0;

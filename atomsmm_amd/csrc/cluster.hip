@@ -29,6 +29,13 @@
 #include "pair_math.h"
 #include "pair_tab.h"
 
+#ifndef AMM_CW_USITE
+#define AMM_CW_USITE 0
+#endif
+#ifndef AMM_CW_STAGE2
+#define AMM_CW_STAGE2 0
+#endif
+
 __device__ double amm_erfcx_table_dev_c[AMM_ERFCX_NI * AMM_ERFCX_NC];
 static bool g_erfcx_uploaded_c[64] = {false};
 
@@ -506,6 +513,7 @@ struct CPairArgs {
     double margin;
     int ntask;
     int per_pair_image;
+    double hsig_site, seps2_site;      // sigma/2 and 2 sqrt(eps) of the system's one Lennard-Jones site class (AMM_CW_USITE)
 };
 
 // IMG: 0 interior rows (no periodic image), 1 one image per molecule pair (from the first atoms), 2 minimum image per atom pair
@@ -523,8 +531,8 @@ struct CPairArgs {
 // rows, the near force over their front parts (140 + 63 us; the list check, the sorted copies and the rows are shared).
 template <int FAM, int CMODE, int IMG>
 __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &c, const char *tabh, const double *s_erfcx,
-                                          const double4 (&pi)[3], const double2 *li, int i_sites, const int *row, int nfront, int nn,
-                                          int sub, int lpa, int self, double (&f)[9]) {
+                                          const double4 (&pi)[3], const double2 *li, int i_sites, int my_sites, double sign_lj, const int *row,
+                                          int nfront, int nn, int sub, int lpa, int self, double (&f)[9]) {
     // pi[a].w = sign Kc q_a (folded by the caller); li[a]: the row atoms' Lennard-Jones parameters (2 sqrt(eps) times the sign) in an
     // LDS strip of the wavefront (only the rare pairs of two sites read them: 12 registers less)
     const int back = A.cap - 1 + nfront;
@@ -547,8 +555,9 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         pj[b] = load_pos(e, b);
-        lj[b] = load_lj(e, b);
+        if (!AMM_CW_USITE) lj[b] = load_lj(e, b);
     }
+    const double sig_site = 2.0 * A.hsig_site, eps4_site = A.seps2_site * A.seps2_site * sign_lj;
     while (__builtin_amdgcn_ballot_w64(k < nn) != 0ull) {
         const bool ok = k < nn;
         const unsigned bits = (unsigned)e >> 29;
@@ -575,18 +584,40 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
                     dz[a] = amm_min_image(dz[a], A.box.L[2], A.box.invL[2]);
                 }
                 r2[a] = dx[a] * dx[a] + dy[a] * dy[a] + dz[a] * dz[a];
+#if !AMM_CW_STAGE2
                 th[a] = amm_tab_fetch(tabh, c.tab, r2[a]);
+#endif
             }
+#if AMM_CW_STAGE2
+            // two look-ups in flight, the third issued while the first is evaluated (14 registers less than three at once)
+            th[0] = amm_tab_fetch(tabh, c.tab, r2[0]);
+            th[1] = amm_tab_fetch(tabh, c.tab, r2[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            fr[0] = (pi[0].w * qb) * amm_tab_horner(th[0]);
+            th[2] = amm_tab_fetch(tabh, c.tab, r2[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            fr[1] = (pi[1].w * qb) * amm_tab_horner(th[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            fr[2] = (pi[2].w * qb) * amm_tab_horner(th[2]);
+#else
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 3; ++a) fr[a] = (pi[a].w * qb) * amm_tab_horner(th[a]);
+#endif
             // Lennard-Jones part: only where two sites can meet (wave-uniform); the other lanes add an exact zero (eps4 = 0)
             if (i_sites != 0 && __builtin_amdgcn_ballot_w64(ok && ((bits >> b) & 1u)) != 0ull) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
                     if ((i_sites >> a) & 1) {
+#if AMM_CW_USITE
+                        // one site class in the system (water: the oxygens): its parameters are constants of the launch, the
+                        // per-lane site bits decide which lanes' pairs are site-site
+                        const bool both = ((my_sites >> a) & 1) && ((bits >> b) & 1u);
+                        const double sig = sig_site, eps4 = both ? eps4_site : 0.0;
+#else
                         const double2 la = li[64 * a];
                         const double sig = la.x + lj[b].x, eps4 = la.y * lj[b].y;
+#endif
                         const LJCommon L = amm_lj_common(r2[a], sig, eps4);
                         fr[a] += amm_lj_force<FAM, CMODE>(c, L, sig, eps4);
                     }
@@ -605,11 +636,17 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
             if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {       // closer than the table reaches: analytic (never in a liquid)
                 for (int a = 0; a < 3; ++a) {
                     const bool low = ok && (r2[a] < c.rc2) && (r2[a] < r2low);
+#if AMM_CW_USITE
+                    const bool both = ((my_sites >> a) & 1) && ((bits >> b) & 1u);
+                    const double sg = sig_site, e4 = both ? eps4_site : 0.0;
+#else
                     const double2 lx = A.lj[3 * ((unsigned)e & 0x1fffffffu) + b];
                     const double2 la = li[64 * a];
+                    const double sg = la.x + lx.x, e4 = la.y * lx.y;
+#endif
                     double e_, fr_;
-                    // (pi.w and la.y carry the sign already: the math runs with sign 1)
-                    amm_pair_math<FAM, CMODE, false, false>(c, low ? r2[a] : 1.0, pi[a].w * qb, la.x + lx.x, la.y * lx.y, e_, fr_, s_erfcx);
+                    // (pi.w and the epsilons carry the sign already: the math runs with sign 1)
+                    amm_pair_math<FAM, CMODE, false, false>(c, low ? r2[a] : 1.0, pi[a].w * qb, sg, e4, e_, fr_, s_erfcx);
                     fr_ = low ? fr_ : 0.0;
                     f[3 * a] += fr_ * dx[a];
                     f[3 * a + 1] += fr_ * dy[a];
@@ -618,7 +655,7 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
             }
             // this partner atom's record is dead: its registers take the next trip's (the image shift of THIS trip is in sx, sy, sz)
             pj[b] = load_pos(en, b);
-            lj[b] = load_lj(en, b);
+            if (!AMM_CW_USITE) lj[b] = load_lj(en, b);
         }
         e = en;
         en = e2;
@@ -662,7 +699,7 @@ k_cpair_tab(CPairArgs A, PairConsts c) {
         const bool valid = a < A.nrows;
         const int cs = A.c_begin + (valid ? a : 0);
         double4 pi[3];
-        int i_sites = 0;
+        int i_sites = 0, my_sites = 0;
         __builtin_amdgcn_wave_barrier();                 // the previous task's reads of the strip are done
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -670,7 +707,8 @@ k_cpair_tab(CPairArgs A, PairConsts c) {
             pi[t].w *= c.Kc * sign;
             double2 l = A.lj[3 * cs + t];
             l.y *= sign;
-            s_li[64 * t + lane] = l;
+            if (!AMM_CW_USITE) s_li[64 * t + lane] = l;
+            if (valid && l.y != 0.0) my_sites |= 1 << t;
             if (__builtin_amdgcn_ballot_w64(valid && l.y != 0.0) != 0ull) i_sites |= 1 << t;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -686,9 +724,9 @@ k_cpair_tab(CPairArgs A, PairConsts c) {
         double f[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) f[k] = 0.0;
-        if (A.per_pair_image) cwalk_row<FAM, CMODE, 2>(A, c1, tabh, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f);
-        else if (interior) cwalk_row<FAM, CMODE, 0>(A, c1, tabh, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f);
-        else cwalk_row<FAM, CMODE, 1>(A, c1, tabh, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f);
+        if (A.per_pair_image) cwalk_row<FAM, CMODE, 2>(A, c1, tabh, s_erfcx, pi, li, i_sites, my_sites, sign, row, nfront, nn, sub, lpa, cs, f);
+        else if (interior) cwalk_row<FAM, CMODE, 0>(A, c1, tabh, s_erfcx, pi, li, i_sites, my_sites, sign, row, nfront, nn, sub, lpa, cs, f);
+        else cwalk_row<FAM, CMODE, 1>(A, c1, tabh, s_erfcx, pi, li, i_sites, my_sites, sign, row, nfront, nn, sub, lpa, cs, f);
         for (int off = lpa >> 1; off > 0; off >>= 1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) f[k] += __shfl_xor(f[k], off);
@@ -1020,6 +1058,8 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         const int rpw = 64 >> A.lpa_shift;
         A.ntask = (nrows + rpw - 1) / rpw;
         A.per_pair_image = cl->per_pair_image ? 1 : 0;
+        A.hsig_site = pf->site_hsig;
+        A.seps2_site = pf->site_seps2;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = ctx->profile && (ctx->profile_only < 0 || ctx->profile_only == pf->id);
         if (timed) {
