@@ -195,12 +195,15 @@ struct CBoxF {
 // The old per-atom build spent 42 instructions per 64 ATOM-pair tests, mostly compaction; here the compaction is paid per
 // MOLECULE pair and only for a stream that is already 80 % hits.
 #ifndef CB_BATCH
-#define CB_BATCH 8
+#define CB_BATCH 5
 #endif
-#define CB_QCAP 256         // ring of survivors per row molecule: a power of two >= 63 + 128
+#ifndef CB_QCAP
+#define CB_QCAP 192         // ring of survivors per row molecule: >= 63 + 128 (a drain leaves at most 63 behind, a chunk pair adds 128)
+#endif
+__device__ __forceinline__ int cq_wrap(int i) { return i >= CB_QCAP ? i - CB_QCAP : i; }      // i < 2 CB_QCAP
 
 __device__ void cfinish_build_block(int *flags, unsigned long long *counters, const unsigned long long *blockstats, int nblocks, int count_only) {
-    __shared__ unsigned long long sh_sum[256], sh_max[256], sh_near[256];
+    __shared__ unsigned long long sh_part[4][3];
     unsigned long long sum = 0, mx = 0, nr = 0;
     for (int b0 = threadIdx.x; b0 < nblocks; b0 += 8 * 256) {
         unsigned long long v[8][3];
@@ -218,22 +221,21 @@ __device__ void cfinish_build_block(int *flags, unsigned long long *counters, co
             nr += v[j][2];
         }
     }
-    sh_sum[threadIdx.x] = sum;
-    sh_max[threadIdx.x] = mx;
-    sh_near[threadIdx.x] = nr;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            sh_sum[threadIdx.x] += sh_sum[threadIdx.x + off];
-            sh_near[threadIdx.x] += sh_near[threadIdx.x + off];
-            sh_max[threadIdx.x] = max(sh_max[threadIdx.x], sh_max[threadIdx.x + off]);
-        }
-        __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        nr += __shfl_xor(nr, off);
+        mx = max(mx, __shfl_xor(mx, off));
     }
+    if ((threadIdx.x & 63) == 0) {
+        sh_part[threadIdx.x >> 6][0] = sum;
+        sh_part[threadIdx.x >> 6][1] = mx;
+        sh_part[threadIdx.x >> 6][2] = nr;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        flags[2] = (int)sh_max[0];
-        counters[1] = sh_sum[0];
-        counters[2] = sh_near[0];
+        flags[2] = (int)max(max(sh_part[0][1], sh_part[1][1]), max(sh_part[2][1], sh_part[3][1]));
+        counters[1] = sh_part[0][0] + sh_part[1][0] + sh_part[2][0] + sh_part[3][0];
+        counters[2] = sh_part[0][2] + sh_part[1][2] + sh_part[2][2] + sh_part[3][2];
         if (!count_only) {
             flags[0] = 0;
             counters[0] += 1;
@@ -326,7 +328,7 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
             auto drain = [&](int t, int n) {
                 const int head = __builtin_amdgcn_readlane(q_head, t);
                 const bool v0 = lane < n;
-                const int slot = v0 ? s_q[w][t][(head + lane) & (CB_QCAP - 1)] : tb + t;
+                const int slot = v0 ? s_q[w][t][cq_wrap(head + lane)] : tb + t;
                 const bool v = v0 && slot != tb + t;          // (a molecule is not its own partner)
                 float4 A[3];
                 A[0] = pos4f[3 * slot];
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
                     }
                     row_cnt = lane == t ? c2 + nn_ + ((np_ - nn_) << 16) : row_cnt;
                 }
-                q_head = lane == t ? (head + n) & (CB_QCAP - 1) : q_head;
+                q_head = lane == t ? cq_wrap(head + n) : q_head;
                 q_cnt = lane == t ? q_cnt - n : q_cnt;
             };
             // ---- pass 1: the candidate stream, first atoms only; a row's ring is drained in FULL chunks as soon as it holds 64 ----
@@ -433,7 +435,7 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
                         const unsigned long long m = __builtin_amdgcn_ballot_w64(r2 < lim * lim && lim > 0.f);
                         if (m == 0ull) continue;
                         const int at = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        if ((m >> lane) & 1ull) s_q[w][t][(head + at) & (CB_QCAP - 1)] = js[u];
+                        if ((m >> lane) & 1ull) s_q[w][t][cq_wrap(head + at)] = js[u];
                         qn += __popcll(m);
                     }
                     q_cnt = lane == t ? qn : q_cnt;
@@ -675,7 +677,11 @@ k_cpair_tab(CPairArgs A, PairConsts c) {
     extern __shared__ __align__(16) char s_lds[];
     for (int o = threadIdx.x * 16; o < A.host_bytes; o += BS * 16)
         *reinterpret_cast<double2 *>(s_lds + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.host_tab) + o);
+#if defined(AMM_EXP_TAB_GLOBAL)           // measurement only: the table is read through the vector-memory path instead of LDS
+    const char *tabh = reinterpret_cast<const char *>(A.host_tab);
+#else
     const char *tabh = s_lds;
+#endif
     double *s_erfcx = reinterpret_cast<double *>(s_lds + A.host_bytes);
     for (int k = threadIdx.x; k < AMM_ERFCX_NI * AMM_ERFCX_NC; k += BS) s_erfcx[k] = amm_erfcx_table_dev_c[k];
     // Lennard-Jones parameters of the rows' atoms: [wave][atom][lane] (read by the rare site-site pairs only)
@@ -937,9 +943,18 @@ static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) 
     AMM_HIP(hipStreamSynchronize(ctx->stream));
     cl->capc = 2 * flags[6] + 16;
     AMM_HIP(hipMalloc(&cl->d_cell_members, sizeof(int) * (size_t)ncell * cl->capc));
-    // wavefronts per cell: one batch of CB_BATCH row molecules each at the MEAN cell occupancy (a wave walks the cell's whole
-    // candidate stream once per batch: sized by the fullest cell -- the first version -- most waves walked it for two molecules)
-    cl->parts = std::max(1, std::min(16, (int)std::ceil((double)nc / ncell / CB_BATCH)));
+    // wavefronts per cell: a wave walks the cell's whole candidate stream once per batch of CB_BATCH row molecules, so batches
+    // should be full -- but the build is a chain of dependent reads (piece search, gather, ring, gather) that only more
+    // wavefronts hide: 1.5 x the parts that would just fill the batches at the MEAN occupancy measured fastest
+    // (98 304 atoms, 11.5 molecules per cell, us per rebuild: batch 8 x 2 parts 150, 6 x 3 127, 5 x 4 125, 4 x 4 131, 3 x 6 138).
+    // A rank's slice covers 1 / world of the cells: its rows are spread over more waves, up to one row each (slice of 1/8: 99 us
+    // with 2 parts, 58 with 6)
+    cl->parts = std::max(1, std::min(16, (int)std::ceil(1.5 * (double)nc / ncell / CB_BATCH)));
+    if (ctx->world > 1) {
+        const int active_cells = std::max(1, ncell / ctx->world);
+        const int want = (4096 + active_cells - 1) / active_cells, most = std::max(1, (int)std::ceil((double)nc / ncell));
+        cl->parts = std::max(cl->parts, std::min(want, std::min(most, 8)));
+    }
     if (ctx->opt_parts > 0) cl->parts = std::max(1, std::min(16, ctx->opt_parts));
     {
         const long t1 = (long)ncell * cl->parts * 64;

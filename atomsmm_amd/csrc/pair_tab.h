@@ -234,6 +234,9 @@ __device__ __forceinline__ TabLookup amm_tab_fetch(const char *lds_tab, const Pa
     const double centre = __hiloint2double((int)((raw << sh) | (unsigned)(above ? T.halfB : (1 << (AMM_TAB_SHIFT - 1)))), 0);
     TabLookup L;
     L.t = w - centre;
+#if defined(AMM_EXP_TAB_BCAST)          // measurement only: every lane reads interval 0 (no bank conflicts; wrong forces)
+    idx &= 0u;
+#endif
     const double2 *cf = reinterpret_cast<const double2 *>(lds_tab + __umul24(idx, AMM_TAB_STRIDE));
     L.c01 = cf[0];
     L.c23 = cf[1];

@@ -328,7 +328,7 @@ def main():
         kname = 'k_cpair_tab' if molecule_rows else 'k_pair_tab'
         outer_name = 'DAMPED' if args.outer == 'damped' else 'NONBONDED/Ewald'
 
-        def roofline(kernel, seconds, launches, alg_bytes, flops, tag, npairs):
+        def roofline(kernel, seconds, launches, alg_bytes, flops, tag, npairs, listed):
             achieved = alg_bytes / max(seconds, 1e-12) / 1e9
             tf = flops / max(seconds, 1e-12) / 1e12
             entry = {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -348,6 +348,8 @@ def main():
                 if t_.get('valu_insts_per_launch') and npairs:
                     # lane-instructions (64 x SQ_INSTS_VALU) per in-cutoff pair counted once (the pass evaluates both directions)
                     entry['valu_insts_per_pair'] = round(64.0 * t_['valu_insts_per_launch'] / npairs, 1)
+                    if listed:   # ... and per pair evaluation (a listed pair, each direction, inside the cutoff or not)
+                        entry['valu_insts_per_listed_pair'] = round(64.0 * t_['valu_insts_per_launch'] / listed, 1)
                 entry['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, kernels %s)' % (
                     TRAFFIC_FILE, traffic.get('kernel_revision'))
             return entry
@@ -371,14 +373,14 @@ def main():
             # the kernel the metric names: the near-force traversal (group 1, force only).  Molecule rows: the same kernel serves the
             # stand-alone evaluation and the near force's launch of the step-boundary pass (front parts of the shared rows)
             'roofline': roofline('%s<NEAR_FSWITCH> (group-1 near force, force only)' % kname, t_near, n_near,
-                                 BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_NEAR * pairs_near, 'near', pairs_near),
+                                 BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_NEAR * pairs_near, 'near', pairs_near, near_stats['n_list_pairs']),
             # the dominant kernel of the step: the outer force over the whole rows.  Molecule rows: one force per launch (72 B per
             # atom); per-atom rows (--option cluster=0): outer + near force in one traversal (96 B per atom, both forces' flops)
             'roofline_dominant': (roofline('%s<%s> (group-2 outer force, force only)' % (kname, outer_name), t_dual, n_dual,
-                                           BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_FAR * pairs_far, 'outer', pairs_far)
+                                           BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_FAR * pairs_far, 'outer', pairs_far, st1[far_id]['n_list_pairs'])
                                   if molecule_rows else
                                   roofline('%s<%s, guest NEAR_FSWITCH> (outer + near force in one pass)' % (kname, outer_name), t_dual, n_dual,
-                                           BYTES_PER_ATOM_DUAL * atoms_per_launch, flop_dual, 'dual', pairs_far)),
+                                           BYTES_PER_ATOM_DUAL * atoms_per_launch, flop_dual, 'dual', pairs_far, st1[far_id]['n_list_pairs'])),
             'detail': {'near_kernel_us': round(t_near * 1e6, 2), 'near_launches': n_near,
                        'outer_kernel_us' if molecule_rows else 'dual_kernel_us': round(t_dual * 1e6, 2), 'outer_launches' if molecule_rows else 'dual_launches': n_dual,
                        'step_boundary_pass_us': round((t_dual + (t_near if molecule_rows else 0.0)) * 1e6, 2),

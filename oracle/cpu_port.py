@@ -87,7 +87,7 @@ def best_thread_count(case, candidates=None, **kw):
     """The thread count that runs the step fastest on this host (2 timed steps per candidate): a container's CPU quota can be far
     below the number of logical CPUs it sees, and over-subscribed OpenMP threads run slower, not faster."""
     ncpu = os.cpu_count() or 1
-    candidates = candidates or sorted(set(c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu))
+    candidates = candidates or sorted(set(c for c in (8, 16, 32, 64, 128) if c <= ncpu) | {min(ncpu, 128)})
     sim = RespaPort(case, **kw)
     sim.step(1)
     timing = {}
