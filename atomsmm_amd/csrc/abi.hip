@@ -1238,6 +1238,7 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     out->list_kind = L->last_kind;
     out->tab_error = pf->tab_error;
     out->has_table = (pf->pc.tab.nint > 0 && pf->d_tab) ? 1 : 0;
+    out->rode_along = pf->last_fused;
     if (L->last_kind == 1 && L->cl && L->cl->built) {
         ClusterList *cl = L->cl;
         int flags[8];
@@ -1308,6 +1309,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "tab_block") ctx->opt_tab_bs = v;
     else if (k == "tab_dual_block") ctx->opt_tab_dual_bs = v;
     else if (k == "no_dual") ctx->opt_no_dual = v;
+    else if (k == "fuse_rows") ctx->opt_fuse_rows = v;
     else if (k == "no_defer") ctx->opt_no_defer = v;
     else if (k == "terms_from") ctx->opt_terms_from = v;
     else if (k == "no_term_lanes") ctx->opt_no_term_lanes = v;

@@ -64,6 +64,7 @@ struct PairForce {
     bool force_rebuild_c = false;  // the molecule rows carry site bits of another site pattern
     bool one_site_class = false;   // all atoms with eps != 0 share ONE (sigma, eps): the molecule-row kernels carry them as constants
     double site_hsig = 0, site_seps2 = 0;
+    int last_fused = 0;            // 1: the last force-only evaluation rode on the list owner's launch (molecule rows, fused pass)
     int last_kind = 0;             // list walked by the last evaluation: 0 per-atom rows, 1 molecule rows (statistics)
     PairConsts pc;
     int n = 0;
@@ -243,6 +244,7 @@ struct amm_ctx {
     int opt_cluster = 1;           // molecule rows for qualifying forces (0: per-atom rows everywhere)
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
     int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
+    int opt_fuse_rows = 1;              // molecule rows: host + guest force of a shared list in ONE launch when a fused kernel exists
     int opt_no_dual = 0, opt_no_defer = 0, opt_terms_from = 8192, opt_no_term_lanes = 0;
     ListWatch watched[2];
     int n_watched = 0;

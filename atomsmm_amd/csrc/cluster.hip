@@ -516,6 +516,11 @@ struct CPairArgs {
     int ntask;
     int per_pair_image;
     double hsig_site, seps2_site;      // sigma/2 and 2 sqrt(eps) of the system's one Lennard-Jones site class (AMM_CW_USITE)
+    // the guest force of a fused pass (k_cpair_dual): its table, its output and its factors relative to the host's
+    const double *guest_tab;
+    int guest_bytes, g_accumulate;
+    double *gforce;
+    double gfac, gsr;                  // (Kc sign)_guest / (Kc sign)_host ; sign_guest / sign_host
 };
 
 // IMG: 0 interior rows (no periodic image), 1 one image per molecule pair (from the first atoms), 2 minimum image per atom pair
@@ -621,7 +626,7 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
                         const double sig = la.x + lj[b].x, eps4 = la.y * lj[b].y;
 #endif
                         const LJCommon L = amm_lj_common(r2[a], sig, eps4);
-                        fr[a] += amm_lj_force<FAM, CMODE>(c, L, sig, eps4);
+                        fr[a] = amm_sum_unfused(fr[a], amm_lj_force<FAM, CMODE>(c, L, sig, eps4));
                     }
             }
             bool any_low = false;
@@ -760,6 +765,277 @@ struct CLaunchCfg {
     int lds_set = 0, bpc = -1;
 };
 static int g_num_cu_c[64] = {0};
+
+// ------------------------------------------------------------------------------------------------ fused pass (host + guest)
+// The step-boundary pass of RESPA needs the outer force over the whole rows AND the near force over their front parts.  As two
+// launches the front entries are gathered and their geometry formed twice; here the guest rides on the host's walk: per partner
+// atom the host's three look-ups, Horner chains and accumulation come first, then -- only on trips where some row of the
+// wavefront is still in its front part (wave-uniform) -- the guest's three look-ups into its own table (second LDS region),
+// into a second set of nine accumulators.  The scheduling barriers keep the two forces' look-up registers from being live
+// together.
+template <int FAM, int CMODE, int GFAM, int IMG>
+__device__ __forceinline__ void cwalk_row_dual(const CPairArgs &A, const PairConsts &c, const PairConsts &g, const char *tabh, const char *tabg,
+                                               const double *s_erfcx, const double4 (&pi)[3], const double2 *li, int i_sites, const int *row,
+                                               int nfront, int nn, int sub, int lpa, int self, double (&f)[9], double (&fg)[9]) {
+    const int back = A.cap - 1 + nfront;
+    const double r2low = fmax(c.tab.r2min, g.tab.r2min);      // closer pairs: both forces analytically (never in a liquid)
+    auto entry = [&](int k) { return k < nn ? row[k < nfront ? k : back - k] : self; };
+    auto load_pos = [&](int e, int b) {
+        return *reinterpret_cast<const double4 *>(reinterpret_cast<const char *>(A.posq) + (size_t)((unsigned)e & 0x1fffffffu) * 96u + 32 * b);
+    };
+    auto load_lj = [&](int e, int b) {
+        double2 l = make_double2(0.0, 0.0);
+        if (i_sites != 0 && __builtin_amdgcn_ballot_w64((((unsigned)e >> 29) >> b) & 1u) != 0ull)
+            l = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.lj) + (size_t)((unsigned)e & 0x1fffffffu) * 48u + 16 * b);
+        return l;
+    };
+    double4 pj[3];
+    double2 lj[3];
+    int k = sub;
+    int e = entry(k), en = entry(k + lpa);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        pj[b] = load_pos(e, b);
+        lj[b] = load_lj(e, b);
+    }
+    while (__builtin_amdgcn_ballot_w64(k < nn) != 0ull) {
+        const bool ok = k < nn;
+        const bool front = k < nfront;
+        const bool any_front = __builtin_amdgcn_ballot_w64(front) != 0ull;
+        const unsigned bits = (unsigned)e >> 29;
+        const int e2 = entry(k + 2 * lpa);
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        if (IMG == 1) {
+            sx = A.box.L[0] * rint((pj[0].x - pi[0].x) * A.box.invL[0]);
+            sy = A.box.L[1] * rint((pj[0].y - pi[0].y) * A.box.invL[1]);
+            sz = A.box.L[2] * rint((pj[0].z - pi[0].z) * A.box.invL[2]);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const double xb = pj[b].x - sx, yb = pj[b].y - sy, zb = pj[b].z - sz, qb = pj[b].w;
+            double dx[3], dy[3], dz[3], r2[3], fr[3], gl[3];
+            {
+                TabLookup th[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    dx[a] = pi[a].x - xb;
+                    dy[a] = pi[a].y - yb;
+                    dz[a] = pi[a].z - zb;
+                    if (IMG == 2) {
+                        dx[a] = amm_min_image(dx[a], A.box.L[0], A.box.invL[0]);
+                        dy[a] = amm_min_image(dy[a], A.box.L[1], A.box.invL[1]);
+                        dz[a] = amm_min_image(dz[a], A.box.L[2], A.box.invL[2]);
+                    }
+                    r2[a] = dx[a] * dx[a] + dy[a] * dy[a] + dz[a] * dz[a];
+                    th[a] = amm_tab_fetch(tabh, c.tab, r2[a]);
+                    gl[a] = 0.0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) fr[a] = (pi[a].w * qb) * amm_tab_horner(th[a]);
+            }
+            if (i_sites != 0 && __builtin_amdgcn_ballot_w64(ok && ((bits >> b) & 1u)) != 0ull) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if ((i_sites >> a) & 1) {
+                        const double2 la = li[64 * a];
+                        const double sig = la.x + lj[b].x, eps4 = la.y * lj[b].y;
+                        const LJCommon L = amm_lj_common(r2[a], sig, eps4);
+                        fr[a] = amm_sum_unfused(fr[a], amm_lj_force<FAM, CMODE>(c, L, sig, eps4));
+                        if (any_front) {     // the guest's Lennard-Jones force from the same 1/r, (sigma/r)^6 ... (a sign apart)
+                            LJCommon Lg = L;
+                            Lg.dlj_r *= A.gsr;
+                            gl[a] = amm_lj_force<GFAM, 0>(g, Lg, sig, eps4 * A.gsr);
+                        }
+                    }
+            }
+            bool any_low = false;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const bool low = r2[a] < r2low;
+                const bool pass = ok && (r2[a] < c.rc2);
+                any_low = any_low || (ok && low);
+                const double fh = (pass && !low) ? fr[a] : 0.0;
+                f[3 * a] += fh * dx[a];
+                f[3 * a + 1] += fh * dy[a];
+                f[3 * a + 2] += fh * dz[a];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (any_front) {
+                TabLookup tg[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) tg[a] = amm_tab_fetch(tabg, g.tab, r2[a]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    // (product and sum rounded separately, as the stand-alone launch forms them: the same bits either way)
+                    const double gr = amm_sum_unfused(((pi[a].w * qb) * A.gfac) * amm_tab_horner(tg[a]), gl[a]);
+                    const bool pass = front && (r2[a] < g.rc2) && !(r2[a] < r2low);
+                    const double gh = pass ? gr : 0.0;
+                    fg[3 * a] += gh * dx[a];
+                    fg[3 * a + 1] += gh * dy[a];
+                    fg[3 * a + 2] += gh * dz[a];
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {
+                for (int a = 0; a < 3; ++a) {
+                    const bool low = ok && (r2[a] < r2low);
+                    const double2 lx = A.lj[3 * ((unsigned)e & 0x1fffffffu) + b];
+                    const double2 la = li[64 * a];
+                    const double sg = la.x + lx.x, e4 = la.y * lx.y;
+                    double e_, fr_, gr_;
+                    amm_pair_math<FAM, CMODE, false, false>(c, low ? r2[a] : 1.0, pi[a].w * qb, sg, e4, e_, fr_, s_erfcx);
+                    amm_pair_math<GFAM, 0, false, false>(g, low ? r2[a] : 1.0, (pi[a].w * qb) * A.gfac, sg, e4 * A.gsr, e_, gr_, s_erfcx);
+                    fr_ = (low && r2[a] < c.rc2) ? fr_ : 0.0;
+                    gr_ = (low && front && r2[a] < g.rc2) ? gr_ : 0.0;
+                    f[3 * a] += fr_ * dx[a];
+                    f[3 * a + 1] += fr_ * dy[a];
+                    f[3 * a + 2] += fr_ * dz[a];
+                    fg[3 * a] += gr_ * dx[a];
+                    fg[3 * a + 1] += gr_ * dy[a];
+                    fg[3 * a + 2] += gr_ * dz[a];
+                }
+            }
+            pj[b] = load_pos(en, b);
+            lj[b] = load_lj(en, b);
+        }
+        e = en;
+        en = e2;
+        k += lpa;
+    }
+}
+
+#ifndef AMM_CBS_DUAL
+#define AMM_CBS_DUAL 512
+#endif
+template <int FAM, int CMODE, int GFAM, int BS>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_CTAB_WAVES_PER_EU)))
+k_cpair_dual(CPairArgs A, PairConsts c, PairConsts g) {
+    extern __shared__ __align__(16) char s_lds[];
+    for (int o = threadIdx.x * 16; o < A.host_bytes; o += BS * 16)
+        *reinterpret_cast<double2 *>(s_lds + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.host_tab) + o);
+    for (int o = threadIdx.x * 16; o < A.guest_bytes; o += BS * 16)
+        *reinterpret_cast<double2 *>(s_lds + A.host_bytes + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.guest_tab) + o);
+    const char *tabh = s_lds, *tabg = s_lds + A.host_bytes;
+    double *s_erfcx = reinterpret_cast<double *>(s_lds + A.host_bytes + A.guest_bytes);
+    for (int k = threadIdx.x; k < AMM_ERFCX_NI * AMM_ERFCX_NC; k += BS) s_erfcx[k] = amm_erfcx_table_dev_c[k];
+    double2 *s_li = reinterpret_cast<double2 *>(s_erfcx + AMM_ERFCX_NI * AMM_ERFCX_NC) + (threadIdx.x >> 6) * 192;
+    __syncthreads();
+
+    constexpr int WPB = BS / 64;
+    const int lane = threadIdx.x & 63;
+    const int lpa = 1 << A.lpa_shift;
+    const int sub = lane & (lpa - 1);
+    const int rpw = 64 >> A.lpa_shift;
+    const double sign = c.sign;
+    PairConsts c1 = c, g1 = g;
+    c1.sign = 1.0;
+    g1.sign = 1.0;
+    const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
+    const int per = (A.ntask + 7) >> 3;
+    const int t0 = min(xcd * per, A.ntask), t1 = min(t0 + per, A.ntask);
+    for (int task = t0 + (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); task < t1; task += nwx) {
+        const int a = task * rpw + (lane >> A.lpa_shift);
+        const bool valid = a < A.nrows;
+        const int cs = A.c_begin + (valid ? a : 0);
+        double4 pi[3];
+        int i_sites = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            pi[t] = A.posq[3 * cs + t];
+            pi[t].w *= c.Kc * sign;
+            double2 l = A.lj[3 * cs + t];
+            l.y *= sign;
+            s_li[64 * t + lane] = l;
+            if (__builtin_amdgcn_ballot_w64(valid && l.y != 0.0) != 0ull) i_sites |= 1 << t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double2 *li = s_li + lane;
+        const int nfront = valid ? A.nnb[a] : 0;
+        const int nn = valid ? A.nnb_total[a] : 0;
+        const int *row = A.nl + (size_t)(valid ? a : 0) * A.cap;
+        const bool edge = valid && !(pi[0].x >= A.margin && pi[0].x <= A.box.L[0] - A.margin && pi[0].y >= A.margin &&
+                                     pi[0].y <= A.box.L[1] - A.margin && pi[0].z >= A.margin && pi[0].z <= A.box.L[2] - A.margin);
+        const bool interior = __builtin_amdgcn_ballot_w64(edge) == 0ull;
+        double f[9], fg[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[k] = fg[k] = 0.0;
+        if (A.per_pair_image) cwalk_row_dual<FAM, CMODE, GFAM, 2>(A, c1, g1, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, fg);
+        else if (interior) cwalk_row_dual<FAM, CMODE, GFAM, 0>(A, c1, g1, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, fg);
+        else cwalk_row_dual<FAM, CMODE, GFAM, 1>(A, c1, g1, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, fg);
+        for (int off = lpa >> 1; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                f[k] += __shfl_xor(f[k], off);
+                fg[k] += __shfl_xor(fg[k], off);
+            }
+        }
+        if (valid && sub == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int i = A.sorted_out ? 3 * a + t : A.aperm[3 * cs + t];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    // (host first: when both forces go to the same buffer the guest adds to what the host just wrote)
+                    if (A.accumulate) A.force[3 * i + d] += f[3 * t + d];
+                    else A.force[3 * i + d] = f[3 * t + d];
+                    if (A.g_accumulate) A.gforce[3 * i + d] += fg[3 * t + d];
+                    else A.gforce[3 * i + d] = fg[3 * t + d];
+                }
+            }
+        }
+    }
+}
+
+template <int FAM, int CMODE, int GFAM>
+static int launch_cdual_i(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g) {
+    constexpr int BS = AMM_CBS_DUAL;
+    static CLaunchCfg cfg[64];
+    CLaunchCfg &k = cfg[ctx->device & 63];
+    const int lds = A.host_bytes + A.guest_bytes + AMM_ERFCX_NI * AMM_ERFCX_NC * 8 + (BS / 64) * 192 * 16;
+    auto kern = k_cpair_dual<FAM, CMODE, GFAM, BS>;
+    if (lds > k.lds_set) {
+        AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        k.lds_set = lds;
+        k.bpc = -1;
+    }
+    if (k.bpc < 0) {
+        int nb = 0;
+        AMM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BS, (size_t)lds));
+        if (nb < 1) {
+            amm_set_error("molecule-row fused pair kernel does not fit on a CU (LDS)");
+            return 1;
+        }
+        k.bpc = nb;
+    }
+    int &ncu = g_num_cu_c[ctx->device & 63];
+    if (!ncu) AMM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    constexpr int WPB = BS / 64;
+    long nblk = std::min((long)ncu * k.bpc, ((long)A.ntask + WPB - 1) / WPB);
+    nblk = std::max(8L, (nblk + 7) / 8 * 8);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, A, c, g);
+    return 0;
+}
+
+// fused pass: which (host, guest) pairs have a kernel.  Returns -1 when there is none (the caller launches the two forces one
+// after the other), 0 / 1 as the launch functions
+static int launch_cdual(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g) {
+    if (g.family != AMM_NEAR_FSWITCH) return -1;
+    if (c.family == AMM_DAMPED && c.degree == 1) return launch_cdual_i<AMM_DAMPED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+#ifndef AMM_CLUSTER_TUNE
+    if (c.family == AMM_DAMPED) return launch_cdual_i<AMM_DAMPED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+    if (c.family == AMM_NONBONDED) {
+        if (c.cmode == 1) return launch_cdual_i<AMM_NONBONDED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+        if (c.cmode == 2) return launch_cdual_i<AMM_NONBONDED, 2, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+        return launch_cdual_i<AMM_NONBONDED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+    }
+#endif
+    return -1;
+}
+
 
 template <int FAM, int CMODE>
 static int launch_cpair_i(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c) {
@@ -1088,9 +1364,28 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             e1 = pf->ev[pf->ev_used++];
             AMM_HIP(hipEventRecord(e0, st));
         }
-        int rc_ = launch_cpair(ctx, A, pf->pc);
+        int rc_ = 0;
+        bool fused = false;
+        if (guest) guest->last_fused = 0;
+        if (guest && ctx->opt_fuse_rows && A.nnb_total) {
+            // host and guest in ONE walk of the rows when a fused kernel exists for the two families
+            CPairArgs D = A;
+            D.guest_tab = guest->d_tab;
+            D.guest_bytes = guest->pc.tab.nint * AMM_TAB_STRIDE;
+            D.gforce = gout;
+            D.g_accumulate = (g_force == d_force && !exchange) ? 1 : g_accumulate;
+            D.gfac = (guest->pc.Kc * guest->pc.sign) / (pf->pc.Kc * pf->pc.sign);
+            D.gsr = guest->pc.sign / pf->pc.sign;
+            PairConsts gpc = guest->pc;
+            if (guest->desc.flags & AMM_GUARD_RC0) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);      // step(rc0 - r)
+            const int r = launch_cdual(ctx, D, pf->pc, gpc);
+            if (r > 0) return 1;
+            fused = r == 0;
+            if (fused) guest->last_fused = 1;
+        }
+        if (!fused) rc_ = launch_cpair(ctx, A, pf->pc);
         if (timed) AMM_HIP(hipEventRecord(e1, st));          // (the guest's launch below is timed under the guest's own id)
-        if (!rc_ && guest) {
+        if (!rc_ && guest && !fused) {
             // the guest force of the shared list (same particles, bitwise equal parameters: the host's sorted copies serve): a
             // second launch over the FRONT parts of the same rows, into its own buffer -- or, for the discount of
             // FarNonbondedForce, added to the host's (sign -1 and the step(rc0 - r) guard travel in its constants)

@@ -1817,7 +1817,10 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
                 else rc_ = launch_pair_tab<AMM_NONBONDED, 0>(st, gfam, A, pf->pc, gpc, T);
             }
             if (rc_) return 1;
-            if (guest) guest->n_evals++;
+            if (guest) {
+                guest->n_evals++;
+                guest->last_fused = 1;
+            }
         } else if (guest) {
             if (A.gsame || (guest->desc.flags & AMM_GUARD_RC0) || guest->pc.sign != 1.0) {
                 amm_set_error("dual evaluation of a guarded / signed guest needs the tabulated kernel (AMM_TAB=0?)");
@@ -1839,6 +1842,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             }
             if (rc_) return 1;
             guest->n_evals++;
+            guest->last_fused = 1;
         } else if (pf->pc.flags & (AMM_GROUP_LJ | AMM_GROUP_Q)) {
             if (pf->desc.family == AMM_NEAR_FSWITCH) launch_pair_grouped<AMM_NEAR_FSWITCH>(grid, block, st, guard, en, A, pf->pc);
             else if (pf->desc.family == AMM_NONBONDED && pf->pc.cmode == 0) launch_pair_grouped<AMM_NONBONDED>(grid, block, st, false, en, A, pf->pc);
@@ -1972,7 +1976,7 @@ int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos,
 }
 
 // bump when a pair-traversal kernel changes: stored measurements (profiles/*_traffic.json) are matched against it
-const char *amm_kernel_revision_impl() { return "r03-mol2"; }
+const char *amm_kernel_revision_impl() { return "r03-mol3"; }
 
 // radial Coulomb table of the force-only traversal (pair_tab.h): built from the descriptor alone, once per pair force
 int amm_pair_build_table(PairForce *pf) {

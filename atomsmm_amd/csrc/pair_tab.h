@@ -254,6 +254,12 @@ __device__ __forceinline__ double amm_tab_horner(const TabLookup &L) {
 // Lennard-Jones part of (-dE/dr)/r for mixed sig = (sigma_i + sigma_j)/2, eps4 = 4 sqrt(eps_i eps_j): the qq = 0 case of
 // amm_pair_math, same expressions and order of operations.  The pieces two forces of a shared list have in common
 // (1/r, (sigma/r)^6, (sigma/r)^12, the unswitched force) are formed once.
+// a + b rounded on its own, never contracted with a product that made a or b (HIP's __dadd_rn is a plain '+'): the force of a
+// pair must come out bit for bit the same from a stand-alone launch and from the guest part of a fused pass
+__device__ __forceinline__ double amm_sum_unfused(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
 struct LJCommon {
     double rinv, r, s6, s12, dlj_r;
 };

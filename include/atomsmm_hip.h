@@ -294,7 +294,9 @@ typedef struct {
     double rlist_outer;
     double tab_error;       /* largest relative interpolation error of the force's radial Coulomb table at its check points;
                                0 without a table (analytic kernels: family without one, or a table that missed 1e-13) */
-    int32_t has_table, pad2_;
+    int32_t has_table;
+    int32_t rode_along;     /* 1: this force's last force-only evaluation was computed inside its list owner's launch (molecule rows:
+                               the fused step-boundary pass), so it has no launch and no profile time of its own */
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
 /* Measurement helper (bench.py): the number of directed list entries of this force with r < r_within at d_pos, counted in

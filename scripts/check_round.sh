@@ -9,6 +9,6 @@ python bench.py --no-cpu-baseline --pme-steps 0 > gpurun_out/${tag}_bench.json |
 python - <<PY
 import json
 d = json.load(open("gpurun_out/${tag}_bench.json"))
-print(d["value"], "ns/day", d["ms_per_step"], "ms/step  near", d["detail"]["near_kernel_us"], "outer", d["detail"].get("outer_kernel_us"))
+print(d["value"], "ns/day", d["ms_per_step"], "ms/step  near", d["detail"]["near_kernel_us"], "boundary pass", d["detail"]["step_boundary_pass_us"])
 PY
 bash scripts/kstats_probe.sh ${tag}_w8 --cluster 1 --world 8 --rank 3 | grep world

@@ -42,6 +42,8 @@ def main():
     ap.add_argument('--world', type=int, default=1, help='emulate rank --rank of this many ranks (its slice of the rows, no collectives)')
     ap.add_argument('--rank', type=int, default=0)
     ap.add_argument('--cluster', type=int, default=1, help='1: molecule rows (product default for water), 0: per-atom rows')
+    ap.add_argument('--no-lj', action='store_true', help='all epsilons zero (diagnostics)')
+    ap.add_argument('--compare-fused', action='store_true', help='forces of the fused pass against the stand-alone launches, bit for bit')
     ap.add_argument('--option', action='append', default=[], help='name=value context option (amm_set_option), repeatable')
     args = ap.parse_args()
     if args.make_config:
@@ -55,6 +57,8 @@ def main():
         c['positions'] = np.load(CACHE)['positions']
     else:
         print('warning: no relaxed configuration (%s): timing the lattice start' % CACHE)
+    if args.no_lj:
+        c['epsilon'] = np.zeros_like(c['epsilon'])
     dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device='cuda')   # noqa: E731
     ctx = B.HipContext(n, c['box'], rank=args.rank, world=args.world)
     ctx.set_option('cluster', args.cluster)
@@ -83,6 +87,19 @@ def main():
     ctx.run_ops(dual, 2)
     ctx.check()
     torch.cuda.synchronize()
+    if args.compare_fused:
+        fused = [f[1].cpu().numpy().copy(), f[2].cpu().numpy().copy()]
+        ctx.run_ops(near_only, 1)
+        ctx.run_ops(far_only, 1)
+        torch.cuda.synchronize()
+        for name, a, b in (('near', fused[0], f[1].cpu().numpy()), ('outer', fused[1], f[2].cpu().numpy())):
+            d = np.abs(a - b)
+            print('%s: fused vs stand-alone max |diff| %.3e (max |f| %.3e), differing components %d of %d; rode_along %s' % (
+                name, d.max(), np.abs(b).max(), int((d != 0).sum()), d.size, ctx.pair_stats(fn).get('rode_along')))
+            if (d != 0).any():
+                i = np.argwhere(d != 0)[:5]
+                print('   first differing (atom, component):', i.tolist(), [float(d[tuple(k)]) for k in i])
+        return
     res = {}
     for label, ops, fid in (('near', near_only, fn), ('far', far_only, ff), ('dual', dual, ff)):
         ctx.run_ops(ops, 3)

@@ -180,9 +180,9 @@ def test_far_plus_near_equals_total(spcfw, method):
 def test_far_force_shares_one_list(spcfw, method, rows):
     """FarNonbondedForce = total + discount (forces.py:710-724): the reference -- and OpenMM -- run two passes over two neighbour
     lists; here the discount (a near force guarded by step(rc0 - r), sign -1) shares the total's neighbour list, its displacement
-    check and its sorted copies, and accumulates into the same force rows.  Per-atom rows (option cluster = 0): ONE kernel launch
-    for both, under the total's id.  Molecule rows (water, the default): one launch per force over the same rows -- the
-    discount's over their front parts.  Either way the forces equal the separate (energy-carrying, analytic) evaluations."""
+    check and its sorted copies, and accumulates into the same force rows: ONE kernel launch for both, under the total's id, with
+    per-atom rows (option cluster = 0) and with molecule rows (water, the default: the fused pass walks the front parts of the rows
+    for both forces).  Either way the forces equal the separate (energy-carrying, analytic) evaluations."""
     system, positions, topology = create_system(spcfw, nonbondedMethod=method, flexible=False)
     nbforce = atomsmm.hijackForce(system, atomsmm.findNonbondedForce(system))
     inner = atomsmm.NearNonbondedForce(7.0 * unit.angstroms, 6.5 * unit.angstroms, 'force-switch')
@@ -202,7 +202,8 @@ def test_far_force_shares_one_list(spcfw, method, rows):
     integrator.step(1)
     launches = {pid: eng.ctx.profile_read(pid)[0] for pid in ids}
     eng.ctx.profile_enable(False)
-    assert launches == {total: 1, discount: 1 if rows == 'molecule' else 0}
+    assert eng.ctx.pair_stats(discount)['rode_along'] == 1       # computed inside the total's launch
+    assert launches == {total: 1, discount: 0}
     assert eng.ctx.pair_stats(total)['list_kind'] == (1 if rows == 'molecule' else 0)
     assert eng.ctx.pair_stats(discount)['shares_list'] == 1 and eng.ctx.pair_stats(discount)['n_evals'] == 1
     fused = eng._buffers['f2'].cpu().numpy().copy()
