@@ -19,4 +19,4 @@ run_pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT
 run_pass grbm GRBM_GUI_ACTIVE TA_TA_BUSY_sum
 cd "$root"
 python3 scripts/pmc_summary.py "$out/${tag}_pmc.txt" "$out/${tag}_pmc_sq1" "$out/${tag}_pmc_lds" "$out/${tag}_pmc_grbm" > /dev/null
-grep -E "k_cpair_tab|k_cbuild|k_csort|k_cassign|k_pair_tab|k_build_nlist" "$out/${tag}_pmc.txt" | cut -c1-70,100-
+python3 scripts/pmc_table.py "$out/${tag}_pmc.txt"

@@ -17,4 +17,4 @@ run_pass if SQ_IFETCH SQ_IFETCH_LEVEL SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_TH
 run_pass fl SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_BRANCH SQ_INSTS_VALU_INT64
 cd "$root"
 python3 scripts/pmc_summary.py "$out/${tag}_pmc2.txt" "$out/${tag}_pmc_if" "$out/${tag}_pmc_fl" > /dev/null
-grep -E "k_cpair_tab|k_cbuild<false" "$out/${tag}_pmc2.txt" | sed -e "s/void //" | cut -c1-58,100-
+python3 scripts/pmc_table.py "$out/${tag}_pmc2.txt"

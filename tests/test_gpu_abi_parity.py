@@ -97,6 +97,47 @@ def test_narrow_switch_tables_meet_their_bound_or_are_not_used(spcfw, name):
     ctx.close()
 
 
+def test_molecule_rows_edge_cases(spcfw):
+    """Molecule rows (csrc/cluster.hip) on the reference's small water box: the box is too small for one periodic image per
+    molecule pair (the per-atom-pair image path), rows are rebuilt when whole molecules move, a molecule whose atoms drift
+    apart WITHIN the extent bound stays exact, and one stretched BEYOND the bound the cells were sized for is reported by
+    amm_check instead of giving silently incomplete forces."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    d = near('force-switch', 0.7, 0.5)
+    ctx = B.HipContext(n, c['box'])
+    fid = hip_pair(B, ctx, d, c)
+    f = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+
+    def check_against_oracle(pos):
+        ctx.force_eval(fid, dev(pos), f)
+        ctx.check()
+        ref = O.pair_eval(d, pos, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
+        assert np.abs(f.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
+
+    check_against_oracle(c['positions'])
+    st = ctx.pair_stats(fid)
+    assert st['list_kind'] == 1 and st['n_builds'] == 1
+    rng = np.random.default_rng(7)
+    # whole molecules move by up to 0.12 nm (beyond skin / 2: rebuild), every atom a little on top, across the box faces
+    pos = c['positions'].reshape(-1, 3, 3) + rng.uniform(-0.12, 0.12, (n // 3, 1, 3)) + rng.normal(0.0, 0.004, (n // 3, 3, 3))
+    pos = pos.reshape(n, 3) + np.array([0.4, -0.7, 1.3]) * c['box']
+    check_against_oracle(pos)
+    assert ctx.pair_stats(fid)['n_builds'] == 2
+    # a hydrogen 0.03 nm farther from its oxygen: inside the bound (1.5 x the first extent)
+    pos2 = pos.copy()
+    pos2[1] += 0.03 * (pos2[1] - pos2[0]) / np.linalg.norm(pos2[1] - pos2[0])
+    check_against_oracle(pos2)
+    # ... and 0.6 nm away: beyond it -- amm_check must say so
+    pos3 = pos.copy()
+    pos3[4] += np.array([0.6, 0.0, 0.0])
+    ctx.force_eval(fid, dev(pos3), f)
+    with pytest.raises(RuntimeError, match='stretched beyond'):
+        ctx.check()
+    ctx.close()
+
+
 @pytest.mark.parametrize('name', sorted(CASES))
 def test_pair_families_vs_oracle_and_goldens(spcfw, goldens, name):
     B = _backend()
