@@ -58,7 +58,8 @@ class PairStats(C.Structure):
                 ('lanes_per_atom', C.c_int32), ('n_cells', C.c_int32), ('rlist', C.c_double),
                 ('shares_list', C.c_int32), ('list_kind', C.c_int32), ('n_outer_builds', C.c_int64),
                 ('n_outer_pairs', C.c_int64), ('rlist_outer', C.c_double), ('tab_error', C.c_double),
-                ('has_table', C.c_int32), ('rode_along', C.c_int32)]
+                ('has_table', C.c_int32), ('rode_along', C.c_int32),
+                ('has_site_table', C.c_int32), ('pad3_', C.c_int32), ('site_tab_error', C.c_double)]
 
 
 def slice_per(n, world):

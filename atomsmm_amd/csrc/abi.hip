@@ -422,6 +422,29 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
             }
         }
         if (!seen) pf->site_hsig = pf->site_seps2 = 0.0;
+        // ... and one charge?  Then the pairs of two sites have ONE radial force function and a table of their own (pair_tab.h)
+        pf->site_one_charge = pf->one_site_class && seen;
+        pf->site_q = 0.0;
+        bool first = true;
+        for (int i = 0; i < n && pf->site_one_charge; ++i) {
+            if (h_eps[i] == 0.0) continue;
+            if (first) {
+                first = false;
+                pf->site_q = h_q[i];
+            } else if (h_q[i] != pf->site_q) {
+                pf->site_one_charge = false;
+            }
+        }
+        pf->site_atoms = 0;
+        for (int i = 0; i < n; ++i)
+            if (h_eps[i] != 0.0) pf->site_atoms |= 1 << (i % 3);
+        const double now[3] = {pf->site_hsig, pf->site_seps2, (pf->one_site_class && pf->site_one_charge) ? pf->site_q : 0.0};
+        if (pf->cluster_ok && (now[0] != pf->ss_built_for[0] || now[1] != pf->ss_built_for[1] || now[2] != pf->ss_built_for[2])) {
+            AMM_HIP(hipStreamSynchronize(ctx->stream));       // (kernels in flight read the tables about to be replaced)
+            if (amm_pair_build_table(pf)) return 1;
+            pf->dual_ok = -1;
+            pf->fuse_ok = -1;
+        }
     }
     // class of each atom for the traversal order: 1 = no Lennard-Jones site (its rows skip the LJ arithmetic)
     std::vector<int> cls(n);
@@ -1239,6 +1262,8 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     out->tab_error = pf->tab_error;
     out->has_table = (pf->pc.tab.nint > 0 && pf->d_tab) ? 1 : 0;
     out->rode_along = pf->last_fused;
+    out->has_site_table = (ctx->opt_site_tab && pf->d_tab_ss && pf->pc.tab.ss_first >= 0) ? 1 : 0;
+    out->site_tab_error = pf->ss_error;
     if (L->last_kind == 1 && L->cl && L->cl->built) {
         ClusterList *cl = L->cl;
         int flags[8];
@@ -1310,6 +1335,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "tab_dual_block") ctx->opt_tab_dual_bs = v;
     else if (k == "no_dual") ctx->opt_no_dual = v;
     else if (k == "fuse_rows") ctx->opt_fuse_rows = v;
+    else if (k == "site_tab") ctx->opt_site_tab = v;
     else if (k == "no_defer") ctx->opt_no_defer = v;
     else if (k == "terms_from") ctx->opt_terms_from = v;
     else if (k == "no_term_lanes") ctx->opt_no_term_lanes = v;

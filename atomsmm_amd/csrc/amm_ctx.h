@@ -29,6 +29,8 @@ struct PairTab {
     int baseA, nA;                      // zone A (w < 1): interval = (hi32(w) >> 13) - baseA, nA intervals
     int shiftB, rawB_minus_nA, halfB;   // zone B (w >= 1): interval = (hi32(w) >> shiftB) - rawB_minus_nA
     int nint;                           // all intervals; 0: the family has no table
+    int ss_first;                       // site-site table (pair_tab.h): first interval it covers; -1: none
+    double ss_r2min;                    // site pairs closer than this are below it (analytic path)
 };
 
 // Constants of one pair force, precomputed on the host and passed to kernels by value.
@@ -64,6 +66,12 @@ struct PairForce {
     bool force_rebuild_c = false;  // the molecule rows carry site bits of another site pattern
     bool one_site_class = false;   // all atoms with eps != 0 share ONE (sigma, eps): the molecule-row kernels carry them as constants
     double site_hsig = 0, site_seps2 = 0;
+    bool site_one_charge = false;  // ... and ONE charge (site_q): the site-site radial table of pair_tab.h can stand for their pairs
+    double site_q = 0;
+    int site_atoms = 7;            // bit a set when atom 3 m + a of some molecule m has a site (molecule-row forces)
+    double *d_tab_ss = nullptr;    // site-site table [nint - ss_first][6] (molecule-row kernels); null: none
+    double ss_error = 0;           // its largest relative interpolation error
+    double ss_built_for[3] = {0, 0, 0};     // (sigma/2, 2 sqrt(eps), q) the tables were last built for
     int last_fused = 0;            // 1: the last force-only evaluation rode on the list owner's launch (molecule rows, fused pass)
     int last_kind = 0;             // list walked by the last evaluation: 0 per-atom rows, 1 molecule rows (statistics)
     PairConsts pc;
@@ -244,6 +252,7 @@ struct amm_ctx {
     int opt_cluster = 1;           // molecule rows for qualifying forces (0: per-atom rows everywhere)
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
     int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
+    int opt_site_tab = 1;               // molecule rows: site-site radial tables instead of Lennard-Jones arithmetic where a force has one
     int opt_fuse_rows = 1;              // molecule rows: host + guest force of a shared list in ONE launch when a fused kernel exists
     int opt_no_dual = 0, opt_no_defer = 0, opt_terms_from = 8192, opt_no_term_lanes = 0;
     ListWatch watched[2];

@@ -29,11 +29,8 @@
 #include "pair_math.h"
 #include "pair_tab.h"
 
-#ifndef AMM_CW_USITE
-#define AMM_CW_USITE 0
-#endif
-#ifndef AMM_CW_STAGE2
-#define AMM_CW_STAGE2 0
+#ifndef AMM_EXP_NOLJ
+#define AMM_EXP_NOLJ 0        // measurement only: no Lennard-Jones arithmetic at all (wrong forces)
 #endif
 
 __device__ double amm_erfcx_table_dev_c[AMM_ERFCX_NI * AMM_ERFCX_NC];
@@ -515,35 +512,52 @@ struct CPairArgs {
     double margin;
     int ntask;
     int per_pair_image;
-    double hsig_site, seps2_site;      // sigma/2 and 2 sqrt(eps) of the system's one Lennard-Jones site class (AMM_CW_USITE)
-    // the guest force of a fused pass (k_cpair_dual): its table, its output and its factors relative to the host's
-    const double *guest_tab;
-    int guest_bytes, g_accumulate;
+    // site-site tables (pair_tab.h: SiteTable; kernels with SS): LDS byte offset FROM THE FORCE'S COULOMB TABLE to the place
+    // interval 0 of its site-site table would have, the bytes it really holds, and the site class for the analytic fallback
+    const double *host_tab_ss;
+    int host_ss_bytes, host_ss_off, site_atoms;      // site_atoms: bit a set when atom a of some molecule is a site
+    double hsig_site, seps2_site;
+    // the guest force of a fused pass: its tables, its output and its factors relative to the host's
+    const double *guest_tab, *guest_tab_ss;
+    int guest_bytes, guest_ss_bytes, guest_ss_off, g_accumulate;
     double *gforce;
     double gfac, gsr;                  // (Kc sign)_guest / (Kc sign)_host ; sign_guest / sign_host
 };
 
-// IMG: 0 interior rows (no periodic image), 1 one image per molecule pair (from the first atoms), 2 minimum image per atom pair
+// One walk of a wavefront's rows.  IMG: 0 interior rows (no periodic image), 1 one image per molecule pair (from the first
+// atoms), 2 minimum image per atom pair.  GFAM >= 0: the fused step-boundary pass (below).  SS: site-site tables.
 //
 // One trip = one partner molecule per lane = nine atom pairs, walked partner atom by partner atom (b outer, a inner).  Per partner
 // atom: geometry, index arithmetic and LDS reads of its three pairs are pinned AHEAD of the three Horner chains (a scheduling
 // barrier: left to itself the compiler waits for each pair's reads right behind them, s_waitcnt lgkmcnt(0) nine times per trip),
-// then the rare Lennard-Jones branch, then the accumulation.  When the three pairs of partner atom b are done its record is dead
-// and the same registers take the record of the NEXT trip's partner: the loads of trip t + 1 are in flight behind ~1 000 cycles
-// of arithmetic without a second register set.
+// then the Lennard-Jones part, then the accumulation.  When the three pairs of partner atom b are done its record is dead and the
+// same registers take the record of the NEXT trip's partner: the loads of trip t + 1 are in flight behind ~1 000 cycles of
+// arithmetic without a second register set.
 //
-// ONE force per launch.  The forms that evaluated the guest force of a shared list on the same walk (two radial tables, 18 more
-// accumulators) all spilled at 256 registers -- 72 to 436 bytes of scratch per lane, 200 us for DAMPED + near and 680 us for
-// Ewald-direct + near -- so the "dual pass" of molecule rows is two launches over the same rows: the outer force over the whole
-// rows, the near force over their front parts (140 + 63 us; the list check, the sorted copies and the rows are shared).
-template <int FAM, int CMODE, int IMG>
-__device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &c, const char *tabh, const double *s_erfcx,
-                                          const double4 (&pi)[3], const double2 *li, int i_sites, int my_sites, double sign_lj, const int *row,
-                                          int nfront, int nn, int sub, int lpa, int self, double (&f)[9]) {
-    // pi[a].w = sign Kc q_a (folded by the caller); li[a]: the row atoms' Lennard-Jones parameters (2 sqrt(eps) times the sign) in an
-    // LDS strip of the wavefront (only the rare pairs of two sites read them: 12 registers less)
+// Lennard-Jones part.  SS (every site of the force has the same sigma, eps and charge -- water): a pair of two sites reads the
+// site-site table instead of the Coulomb table -- the same interval, `ss_off` bytes further -- and that is all: no 1/r, no switch
+// in r, no parameter records (measured on the 98 304-atom box: near 68 -> 58 us, fused pass 174 -> 141 us with the arithmetic
+// removed; the table costs 4 integer instructions per partner atom).  Otherwise: analytically under a wave-uniform branch on the
+// partner's site bit, the row atoms' parameters in an LDS strip.
+//
+// Fused pass (GFAM >= 0): the step boundary of RESPA needs the outer force over the whole rows AND the near force over their
+// front parts.  As two launches the front entries are gathered and their geometry formed twice; here the guest rides on the
+// host's walk: per partner atom the host's three look-ups, Horner chains and accumulation come first, then -- only on trips where
+// some row of the wavefront is still in its front part (wave-uniform) -- the guest's three look-ups into its own tables, into a
+// second set of nine accumulators.  The scheduling barriers keep the two forces' look-up registers from being live together
+// (the forms with the guest inside the host's nine-pair body all spilled: 72 to 436 bytes of scratch per lane).  Product and sum
+// of the guest are rounded as its stand-alone launch rounds them: the same bits either way.
+template <int FAM, int CMODE, int GFAM, int IMG, int SMASK>
+__device__ __forceinline__ void cwalk_rows(const CPairArgs &A, const PairConsts &c, const PairConsts &g, const char *tabh, const char *tabg,
+                                           const double *erfcx, const double4 (&pi)[3], const double2 *li, int i_sites, const int (&so)[3],
+                                           const int (&sog)[3], double sign_lj, const int *row, int nfront, int nn, int sub, int lpa,
+                                           int self, double (&f)[9], double (&fg)[9]) {
+    constexpr bool DUAL = GFAM >= 0;
+    constexpr bool SS = SMASK != 0;          // SMASK: the row atoms that can be sites (1: only the first -- water; 7: any)
     const int back = A.cap - 1 + nfront;
-    const double r2low = c.tab.r2min;      // closer pairs are left out of the main path and redone analytically below
+    // closer pairs are left out of the main path and redone analytically below (never in a liquid)
+    const double r2low = DUAL ? fmax(c.tab.r2min, g.tab.r2min) : c.tab.r2min;
+    const double r2low_ss = DUAL ? fmax(c.tab.ss_r2min, g.tab.ss_r2min) : c.tab.ss_r2min;
     auto entry = [&](int k) { return k < nn ? row[k < nfront ? k : back - k] : self; };
     auto load_pos = [&](int e, int b) {
         return *reinterpret_cast<const double4 *>(reinterpret_cast<const char *>(A.posq) + (size_t)((unsigned)e & 0x1fffffffu) * 96u + 32 * b);
@@ -562,11 +576,12 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         pj[b] = load_pos(e, b);
-        if (!AMM_CW_USITE) lj[b] = load_lj(e, b);
+        if (!SS) lj[b] = load_lj(e, b);
     }
-    const double sig_site = 2.0 * A.hsig_site, eps4_site = A.seps2_site * A.seps2_site * sign_lj;
     while (__builtin_amdgcn_ballot_w64(k < nn) != 0ull) {
         const bool ok = k < nn;
+        const bool front = k < nfront;
+        const bool any_front = DUAL && __builtin_amdgcn_ballot_w64(front) != 0ull;
         const unsigned bits = (unsigned)e >> 29;
         const int e2 = entry(k + 2 * lpa);           // the entry after next: its index is there when the next trip starts
         double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -578,241 +593,8 @@ __device__ __forceinline__ void cwalk_row(const CPairArgs &A, const PairConsts &
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             const double xb = pj[b].x - sx, yb = pj[b].y - sy, zb = pj[b].z - sz, qb = pj[b].w;
-            double dx[3], dy[3], dz[3], r2[3], fr[3];
-            TabLookup th[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                dx[a] = pi[a].x - xb;
-                dy[a] = pi[a].y - yb;
-                dz[a] = pi[a].z - zb;
-                if (IMG == 2) {
-                    dx[a] = amm_min_image(dx[a], A.box.L[0], A.box.invL[0]);
-                    dy[a] = amm_min_image(dy[a], A.box.L[1], A.box.invL[1]);
-                    dz[a] = amm_min_image(dz[a], A.box.L[2], A.box.invL[2]);
-                }
-                r2[a] = dx[a] * dx[a] + dy[a] * dy[a] + dz[a] * dz[a];
-#if !AMM_CW_STAGE2
-                th[a] = amm_tab_fetch(tabh, c.tab, r2[a]);
-#endif
-            }
-#if AMM_CW_STAGE2
-            // two look-ups in flight, the third issued while the first is evaluated (14 registers less than three at once)
-            th[0] = amm_tab_fetch(tabh, c.tab, r2[0]);
-            th[1] = amm_tab_fetch(tabh, c.tab, r2[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            fr[0] = (pi[0].w * qb) * amm_tab_horner(th[0]);
-            th[2] = amm_tab_fetch(tabh, c.tab, r2[2]);
-            __builtin_amdgcn_sched_barrier(0);
-            fr[1] = (pi[1].w * qb) * amm_tab_horner(th[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            fr[2] = (pi[2].w * qb) * amm_tab_horner(th[2]);
-#else
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) fr[a] = (pi[a].w * qb) * amm_tab_horner(th[a]);
-#endif
-            // Lennard-Jones part: only where two sites can meet (wave-uniform); the other lanes add an exact zero (eps4 = 0)
-            if (i_sites != 0 && __builtin_amdgcn_ballot_w64(ok && ((bits >> b) & 1u)) != 0ull) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    if ((i_sites >> a) & 1) {
-#if AMM_CW_USITE
-                        // one site class in the system (water: the oxygens): its parameters are constants of the launch, the
-                        // per-lane site bits decide which lanes' pairs are site-site
-                        const bool both = ((my_sites >> a) & 1) && ((bits >> b) & 1u);
-                        const double sig = sig_site, eps4 = both ? eps4_site : 0.0;
-#else
-                        const double2 la = li[64 * a];
-                        const double sig = la.x + lj[b].x, eps4 = la.y * lj[b].y;
-#endif
-                        const LJCommon L = amm_lj_common(r2[a], sig, eps4);
-                        fr[a] = amm_sum_unfused(fr[a], amm_lj_force<FAM, CMODE>(c, L, sig, eps4));
-                    }
-            }
-            bool any_low = false;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const bool low = r2[a] < r2low;
-                const bool pass = ok && (r2[a] < c.rc2);
-                any_low = any_low || (pass && low);
-                const double fh = (pass && !low) ? fr[a] : 0.0;
-                f[3 * a] += fh * dx[a];
-                f[3 * a + 1] += fh * dy[a];
-                f[3 * a + 2] += fh * dz[a];
-            }
-            if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {       // closer than the table reaches: analytic (never in a liquid)
-                for (int a = 0; a < 3; ++a) {
-                    const bool low = ok && (r2[a] < c.rc2) && (r2[a] < r2low);
-#if AMM_CW_USITE
-                    const bool both = ((my_sites >> a) & 1) && ((bits >> b) & 1u);
-                    const double sg = sig_site, e4 = both ? eps4_site : 0.0;
-#else
-                    const double2 lx = A.lj[3 * ((unsigned)e & 0x1fffffffu) + b];
-                    const double2 la = li[64 * a];
-                    const double sg = la.x + lx.x, e4 = la.y * lx.y;
-#endif
-                    double e_, fr_;
-                    // (pi.w and the epsilons carry the sign already: the math runs with sign 1)
-                    amm_pair_math<FAM, CMODE, false, false>(c, low ? r2[a] : 1.0, pi[a].w * qb, sg, e4, e_, fr_, s_erfcx);
-                    fr_ = low ? fr_ : 0.0;
-                    f[3 * a] += fr_ * dx[a];
-                    f[3 * a + 1] += fr_ * dy[a];
-                    f[3 * a + 2] += fr_ * dz[a];
-                }
-            }
-            // this partner atom's record is dead: its registers take the next trip's (the image shift of THIS trip is in sx, sy, sz)
-            pj[b] = load_pos(en, b);
-            if (!AMM_CW_USITE) lj[b] = load_lj(en, b);
-        }
-        e = en;
-        en = e2;
-        k += lpa;
-    }
-}
-
-#ifndef AMM_CBS_SINGLE
-#define AMM_CBS_SINGLE 512
-#endif
-#ifndef AMM_CTAB_WAVES_PER_EU
-#define AMM_CTAB_WAVES_PER_EU 1
-#endif
-template <int FAM, int CMODE, int BS>
-__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_CTAB_WAVES_PER_EU)))
-k_cpair_tab(CPairArgs A, PairConsts c) {
-    extern __shared__ __align__(16) char s_lds[];
-    for (int o = threadIdx.x * 16; o < A.host_bytes; o += BS * 16)
-        *reinterpret_cast<double2 *>(s_lds + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.host_tab) + o);
-#if defined(AMM_EXP_TAB_GLOBAL)           // measurement only: the table is read through the vector-memory path instead of LDS
-    const char *tabh = reinterpret_cast<const char *>(A.host_tab);
-#else
-    const char *tabh = s_lds;
-#endif
-    double *s_erfcx = reinterpret_cast<double *>(s_lds + A.host_bytes);
-    for (int k = threadIdx.x; k < AMM_ERFCX_NI * AMM_ERFCX_NC; k += BS) s_erfcx[k] = amm_erfcx_table_dev_c[k];
-    // Lennard-Jones parameters of the rows' atoms: [wave][atom][lane] (read by the rare site-site pairs only)
-    double2 *s_li = reinterpret_cast<double2 *>(s_erfcx + AMM_ERFCX_NI * AMM_ERFCX_NC) + (threadIdx.x >> 6) * 192;
-    __syncthreads();
-
-    constexpr int WPB = BS / 64;
-    const int lane = threadIdx.x & 63;
-    const int lpa = 1 << A.lpa_shift;
-    const int sub = lane & (lpa - 1);
-    const int rpw = 64 >> A.lpa_shift;
-    const double sign = c.sign;
-    PairConsts c1 = c;
-    c1.sign = 1.0;          // the sign travels with the row atoms' charges and epsilons (every family is linear in both)
-    // one contiguous eighth of the tasks per XCD (blockIdx & 7): consecutive cell-sorted rows = one slab of the box per L2
-    const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
-    const int per = (A.ntask + 7) >> 3;
-    const int t0 = min(xcd * per, A.ntask), t1 = min(t0 + per, A.ntask);
-    for (int task = t0 + (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); task < t1; task += nwx) {
-        const int a = task * rpw + (lane >> A.lpa_shift);
-        const bool valid = a < A.nrows;
-        const int cs = A.c_begin + (valid ? a : 0);
-        double4 pi[3];
-        int i_sites = 0, my_sites = 0;
-        __builtin_amdgcn_wave_barrier();                 // the previous task's reads of the strip are done
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            pi[t] = A.posq[3 * cs + t];
-            pi[t].w *= c.Kc * sign;
-            double2 l = A.lj[3 * cs + t];
-            l.y *= sign;
-            if (!AMM_CW_USITE) s_li[64 * t + lane] = l;
-            if (valid && l.y != 0.0) my_sites |= 1 << t;
-            if (__builtin_amdgcn_ballot_w64(valid && l.y != 0.0) != 0ull) i_sites |= 1 << t;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double2 *li = s_li + lane;                 // li[64 a]
-        const int nfront = valid ? A.nnb[a] : 0;
-        const int nn = valid ? (A.nnb_total ? A.nnb_total[a] : nfront) : 0;
-        const int *row = A.nl + (size_t)(valid ? a : 0) * A.cap;
-        const bool edge = valid && !(pi[0].x >= A.margin && pi[0].x <= A.box.L[0] - A.margin && pi[0].y >= A.margin &&
-                                     pi[0].y <= A.box.L[1] - A.margin && pi[0].z >= A.margin && pi[0].z <= A.box.L[2] - A.margin);
-        const bool interior = __builtin_amdgcn_ballot_w64(edge) == 0ull;
-        double f[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) f[k] = 0.0;
-        if (A.per_pair_image) cwalk_row<FAM, CMODE, 2>(A, c1, tabh, s_erfcx, pi, li, i_sites, my_sites, sign, row, nfront, nn, sub, lpa, cs, f);
-        else if (interior) cwalk_row<FAM, CMODE, 0>(A, c1, tabh, s_erfcx, pi, li, i_sites, my_sites, sign, row, nfront, nn, sub, lpa, cs, f);
-        else cwalk_row<FAM, CMODE, 1>(A, c1, tabh, s_erfcx, pi, li, i_sites, my_sites, sign, row, nfront, nn, sub, lpa, cs, f);
-        for (int off = lpa >> 1; off > 0; off >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) f[k] += __shfl_xor(f[k], off);
-        }
-        if (valid && sub == 0) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int i = A.sorted_out ? 3 * a + t : A.aperm[3 * cs + t];
-                if (A.accumulate) {
-                    A.force[3 * i] += f[3 * t];
-                    A.force[3 * i + 1] += f[3 * t + 1];
-                    A.force[3 * i + 2] += f[3 * t + 2];
-                } else {
-                    A.force[3 * i] = f[3 * t];
-                    A.force[3 * i + 1] = f[3 * t + 1];
-                    A.force[3 * i + 2] = f[3 * t + 2];
-                }
-            }
-        }
-    }
-}
-
-// per (device, kernel) launch configuration: dynamic LDS attribute + blocks per CU from the occupancy query
-struct CLaunchCfg {
-    int lds_set = 0, bpc = -1;
-};
-static int g_num_cu_c[64] = {0};
-
-// ------------------------------------------------------------------------------------------------ fused pass (host + guest)
-// The step-boundary pass of RESPA needs the outer force over the whole rows AND the near force over their front parts.  As two
-// launches the front entries are gathered and their geometry formed twice; here the guest rides on the host's walk: per partner
-// atom the host's three look-ups, Horner chains and accumulation come first, then -- only on trips where some row of the
-// wavefront is still in its front part (wave-uniform) -- the guest's three look-ups into its own table (second LDS region),
-// into a second set of nine accumulators.  The scheduling barriers keep the two forces' look-up registers from being live
-// together.
-template <int FAM, int CMODE, int GFAM, int IMG>
-__device__ __forceinline__ void cwalk_row_dual(const CPairArgs &A, const PairConsts &c, const PairConsts &g, const char *tabh, const char *tabg,
-                                               const double *s_erfcx, const double4 (&pi)[3], const double2 *li, int i_sites, const int *row,
-                                               int nfront, int nn, int sub, int lpa, int self, double (&f)[9], double (&fg)[9]) {
-    const int back = A.cap - 1 + nfront;
-    const double r2low = fmax(c.tab.r2min, g.tab.r2min);      // closer pairs: both forces analytically (never in a liquid)
-    auto entry = [&](int k) { return k < nn ? row[k < nfront ? k : back - k] : self; };
-    auto load_pos = [&](int e, int b) {
-        return *reinterpret_cast<const double4 *>(reinterpret_cast<const char *>(A.posq) + (size_t)((unsigned)e & 0x1fffffffu) * 96u + 32 * b);
-    };
-    auto load_lj = [&](int e, int b) {
-        double2 l = make_double2(0.0, 0.0);
-        if (i_sites != 0 && __builtin_amdgcn_ballot_w64((((unsigned)e >> 29) >> b) & 1u) != 0ull)
-            l = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.lj) + (size_t)((unsigned)e & 0x1fffffffu) * 48u + 16 * b);
-        return l;
-    };
-    double4 pj[3];
-    double2 lj[3];
-    int k = sub;
-    int e = entry(k), en = entry(k + lpa);
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        pj[b] = load_pos(e, b);
-        lj[b] = load_lj(e, b);
-    }
-    while (__builtin_amdgcn_ballot_w64(k < nn) != 0ull) {
-        const bool ok = k < nn;
-        const bool front = k < nfront;
-        const bool any_front = __builtin_amdgcn_ballot_w64(front) != 0ull;
-        const unsigned bits = (unsigned)e >> 29;
-        const int e2 = entry(k + 2 * lpa);
-        double sx = 0.0, sy = 0.0, sz = 0.0;
-        if (IMG == 1) {
-            sx = A.box.L[0] * rint((pj[0].x - pi[0].x) * A.box.invL[0]);
-            sy = A.box.L[1] * rint((pj[0].y - pi[0].y) * A.box.invL[1]);
-            sz = A.box.L[2] * rint((pj[0].z - pi[0].z) * A.box.invL[2]);
-        }
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const double xb = pj[b].x - sx, yb = pj[b].y - sy, zb = pj[b].z - sz, qb = pj[b].w;
+            // SS: all ones where the partner atom is a site (bit field extract with sign extension)
+            const int mb = SS ? -(int)((bits >> b) & 1u) : 0;
             double dx[3], dy[3], dz[3], r2[3], fr[3], gl[3];
             {
                 TabLookup th[3];
@@ -827,14 +609,15 @@ __device__ __forceinline__ void cwalk_row_dual(const CPairArgs &A, const PairCon
                         dz[a] = amm_min_image(dz[a], A.box.L[2], A.box.invL[2]);
                     }
                     r2[a] = dx[a] * dx[a] + dy[a] * dy[a] + dz[a] * dz[a];
-                    th[a] = amm_tab_fetch(tabh, c.tab, r2[a]);
-                    gl[a] = 0.0;
+                    th[a] = amm_tab_fetch(tabh, c.tab, r2[a], ((SMASK >> a) & 1) ? (unsigned)(so[a] & mb) : 0u);
+                    if (DUAL) gl[a] = 0.0;
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) fr[a] = (pi[a].w * qb) * amm_tab_horner(th[a]);
             }
-            if (i_sites != 0 && __builtin_amdgcn_ballot_w64(ok && ((bits >> b) & 1u)) != 0ull) {
+            // Lennard-Jones part, analytic: only where two sites can meet (wave-uniform); the other lanes add an exact zero (eps4 = 0)
+            if (!SS && !AMM_EXP_NOLJ && i_sites != 0 && __builtin_amdgcn_ballot_w64(ok && ((bits >> b) & 1u)) != 0ull) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
                     if ((i_sites >> a) & 1) {
@@ -842,17 +625,21 @@ __device__ __forceinline__ void cwalk_row_dual(const CPairArgs &A, const PairCon
                         const double sig = la.x + lj[b].x, eps4 = la.y * lj[b].y;
                         const LJCommon L = amm_lj_common(r2[a], sig, eps4);
                         fr[a] = amm_sum_unfused(fr[a], amm_lj_force<FAM, CMODE>(c, L, sig, eps4));
-                        if (any_front) {     // the guest's Lennard-Jones force from the same 1/r, (sigma/r)^6 ... (a sign apart)
+                        if (DUAL && any_front) {     // the guest's Lennard-Jones force from the same 1/r, (sigma/r)^6 ... (a sign apart)
                             LJCommon Lg = L;
                             Lg.dlj_r *= A.gsr;
-                            gl[a] = amm_lj_force<GFAM, 0>(g, Lg, sig, eps4 * A.gsr);
+                            gl[a] = amm_lj_force<(DUAL ? GFAM : FAM), 0>(g, Lg, sig, eps4 * A.gsr);
                         }
                     }
             }
             bool any_low = false;
+            bool lowp[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const bool low = r2[a] < r2low;
+                bool low = r2[a] < r2low;
+                // (a site pair below its own table; no branch here: a branch in this loop costs more than it skips)
+                if ((SMASK >> a) & 1) low = low || ((so[a] & mb) != 0 && r2[a] < r2low_ss);
+                lowp[a] = low;
                 const bool pass = ok && (r2[a] < c.rc2);
                 any_low = any_low || (ok && low);
                 const double fh = (pass && !low) ? fr[a] : 0.0;
@@ -860,44 +647,58 @@ __device__ __forceinline__ void cwalk_row_dual(const CPairArgs &A, const PairCon
                 f[3 * a + 1] += fh * dy[a];
                 f[3 * a + 2] += fh * dz[a];
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (any_front) {
-                TabLookup tg[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) tg[a] = amm_tab_fetch(tabg, g.tab, r2[a]);
+            if (DUAL) {
                 __builtin_amdgcn_sched_barrier(0);
+                if (any_front) {
+                    TabLookup tg[3];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    // (product and sum rounded separately, as the stand-alone launch forms them: the same bits either way)
-                    const double gr = amm_sum_unfused(((pi[a].w * qb) * A.gfac) * amm_tab_horner(tg[a]), gl[a]);
-                    const bool pass = front && (r2[a] < g.rc2) && !(r2[a] < r2low);
-                    const double gh = pass ? gr : 0.0;
-                    fg[3 * a] += gh * dx[a];
-                    fg[3 * a + 1] += gh * dy[a];
-                    fg[3 * a + 2] += gh * dz[a];
+                    for (int a = 0; a < 3; ++a) tg[a] = amm_tab_fetch(tabg, g.tab, r2[a], ((SMASK >> a) & 1) ? (unsigned)(sog[a] & mb) : 0u);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const double gr = amm_sum_unfused(((pi[a].w * qb) * A.gfac) * amm_tab_horner(tg[a]), gl[a]);
+                        const bool pass = front && (r2[a] < g.rc2) && !lowp[a];
+                        const double gh = pass ? gr : 0.0;
+                        fg[3 * a] += gh * dx[a];
+                        fg[3 * a + 1] += gh * dy[a];
+                        fg[3 * a + 2] += gh * dz[a];
+                    }
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {       // closer than a table reaches: analytic
                 for (int a = 0; a < 3; ++a) {
-                    const bool low = ok && (r2[a] < r2low);
-                    const double2 lx = A.lj[3 * ((unsigned)e & 0x1fffffffu) + b];
-                    const double2 la = li[64 * a];
-                    const double sg = la.x + lx.x, e4 = la.y * lx.y;
-                    double e_, fr_, gr_;
-                    amm_pair_math<FAM, CMODE, false, false>(c, low ? r2[a] : 1.0, pi[a].w * qb, sg, e4, e_, fr_, s_erfcx);
-                    amm_pair_math<GFAM, 0, false, false>(g, low ? r2[a] : 1.0, (pi[a].w * qb) * A.gfac, sg, e4 * A.gsr, e_, gr_, s_erfcx);
+                    const bool low = ok && lowp[a];
+                    double sg, e4;
+                    if (SS) {
+                        const bool both = ((SMASK >> a) & 1) && (so[a] & mb) != 0;
+                        sg = 2.0 * A.hsig_site;
+                        e4 = both ? A.seps2_site * A.seps2_site * sign_lj : 0.0;
+                    } else {
+                        const double2 lx = A.lj[3 * ((unsigned)e & 0x1fffffffu) + b];
+                        const double2 la = li[64 * a];
+                        sg = la.x + lx.x;
+                        e4 = la.y * lx.y;
+                    }
+                    double e_, fr_;
+                    // (pi.w and the epsilons carry the sign already: the math runs with sign 1)
+                    amm_pair_math<FAM, CMODE, false, false>(c, low ? r2[a] : 1.0, pi[a].w * qb, sg, e4, e_, fr_, erfcx);
                     fr_ = (low && r2[a] < c.rc2) ? fr_ : 0.0;
-                    gr_ = (low && front && r2[a] < g.rc2) ? gr_ : 0.0;
                     f[3 * a] += fr_ * dx[a];
                     f[3 * a + 1] += fr_ * dy[a];
                     f[3 * a + 2] += fr_ * dz[a];
-                    fg[3 * a] += gr_ * dx[a];
-                    fg[3 * a + 1] += gr_ * dy[a];
-                    fg[3 * a + 2] += gr_ * dz[a];
+                    if (DUAL) {
+                        double gr_;
+                        amm_pair_math<(DUAL ? GFAM : FAM), 0, false, false>(g, low ? r2[a] : 1.0, (pi[a].w * qb) * A.gfac, sg, e4 * A.gsr, e_, gr_, erfcx);
+                        gr_ = (low && front && r2[a] < g.rc2) ? gr_ : 0.0;
+                        fg[3 * a] += gr_ * dx[a];
+                        fg[3 * a + 1] += gr_ * dy[a];
+                        fg[3 * a + 2] += gr_ * dz[a];
+                    }
                 }
             }
+            // this partner atom's record is dead: its registers take the next trip's (the image shift of THIS trip is in sx, sy, sz)
             pj[b] = load_pos(en, b);
-            lj[b] = load_lj(en, b);
+            if (!SS) lj[b] = load_lj(en, b);
         }
         e = en;
         en = e2;
@@ -905,21 +706,51 @@ __device__ __forceinline__ void cwalk_row_dual(const CPairArgs &A, const PairCon
     }
 }
 
-#ifndef AMM_CBS_DUAL
-#define AMM_CBS_DUAL 512
+#ifndef AMM_CBS_SINGLE
+#define AMM_CBS_SINGLE 512
 #endif
-template <int FAM, int CMODE, int GFAM, int BS>
+#ifndef AMM_CTAB_WAVES_PER_EU
+#define AMM_CTAB_WAVES_PER_EU 1
+#endif
+// LDS: [host Coulomb table][guest Coulomb table][host site-site table][guest site-site table][erfcx table][parameter strips];
+// kernels with site-site tables need neither strips nor -- in LDS -- the erfcx table (their rare analytic path reads it from HBM)
+template <int FAM, int CMODE, int GFAM, int BS, int SMASK>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_CTAB_WAVES_PER_EU)))
-k_cpair_dual(CPairArgs A, PairConsts c, PairConsts g) {
+k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
+    constexpr bool DUAL = GFAM >= 0;
+    constexpr bool SS = SMASK != 0;
     extern __shared__ __align__(16) char s_lds[];
-    for (int o = threadIdx.x * 16; o < A.host_bytes; o += BS * 16)
-        *reinterpret_cast<double2 *>(s_lds + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.host_tab) + o);
-    for (int o = threadIdx.x * 16; o < A.guest_bytes; o += BS * 16)
-        *reinterpret_cast<double2 *>(s_lds + A.host_bytes + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(A.guest_tab) + o);
-    const char *tabh = s_lds, *tabg = s_lds + A.host_bytes;
-    double *s_erfcx = reinterpret_cast<double *>(s_lds + A.host_bytes + A.guest_bytes);
-    for (int k = threadIdx.x; k < AMM_ERFCX_NI * AMM_ERFCX_NC; k += BS) s_erfcx[k] = amm_erfcx_table_dev_c[k];
-    double2 *s_li = reinterpret_cast<double2 *>(s_erfcx + AMM_ERFCX_NI * AMM_ERFCX_NC) + (threadIdx.x >> 6) * 192;
+    auto stage = [&](int at, const double *src, int bytes) {
+        for (int o = threadIdx.x * 16; o < bytes; o += BS * 16)
+            *reinterpret_cast<double2 *>(s_lds + at + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(src) + o);
+    };
+    const int gbytes = DUAL ? A.guest_bytes : 0;
+    stage(0, A.host_tab, A.host_bytes);
+    if (DUAL) stage(A.host_bytes, A.guest_tab, gbytes);
+    int used = A.host_bytes + gbytes;
+    if (SS) {
+        stage(used, A.host_tab_ss, A.host_ss_bytes);
+        used += A.host_ss_bytes;
+        if (DUAL) {
+            stage(used, A.guest_tab_ss, A.guest_ss_bytes);
+            used += A.guest_ss_bytes;
+        }
+    }
+#if defined(AMM_EXP_TAB_GLOBAL)           // measurement only: the table is read through the vector-memory path instead of LDS
+    const char *tabh = reinterpret_cast<const char *>(A.host_tab);
+#else
+    const char *tabh = s_lds;
+#endif
+    const char *tabg = s_lds + A.host_bytes;
+    const double *erfcx = amm_erfcx_table_dev_c;
+    double2 *s_li = nullptr;
+    if (!SS) {
+        double *s_erfcx = reinterpret_cast<double *>(s_lds + used);
+        for (int k = threadIdx.x; k < AMM_ERFCX_NI * AMM_ERFCX_NC; k += BS) s_erfcx[k] = amm_erfcx_table_dev_c[k];
+        erfcx = s_erfcx;
+        // Lennard-Jones parameters of the rows' atoms: [wave][atom][lane] (read by the site-site pairs only)
+        s_li = reinterpret_cast<double2 *>(s_erfcx + AMM_ERFCX_NI * AMM_ERFCX_NC) + (threadIdx.x >> 6) * 192;
+    }
     __syncthreads();
 
     constexpr int WPB = BS / 64;
@@ -929,8 +760,9 @@ k_cpair_dual(CPairArgs A, PairConsts c, PairConsts g) {
     const int rpw = 64 >> A.lpa_shift;
     const double sign = c.sign;
     PairConsts c1 = c, g1 = g;
-    c1.sign = 1.0;
+    c1.sign = 1.0;          // the sign travels with the row atoms' charges and epsilons (every family is linear in both)
     g1.sign = 1.0;
+    // one contiguous eighth of the tasks per XCD (blockIdx & 7): consecutive cell-sorted rows = one slab of the box per L2
     const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
     const int per = (A.ntask + 7) >> 3;
     const int t0 = min(xcd * per, A.ntask), t1 = min(t0 + per, A.ntask);
@@ -940,22 +772,30 @@ k_cpair_dual(CPairArgs A, PairConsts c, PairConsts g) {
         const int cs = A.c_begin + (valid ? a : 0);
         double4 pi[3];
         int i_sites = 0;
-        __builtin_amdgcn_wave_barrier();
+        int so[3] = {0, 0, 0}, sog[3] = {0, 0, 0};
+        if (!SS) __builtin_amdgcn_wave_barrier();        // the previous task's reads of the strip are done
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             pi[t] = A.posq[3 * cs + t];
             pi[t].w *= c.Kc * sign;
             double2 l = A.lj[3 * cs + t];
             l.y *= sign;
-            s_li[64 * t + lane] = l;
-            if (__builtin_amdgcn_ballot_w64(valid && l.y != 0.0) != 0ull) i_sites |= 1 << t;
+            if (!SS) s_li[64 * t + lane] = l;
+            const bool site = valid && l.y != 0.0;
+            if ((SMASK >> t) & 1) {
+                so[t] = site ? A.host_ss_off : 0;
+                if (DUAL) sog[t] = site ? A.guest_ss_off : 0;
+            }
+            if (__builtin_amdgcn_ballot_w64(site) != 0ull) i_sites |= 1 << t;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double2 *li = s_li + lane;
+        if (!SS) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const double2 *li = SS ? nullptr : s_li + lane;  // li[64 a]
         const int nfront = valid ? A.nnb[a] : 0;
-        const int nn = valid ? A.nnb_total[a] : 0;
+        const int nn = valid ? (A.nnb_total ? A.nnb_total[a] : nfront) : 0;
         const int *row = A.nl + (size_t)(valid ? a : 0) * A.cap;
         const bool edge = valid && !(pi[0].x >= A.margin && pi[0].x <= A.box.L[0] - A.margin && pi[0].y >= A.margin &&
                                      pi[0].y <= A.box.L[1] - A.margin && pi[0].z >= A.margin && pi[0].z <= A.box.L[2] - A.margin);
@@ -963,14 +803,14 @@ k_cpair_dual(CPairArgs A, PairConsts c, PairConsts g) {
         double f[9], fg[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) f[k] = fg[k] = 0.0;
-        if (A.per_pair_image) cwalk_row_dual<FAM, CMODE, GFAM, 2>(A, c1, g1, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, fg);
-        else if (interior) cwalk_row_dual<FAM, CMODE, GFAM, 0>(A, c1, g1, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, fg);
-        else cwalk_row_dual<FAM, CMODE, GFAM, 1>(A, c1, g1, tabh, tabg, s_erfcx, pi, li, i_sites, row, nfront, nn, sub, lpa, cs, f, fg);
+        if (A.per_pair_image) cwalk_rows<FAM, CMODE, GFAM, 2, SMASK>(A, c1, g1, tabh, tabg, erfcx, pi, li, i_sites, so, sog, sign, row, nfront, nn, sub, lpa, cs, f, fg);
+        else if (interior) cwalk_rows<FAM, CMODE, GFAM, 0, SMASK>(A, c1, g1, tabh, tabg, erfcx, pi, li, i_sites, so, sog, sign, row, nfront, nn, sub, lpa, cs, f, fg);
+        else cwalk_rows<FAM, CMODE, GFAM, 1, SMASK>(A, c1, g1, tabh, tabg, erfcx, pi, li, i_sites, so, sog, sign, row, nfront, nn, sub, lpa, cs, f, fg);
         for (int off = lpa >> 1; off > 0; off >>= 1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 f[k] += __shfl_xor(f[k], off);
-                fg[k] += __shfl_xor(fg[k], off);
+                if (DUAL) fg[k] += __shfl_xor(fg[k], off);
             }
         }
         if (valid && sub == 0) {
@@ -982,70 +822,35 @@ k_cpair_dual(CPairArgs A, PairConsts c, PairConsts g) {
                     // (host first: when both forces go to the same buffer the guest adds to what the host just wrote)
                     if (A.accumulate) A.force[3 * i + d] += f[3 * t + d];
                     else A.force[3 * i + d] = f[3 * t + d];
-                    if (A.g_accumulate) A.gforce[3 * i + d] += fg[3 * t + d];
-                    else A.gforce[3 * i + d] = fg[3 * t + d];
+                    if (DUAL) {
+                        if (A.g_accumulate) A.gforce[3 * i + d] += fg[3 * t + d];
+                        else A.gforce[3 * i + d] = fg[3 * t + d];
+                    }
                 }
             }
         }
     }
 }
 
-template <int FAM, int CMODE, int GFAM>
-static int launch_cdual_i(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g) {
-    constexpr int BS = AMM_CBS_DUAL;
-    static CLaunchCfg cfg[64];
-    CLaunchCfg &k = cfg[ctx->device & 63];
-    const int lds = A.host_bytes + A.guest_bytes + AMM_ERFCX_NI * AMM_ERFCX_NC * 8 + (BS / 64) * 192 * 16;
-    auto kern = k_cpair_dual<FAM, CMODE, GFAM, BS>;
-    if (lds > k.lds_set) {
-        AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        k.lds_set = lds;
-        k.bpc = -1;
-    }
-    if (k.bpc < 0) {
-        int nb = 0;
-        AMM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BS, (size_t)lds));
-        if (nb < 1) {
-            amm_set_error("molecule-row fused pair kernel does not fit on a CU (LDS)");
-            return 1;
-        }
-        k.bpc = nb;
-    }
-    int &ncu = g_num_cu_c[ctx->device & 63];
-    if (!ncu) AMM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    constexpr int WPB = BS / 64;
-    long nblk = std::min((long)ncu * k.bpc, ((long)A.ntask + WPB - 1) / WPB);
-    nblk = std::max(8L, (nblk + 7) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, A, c, g);
-    return 0;
-}
+// per (device, kernel) launch configuration: dynamic LDS attribute + blocks per CU from the occupancy query
+struct CLaunchCfg {
+    int lds_set = 0, bpc = -1;
+};
+static int g_num_cu_c[64] = {0};
 
-// fused pass: which (host, guest) pairs have a kernel.  Returns -1 when there is none (the caller launches the two forces one
-// after the other), 0 / 1 as the launch functions
-static int launch_cdual(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g) {
-    if (g.family != AMM_NEAR_FSWITCH) return -1;
-    if (c.family == AMM_DAMPED && c.degree == 1) return launch_cdual_i<AMM_DAMPED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g);
-#ifndef AMM_CLUSTER_TUNE
-    if (c.family == AMM_DAMPED) return launch_cdual_i<AMM_DAMPED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g);
-    if (c.family == AMM_NONBONDED) {
-        if (c.cmode == 1) return launch_cdual_i<AMM_NONBONDED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g);
-        if (c.cmode == 2) return launch_cdual_i<AMM_NONBONDED, 2, AMM_NEAR_FSWITCH>(ctx, A, c, g);
-        return launch_cdual_i<AMM_NONBONDED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g);
-    }
-#endif
-    return -1;
-}
-
-
-template <int FAM, int CMODE>
-static int launch_cpair_i(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c) {
-    // 2 wavefronts per SIMD (187 registers with the look-ups of three pairs pinned ahead of their Horner chains): one block
-    // of 512; 8 rows per wavefront then deal 2 tasks to every wavefront at 98 304 atoms (768 threads: 1.33 -- a third idle)
+// 2 wavefronts per SIMD (187 registers one force, 240 fused): one block of 512 per CU; 8 rows per wavefront then deal 2 tasks to
+// every wavefront at 98 304 atoms (768 threads: 1.33 -- a third of the chip idles in the tail)
+template <int FAM, int CMODE, int GFAM, int SMASK>
+static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g) {
     constexpr int BS = AMM_CBS_SINGLE;
+    constexpr bool DUAL = GFAM >= 0;
+    constexpr bool SS = SMASK != 0;
     static CLaunchCfg cfg[64];
     CLaunchCfg &k = cfg[ctx->device & 63];
-    const int lds = A.host_bytes + AMM_ERFCX_NI * AMM_ERFCX_NC * 8 + (BS / 64) * 192 * 16;
-    auto kern = k_cpair_tab<FAM, CMODE, BS>;
+    int lds = A.host_bytes + (DUAL ? A.guest_bytes : 0);
+    if (SS) lds += A.host_ss_bytes + (DUAL ? A.guest_ss_bytes : 0);
+    else lds += AMM_ERFCX_NI * AMM_ERFCX_NC * 8 + (BS / 64) * 192 * 16;
+    auto kern = k_cpair<FAM, CMODE, GFAM, BS, SMASK>;
     if (lds > k.lds_set) {
         AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         k.lds_set = lds;
@@ -1065,26 +870,57 @@ static int launch_cpair_i(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c)
     constexpr int WPB = BS / 64;
     long nblk = std::min((long)ncu * k.bpc, ((long)A.ntask + WPB - 1) / WPB);
     nblk = std::max(8L, (nblk + 7) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, A, c);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, A, c, g);
     return 0;
+}
+
+#define AMM_CPAIR_LDS_LIMIT (160 * 1024)
+// site-site tables are used when the force has one (A.host_ss_bytes > 0; for a fused pass: both forces) and everything fits LDS
+template <int FAM, int CMODE, int GFAM>
+static int launch_cpair_s(amm_ctx *ctx, CPairArgs A, const PairConsts &c, const PairConsts &g) {
+    constexpr bool DUAL = GFAM >= 0;
+    bool ss = ctx->opt_site_tab && A.host_ss_bytes > 0 && (!DUAL || A.guest_ss_bytes > 0);
+    if (ss && A.host_bytes + A.host_ss_bytes + (DUAL ? A.guest_bytes + A.guest_ss_bytes : 0) > AMM_CPAIR_LDS_LIMIT) ss = false;
+    // (A.site_atoms: the row atoms that are sites in some molecule -- 1 for three-site water: only the first)
+    if (ss) return A.site_atoms == 1 ? launch_cpair_t<FAM, CMODE, GFAM, 1>(ctx, A, c, g) : launch_cpair_t<FAM, CMODE, GFAM, 7>(ctx, A, c, g);
+    PairConsts c0 = c, g0 = g;
+    c0.tab.ss_first = g0.tab.ss_first = -1;
+    A.host_ss_bytes = A.guest_ss_bytes = 0;
+    return launch_cpair_t<FAM, CMODE, GFAM, 0>(ctx, A, c0, g0);
+}
+
+// fused pass: which (host, guest) pairs have a kernel.  Returns -1 when there is none (the caller launches the two forces one
+// after the other), 0 / 1 as the launch functions
+static int launch_cdual(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g) {
+    if (g.family != AMM_NEAR_FSWITCH) return -1;
+    if (c.family == AMM_DAMPED && c.degree == 1) return launch_cpair_s<AMM_DAMPED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+#ifndef AMM_CLUSTER_TUNE
+    if (c.family == AMM_DAMPED) return launch_cpair_s<AMM_DAMPED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+    if (c.family == AMM_NONBONDED) {
+        if (c.cmode == 1) return launch_cpair_s<AMM_NONBONDED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+        if (c.cmode == 2) return launch_cpair_s<AMM_NONBONDED, 2, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+        return launch_cpair_s<AMM_NONBONDED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+    }
+#endif
+    return -1;
 }
 
 static int launch_cpair(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c) {
 #ifdef AMM_CLUSTER_TUNE      // kernel tuning builds: the two instantiations of the bench only (compile time)
-    if (c.family == AMM_NEAR_FSWITCH) return launch_cpair_i<AMM_NEAR_FSWITCH, 0>(ctx, A, c);
-    return launch_cpair_i<AMM_DAMPED, 1>(ctx, A, c);
+    if (c.family == AMM_NEAR_FSWITCH) return launch_cpair_s<AMM_NEAR_FSWITCH, 0, -1>(ctx, A, c, c);
+    return launch_cpair_s<AMM_DAMPED, 1, -1>(ctx, A, c, c);
 #else
     switch (c.family) {
-    case AMM_NEAR_NONE: return launch_cpair_i<AMM_NEAR_NONE, 0>(ctx, A, c);
-    case AMM_NEAR_SHIFT: return launch_cpair_i<AMM_NEAR_SHIFT, 0>(ctx, A, c);
-    case AMM_NEAR_FSWITCH: return launch_cpair_i<AMM_NEAR_FSWITCH, 0>(ctx, A, c);
+    case AMM_NEAR_NONE: return launch_cpair_s<AMM_NEAR_NONE, 0, -1>(ctx, A, c, c);
+    case AMM_NEAR_SHIFT: return launch_cpair_s<AMM_NEAR_SHIFT, 0, -1>(ctx, A, c, c);
+    case AMM_NEAR_FSWITCH: return launch_cpair_s<AMM_NEAR_FSWITCH, 0, -1>(ctx, A, c, c);
     case AMM_DAMPED:
-        if (c.degree == 1) return launch_cpair_i<AMM_DAMPED, 1>(ctx, A, c);
-        return launch_cpair_i<AMM_DAMPED, 0>(ctx, A, c);
+        if (c.degree == 1) return launch_cpair_s<AMM_DAMPED, 1, -1>(ctx, A, c, c);
+        return launch_cpair_s<AMM_DAMPED, 0, -1>(ctx, A, c, c);
     default:
-        if (c.cmode == 1) return launch_cpair_i<AMM_NONBONDED, 1>(ctx, A, c);
-        if (c.cmode == 2) return launch_cpair_i<AMM_NONBONDED, 2>(ctx, A, c);
-        return launch_cpair_i<AMM_NONBONDED, 0>(ctx, A, c);
+        if (c.cmode == 1) return launch_cpair_s<AMM_NONBONDED, 1, -1>(ctx, A, c, c);
+        if (c.cmode == 2) return launch_cpair_s<AMM_NONBONDED, 2, -1>(ctx, A, c, c);
+        return launch_cpair_s<AMM_NONBONDED, 0, -1>(ctx, A, c, c);
     }
 #endif
 }
@@ -1345,6 +1181,16 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         A.box = ctx->box;
         A.host_tab = pf->d_tab;
         A.host_bytes = pf->pc.tab.nint * AMM_TAB_STRIDE;
+        // site-site table right behind the Coulomb table in LDS (fused pass: behind both Coulomb tables, the host's first)
+        auto ss_bytes = [](const PairForce *p) { return (p->d_tab_ss && p->pc.tab.ss_first >= 0) ? (p->pc.tab.nint - p->pc.tab.ss_first) * AMM_TAB_STRIDE : 0; };
+        A.host_tab_ss = pf->d_tab_ss;
+        A.host_ss_bytes = ss_bytes(pf);
+        A.host_ss_off = A.host_bytes - pf->pc.tab.ss_first * AMM_TAB_STRIDE;
+        A.site_atoms = pf->site_atoms;
+        A.guest_tab = A.guest_tab_ss = nullptr;
+        A.guest_bytes = A.guest_ss_bytes = A.guest_ss_off = A.g_accumulate = 0;
+        A.gforce = nullptr;
+        A.gfac = A.gsr = 1.0;
         A.margin = cl->rlist_build + cl->skin + 2.0 * cl->rext + 1e-6;
         const int rpw = 64 >> A.lpa_shift;
         A.ntask = (nrows + rpw - 1) / rpw;
@@ -1372,6 +1218,10 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             CPairArgs D = A;
             D.guest_tab = guest->d_tab;
             D.guest_bytes = guest->pc.tab.nint * AMM_TAB_STRIDE;
+            D.guest_tab_ss = guest->d_tab_ss;
+            D.guest_ss_bytes = ss_bytes(guest);
+            D.host_ss_off = D.host_bytes + D.guest_bytes - pf->pc.tab.ss_first * AMM_TAB_STRIDE;
+            D.guest_ss_off = D.guest_bytes + D.host_ss_bytes - guest->pc.tab.ss_first * AMM_TAB_STRIDE;
             D.gforce = gout;
             D.g_accumulate = (g_force == d_force && !exchange) ? 1 : g_accumulate;
             D.gfac = (guest->pc.Kc * guest->pc.sign) / (pf->pc.Kc * pf->pc.sign);
@@ -1396,6 +1246,12 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             G.accumulate = (g_force == d_force && !exchange) ? 1 : g_accumulate;
             G.host_tab = guest->d_tab;
             G.host_bytes = guest->pc.tab.nint * AMM_TAB_STRIDE;
+            G.host_tab_ss = guest->d_tab_ss;
+            G.host_ss_bytes = ss_bytes(guest);
+            G.host_ss_off = G.host_bytes - guest->pc.tab.ss_first * AMM_TAB_STRIDE;
+            G.site_atoms = guest->site_atoms;
+            G.hsig_site = guest->site_hsig;
+            G.seps2_site = guest->site_seps2;
             PairConsts gpc = guest->pc;
             if (guest->desc.flags & AMM_GUARD_RC0) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);      // step(rc0 - r)
             const bool gtimed = ctx->profile && (ctx->profile_only < 0 || ctx->profile_only == guest->id);

@@ -1976,16 +1976,30 @@ int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos,
 }
 
 // bump when a pair-traversal kernel changes: stored measurements (profiles/*_traffic.json) are matched against it
-const char *amm_kernel_revision_impl() { return "r03-mol3"; }
+const char *amm_kernel_revision_impl() { return "r03-mol4"; }
 
 // radial Coulomb table of the force-only traversal (pair_tab.h): built from the descriptor alone, once per pair force
 int amm_pair_build_table(PairForce *pf) {
     std::vector<double> coef;
-    pf->tab_error = amm_build_coulomb_table(pf->pc, coef);
+    // the site-site table (pair_tab.h) for molecule-row forces whose Lennard-Jones sites share one (sigma, eps, q)
+    SiteTable ss;
+    ss.want = pf->cluster_ok && pf->one_site_class && pf->site_one_charge && pf->site_q != 0.0 && pf->site_seps2 != 0.0;
+    ss.sig = 2.0 * pf->site_hsig;
+    ss.eps4 = pf->site_seps2 * pf->site_seps2;
+    ss.QQ = pf->pc.Kc * pf->site_q * pf->site_q;
+    pf->tab_error = amm_build_coulomb_table(pf->pc, coef, &ss);
+    pf->ss_built_for[0] = pf->site_hsig;
+    pf->ss_built_for[1] = pf->site_seps2;
+    pf->ss_built_for[2] = ss.want ? pf->site_q : 0.0;
     if (pf->d_tab) {
         (void)hipFree(pf->d_tab);
         pf->d_tab = nullptr;
     }
+    if (pf->d_tab_ss) {
+        (void)hipFree(pf->d_tab_ss);
+        pf->d_tab_ss = nullptr;
+    }
+    pf->ss_error = ss.error;
     // The bound is enforced, not assumed: the refinement stops at the LDS budget (or at its finest level), and a narrow
     // switching window or a high DAMPED degree can leave the table short of the arithmetic's accuracy.  Such a force keeps
     // the analytic kernels (no table: `tab_ok` is false for it, and a guest without a table disables the one-pass forms).
@@ -1993,9 +2007,17 @@ int amm_pair_build_table(PairForce *pf) {
         pf->pc.tab.nint = 0;
         coef.clear();
     }
+    if (pf->pc.tab.nint == 0 || ss.coef.empty() || !(ss.error <= AMM_TAB_SS_MAX_ERROR)) {
+        pf->pc.tab.ss_first = -1;             // site pairs keep the analytic Lennard-Jones arithmetic
+        ss.coef.clear();
+    }
     if (pf->pc.tab.nint > 0) {
         AMM_HIP(hipMalloc(&pf->d_tab, sizeof(double) * coef.size()));
         AMM_HIP(hipMemcpy(pf->d_tab, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
+    }
+    if (!ss.coef.empty()) {
+        AMM_HIP(hipMalloc(&pf->d_tab_ss, sizeof(double) * ss.coef.size()));
+        AMM_HIP(hipMemcpy(pf->d_tab_ss, ss.coef.data(), sizeof(double) * ss.coef.size(), hipMemcpyHostToDevice));
     }
     return 0;
 }

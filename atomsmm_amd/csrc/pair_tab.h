@@ -92,17 +92,22 @@ static inline void amm_tab_interval(const PairTab &T, int j, long double &lo, lo
     width = ldexpl(1.0L / (long double)(1u << nb), e);
 }
 
-static inline double amm_fit_coulomb_table(const PairConsts &pc, const PairTab &T, std::vector<double> &coef) {
+// Degree-5 Chebyshev-node interpolation of `exact(r)` on the intervals [j0, T.nint) of T; coefficients of interval j at
+// coef[(j - j0) * 6 ..].  Returns the largest relative error met between the nodes (in zone B only if `zone_b_err` is given: there).
+template <class F>
+static inline double amm_fit_radial_table(const PairConsts &pc, const PairTab &T, std::vector<double> &coef, F exact, int j0 = 0,
+                                          double *zone_b_err = nullptr) {
     // a force guarded by step(rc0 - r) is never looked up beyond rc0, whatever its nominal cutoff (the discount of FarNonbondedForce)
     const double reach = ((pc.flags & AMM_GUARD_RC0) && pc.rc0 > 0.0) ? std::min(pc.rc, pc.rc0) : pc.rc;
-    coef.assign((size_t)T.nint * 6, 0.0);
+    coef.assign((size_t)(T.nint - j0) * 6, 0.0);
     long double nodes[6];
     for (int k = 0; k < 6; ++k) nodes[k] = cosl((2 * k + 1) * 3.14159265358979323846264338327950288L / 12.0L);
-    double worst = 0.0;
-    for (int j = 0; j < T.nint; ++j) {
+    double worst = 0.0, worst_b = 0.0;
+    for (int j = j0; j < T.nint; ++j) {
         long double lo, width;
         amm_tab_interval(T, j, lo, width);
         const long double h = 0.5L * width, centre = lo + h;
+        double *cj = &coef[(size_t)(j - j0) * 6];
         // interpolate at the Chebyshev nodes: solve V a = f with V[k][m] = s_k^m (6 x 6, long double, partial pivoting)
         long double A[6][7];
         for (int k = 0; k < 6; ++k) {
@@ -111,7 +116,7 @@ static inline double amm_fit_coulomb_table(const PairConsts &pc, const PairTab &
                 A[k][q] = p;
                 p *= nodes[k];
             }
-            A[k][6] = amm_coul_radial_exact(pc, sqrtl((centre + h * nodes[k]) / (long double)T.scale));
+            A[k][6] = exact(sqrtl((centre + h * nodes[k]) / (long double)T.scale));
         }
         for (int col = 0; col < 6; ++col) {
             int piv = col;
@@ -131,42 +136,108 @@ static inline double amm_fit_coulomb_table(const PairConsts &pc, const PairTab &
         }
         long double hp = 1.0L;
         for (int q = 0; q < 6; ++q) {
-            coef[(size_t)j * 6 + q] = (double)(a[q] / hp);
+            cj[q] = (double)(a[q] / hp);
             hp *= h;
         }
         // check between the nodes, with the double coefficients and double Horner arithmetic
         for (int k = 0; k < 7; ++k) {
             const double t = (double)(h * (-1.0L + k / 3.0L));
-            double p = coef[(size_t)j * 6 + 5];
-            for (int q = 4; q >= 0; --q) p = fma(p, t, coef[(size_t)j * 6 + q]);
+            double p = cj[5];
+            for (int q = 4; q >= 0; --q) p = fma(p, t, cj[q]);
             const long double r = sqrtl((centre + (long double)t) / (long double)T.scale);
             if (r >= (long double)reach) continue;
-            const long double exact = amm_coul_radial_exact(pc, r);
+            const long double ex = exact(r);
             // where a switching function takes the force through zero the error is measured against the unswitched 1/r^3
-            const long double denom = fmaxl(fabsl(exact), 1e-3L / (r * r * r));
-            worst = fmax(worst, (double)(fabsl((long double)p - exact) / denom));
+            const long double denom = fmaxl(fabsl(ex), 1e-3L / (r * r * r));
+            const double e = (double)(fabsl((long double)p - ex) / denom);
+            worst = fmax(worst, e);
+            if (j >= T.nA) worst_b = fmax(worst_b, e);
         }
     }
+    if (zone_b_err) *zone_b_err = worst_b;
     return worst;
 }
 
-// Fills pc.tab and `coef` (nint x 6 doubles).  Returns the largest relative interpolation error met at the check points.
-static inline double amm_build_coulomb_table(PairConsts &pc, std::vector<double> &coef) {
+// exact Lennard-Jones force over r of one pair (sig, eps4 = 4 eps) in long double: the formulas of amm_lj_force below
+static inline long double amm_lj_radial_exact(const PairConsts &c, long double sig, long double eps4, long double r) {
+    const long double rinv = 1.0L / r, rinv2 = rinv * rinv;
+    const long double s2 = sig * sig * rinv2, s6 = s2 * s2 * s2, s12 = s6 * s6;
+    const long double dlj_r = eps4 * (12.0L * s12 - 6.0L * s6) * rinv2;
+    auto S = [](long double u) { return 1.0L + u * u * u * (15.0L * u - 6.0L * u * u - 10.0L); };
+    auto dS = [](long double u) { const long double w = u * (1.0L - u); return -30.0L * w * w; };
+    switch (c.family) {
+    case AMM_NEAR_NONE:
+    case AMM_NEAR_SHIFT:
+    case AMM_NEAR_FSWITCH: {
+        const long double du = r - (long double)c.rs0;
+        const long double u = du >= 0 ? du * (long double)c.inv_dr0 : 0.0L;
+        if (c.family == AMM_NEAR_FSWITCH) return S(u) * dlj_r;
+        long double V = eps4 * (s12 - s6);
+        if (c.family == AMM_NEAR_SHIFT) {
+            const long double sc2 = sig * sig * (long double)c.inv_rc0_2, sc6 = sc2 * sc2 * sc2, sc12 = sc6 * sc6;
+            V = eps4 * (s12 - s6 - (sc12 - sc6));
+        }
+        return S(u) * dlj_r - dS(u) * (long double)c.inv_dr0 * V * rinv;
+    }
+    case AMM_DAMPED: {
+        const long double V = eps4 * (s12 - s6);
+        const int d = c.degree;
+        const long double rd1 = powl(r, d - 1);
+        const long double du = rd1 * r - (long double)c.rswitch_d;
+        const long double u = du >= 0 ? du * (long double)c.inv_sw_den : 0.0L;
+        return S(u) * dlj_r - dS(u) * d * rd1 * (long double)c.inv_sw_den * V * rinv;
+    }
+    case AMM_NONBONDED: {
+        long double Sv = 1.0L, dSdr = 0.0L;
+        if ((c.flags & AMM_SWITCH) && r > (long double)c.rswitch) {
+            const long double t = (r - (long double)c.rswitch) * (long double)c.inv_sw_dr;
+            Sv = S(t);
+            dSdr = dS(t) * (long double)c.inv_sw_dr;
+        }
+        return Sv * dlj_r - dSdr * (eps4 * (s12 - s6)) * rinv;
+    }
+    default: return 0.0L;
+    }
+}
+
+// The site-site table of a force whose Lennard-Jones sites all carry ONE (sigma, eps, q) -- water: the oxygens.  For a pair
+// of two sites the whole force over r is a radial function too,
+//     F/r = qq B_C(r^2) + B_LJ(r^2) = qq B'(r^2),   B' = B_C + B_LJ / QQ,   QQ = Kc q_site^2 = that pair's qq,
+// so the force-only kernels read B' instead of B_C for such a pair -- same interval, same Horner chain, same multiply by qq --
+// and need no Lennard-Jones arithmetic (1/r, two Newton steps, the switch in r ...) at all.  B' is tabulated on the SAME
+// intervals as B_C, from the interval that holds 0.7 sigma upwards (4 eps ((1/0.7)^12 - (1/0.7)^6) = 255 eps: sites do not get
+// closer; if they do, the pair takes the analytic path like any pair below a table).  Its error is dominated by the r^-14 wall
+// (1.0-1.4e-13 relative at 128 intervals per octave, whatever r): bound AMM_TAB_SS_MAX_ERROR.
+#define AMM_TAB_SS_MAX_ERROR 3e-13
+struct SiteTable {
+    bool want = false;                 // in: build it
+    double sig = 0, eps4 = 0, QQ = 0;  // in: sigma, 4 eps of a site pair, Kc q_site^2
+    std::vector<double> coef;          // out: (nint - first) x 6
+    double error = 0;                  // out: largest relative error met
+};
+
+// Fills pc.tab and `coef` (nint x 6 doubles) -- and the site-site table if one is wanted.  Returns the largest relative
+// interpolation error of the Coulomb table met at the check points.
+static inline double amm_build_coulomb_table(PairConsts &pc, std::vector<double> &coef, SiteTable *ss = nullptr) {
     memset(&pc.tab, 0, sizeof(pc.tab));
     coef.clear();
+    if (ss) ss->coef.clear();
     if (!amm_family_has_table(pc.family)) return 0.0;
     const bool near_family = pc.family == AMM_NEAR_NONE || pc.family == AMM_NEAR_SHIFT || pc.family == AMM_NEAR_FSWITCH;
     double rkink = pc.rc;
     if (pc.family == AMM_DAMPED && pc.rswitch > 0 && pc.rswitch < pc.rc) rkink = pc.rswitch;
     if (near_family && pc.rs0 > 0 && pc.rs0 < pc.rc) rkink = pc.rs0;
-    // zone A reaches down to r <= 0.09 nm (closer pairs take the analytic path): 5 octaves of r^2 for rs0 = 0.5, 7 for 0.9
-    const int octaves_below = std::max(3, std::min(10, (int)std::ceil(2.0 * std::log2(rkink / 0.09))));
+    // (the built-in switch of the NonbondedForce acts on the Lennard-Jones term only: its start is a kink of the site-site table)
+    if (pc.family == AMM_NONBONDED && (pc.flags & AMM_SWITCH) && pc.rswitch > 0 && pc.rswitch < pc.rc) rkink = pc.rswitch;
+    // zone A reaches down to r <= 0.115 nm (closer pairs take the analytic path): 5 octaves of r^2 for rs0 = 0.5, 6 for 0.9
+    const int octaves_below = std::max(3, std::min(10, (int)std::ceil(2.0 * std::log2(rkink / 0.115))));
     auto raw_index = [](double w, int shift) {
         unsigned long long bits;
         memcpy(&bits, &w, 8);
         return (unsigned)(bits >> (32 + shift));
     };
     PairTab T;
+    memset(&T, 0, sizeof(T));
     T.scale = 1.0 / (rkink * rkink);
     T.r2min = ldexp(1.0, -octaves_below) / T.scale * (1.0 + 1e-12);
     T.baseA = (int)raw_index(ldexp(1.0, -octaves_below), AMM_TAB_SHIFT);
@@ -174,6 +245,21 @@ static inline double amm_build_coulomb_table(PairConsts &pc, std::vector<double>
     // (a force guarded by step(rc0 - r) is looked up to rc0 only: its table ends there, whatever the nominal cutoff)
     const double reach = ((pc.flags & AMM_GUARD_RC0) && pc.rc0 > 0.0) ? std::min(pc.rc, pc.rc0) : pc.rc;
     const double wtop = reach * reach * T.scale * (1.0 + 1e-12);
+    const bool with_ss = ss && ss->want && ss->QQ != 0.0 && ss->eps4 > 0.0 && ss->sig > 0.0;
+    if (with_ss) {
+        // first interval of the site-site table: the one that holds (0.7 sigma)^2, if zone A reaches that far down
+        const double w0 = 0.49 * ss->sig * ss->sig * T.scale;
+        const int first = (int)raw_index(w0, AMM_TAB_SHIFT) - T.baseA;
+        T.ss_first = std::max(0, std::min(first, T.nA));
+        long double lo, width;
+        PairTab tmp = T;
+        tmp.nint = T.nA + 1;
+        amm_tab_interval(tmp, T.ss_first, lo, width);
+        T.ss_r2min = (double)lo / T.scale * (1.0 + 1e-12);
+        if (!(w0 < 1.0)) T.ss_first = -1;          // sites larger than the kink radius: no table
+    } else {
+        T.ss_first = -1;
+    }
     double worst = 0.0;
     for (int fine = 0; fine <= 6; ++fine) {        // refine the switching zone until the table is as good as the arithmetic
         T.shiftB = AMM_TAB_SHIFT - fine;
@@ -181,13 +267,26 @@ static inline double amm_build_coulomb_table(PairConsts &pc, std::vector<double>
         const unsigned rawB = raw_index(1.0, T.shiftB);
         T.rawB_minus_nA = (int)rawB - T.nA;
         T.nint = T.nA + (int)(raw_index(wtop, T.shiftB) - rawB) + 2;   // one interval beyond the cutoff (r2 < rc2 may round up)
-        std::vector<double> trial;
-        const double err = amm_fit_coulomb_table(pc, T, trial);
-        if (fine > 0 && (size_t)T.nint * AMM_TAB_STRIDE > 72 * 1024 && !coef.empty()) break;      // LDS budget: keep the previous one
+        std::vector<double> trial, trial_ss;
+        const double err = amm_fit_radial_table(pc, T, trial, [&](long double r) { return amm_coul_radial_exact(pc, r); });
+        double err_ss = 0.0, err_ss_b = 0.0;
+        if (T.ss_first >= 0) {
+            const long double sg = ss->sig, e4 = ss->eps4, iqq = 1.0L / (long double)ss->QQ;
+            err_ss = amm_fit_radial_table(pc, T, trial_ss,
+                                          [&](long double r) { return amm_coul_radial_exact(pc, r) + amm_lj_radial_exact(pc, sg, e4, r) * iqq; },
+                                          T.ss_first, &err_ss_b);
+        }
+        const size_t bytes = ((size_t)T.nint + (T.ss_first >= 0 ? (size_t)(T.nint - T.ss_first) : 0)) * AMM_TAB_STRIDE;
+        if (fine > 0 && bytes > (T.ss_first >= 0 ? 112 : 72) * 1024 && !coef.empty()) break;      // LDS budget: keep the previous one
         coef.swap(trial);
+        if (ss) {
+            ss->coef.swap(trial_ss);
+            ss->error = err_ss;
+        }
         pc.tab = T;
         worst = err;
-        if (err < 1e-14) break;
+        // (the site-site table's error in zone A is that of the r^-14 wall and does not move with the refinement of zone B)
+        if (err < 1e-14 && err_ss_b < 1e-13) break;
     }
     return worst;
 }
@@ -223,7 +322,8 @@ struct TabLookup {
     double2 c01, c23, c45;
     double t;
 };
-__device__ __forceinline__ TabLookup amm_tab_fetch(const char *lds_tab, const PairTab &T, double r2) {
+// (`extra`: bytes added to the interval's address -- the way from a force's Coulomb table to its site-site table, or 0)
+__device__ __forceinline__ TabLookup amm_tab_fetch(const char *lds_tab, const PairTab &T, double r2, unsigned extra = 0u) {
     const double w = r2 * T.scale;
     const unsigned hi = (unsigned)__double2hiint(w);
     const bool above = hi >= 0x3FF00000u;
@@ -237,7 +337,7 @@ __device__ __forceinline__ TabLookup amm_tab_fetch(const char *lds_tab, const Pa
 #if defined(AMM_EXP_TAB_BCAST)          // measurement only: every lane reads interval 0 (no bank conflicts; wrong forces)
     idx &= 0u;
 #endif
-    const double2 *cf = reinterpret_cast<const double2 *>(lds_tab + __umul24(idx, AMM_TAB_STRIDE));
+    const double2 *cf = reinterpret_cast<const double2 *>(lds_tab + (__umul24(idx, AMM_TAB_STRIDE) + extra));
     L.c01 = cf[0];
     L.c23 = cf[1];
     L.c45 = cf[2];

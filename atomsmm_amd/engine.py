@@ -1930,3 +1930,7 @@ class Engine:
     # measurement helpers (bench / tests)
     def pair_force_ids(self, group):
         return [pid for e in self.entries if e.group == group for pid in e.pair_ids]
+
+    def recip_force_ids(self, group):
+        """Library ids of the PME reciprocal-space forces of a force group (amm_pme_create)."""
+        return [e.recip for e in self.entries if getattr(e, 'recip', None) is not None and e.recip_group == group]

@@ -299,8 +299,24 @@ def main():
             t = torch.tensor([el2], dtype=torch.float64, device='cuda')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = t.item()
+        # reciprocal space alone: stand-alone evaluations of the mesh force (bin, spread, two FFTs, convolution, gather), HIP events
+        recip_us = None
+        eng2 = sim2.context._engine
+        rec = eng2.recip_force_ids(2)
+        if rec:
+            scratch = torch.empty_like(eng2.x)
+            for _ in range(3):
+                eng2.ctx.force_eval(rec[0], eng2.x, scratch)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                eng2.ctx.force_eval(rec[0], eng2.x, scratch)
+            e1.record()
+            torch.cuda.synchronize()
+            recip_us = round(1e3 * e0.elapsed_time(e1) / 20, 1)
         pme_outer = {'ms_per_step': round(el2 / args.pme_steps * 1e3, 4), 'ns_day': round(dt_fs * 1e-6 * 86400.0 / (el2 / args.pme_steps), 2),
-                     'steps': args.pme_steps,
+                     'recip_us': recip_us, 'steps': args.pme_steps,
                      'workload': 'the same box and RESPA split, outer force = PME NonbondedForce (rc 1.0, switch 0.9, Ewald tolerance 5e-4: '
                                  'direct space + reciprocal space on an 80^3 mesh), continued from the final state of the headline run'}
         del sim2

@@ -297,6 +297,10 @@ typedef struct {
     int32_t has_table;
     int32_t rode_along;     /* 1: this force's last force-only evaluation was computed inside its list owner's launch (molecule rows:
                                the fused step-boundary pass), so it has no launch and no profile time of its own */
+    int32_t has_site_table; /* 1: pairs of two Lennard-Jones sites read a radial table of their own in the molecule-row kernels (the
+                               force's sites share one sigma, eps and charge: water) instead of Lennard-Jones arithmetic */
+    int32_t pad3_;
+    double site_tab_error;  /* its largest relative interpolation error (bound 3e-13: the r^-14 wall) */
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
 /* Measurement helper (bench.py): the number of directed list entries of this force with r < r_within at d_pos, counted in

@@ -24,6 +24,6 @@ line = open('gpurun_out/${tag}_w$w.txt').read()
 import re
 lanes = re.search(r'lanes/row (\d+)', line).group(1)
 print('W %d  lanes/row %2s  near %.1f  outer alone %.1f  fused pass %.1f  | rebuild: assign %.1f  sort+copies %.1f  build %.1f  | sorted copies alone %.1f  (us)' % (
-    $w, lanes, mean('void k_cpair_tab<2'), mean('void k_cpair_tab<3'), mean('void k_cpair_dual'), real('k_cassign'), real('k_csort_gather'), real('void k_cbuild<false'), mean('k_csort_gather')))
+    $w, lanes, mean('void k_cpair<2, 0, -1'), mean('void k_cpair<3, 1, -1'), mean('void k_cpair<3, 1, 2'), real('k_cassign'), real('k_csort_gather'), real('void k_cbuild<false'), mean('k_csort_gather')))
 PY
 done

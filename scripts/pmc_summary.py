@@ -31,9 +31,9 @@ def main():
     print('\n'.join(lines))
     if tj:
         res = {}
-        for tag, pats in (('near', ('k_cpair_tab<2, 0', 'k_pair_tab<2, 0, -1', 'k_pair_nlist<2')),
-                          ('outer', ('k_cpair_tab<3, 1', 'k_cpair_tab<4, 1')),
-                          ('dual', ('k_cpair_dual<3, 1, 2', 'k_cpair_dual<4, 1, 2', 'k_pair_tab<3, 1, 2', 'k_pair_nlist<3')),
+        for tag, pats in (('near', ('k_cpair<2, 0, -1', 'k_cpair_tab<2, 0', 'k_pair_tab<2, 0, -1', 'k_pair_nlist<2')),
+                          ('outer', ('k_cpair<3, 1, -1', 'k_cpair<4, 1, -1', 'k_cpair_tab<3, 1', 'k_cpair_tab<4, 1')),
+                          ('dual', ('k_cpair<3, 1, 2', 'k_cpair<4, 1, 2', 'k_cpair_dual<3, 1, 2', 'k_cpair_dual<4, 1, 2', 'k_pair_tab<3, 1, 2', 'k_pair_nlist<3')),
                           ('build', ('k_cbuild<false', 'k_build_nlist<false'))):
             fe = [x for (cn, kn), v in acc.items() if cn == 'FETCH_SIZE' and any(p in kn for p in pats) for x in v]
             wr = [x for (cn, kn), v in acc.items() if cn == 'WRITE_SIZE' and any(p in kn for p in pats) for x in v]

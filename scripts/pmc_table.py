@@ -4,7 +4,7 @@ import re
 import sys
 
 KERNELS = [('near', 'k_pair_nlist<2'), ('dual', 'k_pair_nlist<3'), ('tab_near', 'k_pair_tab<2'), ('tab_dual', 'k_pair_tab<3'),
-           ('build(max)', 'k_build_nlist<false'), ('mol_near', 'k_cpair_tab<2'), ('mol_outer', 'k_cpair_tab<3'), ('mol_fused', 'k_cpair_dual<3'),
+           ('build(max)', 'k_build_nlist<false'), ('mol_near', 'k_cpair<2, 0, -1'), ('mol_outer', 'k_cpair<3, 1, -1'), ('mol_fused', 'k_cpair<3, 1, 2'),
            ('build_mol(max)', 'k_cbuild<false'), ('inner', 'k_inner_lanes')]
 rows = collections.defaultdict(dict)
 for line in open(sys.argv[1]):

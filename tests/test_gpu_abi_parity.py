@@ -138,6 +138,58 @@ def test_molecule_rows_edge_cases(spcfw):
     ctx.close()
 
 
+@pytest.mark.parametrize('family', ['near-fswitch', 'damped', 'ewald-direct', 'near-shift'])
+def test_site_site_tables(spcfw, family):
+    """Molecule rows: when every Lennard-Jones site of a force has the same sigma, eps and charge (water: the oxygens) a pair of
+    two sites reads ONE radial table that holds Coulomb + Lennard-Jones (csrc/pair_tab.h: SiteTable) and the kernels carry no
+    Lennard-Jones arithmetic.  Checked: the table exists and meets its bound; forces equal the oracle's and the analytic-LJ
+    kernels' (option site_tab = 0); two oxygens pushed closer than the table reaches (0.7 sigma) take the analytic path; sites
+    with unequal charges get no table and the same kernels' analytic branch."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    d = {'near-fswitch': near('force-switch', 0.7, 0.5), 'near-shift': near('shift', 0.7, 0.5),
+         'damped': O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1),
+         'ewald-direct': O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, alpha=2.628260884878466, flags=O.COULOMB_EWALD | O.SWITCH)}[family]
+
+    def forces(pos, q, site_tab):
+        ctx = B.HipContext(n, c['box'])
+        ctx.set_option('site_tab', site_tab)
+        fid = hip_pair(B, ctx, d, c, q=q)
+        f = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+        ctx.force_eval(fid, dev(pos), f)
+        ctx.check()
+        st = ctx.pair_stats(fid)
+        ctx.close()
+        return f.cpu().numpy(), st
+
+    pos = c['positions']
+    ref = O.pair_eval(d, pos, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
+    f1, st1 = forces(pos, c['charge'], 1)
+    f0, st0 = forces(pos, c['charge'], 0)
+    assert st1['list_kind'] == 1 and st1['has_site_table'] == 1 and 0.0 < st1['site_tab_error'] <= 3e-13
+    assert st0['has_site_table'] == 0
+    scale = np.abs(ref).max()
+    assert np.abs(f1 - ref).max() <= 1e-9 * scale and np.abs(f0 - ref).max() <= 1e-9 * scale
+    assert np.abs(f1 - f0).max() <= 1e-11 * scale
+    # two water molecules with their oxygens 0.2 nm apart (0.63 sigma: below the site-site table, above the Coulomb table's end)
+    close = pos.copy()
+    shift = close[0] + np.array([0.2, 0.0, 0.0]) - close[3]
+    close[3:6] += shift
+    ref_c = O.pair_eval(d, close, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
+    fc, _ = forces(close, c['charge'], 1)
+    assert np.abs(fc - ref_c).max() <= 1e-9 * np.abs(ref_c).max()
+    # unequal site charges: no site-site table (the pair's qq is no longer one number), same forces as the oracle
+    q2 = c['charge'].copy()
+    q2[0] *= 1.25
+    q2[1] -= 0.125 * c['charge'][0]
+    q2[2] -= 0.125 * c['charge'][0]
+    ref_q = O.pair_eval(d, pos, c['box'], q2, c['sigma'], c['epsilon'], c['exc_pairs'])[1]
+    fq, stq = forces(pos, q2, 1)
+    assert stq['has_site_table'] == 0
+    assert np.abs(fq - ref_q).max() <= 1e-9 * np.abs(ref_q).max()
+
+
 @pytest.mark.parametrize('name', sorted(CASES))
 def test_pair_families_vs_oracle_and_goldens(spcfw, goldens, name):
     B = _backend()
