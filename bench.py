@@ -345,7 +345,7 @@ def main():
         # (its own launches are the stand-alone evaluations of the middle RESPA loop); without one it is a second launch over the rows
         fused_rows = molecule_rows and bool(near_stats.get('rode_along'))
         two_launches = molecule_rows and not fused_rows
-        kname = 'k_cpair_tab' if molecule_rows else 'k_pair_tab'
+        kname = 'k_cpair' if molecule_rows else 'k_pair_tab'
         outer_name = 'DAMPED' if args.outer == 'damped' else 'NONBONDED/Ewald'
 
         def roofline(kernel, seconds, launches, alg_bytes, flops, tag, npairs, listed):
@@ -399,7 +399,7 @@ def main():
             'roofline_dominant': (roofline('%s<%s> (group-2 outer force, force only)' % (kname, outer_name), t_dual, n_dual,
                                            BYTES_PER_ATOM * atoms_per_launch, FLOP_PER_PAIR_FAR * pairs_far, 'outer', pairs_far, st1[far_id]['n_list_pairs'])
                                   if two_launches else
-                                  roofline('%s<%s, guest NEAR_FSWITCH> (outer + near force in one pass)' % ('k_cpair_dual' if fused_rows else kname, outer_name),
+                                  roofline('%s<%s, guest NEAR_FSWITCH> (outer + near force in one pass)' % (kname, outer_name),
                                            t_dual, n_dual, BYTES_PER_ATOM_DUAL * atoms_per_launch, flop_dual, 'dual', pairs_far, st1[far_id]['n_list_pairs'])),
             'detail': {'near_kernel_us': round(t_near * 1e6, 2), 'near_launches': n_near,
                        'outer_kernel_us' if two_launches else 'dual_kernel_us': round(t_dual * 1e6, 2), 'outer_launches' if two_launches else 'dual_launches': n_dual,
