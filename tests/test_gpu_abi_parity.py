@@ -572,6 +572,83 @@ def test_neighbour_list_rebuild_and_reuse(spcfw, outer_skin):
     ctx.close()
 
 
+@pytest.mark.parametrize('seed', [1, 2, 3, 4, 5, 6, 7, 8, 9])
+def test_random_molecule_boxes_vs_oracle(seed):
+    """Randomised boxes of three-atom molecules for the molecule-row path (csrc/cluster.hip): non-cubic boxes from the size that
+    needs the image per atom pair up to one with interior rows, molecules of random shape and orientation (extent 0.07-0.14 nm),
+    and the site patterns that select the kernel variants -- one site class on the first atom (site-site tables, SMASK 1), the
+    same class on any atom (SMASK 7), two classes or unequal site charges (no table: analytic Lennard-Jones part), no site at
+    all.  The near force alone and the fused pass (near force as guest of a damped or Ewald-direct outer force) against the
+    oracle, before and after whole molecules move far enough to rebuild the rows."""
+    B = _backend()
+    rng = np.random.default_rng(100 + seed)
+    box = rng.uniform(2.2, 3.0, 3) if seed % 3 else rng.uniform(3.6, 4.4, 3)
+    nm = int(rng.integers(250, 420) * np.prod(box) / 15.0)
+    m = int(np.ceil(nm ** (1 / 3)))
+    grid = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing='ij'), -1).reshape(-1, 3)[rng.permutation(m ** 3)[:nm]]
+    centre = (grid + 0.5 + rng.uniform(-0.2, 0.2, (nm, 3))) / m * box
+    arms = rng.normal(size=(nm, 2, 3))
+    arms *= (rng.uniform(0.07, 0.14, (nm, 2)) / np.linalg.norm(arms, axis=2))[:, :, None]
+    pos = np.concatenate([centre[:, None, :], centre[:, None, :] + arms], axis=1).reshape(-1, 3)
+    n = 3 * nm
+    pattern = ['first', 'any', 'two-classes', 'unequal-charges', 'first', 'none', 'any', 'first', 'two-classes'][seed - 1]
+    q = np.tile([-0.8, 0.4, 0.4], nm) * rng.uniform(0.9, 1.1)
+    sigma = np.full(n, 0.1)
+    eps = np.zeros(n)
+    first = np.arange(0, n, 3)
+    if pattern in ('first', 'two-classes', 'unequal-charges'):
+        sigma[first], eps[first] = 0.31, 0.65
+    if pattern == 'two-classes':
+        some = first[rng.random(nm) < 0.3]
+        sigma[some], eps[some] = 0.27, 0.4
+    if pattern == 'unequal-charges':
+        some = rng.random(nm) < 0.5
+        q[first[some]] *= 1.2
+        q[first[some] + 1] -= 0.1 * q[first[some]] / 1.2
+        q[first[some] + 2] -= 0.1 * q[first[some]] / 1.2
+    if pattern == 'any':
+        q[:] = np.tile([0.3, -0.6, 0.3], nm)
+        who = rng.integers(0, 3, nm)
+        sigma[first + who], eps[first + who] = 0.30, 0.5
+        q[first + who] = -0.6                       # every site carries the same charge
+        rest = np.ones(n, bool)
+        rest[first + who] = False
+        q[rest] = 0.3
+    excl = np.array([(3 * k + a, 3 * k + b) for k in range(nm) for a, b in ((0, 1), (0, 2), (1, 2))])
+    dn = near('force-switch', 0.7, 0.5)
+    dd = (O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1) if seed % 2 else
+          O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, alpha=2.628260884878466, flags=O.COULOMB_EWALD | O.SWITCH))
+    ctx = B.HipContext(n, box)
+    case = dict(charge=q, sigma=sigma, epsilon=eps, exc_pairs=excl)
+    fn = hip_pair(B, ctx, dn, case, skin=0.1)
+    ff = hip_pair(B, ctx, dd, case, skin=0.1)
+    ctx.pair_share_list(fn, ff)
+    x, v, mass = dev(pos), dev(np.zeros((n, 3))), dev(np.ones(n))
+    f = [torch.zeros((n, 3), dtype=torch.float64, device='cuda') for _ in range(3)]
+    ctx.bind_state(x, v, mass)
+    for slot, buf in enumerate(f):
+        ctx.bind_buffer(slot, buf)
+    ctx.group_define(1, 1, [fn])
+    ctx.group_define(2, 2, [ff])
+    for stage in range(2):
+        x.copy_(dev(pos))
+        refs = {1: O.pair_eval(dn, pos, box, q, sigma, eps, excl)[1], 2: O.pair_eval(dd, pos, box, q, sigma, eps, excl)[1]}
+        fa = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+        ctx.force_eval(fn, x, fa)                                        # the near force alone
+        ctx.check()
+        assert np.abs(fa.cpu().numpy() - refs[1]).max() <= 1e-9 * np.abs(refs[1]).max()
+        ctx.run_ops([B.Op(B.OP_EVAL, 1, 0, 0, 0.0), B.Op(B.OP_EVAL, 2, 0, 0, 0.0)], 1)       # the fused pass
+        ctx.check()
+        for slot in (1, 2):
+            assert np.abs(f[slot].cpu().numpy() - refs[slot]).max() <= 1e-9 * np.abs(refs[slot]).max(), (pattern, slot)
+        st = ctx.pair_stats(fn)
+        assert st['list_kind'] == 1 and st['n_builds'] == stage + 1 and st['rode_along'] == 1
+        assert st['has_site_table'] == (1 if pattern in ('first', 'any') else 0)
+        # whole molecules move (many beyond skin / 2), across the faces of the box
+        pos = (pos.reshape(nm, 3, 3) + rng.uniform(-0.09, 0.09, (nm, 1, 3))).reshape(n, 3) + rng.normal(0.0, 0.003, (n, 3))
+    ctx.close()
+
+
 @pytest.mark.parametrize('seed', [11, 12, 13, 14, 15, 16, 21, 22, 23, 31, 32])
 def test_random_boxes_and_site_mixes_vs_oracle(seed):
     """Randomised configurations for the list build and both traversals: non-cubic boxes down to the size where a
