@@ -1291,13 +1291,29 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
     }
 }
 
-static int g_num_cu = 0;
 
 // one instantiation: dynamic LDS attribute + blocks per CU (cached), persistent grid (a multiple of 8 blocks)
 template <int FAM, int CMODE, int GFAM, int BS>
 static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts &c, const PairConsts &gc, TabArgs &T) {
-    static int bpc = -1, lds_set = 0;
+    // (the LDS attribute and the occupancy answer belong to a device: one slot per device, like the erfcx upload flags)
+    static int bpc_dev[64], lds_set_dev[64], cu_dev[64];
+    static bool init_dev[64];
+    int dev = 0;
+    AMM_HIP(hipGetDevice(&dev));
+    dev &= 63;
+    if (!init_dev[dev]) {
+        init_dev[dev] = true;
+        bpc_dev[dev] = -1;
+        lds_set_dev[dev] = 0;
+        AMM_HIP(hipDeviceGetAttribute(&cu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    int &bpc = bpc_dev[dev], &lds_set = lds_set_dev[dev];
+    const int g_num_cu = cu_dev[dev];
     const int lds = T.host_bytes + (GFAM >= 0 ? T.guest_bytes : 0) + AMM_ERFCX_NI * AMM_ERFCX_NC * 8;
+    if (lds > 160 * 1024) {
+        amm_set_error("tabulated pair kernel: the radial tables of the two forces do not fit LDS together");
+        return 1;
+    }
     auto kern = k_pair_tab<FAM, CMODE, GFAM, BS>;
     if (lds > lds_set) {
         AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1312,11 +1328,6 @@ static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts
             return 1;
         }
         bpc = nb;
-    }
-    if (!g_num_cu) {
-        int dev = 0;
-        AMM_HIP(hipGetDevice(&dev));
-        AMM_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     constexpr int WPB = BS / 64;
     long nblk = std::min((long)g_num_cu * bpc, ((long)T.ntask + WPB - 1) / WPB);
