@@ -179,6 +179,27 @@ def test_site_site_tables(spcfw, family):
     ref_c = O.pair_eval(d, close, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
     fc, _ = forces(close, c['charge'], 1)
     assert np.abs(fc - ref_c).max() <= 1e-9 * np.abs(ref_c).max()
+    # parameter updates through amm_pair_set_params (what parameter offsets do): charges scaled (another QQ), then other sites
+    # (another sigma / eps), then back to a state without a table and with one again -- the tables follow every time
+    ctx = B.HipContext(n, c['box'])
+    fid = hip_pair(B, ctx, d, c)
+    f = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+    ctx.force_eval(fid, dev(pos), f)
+    sites = c['epsilon'] != 0.0
+    uneven = c['charge'].copy()
+    uneven[np.where(sites)[0][0]] *= 1.1
+    for q_, s_, e_, table in ((0.9 * c['charge'], c['sigma'], c['epsilon'], 1),
+                              (0.9 * c['charge'], np.where(sites, 0.29, c['sigma']), 1.7 * c['epsilon'], 1),
+                              (uneven, c['sigma'], c['epsilon'], 0),
+                              (c['charge'], c['sigma'], c['epsilon'], 1)):
+        ctx.pair_set_params(fid, q_, s_, e_)
+        ctx.force_eval(fid, dev(pos), f)
+        ctx.check()
+        ref_p = O.pair_eval(d, pos, c['box'], q_, s_, e_, c['exc_pairs'])[1]
+        assert ctx.pair_stats(fid)['has_site_table'] == table
+        assert np.abs(f.cpu().numpy() - ref_p).max() <= 1e-9 * np.abs(ref_p).max()
+    assert np.array_equal(f.cpu().numpy(), f1)          # the same tables as a fresh context builds
+    ctx.close()
     # unequal site charges: no site-site table (the pair's qq is no longer one number), same forces as the oracle
     q2 = c['charge'].copy()
     q2[0] *= 1.25
