@@ -1040,10 +1040,12 @@ static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) 
     AMM_HIP(hipMemset(cl->d_ticket, 0, sizeof(int) * 4 * AMM_TICKET_INTS));
     AMM_HIP(hipMalloc(&cl->d_counters, sizeof(unsigned long long) * 8));
     AMM_HIP(hipMemset(cl->d_counters, 0, sizeof(unsigned long long) * 8));
-    // lanes per row: 8 rows per wavefront on a whole box; a rank's slice has fewer rows than the persistent grid has wavefronts
+    // lanes per row: 16 rows per wavefront on a whole box; a rank's slice has fewer rows than the persistent grid has wavefronts
     // (256 CUs x 8), so rows are shared out over more lanes until every wavefront has one task (measured on slices of the
     // 98 304-atom box, dual pass: 2 ranks 113 us with 8 lanes; 4 ranks 68 with 16 (107 with 8); 8 ranks 44 with 32 (105 with 8))
-    int lpa = 8;
+    // (whole boxes: 4 lanes = 16 rows per wavefront, one task per wavefront at 98 304 atoms: near / outer / fused 58 / 118 / 153 us
+    // against 60 / 121 / 156 with 8; at 255 552 atoms 142 / 314 / 416 against 150 / 319 / 427)
+    int lpa = 4;
     while (lpa < 64 && (long)(cl->c_end - cl->c_begin) * lpa < 64L * 2048) lpa <<= 1;
     if (ctx->opt_lpa > 0) lpa = ctx->opt_lpa;
     cl->lpa = lpa;

@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--world', type=int, default=1, help='emulate rank --rank of this many ranks (its slice of the rows, no collectives)')
     ap.add_argument('--rank', type=int, default=0)
     ap.add_argument('--cluster', type=int, default=1, help='1: molecule rows (product default for water), 0: per-atom rows')
+    ap.add_argument('--nside', type=int, default=32, help='waters per box edge (32: the relaxed C3 configuration; others: lattice start + jitter)')
     ap.add_argument('--no-lj', action='store_true', help='all epsilons zero (diagnostics)')
     ap.add_argument('--compare-fused', action='store_true', help='forces of the fused pass against the stand-alone launches, bit for bit')
     ap.add_argument('--option', action='append', default=[], help='name=value context option (amm_set_option), repeatable')
@@ -51,9 +52,11 @@ def main():
     import torch
     from atomsmm_amd import backend as B
     from atomsmm_amd.testing import tip3p_box
-    c = tip3p_box(32)
+    c = tip3p_box(args.nside)
     n = len(c['positions'])
-    if os.path.exists(CACHE):
+    if args.nside != 32:
+        c['positions'] = c['positions'] + np.random.default_rng(1).normal(0.0, 0.02, c['positions'].shape)
+    elif os.path.exists(CACHE):
         c['positions'] = np.load(CACHE)['positions']
     else:
         print('warning: no relaxed configuration (%s): timing the lattice start' % CACHE)
