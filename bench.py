@@ -42,6 +42,9 @@ TRAFFIC_FILE = 'r03_traffic.json'
 KB = 0.0083144626181532
 
 
+EXTRA_OPTIONS = []          # --option name=value: context options of the library (amm_set_option), tuning only
+
+
 def build_simulation(nside, loops, dt_fs, outer_kind='damped', skin=None, outer_skin=None):
     import atomsmm_amd as atomsmm
     from atomsmm_amd import openmm, unit
@@ -63,7 +66,8 @@ def build_simulation(nside, loops, dt_fs, outer_kind='damped', skin=None, outer_
     simulation = app.Simulation(app.Topology(len(case['positions'])), respa, integrator,
                                 openmm.Platform.getPlatformByName('HIP'),
                                 dict(([('Skin', str(skin))] if skin is not None else []) +
-                                     ([('OuterSkin', str(outer_skin))] if outer_skin is not None else [])) or None)
+                                     ([('OuterSkin', str(outer_skin))] if outer_skin is not None else []) +
+                                     [('Option.' + k, v) for k, v in EXTRA_OPTIONS]) or None)
     simulation.context.setPositions(case['positions'] * unit.nanometers)
     simulation.context.setVelocities(case['velocities'])
     return simulation, case
@@ -187,6 +191,7 @@ def main():
                     help='c3: the headline 98 304-atom TIP3P RESPA box; c5: ~249 000-atom solvated chain, RESPA + exceptions + AFED (2 fs inner step)')
     ap.add_argument('--outer-skin', type=float, default=None, help='dual Verlet list: buffer of the cell-built outer list in nm (default: single list)')
     ap.add_argument('--skin', type=float, default=None, help='Verlet buffer in nm (default: the library default, 0.1)')
+    ap.add_argument('--option', action='append', default=[], help='name=value: a context option of the library (tuning; not for the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-relax', action='store_true')
     ap.add_argument('--verbose', action='store_true')
@@ -194,6 +199,7 @@ def main():
                     help='also time this many steps with the PME NonbondedForce as the outer force (what RESPASystem leaves in group 2 for a '
                          'PME source, systems.py:74-75) and report them under detail.pme_outer; 0 skips it')
     args = ap.parse_args()
+    EXTRA_OPTIONS.extend(tuple(item.split('=', 1)) for item in args.option)
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), BEFORE anything touches
     # the GPU -- this process only waits and relays rank 0's JSON line
