@@ -290,7 +290,7 @@ def main():
     # the same box with the PME NonbondedForce as the outer force (what RESPASystem leaves in group 2 for a PME source,
     # systems.py:74-75; SURVEY 8d C3 ii): continued from the state the headline run ended in, its own short timed region
     pme_outer = None
-    if args.pme_steps > 0 and args.outer == 'damped' and args.config == 'c3':
+    if args.pme_steps > 0 and args.outer == 'damped' and args.config == 'c3' and world == 1:      # (a second context + communicator only on the 1-GPU line)
         from atomsmm_amd import unit
         sim2, _ = build_simulation(args.nside, loops, dt_fs, 'pme', args.skin, args.outer_skin)
         sim2.context.setPositions(eng.x.cpu().numpy() * unit.nanometers)
