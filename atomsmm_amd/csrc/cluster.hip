@@ -1062,12 +1062,12 @@ static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) 
     // wavefronts hide: 1.5 x the parts that would just fill the batches at the MEAN occupancy measured fastest
     // (98 304 atoms, 11.5 molecules per cell, us per rebuild: batch 8 x 2 parts 150, 6 x 3 127, 5 x 4 125, 4 x 4 131, 3 x 6 138).
     // A rank's slice covers 1 / world of the cells: its rows are spread over more waves, up to one row each (slice of 1/8: 99 us
-    // with 2 parts, 58 with 6)
+    // with 2 parts, 67 with 5-6)
     cl->parts = std::max(1, std::min(16, (int)std::ceil(1.5 * (double)nc / ncell / CB_BATCH)));
     if (ctx->world > 1) {
         const int active_cells = std::max(1, ncell / ctx->world);
         const int want = (4096 + active_cells - 1) / active_cells, most = std::max(1, (int)std::ceil((double)nc / ncell));
-        cl->parts = std::max(cl->parts, std::min(want, std::min(most, 8)));
+        cl->parts = std::max(cl->parts, std::min(want, std::min(most, 6)));      // (1/8 slice, us: 3 parts 87, 4 73, 5 67, 6 68, 8 79, 12 83)
     }
     if (ctx->opt_parts > 0) cl->parts = std::max(1, std::min(16, ctx->opt_parts));
     {
