@@ -9,8 +9,8 @@
  *   - the whole step loop in C (the Python driver of oracle/respa_cpu.py spent most of a step outside the pair loops);
  *   - one Verlet list (rc + skin) built from a cell grid in parallel, rows in cell-sorted order with the partners inside the
  *     near list radius first, shared by both pair forces; rebuilt when an atom has moved more than skin / 2;
- *   - owner-computes full rows (no atomics, no per-thread force copies), OpenMP over rows / molecules / atoms everywhere,
- *     first-touch allocation by the threads that later use the pages;
+ *   - every pair evaluated once (Newton's third law) into per-thread copies of the force arrays, summed in thread order (no
+ *     atomics); OpenMP over rows / molecules / atoms everywhere, first-touch allocation by the threads that later use the pages;
  *   - one force cache per group: 1 outer + n1 near + n0 n1 inner evaluations per step, the outer and the last near one in a
  *     single traversal.
  * Exclusions are the pairs inside a molecule (atoms 3m, 3m+1, 3m+2): what the reference's exceptions -> exclusions give for water.
@@ -33,6 +33,8 @@ typedef struct {
     int *nfront;                                /* entries of a row within the near list radius (they come first) */
     long builds, evals[3];
     double f12c, f6c, f1c, b;
+    double *scratch;                            /* per-thread copies of f1 and f2 (pair_pass) */
+    int scratch_threads;
 } port_t;
 
 static inline double min_image(double d, double L) { return d - L * nearbyint(d / L); }
@@ -198,33 +200,63 @@ static void check_list(port_t *p) {
     if (stale) build_list(p);
 }
 
-/* which: 1 near force only (front parts) -> f1; 2 outer force over the whole rows AND the near force over the front parts -> f2, f1 */
+/* which: 1 near force only (front parts) -> f1; 2 outer force over the whole rows AND the near force over the front parts -> f2, f1.
+ * Every pair is evaluated ONCE (Newton's third law: the row of the atom with the smaller index does it -- the rows are full, so it
+ * is there) into per-thread copies of the force arrays, which are then added up in thread order. */
 static void pair_pass(port_t *p, int which) {
     check_list(p);
     const double rc2 = p->rc * p->rc, rc02 = p->rc0 * p->rc0;
-#pragma omp parallel for schedule(dynamic, 32)
-    for (int s = 0; s < p->n; s++) {
-        const int i = p->order[s];
-        const double xi = p->x[3 * i], yi = p->x[3 * i + 1], zi = p->x[3 * i + 2], qi = p->q[i], hi = p->hsig[i], ei = p->seps2[i];
-        double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
-        const long b = p->nbr_ptr[s], e = which == 2 ? p->nbr_ptr[s + 1] : b + p->nfront[s], fe = b + p->nfront[s];
-        for (long k = b; k < e; k++) {
-            const int j = p->nbr_idx[k];
-            const double dx = min_image(xi - p->x[3 * j], p->box[0]), dy = min_image(yi - p->x[3 * j + 1], p->box[1]),
-                         dz = min_image(zi - p->x[3 * j + 2], p->box[2]);
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            const double qq = qi * p->q[j], sig = hi + p->hsig[j], eps4 = ei * p->seps2[j];
-            if (which == 2 && r2 < rc2) {
-                const double fr = damped_fr(p, r2, qq, sig, eps4);
-                fx += fr * dx; fy += fr * dy; fz += fr * dz;
+    const int nt = omp_get_max_threads();
+    const size_t n3 = 3 * (size_t)p->n;
+    if (p->scratch_threads < nt) {
+        free(p->scratch);
+        p->scratch = (double *)malloc(sizeof(double) * 2 * n3 * (size_t)nt);
+        p->scratch_threads = nt;
+    }
+#pragma omp parallel
+    {
+        const int t = omp_get_thread_num();
+        double *g1 = p->scratch + (size_t)t * 2 * n3, *g2 = g1 + n3;
+        memset(g1, 0, sizeof(double) * n3);
+        if (which == 2) memset(g2, 0, sizeof(double) * n3);
+#pragma omp for schedule(dynamic, 32)
+        for (int s = 0; s < p->n; s++) {
+            const int i = p->order[s];
+            const double xi = p->x[3 * i], yi = p->x[3 * i + 1], zi = p->x[3 * i + 2], qi = p->q[i], hi = p->hsig[i], ei = p->seps2[i];
+            double fx = 0, fy = 0, fz = 0, gx = 0, gy = 0, gz = 0;
+            const long b = p->nbr_ptr[s], e = which == 2 ? p->nbr_ptr[s + 1] : b + p->nfront[s], fe = b + p->nfront[s];
+            for (long k = b; k < e; k++) {
+                const int j = p->nbr_idx[k];
+                if (j < i) continue;                              /* the row of j has this pair */
+                const double dx = min_image(xi - p->x[3 * j], p->box[0]), dy = min_image(yi - p->x[3 * j + 1], p->box[1]),
+                             dz = min_image(zi - p->x[3 * j + 2], p->box[2]);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const double qq = qi * p->q[j], sig = hi + p->hsig[j], eps4 = ei * p->seps2[j];
+                if (which == 2 && r2 < rc2) {
+                    const double fr = damped_fr(p, r2, qq, sig, eps4);
+                    fx += fr * dx; fy += fr * dy; fz += fr * dz;
+                    g2[3 * j] -= fr * dx; g2[3 * j + 1] -= fr * dy; g2[3 * j + 2] -= fr * dz;
+                }
+                if (k < fe && r2 < rc02) {
+                    const double fr = near_fr(p, r2, qq, sig, eps4);
+                    gx += fr * dx; gy += fr * dy; gz += fr * dz;
+                    g1[3 * j] -= fr * dx; g1[3 * j + 1] -= fr * dy; g1[3 * j + 2] -= fr * dz;
+                }
             }
-            if (k < fe && r2 < rc02) {
-                const double fr = near_fr(p, r2, qq, sig, eps4);
-                gx += fr * dx; gy += fr * dy; gz += fr * dz;
-            }
+            if (which == 2) { g2[3 * i] += fx; g2[3 * i + 1] += fy; g2[3 * i + 2] += fz; }
+            g1[3 * i] += gx; g1[3 * i + 1] += gy; g1[3 * i + 2] += gz;
         }
-        if (which == 2) { p->f2[3 * i] = fx; p->f2[3 * i + 1] = fy; p->f2[3 * i + 2] = fz; }
-        p->f1[3 * i] = gx; p->f1[3 * i + 1] = gy; p->f1[3 * i + 2] = gz;
+        /* (implicit barrier) the threads' copies, added in thread order */
+#pragma omp for schedule(static)
+        for (long c = 0; c < (long)n3; c++) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int u = 0; u < nt; u++) {
+                a1 += p->scratch[(size_t)u * 2 * n3 + c];
+                if (which == 2) a2 += p->scratch[(size_t)u * 2 * n3 + n3 + c];
+            }
+            p->f1[c] = a1;
+            if (which == 2) p->f2[c] = a2;
+        }
     }
     p->evals[1]++;
     if (which == 2) p->evals[2]++;
@@ -336,6 +368,6 @@ void port_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 void port_destroy(port_t *p) {
     double *d[] = {p->x, p->v, p->m, p->q, p->hsig, p->seps2, p->f0, p->f1, p->f2, p->xref};
     for (unsigned a = 0; a < sizeof(d) / sizeof(d[0]); a++) free(d[a]);
-    free(p->order); free(p->nbr_idx); free(p->nbr_ptr); free(p->nfront);
+    free(p->order); free(p->nbr_idx); free(p->nbr_ptr); free(p->nfront); free(p->scratch);
     free(p);
 }
