@@ -595,6 +595,10 @@ def test_neighbour_list_rebuild_and_reuse(spcfw, outer_skin):
 
 @pytest.mark.parametrize('seed', [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_random_molecule_boxes_vs_oracle(seed):
+    random_molecule_case(seed, seed - 1)
+
+
+def random_molecule_case(seed, pattern_index):
     """Randomised boxes of three-atom molecules for the molecule-row path (csrc/cluster.hip): non-cubic boxes from the size that
     needs the image per atom pair up to one with interior rows, molecules of random shape and orientation (extent 0.07-0.14 nm),
     and the site patterns that select the kernel variants -- one site class on the first atom (site-site tables, SMASK 1), the
@@ -612,7 +616,7 @@ def test_random_molecule_boxes_vs_oracle(seed):
     arms *= (rng.uniform(0.07, 0.14, (nm, 2)) / np.linalg.norm(arms, axis=2))[:, :, None]
     pos = np.concatenate([centre[:, None, :], centre[:, None, :] + arms], axis=1).reshape(-1, 3)
     n = 3 * nm
-    pattern = ['first', 'any', 'two-classes', 'unequal-charges', 'first', 'none', 'any', 'first', 'two-classes'][seed - 1]
+    pattern = ['first', 'any', 'two-classes', 'unequal-charges', 'first', 'none', 'any', 'first', 'two-classes'][pattern_index % 9]
     q = np.tile([-0.8, 0.4, 0.4], nm) * rng.uniform(0.9, 1.1)
     sigma = np.full(n, 0.1)
     eps = np.zeros(n)
