@@ -34,7 +34,7 @@ EXPORTS = [
     'amm_bonded_add_terms', 'amm_bonded_finalize', 'amm_bonded_set_sliced', 'amm_bonded_release', 'amm_force_eval', 'amm_kick',
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
-    'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read', 'amm_pair_count_within', 'amm_kernel_revision',
+    'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read', 'amm_pair_count_within', 'amm_pair_row_padding', 'amm_kernel_revision',
     'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_bath_define_nhl', 'amm_bath_define_sin', 'amm_iso_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
     'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_destroy', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
     'amm_set_option', 'amm_exchange_per',
@@ -131,6 +131,7 @@ def lib():
         L.amm_pair_get_stats.argtypes = [vp, C.c_int32, C.POINTER(PairStats)]
         L.amm_profile_enable.argtypes = [vp, C.c_int32]
         L.amm_pair_count_within.argtypes = [vp, C.c_int32, vp, C.c_double, C.POINTER(C.c_int64)]
+        L.amm_pair_row_padding.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
         L.amm_kernel_revision.restype = C.c_char_p
         L.amm_kernel_revision.argtypes = []
         L.amm_profile_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), dp]
@@ -425,6 +426,12 @@ class HipContext:
         st = PairStats()
         _chk(lib().amm_pair_get_stats(self.h, fid, C.byref(st)))
         return {name: getattr(st, name) for name, _ in PairStats._fields_}
+
+    def pair_row_padding(self, fid):
+        """(lane-trips executed, row entries) of the molecule-row traversal of this force; (0, 0) for per-atom rows."""
+        out = (C.c_int64 * 2)()
+        _chk(lib().amm_pair_row_padding(self.h, fid, out))
+        return int(out[0]), int(out[1])
 
     def pair_count_within(self, fid, pos, r_within):
         """Directed list entries of force `fid` with r < r_within at `pos` (fp64 count on the device; synchronises)."""

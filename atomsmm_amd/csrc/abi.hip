@@ -1295,6 +1295,22 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     return 0;
 }
 
+int amm_pair_row_padding(amm_ctx *ctx, int32_t force_id, int64_t out[2]) {
+    PairForce *pf = get_pair(ctx, force_id);
+    if (!pf || !out) {
+        amm_set_error("amm_pair_row_padding: null argument or not a pair force");
+        return 1;
+    }
+    PairForce *L = pf->host ? pf->host : pf;
+    out[0] = out[1] = 0;
+    if (!(L->last_kind == 1 && L->cl && L->cl->built)) return 0;       // per-atom rows: not reported
+    long long v[2];
+    if (amm_cluster_row_padding_impl(ctx, pf, v)) return 1;
+    out[0] = v[0];
+    out[1] = v[1];
+    return 0;
+}
+
 int amm_pair_count_within(amm_ctx *ctx, int32_t force_id, const double *d_pos, double r_within, int64_t *count) {
     PairForce *pf = get_pair(ctx, force_id);
     if (!pf || !d_pos || !count) {

@@ -47,4 +47,5 @@ bool amm_cluster_qualifies(int n, const std::vector<int> &excl_ptr, const std::v
 int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, PairForce *guest,
                           double *g_force, int g_accumulate, int exchange);
 int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double r_within, long long *count);
+int amm_cluster_row_padding_impl(amm_ctx *ctx, PairForce *pf, long long out[2]);
 int amm_cluster_free(ClusterList *cl);

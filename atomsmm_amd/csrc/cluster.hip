@@ -1351,6 +1351,51 @@ int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_p
     return 0;
 }
 
+// measurement helper: how much of the traversal's lane-trips holds an entry.  A wavefront walks 64 / lpa rows at once, lpa lanes per
+// row, until the LONGEST of them is done: out[0] = lane-trips executed (64 x trips, summed over the wavefront tasks), out[1] = entries.
+__global__ void __launch_bounds__(256) k_crow_padding(int nrows, int lpa_shift, const int *__restrict__ nnb, unsigned long long *out) {
+    const int task = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rpw = 64 >> lpa_shift, lpa = 1 << lpa_shift;
+    unsigned long long slots = 0, entries = 0;
+    if (task * rpw < nrows) {
+        int longest = 0;
+        for (int r = task * rpw; r < min(nrows, (task + 1) * rpw); ++r) {
+            const int nn = nnb[r];
+            entries += (unsigned long long)nn;
+            longest = max(longest, (nn + lpa - 1) >> lpa_shift);
+        }
+        slots = 64ull * (unsigned long long)longest;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        slots += __shfl_xor(slots, off);
+        entries += __shfl_xor(entries, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], slots);
+        atomicAdd(&out[1], entries);
+    }
+}
+
+int amm_cluster_row_padding_impl(amm_ctx *ctx, PairForce *pf, long long out[2]) {
+    PairForce *L = pf->host ? pf->host : pf;
+    ClusterList *cl = L->cl;
+    hipStream_t st = ctx->stream;
+    const int nrows = cl->c_end - cl->c_begin;
+    int sh = 0;
+    while ((1 << sh) < cl->lpa) ++sh;
+    unsigned long long *d_out = cl->d_counters + 5;
+    AMM_HIP(hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), st));
+    const int ntask = (nrows + (64 >> sh) - 1) / (64 >> sh);
+    if (ntask > 0)
+        hipLaunchKernelGGL(k_crow_padding, dim3((unsigned)((ntask + 255) / 256)), dim3(256), 0, st, nrows, sh, (pf == L) ? cl->d_nnb : cl->d_nnb_near, d_out);
+    unsigned long long h[2] = {0, 0};
+    AMM_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));
+    AMM_HIP(hipStreamSynchronize(st));
+    out[0] = (long long)h[0];
+    out[1] = (long long)h[1];
+    return 0;
+}
+
 int amm_cluster_free(ClusterList *cl) {
     void *ptrs[] = {cl->d_cell_count, cl->d_cell_start, cl->d_cell_members, cl->d_cperm, cl->d_aperm, cl->d_pos4f, cl->d_xref, cl->d_nl,
                     cl->d_nnb, cl->d_nnb_near, cl->d_flags, cl->d_counters, cl->d_blockstats, cl->d_ticket};

@@ -293,6 +293,13 @@ def main():
     # (fp64, outside the timed region); directed entries / 2 = pairs counted once (this rank's slice of the rows)
     pairs_near = eng.ctx.pair_count_within(near_id, eng.x, 0.7) / 2
     pairs_far = eng.ctx.pair_count_within(far_id, eng.x, 1.0) / 2
+    # molecule rows: lane-trips the walks execute against the entries they hold (a wavefront's rows run to the longest of them)
+    padding = {}
+    if hasattr(eng.ctx, 'pair_row_padding'):
+        for name, fid in (('near', near_id), ('outer', far_id)):
+            slots, entries = eng.ctx.pair_row_padding(fid)
+            if slots:
+                padding[name] = {'lane_trips': slots, 'entries': entries, 'used': round(entries / slots, 4)}
 
     # the same box with the PME NonbondedForce as the outer force (what RESPASystem leaves in group 2 for a PME source,
     # systems.py:74-75; SURVEY 8d C3 ii): continued from the state the headline run ended in, its own short timed region
@@ -425,7 +432,7 @@ def main():
                        'near_list_pairs': near_stats['n_list_pairs'], 'far_list_pairs': st1[far_id]['n_list_pairs'],
                        'pairs_within_0.7nm_counted': int(pairs_near), 'pairs_within_1.0nm_counted': int(pairs_far),
                        'kernel_revision': backend.kernel_revision(), 'rows': 'one per molecule' if near_stats.get('list_kind') else 'one per atom',
-                       'pme_outer': pme_outer},
+                       'row_padding': padding or None, 'pme_outer': pme_outer},
         }
         if world == 1 and not args.no_cpu_baseline and args.outer == 'damped':
             try:

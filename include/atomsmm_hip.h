@@ -307,6 +307,10 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /
  * fp64 by one launch over the neighbour rows (an evaluation must have built them).  Half of it is the number of pairs the
  * reference's expression is evaluated for when r_within is the force's cutoff (forces.py:659-661).  Synchronises. */
 int amm_pair_count_within(amm_ctx *ctx, int32_t force_id, const double *d_pos, double r_within, int64_t *count);
+/* Measurement helper (bench.py): molecule rows -- out[0] = lane-trips the traversal of this force executes (a wavefront walks
+   64 / lanes_per_row rows until the longest is done), out[1] = row entries; their ratio is the padding of the walk.  Zeros for
+   per-atom rows.  Synchronises. */
+int amm_pair_row_padding(amm_ctx *ctx, int32_t force_id, int64_t out[2]);
 /* Revision tag of the pair-traversal kernels: measurements kept under profiles/ carry it, and bench.py drops a stored
  * figure (the PMC traffic) once the kernels it was measured on have changed. */
 const char *amm_kernel_revision(void);
