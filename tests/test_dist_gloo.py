@@ -274,3 +274,15 @@ def test_bench_launches_its_own_ranks():
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     assert json.loads(lines[0]) == {'dryrun': True, 'n_gpus': 3, 'rank_sum': 6.0}
+
+
+def test_slices_are_whole_molecules_and_cover_every_atom():
+    """The rule both list kinds slice by (backend.slice_per == amm_slice_per of csrc/amm_ctx.h): a rank owns `per` consecutive
+    slots of the cell-sorted order, per a multiple of three (molecule rows slice by molecule), world * per >= n."""
+    from atomsmm_amd import backend as B
+    for n in (3, 24, 1536, 4233, 98304, 249075):
+        for world in (1, 2, 3, 4, 5, 8, 16):
+            per = B.slice_per(n, world)
+            assert per % 3 == 0 and world * per >= n
+            assert (world - 1) * per < n + 3 * world            # no more than a molecule of slack per rank
+            assert per == 3 * -(-(-(-n // 3)) // world)
