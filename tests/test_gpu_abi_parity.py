@@ -119,6 +119,8 @@ def test_molecule_rows_edge_cases(spcfw):
     check_against_oracle(c['positions'])
     st = ctx.pair_stats(fid)
     assert st['list_kind'] == 1 and st['n_builds'] == 1
+    slots, entries = ctx.pair_row_padding(fid)            # lane-trips executed vs entries held (measurement helper)
+    assert 9 * entries == st['n_list_pairs'] and entries <= slots <= 4 * entries
     rng = np.random.default_rng(7)
     # whole molecules move by up to 0.12 nm (beyond skin / 2: rebuild), every atom a little on top, across the box faces
     pos = c['positions'].reshape(-1, 3, 3) + rng.uniform(-0.12, 0.12, (n // 3, 1, 3)) + rng.normal(0.0, 0.004, (n // 3, 3, 3))
