@@ -245,8 +245,24 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
         idx[fill[j]++] = i;
     }
     if (upload(&pf->d_excl_ptr, ptr.data(), ptr.size()) || upload(&pf->d_excl_idx, idx.data(), idx.size())) return 1;
-    // water-like systems take molecule rows on the force-only hot path (cluster.h)
-    pf->cluster_ok = amm_family_allows_cluster(desc->family, desc->flags) && amm_cluster_qualifies(n, ptr, idx);
+    // Three-site molecules take molecule rows on the force-only hot path (cluster.h).  A box of nothing else: molecule rows only.
+    // Molecules next to other atoms (ions, a solute, a chain; at least half of the atoms in molecules): a hybrid list -- molecule
+    // rows for the pairs of two molecules, per-atom rows kept by a hidden child force for every pair with an atom outside them.
+    // The reference makes no such distinction (forces.py:299-312 copies any particle list, every exception -> exclusion).
+    std::vector<int> rest_atoms;
+    if (amm_family_allows_cluster(desc->family, desc->flags) && !ctx->creating_rest) {
+        std::vector<int> mol_first;
+        amm_cluster_classify(n, ptr, idx, mol_first, rest_atoms);
+        pf->n_mol = (int)mol_first.size();
+        pf->n_rest = (int)rest_atoms.size();
+        if (pf->n_mol > 0 && pf->n_rest == 0) {
+            pf->cluster_ok = true;
+        } else if (pf->n_mol > 0 && 2 * 3 * (long)pf->n_mol >= (long)n) {
+            pf->cluster_ok = pf->hybrid = true;
+            pf->h_mol_first = mol_first;
+            if (upload(&pf->d_mol_first, mol_first.data(), mol_first.size()) || upload(&pf->d_rest_idx, rest_atoms.data(), rest_atoms.size())) return 1;
+        }
+    }
     AMM_HIP(hipMalloc(&pf->d_q, sizeof(double) * n));
     AMM_HIP(hipMalloc(&pf->d_hsig, sizeof(double) * n));
     AMM_HIP(hipMalloc(&pf->d_seps2, sizeof(double) * n));
@@ -278,7 +294,22 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
     ctx->forces.push_back(fo);
     *force_id = (int)ctx->forces.size() - 1;
     pf->id = *force_id;
-    return amm_pair_set_params(ctx, *force_id, h_q, h_sigma, h_eps);
+    if (amm_pair_set_params(ctx, *force_id, h_q, h_sigma, h_eps)) return 1;
+    if (pf->hybrid) {
+        // the child: same particles, parameters, exclusions and Verlet buffer; its list keeps the pairs with a rest atom (code 2)
+        int32_t child_id = -1;
+        ctx->creating_rest = true;
+        const int rc = amm_pair_create(ctx, desc, h_q, h_sigma, h_eps, h_excl, n_excl, skin, &child_id);
+        ctx->creating_rest = false;
+        if (rc) return 1;
+        PairForce *child = ctx->forces[child_id].pair;
+        child->hybrid_rest = true;
+        std::vector<float> code(n, 1.0f);
+        for (int i : rest_atoms) code[i] = 2.0f;
+        if (upload(&child->d_member, code.data(), code.size())) return 1;
+        pf->rest = child;
+    }
+    return 0;
 }
 
 int amm_pair_set_lambda(amm_ctx *ctx, int32_t force_id, double value) {
@@ -319,14 +350,12 @@ int amm_pair_energy_derivative(amm_ctx *ctx, int32_t force_id, const double *d_p
     return rc;
 }
 
-int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id) {
-    PairForce *g = get_pair(ctx, force_id), *h = get_pair(ctx, host_id);
-    if (!g || !h) return 1;
+static int share_list_pf(amm_ctx *ctx, PairForce *g, PairForce *h) {
     if (g == h || h->host || g->host || g->rnear_build > 0) {
         amm_set_error("amm_pair_share_list: invalid host/guest combination");
         return 1;
     }
-    if (g->d_member || h->d_member) {
+    if ((g->d_member || h->d_member) && !(g->hybrid_rest && h->hybrid_rest)) {
         amm_set_error("amm_pair_share_list: an interaction-group force keeps its own (filtered) neighbour list");
         return 1;
     }
@@ -372,7 +401,19 @@ int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id) {
     h->rlist_out_build = h->desc.rc + h->skin_out + 2e-4;
     h->rnear_build = g->rlist_build;
     g->host = h;
+    // both hybrid (same exclusions: the same molecules): the per-atom parts share a list the same way
+    if (g->rest && h->rest) return share_list_pf(ctx, g->rest, h->rest);
     return 0;
+}
+
+int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id) {
+    PairForce *g = get_pair(ctx, force_id), *h = get_pair(ctx, host_id);
+    if (!g || !h) return 1;
+    if (g->hybrid_rest || h->hybrid_rest) {
+        amm_set_error("amm_pair_share_list: not a force of the caller's");
+        return 1;
+    }
+    return share_list_pf(ctx, g, h);
 }
 
 int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const double *h_sigma, const double *h_eps) {
@@ -408,10 +449,17 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
     }
     // one Lennard-Jones site class?  (water: the oxygens) -- the molecule-row kernels then need no per-atom LJ records
     {
+        // (hybrid lists: the molecule rows hold the molecules' atoms only -- the sites that matter are theirs)
+        std::vector<char> in_mol;
+        if (pf->hybrid) {
+            in_mol.assign(n, 0);
+            for (int i0 : pf->h_mol_first) in_mol[i0] = in_mol[i0 + 1] = in_mol[i0 + 2] = 1;
+        }
+        auto skip = [&](int i) { return h_eps[i] == 0.0 || (pf->hybrid && !in_mol[i]); };
         pf->one_site_class = true;
         bool seen = false;
         for (int i = 0; i < n; ++i) {
-            if (h_eps[i] == 0.0) continue;
+            if (skip(i)) continue;
             if (!seen) {
                 seen = true;
                 pf->site_hsig = hs[i];
@@ -427,7 +475,7 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
         pf->site_q = 0.0;
         bool first = true;
         for (int i = 0; i < n && pf->site_one_charge; ++i) {
-            if (h_eps[i] == 0.0) continue;
+            if (skip(i)) continue;
             if (first) {
                 first = false;
                 pf->site_q = h_q[i];
@@ -436,8 +484,14 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
             }
         }
         pf->site_atoms = 0;
-        for (int i = 0; i < n; ++i)
-            if (h_eps[i] != 0.0) pf->site_atoms |= 1 << (i % 3);
+        if (pf->hybrid) {
+            for (int i0 : pf->h_mol_first)
+                for (int a = 0; a < 3; ++a)
+                    if (h_eps[i0 + a] != 0.0) pf->site_atoms |= 1 << a;
+        } else {
+            for (int i = 0; i < n; ++i)
+                if (h_eps[i] != 0.0) pf->site_atoms |= 1 << (i % 3);
+        }
         const double now[3] = {pf->site_hsig, pf->site_seps2, (pf->one_site_class && pf->site_one_charge) ? pf->site_q : 0.0};
         if (pf->cluster_ok && (now[0] != pf->ss_built_for[0] || now[1] != pf->ss_built_for[1] || now[2] != pf->ss_built_for[2])) {
             AMM_HIP(hipStreamSynchronize(ctx->stream));       // (kernels in flight read the tables about to be replaced)
@@ -464,6 +518,7 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
     pf->dual_ok = pf->fuse_ok = -1;
     for (auto &fo : ctx->forces)
         if (fo.type == 1 && fo.pair->host == pf) fo.pair->dual_ok = fo.pair->fuse_ok = -1;
+    if (pf->rest) return amm_pair_set_params(ctx, pf->rest->id, h_q, h_sigma, h_eps);
     return 0;
 }
 
@@ -1264,7 +1319,8 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     out->rode_along = pf->last_fused;
     out->has_site_table = (ctx->opt_site_tab && pf->d_tab_ss && pf->pc.tab.ss_first >= 0) ? 1 : 0;
     out->site_tab_error = pf->ss_error;
-    if (L->last_kind == 1 && L->cl && L->cl->built) {
+    out->n_rest_atoms = L->hybrid ? L->n_rest : 0;
+    if (L->last_kind >= 1 && L->cl && L->cl->built) {
         ClusterList *cl = L->cl;
         int flags[8];
         unsigned long long cnt[8];
@@ -1278,6 +1334,10 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
         out->n_list_pairs = 9 * (int64_t)(pf->host ? cnt[2] : cnt[1]);      // atom pairs evaluated: nine per molecule-pair entry
         out->max_neighbors = flags[2];
         out->rlist_outer = L->desc.rc + L->skin;
+        if (L->last_kind == 2 && L->rest && L->rest->built) {          // + the entries of the per-atom part
+            AMM_HIP(hipMemcpy(cnt, L->rest->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+            out->n_list_pairs += (int64_t)(pf->host ? cnt[2] : cnt[1]);
+        }
         return 0;
     }
     if (L->built) {
@@ -1303,7 +1363,7 @@ int amm_pair_row_padding(amm_ctx *ctx, int32_t force_id, int64_t out[2]) {
     }
     PairForce *L = pf->host ? pf->host : pf;
     out[0] = out[1] = 0;
-    if (!(L->last_kind == 1 && L->cl && L->cl->built)) return 0;       // per-atom rows: not reported
+    if (!(L->last_kind >= 1 && L->cl && L->cl->built)) return 0;       // per-atom rows: not reported
     long long v[2];
     if (amm_cluster_row_padding_impl(ctx, pf, v)) return 1;
     out[0] = v[0];
@@ -1319,8 +1379,13 @@ int amm_pair_count_within(amm_ctx *ctx, int32_t force_id, const double *d_pos, d
     }
     long long c = 0;
     PairForce *Lw = pf->host ? pf->host : pf;
-    if (Lw->last_kind == 1 && Lw->cl && Lw->cl->built) {
+    if (Lw->last_kind >= 1 && Lw->cl && Lw->cl->built) {
         if (amm_cluster_count_within_impl(ctx, pf, d_pos, r_within, &c)) return 1;
+        if (Lw->last_kind == 2 && pf->rest && Lw->rest && Lw->rest->built) {
+            long long c2 = 0;
+            if (amm_pair_count_within_impl(ctx, pf->rest, d_pos, r_within, &c2)) return 1;
+            c += c2;
+        }
     } else if (amm_pair_count_within_impl(ctx, pf, d_pos, r_within, &c)) return 1;
     *count = (int64_t)c;
     return 0;
@@ -1341,6 +1406,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     const std::string k(name);
     const int v = (int)value;
     if (k == "cluster") ctx->opt_cluster = v;
+    else if (k == "hybrid") ctx->opt_hybrid = v;
     else if (k == "tab") ctx->opt_tab = v;
     else if (k == "site_trips") ctx->site_trips = v != 0;
     else if (k == "lanes_per_row") ctx->opt_lpa = v;

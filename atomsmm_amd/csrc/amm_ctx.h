@@ -62,7 +62,15 @@ struct ClusterList;   // cluster.h: molecule-row list of the force-only traversa
 struct PairForce {
     amm_pair_desc desc;
     ClusterList *cl = nullptr;     // molecule rows (built on the first force-only evaluation of a qualifying force; list owners only)
-    bool cluster_ok = false;       // every atom sits in a three-atom molecule whose three pairs are the force's only exclusions
+    bool cluster_ok = false;       // the force has three-site molecules (their three pairs their only exclusions) and walks molecule rows
+    // Hybrid list: molecule rows for the pairs of two such molecules + per-atom rows, kept by a hidden child force (`rest`, filtered to
+    // the pairs that involve an atom outside the molecules), for everything else -- an ion, a solute, a chain next to the waters.
+    bool hybrid = false;
+    PairForce *rest = nullptr;     // the child (registered in ctx->forces behind its parent, in no group)
+    bool hybrid_rest = false;      // this force IS such a child: its list keeps the pairs with at least one rest atom (code 2)
+    std::vector<int> h_mol_first;  // first atom of every molecule; empty: molecule m = atoms 3 m .. 3 m + 2 (no rest atoms)
+    int n_mol = 0, n_rest = 0;
+    int *d_mol_first = nullptr, *d_rest_idx = nullptr;
     bool force_rebuild_c = false;  // the molecule rows carry site bits of another site pattern
     bool one_site_class = false;   // all atoms with eps != 0 share ONE (sigma, eps): the molecule-row kernels carry them as constants
     double site_hsig = 0, site_seps2 = 0;
@@ -73,7 +81,7 @@ struct PairForce {
     double ss_error = 0;           // its largest relative interpolation error
     double ss_built_for[3] = {0, 0, 0};     // (sigma/2, 2 sqrt(eps), q) the tables were last built for
     int last_fused = 0;            // 1: the last force-only evaluation rode on the list owner's launch (molecule rows, fused pass)
-    int last_kind = 0;             // list walked by the last evaluation: 0 per-atom rows, 1 molecule rows (statistics)
+    int last_kind = 0;             // list walked by the last evaluation: 0 per-atom rows, 1 molecule rows, 2 hybrid (statistics)
     PairConsts pc;
     int n = 0;
     int id = -1;                   // force id within the context
@@ -231,6 +239,7 @@ struct PendingExchange {
 };
 
 // a neighbour list whose displacement trigger the kernel that moves the atoms evaluates (saves the check launch)
+#define AMM_MAX_WATCH 4
 struct ListWatch {
     const double *xref = nullptr;
     double thr2 = 0;
@@ -250,12 +259,14 @@ struct amm_ctx {
     // tuning / test options (amm_set_option): never read from the environment, so that a stray variable cannot change the
     // order of summation of a production run
     int opt_cluster = 1;           // molecule rows for qualifying forces (0: per-atom rows everywhere)
+    int opt_hybrid = 1;            // ... also when the three-site molecules share the box with other atoms (hybrid lists)
+    bool creating_rest = false;    // amm_pair_create is making the hidden child of a hybrid list
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
     int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
     int opt_site_tab = 1;               // molecule rows: site-site radial tables instead of Lennard-Jones arithmetic where a force has one
     int opt_fuse_rows = 1;              // molecule rows: host + guest force of a shared list in ONE launch when a fused kernel exists
     int opt_no_dual = 0, opt_no_defer = 0, opt_terms_from = 8192, opt_no_term_lanes = 0;
-    ListWatch watched[2];
+    ListWatch watched[AMM_MAX_WATCH];
     int n_watched = 0;
     int device = 0;
     hipStream_t stream = nullptr;

@@ -358,9 +358,9 @@ struct CompArgs {
     // displacement watchers: neighbour lists whose rebuild trigger this kernel evaluates for the positions it
     // writes (saves the separate k_check_displacement launch before the next pair-force evaluation)
     int nwatch;
-    const double *wref[2];
-    double wthr2[2];
-    int *wflags[2];
+    const double *wref[AMM_MAX_WATCH];
+    double wthr2[AMM_MAX_WATCH];
+    int *wflags[AMM_MAX_WATCH];
 };
 
 // G lanes (4 or 8, a power of two dividing the wavefront) share one component, lane l owns the component's atom l.  Each lane kicks/moves its own atom, publishes the new position in
@@ -901,7 +901,7 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     {
         // lists whose rebuild trigger this launch evaluates: the molecule rows first (the hot path's), then single per-atom lists
         auto watch = [&](const double *xref, double skin, int *flags, long *pre_epoch, const double **pre_pos) {
-            if (C.nwatch >= 2) return;
+            if (C.nwatch >= AMM_MAX_WATCH) return;
             C.wref[C.nwatch] = xref;
             C.wthr2[C.nwatch] = 0.25 * skin * skin;
             C.wflags[C.nwatch] = flags;
@@ -914,10 +914,10 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
             C.nwatch++;
         };
         for (auto &fo : ctx->forces)
-            if (fo.type == 1 && fo.pair->cl && fo.pair->cl->built && fo.pair->last_kind == 1)
+            if (fo.type == 1 && fo.pair->cl && fo.pair->cl->built && fo.pair->last_kind >= 1)
                 watch(fo.pair->cl->d_xref, fo.pair->cl->skin, fo.pair->cl->d_flags, &fo.pair->cl->pre_epoch, &fo.pair->cl->pre_pos);
         for (auto &fo : ctx->forces)
-            if (fo.type == 1 && fo.pair->built && !fo.pair->host && !fo.pair->dual && !(fo.pair->cl && fo.pair->last_kind == 1))
+            if (fo.type == 1 && fo.pair->built && !fo.pair->host && !fo.pair->dual && !(fo.pair->cl && fo.pair->last_kind >= 1))
                 watch(fo.pair->d_xref, fo.pair->skin, fo.pair->d_flags, &fo.pair->pre_epoch, &fo.pair->pre_pos);
         ctx->n_watched = C.nwatch;
     }

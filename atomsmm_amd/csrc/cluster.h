@@ -16,7 +16,10 @@
 #include "amm_ctx.h"
 
 struct ClusterList {
-    int nc = 0;                    // molecules (clusters of 3 atoms: 3m, 3m+1, 3m+2)
+    int nc = 0;                    // molecules (clusters of 3 atoms: first[m], first[m] + 1, first[m] + 2)
+    const int *d_first = nullptr;  // first atom of every molecule (the force's); nullptr: 3 m (every atom of the force is in a molecule)
+    const int *d_rest = nullptr;   // hybrid list: the atoms outside the molecules (their pairs are the child's, per-atom rows) ...
+    int nrest = 0;                 // ... and their number
     bool built = false;
     CellGrid grid;
     int capc = 0;                  // members per cell in the cell tables
@@ -41,8 +44,9 @@ struct ClusterList {
     bool per_pair_image = false;   // small box: the periodic image is chosen per atom pair, not per molecule pair
 };
 
-// does the force qualify?  (host; exclusion CSR in original indices)
-bool amm_cluster_qualifies(int n, const std::vector<int> &excl_ptr, const std::vector<int> &excl_idx);
+// three-site molecules of a force and the atoms outside them (host; exclusion CSR in original indices)
+void amm_cluster_classify(int n, const std::vector<int> &excl_ptr, const std::vector<int> &excl_idx, std::vector<int> &mol_first,
+                          std::vector<int> &rest);
 // the force-only evaluation of `pf` (and of `guest` on the same pass) over molecule rows; same contract as amm_pair_eval_impl
 int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, PairForce *guest,
                           double *g_force, int g_accumulate, int exchange);

@@ -36,17 +36,30 @@
 __device__ double amm_erfcx_table_dev_c[AMM_ERFCX_NI * AMM_ERFCX_NC];
 static bool g_erfcx_uploaded_c[64] = {false};
 
-// ------------------------------------------------------------------------------------------------ qualification (host)
-bool amm_cluster_qualifies(int n, const std::vector<int> &ptr, const std::vector<int> &idx) {
-    if (n < 3 || n % 3 != 0) return false;
-    for (int i = 0; i < n; ++i) {
+// ------------------------------------------------------------------------------------------------ classification (host)
+// Three-site molecules of a force: atoms i, i + 1, i + 2 whose only exclusions are their own three pairs (the reference turns
+// every exception into an exclusion, forces.py:310-312, so this is a flexible or rigid three-site water).  Every other atom --
+// an ion, a solute, a chain, a four-site water -- is "rest": its pairs go through per-atom rows (the force's hidden child).
+void amm_cluster_classify(int n, const std::vector<int> &ptr, const std::vector<int> &idx, std::vector<int> &mol_first, std::vector<int> &rest) {
+    mol_first.clear();
+    rest.clear();
+    auto own_pairs_only = [&](int i, int i0) {
         if (ptr[i + 1] - ptr[i] != 2) return false;
-        const int m = i / 3, a = i - 3 * m;
-        const int p0 = 3 * m + (a == 0 ? 1 : 0), p1 = 3 * m + (a == 2 ? 1 : 2);
+        const int a = i - i0;
+        const int p0 = i0 + (a == 0 ? 1 : 0), p1 = i0 + (a == 2 ? 1 : 2);
         const int e0 = idx[ptr[i]], e1 = idx[ptr[i] + 1];
-        if (!((e0 == p0 && e1 == p1) || (e0 == p1 && e1 == p0))) return false;
+        return (e0 == p0 && e1 == p1) || (e0 == p1 && e1 == p0);
+    };
+    int i = 0;
+    while (i < n) {
+        if (i + 2 < n && own_pairs_only(i, i) && own_pairs_only(i + 1, i) && own_pairs_only(i + 2, i)) {
+            mol_first.push_back(i);
+            i += 3;
+        } else {
+            rest.push_back(i);
+            i += 1;
+        }
     }
-    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ cell list of molecules
@@ -66,21 +79,32 @@ __global__ void k_ccheck_displacement(int n, const double *__restrict__ pos, con
 
 // cell of every molecule (by its first atom) + per-cell counts; the arrival rank places the molecule in the cell's member table;
 // the last block scans the counts (device_utils.h).  members == nullptr: sizing pass (counts only).
+// first atom of molecule m: molecules are 3 m, 3 m + 1, 3 m + 2 in a pure water box (first == nullptr); a hybrid list
+// (molecule rows for the three-site molecules, per-atom rows for the rest) carries the table
+__device__ __forceinline__ int cfirst(const int *__restrict__ first, int m) { return first ? first[m] : 3 * m; }
+
 __global__ void __launch_bounds__(256) k_cassign(int nc, const double *__restrict__ pos, Box box, CellGrid g, int *count, int *start,
-                                                 int *members, int capc, double *xref, int *flags, int *ticket, int force) {
+                                                 int *members, int capc, double *xref, int *flags, int *ticket, int force,
+                                                 const int *__restrict__ first, const int *__restrict__ rest, int nrest) {
     if (!force && !flags[0]) return;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nc && m < nc + nrest && xref) {       // hybrid list: the displacement trigger watches every atom of the force
+        const int i = rest[m - nc];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xref[3 * i + k] = pos[3 * i + k];
+    }
     if (m < nc) {
+        const int i0 = cfirst(first, m);
         int cidx[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const double w = cwrap1(pos[9 * m + k], box.L[k], box.invL[k]);
+            const double w = cwrap1(pos[3 * i0 + k], box.L[k], box.invL[k]);
             const int ck = (w == w) ? (int)(w * g.inv_cw[k]) : 0;          // NaN-safe
             cidx[k] = ck >= g.nc[k] ? g.nc[k] - 1 : (ck < 0 ? 0 : ck);
         }
         if (xref) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) xref[9 * m + k] = pos[9 * m + k];
+            for (int k = 0; k < 9; ++k) xref[3 * i0 + k] = pos[3 * i0 + k];
         }
         const int cell = (cidx[2] * g.nc[1] + cidx[1]) * g.nc[0] + cidx[0];
         const int rank = atomicAdd(&count[cell], 1);
@@ -95,18 +119,20 @@ __global__ void __launch_bounds__(256) k_cassign(int nc, const double *__restric
 }
 
 // sorted fp64 copies of one molecule (kept whole: every atom takes the image of the first)
-__device__ __forceinline__ void cgather_one(int c, int m, const double *__restrict__ pos, Box box, const double *__restrict__ q,
+__device__ __forceinline__ void cgather_one(int c, int i0, const double *__restrict__ pos, Box box, const double *__restrict__ q,
                                             const double *__restrict__ hsig, const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s) {
     double sh[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) sh[k] = cwrap1(pos[9 * m + k], box.L[k], box.invL[k]) - pos[9 * m + k];
+    for (int k = 0; k < 3; ++k) sh[k] = cwrap1(pos[3 * i0 + k], box.L[k], box.invL[k]) - pos[3 * i0 + k];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const int i = 3 * m + a;
+        const int i = i0 + a;
         double4 p;
-        p.x = pos[3 * i] + sh[0];
-        p.y = pos[3 * i + 1] + sh[1];
-        p.z = pos[3 * i + 2] + sh[2];
+        // (the image of the first atom's; an atom that was wrapped into the box on its own comes back to its molecule: the
+        // rint is 0 for a whole molecule and the sum below then has the bits of pos + sh)
+        p.x = pos[3 * i] + (sh[0] - box.L[0] * rint((pos[3 * i] - pos[3 * i0]) * box.invL[0]));
+        p.y = pos[3 * i + 1] + (sh[1] - box.L[1] * rint((pos[3 * i + 1] - pos[3 * i0 + 1]) * box.invL[1]));
+        p.z = pos[3 * i + 2] + (sh[2] - box.L[2] * rint((pos[3 * i + 2] - pos[3 * i0 + 2]) * box.invL[2]));
         p.w = q[i];
         posq_s[3 * c + a] = p;
         lj_s[3 * c + a] = make_double2(hsig[i], seps2[i]);
@@ -120,10 +146,11 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
                                                       int capc, int *cperm, int *aperm, const double *__restrict__ pos, Box box,
                                                       float4 *pos4f, const int *flags, int *wflags, int force, const double *__restrict__ q,
                                                       const double *__restrict__ hsig, const double *__restrict__ seps2, double4 *posq_s,
-                                                      double2 *lj_s, float rext, const double *__restrict__ site_eps) {
+                                                      double2 *lj_s, float rext, const double *__restrict__ site_eps,
+                                                      const int *__restrict__ first) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (!force && !flags[0]) {
-        if (posq_s && gid < nc) cgather_one(gid, cperm[gid], pos, box, q, hsig, seps2, posq_s, lj_s);
+        if (posq_s && gid < nc) cgather_one(gid, cfirst(first, cperm[gid]), pos, box, q, hsig, seps2, posq_s, lj_s);
         return;
     }
     const int wave = gid >> 6, lane = threadIdx.x & 63;
@@ -144,10 +171,11 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
         if (a >= cnt) continue;
         const int sl = b + rank;
         cperm[sl] = me;
+        const int i0 = cfirst(first, me);
         double sh[3], p0[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            p0[k] = pos[9 * me + k];
+            p0[k] = pos[3 * i0 + k];
             sh[k] = cwrap1(p0[k], box.L[k], box.invL[k]) - p0[k];
         }
         float ext2 = 0.f;
@@ -155,9 +183,11 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
         float4 pf[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const int i = 3 * me + t;
+            const int i = i0 + t;
             aperm[3 * sl + t] = i;
-            const double x = pos[3 * i] + sh[0], y = pos[3 * i + 1] + sh[1], z = pos[3 * i + 2] + sh[2];
+            const double x = pos[3 * i] + (sh[0] - box.L[0] * rint((pos[3 * i] - p0[0]) * box.invL[0]));
+            const double y = pos[3 * i + 1] + (sh[1] - box.L[1] * rint((pos[3 * i + 1] - p0[1]) * box.invL[1]));
+            const double z = pos[3 * i + 2] + (sh[2] - box.L[2] * rint((pos[3 * i + 2] - p0[2]) * box.invL[2]));
             pf[t] = make_float4((float)x, (float)y, (float)z, 0.f);
             const float dx = pf[t].x - pf[0].x, dy = pf[t].y - pf[0].y, dz = pf[t].z - pf[0].z;
             ext2 = fmaxf(ext2, dx * dx + dy * dy + dz * dz);
@@ -950,15 +980,16 @@ static int cluster_setup_grid(amm_ctx *ctx, ClusterList *cl, double rc) {
 static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const double *d_pos, int force, bool count_only, PairForce *gather_for) {
     hipStream_t st = ctx->stream;
     const int nc = cl->nc;
-    hipLaunchKernelGGL(k_cassign, dim3((nc + 255) / 256), dim3(256), 0, st, nc, d_pos, ctx->box, cl->grid, cl->d_cell_count, cl->d_cell_start,
-                       cl->d_cell_members, cl->capc, count_only ? (double *)nullptr : cl->d_xref, cl->d_flags, cl->d_ticket, force);
+    hipLaunchKernelGGL(k_cassign, dim3((nc + cl->nrest + 255) / 256), dim3(256), 0, st, nc, d_pos, ctx->box, cl->grid, cl->d_cell_count, cl->d_cell_start,
+                       cl->d_cell_members, cl->capc, count_only ? (double *)nullptr : cl->d_xref, cl->d_flags, cl->d_ticket, force, cl->d_first,
+                       cl->d_rest, cl->nrest);
     if (!cl->d_cell_members) return 0;
     PairForce *gf = gather_for;
     const long sort_threads = std::max((long)cl->grid.ncell * 64, gf ? (long)nc : 0L);
     hipLaunchKernelGGL(k_csort_gather, dim3((unsigned)((sort_threads + 255) / 256)), dim3(256), 0, st, cl->grid.ncell, nc, cl->d_cell_start,
                        cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags, cl->d_flags, force,
                        gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr, gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr,
-                       gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2);
+                       gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2, cl->d_first);
     const long threads = (long)cl->grid.ncell * cl->parts * 64;
     dim3 grid((unsigned)((threads + 255) / 256));
     CBoxF bf;
@@ -986,32 +1017,39 @@ static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const doub
 }
 
 // largest distance of an atom from the first atom of its molecule (host, first build only)
-static double cluster_extent_host(amm_ctx *ctx, const double *d_pos, int n) {
+// (minimum image: a configuration whose atoms were wrapped into the box one by one still has whole molecules)
+static double cluster_extent_host(amm_ctx *ctx, const double *d_pos, int n, int nc, const std::vector<int> &first) {
     std::vector<double> x(3 * (size_t)n);
     if (hipMemcpyAsync(x.data(), d_pos, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return -1.0;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1.0;
     double worst = 0.0;
-    for (int m = 0; m < n / 3; ++m)
+    for (int m = 0; m < nc; ++m) {
+        const size_t i0 = first.empty() ? 3 * (size_t)m : (size_t)first[m];
         for (int a = 1; a < 3; ++a) {
             double d2 = 0.0;
             for (int k = 0; k < 3; ++k) {
-                const double d = x[9 * (size_t)m + 3 * a + k] - x[9 * (size_t)m + k];
+                double d = x[3 * (i0 + a) + k] - x[3 * i0 + k];
+                d -= ctx->box.L[k] * std::nearbyint(d * ctx->box.invL[k]);
                 d2 += d * d;
             }
             worst = std::max(worst, d2);
         }
+    }
     return std::sqrt(worst);
 }
 
 static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) {
     ClusterList *cl = new ClusterList();
     L->cl = cl;
-    const int n = L->n, nc = n / 3;
+    const int n = L->n, nc = L->n_mol;
     cl->nc = nc;
+    cl->d_first = L->d_mol_first;
+    cl->d_rest = L->d_rest_idx;
+    cl->nrest = L->n_rest;
     cl->skin = L->skin;
     cl->rlist_build = L->rlist_build;
     cl->rnear_build = L->rnear_build;
-    const double ext = cluster_extent_host(ctx, d_pos, n);
+    const double ext = cluster_extent_host(ctx, d_pos, n, nc, L->h_mol_first);
     if (!(ext >= 0.0) || !(ext == ext)) {
         amm_set_error("molecule-row list: cannot read the positions (or NaN positions)");
         return 1;
@@ -1029,8 +1067,8 @@ static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) 
     AMM_HIP(hipMemset(cl->d_cell_count, 0, sizeof(int) * (ncell + 1)));
     AMM_HIP(hipMalloc(&cl->d_cell_start, sizeof(int) * (ncell + 1)));
     AMM_HIP(hipMalloc(&cl->d_cperm, sizeof(int) * nc));
-    AMM_HIP(hipMalloc(&cl->d_aperm, sizeof(int) * n));
-    AMM_HIP(hipMalloc(&cl->d_pos4f, sizeof(float4) * n));
+    AMM_HIP(hipMalloc(&cl->d_aperm, sizeof(int) * 3 * (size_t)nc));
+    AMM_HIP(hipMalloc(&cl->d_pos4f, sizeof(float4) * 3 * (size_t)nc));
     AMM_HIP(hipMalloc(&cl->d_xref, sizeof(double) * 3 * (size_t)n));
     AMM_HIP(hipMalloc(&cl->d_nnb, sizeof(int) * ns));
     AMM_HIP(hipMalloc(&cl->d_nnb_near, sizeof(int) * ns));
@@ -1136,7 +1174,7 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
     if (!gathered)
         hipLaunchKernelGGL(k_csort_gather, dim3((cl->nc + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start,
                            cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0,
-                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2);     // flags[8] stays 0: copies only
+                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first);     // flags[8] stays 0: copies only
     const int nrows = cl->c_end - cl->c_begin;
     const int per_c = (cl->nc + ctx->world - 1) / ctx->world, per = 3 * per_c, nf = guest ? 2 : 1;
     double *out = d_force, *gout = g_force;
@@ -1325,7 +1363,7 @@ int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_p
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(k_csort_gather, dim3((cl->nc + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start, cl->d_cell_members,
                        cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0, pf->d_q, pf->d_hsig,
-                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2);
+                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first);
     CPairArgs A;
     std::memset(&A, 0, sizeof(A));
     A.c_begin = cl->c_begin;

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
                                                           const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s,
                                                           const int *__restrict__ cls, const int *__restrict__ start_lj,
                                                           int *row_order, int s_begin, int s_end, int *n_lj_out, const float *__restrict__ member,
-                                                          int *cell_sets) {
+                                                          int *cell_sets, int filter_mode) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (!force && !flags[which]) {
         if (posq_s && gid < n) {
@@ -191,7 +191,10 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
         const int me = a < cnt ? mem[a] : 0;
         if (cell_sets) {
             const float code = a < cnt ? member[me] : 0.f;
-            sets_here |= (__builtin_amdgcn_ballot_w64(code == 1.0f) != 0ull ? 1 : 0) | (__builtin_amdgcn_ballot_w64(code == 2.0f) != 0ull ? 2 : 0);
+            // (filter_mode 2, the rest part of a hybrid list: set 1 = the rest atoms (code 2), set 2 = every atom -- a rest atom is
+            // in both, and the build's test "home has set 1 and the stencil set 2, or the other way round" becomes "the stencil holds a rest atom")
+            sets_here |= (__builtin_amdgcn_ballot_w64(code == 1.0f) != 0ull ? 1 : 0) |
+                         (__builtin_amdgcn_ballot_w64(code == 2.0f) != 0ull ? (filter_mode == 2 ? 3 : 2) : 0);
         }
         // sort key: class (atoms with a Lennard-Jones site first), then atom index -> deterministic whatever the atomics did
         const int key = a < cnt ? (me | (cls[me] << 30)) : 0x7fffffff;
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
         p.x = (float)pd.x;
         p.y = (float)pd.y;
         p.z = (float)pd.z;
-        p.w = member ? member[me] : 0.f;       // set code of an interaction-group force (the build keeps (1, 2) pairs only)
+        p.w = member ? member[me] : 0.f;       // set code of a filtered list (interaction group: the build keeps (1, 2) pairs only; hybrid rest part: pairs with a code-2 atom)
         pos4f_s[sl] = p;
         inv_perm[me] = sl;
         if (row_order && sl >= s_begin && sl < s_end) {
@@ -545,7 +548,8 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                         // lane masks live in scalar registers: ballots of plain compares, combined with scalar logic
                         unsigned long long m_pass = __builtin_amdgcn_ballot_w64(r2 < rlist2);
                         if (RINT) m_pass &= __builtin_amdgcn_ballot_w64(js[u] >= 0);
-                        if (filtered) m_pass &= __builtin_amdgcn_ballot_w64(pw[t] * cand[u].w == 2.0f);   // (set 1, set 2) pairs only
+                        if (filtered == 1) m_pass &= __builtin_amdgcn_ballot_w64(pw[t] * cand[u].w == 2.0f);   // (set 1, set 2) pairs only
+                        else if (filtered == 2) m_pass &= __builtin_amdgcn_ballot_w64(pw[t] * cand[u].w >= 2.0f);   // codes 1 / 2: at least one rest atom
                         if (special) {       // wave-uniform branch, scalar loop over the atom's exclusions
                             const int st = tb + t;
                             unsigned long long m_excl = __builtin_amdgcn_ballot_w64(js[u] == st);
@@ -1154,8 +1158,10 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
     // (blockIdx & 7) owns one contiguous eighth of either pool.
     const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
     const int rpw = 64 >> A.lpa_shift;
-    const int n_lj = T.n_lj ? min(*T.n_lj, T.nslice) : T.nslice;
-    const int t_lj = (n_lj + rpw - 1) / rpw, t_h = (T.nslice - n_lj + rpw - 1) / rpw;
+    // filtered lists (the rest part of a hybrid list): only the rows that hold entries, in the order the build collected them
+    const int nrows = A.active ? min(*A.n_active, T.nslice) : T.nslice;
+    const int n_lj = T.n_lj ? min(*T.n_lj, nrows) : nrows;
+    const int t_lj = (n_lj + rpw - 1) / rpw, t_h = (nrows - n_lj + rpw - 1) / rpw;
     // one contiguous eighth of either pool per XCD: consecutive cell-sorted rows, i.e. a slab of the box, whose gathers (the
     // slab + one list radius either side: 3.4 MB at 249k atoms, 2 MB at 98k) stay in the XCD's 4 MiB of L2.  (Two thinner
     // slabs per XCD -- to spread the face slabs, whose rows all need the minimum image -- gained nothing at 98k atoms and
@@ -1173,14 +1179,14 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
         const bool lj_pool = upto > before;
         const int task = lj_pool ? before : nlj_x + (p - upto);
         const int a = lj_pool ? (lj0 + task) * rpw + (lane >> A.lpa_shift) : n_lj + (h0 + task - nlj_x) * rpw + (lane >> A.lpa_shift);
-        const bool valid = lj_pool ? a < n_lj : a < T.nslice;
+        const bool valid = lj_pool ? a < n_lj : a < nrows;
         int s = A.s_begin;
         double4 pi = make_double4(0.0, 0.0, 0.0, 0.0);
         double2 li = make_double2(0.0, 0.0);
         int nfront = 0, nn = 0, ntot = 0, sites_front = 0x7fffffff, sites_back = 0x7fffffff;
         const int *row = A.nl;
         if (valid) {
-            s = T.row_order ? T.row_order[a] : A.s_begin + a;
+            s = A.active ? A.s_begin + A.active[a] : (T.row_order ? T.row_order[a] : A.s_begin + a);
             const int ra = s - A.s_begin;
             pi = A.posq_s[s];
             li = A.lj_s[s];
@@ -1435,7 +1441,7 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
                        pf->d_inv_perm, pf->d_flags, which, force, gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr,
                        gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr, gf ? gf->d_lj_s : (double2 *)nullptr,
                        pf->d_cls, pf->d_cell_start_lj, pf->d_row_order, pf->s_begin, pf->s_end, pf->d_flags + 3, pf->d_member,
-                       pf->d_cell_sets);
+                       pf->d_cell_sets, pf->hybrid_rest ? 2 : 1);
     const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
@@ -1454,7 +1460,7 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
                        pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
                        pf->d_excl_idx, cap, nl, nnb, nnb_near, pf->d_flags, pf->d_blockstats, pf->d_counters,      \
-                       pf->d_ticket + AMM_TICKET_INTS, which, force, pf->d_member ? 1 : 0, direct ? pf->d_active : (int *)nullptr, pf->active_cap, pf->d_cell_sets,        \
+                       pf->d_ticket + AMM_TICKET_INTS, which, force, pf->d_member ? (pf->hybrid_rest ? 2 : 1) : 0, direct ? pf->d_active : (int *)nullptr, pf->active_cap, pf->d_cell_sets,        \
                        pf->d_cell_start_lj, direct ? pf->d_nnb_lj : (int *)nullptr)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
@@ -1610,6 +1616,15 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     return 0;
 }
 
+// hybrid lists: the force rows of the atoms outside the molecules start from zero (the molecule-row kernel writes the others)
+__global__ void k_zero_rows(int nrest, const int *__restrict__ rest, double *f0, double *f1) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrest) return;
+    const int i = rest[t];
+    if (f0) f0[3 * i] = f0[3 * i + 1] = f0[3 * i + 2] = 0.0;
+    if (f1) f1[3 * i] = f1[3 * i + 1] = f1[3 * i + 2] = 0.0;
+}
+
 // guest != nullptr: `pf` owns the list `guest` traverses, both forces act on the same particles (checked by
 // amm_pair_can_eval_dual) and only forces are wanted: one pass writes pf's force to d_force and the guest's to g_force.
 __global__ void k_unsort(int n, int per, int nf, const int *__restrict__ perm, const double *__restrict__ xchg, double *force,
@@ -1667,9 +1682,31 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         if (pf->sites_match < 0) pf->sites_match = (pf == L || pf->h_cls == L->h_cls) ? 1 : 0;
         if (guest && guest->sites_match < 0) guest->sites_match = (guest == L || guest->h_cls == L->h_cls) ? 1 : 0;
         const bool cluster = ctx->opt_cluster && ctx->opt_tab && L->cluster_ok && pf->cluster_ok && !d_energy && !guard0 &&
+                             (!L->hybrid || (ctx->opt_hybrid && pf->hybrid && (!guest || guest->hybrid))) &&
                              pf->sites_match == 1 && (!guest || guest->sites_match == 1) &&
                              pf->pc.tab.nint > 0 && pf->d_tab && pf->pc.sign == 1.0 && !(L->skin_out > L->skin * (1 + 1e-9)) &&
                              (!guest || (guest->cluster_ok && guest->pc.tab.nint > 0 && guest->d_tab));
+        if (cluster && L->hybrid) {
+            // hybrid list: the pairs of two three-site molecules walk molecule rows; every pair with an atom outside those molecules
+            // is the child's (per-atom rows filtered to such pairs, pair.hip), which adds to the same buffers afterwards
+            if (exchange) {
+                amm_set_error("a hybrid list (molecule rows + per-atom rows) exchanges its forces by all-reduce, not by all-gather");
+                return 1;
+            }
+            if (!pf->rest || (guest && !guest->rest)) {
+                amm_set_error("hybrid list: the per-atom part of the force is missing");
+                return 1;
+            }
+            L->last_kind = 2;
+            if (ctx->world == 1 && L->n_rest > 0) {     // (world > 1: the molecule-row evaluation clears whole buffers)
+                double *z0 = accumulate ? nullptr : d_force;
+                double *z1 = (guest && !g_accumulate && g_force != d_force) ? g_force : nullptr;
+                if (z0 || z1)
+                    hipLaunchKernelGGL(k_zero_rows, dim3((L->n_rest + 255) / 256), dim3(256), 0, st, L->n_rest, L->d_rest_idx, z0, z1);
+            }
+            if (amm_cluster_eval_impl(ctx, pf, d_pos, d_force, accumulate, guest, g_force, g_accumulate, 0)) return 1;
+            return amm_pair_eval_impl(ctx, pf->rest, d_pos, d_force, 1, nullptr, guest ? guest->rest : nullptr, g_force, 1, 0);
+        }
         if (cluster) {
             L->last_kind = 1;
             return amm_cluster_eval_impl(ctx, pf, d_pos, d_force, accumulate, guest, g_force, g_accumulate, exchange);
@@ -1750,14 +1787,18 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         A.active = nullptr;
         A.n_active = nullptr;
         int rows = nslice;
-        if (L->d_active && !exchange && !guest) {
+        if (L->d_active && !exchange && (!guest || L->hybrid_rest)) {
             // interaction-group force: walk the rows that hold entries, the others' forces are zero.  Those rows are few and
-            // either long (a solute atom against all the solvent around it) or a handful of entries: a whole wavefront each
+            // either long (a solute atom against all the solvent around it) or a handful of entries: a whole wavefront each.
+            // The rest part of a hybrid list (rows of the atoms outside the molecules: long; rows of molecule atoms near them: their
+            // few partners outside the molecules) is walked the same way with 8 lanes per row; it always adds to its parent's rows
             A.active = L->d_active;
             A.n_active = L->d_flags + 8;
             if (!accumulate && ctx->world == 1) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, st));
+            if (guest && !g_accumulate && g_force != d_force && ctx->world == 1) AMM_HIP(hipMemsetAsync(g_force, 0, sizeof(double) * 3 * (size_t)n, st));
             A.accumulate = 1;
-            A.lpa_shift = 6;
+            A.gaccumulate = 1;
+            A.lpa_shift = L->hybrid_rest ? 3 : 6;
             rows = std::min(nslice, L->active_cap);
         }
         const long threads = (long)rows << A.lpa_shift;
@@ -1797,9 +1838,9 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             T.guest_bytes = guest ? guest->pc.tab.nint * AMM_TAB_STRIDE : 0;
             T.need_erfcx = 1;
             T.margin = L->rlist_build + L->skin + 1e-6;
-            T.row_order = L->d_row_order;
-            T.n_lj = L->d_row_order ? L->d_flags + 3 : nullptr;
-            T.nslice = nslice;
+            T.row_order = A.active ? nullptr : L->d_row_order;
+            T.n_lj = (L->d_row_order && !A.active) ? L->d_flags + 3 : nullptr;
+            T.nslice = A.active ? rows : nslice;
             T.ntask = (int)((threads + 63) / 64);
             // the rows' site counts are the list owner's: a guest may cut its walk by them only if it has its sites on the same atoms
             if (pf->sites_match < 0) pf->sites_match = (pf == L || pf->h_cls == L->h_cls) ? 1 : 0;
@@ -1808,7 +1849,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
                 if (guest->sites_match < 0) guest->sites_match = (guest == L || guest->h_cls == L->h_cls) ? 1 : 0;
                 sites_ok = sites_ok && guest->sites_match == 1;
             }
-            T.nnb_lj = (ctx->site_trips && !L->dual && sites_ok) ? L->d_nnb_lj : nullptr;    // (the prune of a two-level list does not keep the counts)
+            T.nnb_lj = (ctx->site_trips && !L->dual && sites_ok && !A.active) ? L->d_nnb_lj : nullptr;    // (the prune of a two-level list does not keep the counts)
             T.nnb_all = L->d_nnb;
             const int gfam = guest ? guest->desc.family : -1;
             PairConsts gpc = guest ? guest->pc : pf->pc;
@@ -2066,7 +2107,7 @@ int amm_pair_free(PairForce *pf) {
                     pf->d_cell_start, pf->d_cell_members, pf->d_perm, pf->d_posq_s, pf->d_lj_s, pf->d_xref,
                     pf->d_nl, pf->d_nnb, pf->d_flags, pf->d_counters, pf->d_epart, pf->d_pos4f_s, pf->d_blockstats, pf->d_inv_perm, pf->d_nnb_near, pf->d_nl_out, pf->d_nnb_out,
                     pf->d_nnb_scratch, pf->d_xref_out, pf->d_ticket, pf->d_tab, pf->d_cls, pf->d_cell_count_lj, pf->d_cell_start_lj,
-                    pf->d_row_order, pf->d_member, pf->d_active, pf->d_cell_sets, pf->d_nnb_lj};
+                    pf->d_row_order, pf->d_member, pf->d_active, pf->d_cell_sets, pf->d_nnb_lj, pf->d_mol_first, pf->d_rest_idx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);

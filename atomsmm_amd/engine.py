@@ -1062,6 +1062,10 @@ class Engine:
         reduced = self._coll and (bool(pair_ids) or has_recip)
         gather = reduced and self._gather and g != 'all' and len(pair_ids) == 1 and not terms and not any(
             e.recip is not None and e.recip_group == g for e in self.entries)
+        # a hybrid list (molecule rows + per-atom rows for the atoms outside the three-site molecules) has two sorted orders:
+        # its forces are exchanged by all-reduce
+        if gather and self.ctx.pair_stats(pair_ids[0]).get('n_rest_atoms', 0) > 0:
+            gather = False
         ids = list(pair_ids)
         if terms:
             merged = self._make_bonded(terms, sliced=reduced)

@@ -264,7 +264,8 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat);
  * (rc + skin) that the traversal walks whenever an atom moved more than skin/2.  Applies to pair forces created later. */
 int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
 /* Tuning and test options of a context (set before the first evaluation; never read from the environment).  Names:
- * "cluster" (1: molecule rows for water-like systems on the force-only path, 0: per-atom rows everywhere), "tab" (tabulated
+ * "cluster" (1: molecule rows for water-like systems on the force-only path, 0: per-atom rows everywhere), "hybrid" (1: molecule
+ * rows also for waters that share the box with other atoms, the rest through per-atom rows), "tab" (tabulated
  * force-only kernels), "site_trips", "lanes_per_row", "build_parts", "unroll", "dual_unroll", "tab_block", "tab_dual_block",
  * "no_dual", "no_defer", "terms_from", "no_term_lanes".  Unknown names are an error. */
 int amm_set_option(amm_ctx *ctx, const char *name, double value);
@@ -288,7 +289,9 @@ typedef struct {
     int32_t shares_list;    /* 1 if this force traverses another force's list */
     int32_t list_kind;      /* rows walked by the last evaluation: 0 one per atom, 1 one per molecule (water-like systems,
                                force-only evaluations: n_list_pairs then counts nine atom pairs per entry, capacity and
-                               max_neighbors are molecule partners per row, lanes_per_atom is lanes per row) */
+                               max_neighbors are molecule partners per row, lanes_per_atom is lanes per row), 2 hybrid: one per
+                               three-site molecule for the pairs of two molecules + one per atom, filtered to the pairs with an
+                               atom outside the molecules, for the rest (an ion, a solute, a chain next to the waters) */
     int64_t n_outer_builds; /* cell-based builds of the outer list (n_builds counts prunes of the inner list) */
     int64_t n_outer_pairs;
     double rlist_outer;
@@ -299,7 +302,7 @@ typedef struct {
                                the fused step-boundary pass), so it has no launch and no profile time of its own */
     int32_t has_site_table; /* 1: pairs of two Lennard-Jones sites read a radial table of their own in the molecule-row kernels (the
                                force's sites share one sigma, eps and charge: water) instead of Lennard-Jones arithmetic */
-    int32_t pad3_;
+    int32_t n_rest_atoms;   /* hybrid lists: atoms outside the three-site molecules (0: none, or the force keeps per-atom rows) */
     double site_tab_error;  /* its largest relative interpolation error (bound 3e-13: the r^-14 wall) */
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */

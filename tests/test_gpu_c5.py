@@ -38,6 +38,14 @@ def check_groups(case, context, ref, lam):
     assert np.abs(f_only - r0f).max() <= 1e-9 * np.abs(r0f).max()
     d = context._engine.energy_derivative('lambda_vdw')
     assert d == pytest.approx(ref.dE_dlambda(), rel=2e-6)
+    # which lists ran: the near and the outer force walk a HYBRID list (molecule rows for the water-water pairs, per-atom rows for
+    # every pair with a chain or solute atom) -- a silent fall-back to per-atom rows for the whole box would stay green above
+    eng = context._engine
+    n_rest = len(case['chain']) + len(case['solute'])
+    for g in (1, 2):
+        for pid in eng.pair_force_ids(g):
+            st = eng.ctx.pair_stats(pid)
+            assert st['list_kind'] == 2 and st['n_rest_atoms'] == n_rest, st
 
 
 def test_c5_groups_and_afed_steps_vs_oracle_small():
