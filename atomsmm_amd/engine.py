@@ -37,6 +37,10 @@ _SAFE_FUNCS.update(step=lambda x: 1.0 if x >= 0 else 0.0, delta=lambda x: 1.0 if
 ALLREDUCE = 'allreduce'
 _AUX_FORCE = re.compile(r'_f[0-9]*_')      # auxiliary buffers of multi-force expressions (integrators.py:134-145)
 _NO_ALIAS = os.environ.get('AMM_NO_ALIAS') is not None      # tuning knob (A/B)
+# host-walked step programs evaluate the same few dozen texts every step: compiled code, split conditions, symbol lists
+_CODE_CACHE, _CONDITION_CACHE, _PER_DOF_SYMBOLS = {}, {}, {}
+_COMPARE = {'<': lambda a, b: a < b, '>': lambda a, b: a > b, '<=': lambda a, b: a <= b, '>=': lambda a, b: a >= b,
+            '=': lambda a, b: a == b, '!=': lambda a, b: a != b}
 _context_factory = B.HipContext   # the only backend; tests of the host logic substitute a call recorder
 
 
@@ -246,6 +250,7 @@ class Engine:
         self._group_defs = {}
         self._group_bonded = []     # merged bond-list sets made by _define_group
         self._deriv_cache = {}      # deriv(energy, name) at the current positions and parameters (host-walked programs)
+        self._emit_memo = {}        # what the per-DOF steps of a host-walked program emit (_emit_per_dof_memo)
         self._pending = None        # device scalars that deferred globals wait for: (buffer, number in use)
         self._valid = {}
         self._interpreted = None    # None: undecided; True: general (host-walked) step programs
@@ -887,6 +892,7 @@ class Engine:
                         self._forget_groups()       # bond-list terms were rebuilt
         if dirty:
             self._programs.clear()
+            self._emit_memo.clear()
             self._invalidate_forces()
 
     def get_parameter(self, name):
@@ -907,10 +913,12 @@ class Engine:
                 if result != 'values':
                     self._forget_groups()
                 self._programs.clear()
+                self._emit_memo.clear()
                 self._invalidate_forces()
 
     def invalidate_program(self):
         self._programs.clear()
+        self._emit_memo.clear()
         self._interpreted = None
 
     def reinitialize(self, preserveState=False):
@@ -1117,7 +1125,10 @@ class Engine:
             self._check()
 
     def _eval(self, expr, env):
-        return float(eval(expr.replace('^', '**'), {'__builtins__': {}}, env))
+        code = _CODE_CACHE.get(expr)
+        if code is None:
+            code = _CODE_CACHE[expr] = compile(expr.replace('^', '**').strip(), '<step program>', 'eval')
+        return float(eval(code, {'__builtins__': {}}, env))
 
     def _compile(self):
         """Unroll one outer step of the CustomIntegrator program into backend ops (host-side control flow)."""
@@ -1349,11 +1360,13 @@ class Engine:
         return out
 
     def _condition(self, expr, env):
-        m = re.match(r'^(.*?)(<=|>=|!=|=|<|>)(.*)$', expr)
-        if not m:
-            raise NotImplementedError('unsupported block condition: ' + expr)
-        a, op, b = self._eval(m.group(1), env), m.group(2), self._eval(m.group(3), env)
-        return {'<': a < b, '>': a > b, '<=': a <= b, '>=': a >= b, '=': a == b, '!=': a != b}[op]
+        parts = _CONDITION_CACHE.get(expr)
+        if parts is None:
+            m = re.match(r'^(.*?)(<=|>=|!=|=|<|>)(.*)$', expr)
+            if not m:
+                raise NotImplementedError('unsupported block condition: ' + expr)
+            parts = _CONDITION_CACHE[expr] = (m.group(1), _COMPARE[m.group(2)], m.group(3))
+        return parts[1](self._eval(parts[0], env), self._eval(parts[2], env))
 
     @staticmethod
     def _split_leading_group(text):
@@ -1431,6 +1444,37 @@ class Engine:
                     break
             keep[k] = not dead
         return [op for op, kept in zip(ops, keep) if kept]
+
+    def _emit_per_dof_memo(self, pc, target, expr, env, ops, valid):
+        """_emit_per_dof for the host-walked path, remembered: what a per-DOF step of the program emits is a function of the
+        values of the globals its text names, of which force groups are valid and of which auxiliary buffers mirror a force --
+        a RESPA block inside an AFED step meets the same few dozen combinations every step, and re-deriving them (regular
+        expressions, eval) was what made the host slower than the GPU at config C5."""
+        names = _PER_DOF_SYMBOLS.get(expr)
+        if names is None:
+            names = _PER_DOF_SYMBOLS[expr] = tuple(sorted(X.symbols(expr)))
+        try:
+            key = (pc, tuple(env.get(name) for name in names), tuple(sorted(valid.items(), key=str)),
+                   tuple(sorted(self._mirror_work.items())), getattr(self, '_static_exprs', False))
+            hit = self._emit_memo.get(key)
+        except TypeError:                # a deferred global (unhashable) among the values: no memo for this one
+            return self._emit_per_dof(target, expr, env, ops, valid)
+        if hit is None:
+            before = len(ops)
+            self._emit_per_dof(target, expr, env, ops, valid)
+            if len(self._emit_memo) < 4096:
+                self._emit_memo[key] = (tuple(ops[before:]), dict(valid), dict(self._mirror_work), target == 'x', self._plain_kick)
+            return
+        new_ops, valid_after, mirror_after, moved, kicked = hit
+        ops.extend(new_ops)
+        valid.clear()
+        valid.update(valid_after)
+        self._mirror_work.clear()
+        self._mirror_work.update(mirror_after)
+        if moved:
+            self._deriv_cache.clear()
+        if kicked:
+            self._plain_kick = True
 
     def _emit_per_dof(self, target, expr, env, ops, valid):
         text = expr.replace(' ', '')
@@ -1701,6 +1745,7 @@ class Engine:
             if rebuilt:
                 self._forget_groups()
                 self._programs.clear()
+                self._emit_memo.clear()
             self._invalidate_forces()
             total += (values[0] - values[1]) / (here + h - lo)
         return total
@@ -1853,7 +1898,7 @@ class Engine:
                     done = False
                     if kind == C.ComputePerDof:
                         try:
-                            self._emit_per_dof(target, expr, env, ops, valid)
+                            self._emit_per_dof_memo(pc, target, expr, env, ops, valid)
                             done = True
                         except (NotImplementedError, NameError, SyntaxError, TypeError):
                             done = False

@@ -25,6 +25,9 @@ class RecordingContext:
                                q=q.copy(), sigma=sigma.copy(), eps=eps.copy(), n_excl=0 if excl_pairs is None else len(excl_pairs)))
         return fid
 
+    def pair_stats(self, fid):
+        return dict(n_rest_atoms=0, list_kind=0)
+
     def pair_share_list(self, fid, host_fid):
         self.calls.append(('pair_share_list', fid, host_fid))
 
