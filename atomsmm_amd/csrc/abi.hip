@@ -245,6 +245,10 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
         idx[fill[j]++] = i;
     }
     if (upload(&pf->d_excl_ptr, ptr.data(), ptr.size()) || upload(&pf->d_excl_idx, idx.data(), idx.size())) return 1;
+    if (desc->family == AMM_SOFTCORE || (desc->flags & (AMM_GROUP_LJ | AMM_GROUP_Q))) {
+        pf->h_excl_ptr = ptr;
+        pf->h_excl_idx = idx;
+    }
     // Three-site molecules take molecule rows on the force-only hot path (cluster.h).  A box of nothing else: molecule rows only.
     // Molecules next to other atoms (ions, a solute, a chain; at least half of the atoms in molecules): a hybrid list -- molecule
     // rows for the pairs of two molecules, per-atom rows kept by a hidden child force for every pair with an atom outside them.
@@ -445,6 +449,8 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
             for (int i = 0; i < n; ++i) member[i] = (float)(by_q ? h_q[i] : 0.5 * h_sigma[i]);
             if (!pf->d_member) AMM_HIP(hipMalloc(&pf->d_member, sizeof(float) * n));
             AMM_HIP(hipMemcpy(pf->d_member, member.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+            // a small set (a solute): no neighbour list at all (group.hip); decided again whenever the codes change
+            if (!pf->built && amm_small_group_setup(ctx, pf, member)) return 1;
         }
     }
     // one Lennard-Jones site class?  (water: the oxygens) -- the molecule-row kernels then need no per-atom LJ records
@@ -1119,6 +1125,59 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     }
                 }
             }
+            // EVAL(g) ; KICK ... [; MOVE] with g = a term-parallel bond-list set [+ an interaction-group pair force with a small set,
+            // which group.hip evaluates without a list and which writes EVERY row]: the pair force goes first, the terms are
+            // evaluated, and the launch that gathers their forces also applies the kicks and the move that follow -- an inner RESPA
+            // iteration of a system that is not pure water (config C5: chain + solute + waters) is then 3 launches, not 8.
+            if (ctx->fuse_inner && !ctx->iso.on && op.op == AMM_OP_EVAL && op.a >= 0 && op.a < AMM_MAX_GROUPS && ctx->groups[op.a].slot >= 0 &&
+                !ctx->groups[op.a].exchange && k + 1 < n_ops && ops[k + 1].op == AMM_OP_KICK) {
+                GroupDef &g = ctx->groups[op.a];
+                BondedSet *bs = nullptr;
+                PairForce *ps = nullptr;
+                bool plain = g.forces.size() >= 1 && g.forces.size() <= 2;
+                for (int fid : g.forces) {
+                    ForceObj &fo = ctx->forces[fid];
+                    if (fo.type == 2 && !bs) bs = fo.bonded;
+                    else if (fo.type == 1 && !ps && fo.pair->small && ctx->opt_small_group && !fo.pair->built) ps = fo.pair;
+                    else plain = false;
+                }
+                double *buf = ctx->slots[g.slot];
+                if (plain && bs && buf && bs->n_gterms > 0 && !(bs->sliced && ctx->world > 1) && ctx->world == 1) {
+                    KickList K;
+                    K.n = 0;
+                    int j = k + 1;
+                    bool bound = true;
+                    while (j < n_ops && K.n < 4 && ops[j].op == AMM_OP_KICK) {
+                        const amm_op &kick = ops[j];
+                        const double *a_ = (kick.a >= 0 && kick.a < AMM_MAX_SLOTS) ? ctx->slots[kick.a] : nullptr;
+                        const double *b_ = (kick.b >= 0 && kick.b < AMM_MAX_SLOTS) ? ctx->slots[kick.b] : nullptr;
+                        if (!a_ || (kick.b >= 0 && !b_)) {
+                            bound = false;
+                            break;
+                        }
+                        K.f[K.n] = a_;
+                        K.f2[K.n] = b_;
+                        K.plus[K.n] = kick.c;
+                        K.coef[K.n] = kick.coef;
+                        ++K.n;
+                        ++j;
+                    }
+                    for (int q = K.n; q < 4; ++q) {
+                        K.f[q] = K.f2[q] = nullptr;
+                        K.plus[q] = 0;
+                        K.coef[q] = 0.0;
+                    }
+                    const bool more_kicks = j < n_ops && ops[j].op == AMM_OP_KICK;      // a fifth kick: left to the next launch
+                    const bool moves = !more_kicks && j < n_ops && ops[j].op == AMM_OP_MOVE;
+                    if (bound && K.n >= 1) {
+                        if (ps && amm_pair_eval_impl(ctx, ps, ctx->d_x, buf, 0, nullptr)) return 1;
+                        if (amm_bonded_eval_kicks_impl(ctx, bs, ctx->d_x, buf, ps ? 1 : 0, K, moves ? 1 : 0, moves ? ops[j].coef : 0.0)) return 1;
+                        if (moves) ctx->pos_epoch++;
+                        k = j - (moves ? 0 : 1);
+                        continue;
+                    }
+                }
+            }
             // a run of plain kicks, then (maybe) a move: one launch (same arithmetic per degree of freedom, same order)
             if (ctx->fuse_inner && !ctx->iso.on && op.op == AMM_OP_KICK) {
                 const double *fa[4], *fb[4];
@@ -1407,6 +1466,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     const int v = (int)value;
     if (k == "cluster") ctx->opt_cluster = v;
     else if (k == "hybrid") ctx->opt_hybrid = v;
+    else if (k == "small_group") ctx->opt_small_group = v;
     else if (k == "tab") ctx->opt_tab = v;
     else if (k == "site_trips") ctx->site_trips = v != 0;
     else if (k == "lanes_per_row") ctx->opt_lpa = v;

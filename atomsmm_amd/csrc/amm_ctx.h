@@ -58,6 +58,7 @@ struct CellGrid {
 };
 
 struct ClusterList;   // cluster.h: molecule-row list of the force-only traversal
+struct SmallGroup;    // group.hip: interaction-group force with one small set, evaluated without a neighbour list
 
 struct PairForce {
     amm_pair_desc desc;
@@ -66,6 +67,8 @@ struct PairForce {
     // Hybrid list: molecule rows for the pairs of two such molecules + per-atom rows, kept by a hidden child force (`rest`, filtered to
     // the pairs that involve an atom outside the molecules), for everything else -- an ion, a solute, a chain next to the waters.
     bool hybrid = false;
+    SmallGroup *small = nullptr;   // interaction-group force whose smaller set has <= 128 atoms (group.hip): no list at all
+    std::vector<int> h_excl_ptr, h_excl_idx;    // host copy of the exclusion CSR (interaction-group forces)
     PairForce *rest = nullptr;     // the child (registered in ctx->forces behind its parent, in no group)
     bool hybrid_rest = false;      // this force IS such a child: its list keeps the pairs with at least one rest atom (code 2)
     std::vector<int> h_mol_first;  // first atom of every molecule; empty: molecule m = atoms 3 m .. 3 m + 2 (no rest atoms)
@@ -260,6 +263,7 @@ struct amm_ctx {
     // order of summation of a production run
     int opt_cluster = 1;           // molecule rows for qualifying forces (0: per-atom rows everywhere)
     int opt_hybrid = 1;            // ... also when the three-site molecules share the box with other atoms (hybrid lists)
+    int opt_small_group = 1;       // interaction-group forces with a small set (a solute) without a neighbour list (group.hip)
     bool creating_rest = false;    // amm_pair_create is making the hidden child of a hybrid list
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
     int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
@@ -303,6 +307,15 @@ struct amm_ctx {
     long long comm_calls = 0, comm_doubles = 0;     // collectives issued / doubles per rank they carried
 };
 
+// up to four kicks v <- v + (coef (f -/+ f2)) / m that one launch applies in order (integrate.hip: k_kicks_move; bonded.hip: the
+// gather of a term-parallel bond-list evaluation carries the kicks that follow it)
+struct KickList {
+    const double *f[4], *f2[4];
+    int plus[4];
+    double coef[4];
+    int n;
+};
+
 // comm.hip
 int amm_comm_unique_id_impl(const char *rccl_path, unsigned char *out);
 int amm_comm_init_impl(amm_ctx *ctx, const char *rccl_path, const unsigned char *id_bytes, int rank, int world);
@@ -311,6 +324,10 @@ int amm_comm_allreduce_impl(amm_ctx *ctx, double *d_buf, size_t count);
 int amm_comm_allgather_impl(amm_ctx *ctx, double *d_buf, size_t count_per_rank);
 int amm_exchange_finish_impl(amm_ctx *ctx);
 
+// group.hip
+int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> &member);
+int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy);
+int amm_small_group_free(SmallGroup *sg);
 // implemented in pair.hip / cells.hip / bonded.hip / integrate.hip
 int amm_pair_build_consts(const amm_pair_desc &d, PairConsts &pc);
 int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate,
@@ -325,6 +342,9 @@ const char *amm_kernel_revision_impl();
 int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate,
                          double *d_energy);
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
+// EVAL of a term-parallel set followed by kicks (and a move): the gather launch applies them (bit-identical to the separate ops)
+int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate, const KickList &K,
+                               int with_move, double dcoef);
 int amm_bonded_free(BondedSet *bs);
 int amm_kicks_move_impl(amm_ctx *ctx, const double *const *fa, const double *const *fb, const int *plus, const double *coef, int nk,
                         int with_move, double dcoef);

@@ -281,6 +281,55 @@ __global__ void __launch_bounds__(256) k_terms_gather(BondedArgs A, const int *_
     }
 }
 
+// k_terms_gather + the kicks (and the move) that follow the EVAL in the step program (propagators.py:933-973: `v <- v +
+// (c2) f0 / m` closes an inner iteration, `v <- v + (c1) f0 / m ; x <- x + (d) v` opens the next): per degree of freedom the
+// operations of k_kicks_move in the same order (mul, div, add rounded separately), on the force row this thread has just
+// written -- a kick that reads this group's buffer takes the value from the register, the same number.  Positions are not
+// read here (the terms' forces are parked in tf), so moving them is safe.
+__global__ void __launch_bounds__(256) k_terms_gather_kicks(BondedArgs A, const int *__restrict__ rec_src, const double *__restrict__ tf,
+                                                            KickList K, double *__restrict__ x, double *__restrict__ v,
+                                                            const double *__restrict__ mass, int with_move, double dcoef) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    double f[3] = {0.0, 0.0, 0.0};
+    const int rb = A.ref_ptr[i], re = A.ref_ptr[i + 1];
+    for (int r = rb; r < re; ++r) {
+        const double *src = tf + (size_t)rec_src[r] * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[c] += src[c];
+    }
+    if (A.accumulate) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[c] = A.force[3 * i + c] + f[c];
+    }
+    const double m = mass[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int t = 3 * i + c;
+        A.force[t] = f[c];
+        double vt = v[t];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < K.n) {
+                double ff = K.f[k] == A.force ? f[c] : K.f[k][t];
+                if (K.f2[k]) {
+                    const double g2 = K.f2[k] == A.force ? f[c] : K.f2[k][t];
+                    ff = K.plus[k] ? ff + g2 : ff - g2;
+                }
+                const double num = K.coef[k] * ff;
+                const double dv = num / m;
+                vt = vt + dv;
+            }
+        }
+        v[t] = vt;
+        if (with_move) {
+            const double dx = dcoef * vt;
+            x[t] = x[t] + dx;
+        }
+    }
+}
+
 // Fused inner RESPA iteration (propagators.py:940-973, innermost level):
 //     v <- v + c1*f0/m ;  x <- x + d*v ;  f0 <- bonded(x) ;  v <- v + c2*f0/m
 // in ONE launch.  Each thread advances its own atom and, redundantly, the few atoms it shares bond-list terms
@@ -835,6 +884,39 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
     hipLaunchKernelGGL(k_bonded, dim3(nblk), dim3(256), 0, ctx->stream, A);
     AMM_HIP(hipGetLastError());
     if (d_energy) return amm_reduce_add(ctx, bs->d_epart, nblk, 1.0, d_energy);
+    return 0;
+}
+
+int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate, const KickList &K,
+                               int with_move, double dcoef) {
+    if (!bs->finalized || bs->n_gterms <= 0 || (bs->sliced && ctx->world > 1)) {
+        amm_set_error("amm_bonded_eval_kicks_impl: needs a finalized, unsliced, term-parallel bond-list set");
+        return 1;
+    }
+    const int n = ctx->n;
+    BondedArgs A;
+    A.n = n;
+    A.row_begin = 0;
+    A.row_end = n;
+    A.ref_ptr = bs->d_ref_ptr;
+    A.rec_a = bs->d_rec_a;
+    A.rec_q = bs->d_rec_q;
+    A.rec_l = bs->d_rec_l;
+    A.pos = d_pos;
+    A.force = d_force;
+    A.epart = bs->d_epart;
+    A.accumulate = accumulate;
+    A.want_energy = 0;
+    A.box = ctx->box;
+    A.near_pc = bs->near_pc;
+    A.ewald_alpha = bs->ewald_alpha;
+    A.ewald_tasp = bs->ewald_alpha * 1.1283791670955125739;
+    A.Kc_ljc = bs->ljc_Kc;
+    hipLaunchKernelGGL(k_terms_eval, dim3((bs->n_gterms + 255) / 256), dim3(256), 0, ctx->stream, A, bs->n_gterms, bs->d_gt_a, bs->d_gt_q,
+                       bs->d_tf);
+    hipLaunchKernelGGL(k_terms_gather_kicks, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, bs->d_rec_src, bs->d_tf, K, ctx->d_x,
+                       ctx->d_v, ctx->d_mass, with_move, dcoef);
+    AMM_HIP(hipGetLastError());
     return 0;
 }
 

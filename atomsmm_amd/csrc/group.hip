@@ -1,0 +1,333 @@
+// atomsmm_amd/csrc/group.hip -- interaction-group pair forces with ONE SMALL SET, without a neighbour list (gfx950, fp64).
+//
+// The reference restricts some CustomNonbondedForce objects to an interaction group (set 1 x set 2): the softcore solute-solvent
+// force of SolvationSystem (systems.py:266-272), the solute-solvent Lennard-Jones / Coulomb forces of AlchemicalRespaSystem
+// (systems.py:696-708, 739-772).  One of the two sets is a solute: a few dozen atoms.  Such a force needs no cell list, no
+// Verlet rows and none of the launches that maintain them (displacement check, cell assign, sort, conditional build: four
+// launches per evaluation, and RESPASystem leaves these forces in group 0, i.e. on the INNERMOST loop -- config C5 paid them
+// 32 times per AFED step): every atom of the large set tests the small set's atoms directly.
+//
+// Work decomposition: one thread per atom j (grid stride); the small set's positions and parameters sit in LDS; thread j walks
+// them in order (a fixed order of summation) and keeps the force on j.  The reaction forces on the small set's atoms are reduced
+// over the wavefront in a fixed order (through LDS, four small atoms at a time) -- only for the few (wavefront, small atoms)
+// combinations that hold a pair inside the cutoff -- and added to 64-bit FIXED-POINT accumulators (2^-40 kJ/mol/nm) with
+// device-scope integer atomics: integer additions commute, so the sums -- and every bit of the forces -- are the same on every
+// launch whatever the order the wavefronts arrive in (the PME spread of pme.hip does the same); the LAST block (ticket) turns the
+// accumulators into force rows and clears them.
+// (A first version staged per-block floating-point partial sums for the last block to add in block order: the ~100 blocks'
+// partials sit behind loads that bypass the XCD's L2 -- 17 us of a 38 us kernel at 249 075 atoms.)  Resolution 9e-13 against forces
+// of 1e2..1e4: at the level of the fp64 rounding of the sums themselves.  Same pair arithmetic (amm_pair_math) and the same
+// arguments as the list-based kernel k_pair_nlist.
+// HBM traffic: positions + parameters + force rows once (~56 B per atom), 7.5 M distance tests at 249 075 atoms x 30.
+#include <algorithm>
+#include <vector>
+
+#include "amm_ctx.h"
+#include "device_utils.h"
+#include "pair_math.h"
+
+#define AMM_SMALL_MAX 128
+#ifndef AMM_SG_EXP
+#define AMM_SG_EXP 0        // measurement variants (scripts/build_variant.sh group ...): wrong forces
+#endif
+#define AMM_FIX_SCALE 1099511627776.0        // 2^40
+
+
+struct SmallArgs {
+    int n, j0, j1;                 // atoms; this rank's block of them
+    int ns;                        // atoms of the small set
+    const int *small;              // their indices (ascending)
+    float small_code;              // set code of the small set (1 or 2); partners carry 3 - small_code
+    const double *pos;             // [n][3], original order, not wrapped
+    const double *q, *hsig, *seps2;
+    const float *member;           // set code of every atom (0: in neither set)
+    double *force;
+    int accumulate;                // rows of the large set: += or =
+    int small_accumulate;          // rows of the small set (written by the last block): += or =
+    Box box;
+    unsigned long long *acc;       // [ns][3] fixed-point sums of the reaction forces (zero between launches)
+    int *ticket;
+    double *epart;                 // [nblocks] energies (EN)
+};
+
+template <int FAM, bool GUARD, bool EN, bool GROUPED>
+__global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c) {
+    __shared__ double4 s_pos[AMM_SMALL_MAX];          // x, y, z, Kc q
+    __shared__ double2 s_lj[AMM_SMALL_MAX];
+    __shared__ double s_tr[4][12][65];                // per wavefront: the twelve reaction components of a trip, [value][lane]
+    static_assert(FAM == AMM_SOFTCORE || FAM == AMM_NEAR_FSWITCH || FAM == AMM_NONBONDED, "families of the reference's interaction groups");
+    const double *s_tab = nullptr;          // (none of them evaluates erfc: NONBONDED here is the plain-Coulomb instantiation, CMODE 0)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < A.ns; k += 256) {
+        const int i = A.small[k];
+        s_pos[k] = make_double4(A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2], A.q[i]);
+        s_lj[k] = make_double2(A.hsig[i], A.seps2[i]);
+    }
+    __syncthreads();
+    const double guard2 = GUARD ? c.rc0 * c.rc0 : 0.0;
+    double esum = 0.0;
+    // Four lanes share an atom j of the large set: lane `sub` of them takes the small atoms sub, sub + 4, sub + 8 ... -- four per
+    // trip, as independent chains.  The wavefronts next to the solute meet EVERY small atom and are the kernel's critical path:
+    // sixteen atoms per wavefront instead of sixty-four cuts it four times (30 small atoms: 2 trips of pair arithmetic per
+    // wavefront instead of 8; measured 31 -> see DESIGN.md).  A block walks its share of the atoms with a grid stride.
+    const int sub = lane & 3;
+    for (int jb = A.j0 + blockIdx.x * 64; jb < A.j1; jb += gridDim.x * 64) {
+        const int j = jb + (threadIdx.x >> 2);
+        const bool in = j < A.j1;
+        const float code = in ? A.member[j] : 0.f;
+        const bool partner = in && code != 0.f && code != A.small_code;       // an atom of the other (large) set
+        double px = 0.0, py = 0.0, pz = 0.0, qj = 0.0;
+        double2 lj = make_double2(0.0, 0.0);
+        if (partner) {
+            px = A.pos[3 * j];
+            py = A.pos[3 * j + 1];
+            pz = A.pos[3 * j + 2];
+            qj = c.Kc * A.q[j];
+            lj = make_double2(A.hsig[j], A.seps2[j]);
+        }
+        double fx = 0.0, fy = 0.0, fz = 0.0;
+        // (a wavefront without an atom of the large set has nothing to do: wave-uniform)
+        if (AMM_SG_EXP != 3 && __builtin_amdgcn_ballot_w64(partner) != 0ull) {
+            for (int k0 = 0; k0 < A.ns; k0 += 16) {
+                double dx[4], dy[4], dz[4], r2[4];
+                bool pass[4];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = k0 + 4 * u + sub;
+                    const double4 pk = s_pos[min(kk, A.ns - 1)];
+                    dx[u] = amm_min_image(px - pk.x, A.box.L[0], A.box.invL[0]);
+                    dy[u] = amm_min_image(py - pk.y, A.box.L[1], A.box.invL[1]);
+                    dz[u] = amm_min_image(pz - pk.z, A.box.L[2], A.box.invL[2]);
+                    r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+                    pass[u] = partner && (kk < A.ns) && (r2[u] < c.rc2);
+                    if (GUARD) pass[u] = pass[u] && (r2[u] <= guard2);
+                    any = any || pass[u];
+                }
+                if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;            // wave-uniform: almost always
+#if AMM_SG_EXP == 1        // measurement only: no pair arithmetic at all
+                continue;
+#endif
+                double rr[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = min(k0 + 4 * u + sub, A.ns - 1);
+                    const double4 pk = s_pos[kk];
+                    const double2 lk = s_lj[kk];
+                    double e, fr;
+                    amm_pair_math<FAM, 0, false, EN, GROUPED>(c, pass[u] ? r2[u] : 1.0, qj * pk.w, lj.x + lk.x, lj.y * lk.y, e, fr, s_tab);
+                    fr = pass[u] ? fr : 0.0;
+                    const double gx = fr * dx[u], gy = fr * dy[u], gz = fr * dz[u];
+                    fx += gx;
+                    fy += gy;
+                    fz += gz;
+                    if (EN) esum += pass[u] ? e : 0.0;
+                    rr[u][0] = -gx;
+                    rr[u][1] = -gy;
+                    rr[u][2] = -gz;
+                }
+                // Reactions on the small atoms k0 + 4 u + s (u, s = 0..3), three components each: 48 sums over the 16 lanes with
+                // sub = s.  Through LDS: every lane parks its twelve values ([value][lane], rows padded against bank conflicts),
+                // lane 4 v + s adds value v of the lanes s, s + 4, ... in lane order -- a fixed order, and a tenth of the
+                // cross-lane traffic of the six-round butterflies that stood here first (17 us of this kernel then)
+                double(*tr)[65] = s_tr[w];
+                __builtin_amdgcn_wave_barrier();                  // the previous trip's reads are done
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) tr[3 * u + d][lane] = rr[u][d];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int v = min(lane >> 2, 11);
+                double part = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) part += tr[v][sub + 4 * i];
+                // (small atom of this sum: k0 + 4 (v / 3) + sub, component v % 3; skipped when no lane holds a pair with it)
+                const int ku = v / 3, kd = v - 3 * ku, ksum = k0 + 4 * ku + sub;
+                bool mine = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(pass[u]);       // lanes (any sub) with a pair in slot u
+                    // the lanes with this lane's sub sit at bit positions == sub (mod 4)
+                    const bool hit = (m & (0x1111111111111111ull << sub)) != 0ull;
+                    mine = mine || (u == ku && hit);
+                }
+                if (lane < 48 && mine && ksum < A.ns)
+                    atomicAdd(&A.acc[3 * ksum + kd], (unsigned long long)__double2ll_rn(part * AMM_FIX_SCALE));
+            }
+        }
+        // the four lanes' shares of the force on j
+        fx += __shfl_xor(fx, 1);
+        fy += __shfl_xor(fy, 1);
+        fz += __shfl_xor(fz, 1);
+        fx += __shfl_xor(fx, 2);
+        fy += __shfl_xor(fy, 2);
+        fz += __shfl_xor(fz, 2);
+        if (sub == 0) {
+            if (partner) {
+                if (A.accumulate) {
+                    A.force[3 * j] += fx;
+                    A.force[3 * j + 1] += fy;
+                    A.force[3 * j + 2] += fz;
+                } else {
+                    A.force[3 * j] = fx;
+                    A.force[3 * j + 1] = fy;
+                    A.force[3 * j + 2] = fz;
+                }
+            } else if (in && !A.accumulate && code != A.small_code) {
+                A.force[3 * j] = A.force[3 * j + 1] = A.force[3 * j + 2] = 0.0;       // an atom of neither set
+            }
+        }
+    }
+    if (EN) {
+        __shared__ double red[4];
+        for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off);
+        if (lane == 0) red[w] = esum;
+        __syncthreads();
+        if (threadIdx.x == 0) A.epart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];       // every pair once: no factor 1/2
+    }
+#if AMM_SG_EXP == 2            // measurement only: no ticket, no tail
+    return;
+#endif
+    if (!amm_last_block(A.ticket)) return;
+    // ---- last block: accumulators -> force rows of the small set; the accumulators are cleared for the next launch ----
+    for (int t = threadIdx.x; t < A.ns * 3; t += 256) {
+        const long long fixed = (long long)amm_ld_l2(&A.acc[t]);
+        amm_st_l2(&A.acc[t], 0ull);
+        const double sum = (double)fixed * (1.0 / AMM_FIX_SCALE);
+        const int k = t / 3, d = t - 3 * k, i = A.small[k];
+        if (A.small_accumulate) A.force[3 * i + d] += sum;
+        else A.force[3 * i + d] = sum;
+    }
+}
+
+struct SmallGroup {
+    int ns = 0;
+    float code = 0.f;
+    int *d_small = nullptr;
+    unsigned long long *d_acc = nullptr;
+    int *d_ticket = nullptr;
+    double *d_epart = nullptr;
+    int nblocks = 0;
+};
+
+int amm_small_group_free(SmallGroup *sg) {
+    if (!sg) return 0;
+    void *ptrs[] = {sg->d_small, sg->d_acc, sg->d_ticket, sg->d_epart};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete sg;
+    return 0;
+}
+
+// (re)decide whether `pf` takes this path: set codes on the host, the exclusion CSR of the force
+int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> &member) {
+    if (pf->small) {
+        amm_small_group_free(pf->small);
+        pf->small = nullptr;
+    }
+    const int n = pf->n;
+    std::vector<int> set1, set2;
+    for (int i = 0; i < n; ++i) {
+        if (member[i] == 1.0f) set1.push_back(i);
+        else if (member[i] == 2.0f) set2.push_back(i);
+        else if (member[i] != 0.0f) return 0;           // codes other than 0, 1, 2: the list path's product test decides
+    }
+    const bool first = set1.size() <= set2.size();
+    const std::vector<int> &small = first ? set1 : set2;
+    if (small.empty() || (int)small.size() > AMM_SMALL_MAX) return 0;
+    // an excluded (set 1, set 2) pair would have to be skipped per pair: left to the list path (none in the reference's systems)
+    for (int i : small)
+        for (int e = pf->h_excl_ptr[i]; e < pf->h_excl_ptr[i + 1]; ++e) {
+            const float other = member[pf->h_excl_idx[e]];
+            if (other != 0.0f && other != member[i]) return 0;
+        }
+    SmallGroup *sg = new SmallGroup();
+    sg->ns = (int)small.size();
+    sg->code = first ? 1.0f : 2.0f;
+    sg->nblocks = (n + 63) / 64;            // (a rank's block of atoms needs fewer; the slice may be set after this)
+    AMM_HIP(hipMalloc(&sg->d_small, sizeof(int) * sg->ns));
+    AMM_HIP(hipMemcpy(sg->d_small, small.data(), sizeof(int) * sg->ns, hipMemcpyHostToDevice));
+    AMM_HIP(hipMalloc(&sg->d_acc, sizeof(unsigned long long) * sg->ns * 3));
+    AMM_HIP(hipMemset(sg->d_acc, 0, sizeof(unsigned long long) * sg->ns * 3));
+    AMM_HIP(hipMalloc(&sg->d_ticket, sizeof(int) * AMM_TICKET_INTS));
+    AMM_HIP(hipMemset(sg->d_ticket, 0, sizeof(int) * AMM_TICKET_INTS));
+    AMM_HIP(hipMalloc(&sg->d_epart, sizeof(double) * sg->nblocks));
+    pf->small = sg;
+    return 0;
+}
+
+template <int FAM, bool GROUPED>
+static void launch_small(hipStream_t st, int nblocks, bool guard, bool en, const SmallArgs &A, const PairConsts &c) {
+    dim3 grid(nblocks), block(256);
+    if (guard) {
+        if (en) hipLaunchKernelGGL((k_small_group<FAM, true, true, GROUPED>), grid, block, 0, st, A, c);
+        else hipLaunchKernelGGL((k_small_group<FAM, true, false, GROUPED>), grid, block, 0, st, A, c);
+    } else {
+        if (en) hipLaunchKernelGGL((k_small_group<FAM, false, true, GROUPED>), grid, block, 0, st, A, c);
+        else hipLaunchKernelGGL((k_small_group<FAM, false, false, GROUPED>), grid, block, 0, st, A, c);
+    }
+}
+
+// same contract as amm_pair_eval_impl (no guest, no exchange); returns -1 when the force's family has no instantiation here
+int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy) {
+    SmallGroup *sg = pf->small;
+    hipStream_t st = ctx->stream;
+    const int fam = pf->desc.family;
+    const bool grouped = (pf->pc.flags & (AMM_GROUP_LJ | AMM_GROUP_Q)) != 0;
+    if (!((fam == AMM_SOFTCORE && !grouped) || (grouped && (fam == AMM_NEAR_FSWITCH || (fam == AMM_NONBONDED && pf->pc.cmode == 0))))) return -1;
+    const int n = pf->n;
+    const int per = (n + ctx->world - 1) / ctx->world;
+    SmallArgs A;
+    A.n = n;
+    A.j0 = std::min(n, ctx->rank * per);
+    A.j1 = std::min(n, A.j0 + per);
+    A.ns = sg->ns;
+    A.small = sg->d_small;
+    A.small_code = sg->code;
+    A.pos = d_pos;
+    A.q = pf->d_q;
+    A.hsig = pf->d_hsig;
+    A.seps2 = pf->d_seps2;
+    A.member = pf->d_member;
+    A.force = d_force;
+    A.accumulate = accumulate;
+    A.small_accumulate = accumulate;
+    if (ctx->world > 1 && !accumulate) {          // the rows outside this rank's block are zero: the group is summed over the ranks
+        AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, st));
+        A.accumulate = A.small_accumulate = 1;
+    }
+    A.box = ctx->box;
+    A.acc = sg->d_acc;
+    A.ticket = sg->d_ticket;
+    A.epart = sg->d_epart;
+    // four blocks per CU at most (grid stride in the kernel)
+    static int ncu_dev[64] = {0};
+    int &ncu = ncu_dev[ctx->device & 63];
+    if (!ncu) AMM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const int nblocks = std::max(1, std::min((A.j1 - A.j0 + 63) / 64, 4 * std::max(ncu, 1)));
+    const bool guard = (pf->desc.flags & AMM_GUARD_RC0) != 0, en = d_energy != nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = ctx->profile && (ctx->profile_only < 0 || ctx->profile_only == pf->id);
+    if (timed) {
+        if (pf->ev_used + 2 > pf->ev.size())
+            for (int k = 0; k < 64; ++k) {
+                hipEvent_t ev;
+                AMM_HIP(hipEventCreate(&ev));
+                pf->ev.push_back(ev);
+            }
+        e0 = pf->ev[pf->ev_used++];
+        e1 = pf->ev[pf->ev_used++];
+        AMM_HIP(hipEventRecord(e0, st));
+    }
+    if (fam == AMM_SOFTCORE) launch_small<AMM_SOFTCORE, false>(st, nblocks, false, en, A, pf->pc);
+    else if (fam == AMM_NEAR_FSWITCH) launch_small<AMM_NEAR_FSWITCH, true>(st, nblocks, guard, en, A, pf->pc);
+    else launch_small<AMM_NONBONDED, true>(st, nblocks, false, en, A, pf->pc);
+    if (timed) AMM_HIP(hipEventRecord(e1, st));
+    AMM_HIP(hipGetLastError());
+    if (en && amm_reduce_add(ctx, sg->d_epart, nblocks, 1.0, d_energy)) return 1;
+    pf->n_evals++;
+    pf->last_kind = 3;
+    return 0;
+}

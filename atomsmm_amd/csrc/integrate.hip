@@ -34,12 +34,6 @@ __global__ void k_move(int n3, double *__restrict__ x, const double *__restrict_
 // up to four kicks and a move in one launch: the same operations per degree of freedom, in the same order, as the separate
 // kernels (v <- v + (c*f)/m ... ; x <- x + d*v) -- programs outside the one-launch inner loop (a pair force in the innermost
 // group) spend a tenth of their step in these 5 us launches otherwise
-struct KickList {
-    const double *f[4], *f2[4];
-    int plus[4];
-    double coef[4];
-    int n;
-};
 __global__ void k_kicks_move(int n3, double *__restrict__ x, double *__restrict__ v, KickList K, const double *__restrict__ mass,
                              int with_move, double dcoef) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;

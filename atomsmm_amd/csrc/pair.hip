@@ -1670,6 +1670,11 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
     }
     // the neighbour list may belong to another, longer-ranged pair force (amm_pair_share_list)
     PairForce *L = pf->host ? pf->host : pf;
+    // an interaction-group force whose smaller set is a few dozen atoms: evaluated directly, no list (group.hip)
+    if (pf->small && ctx->opt_small_group && !pf->built && !guest && !exchange) {
+        const int r = amm_small_group_eval_impl(ctx, pf, d_pos, d_force, accumulate, d_energy);
+        if (r >= 0) return r;
+    }
     g_opt_unroll = ctx->opt_unroll;
     g_opt_dual_unroll = ctx->opt_dual_unroll;
     g_opt_tab_bs = ctx->opt_tab_bs;
@@ -2113,6 +2118,8 @@ int amm_pair_free(PairForce *pf) {
     for (hipEvent_t e : pf->ev) (void)hipEventDestroy(e);
     if (pf->cl) amm_cluster_free(pf->cl);
     pf->cl = nullptr;
+    if (pf->small) amm_small_group_free(pf->small);
+    pf->small = nullptr;
     return 0;
 }
 

@@ -336,7 +336,7 @@ class AlchemicalCoulombCVForce(object):
         return 'alchemical_coulomb_energy'
 
     def getCollectiveVariableValues(self, context):
-        lambda_coul = self._system._lambda_coul
+        lambda_coul = self._system._coulomb_factor
         group = 2 if self._system._middle_scale else 1
         self._system.reset_coulomb_scaling_factor(0.0, context)
         E0 = context.getState(getEnergy=True, groups=2 ** group).getPotentialEnergy()
@@ -375,8 +375,8 @@ class AlchemicalRespaSystem(openmm.System):
         self._copy_from(system)
         self._parameter, self._middle_scale, self._use_softcore = coupling_parameter, middle_scale, use_softcore
         self._coulomb_scaling = coulomb_scaling
-        self._solute_charges = {}
-        self._lambda_coul = 0
+        self._original_solute_charge = {}
+        self._coulomb_factor = 0
         self._inner_cutoff = rcutIn
         solute = set(int(i) for i in alchemical_atoms)
         solvent = set(range(self.getNumParticles())) - solute
@@ -412,8 +412,8 @@ class AlchemicalRespaSystem(openmm.System):
         #    reset_coulomb_scaling_factor rescales the solute's, systems.py:698-708)
         if coulomb_scaling and middle_scale:
             text = self._force_switched_eletrostatic_potential(rc, rs, self.Kc)
-            self._fsep_force = self._switched_pair_force(text, original, group=1, sets=(solute, solvent))
-            self.addForce(self._fsep_force)
+            self._switched_coulomb_force = self._switched_pair_force(text, original, group=1, sets=(solute, solvent))
+            self.addForce(self._switched_coulomb_force)
 
         # 4. solute-solvent Lennard-Jones: softcore, or a collective variable times the coupling function
         if use_softcore:
@@ -442,7 +442,7 @@ class AlchemicalRespaSystem(openmm.System):
 
         # stored as zero and reset only if a different value was passed (systems.py:781-783): with the default the
         # force-switched electrostatic force keeps the solute's full charges, as in the reference
-        self._lambda_coul = 0
+        self._coulomb_factor = 0
         self.reset_coulomb_scaling_factor(lambda_coul)
 
     # ---- pieces of the constructor -------------------------------------------------------------------------------
@@ -456,7 +456,7 @@ class AlchemicalRespaSystem(openmm.System):
         force.setForceGroup(group)
         force.setReciprocalSpaceForceGroup(group)
         for i in solute:
-            self._solute_charges[i] = force.getParticleParameters(i)[0]
+            self._original_solute_charge[i] = force.getParticleParameters(i)[0]
             force.setParticleParameters(i, 0.0, 1.0, 0.0)
         listed = set()
         for index, (i, j) in enumerate(e[:2] for e in self._exceptions(original)):
@@ -535,19 +535,26 @@ class AlchemicalRespaSystem(openmm.System):
         return AlchemicalCoulombCVForce(self)
 
     def reset_coulomb_scaling_factor(self, lambda_coul, context=None):
-        """Scaling factor of the solute-solvent electrostatics (systems.py:794-815); with a Context the particle
-        parameters are uploaded again."""
-        lambda_coul = md_value(lambda_coul)
-        if self._coulomb_scaling and lambda_coul != self._lambda_coul:
-            for i, charge in self._solute_charges.items():
-                self._nonbonded_force.setParticleParameters(i, lambda_coul * charge, 1.0, 0.0)
-                if self._middle_scale:
-                    self._fsep_force.setParticleParameters(i, (lambda_coul * charge, 1.0, 0.0))
+        """Scaling factor of the solute-solvent electrostatics (interface of systems.py:794-815).  Every force that carries the
+        solute's charges gets them again as factor x original charge -- the NonbondedForce always, the force-switched
+        solute-solvent force of the middle time scale when there is one -- and, given a Context, uploads them."""
+        factor = md_value(lambda_coul)
+        if not self._coulomb_scaling or factor == self._coulomb_factor:
+            return
+        carriers = [self._nonbonded_force]
+        if self._middle_scale:
+            carriers.append(self._switched_coulomb_force)
+        for force in carriers:
+            packed = force is not self._nonbonded_force          # a CustomNonbondedForce takes its parameters as one sequence
+            for index, original in self._original_solute_charge.items():
+                values = (factor * original, 1.0, 0.0)
+                if packed:
+                    force.setParticleParameters(index, values)
+                else:
+                    force.setParticleParameters(index, *values)
             if context is not None:
-                self._nonbonded_force.updateParametersInContext(context)
-                if self._middle_scale:
-                    self._fsep_force.updateParametersInContext(context)
-            self._lambda_coul = lambda_coul
+                force.updateParametersInContext(context)
+        self._coulomb_factor = factor
 
     @staticmethod
     def _force_switched_eletrostatic_potential(rc, rs, Kc):

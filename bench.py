@@ -15,8 +15,9 @@ RESPA step = 1 far + 2 near + 8 bonded evaluations, 22 kicks, 8 moves.  The latt
 before timing (velocity rescaling to 300 K, untimed) so that neighbour-list rebuild frequency is that of
 liquid water.  Inputs are resident in HBM when the timed region starts.
 
-N > 1: one process per GPU; every rank integrates all atoms, evaluates pair forces for its slice of the
-cell-sorted atom order and all-reduces the per-group force buffer (RCCL).  Strong scaling (fixed box).
+N > 1: one process per GPU; every rank integrates all atoms, evaluates the pair-force rows of its slice of the
+cell-sorted order and the slices are all-gathered (RCCL, the library's own communicator; groups with sliced bond
+lists or reciprocal space all-reduce their buffer instead).  Strong scaling (fixed box).
 
 Prints ONE JSON line on rank 0.
 """
@@ -95,6 +96,90 @@ def build_simulation_c5(loops, dt_fs, afed_substeps=2, skin=None):
     return simulation, case
 
 
+def bench_c2(args, torch):
+    """Config C2 of BASELINE.json: 32 768-atom Lennard-Jones fluid (atomsmm_amd.testing.lj_fluid, rho sigma^3 = 0.8), the ONLY force a
+    NearNonbondedForce(2.5 sigma, 0.9 x that, 'force-switch') imported from the NonbondedForce (forces.py:655-670), fp64, one GPU;
+    velocity Verlet at 4 fs through the AtomsMM-shaped API.  A step = one force evaluation + the two half kicks and the move.  The
+    atoms are not molecules: the traversal is the per-atom-row kernel k_pair_tab<NEAR_FSWITCH> (radial table, analytic
+    Lennard-Jones).  Roofline as for C3: algorithmic bytes 72 N per launch against the HBM peak, and the fp64 fraction."""
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import backend, openmm, unit
+    from atomsmm_amd.openmm import app
+    from atomsmm_amd.testing import lj_fluid, system_from_arrays
+    case = lj_fluid(32)
+    n = len(case['positions'])
+    sigma = float(case['sigma'][0])
+    rc, rs, dt_fs = 2.5 * sigma, 0.9 * 2.5 * sigma, 4.0
+    rng = np.random.default_rng(7)
+    case['velocities'] = rng.normal(size=(n, 3)) * np.sqrt(KB * 100.0 / case['mass'])[:, None]
+    system = system_from_arrays(case, nonbondedMethod='CutoffPeriodic', cutoff=rc)
+    nb = atomsmm.hijackForce(system, atomsmm.findNonbondedForce(system))
+    near = atomsmm.NearNonbondedForce(rc * unit.nanometers, rs * unit.nanometers, 'force-switch').importFrom(nb)
+    near.addTo(system)
+    integrator = atomsmm.UnconstrainedVelocityVerletPropagator().integrator(dt_fs * unit.femtoseconds)
+    simulation = app.Simulation(app.Topology(n), system, integrator, openmm.Platform.getPlatformByName('HIP'),
+                                dict([('Skin', str(args.skin))] if args.skin is not None else []) or None)
+    simulation.context.setPositions(case['positions'] * unit.nanometers)
+    simulation.context.setVelocities(case['velocities'])
+    eng = simulation.context._engine
+    relaxed = 0 if args.no_relax else relax(simulation, torch, target=100.0)
+    simulation.step(args.warmup)
+    fid = eng.pair_force_ids(0)[0]
+    st0 = eng.ctx.pair_stats(fid)
+    eng.ctx.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    simulation.step(args.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    launches, ms = eng.ctx.profile_read(fid)
+    eng.ctx.profile_enable(False)
+    st1 = eng.ctx.pair_stats(fid)
+    pairs = eng.ctx.pair_count_within(fid, eng.x, rc) / 2
+    t_k = ms * 1e-3 / max(launches, 1)
+    alg = BYTES_PER_ATOM * n
+    achieved = alg / max(t_k, 1e-12) / 1e9
+    tf = FLOP_PER_PAIR_NEAR * pairs / max(t_k, 1e-12) / 1e12
+    result = {
+        'metric': 'ns/day on 100k-atom TIP3P RESPA box; near-nonbonded HBM GB/s vs 8 TB/s peak',
+        'value': round(dt_fs * 1e-6 * 86400.0 / (elapsed / args.steps), 3), 'unit': 'ns/day', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'C2: %d-atom Lennard-Jones fluid (L = %.3f nm, rho sigma^3 = 0.8), NearNonbondedForce(%.3f, %.3f, force-switch) '
+                               'only, velocity Verlet at %.0f fs' % (n, case['box'][0], rc, rs, dt_fs),
+                   'atoms': n, 'step_fs': dt_fs, 'relax_steps': relaxed, 'parallelism': 'single GPU',
+                   'temperature_K_end': round(temperature(eng, torch), 1)},
+        'roofline': {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': None,
+                     'kernel': 'k_pair_tab<NEAR_FSWITCH> (per-atom rows, force only)', 'avg_launch_us': round(t_k * 1e6, 2),
+                     'launches': launches, 'algorithmic_bytes_per_launch': alg, 'fp64_tflops': round(tf, 3),
+                     'fp64_frac_of_vector_peak': round(tf / FP64_VECTOR_PEAK_TF, 4),
+                     'note': 'FP64-VALU / latency bound, not HBM bound (SURVEY.md 8d)'},
+        'detail': {'list_builds_in_timed_region': st1['n_builds'] - st0['n_builds'], 'list_pairs': st1['n_list_pairs'],
+                   'pairs_within_cutoff_counted': int(pairs), 'lanes_per_atom': st1['lanes_per_atom'], 'rlist_nm': st1['rlist'],
+                   'list_kind': st1['list_kind'], 'kernel_revision': backend.kernel_revision()},
+    }
+    if not args.no_cpu_baseline:
+        # CPU leg: the oracle's OpenMP cell-list traversal of the same force at the final configuration (one evaluation = one step's
+        # force work; kicks and moves are negligible next to it), all host threads OpenMP gives it
+        try:
+            from oracle import oracle as O
+            d = O.desc(O.ADJ['force-switch'], rc=rc, rc0=rc, rs0=rs)
+            x = eng.x.cpu().numpy()
+            O.pair_eval(d, x, case['box'], case['charge'], case['sigma'], case['epsilon'], None, use_cells=True)
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                O.pair_eval(d, x, case['box'], case['charge'], case['sigma'], case['epsilon'], None, use_cells=True)
+            sec = (time.perf_counter() - t0) / reps
+            result['cpu_baseline'] = {'value': round(dt_fs * 1e-6 * 86400.0 / sec, 4), 'unit': 'ns/day', 'cores': os.cpu_count(), 'kind': 'port',
+                                      'sample': '%d force evaluations of the same %d-atom configuration by the oracle (oracle/amm_oracle.c, OpenMP '
+                                                'cell traversal, every pair twice), %.1f ms each' % (reps, n, sec * 1e3)}
+        except Exception as exc:
+            result['cpu_baseline'] = {'value': None, 'unit': 'ns/day', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
+    print(json.dumps(result), flush=True)
+
+
 def temperature(engine, torch):
     out = torch.zeros(1, dtype=torch.float64, device=engine.x.device)
     engine.ctx.mvv(engine.v, engine.mass, out)
@@ -134,13 +219,16 @@ def cpu_baseline(nside, loops, dt_fs, sample_steps=40, state=None):
     if state is not None:
         case = dict(case, positions=state[0], velocities=state[1])
     kw = dict(loops=tuple(loops), dt=dt_fs * 1e-3)
-    threads, timing = cpu_port.best_thread_count(case, skin=0.2, **kw)
+    # every candidate over 12 steps: two or more rebuild intervals of its Verlet buffer (five steps were fewer than one)
+    threads, timing = cpu_port.best_thread_count(case, steps=12, skin=0.2, **kw)
     skins = {}
     for skin in (0.1, 0.2, 0.3, 0.4):
-        skins[skin] = cpu_port.time_port(case, warmup=1, steps=5, skin=skin, **kw)[0]
+        skins[skin] = cpu_port.time_port(case, warmup=1, steps=12, skin=skin, **kw)[0]
     best_skin = min(skins, key=skins.get)
     sec, st = cpu_port.time_port(case, warmup=3, steps=sample_steps, skin=best_skin, **kw)
+    quota = cpu_port.cpu_quota()
     return {'value': round(dt_fs * 1e-6 * 86400.0 / sec, 4), 'unit': 'ns/day', 'cores': threads, 'kind': 'port',
+            'threads': threads, 'cgroup_cpu_quota': None if quota is None else round(quota, 2), 'logical_cpus': os.cpu_count(),
             'thread_scan_ms_per_step': {str(t): round(v * 1e3, 1) for t, v in sorted(timing.items())},
             'skin_scan_ms_per_step': {'%.1f' % k: round(v * 1e3, 1) for k, v in sorted(skins.items())},
             'sample': '%d outer RESPA steps (after 3 warm-up) of the same %d-atom workload continued from the state the GPU run ended in, '
@@ -148,26 +236,93 @@ def cpu_baseline(nside, loops, dt_fs, sample_steps=40, state=None):
                       'cell-sorted Verlet list, each pair once), not OpenMM' % (sample_steps, len(case['positions']), sec * 1e3, st['builds'], best_skin)}
 
 
-def launch_ranks(n):
+def cpu_baseline_in_child(nside, x, v, timeout_s=600):
+    """cpu_baseline() in a child process of its own (fresh interpreter, never touches the GPU): the baseline is a reported figure
+    and must never cost the GPU result -- an exception, a crash of the C port (an illegal instruction on another host CPU cannot
+    be caught in-process) or a hang all leave the bench line intact with the reason in `sample`."""
+    import subprocess
+    import tempfile
+    failed = {'value': None, 'unit': 'ns/day', 'cores': 0, 'kind': 'port'}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'state.npz')
+        np.savez(path, x=x, v=v)
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', path, '--nside', str(nside)],
+                                 capture_output=True, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return dict(failed, sample='failed: no result after %d s' % timeout_s)
+    lines = [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith('{')]
+    if out.returncode != 0 or not lines:
+        return dict(failed, sample='failed: child exit code %s: %s' % (out.returncode, out.stderr.strip()[-300:]))
+    return json.loads(lines[-1])
+
+
+def launch_ranks(n, poll_s=0.2, timeout_s=None):
     """Self-launch: N child processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what
-    torch.distributed.run would do), rank 0's stdout relayed.  The parent never initialises the GPU."""
+    torch.distributed.run would do), rank 0's stdout relayed.  The parent never initialises the GPU.
+
+    All children are polled: the first one that exits non-zero (an import error, no device, a failed RCCL rendezvous) ends the
+    run -- the others, which would otherwise sit in the rendezvous or in a collective until the driver's time limit, are
+    terminated (fresh child processes only: nothing is ever re-executed), and the parent exits non-zero with the tail of the
+    failing rank's stderr.  AMM_BENCH_TIMEOUT (seconds) bounds the whole run the same way."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
-    procs = []
+    if timeout_s is None:
+        timeout_s = float(os.environ.get('AMM_BENCH_TIMEOUT', '0')) or None
+    procs, logs = [], []
+    out_file = tempfile.TemporaryFile()
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        logs.append(tempfile.TemporaryFile())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in out.decode().splitlines():        # the JSON line to stdout, library chatter (if any) to stderr
+                                      stdout=out_file if rank == 0 else subprocess.DEVNULL, stderr=logs[-1]))
+
+    def tail(f, n_bytes=4000):
+        f.seek(0, 2)
+        size = f.tell()
+        f.seek(max(0, size - n_bytes))
+        return f.read().decode(errors='replace')
+
+    t0 = time.monotonic()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = (bad[0], 'exit code %s' % codes[bad[0]])
+            break
+        if all(c == 0 for c in codes):
+            break
+        if timeout_s and time.monotonic() - t0 > timeout_s:
+            running = [r for r, c in enumerate(codes) if c is None]
+            failed = (running[0], 'no result after %.0f s (AMM_BENCH_TIMEOUT)' % timeout_s)
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out_file.seek(0)
+    for line in out_file.read().decode(errors='replace').splitlines():    # the JSON line to stdout, library chatter (if any) to stderr
         print(line, file=sys.stdout if line.lstrip().startswith('{') else sys.stderr, flush=True)
-    if any(codes):
-        raise SystemExit('bench.py: rank exit codes %s' % codes)
+    if failed is not None:
+        rank, why = failed
+        sys.stderr.write('bench.py: rank %d failed (%s); the other ranks were terminated.  Its stderr (tail):\n%s\n' % (rank, why, tail(logs[rank])))
+        raise SystemExit(1)
+    if os.environ.get('AMM_BENCH_VERBOSE_RANKS'):
+        for rank, f in enumerate(logs):
+            sys.stderr.write('--- rank %d stderr ---\n%s\n' % (rank, tail(f)))
 
 
 def dry_run():
@@ -176,6 +331,8 @@ def dry_run():
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    if os.environ.get('AMM_BENCH_DRYRUN_FAIL_RANK') == str(rank):       # (test of the launcher: a rank that dies during start-up)
+        raise SystemExit('rank %d: simulated start-up failure' % rank)
     os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
@@ -194,8 +351,9 @@ def main():
     ap.add_argument('--nside', type=int, default=32, help='waters per box edge (32 -> 98 304 atoms)')
     ap.add_argument('--outer', choices=['damped', 'pme'], default='damped',
                     help="group-2 force: DampedSmoothedForce (headline, SURVEY 8d C3 i) or the PME NonbondedForce (C3 ii)")
-    ap.add_argument('--config', choices=['c3', 'c5'], default='c3',
-                    help='c3: the headline 98 304-atom TIP3P RESPA box; c5: ~249 000-atom solvated chain, RESPA + exceptions + AFED (2 fs inner step)')
+    ap.add_argument('--config', choices=['c3', 'c5', 'c2'], default='c3',
+                    help='c3: the headline 98 304-atom TIP3P RESPA box; c5: ~249 000-atom solvated chain, RESPA + exceptions + AFED (2 fs inner step); '
+                         'c2: 32 768-atom Lennard-Jones fluid, NearNonbondedForce only (one GPU)')
     ap.add_argument('--outer-skin', type=float, default=None, help='dual Verlet list: buffer of the cell-built outer list in nm (default: single list)')
     ap.add_argument('--skin', type=float, default=None, help='Verlet buffer in nm (default: the library default, 0.1)')
     ap.add_argument('--option', action='append', default=[], help='name=value: a context option of the library (tuning; not for the headline)')
@@ -205,8 +363,13 @@ def main():
     ap.add_argument('--pme-steps', type=int, default=100,
                     help='also time this many steps with the PME NonbondedForce as the outer force (what RESPASystem leaves in group 2 for a '
                          'PME source, systems.py:74-75) and report them under detail.pme_outer; 0 skips it')
+    ap.add_argument('--cpu-baseline-child', default=None, help=argparse.SUPPRESS)      # internal: cpu_baseline_in_child
     args = ap.parse_args()
     EXTRA_OPTIONS.extend(tuple(item.split('=', 1)) for item in args.option)
+    if args.cpu_baseline_child:          # (no GPU in this process)
+        state = np.load(args.cpu_baseline_child)
+        print(json.dumps(cpu_baseline(args.nside, (4, 2, 1), 4.0, state=(state['x'], state['v']))), flush=True)
+        return
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), BEFORE anything touches
     # the GPU -- this process only waits and relays rank 0's JSON line
@@ -244,6 +407,10 @@ def main():
         if args.verbose and rank == 0:
             print('[bench] ' + msg, file=sys.stderr, flush=True)
 
+    if args.config == 'c2':
+        if world > 1:
+            raise SystemExit('bench.py --config c2 is a one-GPU line')
+        return bench_c2(args, torch)
     loops, dt_fs = (4, 2, 1), 4.0
     t_setup = time.perf_counter()
     if args.config == 'c5':
@@ -435,10 +602,7 @@ def main():
                        'row_padding': padding or None, 'pme_outer': pme_outer},
         }
         if world == 1 and not args.no_cpu_baseline and args.outer == 'damped':
-            try:
-                result['cpu_baseline'] = cpu_baseline(args.nside, loops, dt_fs, state=(eng.x.cpu().numpy(), eng.v.cpu().numpy()))
-            except Exception as exc:   # the baseline is a reported figure, never a reason to lose the GPU result
-                result['cpu_baseline'] = {'value': None, 'unit': 'ns/day', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
+            result['cpu_baseline'] = cpu_baseline_in_child(args.nside, eng.x.cpu().numpy(), eng.v.cpu().numpy())
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

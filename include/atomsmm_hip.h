@@ -15,11 +15,15 @@
  *   - units: nm, ps, dalton, kJ/mol, elementary charge (OpenMM's unit system).
  *   - all work is enqueued on the context's HIP stream; nothing synchronises unless stated.
  *   - one context per process per GPU; not thread-safe.
- *   - atom decomposition: amm_set_slice(rank, world) makes pair forces compute only the atoms of
- *     this rank's slice (rows of other atoms are written as 0), so that an all-reduce(sum) over
- *     ranks yields the full force: either issued by the host (torch.distributed) between amm_run_ops
- *     calls, or by the library itself on its own RCCL communicator (amm_comm_init + AMM_OP_ALLREDUCE),
- *     which keeps a whole multi-rank step program inside one amm_run_ops call.
+ *   - atom decomposition: amm_set_slice(rank, world) makes pair forces compute only the rows of this
+ *     rank's slice of the cell-sorted order (owner-computes: every force row has one producer).  The
+ *     default exchange of a group that holds one pair force is an ALL-GATHER of those slices
+ *     (AMM_EXCHANGE_GATHER: each rank leaves its rows, in sorted order, in its chunk of the exchange
+ *     buffer; 1/world of the bytes of an all-reduce and no additions); groups that also hold sliced
+ *     bond lists or reciprocal space, and hybrid lists, write zeros for the rows they do not own and
+ *     all-reduce(sum) the buffer (AMM_OP_ALLREDUCE).  Either is issued by the library itself on its
+ *     own RCCL communicator (amm_comm_init), which keeps a whole multi-rank step program inside one
+ *     amm_run_ops call, or by the host (torch.distributed) between amm_run_ops calls.
  */
 #ifndef ATOMSMM_HIP_H
 #define ATOMSMM_HIP_H
@@ -265,7 +269,8 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat);
 int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
 /* Tuning and test options of a context (set before the first evaluation; never read from the environment).  Names:
  * "cluster" (1: molecule rows for water-like systems on the force-only path, 0: per-atom rows everywhere), "hybrid" (1: molecule
- * rows also for waters that share the box with other atoms, the rest through per-atom rows), "tab" (tabulated
+ * rows also for waters that share the box with other atoms, the rest through per-atom rows), "small_group" (1: interaction-group
+ * forces with a set of <= 128 atoms are evaluated without a neighbour list), "tab" (tabulated
  * force-only kernels), "site_trips", "lanes_per_row", "build_parts", "unroll", "dual_unroll", "tab_block", "tab_dual_block",
  * "no_dual", "no_defer", "terms_from", "no_term_lanes".  Unknown names are an error. */
 int amm_set_option(amm_ctx *ctx, const char *name, double value);
@@ -291,7 +296,8 @@ typedef struct {
                                force-only evaluations: n_list_pairs then counts nine atom pairs per entry, capacity and
                                max_neighbors are molecule partners per row, lanes_per_atom is lanes per row), 2 hybrid: one per
                                three-site molecule for the pairs of two molecules + one per atom, filtered to the pairs with an
-                               atom outside the molecules, for the rest (an ion, a solute, a chain next to the waters) */
+                               atom outside the molecules, for the rest (an ion, a solute, a chain next to the waters), 3 none:
+                               an interaction-group force whose smaller set has <= 128 atoms is evaluated without a list */
     int64_t n_outer_builds; /* cell-based builds of the outer list (n_builds counts prunes of the inner list) */
     int64_t n_outer_pairs;
     double rlist_outer;

@@ -83,11 +83,36 @@ def set_threads(n):
     lib().port_set_threads(int(n))
 
 
-def best_thread_count(case, candidates=None, **kw):
-    """The thread count that runs the step fastest on this host (2 timed steps per candidate): a container's CPU quota can be far
-    below the number of logical CPUs it sees, and over-subscribed OpenMP threads run slower, not faster."""
+def cpu_quota():
+    """CPUs this process may use according to its cgroup (cpu.max of cgroup v2, cfs_quota of v1); None: no limit stated."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        return None if quota == 'max' else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+            quota = float(f.read())
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+            period = float(f.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
+def best_thread_count(case, candidates=None, steps=12, **kw):
+    """The thread count that runs the step fastest on this host: a container's CPU quota can be far below the number of logical
+    CPUs it sees, and over-subscribed OpenMP threads run slower, not faster.  `steps` timed steps per candidate -- at least two
+    list-rebuild intervals of the CPU's Verlet buffer, so that every candidate pays its share of list builds (five steps, less
+    than one interval, made the scan disagree with the sample it chose for by up to 1.5 x)."""
     ncpu = os.cpu_count() or 1
-    candidates = candidates or sorted(set(c for c in (8, 16, 32, 64, 128) if c <= ncpu) | {min(ncpu, 128)})
+    quota = cpu_quota()
+    if candidates is None:
+        candidates = set(c for c in (8, 16, 32, 64) if c <= ncpu)
+        if quota:
+            candidates |= {max(1, int(round(quota))), max(1, int(round(2 * quota)))}
+        candidates = sorted(c for c in candidates if c <= ncpu) or [ncpu]
     sim = RespaPort(case, **kw)
     sim.step(1)
     timing = {}
@@ -95,8 +120,8 @@ def best_thread_count(case, candidates=None, **kw):
         set_threads(t)
         sim.step(1)
         t0 = time.perf_counter()
-        sim.step(2)
-        timing[t] = (time.perf_counter() - t0) / 2
+        sim.step(steps)
+        timing[t] = (time.perf_counter() - t0) / steps
     sim.close()
     best = min(timing, key=timing.get)
     set_threads(best)

@@ -325,21 +325,29 @@ def test_pme_small_mesh_atomic_path_is_consistent(spcfw):
     ctx.close()
 
 
-def test_softcore_interaction_group_vs_oracle_and_G15(heaq, goldens):
+@pytest.mark.parametrize('small_group', [1, 0])
+def test_softcore_interaction_group_vs_oracle_and_G15(heaq, goldens, small_group):
     """AMM_SOFTCORE (SolvationSystem's solute-solvent softcore LJ, systems.py:266-272) through the C-ABI: energy
     and forces vs the oracle at three lambdas (amm_pair_set_lambda), and with the long-range correction vs the
-    reference literal tests/test_systems.py:39."""
+    reference literal tests/test_systems.py:39.  Both evaluation paths: without a neighbour list (the solute is a small set:
+    csrc/group.hip, list_kind 3) and through the filtered list (option small_group = 0)."""
     B = _backend()
     h = heaq
     n = len(h['positions'])
     codes = np.where(h['resname'] == 'aaa', 1.0, 2.0)
     ctx = B.HipContext(n, h['box'])
+    ctx.set_option('small_group', small_group)
     desc = B.pair_desc(B.SOFTCORE, 1.0, rswitch=0.9, alpha=0.5, flags=B.SWITCH, Kc=1.0)
     fid = ctx.pair_create(desc, codes, h['sigma'], h['epsilon'], h['exc_pairs'])
     pos = dev(h['positions'])
     for lam in (0.5, 1.0, 0.1):
         ctx.pair_set_lambda(fid, lam)
         e, f = eval_force(ctx, fid, pos, n)
+        assert ctx.pair_stats(fid)['list_kind'] == (3 if small_group else 0)
+        # force only, added to a buffer: the rows of both sets and of neither
+        g = torch.full((n, 3), 0.25, dtype=torch.float64, device='cuda')
+        ctx.force_eval(fid, pos, g, accumulate=True)
+        assert np.abs(g.cpu().numpy() - 0.25 - f).max() <= 1e-12 * np.abs(f).max()
         d = O.desc(O.SOFTCORE, rc=1.0, rswitch=0.9, alpha=lam, flags=O.SWITCH, Kc=1.0)
         e_ref, f_ref, _ = O.pair_eval(d, h['positions'], h['box'], codes, h['sigma'], h['epsilon'], h['exc_pairs'])
         assert e == pytest.approx(e_ref, rel=1e-10)
@@ -350,7 +358,8 @@ def test_softcore_interaction_group_vs_oracle_and_G15(heaq, goldens):
     ctx.close()
 
 
-def test_group_flags_vs_oracle(heaq):
+@pytest.mark.parametrize('small_group', [1, 0])
+def test_group_flags_vs_oracle(heaq, small_group):
     """AMM_GROUP_LJ (Lennard-Jones over a (set 1, set 2) interaction group: the charge slot carries the set codes) and
     AMM_GROUP_Q (Coulomb only: the sigma slot carries twice the set code; the force-switched electrostatics of Coulomb
     scaling, systems.py:848-856) through the C-ABI vs the oracle, and the group energy as a difference of plain sums:
@@ -362,6 +371,7 @@ def test_group_flags_vs_oracle(heaq):
     pos = dev(h['positions'])
     zero = np.zeros(n)
     ctx = B.HipContext(n, h['box'])
+    ctx.set_option('small_group', small_group)
     cases = [(B.GROUP_LJ | B.NO_SHIFT, O.GROUP_LJ | O.NO_SHIFT, codes, h['sigma'], h['epsilon'], 1.0),
              (B.GROUP_Q | B.NO_SHIFT, O.GROUP_Q | O.NO_SHIFT, h['charge'], 2.0 * codes, zero, 138.935456637)]
     for bflags, oflags, q, sigma, eps, Kc in cases:
@@ -398,18 +408,20 @@ def test_filtered_list_follows_a_moving_solute_and_reports_overflow():
     eps = np.full(n, 0.5)
     desc = B.pair_desc(B.SOFTCORE, 0.9, rswitch=0.8, alpha=0.7, flags=B.SWITCH, Kc=1.0)
     d = O.desc(O.SOFTCORE, rc=0.9, rswitch=0.8, alpha=0.7, flags=O.SWITCH, Kc=1.0)
-    ctx = B.HipContext(n, c['box'])
-    fid = ctx.pair_create(desc, codes, sigma, eps, c['exc_pairs'])
-    x = c['positions'].copy()
-    for hop in range(4):
-        pos = dev(x)
-        e, f = eval_force(ctx, fid, pos, n)
-        e_ref, f_ref, _ = O.pair_eval(d, x, c['box'], codes, sigma, eps, c['exc_pairs'])
-        assert e == pytest.approx(e_ref, rel=1e-10), hop
-        assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max(), hop
-        assert np.count_nonzero(np.abs(f).sum(axis=1)) < n // 2          # most rows are empty and were never visited
-        x[:3] += rng.uniform(0.3, 0.9, 3)                                    # the solute hops (beyond the Verlet buffer)
-    ctx.close()
+    for small_group in (0, 1):         # the filtered list; and no list at all (csrc/group.hip): the same hops
+        ctx = B.HipContext(n, c['box'])
+        ctx.set_option('small_group', small_group)
+        fid = ctx.pair_create(desc, codes, sigma, eps, c['exc_pairs'])
+        x = c['positions'].copy()
+        for hop in range(4):
+            pos = dev(x)
+            e, f = eval_force(ctx, fid, pos, n)
+            e_ref, f_ref, _ = O.pair_eval(d, x, c['box'], codes, sigma, eps, c['exc_pairs'])
+            assert e == pytest.approx(e_ref, rel=1e-10), hop
+            assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max(), hop
+            assert np.count_nonzero(np.abs(f).sum(axis=1)) < n // 2          # most rows are empty and were never visited
+            x[:3] += rng.uniform(0.3, 0.9, 3)                                    # the solute hops (beyond the Verlet buffer)
+        ctx.close()
     # overflow of the active-row grid: solvent = the atoms of one corner only, the solute starts far from it
     corner = np.all(c['positions'] < 0.9, axis=1)
     codes = np.where(corner, 2.0, 0.0)
@@ -420,6 +432,7 @@ def test_filtered_list_follows_a_moving_solute_and_reports_overflow():
     far = np.linalg.norm((x[corner][:, None, :] - x[None, n - 3:, :] + 0.5 * c['box']) % c['box'] - 0.5 * c['box'], axis=2).min()
     assert far > 1.05
     ctx = B.HipContext(n, c['box'])
+    ctx.set_option('small_group', 0)
     fid = ctx.pair_create(desc, codes, sigma, eps, c['exc_pairs'], skin=0.1)
     e, f = eval_force(ctx, fid, dev(x), n)
     assert e == 0.0 and not f.any()

@@ -101,3 +101,31 @@ def test_c5_full_size_groups_and_afed():
     assert all(0.0 <= v <= 1.0 for v in seen) and max(seen) - min(seen) > 1e-5, seen
     st = context.getState(getEnergy=True)
     assert np.isfinite(st.getPotentialEnergy()._value) and np.isfinite(st.getKineticEnergy()._value)
+
+
+def test_c5_fused_inner_iterations_bit_identical():
+    """The inner RESPA iterations of a system that is not pure water (chain + solute + waters: the group of the innermost loop
+    holds the bond lists AND the softcore pair force): softcore force without a list, terms, and ONE launch that gathers the
+    terms' forces and applies the kicks and the move that follow (csrc/bonded.hip: k_terms_gather_kicks) -- against the same
+    program with every fusion switched off (one launch per op), bit for bit, through list rebuilds."""
+    case = solvated_chain(nside=12, n_chain=300, n_solute=30)
+
+    def run(fuse):
+        respa = build_c5_system(case)
+        integrator = atomsmm.RespaPropagator([4, 2, 1]).integrator(2 * unit.femtoseconds)
+        context = openmm.Context(respa, integrator)
+        context._engine.ctx.set_fuse_inner(fuse)
+        context._engine.ctx.set_option('terms_from', 1)        # term-parallel bond lists whatever the size (the full-size path)
+        context.setPositions(case['positions'] * unit.nanometers)
+        context.setVelocities(case['velocities'])
+        context.setParameter('lambda_vdw', 0.7)
+        integrator.step(12)
+        st = context.getState(getPositions=True, getVelocities=True)
+        builds = context._engine.ctx.pair_stats(context._engine.pair_force_ids(2)[0])['n_builds']
+        return st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value, builds
+
+    x1, v1, b1 = run(True)
+    x0, v0, b0 = run(False)
+    assert b1 == b0 and b1 >= 2
+    assert np.array_equal(x1, x0) and np.array_equal(v1, v0)
+    assert np.isfinite(x1).all()

@@ -509,11 +509,11 @@ def test_alchemical_respa_coulomb_scaling_host_logic(phenol, recorder):
     q0 = phenol['charge'][solute[0]]
     # reference quirk (systems.py:781-783, 806): with the default lambda_coul = 0 nothing is reset, and the short-ranged
     # force keeps the charges it was imported with
-    assert sys0._fsep_force.getParticleParameters(solute[0])[0] == pytest.approx(q0)
+    assert sys0._switched_coulomb_force.getParticleParameters(solute[0])[0] == pytest.approx(q0)
     assert sys0._nonbonded_force.getParticleParameters(solute[0])[0]._value == 0.0
     alch = atomsmm.AlchemicalRespaSystem(system, 7 * unit.angstroms, 5 * unit.angstroms, solute, coulomb_scaling=True,
                                          lambda_coul=0.5)
-    fsep = alch._fsep_force
+    fsep = alch._switched_coulomb_force
     text = fsep.getEnergyFunction()
     assert text.startswith('respa_switch*(1 + step(r-0.5)*f1)*138.935456637*chargeprod/r; f1 = ')
     d = F.describe_energy(text, {"respa_switch": 0})
