@@ -27,6 +27,9 @@
 #include "pair_math.h"
 
 #define AMM_SMALL_MAX 128
+#ifndef AMM_SG_BPC
+#define AMM_SG_BPC 4        // blocks per CU at most (grid stride in the kernel)
+#endif
 #ifndef AMM_SG_EXP
 #define AMM_SG_EXP 0        // measurement variants (scripts/build_variant.sh group ...): wrong forces
 #endif
@@ -74,17 +77,12 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c) 
     for (int jb = A.j0 + blockIdx.x * 64; jb < A.j1; jb += gridDim.x * 64) {
         const int j = jb + (threadIdx.x >> 2);
         const bool in = j < A.j1;
-        const float code = in ? A.member[j] : 0.f;
+        const int jl = in ? j : A.j1 - 1;             // (all loads at once, whatever the atom's set: one round trip, not two)
+        const float code = in ? A.member[jl] : 0.f;
+        const double px = A.pos[3 * jl], py = A.pos[3 * jl + 1], pz = A.pos[3 * jl + 2];
+        const double qj = c.Kc * A.q[jl];
+        const double2 lj = make_double2(A.hsig[jl], A.seps2[jl]);
         const bool partner = in && code != 0.f && code != A.small_code;       // an atom of the other (large) set
-        double px = 0.0, py = 0.0, pz = 0.0, qj = 0.0;
-        double2 lj = make_double2(0.0, 0.0);
-        if (partner) {
-            px = A.pos[3 * j];
-            py = A.pos[3 * j + 1];
-            pz = A.pos[3 * j + 2];
-            qj = c.Kc * A.q[j];
-            lj = make_double2(A.hsig[j], A.seps2[j]);
-        }
         double fx = 0.0, fy = 0.0, fz = 0.0;
         // (a wavefront without an atom of the large set has nothing to do: wave-uniform)
         if (AMM_SG_EXP != 3 && __builtin_amdgcn_ballot_w64(partner) != 0ull) {
@@ -302,11 +300,11 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     A.acc = sg->d_acc;
     A.ticket = sg->d_ticket;
     A.epart = sg->d_epart;
-    // four blocks per CU at most (grid stride in the kernel)
+    // AMM_SG_BPC blocks per CU at most (grid stride in the kernel)
     static int ncu_dev[64] = {0};
     int &ncu = ncu_dev[ctx->device & 63];
     if (!ncu) AMM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    const int nblocks = std::max(1, std::min((A.j1 - A.j0 + 63) / 64, 4 * std::max(ncu, 1)));
+    const int nblocks = std::max(1, std::min((A.j1 - A.j0 + 63) / 64, AMM_SG_BPC * std::max(ncu, 1)));
     const bool guard = (pf->desc.flags & AMM_GUARD_RC0) != 0, en = d_energy != nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = ctx->profile && (ctx->profile_only < 0 || ctx->profile_only == pf->id);
