@@ -77,6 +77,32 @@ class HipError(RuntimeError):
     pass
 
 
+class _LiveSet:
+    """Identity set of the open contexts (weak references: a context that is garbage-collected closes itself)."""
+
+    def __init__(self):
+        import weakref
+        self._refs = weakref.WeakValueDictionary()
+
+    def add(self, obj):
+        self._refs[id(obj)] = obj
+
+    def discard(self, obj):
+        self._refs.pop(id(obj), None)
+
+    def close_all(self):
+        for obj in list(self._refs.values()):
+            try:
+                obj.close()
+            except Exception:
+                pass
+
+
+_LIVE = _LiveSet()
+import atexit  # noqa: E402
+atexit.register(_LIVE.close_all)
+
+
 _LIB = None
 
 
@@ -210,7 +236,12 @@ class HipContext:
         self._keep = []
 
     def close(self):
+        """Release the context (and its RCCL communicator) NOW.  Idempotent.  Contexts still open when the interpreter exits are
+        closed by an atexit hook, while the HIP runtime and RCCL are still whole: left to __del__ during interpreter
+        finalisation, ncclCommDestroy can run after the runtime it needs has begun to shut down (the stuck RCCL worker of
+        round 3)."""
         if getattr(self, 'h', None):
+            _LIVE.discard(self)
             lib().amm_destroy(self.h)
             self.h = None
 

@@ -395,6 +395,9 @@ def main():
     if world > 1 or os.environ.get('AMM_FORCE_COLLECTIVES') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
+        # one node: the bootstrap sockets of c10d / RCCL stay on the loopback interface (no interface walk, no name look-ups on
+        # hosts without a resolver); the data path over xGMI is not affected
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
         else:

@@ -1117,6 +1117,13 @@ def test_c3_full_size_tip3p_respa():
     for key, slot in (('near', 1), ('far', 2)):
         f_ref = ref[key][1]
         assert np.abs(f[slot].cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    # ... and WHICH kernel produced them: molecule rows, the near force inside the outer force's launch, site-site tables on both
+    # (a silent fall-back to per-atom rows or to analytic Lennard-Jones would meet the oracle too, while bench.py times this one)
+    st_f, st_n = ctx.pair_stats(ff), ctx.pair_stats(fn)
+    assert st_f['list_kind'] == 1 and st_n['list_kind'] == 1 and st_n['shares_list'] == 1
+    assert st_n['rode_along'] == 1 and st_f['rode_along'] == 0
+    assert st_f['has_site_table'] == 1 and st_n['has_site_table'] == 1 and st_f['has_table'] == 1 and st_n['has_table'] == 1
+    assert st_f['lanes_per_atom'] == 4                 # the product's choice for a whole box of this size
     # one outer step as RespaPropagator([4,2,1]) emits it at 2 fs, steady-state form
     dt = 0.002
     E, K, M, C_ = B.OP_EVAL, B.OP_KICK, B.OP_MOVE, B.OP_COPY
@@ -1148,4 +1155,74 @@ def test_c3_full_size_tip3p_respa():
     ctx.run_ops([B.Op(*op) for op in step_paired], 10)
     ctx.check()
     assert np.abs(x.cpu().numpy() - c['positions']).max() < 1e-9
+    ctx.close()
+
+
+def test_c3_full_size_ewald_direct_fused_pass():
+    """The step-boundary pass of the PME variant that bench.py times under detail.pme_outer -- Ewald direct space (erfc) as list
+    owner, force-switched near force as guest, ONE walk of the molecule rows -- at the full 98 304 atoms against the oracle
+    (direct space only; reciprocal space keeps its small-box pins), with the kernel that ran asserted."""
+    B = _backend()
+    from atomsmm_amd.testing import tip3p_box
+    c = tip3p_box(32)
+    n = len(c['positions'])
+    dn = near('force-switch', 0.7, 0.5)
+    de = O.desc(O.NONBONDED, rc=1.0, rswitch=0.9, alpha=2.628260884878466, flags=O.COULOMB_EWALD | O.SWITCH)
+    ctx = B.HipContext(n, c['box'])
+    fn, fe = hip_pair(B, ctx, dn, c), hip_pair(B, ctx, de, c)
+    ctx.pair_share_list(fn, fe)
+    x, v, m = dev(c['positions']), dev(c['velocities']), dev(c['mass'])
+    bufs = [torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda') for _ in range(2)]
+    ctx.bind_state(x, v, m)
+    ctx.bind_buffer(1, bufs[0])
+    ctx.bind_buffer(2, bufs[1])
+    ctx.group_define(1, 1, [fn])
+    ctx.group_define(2, 2, [fe])
+    ctx.run_ops([B.Op(B.OP_EVAL, 1, 0, 0, 0.0), B.Op(B.OP_EVAL, 2, 0, 0, 0.0)], 1)
+    ctx.check()
+    for d, buf in ((dn, bufs[0]), (de, bufs[1])):
+        f_ref = O.pair_eval(d, c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'], use_cells=True)[1]
+        assert np.abs(buf.cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    st_e, st_n = ctx.pair_stats(fe), ctx.pair_stats(fn)
+    assert st_e['list_kind'] == 1 and st_n['rode_along'] == 1 and st_e['has_site_table'] == 1 and st_n['has_site_table'] == 1
+    # the fused pass == the two stand-alone launches, bit for bit
+    f = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+    ctx.force_eval(fn, x, f)
+    assert torch.equal(f, bufs[0])
+    ctx.force_eval(fe, x, f)
+    assert torch.equal(f, bufs[1])
+    ctx.close()
+
+
+def test_c3_full_size_one_slice_of_eight_with_the_products_lanes():
+    """Rank 3 of a world of 8 at the full 98 304 atoms, exactly as the product walks its slice (lanes per row chosen by the library for
+    4 096 rows: 32), fused pass, against the ORACLE's rows of that slice -- the bit-for-bit multi-rank tests pin the lanes on both
+    sides, so this is the only place the 32-lane walk meets the oracle at full size."""
+    B = _backend()
+    from atomsmm_amd.testing import tip3p_box
+    c = tip3p_box(32)
+    n = len(c['positions'])
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+    ctx = B.HipContext(n, c['box'], rank=3, world=8)
+    fn, fd = hip_pair(B, ctx, dn, c), hip_pair(B, ctx, dd, c)
+    ctx.pair_share_list(fn, fd)
+    x, v, m = dev(c['positions']), dev(c['velocities']), dev(c['mass'])
+    bufs = [torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda') for _ in range(2)]
+    ctx.bind_state(x, v, m)
+    ctx.bind_buffer(1, bufs[0])
+    ctx.bind_buffer(2, bufs[1])
+    ctx.group_define(1, 1, [fn])
+    ctx.group_define(2, 2, [fd])
+    ctx.run_ops([B.Op(B.OP_EVAL, 1, 0, 0, 0.0), B.Op(B.OP_EVAL, 2, 0, 0, 0.0)], 1)       # (no exchange mode: rows outside the slice are zero)
+    ctx.check()
+    st = ctx.pair_stats(fd)
+    assert st['list_kind'] == 1 and st['lanes_per_atom'] == 32 and st['n_slice_atoms'] == n // 8
+    assert ctx.pair_stats(fn)['rode_along'] == 1
+    for d, buf in ((dn, bufs[0]), (dd, bufs[1])):
+        f_ref = O.pair_eval(d, c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'], use_cells=True)[1]
+        got = buf.cpu().numpy()
+        mine = np.abs(got).sum(axis=1) > 0.0
+        assert mine.sum() == n // 8 and (mine.reshape(-1, 3).all(axis=1) == mine.reshape(-1, 3).any(axis=1)).all()      # whole molecules
+        assert np.abs(got[mine] - f_ref[mine]).max() <= 1e-9 * np.abs(f_ref).max()
     ctx.close()

@@ -52,14 +52,21 @@ def _simulate(nsteps, pme=False):
     after = eng.ctx.comm_stats() if eng._native_comm else None
     st = sim.context.getState(getPositions=True, getVelocities=True, getEnergy=True, getForces=True, groups={0, 1, 2})
     stats = eng.ctx.pair_stats(eng.pair_force_ids(2)[0])
+    native = eng._native_comm
+    world = eng.world
+    eng.ctx.close()      # deterministic teardown: stream drained, ncclCommDestroy of the library's communicator, context freed -- now
     return dict(x=st.getPositions(asNumpy=True)._value, v=st.getVelocities(asNumpy=True)._value,
                 f=st.getForces(asNumpy=True)._value, e=st.getPotentialEnergy()._value, e0=e0,
-                slice_atoms=stats['n_slice_atoms'], world=eng.world, native_comm=eng._native_comm,
+                slice_atoms=stats['n_slice_atoms'], world=world, native_comm=native,
                 comm=None if before is None else {k: after[k] - before[k] for k in after})
 
 
 def _worker(rank, world, port, ret, pme=False):
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(100, exit=True, file=sys.stderr)      # a stall names its stack instead of being 'did not finish'
     import torch.distributed as dist
+    os.environ['RANK'] = str(rank)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')      # no hostname resolution on the box
     os.environ['MASTER_PORT'] = str(port)
@@ -86,11 +93,11 @@ def test_two_ranks_match_single_rank_bit_for_bit(pme):
         for p in procs:
             p.start()
         for p in procs:
-            p.join(240)
+            p.join(120)
         stuck = [p for p in procs if p.is_alive()]
         for p in stuck:          # never leave a rank behind on the GPU box
             p.kill()
-        assert not stuck, 'a rank did not finish within 240 s'
+        assert not stuck, 'a rank did not finish within 120 s'
         assert all(p.exitcode == 0 for p in procs)
         out = dict(ret)
     for r in (0, 1):
@@ -108,17 +115,41 @@ def test_two_ranks_match_single_rank_bit_for_bit(pme):
         assert out[r]['e'] == pytest.approx(single['e'], rel=1e-13)
 
 
+def _phase(name):
+    """One line per phase of a spawned rank on its stderr (the parent shows it when the rank fails or stalls)."""
+    import sys
+    import time
+    print('[rank %s] %.1f s: %s' % (os.environ.get('RANK', '0'), time.monotonic() - _T0, name), file=sys.stderr, flush=True)
+
+
+_T0 = __import__('time').monotonic()
+
+
 def _rccl_worker(port, ret, pme):
+    """Phases are announced and a watchdog dumps every thread's stack (and ends the process) after 100 s: a stall names its phase
+    instead of being found as 'did not finish' (round 3: one such stall, cause discussed in DESIGN.md section 4).  The
+    bootstrap sockets of c10d and RCCL are pinned to the loopback interface: the box has no name resolution, and an unpinned
+    bootstrap walks the interfaces with reverse look-ups that can wait for resolver time-outs."""
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(100, exit=True, file=sys.stderr)
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+    os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
     os.environ['AMM_FORCE_COLLECTIVES'] = '1'       # a 1-rank job takes the multi-rank code path
     torch.cuda.set_device(0)
+    _phase('rendezvous + torch NCCL group')
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
+        _phase('context, library communicator, 3 steps')
         ret[0] = _simulate(3, pme)
+        _phase('teardown: library communicator first (its Context is closed), then the process group')
     finally:
         dist.destroy_process_group()
+    _phase('done')
+    faulthandler.cancel_dump_traceback_later()
 
 
 @pytest.mark.parametrize('pme', [False, True])
@@ -134,10 +165,10 @@ def test_library_owned_rccl_communicator(pme):
         ret = manager.dict()
         p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret, pme))
         p.start()
-        p.join(300)
+        p.join(120)          # a healthy run: process start + imports ~15 s, RCCL init ~5 s, the steps < 1 s
         if p.is_alive():
             p.kill()
-            raise AssertionError('the RCCL rank did not finish within 300 s')
+            raise AssertionError('the RCCL rank did not finish within 120 s (its watchdog should have named the phase at 100 s)')
         assert p.exitcode == 0
         out = dict(ret)[0]
     assert out['native_comm'] and out['slice_atoms'] == 3000
