@@ -251,6 +251,7 @@ class Engine:
         self._group_bonded = []     # merged bond-list sets made by _define_group
         self._deriv_cache = {}      # deriv(energy, name) at the current positions and parameters (host-walked programs)
         self._emit_memo = {}        # what the per-DOF steps of a host-walked program emit (_emit_per_dof_memo)
+        self._segment_memo, self._segment_ends, self._segment_symbols, self._segment_open = {}, {}, {}, None      # ... and whole runs of them
         self._pending = None        # device scalars that deferred globals wait for: (buffer, number in use)
         self._valid = {}
         self._interpreted = None    # None: undecided; True: general (host-walked) step programs
@@ -893,6 +894,7 @@ class Engine:
         if dirty:
             self._programs.clear()
             self._emit_memo.clear()
+            self._segment_memo.clear()
             self._invalidate_forces()
 
     def get_parameter(self, name):
@@ -914,11 +916,13 @@ class Engine:
                     self._forget_groups()
                 self._programs.clear()
                 self._emit_memo.clear()
+                self._segment_memo.clear()
                 self._invalidate_forces()
 
     def invalidate_program(self):
         self._programs.clear()
         self._emit_memo.clear()
+        self._segment_memo.clear()
         self._interpreted = None
 
     def reinitialize(self, preserveState=False):
@@ -1445,6 +1449,68 @@ class Engine:
             keep[k] = not dead
         return [op for op, kept in zip(ops, keep) if kept]
 
+    def _run_end(self, steps, pc):
+        """First step at or after pc that is not a ComputePerDof (cached per program position)."""
+        ends = self._segment_ends
+        if pc not in ends:
+            C = mm.CustomIntegrator
+            q = pc
+            while q < len(steps) and steps[q][0] == C.ComputePerDof:
+                q += 1
+            for k in range(pc, q):
+                ends[k] = q
+        return ends[pc]
+
+    def _segment_key(self, pc, pc_end, steps, env, valid):
+        names = self._segment_symbols.get((pc, pc_end))
+        if names is None:
+            found = set()
+            for k in range(pc, pc_end):
+                found |= set(X.symbols(steps[k][2]))
+            names = self._segment_symbols[(pc, pc_end)] = tuple(sorted(found))
+        return (pc, pc_end, tuple(env.get(name) for name in names), tuple(sorted(valid.items(), key=str)),
+                tuple(sorted(self._mirror_work.items())), getattr(self, '_static_exprs', False))
+
+    def _replay_segment(self, pc, pc_end, steps, env, ops, valid):
+        """Emit the remembered ops of the run of per-DOF steps [pc, pc_end); False when this combination has not been seen (the
+        walker then goes through it step by step and _record_segment remembers it) or cannot be keyed (a deferred global)."""
+        self._segment_open = None
+        try:
+            key = self._segment_key(pc, pc_end, steps, env, valid)
+            hit = self._segment_memo.get(key)
+        except TypeError:
+            return False
+        if hit is None:
+            if len(self._segment_memo) < 512:
+                self._segment_open = [key, pc_end, len(ops), True]      # key, end, ops emitted so far, every step emitted natively
+            return False
+        new_ops, valid_after, mirror_after, moved, kicked = hit
+        ops.extend(new_ops)
+        valid.clear()
+        valid.update(valid_after)
+        self._mirror_work.clear()
+        self._mirror_work.update(mirror_after)
+        if moved:
+            self._deriv_cache.clear()
+        if kicked:
+            self._plain_kick = True
+        return True
+
+    def _record_segment(self, pc, emitted, ops, valid):
+        rec = getattr(self, '_segment_open', None)
+        if rec is None:
+            return
+        if not emitted or len(ops) < rec[2]:        # a general expression (run outside the op list) or a flush in between: not a unit
+            self._segment_open = None
+            return
+        if pc + 1 == rec[1]:
+            key, _, before, _ = rec
+            new_ops = tuple(ops[before:])
+            moved = any(op.op == B.OP_MOVE or (op.op in (B.OP_COPY, B.OP_COMBINE) and op.a == B.SLOT_X) or
+                        (op.op == B.OP_EXPR and op.b == B.SLOT_X) for op in new_ops if not isinstance(op, tuple))
+            self._segment_memo[key] = (new_ops, dict(valid), dict(self._mirror_work), moved, self._plain_kick)
+            self._segment_open = None
+
     def _emit_per_dof_memo(self, pc, target, expr, env, ops, valid):
         """_emit_per_dof for the host-walked path, remembered: what a per-DOF step of the program emits is a function of the
         values of the globals its text names, of which force groups are valid and of which auxiliary buffers mirror a force --
@@ -1746,6 +1812,7 @@ class Engine:
                 self._forget_groups()
                 self._programs.clear()
                 self._emit_memo.clear()
+                self._segment_memo.clear()
             self._invalidate_forces()
             total += (values[0] - values[1]) / (here + h - lo)
         return total
@@ -1872,6 +1939,14 @@ class Engine:
                 if guard > 2_000_000:
                     raise RuntimeError('step program does not terminate')
                 kind, target, expr = steps[pc]
+                if kind == C.ComputePerDof:
+                    # a straight run of per-DOF steps (a RESPA block of the atoms inside an AFED step: ~60 kicks, moves and
+                    # copies) emits the same ops whenever the globals it names, the valid force groups and the mirrored buffers
+                    # are the same: remembered as ONE unit (the host was slower than the GPU at config C5 walking it step by step)
+                    pc_end = self._run_end(steps, pc)
+                    if pc_end - pc >= 4 and self._replay_segment(pc, pc_end, steps, env, ops, valid):
+                        pc = pc_end
+                        continue
                 if kind == C.ComputeGlobal:
                     if 'deriv(' in expr:
                         flush()                                   # the derivative is taken at the current positions
@@ -1902,6 +1977,7 @@ class Engine:
                             done = True
                         except (NotImplementedError, NameError, SyntaxError, TypeError):
                             done = False
+                        self._record_segment(pc, done, ops, valid)
                     if not done:
                         prog = X.compile_per_dof(expr, resolve)
                         flush()                                   # EVALs emitted by resolve() run first
