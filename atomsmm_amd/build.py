@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 SOURCES = ['abi.hip', 'pair.hip', 'cluster.hip', 'group.hip', 'bonded.hip', 'integrate.hip', 'pme.hip', 'expr.hip', 'constraints.hip', 'comm.hip']
-HEADERS = ['amm_ctx.h', 'pair_math.h', 'pair_tab.h', 'erfcx_table.h', 'device_utils.h', 'expr_vm.h', 'cluster.h',
+HEADERS = ['amm_ctx.h', 'pair_math.h', 'pair_tab.h', 'erfcx_table.h', 'device_utils.h', 'expr_vm.h', 'cluster.h', 'bonded_terms.h',
            os.path.join('..', '..', 'include', 'atomsmm_hip.h')]
 LIB = os.path.join(HERE, 'libatomsmm_hip.so')
 ARCH = 'gfx950'

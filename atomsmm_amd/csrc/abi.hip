@@ -1170,8 +1170,9 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     const bool more_kicks = j < n_ops && ops[j].op == AMM_OP_KICK;      // a fifth kick: left to the next launch
                     const bool moves = !more_kicks && j < n_ops && ops[j].op == AMM_OP_MOVE;
                     if (bound && K.n >= 1) {
-                        if (ps && amm_pair_eval_impl(ctx, ps, ctx->d_x, buf, 0, nullptr)) return 1;
-                        if (amm_bonded_eval_kicks_impl(ctx, bs, ctx->d_x, buf, ps ? 1 : 0, K, moves ? 1 : 0, moves ? ops[j].coef : 0.0)) return 1;
+                        // (the pair force's launch evaluates the bond-list terms too: group.hip, TermsWork)
+                        if (ps && amm_small_group_eval_impl(ctx, ps, ctx->d_x, buf, 0, nullptr, bs) != 0) return 1;
+                        if (amm_bonded_eval_kicks_impl(ctx, bs, ctx->d_x, buf, ps ? 1 : 0, K, moves ? 1 : 0, moves ? ops[j].coef : 0.0, ps ? 1 : 0)) return 1;
                         if (moves) ctx->pos_epoch++;
                         k = j - (moves ? 0 : 1);
                         continue;

@@ -326,7 +326,9 @@ int amm_exchange_finish_impl(amm_ctx *ctx);
 
 // group.hip
 int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> &member);
-int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy);
+// carry_terms: the launch also evaluates the terms of this (finalized, term-parallel) bond-list set into its parked-force buffer
+int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy,
+                              BondedSet *carry_terms = nullptr);
 int amm_small_group_free(SmallGroup *sg);
 // implemented in pair.hip / cells.hip / bonded.hip / integrate.hip
 int amm_pair_build_consts(const amm_pair_desc &d, PairConsts &pc);
@@ -344,7 +346,7 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
 // EVAL of a term-parallel set followed by kicks (and a move): the gather launch applies them (bit-identical to the separate ops)
 int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate, const KickList &K,
-                               int with_move, double dcoef);
+                               int with_move, double dcoef, int terms_done = 0);
 int amm_bonded_free(BondedSet *bs);
 int amm_kicks_move_impl(amm_ctx *ctx, const double *const *fa, const double *const *fb, const int *plus, const double *coef, int nk,
                         int with_move, double dcoef);

@@ -16,190 +16,8 @@
 #include "expr_vm.h"
 #include "pair_math.h"
 
-struct BondedArgs {
-    int n, row_begin, row_end;
-    const int *ref_ptr;
-    // one packed record per (atom, term) reference: the term's atoms and parameters inline, so a thread needs
-    // only two dependent load levels (ref_ptr -> records -> positions) instead of four
-    const int4 *rec_a;      // atom indices of the term (-1 padded)
-    const double4 *rec_q;   // p0, p1, p2, and kind | role<<3 | periodic<<5 in the bits of .w
-    const int4 *rec_l;      // the same atoms as slots inside their connected component (component kernel)
-    const double *pos;
-    double *force;
-    double *epart;
-    int accumulate, want_energy;
-    Box box;
-    PairConsts near_pc;
-    double ewald_alpha, ewald_tasp;
-    double Kc_ljc;
-};
+#include "bonded_terms.h"
 
-// position accessors: plain array, or "state advanced by kick+move" (fused inner RESPA iteration)
-struct PosPlain {
-    const double *pos;
-    __device__ __forceinline__ double get(int a, int k) const { return pos[3 * a + k]; }
-};
-struct PosAdvanced {
-    // x_new = x + d*(v + (c1*f)/m): exactly the arithmetic (and rounding sequence) of k_kick followed by k_move
-    const double *x, *v, *f, *m;
-    double c1, d;
-    __device__ __forceinline__ double vel(int a, int k) const {
-#pragma clang fp contract(off)
-        const double num = c1 * f[3 * a + k];
-        const double dv = num / m[a];
-        return v[3 * a + k] + dv;
-    }
-    __device__ __forceinline__ double get(int a, int k) const {
-#pragma clang fp contract(off)
-        const double dx = d * vel(a, k);
-        return x[3 * a + k] + dx;
-    }
-};
-
-template <class P>
-__device__ __forceinline__ void delta3(const P &pos, int a, int b, const Box &box, int periodic, double *d) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        double v = pos.get(a, k) - pos.get(b, k);
-        if (periodic) v = amm_min_image(v, box.L[k], box.invL[k]);
-        d[k] = v;
-    }
-}
-__device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-__device__ __forceinline__ void cross3(const double *a, const double *b, double *c) {
-    c[0] = a[1] * b[2] - a[2] * b[1];
-    c[1] = a[2] * b[0] - a[0] * b[2];
-    c[2] = a[0] * b[1] - a[1] * b[0];
-}
-
-// Forces of ONE bond-list term on all of its atoms (fo[role][xyz]) and its energy.  Every path (owner-computes
-// per atom, fused inner iteration, component kernel) goes through this one function, so they agree bit for bit;
-// roles are related by exact IEEE symmetries (x_j - x_i = -(x_i - x_j), rint odd), e.g. f_1 = -f_0 for a bond.
-template <class P>
-__device__ __forceinline__ void bonded_term_forces(const BondedArgs &A, const P &pos, const int *ix, const double *p, int kind,
-                                                   int periodic, double fo[4][3], double &e) {
-    switch (kind) {
-    case AMM_BOND_HARMONIC: {
-        double d[3];
-        delta3(pos, ix[0], ix[1], A.box, periodic, d);
-        const double r2 = dot3(d, d);
-        const double rinv = amm_rsqrt(r2);         // reciprocal-sqrt + Newton: no IEEE sqrt/divide sequences
-        const double dr = r2 * rinv - p[0];
-        const double fr = -p[1] * dr * rinv;
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            fo[0][x] = fr * d[x];
-            fo[1][x] = -fo[0][x];
-        }
-        e = 0.5 * p[1] * dr * dr;
-    } break;
-    case AMM_ANGLE_HARMONIC: {
-        double d1[3], d2[3];
-        delta3(pos, ix[0], ix[1], A.box, periodic, d1);
-        delta3(pos, ix[2], ix[1], A.box, periodic, d2);
-        const double i1 = amm_rsqrt(dot3(d1, d1)), i2 = amm_rsqrt(dot3(d2, d2));
-        double c = dot3(d1, d2) * i1 * i2;
-        c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
-        const double th = acos(c), dth = th - p[0];
-        double s2 = 1.0 - c * c;
-        if (s2 < 1e-24) s2 = 1e-24;
-        const double g = p[1] * dth * amm_rsqrt(s2);
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            const double u1 = d1[x] * i1, u2 = d2[x] * i2;      // unit vectors
-            const double fi = g * (u2 - c * u1) * i1;
-            const double fk = g * (u1 - c * u2) * i2;
-            fo[0][x] = fi;
-            fo[2][x] = fk;
-            fo[1][x] = -(fi + fk);
-        }
-        e = 0.5 * p[1] * dth * dth;
-    } break;
-    case AMM_BOND_LJC:
-    case AMM_BOND_NEAR: {
-        double d[3];
-        delta3(pos, ix[0], ix[1], A.box, periodic, d);
-        const double r2 = dot3(d, d);
-        double fr;
-        if (kind == AMM_BOND_LJC) {   // forces.py:406
-            const double rinv2 = 1.0 / r2, rinv = sqrt(rinv2);
-            const double s2 = p[1] * p[1] * rinv2, x6 = s2 * s2 * s2;
-            e = 4.0 * p[2] * x6 * (x6 - 1.0) + A.Kc_ljc * p[0] * rinv;
-            fr = (4.0 * p[2] * (12.0 * x6 * x6 - 6.0 * x6) + A.Kc_ljc * p[0] * rinv) * rinv2;
-        } else {
-            amm_pair_math_rt(A.near_pc, r2, A.near_pc.Kc * p[0], p[1], 4.0 * p[2], e, fr);
-        }
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            fo[0][x] = fr * d[x];
-            fo[1][x] = -fo[0][x];
-        }
-    } break;
-    case AMM_BOND_EWALD_EXCL: {
-        const double qq = p[0];
-        double d[3];
-        delta3(pos, ix[0], ix[1], A.box, 1, d);
-        const double r2 = dot3(d, d), rr = sqrt(r2), ar = A.ewald_alpha * rr;
-        const double er = erf(ar);
-        // E = -qq erf(ar)/r ;  -dE/dr = qq [ tasp exp(-a^2 r^2)/r - erf(ar)/r^2 ]
-        const double fr = qq * (A.ewald_tasp * exp(-ar * ar) / rr - er / r2) / rr;
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            fo[0][x] = fr * d[x];
-            fo[1][x] = -fo[0][x];
-        }
-        e = -qq * er / rr;
-    } break;
-    case AMM_BOND_VIRIAL_HARMONIC:
-    case AMM_BOND_VIRIAL_LJ: {       // virial contributions as energies (ComputingSystem, systems.py:894-915)
-        double d[3];
-        delta3(pos, ix[0], ix[1], A.box, periodic, d);
-        const double r2 = dot3(d, d), r = sqrt(r2);
-        double fr;
-        if (kind == AMM_BOND_VIRIAL_HARMONIC) {
-            e = -p[1] * r * (r - p[0]);
-            fr = p[1] * (2.0 * r - p[0]) / r;                      // -(dE/dr)/r
-        } else {
-            const double s2 = p[1] * p[1] / r2, x = s2 * s2 * s2;
-            e = 24.0 * p[2] * (2.0 * x * x - x);
-            fr = 24.0 * p[2] * (24.0 * x * x - 6.0 * x) / r2;
-        }
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            fo[0][x] = fr * d[x];
-            fo[1][x] = -fo[0][x];
-        }
-    } break;
-    case AMM_TORSION_PERIODIC: {
-        double F[3], G[3], H[3], Av[3], Bv[3], BA[3];
-        delta3(pos, ix[0], ix[1], A.box, periodic, F);
-        delta3(pos, ix[1], ix[2], A.box, periodic, G);
-        delta3(pos, ix[3], ix[2], A.box, periodic, H);
-        cross3(F, G, Av);
-        cross3(H, G, Bv);
-        cross3(Bv, Av, BA);
-        const double Gn = sqrt(dot3(G, G));
-        const double phi = atan2(dot3(BA, G) / Gn, dot3(Av, Bv));
-        const double nper = p[0];
-        const double dEdphi = -p[2] * nper * sin(nper * phi - p[1]);
-        const double A2 = dot3(Av, Av), B2 = dot3(Bv, Bv), FG = dot3(F, G), HG = dot3(H, G);
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            const double gi = -Gn / A2 * Av[x], gl = Gn / B2 * Bv[x];
-            const double gj = Gn / A2 * Av[x] + FG / (A2 * Gn) * Av[x] - HG / (B2 * Gn) * Bv[x];
-            const double gk = -Gn / B2 * Bv[x] - FG / (A2 * Gn) * Av[x] + HG / (B2 * Gn) * Bv[x];
-            fo[0][x] = -(dEdphi * gi);
-            fo[1][x] = -(dEdphi * gj);
-            fo[2][x] = -(dEdphi * gk);
-            fo[3][x] = -(dEdphi * gl);
-        }
-        e = p[2] * (1.0 + cos(nper * phi - p[1]));
-    } break;
-    default: e = 0.0; break;
-    }
-}
-
-// force on atom i (and, for role-0 references, the energy) of every bond-list term that contains it
 template <class P, bool LOCAL = false>
 __device__ __forceinline__ void bonded_atom(const BondedArgs &A, const P &pos, int iglobal, int i, double *f, double &esum) {
     const int rb = A.ref_ptr[iglobal], re = A.ref_ptr[iglobal + 1];
@@ -269,10 +87,21 @@ __global__ void __launch_bounds__(256) k_terms_gather(BondedArgs A, const int *_
     if (i >= A.row_end) return;
     double f[3] = {0.0, 0.0, 0.0};
     const int rb = A.ref_ptr[i], re = A.ref_ptr[i + 1];
-    for (int r = rb; r < re; ++r) {
-        const double *src = tf + (size_t)rec_src[r] * 3;
+    for (int r0 = rb; r0 < re; r0 += 4) {          // (four records in flight, added in record order: see k_terms_gather_kicks)
+        int src[4];
 #pragma unroll
-        for (int x = 0; x < 3; ++x) f[x] += src[x];
+        for (int u = 0; u < 4; ++u) src[u] = r0 + u < re ? rec_src[r0 + u] : -1;
+        double g[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) g[u][x] = src[u] >= 0 ? tf[(size_t)src[u] * 3 + x] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (src[u] >= 0) {
+#pragma unroll
+                for (int x = 0; x < 3; ++x) f[x] += g[u][x];
+            }
     }
     if (A.accumulate) {
         A.force[3 * i] += f[0]; A.force[3 * i + 1] += f[1]; A.force[3 * i + 2] += f[2];
@@ -294,10 +123,23 @@ __global__ void __launch_bounds__(256) k_terms_gather_kicks(BondedArgs A, const 
     if (i >= A.n) return;
     double f[3] = {0.0, 0.0, 0.0};
     const int rb = A.ref_ptr[i], re = A.ref_ptr[i + 1];
-    for (int r = rb; r < re; ++r) {
-        const double *src = tf + (size_t)rec_src[r] * 3;
+    // four records at a time: their indices, then their parked forces, are fetched together (one record after the other the
+    // kernel was a chain of 2 x records dependent loads per atom at 4 wavefronts per SIMD); added in record order as before
+    for (int r0 = rb; r0 < re; r0 += 4) {
+        int src[4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) f[c] += src[c];
+        for (int u = 0; u < 4; ++u) src[u] = r0 + u < re ? rec_src[r0 + u] : -1;
+        double g[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[u][c] = src[u] >= 0 ? tf[(size_t)src[u] * 3 + c] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (src[u] >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) f[c] += g[u][c];
+            }
     }
     if (A.accumulate) {
 #pragma unroll
@@ -887,14 +729,12 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
     return 0;
 }
 
-int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate, const KickList &K,
-                               int with_move, double dcoef) {
+static int terms_args(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate, BondedArgs &A) {
     if (!bs->finalized || bs->n_gterms <= 0 || (bs->sliced && ctx->world > 1)) {
-        amm_set_error("amm_bonded_eval_kicks_impl: needs a finalized, unsliced, term-parallel bond-list set");
+        amm_set_error("term-parallel evaluation: needs a finalized, unsliced bond-list set with parked-force buffers");
         return 1;
     }
     const int n = ctx->n;
-    BondedArgs A;
     A.n = n;
     A.row_begin = 0;
     A.row_end = n;
@@ -912,8 +752,27 @@ int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos,
     A.ewald_alpha = bs->ewald_alpha;
     A.ewald_tasp = bs->ewald_alpha * 1.1283791670955125739;
     A.Kc_ljc = bs->ljc_Kc;
-    hipLaunchKernelGGL(k_terms_eval, dim3((bs->n_gterms + 255) / 256), dim3(256), 0, ctx->stream, A, bs->n_gterms, bs->d_gt_a, bs->d_gt_q,
-                       bs->d_tf);
+    return 0;
+}
+
+int amm_bonded_terms_work(amm_ctx *ctx, BondedSet *bs, const double *d_pos, BondedArgs *A, int *nterms, const int4 **gt_a,
+                          const double4 **gt_q, double **tf) {
+    if (terms_args(ctx, bs, d_pos, nullptr, 0, *A)) return 1;
+    *nterms = bs->n_gterms;
+    *gt_a = bs->d_gt_a;
+    *gt_q = bs->d_gt_q;
+    *tf = bs->d_tf;
+    return 0;
+}
+
+int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate, const KickList &K,
+                               int with_move, double dcoef, int terms_done) {
+    BondedArgs A;
+    if (terms_args(ctx, bs, d_pos, d_force, accumulate, A)) return 1;
+    const int n = ctx->n;
+    if (!terms_done)
+        hipLaunchKernelGGL(k_terms_eval, dim3((bs->n_gterms + 255) / 256), dim3(256), 0, ctx->stream, A, bs->n_gterms, bs->d_gt_a, bs->d_gt_q,
+                           bs->d_tf);
     hipLaunchKernelGGL(k_terms_gather_kicks, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, bs->d_rec_src, bs->d_tf, K, ctx->d_x,
                        ctx->d_v, ctx->d_mass, with_move, dcoef);
     AMM_HIP(hipGetLastError());

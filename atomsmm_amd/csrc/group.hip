@@ -20,9 +20,11 @@
 // arguments as the list-based kernel k_pair_nlist.
 // HBM traffic: positions + parameters + force rows once (~56 B per atom), 7.5 M distance tests at 249 075 atoms x 30.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "amm_ctx.h"
+#include "bonded_terms.h"
 #include "device_utils.h"
 #include "pair_math.h"
 
@@ -53,8 +55,19 @@ struct SmallArgs {
     double *epart;                 // [nblocks] energies (EN)
 };
 
+// Term evaluation of a bond-list set that shares the force group with this pair force (amm_run_ops: the group of the innermost RESPA
+// loop at config C5 = bond lists + softcore force): the blocks of this launch evaluate the terms too, with a grid stride -- the
+// work of bonded.hip's k_terms_eval (same function, same parked forces), without a launch of its own.  nterms == 0: none.
+struct TermsWork {
+    int nterms;
+    const int4 *gt_a;
+    const double4 *gt_q;
+    double *tf;
+    BondedArgs A;
+};
+
 template <int FAM, bool GUARD, bool EN, bool GROUPED>
-__global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c) {
+__global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, TermsWork T) {
     __shared__ double4 s_pos[AMM_SMALL_MAX];          // x, y, z, Kc q
     __shared__ double2 s_lj[AMM_SMALL_MAX];
     __shared__ double s_tr[4][12][65];                // per wavefront: the twelve reaction components of a trip, [value][lane]
@@ -67,6 +80,23 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c) 
         s_lj[k] = make_double2(A.hsig[i], A.seps2[i]);
     }
     __syncthreads();
+    // (the bond-list terms first: independent of everything below, and their loads overlap the staging above)
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < T.nterms; t += gridDim.x * 256) {
+        const int4 at = T.gt_a[t];
+        const double4 q = T.gt_q[t];
+        const long long code = __double_as_longlong(q.w);
+        const int kind = (int)(code & 7), periodic = (int)((code >> 5) & 1);
+        const int ix[4] = {at.x, at.y, at.z, at.w};
+        const double p[3] = {q.x, q.y, q.z};
+        double fo[4][3], e;
+        PosPlain pos{T.A.pos};
+        bonded_term_forces(T.A, pos, ix, p, kind, periodic, fo, e);
+        double *out = T.tf + (size_t)t * 12;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) out[3 * r + x] = fo[r][x];
+    }
     const double guard2 = GUARD ? c.rc0 * c.rc0 : 0.0;
     double esum = 0.0;
     // Four lanes share an atom j of the large set: lane `sub` of them takes the small atoms sub, sub + 4, sub + 8 ... -- four per
@@ -257,19 +287,20 @@ int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> 
 }
 
 template <int FAM, bool GROUPED>
-static void launch_small(hipStream_t st, int nblocks, bool guard, bool en, const SmallArgs &A, const PairConsts &c) {
+static void launch_small(hipStream_t st, int nblocks, bool guard, bool en, const SmallArgs &A, const PairConsts &c, const TermsWork &T) {
     dim3 grid(nblocks), block(256);
     if (guard) {
-        if (en) hipLaunchKernelGGL((k_small_group<FAM, true, true, GROUPED>), grid, block, 0, st, A, c);
-        else hipLaunchKernelGGL((k_small_group<FAM, true, false, GROUPED>), grid, block, 0, st, A, c);
+        if (en) hipLaunchKernelGGL((k_small_group<FAM, true, true, GROUPED>), grid, block, 0, st, A, c, T);
+        else hipLaunchKernelGGL((k_small_group<FAM, true, false, GROUPED>), grid, block, 0, st, A, c, T);
     } else {
-        if (en) hipLaunchKernelGGL((k_small_group<FAM, false, true, GROUPED>), grid, block, 0, st, A, c);
-        else hipLaunchKernelGGL((k_small_group<FAM, false, false, GROUPED>), grid, block, 0, st, A, c);
+        if (en) hipLaunchKernelGGL((k_small_group<FAM, false, true, GROUPED>), grid, block, 0, st, A, c, T);
+        else hipLaunchKernelGGL((k_small_group<FAM, false, false, GROUPED>), grid, block, 0, st, A, c, T);
     }
 }
 
 // same contract as amm_pair_eval_impl (no guest, no exchange); returns -1 when the force's family has no instantiation here
-int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy) {
+int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy,
+                              BondedSet *carry_terms) {
     SmallGroup *sg = pf->small;
     hipStream_t st = ctx->stream;
     const int fam = pf->desc.family;
@@ -319,9 +350,19 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
         e1 = pf->ev[pf->ev_used++];
         AMM_HIP(hipEventRecord(e0, st));
     }
-    if (fam == AMM_SOFTCORE) launch_small<AMM_SOFTCORE, false>(st, nblocks, false, en, A, pf->pc);
-    else if (fam == AMM_NEAR_FSWITCH) launch_small<AMM_NEAR_FSWITCH, true>(st, nblocks, guard, en, A, pf->pc);
-    else launch_small<AMM_NONBONDED, true>(st, nblocks, false, en, A, pf->pc);
+    TermsWork T;
+    T.nterms = 0;
+    T.gt_a = nullptr;
+    T.gt_q = nullptr;
+    T.tf = nullptr;
+    if (carry_terms) {
+        if (amm_bonded_terms_work(ctx, carry_terms, d_pos, &T.A, &T.nterms, &T.gt_a, &T.gt_q, &T.tf)) return 1;
+    } else {
+        std::memset(&T.A, 0, sizeof(T.A));
+    }
+    if (fam == AMM_SOFTCORE) launch_small<AMM_SOFTCORE, false>(st, nblocks, false, en, A, pf->pc, T);
+    else if (fam == AMM_NEAR_FSWITCH) launch_small<AMM_NEAR_FSWITCH, true>(st, nblocks, guard, en, A, pf->pc, T);
+    else launch_small<AMM_NONBONDED, true>(st, nblocks, false, en, A, pf->pc, T);
     if (timed) AMM_HIP(hipEventRecord(e1, st));
     AMM_HIP(hipGetLastError());
     if (en && amm_reduce_add(ctx, sg->d_epart, nblocks, 1.0, d_energy)) return 1;

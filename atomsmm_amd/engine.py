@@ -883,19 +883,32 @@ class Engine:
             return
         self.parameters[name] = value
         changed = {name}
-        dirty = False
+        groups, rebuilt = set(), False
         for entry in self.entries:
             if entry.update is not None:
                 result = entry.update(self.parameters, changed)
                 if result:
-                    dirty = True
+                    groups.add(entry.group)
+                    if getattr(entry, 'recip', None) is not None:
+                        groups.add(entry.recip_group)
                     if result != 'values':
+                        rebuilt = True
                         self._forget_groups()       # bond-list terms were rebuilt
-        if dirty:
+        if rebuilt:
             self._programs.clear()
             self._emit_memo.clear()
             self._segment_memo.clear()
             self._invalidate_forces()
+        elif groups:
+            # only VALUES changed (an extended variable moved: AFED sets lambda_vdw twice per step): the forces of the groups that
+            # hold a force that depends on it are stale -- the other groups' buffers, the compiled programs and what the step
+            # programs emit are not (invalidating everything cost config C5 a fifth outer + near evaluation per AFED step)
+            for g in self._valid:
+                if g in groups or g == 'all':
+                    self._valid[g] = False
+            self._deriv_cache.clear()
+            self._programs.clear()          # (compiled programs may hold coefficients that name the parameter; the memos of the
+                                            # host-walked path are keyed by the values of the globals they name)
 
     def get_parameter(self, name):
         return self.parameters[name]
