@@ -17,6 +17,7 @@ from .forces import FarNonbondedForce  # noqa: F401
 from .forces import NearExceptionForce  # noqa: F401
 from .forces import NearNonbondedForce  # noqa: F401
 from .forces import NonbondedExceptionsForce  # noqa: F401
+from .forces import SoftcoreForce  # noqa: F401
 from .forces import SoftcoreLennardJonesForce  # noqa: F401
 from .integrators import GlobalThermostatIntegrator  # noqa: F401
 from .integrators import MultipleTimeScaleIntegrator  # noqa: F401
@@ -47,7 +48,7 @@ from .utils import splitPotentialEnergy  # noqa: F401
 from . import forces, integrators, propagators, systems, utils  # noqa: F401
 
 __forces__ = ['DampedSmoothedForce', 'NonbondedExceptionsForce', 'NearExceptionForce', 'NearNonbondedForce',
-              'FarNonbondedForce', 'SoftcoreLennardJonesForce']
+              'FarNonbondedForce', 'SoftcoreLennardJonesForce', 'SoftcoreForce']
 __integrators__ = ['GlobalThermostatIntegrator', 'MultipleTimeScaleIntegrator', 'Langevin_R_Integrator', 'NHL_R_Integrator', 'SIN_R_Integrator',
                    'AdiabaticDynamicsIntegrator', 'ExtendedSystemVariable']
 __propagators__ = ['ChainedPropagator', 'MultipleTimeScalePropagator', 'RespaPropagator', 'SplitPropagator',

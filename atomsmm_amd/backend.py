@@ -119,6 +119,13 @@ def lib():
                            '(hipcc --offload-arch=gfx950). The HIP path has no CPU fallback.' % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        L.amm_kernel_revision.restype = C.c_char_p
+        revision = L.amm_kernel_revision().decode()
+        if revision.endswith('-tune') and os.environ.get('AMM_ALLOW_TUNE') != '1':
+            # a kernel-tuning / measurement build (scripts/build_variant.sh): only part of the kernels, or kernels with arithmetic
+            # removed -- never what a bench line or a test may run on
+            raise HipError('%s is a tuning build (kernel revision %s): rebuild with `python -m atomsmm_amd.build --force`, or set '
+                           'AMM_ALLOW_TUNE=1 for a probe script' % (LIB_PATH, revision))
         L.amm_abi_version.restype = C.c_int
         L.amm_last_error.restype = C.c_char_p
         L.amm_create.argtypes = [C.c_int32, dp, C.c_int32, vp, C.POINTER(vp)]

@@ -2,8 +2,8 @@
 
     python -m atomsmm_amd.build [--force]
 
-Every source is compiled to an object of its own (in parallel, and only when it or a header is newer than the object), then
-linked: an edit of one kernel file costs one compilation, not eight.
+Every source is compiled to an object of its own (in parallel, and only when the content of the source, of a header or the flags
+differ from what the object was built from), then linked: an edit of one kernel file costs one compilation, not ten.
 """
 import os
 import subprocess
@@ -21,29 +21,54 @@ ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC']
 
 
-def _mtime(path):
-    return os.path.getmtime(path) if os.path.exists(path) else 0.0
-
-
-def _headers_time():
-    return max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
+def _digest(paths, extra=''):
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for path in paths:
+        h.update(b'\0' + os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def _object(src):
     return os.path.join(OBJ, os.path.splitext(src)[0] + '.o')
 
 
+def _stamp(src):
+    return _object(src) + '.stamp'
+
+
+def _want(src):
+    """What an up-to-date object of `src` was built from: the source, every header and the flags -- by CONTENT.  (Modification times
+    do not survive a copy to another machine, and a tuning build with other flags left an object newer than its source that the
+    old mtime test kept: ADVICE r3.)"""
+    return _digest([os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS], ' '.join(FLAGS))
+
+
+def _read(path):
+    try:
+        with open(path) as fh:
+            return fh.read().strip()
+    except OSError:
+        return ''
+
+
 def _stale_sources(force=False):
-    ht = _headers_time()
-    return [s for s in SOURCES if force or _mtime(_object(s)) < max(_mtime(os.path.join(CSRC, s)), ht)]
+    return [s for s in SOURCES if force or not os.path.exists(_object(s)) or _read(_stamp(s)) != _want(s)]
+
+
+def _lib_want():
+    return _digest([], ' '.join(_read(_stamp(s)) for s in SOURCES))
 
 
 def _stale():
-    return bool(_stale_sources()) or any(_mtime(_object(s)) > _mtime(LIB) for s in SOURCES) or not os.path.exists(LIB)
+    return bool(_stale_sources()) or not os.path.exists(LIB) or _read(LIB + '.stamp') != _lib_want()
 
 
 def build_hip(force=False, verbose=False, jobs=None):
-    """Compile every HIP source into atomsmm_amd/libatomsmm_hip.so (in-tree, so it travels with the repo)."""
+    """Compile every HIP source into atomsmm_amd/libatomsmm_hip.so (in-tree, so it travels with the repo).  Up to date = the stamps
+    next to the objects and the library match the content of the sources, headers and flags."""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get('HIPCC', 'hipcc')
@@ -54,7 +79,10 @@ def build_hip(force=False, verbose=False, jobs=None):
         cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', _object(src)]
         if verbose:
             print(' '.join(cmd), flush=True)
+        want = _want(src)
         subprocess.check_call(cmd)
+        with open(_stamp(src), 'w') as fh:
+            fh.write(want)
 
     if todo:
         with ThreadPoolExecutor(max_workers=jobs or min(len(todo), max(1, (os.cpu_count() or 2) - 1))) as pool:
@@ -63,6 +91,8 @@ def build_hip(force=False, verbose=False, jobs=None):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(LIB + '.stamp', 'w') as fh:
+        fh.write(_lib_want())
     return LIB
 
 

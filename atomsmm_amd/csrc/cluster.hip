@@ -936,9 +936,11 @@ static int launch_cdual(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, c
 }
 
 static int launch_cpair(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c) {
-#ifdef AMM_CLUSTER_TUNE      // kernel tuning builds: the two instantiations of the bench only (compile time)
+#ifdef AMM_CLUSTER_TUNE      // kernel tuning builds (scripts/build_variant.sh cluster ...): the two instantiations of the bench only
     if (c.family == AMM_NEAR_FSWITCH) return launch_cpair_s<AMM_NEAR_FSWITCH, 0, -1>(ctx, A, c, c);
-    return launch_cpair_s<AMM_DAMPED, 1, -1>(ctx, A, c, c);
+    if (c.family == AMM_DAMPED && c.degree == 1) return launch_cpair_s<AMM_DAMPED, 1, -1>(ctx, A, c, c);
+    amm_set_error("this is a kernel-tuning build (AMM_CLUSTER_TUNE): it holds the near force-switch and degree-1 damped kernels only");
+    return 1;
 #else
     switch (c.family) {
     case AMM_NEAR_NONE: return launch_cpair_s<AMM_NEAR_NONE, 0, -1>(ctx, A, c, c);

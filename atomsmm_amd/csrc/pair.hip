@@ -2033,7 +2033,17 @@ int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos,
 }
 
 // bump when a pair-traversal kernel changes: stored measurements (profiles/*_traffic.json) are matched against it
-const char *amm_kernel_revision_impl() { return "r03-mol4"; }
+// A tuning or measurement build says so in its tag: scripts/build_variant.sh links a marker symbol into every variant library, and
+// AMM_CLUSTER_TUNE is a variant by definition; atomsmm_amd/backend.py refuses a "-tune" library unless AMM_ALLOW_TUNE=1 (the probe
+// scripts set it), so neither bench.py nor the tests can run on one by accident.
+extern "C" __attribute__((weak)) const char *amm_variant_tag(void);
+const char *amm_kernel_revision_impl() {
+#ifdef AMM_CLUSTER_TUNE
+    return "r04-hyb1-tune";
+#else
+    return amm_variant_tag ? "r04-hyb1-tune" : "r04-hyb1";
+#endif
+}
 
 // radial Coulomb table of the force-only traversal (pair_tab.h): built from the descriptor alone, once per pair force
 int amm_pair_build_table(PairForce *pf) {

@@ -454,6 +454,20 @@ class SoftcoreLennardJonesForce(_AtomsMM_CustomNonbondedForce):
                          **{parameter: 1.0})
 
 
+class SoftcoreForce(_AtomsMM_CustomNonbondedForce):
+    """Softened Lennard-Jones plus scaled Coulomb in ONE expression (interface of forces.py:761-793): V = 4 lambda_vdw eps
+    (1 - x)/x^2 + Kc lambda_coul q1 q2 / r with x = (r/sigma)^6 + (1 - lambda_vdw)/2, OpenMM's built-in switch from
+    `switch_distance` to `cutoff_distance`.  The class, its energy text and its global parameters (Kc, lambda_vdw, lambda_coul)
+    are the reference's (pinned by tests/golden/programs.json: 'softcore').  No system class on the RESPA hot path uses it
+    (SolvationSystem / AlchemicalSystem use SoftcoreLennardJonesForce), and the HIP engine has no kernel for this text: creating a
+    Context over a System that holds one raises the 'energy expression not recognised' error."""
+
+    def __init__(self, cutoff_distance, switch_distance=None):
+        terms = ['4*lambda_vdw*epsilon*(1-x)/x^2 + Kc*lambda_coul*chargeprod/r', 'x = (r/sigma)^6 + 0.5*(1-lambda_vdw)']
+        parameters = dict(Kc=KC * unit.kilojoules_per_mole / unit.nanometer, lambda_vdw=1.0, lambda_coul=1.0)
+        super().__init__(';'.join(terms), cutoff_distance, True, switch_distance, **parameters)
+
+
 class NearForce(object):
     """Shared pieces of the near forces (forces.py:533-567)."""
 

@@ -11,11 +11,14 @@ objs=""
 for s in abi pair cluster group bonded integrate pme expr constraints comm; do
     [ "$s" = "$file" ] || objs="$objs $O/$s.o"
 done
+# the revision tag of a variant library ends in "-tune" (amm_kernel_revision): bench.py and the tests refuse it
+printf 'extern "C" const char *amm_variant_tag(void) { return "variant"; }\n' > /tmp/var_tag.cpp
+hipcc -fPIC -c /tmp/var_tag.cpp -o /tmp/var_tag.o
 while [ $# -gt 1 ]; do
     name=$1; flags=$2; shift 2
     (
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c atomsmm_amd/csrc/$file.hip -o /tmp/var_$name.o -Rpass-analysis=kernel-resource-usage 2> /tmp/ru_$name.txt || { grep -E "error" -A3 /tmp/ru_$name.txt; exit 1; }
-    hipcc --offload-arch=gfx950 -fPIC -shared -o atomsmm_amd/exp/lib_$name.so $objs /tmp/var_$name.o -lhipfft -ldl
+    hipcc --offload-arch=gfx950 -fPIC -shared -o atomsmm_amd/exp/lib_$name.so $objs /tmp/var_$name.o /tmp/var_tag.o -lhipfft -ldl
     echo "built atomsmm_amd/exp/lib_$name.so ($flags)"
     ) &
 done

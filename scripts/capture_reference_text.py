@@ -370,6 +370,8 @@ FORCES = {
     'damped_degree_2': 'atomsmm.DampedSmoothedForce(2.9/unit.nanometers, 1.0*unit.nanometers, 0.9*unit.nanometers, degree=2)',
     'exceptions': 'atomsmm.NonbondedExceptionsForce()',
     'near_exception': 'atomsmm.NearExceptionForce(0.7*unit.nanometers, 0.5*unit.nanometers, "force-switch")',
+    'softcore_lj': 'atomsmm.SoftcoreLennardJonesForce(parameter="lambda_vdw")',
+    'softcore': 'atomsmm.SoftcoreForce(1.0*unit.nanometers, 0.9*unit.nanometers)',
 }
 
 

@@ -728,9 +728,18 @@ def test_softcore_force_classes(heaq, recorder):
     openmm.Context(system, openmm.VerletIntegrator(0.0)).setParameter('lambda_vdw', 0.5)
     sc = [p_ for p_ in recorder[-1].pairs if p_['family'] == B.SOFTCORE]
     assert len(sc) == 1 and ('pair_set_lambda', sc[0]['id'], 0.5) in recorder[-1].calls
-    # (the reference's SoftcoreForce -- softcore Lennard-Jones plus scaled Coulomb in one expression, forces.py:761-792 -- is outside the
-    # hot path's scope and is not restated: a stub whose Context raised was dropped in round 3)
-    assert not hasattr(atomsmm, 'SoftcoreForce')
+    # the reference's SoftcoreForce (softcore Lennard-Jones plus scaled Coulomb in one expression, forces.py:761-793) exists with the
+    # reference's text and globals (test_energy_string_equals_the_reference_capture[softcore]); the HIP engine has no kernel for it
+    # and says so when a Context is created over it
+    both = atomsmm.SoftcoreForce(1.0 * unit.nanometers, 0.9 * unit.nanometers).importFrom(nb)
+    assert both.getUseSwitchingFunction() and both.getGlobalParameterName(0) == 'Kc'
+    system2 = openmm.System()
+    for i in range(nb.getNumParticles()):
+        system2.addParticle(1.0)
+    system2.setDefaultPeriodicBoxVectors(*system.getDefaultPeriodicBoxVectors())
+    both.addTo(system2)
+    with pytest.raises(Exception, match='not recognised'):
+        openmm.Context(system2, openmm.VerletIntegrator(0.0))
 
 
 def test_simulation_serves_reporters(spcfw, recorder):
