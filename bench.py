@@ -39,7 +39,7 @@ BYTES_PER_ATOM_DUAL = 96       # dual pass: the same read set, two force arrays 
 FLOP_PER_PAIR_NEAR = 60        # force-switch near, force only
 FLOP_PER_PAIR_FAR = 80         # DampedSmoothedForce (erfc + exp), force only
 FP64_SUSTAINED_TF = 60.7       # measured: v_fma_f64, 8 wavefronts per SIMD, 2.16 ns per wave-instruction per SIMD (DVFS clock)
-TRAFFIC_FILE = 'r03_traffic.json'
+TRAFFIC_FILE = 'r04_traffic.json'
 KB = 0.0083144626181532
 
 
