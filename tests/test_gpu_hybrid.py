@@ -225,3 +225,70 @@ def test_atom_wrapped_waters():
     assert ctx.pair_stats(fd)['list_kind'] == 1
     assert np.abs(f.cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3, 4])
+def test_random_mixtures(seed):
+    """Random mixtures in random index order -- three-site waters, monatomic ions, diatomics (own pair excluded), four-site
+    molecules (all six pairs excluded: NOT three-site molecules, whatever their first three atoms look like) -- at a random density
+    in a random orthorhombic box: the hybrid list (or, below half the atoms in molecules, per-atom rows) against the oracle."""
+    B = _backend()
+    rng = np.random.default_rng(100 + seed)
+    L = rng.uniform(2.6, 3.4, 3)
+    n_w, n_ion, n_di, n_four = int(rng.integers(150, 500)), int(rng.integers(0, 40)), int(rng.integers(0, 30)), int(rng.integers(0, 20))
+    kinds = ['w'] * n_w + ['i'] * n_ion + ['d'] * n_di + ['f'] * n_four
+    rng.shuffle(kinds)
+    pos, q, s, e, exc = [], [], [], [], []
+    # molecules on a jittered lattice (no overlaps), random orientation
+    m = len(kinds)
+    g = int(np.ceil(m ** (1 / 3)))
+    cells = rng.permutation(g ** 3)[:m]
+    for kind, cell in zip(kinds, cells):
+        c = (np.array([cell // (g * g), (cell // g) % g, cell % g]) + 0.5 + rng.uniform(-0.1, 0.1, 3)) / g * L
+        rot = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        i = len(q)
+        if kind == 'w':
+            local = np.array([[0, 0, 0], [0.0757, 0.0586, 0], [-0.0757, 0.0586, 0]])
+            pos.extend(c + local @ rot.T)
+            q.extend([-0.834, 0.417, 0.417]); s.extend([0.315075, 1.0, 1.0]); e.extend([0.635968, 0.0, 0.0])
+            exc.extend([(i, i + 1), (i, i + 2), (i + 1, i + 2)])
+        elif kind == 'i':
+            pos.append(c)
+            q.append(float(rng.choice([-1.0, 1.0]))); s.append(0.3); e.append(0.3)
+        elif kind == 'd':
+            pos.extend(c + np.array([[0.05, 0, 0], [-0.05, 0, 0]]) @ rot.T)
+            q.extend([0.3, -0.3]); s.extend([0.3, 0.28]); e.extend([0.4, 0.2])
+            exc.append((i, i + 1))
+        else:
+            local = np.array([[0, 0, 0], [0.0757, 0.0586, 0], [-0.0757, 0.0586, 0], [0, 0.015, 0]])
+            pos.extend(c + local @ rot.T)
+            q.extend([0.0, 0.52, 0.52, -1.04]); s.extend([0.3154, 1.0, 1.0, 1.0]); e.extend([0.65, 0.0, 0.0, 0.0])
+            exc.extend([(i + a, i + b) for a in range(4) for b in range(a + 1, 4)])
+    c = dict(positions=np.array(pos), box=L, charge=np.array(q), sigma=np.array(s), epsilon=np.array(e),
+             exc_pairs=np.array(exc, dtype=np.int32).reshape(-1, 2))
+    n = len(q)
+    dn_, dd_ = near(0.6, 0.45), O.desc(O.DAMPED, rc=0.9, rswitch=0.8, alpha=2.9, degree=1)
+    ctx = B.HipContext(n, L)
+    fn, fd = create(B, ctx, dn_, c), create(B, ctx, dd_, c)
+    ctx.pair_share_list(fn, fd)
+    x, v, mass = dev(c['positions']), torch.zeros((n, 3), dtype=torch.float64, device='cuda'), torch.ones(n, dtype=torch.float64, device='cuda')
+    bufs = [torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda') for _ in range(2)]
+    ctx.bind_state(x, v, mass)
+    ctx.bind_buffer(1, bufs[0])
+    ctx.bind_buffer(2, bufs[1])
+    ctx.group_define(1, 1, [fn])
+    ctx.group_define(2, 2, [fd])
+    ctx.run_ops([B.Op(B.OP_EVAL, 1, 0, 0, 0.0), B.Op(B.OP_EVAL, 2, 0, 0, 0.0)], 1)
+    ctx.check()
+    for d, buf in ((dn_, bufs[0]), (dd_, bufs[1])):
+        f_ref = oracle_forces(d, c)[1]
+        assert np.abs(buf.cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+    st = ctx.pair_stats(fd)
+    n_rest = n_ion + 2 * n_di + 4 * n_four
+    if n_rest == 0:
+        assert st['list_kind'] == 1
+    elif 2 * 3 * n_w >= n:
+        assert st['list_kind'] == 2 and st['n_rest_atoms'] == n_rest
+    else:
+        assert st['list_kind'] == 0
+    ctx.close()
