@@ -1574,11 +1574,32 @@ class Engine:
                     ops.append(B.Op(B.OP_KICK, a, b, plus, coef))
                     self._plain_kick = True
                     return
+        # the same kick written as a bare product, `v + 0.5*1.0*dt*f/m` (UnconstrainedVelocityVerletPropagator, propagators.py:1136-1153):
+        # OpenMM's parser associates a*b*c*f/m as (((a*b)*c)*f)/m, i.e. (coef * f) / m with coef = the product of the factors in
+        # front of the force symbol -- what AMM_OP_KICK computes -- provided the force is the LAST factor
+        if target == 'v' and text.startswith('v+') and text.endswith('/m'):
+            factors = self._split_product(text[2:-2])
+            if factors and len(factors) >= 2 and self._is_global_product(factors[:-1], env):
+                terms = self._signed_terms(factors[-1])
+                if terms and len(terms) <= 2 and terms[0][0] == 1 and all(self._is_force_symbol(t[1]) for t in terms):
+                    coef = self._eval('*'.join(factors[:-1]), env)
+                    a = self._force_ref(terms[0][1], ops, valid)
+                    b, plus = -1, 0
+                    if len(terms) == 2:
+                        b = self._force_ref(terms[1][1], ops, valid)
+                        plus = 1 if terms[1][0] == 1 else 0
+                    ops.append(B.Op(B.OP_KICK, a, b, plus, coef))
+                    self._plain_kick = True
+                    return
         # move: x <- x + (coef)*v
         if target == 'x' and text.startswith('x+') and text.endswith('*v'):
             parts = self._split_leading_group(text[2:])
-            if parts and parts[1] == 'v':
-                ops.append(B.Op(B.OP_MOVE, 0, 0, 0, self._eval(parts[0], env)))
+            factors = None if parts else self._split_product(text[2:])
+            coef_text = parts[0] if parts and parts[1] == 'v' else None
+            if coef_text is None and factors and len(factors) >= 2 and factors[-1] == 'v' and self._is_global_product(factors[:-1], env):
+                coef_text = '*'.join(factors[:-1])          # `x + 1.0*dt*v`: ((1.0*dt)*v), the move's arithmetic
+            if coef_text is not None:
+                ops.append(B.Op(B.OP_MOVE, 0, 0, 0, self._eval(coef_text, env)))
                 for g in valid:
                     valid[g] = False
                 self._deriv_cache.clear()
@@ -1647,6 +1668,41 @@ class Engine:
                 self._deriv_cache.clear()
             return
         raise NotImplementedError('per-DOF computation outside the RESPA hot path: {} <- {}'.format(target, expr))
+
+    @staticmethod
+    def _split_product(text):
+        """'0.5*1.0*dt*(f1-f2)' -> ['0.5', '1.0', 'dt', '(f1-f2)']; None when the text is not a plain product at its top level."""
+        parts, depth, start = [], 0, 0
+        for k, ch in enumerate(text):
+            if ch == '(':
+                depth += 1
+            elif ch == ')':
+                depth -= 1
+                if depth < 0:
+                    return None
+            elif depth == 0:
+                if ch == '*':
+                    parts.append(text[start:k])
+                    start = k + 1
+                elif ch in '+-/^;' and k > 0 and text[k - 1] not in 'eE':      # (a sign inside 1e-3 is part of the number)
+                    return None
+        parts.append(text[start:])
+        return parts if depth == 0 and all(parts) else None
+
+    def _is_force_symbol(self, name):
+        return bool(re.fullmatch(r'f[0-9]*', name)) or name in self.integrator._pnames
+
+    def _is_global_product(self, factors, env):
+        """Every factor a number or a global / Context parameter known now (no per-DOF symbol, no function call)."""
+        per_dof = set(self.integrator._pnames) | {'x', 'v', 'm', 'f'}
+        for f in factors:
+            if re.fullmatch(r'[0-9.]+([eE][+-]?[0-9]+)?', f):
+                continue
+            if re.fullmatch(r'[A-Za-z_][A-Za-z_0-9]*', f) and f not in per_dof and not re.fullmatch(r'f[0-9]+', f) \
+                    and f in env and not callable(env[f]):
+                continue
+            return False
+        return True
 
     @staticmethod
     def _signed_terms(text):
