@@ -308,6 +308,7 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
         if (rc) return 1;
         PairForce *child = ctx->forces[child_id].pair;
         child->hybrid_rest = true;
+        child->profile_id = pf->id;
         std::vector<float> code(n, 1.0f);
         for (int i : rest_atoms) code[i] = 2.0f;
         if (upload(&child->d_member, code.data(), code.size())) return 1;
@@ -1517,8 +1518,19 @@ int amm_profile_read(amm_ctx *ctx, int32_t force_id, int64_t *n_launches, double
         tot += ms;
     }
     if (n_launches) *n_launches = (int64_t)(pf->ev_used / 2);
-    if (total_ms) *total_ms = tot;
     pf->ev_used = 0;
+    // hybrid lists: an evaluation is two launches -- the molecule rows (timed above) and the per-atom part kept by the hidden child,
+    // whose time belongs to the same evaluations (the launch count stays the parent's)
+    if (pf->rest) {
+        PairForce *rc = pf->rest;
+        for (size_t k = 0; k + 1 < rc->ev_used; k += 2) {
+            float ms = 0.f;
+            AMM_HIP(hipEventElapsedTime(&ms, rc->ev[k], rc->ev[k + 1]));
+            tot += ms;
+        }
+        rc->ev_used = 0;
+    }
+    if (total_ms) *total_ms = tot;
     return 0;
 }
 

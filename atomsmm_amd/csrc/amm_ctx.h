@@ -71,6 +71,7 @@ struct PairForce {
     std::vector<int> h_excl_ptr, h_excl_idx;    // host copy of the exclusion CSR (interaction-group forces)
     PairForce *rest = nullptr;     // the child (registered in ctx->forces behind its parent, in no group)
     bool hybrid_rest = false;      // this force IS such a child: its list keeps the pairs with at least one rest atom (code 2)
+    int profile_id = -1;           // a child is timed when its parent is (amm_profile_enable with a force id): the parent's id
     std::vector<int> h_mol_first;  // first atom of every molecule; empty: molecule m = atoms 3 m .. 3 m + 2 (no rest atoms)
     int n_mol = 0, n_rest = 0;
     int *d_mol_first = nullptr, *d_rest_idx = nullptr;

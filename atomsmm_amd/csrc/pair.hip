@@ -1817,7 +1817,7 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         A.epart = pf->d_epart;
         const bool guard = (pf->desc.flags & AMM_GUARD_RC0) != 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = ctx->profile && (ctx->profile_only < 0 || ctx->profile_only == pf->id);
+        const bool timed = ctx->profile && (ctx->profile_only < 0 || ctx->profile_only == pf->id || ctx->profile_only == pf->profile_id);
         if (timed) {
             if (pf->ev_used + 2 > pf->ev.size()) {
                 for (int k = 0; k < 64; ++k) {

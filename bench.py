@@ -601,7 +601,10 @@ def main():
                        'near_lanes_per_atom': near_stats['lanes_per_atom'], 'near_rlist_nm': near_stats['rlist'],
                        'near_list_pairs': near_stats['n_list_pairs'], 'far_list_pairs': st1[far_id]['n_list_pairs'],
                        'pairs_within_0.7nm_counted': int(pairs_near), 'pairs_within_1.0nm_counted': int(pairs_far),
-                       'kernel_revision': backend.kernel_revision(), 'rows': 'one per molecule' if near_stats.get('list_kind') else 'one per atom',
+                       'kernel_revision': backend.kernel_revision(), 'rows': {0: 'one per atom', 1: 'one per molecule',
+                                2: 'hybrid: one per three-site molecule for the pairs of two molecules + per-atom rows for every pair with one of the '
+                                   '%d other atoms (kernel times: both launches of an evaluation)' % near_stats.get('n_rest_atoms', 0),
+                                3: 'none'}.get(near_stats.get('list_kind'), '?'),
                        'row_padding': padding or None, 'pme_outer': pme_outer},
         }
         if world == 1 and not args.no_cpu_baseline and args.outer == 'damped':
