@@ -1469,6 +1469,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     if (k == "cluster") ctx->opt_cluster = v;
     else if (k == "hybrid") ctx->opt_hybrid = v;
     else if (k == "small_group") ctx->opt_small_group = v;
+    else if (k == "mixed_terms") ctx->opt_mixed_terms = v;
     else if (k == "tab") ctx->opt_tab = v;
     else if (k == "site_trips") ctx->site_trips = v != 0;
     else if (k == "lanes_per_row") ctx->opt_lpa = v;

@@ -184,6 +184,18 @@ struct BondedSet {
     double4 *d_gt_q = nullptr;     // [n_gterms] parameters + kind/periodic code
     int *d_rec_src = nullptr;      // [nref] term * 4 + role of each (atom, term) record
     double *d_tf = nullptr;        // [n_gterms][4][3]
+    // mixed sets (waters + a chain: config C5) on the fused EVAL + kicks path: the SMALL components (<= 4 atoms, <= 4 terms: a water)
+    // are evaluated four lanes per component from registers / LDS (no parked forces, no gather); only the atoms and terms of the big
+    // components go through the term-parallel arrays above
+    bool mixed_ok = false;
+    int n_sc = 0;                                   // small components
+    int4 *d_sc_atoms = nullptr;                     // [n_sc] their atoms (-1 padded)
+    int4 *d_sc_term_l = nullptr;                    // [n_sc*4] atoms of the component's terms as slots 0..3 (x < 0: no term)
+    double4 *d_sc_term_q = nullptr;                 // [n_sc*4]
+    unsigned long long *d_sc_recs = nullptr;        // [n_sc*4] per (component, atom slot): the atom's records, as d_atom_recs
+    int n_big = 0, n_bigterms = 0;
+    int *d_big_atoms = nullptr;                     // atoms of the other components
+    int *d_big_terms = nullptr;                     // global indices of their terms (into d_gt_a / d_gt_q / d_tf)
     double *d_epart = nullptr;
     int n_epart = 0;
 };
@@ -264,6 +276,7 @@ struct amm_ctx {
     // order of summation of a production run
     int opt_cluster = 1;           // molecule rows for qualifying forces (0: per-atom rows everywhere)
     int opt_hybrid = 1;            // ... also when the three-site molecules share the box with other atoms (hybrid lists)
+    int opt_mixed_terms = 1;       // mixed bond-list sets: small components four lanes each on the fused EVAL + kicks path (bonded.hip)
     int opt_small_group = 1;       // interaction-group forces with a small set (a solute) without a neighbour list (group.hip)
     bool creating_rest = false;    // amm_pair_create is making the hidden child of a hybrid list
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)

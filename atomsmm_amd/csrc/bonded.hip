@@ -9,6 +9,7 @@
 // lock-step).  In RESPA this kernel runs n0*n1*n2 times per outer step: it is latency-, not flop-bound.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <cstring>
 
 #include "amm_ctx.h"
@@ -63,9 +64,11 @@ __global__ void __launch_bounds__(256) k_bonded(BondedArgs A) {
 // kind by kind, so these wavefronts are uniform) and parks the forces of the term's roles; one thread per atom then adds up
 // its records from there in record order: the same numbers in the same order as k_bonded, bit for bit.
 __global__ void __launch_bounds__(256) k_terms_eval(BondedArgs A, int nterms, const int4 *__restrict__ gt_a,
-                                                    const double4 *__restrict__ gt_q, double *__restrict__ tf) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nterms) return;
+                                                    const double4 *__restrict__ gt_q, double *__restrict__ tf,
+                                                    const int *__restrict__ list = nullptr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nterms) return;
+    const int t = list ? list[k] : k;          // (mixed sets: only the terms of the big components)
     const int4 at = gt_a[t];
     const double4 q = gt_q[t];
     const long long code = __double_as_longlong(q.w);
@@ -172,6 +175,149 @@ __global__ void __launch_bounds__(256) k_terms_gather_kicks(BondedArgs A, const 
     }
 }
 
+// EVAL + kicks + move of a MIXED bond-list set (BondedSet::mixed_ok: waters next to a chain).  Blocks [0, sc_blocks): four lanes per
+// small component -- lane l holds atom l, the positions are exchanged through a wavefront-private LDS strip, lane l evaluates the
+// component's term l once (all roles) and parks its forces in LDS, every atom adds up its records from there in record order
+// (k_inner_lanes' TERMS scheme: the numbers and the order of the term-parallel gather, bit for bit) -- no parked forces in HBM, no
+// three-level gather for 98 % of the atoms.  Blocks beyond: one thread per atom of the big components, from the parked forces of
+// k_terms_eval (k_terms_gather_kicks' loop).  Then, for both: add the pair force already in the row, store the row, kicks, move.
+struct MixedArgs {
+    int n_sc, sc_blocks, n_big;
+    const int4 *sc_atoms, *sc_term_l;
+    const double4 *sc_term_q;
+    const unsigned long long *sc_recs;
+    const int *big_atoms;
+};
+
+__global__ void __launch_bounds__(256) k_mixed_eval_kicks(BondedArgs A, MixedArgs M, const int *__restrict__ rec_src,
+                                                          const double *__restrict__ tf, KickList K, double *__restrict__ x,
+                                                          double *__restrict__ v, const double *__restrict__ mass, int with_move, double dcoef) {
+#pragma clang fp contract(off)
+    __shared__ double s_x[3][256];
+    __shared__ double s_out[12][256];
+    int a = -1;
+    double f[3] = {0.0, 0.0, 0.0};
+    const bool small_part = (int)blockIdx.x < M.sc_blocks;
+    if (small_part) {
+        const int tid = blockIdx.x * 256 + threadIdx.x;
+        if ((tid >> 2) < M.n_sc) a = (&M.sc_atoms[tid >> 2].x)[tid & 3];
+    } else {
+        const int k = ((int)blockIdx.x - M.sc_blocks) * 256 + threadIdx.x;
+        if (k < M.n_big) a = M.big_atoms[k];
+    }
+    // everything the tail needs is fetched NOW, behind the term arithmetic: the row the pair force left, mass, velocity, the other
+    // buffers the kicks read (left where they were used, the loads sat behind the LDS exchanges: a fourth dependent round trip)
+    const int ah = a >= 0 ? a : 0;
+    double f_row[3] = {0.0, 0.0, 0.0}, v_in[3], kf[4][3], kf2[4][3];
+    const double m = mass[ah];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (A.accumulate) f_row[c] = A.force[3 * ah + c];
+        v_in[c] = v[3 * ah + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            kf[k][c] = (k < K.n && K.f[k] != A.force) ? K.f[k][3 * ah + c] : 0.0;
+            kf2[k][c] = (k < K.n && K.f2[k] && K.f2[k] != A.force) ? K.f2[k][3 * ah + c] : 0.0;
+        }
+    }
+    if (small_part) {
+        const int tid = blockIdx.x * 256 + threadIdx.x;
+        const int c = tid >> 2, l = tid & 3;
+        const bool cvalid = c < M.n_sc;
+        const int al = ah;
+        s_x[0][threadIdx.x] = A.pos[3 * al];
+        s_x[1][threadIdx.x] = A.pos[3 * al + 1];
+        s_x[2][threadIdx.x] = A.pos[3 * al + 2];
+        int4 my_tl = make_int4(-1, -1, -1, -1);
+        double4 my_tq = make_double4(0.0, 0.0, 0.0, 0.0);
+        unsigned long long my_recs = 0ull;
+        if (cvalid) {
+            my_tl = M.sc_term_l[tid];
+            my_tq = M.sc_term_q[tid];
+            my_recs = M.sc_recs[tid];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int gbase = (int)threadIdx.x - l;
+        PosLds pos{&s_x[0][gbase], &s_x[1][gbase], &s_x[2][gbase]};
+        double fo[4][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        if (my_tl.x >= 0) {
+            const long long code = __double_as_longlong(my_tq.w);
+            const int ix[4] = {my_tl.x, my_tl.y, my_tl.z, my_tl.w};
+            const double p[3] = {my_tq.x, my_tq.y, my_tq.z};
+            double e;
+            bonded_term_forces(A, pos, ix, p, (int)(code & 7), (int)((code >> 5) & 1), fo, e);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int xx = 0; xx < 3; ++xx) s_out[r * 3 + xx][threadIdx.x] = fo[r][xx];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int rec_n = (int)(my_recs >> 60);
+        unsigned long long rr = my_recs;
+        for (int t = 0; t < rec_n; ++t) {
+            const int rcode = (int)(rr & 31ull);
+            rr >>= 5;
+            const int src = gbase + (rcode & 7), row = 3 * (rcode >> 3);
+            f[0] += s_out[row][src];
+            f[1] += s_out[row + 1][src];
+            f[2] += s_out[row + 2][src];
+        }
+    } else {
+        if (a >= 0) {
+            const int rb = A.ref_ptr[a], re = A.ref_ptr[a + 1];
+            for (int r0 = rb; r0 < re; r0 += 4) {
+                int src[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) src[u] = r0 + u < re ? rec_src[r0 + u] : -1;
+                double g[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) g[u][c] = src[u] >= 0 ? tf[(size_t)src[u] * 3 + c] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (src[u] >= 0) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) f[c] += g[u][c];
+                    }
+            }
+        }
+    }
+    if (a < 0) return;
+    if (A.accumulate) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[c] = f_row[c] + f[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int t = 3 * a + c;
+        A.force[t] = f[c];
+        double vt = v_in[c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < K.n) {
+                double ff = K.f[k] == A.force ? f[c] : kf[k][c];
+                if (K.f2[k]) {
+                    const double g2 = K.f2[k] == A.force ? f[c] : kf2[k][c];
+                    ff = K.plus[k] ? ff + g2 : ff - g2;
+                }
+                const double num = K.coef[k] * ff;
+                const double dv = num / m;
+                vt = vt + dv;
+            }
+        }
+        v[t] = vt;
+        if (with_move) {
+            const double dx = dcoef * vt;
+            x[t] = x[t] + dx;
+        }
+    }
+}
+
 // Fused inner RESPA iteration (propagators.py:940-973, innermost level):
 //     v <- v + c1*f0/m ;  x <- x + d*v ;  f0 <- bonded(x) ;  v <- v + c2*f0/m
 // in ONE launch.  Each thread advances its own atom and, redundantly, the few atoms it shares bond-list terms
@@ -259,10 +405,7 @@ struct CompArgs {
 // k_bonded does (owner-computes, same order, same bonded_term_forces) -- hence bit-identical -- reading the partner
 // atoms from the strip.  (A first version ran one THREAD per component with everything in registers: 0.5 wavefronts
 // per SIMD at C3 and select chains over register slots, 50 us per 4 iterations; this one: 2 wavefronts per SIMD, 40 us.)
-struct PosLds {
-    const double *sx, *sy, *sz;     // strip of this lane's group, indexed by component slot
-    __device__ __forceinline__ double get(int slot, int k) const { return k == 0 ? sx[slot] : (k == 1 ? sy[slot] : sz[slot]); }
-};
+// (PosLds: bonded_terms.h)
 
 // TERMS: when no component has more terms than lanes, lane l evaluates the component's term l ONCE per iteration (all
 // roles), parks the forces in LDS, and every atom adds up ITS records from there in the same order as before -- the
@@ -668,6 +811,80 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
         AMM_HIP(hipMemcpy(bs->d_rec_src, rec_src.data(), sizeof(int) * nref, hipMemcpyHostToDevice));
         bs->n_gterms = gterm;
     }
+    // mixed sets: small components next to big ones (see BondedSet::mixed_ok)
+    bs->mixed_ok = false;
+    if (bs->n_gterms > 0 && !bs->terms_ok) {
+        std::vector<int> nterm(ncomp, 0), nrec_of(n, 0);
+        std::vector<char> small(ncomp, 0);
+        for (int c2 = 0; c2 < ncomp; ++c2) small[c2] = csize[c2] <= 4;
+        for (int kind = 0; kind < 8; ++kind)
+            for (int t = 0; t < bs->n_terms[kind]; ++t) {
+                const int *at = &bs->h_idx[kind][(size_t)t * kArity[kind]];
+                if (++nterm[comp_of[at[0]]] > 4) small[comp_of[at[0]]] = 0;
+                for (int r = 0; r < kArity[kind]; ++r)
+                    if (++nrec_of[at[r]] > 12) small[comp_of[at[r]]] = 0;
+            }
+        std::vector<int> sc_of(ncomp, -1);
+        int nsc = 0;
+        long small_atoms = 0;
+        for (int c2 = 0; c2 < ncomp; ++c2)
+            if (small[c2]) {
+                sc_of[c2] = nsc++;
+                small_atoms += csize[c2];
+            }
+        if (nsc > 0 && 2 * small_atoms >= n) {           // worth it when most atoms sit in small components
+            std::vector<int4> sc_atoms(nsc, make_int4(-1, -1, -1, -1)), term_l((size_t)nsc * 4, make_int4(-1, -1, -1, -1));
+            std::vector<double4> term_q((size_t)nsc * 4, make_double4(0.0, 0.0, 0.0, 0.0));
+            std::vector<unsigned long long> recs((size_t)nsc * 4, 0ull);
+            std::vector<int> big_atoms, big_terms, filled(nsc, 0), nr(n, 0);
+            for (int i = 0; i < n; ++i) {
+                const int k = sc_of[comp_of[i]];
+                if (k < 0) big_atoms.push_back(i);
+                else (&sc_atoms[k].x)[local_of[i]] = i;
+            }
+            int g = 0;
+            for (int kind = 0; kind < 8; ++kind)
+                for (int t = 0; t < bs->n_terms[kind]; ++t, ++g) {
+                    const int *at = &bs->h_idx[kind][(size_t)t * kArity[kind]];
+                    const int k = sc_of[comp_of[at[0]]];
+                    if (k < 0) {
+                        big_terms.push_back(g);
+                        continue;
+                    }
+                    const int tl = filled[k]++;                 // terms numbered within the component in (kind, term) order: the record order
+                    int lo[4] = {-1, -1, -1, -1};
+                    for (int q = 0; q < kArity[kind]; ++q) lo[q] = local_of[at[q]];
+                    term_l[(size_t)k * 4 + tl] = make_int4(lo[0], lo[1], lo[2], lo[3]);
+                    double pr[3] = {0.0, 0.0, 0.0};
+                    for (int q = 0; q < kNpar[kind]; ++q) pr[q] = bs->h_par[kind][(size_t)t * kNpar[kind] + q];
+                    const long long code = (long long)kind | ((long long)(bs->periodic[kind] ? 1 : 0) << 5);
+                    double w;
+                    std::memcpy(&w, &code, sizeof(w));
+                    term_q[(size_t)k * 4 + tl] = make_double4(pr[0], pr[1], pr[2], w);
+                    for (int r = 0; r < kArity[kind]; ++r) {
+                        const int a = at[r];
+                        recs[(size_t)k * 4 + local_of[a]] |= (unsigned long long)(tl | (r << 3)) << (5 * nr[a]);
+                        nr[a]++;
+                    }
+                }
+            for (int i = 0; i < n; ++i) {
+                const int k = sc_of[comp_of[i]];
+                if (k >= 0) recs[(size_t)k * 4 + local_of[i]] |= (unsigned long long)nr[i] << 60;
+            }
+            auto up = [&](auto **dst, const auto &v) -> int {
+                using T = typename std::remove_reference<decltype(v[0])>::type;
+                AMM_HIP(hipMalloc(dst, sizeof(T) * std::max<size_t>(v.size(), 1)));
+                if (!v.empty()) AMM_HIP(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+                return 0;
+            };
+            if (up(&bs->d_sc_atoms, sc_atoms) || up(&bs->d_sc_term_l, term_l) || up(&bs->d_sc_term_q, term_q) || up(&bs->d_sc_recs, recs) ||
+                up(&bs->d_big_atoms, big_atoms) || up(&bs->d_big_terms, big_terms)) return 1;
+            bs->n_sc = nsc;
+            bs->n_big = (int)big_atoms.size();
+            bs->n_bigterms = (int)big_terms.size();
+            bs->mixed_ok = true;
+        }
+    }
     AMM_HIP(hipMalloc(&bs->d_ref_ptr, sizeof(int) * (n + 1)));
     AMM_HIP(hipMemcpy(bs->d_ref_ptr, cnt.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
     AMM_HIP(hipMalloc(&bs->d_rec_a, sizeof(int4) * std::max<size_t>(nref, 1)));
@@ -756,9 +973,11 @@ static int terms_args(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *
 }
 
 int amm_bonded_terms_work(amm_ctx *ctx, BondedSet *bs, const double *d_pos, BondedArgs *A, int *nterms, const int4 **gt_a,
-                          const double4 **gt_q, double **tf) {
+                          const double4 **gt_q, double **tf, const int **list) {
     if (terms_args(ctx, bs, d_pos, nullptr, 0, *A)) return 1;
-    *nterms = bs->n_gterms;
+    // (mixed sets: the small components are evaluated by the gather launch itself; only the big components' terms are parked)
+    *nterms = (bs->mixed_ok && ctx->opt_mixed_terms) ? bs->n_bigterms : bs->n_gterms;
+    *list = (bs->mixed_ok && ctx->opt_mixed_terms) ? bs->d_big_terms : nullptr;
     *gt_a = bs->d_gt_a;
     *gt_q = bs->d_gt_q;
     *tf = bs->d_tf;
@@ -770,6 +989,24 @@ int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos,
     BondedArgs A;
     if (terms_args(ctx, bs, d_pos, d_force, accumulate, A)) return 1;
     const int n = ctx->n;
+    if (bs->mixed_ok && ctx->opt_mixed_terms) {
+        if (!terms_done && bs->n_bigterms > 0)
+            hipLaunchKernelGGL(k_terms_eval, dim3((bs->n_bigterms + 255) / 256), dim3(256), 0, ctx->stream, A, bs->n_bigterms, bs->d_gt_a,
+                               bs->d_gt_q, bs->d_tf, bs->d_big_terms);
+        MixedArgs M;
+        M.n_sc = bs->n_sc;
+        M.sc_blocks = (4 * bs->n_sc + 255) / 256;
+        M.n_big = bs->n_big;
+        M.sc_atoms = bs->d_sc_atoms;
+        M.sc_term_l = bs->d_sc_term_l;
+        M.sc_term_q = bs->d_sc_term_q;
+        M.sc_recs = bs->d_sc_recs;
+        M.big_atoms = bs->d_big_atoms;
+        hipLaunchKernelGGL(k_mixed_eval_kicks, dim3(M.sc_blocks + (bs->n_big + 255) / 256), dim3(256), 0, ctx->stream, A, M, bs->d_rec_src,
+                           bs->d_tf, K, ctx->d_x, ctx->d_v, ctx->d_mass, with_move, dcoef);
+        AMM_HIP(hipGetLastError());
+        return 0;
+    }
     if (!terms_done)
         hipLaunchKernelGGL(k_terms_eval, dim3((bs->n_gterms + 255) / 256), dim3(256), 0, ctx->stream, A, bs->n_gterms, bs->d_gt_a, bs->d_gt_q,
                            bs->d_tf);
@@ -936,6 +1173,9 @@ int amm_bonded_free(BondedSet *bs) {
     if (bs->d_term_l) (void)hipFree(bs->d_term_l);
     if (bs->d_term_q) (void)hipFree(bs->d_term_q);
     if (bs->d_atom_recs) (void)hipFree(bs->d_atom_recs);
+    for (void *ptr : {(void *)bs->d_sc_atoms, (void *)bs->d_sc_term_l, (void *)bs->d_sc_term_q, (void *)bs->d_sc_recs, (void *)bs->d_big_atoms,
+                      (void *)bs->d_big_terms})
+        if (ptr) (void)hipFree(ptr);
     if (bs->d_comp_ptr) (void)hipFree(bs->d_comp_ptr);
     if (bs->d_comp_atoms) (void)hipFree(bs->d_comp_atoms);
     if (bs->d_epart) (void)hipFree(bs->d_epart);

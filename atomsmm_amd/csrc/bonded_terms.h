@@ -46,6 +46,12 @@ struct PosAdvanced {
     }
 };
 
+// positions of a component's atoms in a wavefront-private LDS strip, indexed by the atom's slot in its component
+struct PosLds {
+    const double *sx, *sy, *sz;     // strip of this lane's group
+    __device__ __forceinline__ double get(int slot, int k) const { return k == 0 ? sx[slot] : (k == 1 ? sy[slot] : sz[slot]); }
+};
+
 template <class P>
 __device__ __forceinline__ void delta3(const P &pos, int a, int b, const Box &box, int periodic, double *d) {
 #pragma unroll
@@ -194,4 +200,4 @@ __device__ __forceinline__ void bonded_term_forces(const BondedArgs &A, const P 
 // the argument block and arrays of a term-parallel evaluation of `bs` at d_pos (bonded.hip), for a launch of another file that
 // carries it (group.hip)
 int amm_bonded_terms_work(amm_ctx *ctx, BondedSet *bs, const double *d_pos, BondedArgs *A, int *nterms, const int4 **gt_a,
-                          const double4 **gt_q, double **tf);
+                          const double4 **gt_q, double **tf, const int **list);

@@ -60,6 +60,7 @@ struct SmallArgs {
 // work of bonded.hip's k_terms_eval (same function, same parked forces), without a launch of its own.  nterms == 0: none.
 struct TermsWork {
     int nterms;
+    const int *list;          // the terms to evaluate (indices into gt_a / gt_q / tf); nullptr: all of 0 .. nterms - 1
     const int4 *gt_a;
     const double4 *gt_q;
     double *tf;
@@ -81,7 +82,8 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
     }
     __syncthreads();
     // (the bond-list terms first: independent of everything below, and their loads overlap the staging above)
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < T.nterms; t += gridDim.x * 256) {
+    for (int kt = blockIdx.x * 256 + threadIdx.x; kt < T.nterms; kt += gridDim.x * 256) {
+        const int t = T.list ? T.list[kt] : kt;
         const int4 at = T.gt_a[t];
         const double4 q = T.gt_q[t];
         const long long code = __double_as_longlong(q.w);
@@ -352,11 +354,12 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     }
     TermsWork T;
     T.nterms = 0;
+    T.list = nullptr;
     T.gt_a = nullptr;
     T.gt_q = nullptr;
     T.tf = nullptr;
     if (carry_terms) {
-        if (amm_bonded_terms_work(ctx, carry_terms, d_pos, &T.A, &T.nterms, &T.gt_a, &T.gt_q, &T.tf)) return 1;
+        if (amm_bonded_terms_work(ctx, carry_terms, d_pos, &T.A, &T.nterms, &T.gt_a, &T.gt_q, &T.tf, &T.list)) return 1;
     } else {
         std::memset(&T.A, 0, sizeof(T.A));
     }
