@@ -150,21 +150,23 @@ int amm_check(amm_ctx *ctx) {
             }
         }
         if (!pf || !pf->built) continue;
+        // (a hidden child is reported under its parent's id: the caller never saw the child's)
+        const std::string who = pf->hybrid_rest ? std::to_string(pf->profile_id) + " (per-atom part of its hybrid list)" : std::to_string(id);
         int flags[16];
         AMM_HIP(hipMemcpy(flags, pf->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
         if (pf->d_active && flags[8] > pf->active_cap) {
-            amm_set_error("interaction-group list of pair force " + std::to_string(id) + ": " + std::to_string(flags[8]) +
+            amm_set_error("interaction-group list of pair force " + who + ": " + std::to_string(flags[8]) +
                           " rows hold entries > the " + std::to_string(pf->active_cap) +
                           " the traversal covers (more than twice the first build's); forces since the last rebuild are incomplete");
             return 2;
         }
         if (flags[7]) {
-            amm_set_error("cell list overflow in pair force " + std::to_string(id) + ": a cell holds " + std::to_string(flags[6]) +
+            amm_set_error("cell list overflow in pair force " + who + ": a cell holds " + std::to_string(flags[6]) +
                           " atoms > capacity " + std::to_string(pf->capc) + " (local density more than doubled since the first build)");
             return 2;
         }
         if (flags[1]) {
-            amm_set_error("neighbour list overflow in pair force " + std::to_string(id) + ": " + std::to_string(flags[2]) +
+            amm_set_error("neighbour list overflow in pair force " + who + ": " + std::to_string(flags[2]) +
                           " neighbours > capacity " + std::to_string(pf->cap) +
                           "; forces since the last rebuild are incomplete");
             return 2;
