@@ -281,14 +281,12 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
     __shared__ float s_rshift[4][3][128];
     __shared__ int s_q[4][CB_BATCH][CB_QCAP];        // per row molecule: ring of survivors of the sphere test (sorted slots)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int c = wave / parts, part = wave - c * parts;
     const float FAR = 1.0e9f;
     const float rlist2 = rlist * rlist;
     unsigned long long wsum = 0, wnear = 0;
     int wmax = 0;
-    // (cell, part) work items with a grid stride (the grid is capped at 4096 blocks: no change at 98 304 atoms, where it is 2 744)
-    const int nwork = g.ncell * parts, wstride = (int)(gridDim.x * (blockDim.x >> 6));
-    for (int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)); wave < nwork; wave += wstride) {
-    const int c = wave / parts, part = wave - c * parts;
     int a_begin = 0, a_end = 0;
     if (c < g.ncell) {
         const int cb0 = __builtin_amdgcn_readfirstlane(cell_start[c]), cb1 = __builtin_amdgcn_readfirstlane(cell_start[c + 1]);
@@ -508,7 +506,6 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
             }
         }
     }
-    }      // work items of this wavefront
     for (int off = 32; off > 0; off >>= 1) {
         wsum += __shfl_xor(wsum, off);
         wnear += __shfl_xor(wnear, off);
@@ -996,7 +993,7 @@ static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const doub
                        gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr, gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr,
                        gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2, cl->d_first);
     const long threads = (long)cl->grid.ncell * cl->parts * 64;
-    dim3 grid((unsigned)std::min<long>((threads + 255) / 256, 4096));       // (grid stride in the kernel)
+    dim3 grid((unsigned)((threads + 255) / 256));
     CBoxF bf;
     for (int k = 0; k < 3; ++k) {
         bf.L[k] = (float)ctx->box.L[k];

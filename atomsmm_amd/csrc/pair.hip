@@ -365,16 +365,12 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
     __shared__ int s_rpref[4][128];
     __shared__ float s_rshift[4][3][128];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int c = wave / parts, part = wave - c * parts;
     const unsigned long long below = (1ull << lane) - 1ull;
     const float FAR = 1.0e9f;
     unsigned long long wsum = 0, wnear = 0;
     int wmax = 0;
-    // (cell, part) work items are dealt with a grid stride: the grid is capped at 4096 blocks (cell_build_chain), so that the cost of
-    // a launch that finds nothing to rebuild does not grow with the box (measured 4.6 us at 249 075 atoms, capped or not: the cap is
-    // for the boxes beyond)
-    const int nwork = g.ncell * parts, wstride = (int)(gridDim.x * (blockDim.x >> 6));
-    for (int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)); wave < nwork; wave += wstride) {
-    const int c = wave / parts, part = wave - c * parts;
     int a_begin = 0, a_end = 0;
     if (c < g.ncell) {
         // this wave's share of the cell's atoms (even split over the parts), clipped to the rank's slice
@@ -625,7 +621,6 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
             }
         }
     }
-    }      // work items of this wavefront
     // per-block (sum, max) of the list lengths -> blockstats; the last block reduces them.  (One same-address
     // atomic per atom serialises at L2: ~0.5 ms for 98k atoms -- measured -- so no atomics here.)
     for (int off = 32; off > 0; off >>= 1) {
@@ -1447,8 +1442,8 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
                        gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr, gf ? gf->d_lj_s : (double2 *)nullptr,
                        pf->d_cls, pf->d_cell_start_lj, pf->d_row_order, pf->s_begin, pf->s_end, pf->d_flags + 3, pf->d_member,
                        pf->d_cell_sets, pf->hybrid_rest ? 2 : 1);
-    const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part), grid stride beyond 4096 blocks
-    dim3 grid((unsigned)std::min<long>((threads + 255) / 256, 4096));
+    const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
+    dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
     for (int k = 0; k < 3; ++k) {
         bf.L[k] = (float)ctx->box.L[k];
