@@ -1052,10 +1052,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                                                           bathed ? &ctx->baths[ops[start + 2].a] : nullptr,
                                                           bathed ? ops[start + 3].coef : 0.0)) return 1;
                             ctx->pos_epoch++;
-                            for (int w = 0; w < ctx->n_watched; ++w) {
-                                *ctx->watched[w].pre_epoch = ctx->pos_epoch;
-                                *ctx->watched[w].pre_pos = ctx->d_x;
-                            }
+                            amm_watch_moved(ctx);
                             k = q - 1;
                             continue;
                         }
@@ -1176,7 +1173,10 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                         // (the pair force's launch evaluates the bond-list terms too: group.hip, TermsWork)
                         if (ps && amm_small_group_eval_impl(ctx, ps, ctx->d_x, buf, 0, nullptr, bs) != 0) return 1;
                         if (amm_bonded_eval_kicks_impl(ctx, bs, ctx->d_x, buf, ps ? 1 : 0, K, moves ? 1 : 0, moves ? ops[j].coef : 0.0, ps ? 1 : 0)) return 1;
-                        if (moves) ctx->pos_epoch++;
+                        if (moves) {
+                            ctx->pos_epoch++;
+                            amm_watch_moved(ctx);
+                        }
                         k = j - (moves ? 0 : 1);
                         continue;
                     }
@@ -1203,7 +1203,10 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 const bool moves = j < n_ops && ops[j].op == AMM_OP_MOVE;
                 if (nk == j - k && (nk >= 2 || (nk == 1 && moves))) {
                     if (amm_kicks_move_impl(ctx, fa, fb, plus, coef, nk, moves ? 1 : 0, moves ? ops[j].coef : 0.0)) return 1;
-                    if (moves) ctx->pos_epoch++;
+                    if (moves) {
+                        ctx->pos_epoch++;
+                        amm_watch_moved(ctx);
+                    }
                     k = j - (moves ? 0 : 1);
                     continue;
                 }

@@ -330,6 +330,18 @@ struct KickList {
     int n;
 };
 
+// the neighbour lists whose displacement trigger a kernel that MOVES the atoms evaluates for the positions it writes (their own
+// check launch is then skipped: amm_watch_moved).  Passed to kernels by value.
+struct WatchArgs {
+    int n;
+    const double *xref[AMM_MAX_WATCH];
+    double thr2[AMM_MAX_WATCH];
+    int *flags[AMM_MAX_WATCH];
+};
+// collect them from the context's pair forces (also recorded in ctx->watched) / tell them the positions they watched are current
+void amm_collect_watches(amm_ctx *ctx, WatchArgs &W);
+void amm_watch_moved(amm_ctx *ctx);
+
 // comm.hip
 int amm_comm_unique_id_impl(const char *rccl_path, unsigned char *out);
 int amm_comm_init_impl(amm_ctx *ctx, const char *rccl_path, const unsigned char *id_bytes, int rank, int world);
@@ -362,6 +374,8 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
 int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate, const KickList &K,
                                int with_move, double dcoef, int terms_done = 0);
 int amm_bonded_free(BondedSet *bs);
+// (with_move: the launch also evaluates the displacement triggers of the context's lists; the caller bumps pos_epoch and calls
+// amm_watch_moved)
 int amm_kicks_move_impl(amm_ctx *ctx, const double *const *fa, const double *const *fb, const int *plus, const double *coef, int nk,
                         int with_move, double dcoef);
 int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v, double *f0, int npre, const double *const *pre_a,

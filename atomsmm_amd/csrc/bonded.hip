@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_terms_gather(BondedArgs A, const int *_
 // read here (the terms' forces are parked in tf), so moving them is safe.
 __global__ void __launch_bounds__(256) k_terms_gather_kicks(BondedArgs A, const int *__restrict__ rec_src, const double *__restrict__ tf,
                                                             KickList K, double *__restrict__ x, double *__restrict__ v,
-                                                            const double *__restrict__ mass, int with_move, double dcoef) {
+                                                            const double *__restrict__ mass, int with_move, double dcoef, WatchArgs W) {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(256) k_terms_gather_kicks(BondedArgs A, const 
         for (int c = 0; c < 3; ++c) f[c] = A.force[3 * i + c] + f[c];
     }
     const double m = mass[i];
+    double xn[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int t = 3 * i + c;
@@ -170,9 +171,11 @@ __global__ void __launch_bounds__(256) k_terms_gather_kicks(BondedArgs A, const 
         v[t] = vt;
         if (with_move) {
             const double dx = dcoef * vt;
-            x[t] = x[t] + dx;
+            xn[c] = x[t] + dx;
+            x[t] = xn[c];
         }
     }
+    if (with_move) amm_watch_atom(W, i, xn);
 }
 
 // EVAL + kicks + move of a MIXED bond-list set (BondedSet::mixed_ok: waters next to a chain).  Blocks [0, sc_blocks): four lanes per
@@ -191,7 +194,8 @@ struct MixedArgs {
 
 __global__ void __launch_bounds__(256) k_mixed_eval_kicks(BondedArgs A, MixedArgs M, const int *__restrict__ rec_src,
                                                           const double *__restrict__ tf, KickList K, double *__restrict__ x,
-                                                          double *__restrict__ v, const double *__restrict__ mass, int with_move, double dcoef) {
+                                                          double *__restrict__ v, const double *__restrict__ mass, int with_move, double dcoef,
+                                                          WatchArgs W) {
 #pragma clang fp contract(off)
     __shared__ double s_x[3][256];
     __shared__ double s_out[12][256];
@@ -292,6 +296,7 @@ __global__ void __launch_bounds__(256) k_mixed_eval_kicks(BondedArgs A, MixedArg
 #pragma unroll
         for (int c = 0; c < 3; ++c) f[c] = f_row[c] + f[c];
     }
+    double xn[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int t = 3 * a + c;
@@ -313,9 +318,11 @@ __global__ void __launch_bounds__(256) k_mixed_eval_kicks(BondedArgs A, MixedArg
         v[t] = vt;
         if (with_move) {
             const double dx = dcoef * vt;
-            x[t] = x[t] + dx;
+            xn[c] = x[t] + dx;
+            x[t] = xn[c];
         }
     }
+    if (with_move) amm_watch_atom(W, a, xn);
 }
 
 // Fused inner RESPA iteration (propagators.py:940-973, innermost level):
@@ -989,6 +996,9 @@ int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos,
     BondedArgs A;
     if (terms_args(ctx, bs, d_pos, d_force, accumulate, A)) return 1;
     const int n = ctx->n;
+    WatchArgs W;
+    W.n = 0;
+    if (with_move) amm_collect_watches(ctx, W);       // (the caller bumps pos_epoch and calls amm_watch_moved)
     if (bs->mixed_ok && ctx->opt_mixed_terms) {
         if (!terms_done && bs->n_bigterms > 0)
             hipLaunchKernelGGL(k_terms_eval, dim3((bs->n_bigterms + 255) / 256), dim3(256), 0, ctx->stream, A, bs->n_bigterms, bs->d_gt_a,
@@ -1003,7 +1013,7 @@ int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos,
         M.sc_recs = bs->d_sc_recs;
         M.big_atoms = bs->d_big_atoms;
         hipLaunchKernelGGL(k_mixed_eval_kicks, dim3(M.sc_blocks + (bs->n_big + 255) / 256), dim3(256), 0, ctx->stream, A, M, bs->d_rec_src,
-                           bs->d_tf, K, ctx->d_x, ctx->d_v, ctx->d_mass, with_move, dcoef);
+                           bs->d_tf, K, ctx->d_x, ctx->d_v, ctx->d_mass, with_move, dcoef, W);
         AMM_HIP(hipGetLastError());
         return 0;
     }
@@ -1011,7 +1021,7 @@ int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos,
         hipLaunchKernelGGL(k_terms_eval, dim3((bs->n_gterms + 255) / 256), dim3(256), 0, ctx->stream, A, bs->n_gterms, bs->d_gt_a, bs->d_gt_q,
                            bs->d_tf);
     hipLaunchKernelGGL(k_terms_gather_kicks, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, bs->d_rec_src, bs->d_tf, K, ctx->d_x,
-                       ctx->d_v, ctx->d_mass, with_move, dcoef);
+                       ctx->d_v, ctx->d_mass, with_move, dcoef, W);
     AMM_HIP(hipGetLastError());
     return 0;
 }
@@ -1074,30 +1084,15 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
     C.v = v;
     C.f0 = f0;
     C.mass = ctx->d_mass;
-    C.nwatch = 0;
-    ctx->n_watched = 0;
     {
-        // lists whose rebuild trigger this launch evaluates: the molecule rows first (the hot path's), then single per-atom lists
-        auto watch = [&](const double *xref, double skin, int *flags, long *pre_epoch, const double **pre_pos) {
-            if (C.nwatch >= AMM_MAX_WATCH) return;
-            C.wref[C.nwatch] = xref;
-            C.wthr2[C.nwatch] = 0.25 * skin * skin;
-            C.wflags[C.nwatch] = flags;
-            ListWatch &w = ctx->watched[C.nwatch];
-            w.xref = xref;
-            w.thr2 = C.wthr2[C.nwatch];
-            w.flags = flags;
-            w.pre_epoch = pre_epoch;
-            w.pre_pos = pre_pos;
-            C.nwatch++;
-        };
-        for (auto &fo : ctx->forces)
-            if (fo.type == 1 && fo.pair->cl && fo.pair->cl->built && fo.pair->last_kind >= 1)
-                watch(fo.pair->cl->d_xref, fo.pair->cl->skin, fo.pair->cl->d_flags, &fo.pair->cl->pre_epoch, &fo.pair->cl->pre_pos);
-        for (auto &fo : ctx->forces)
-            if (fo.type == 1 && fo.pair->built && !fo.pair->host && !fo.pair->dual && !(fo.pair->cl && fo.pair->last_kind >= 1))
-                watch(fo.pair->d_xref, fo.pair->skin, fo.pair->d_flags, &fo.pair->pre_epoch, &fo.pair->pre_pos);
-        ctx->n_watched = C.nwatch;
+        WatchArgs W;
+        amm_collect_watches(ctx, W);
+        C.nwatch = W.n;
+        for (int q = 0; q < AMM_MAX_WATCH; ++q) {
+            C.wref[q] = W.xref[q];
+            C.wthr2[q] = W.thr2[q];
+            C.wflags[q] = W.flags[q];
+        }
     }
     C.c1 = c1;
     C.d = d;
@@ -1161,6 +1156,45 @@ int amm_inner_components_impl(amm_ctx *ctx, BondedSet *bs, double *x, double *v,
 #undef AMM_LAUNCH_INNER
     AMM_HIP(hipGetLastError());
     return 0;
+}
+
+// lists whose rebuild trigger a launch that moves the atoms evaluates: the molecule rows first (the hot path's), then single per-atom
+// lists (a hybrid list's per-atom part is one of those)
+void amm_collect_watches(amm_ctx *ctx, WatchArgs &W) {
+    W.n = 0;
+    for (int q = 0; q < AMM_MAX_WATCH; ++q) {
+        W.xref[q] = nullptr;
+        W.thr2[q] = 0.0;
+        W.flags[q] = nullptr;
+    }
+    auto watch = [&](const double *xref, double skin, int *flags, long *pre_epoch, const double **pre_pos) {
+        if (W.n >= AMM_MAX_WATCH) return;
+        W.xref[W.n] = xref;
+        W.thr2[W.n] = 0.25 * skin * skin;
+        W.flags[W.n] = flags;
+        ListWatch &w = ctx->watched[W.n];
+        w.xref = xref;
+        w.thr2 = W.thr2[W.n];
+        w.flags = flags;
+        w.pre_epoch = pre_epoch;
+        w.pre_pos = pre_pos;
+        W.n++;
+    };
+    for (auto &fo : ctx->forces)
+        if (fo.type == 1 && fo.pair->cl && fo.pair->cl->built && fo.pair->last_kind >= 1)
+            watch(fo.pair->cl->d_xref, fo.pair->cl->skin, fo.pair->cl->d_flags, &fo.pair->cl->pre_epoch, &fo.pair->cl->pre_pos);
+    for (auto &fo : ctx->forces)
+        if (fo.type == 1 && fo.pair->built && !fo.pair->host && !fo.pair->dual && !(fo.pair->cl && fo.pair->last_kind >= 1))
+            watch(fo.pair->d_xref, fo.pair->skin, fo.pair->d_flags, &fo.pair->pre_epoch, &fo.pair->pre_pos);
+    ctx->n_watched = W.n;
+}
+
+// the positions the last collected watches were evaluated for are the context's current ones (call after pos_epoch was bumped)
+void amm_watch_moved(amm_ctx *ctx) {
+    for (int w = 0; w < ctx->n_watched; ++w) {
+        *ctx->watched[w].pre_epoch = ctx->pos_epoch;
+        *ctx->watched[w].pre_pos = ctx->d_x;
+    }
 }
 
 int amm_bonded_free(BondedSet *bs) {

@@ -46,6 +46,14 @@ struct PosAdvanced {
     }
 };
 
+// displacement triggers of the watched lists for ONE atom at its new position (movers call this for every atom they move)
+__device__ __forceinline__ void amm_watch_atom(const WatchArgs &W, int a, const double *xn) {
+    for (int q = 0; q < W.n; ++q) {
+        const double dx = xn[0] - W.xref[q][3 * a], dy = xn[1] - W.xref[q][3 * a + 1], dz = xn[2] - W.xref[q][3 * a + 2];
+        if (!(dx * dx + dy * dy + dz * dz <= W.thr2[q])) W.flags[q][0] = 1;   // benign race (NaN also triggers)
+    }
+}
+
 // positions of a component's atoms in a wavefront-private LDS strip, indexed by the atom's slot in its component
 struct PosLds {
     const double *sx, *sy, *sz;     // strip of this lane's group

@@ -56,6 +56,39 @@ __global__ void k_kicks_move(int n3, double *__restrict__ x, double *__restrict_
         x[t] = x[t] + dx;
     }
 }
+// the same with a move, one thread per ATOM: the three new coordinates are at hand, so the launch also evaluates the displacement
+// triggers of the neighbour lists (WatchArgs) -- the check launch in front of the next pair evaluation is not needed then
+__global__ void k_kicks_move_atoms(int n, double *__restrict__ x, double *__restrict__ v, KickList K, const double *__restrict__ mass,
+                                   double dcoef, WatchArgs W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double m = mass[i];
+    double xn[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int t = 3 * i + c;
+        double vt = v[t];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < K.n) {
+                double ff = K.f[k][t];
+                if (K.f2[k]) ff = K.plus[k] ? ff + K.f2[k][t] : ff - K.f2[k][t];
+                const double num = K.coef[k] * ff;
+                const double dv = num / m;
+                vt = vt + dv;
+            }
+        }
+        v[t] = vt;
+        const double dx = dcoef * vt;
+        xn[c] = x[t] + dx;
+        x[t] = xn[c];
+    }
+    for (int q = 0; q < W.n; ++q) {
+        const double dx = xn[0] - W.xref[q][3 * i], dy = xn[1] - W.xref[q][3 * i + 1], dz = xn[2] - W.xref[q][3 * i + 2];
+        if (!(dx * dx + dy * dy + dz * dz <= W.thr2[q])) W.flags[q][0] = 1;   // benign race (NaN also triggers)
+    }
+}
+
 int amm_kicks_move_impl(amm_ctx *ctx, const double *const *fa, const double *const *fb, const int *plus, const double *coef, int nk,
                         int with_move, double dcoef) {
     KickList K;
@@ -67,6 +100,14 @@ int amm_kicks_move_impl(amm_ctx *ctx, const double *const *fa, const double *con
         K.coef[k] = k < nk ? coef[k] : 0.0;
     }
     const int n3 = 3 * ctx->n;
+    if (with_move) {
+        WatchArgs W;
+        amm_collect_watches(ctx, W);           // (the caller bumps pos_epoch and calls amm_watch_moved)
+        hipLaunchKernelGGL(k_kicks_move_atoms, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, ctx->d_x, ctx->d_v, K,
+                           ctx->d_mass, dcoef, W);
+        AMM_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_kicks_move, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->d_x, ctx->d_v, K, ctx->d_mass,
                        with_move, dcoef);
     AMM_HIP(hipGetLastError());
