@@ -1,17 +1,20 @@
 // atomsmm_amd/csrc/cluster.h -- molecule-row ("cluster") neighbour lists of the force-only pair traversal (gfx950).
 //
-// When every atom of a pair force belongs to a three-atom molecule whose three intramolecular pairs are its only exclusions
-// (a water box: the reference's exceptions -> exclusions, forces.py:310-312), the hot path keeps ONE neighbour row per
-// MOLECULE instead of one per atom: an entry names a partner molecule, and the traversal evaluates the nine atom pairs of
-// the two molecules from registers (this is the "i-tile" of BASELINE.json's north_star, three atoms tall).  Against per-atom rows:
+// The three-site molecules of a pair force -- three consecutive atoms whose three intramolecular pairs are their only exclusions (a
+// water: the reference's exceptions -> exclusions, forces.py:310-312) -- keep ONE neighbour row per MOLECULE on the force-only hot
+// path instead of one per atom: an entry names a partner molecule, and the traversal evaluates the nine atom pairs of the two
+// molecules from registers (this is the "i-tile" of BASELINE.json's north_star, three atoms tall).  Against per-atom rows:
 //   * a ninth of the row entries (list build writes, index stream, row bookkeeping per pair);
 //   * a third of the j-record gathers per pair, one periodic image per molecule pair instead of nine;
 //   * the Lennard-Jones arithmetic exactly where two sites meet (O-O: one pair in nine), with no ordering of the rows by
 //     site class -- so a row's order of summation depends on the row alone again (bit-identical between decompositions);
 //   * exclusions need no look-up at all: a molecule is not its own neighbour.
 // Price: a molecule pair is listed as soon as ANY of its nine atom pairs is within the list radius, so somewhat fewer of the
-// evaluated pairs lie inside the cutoff (measured in DESIGN.md).  Energy evaluations, guarded / grouped / softcore / virial
-// forces and systems that do not qualify keep the per-atom rows of pair.hip (built only when such an evaluation asks).
+// evaluated pairs lie inside the cutoff (measured in DESIGN.md).  A box of nothing but such molecules walks these rows only; when
+// the molecules share the box with other atoms (ions, a solute, a chain) the list is HYBRID: these rows for the pairs of two
+// molecules, per-atom rows (pair.hip, kept by the force's hidden child) for every pair with another atom.  Energy evaluations,
+// guarded / grouped / softcore / virial forces and particle lists with fewer than half of their atoms in molecules keep the per-atom
+// rows of pair.hip (built only when such an evaluation asks).
 #pragma once
 #include "amm_ctx.h"
 

@@ -1,6 +1,6 @@
 // atomsmm_amd/csrc/cluster.hip -- molecule-row neighbour lists and their force-only traversal (gfx950, fp64).  See cluster.h.
 //
-// Takes over, for water-like systems, what OpenMM's neighbour search + per-pair evaluation do for the reference's
+// Takes over, for the three-site molecules of any particle list (cluster.h), what OpenMM's neighbour search + per-pair evaluation do for the reference's
 // CustomNonbondedForce / NonbondedForce objects on the RESPA hot path (forces.py:448-455, 539-567, 655-670, 710-724;
 // systems.py:71-77): same pairs (exclusions = the three pairs inside each molecule), same per-pair arithmetic as pair.hip's
 // tabulated kernel (pair_tab.h), another decomposition of the work.

@@ -268,7 +268,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat);
  * (rc + skin) that the traversal walks whenever an atom moved more than skin/2.  Applies to pair forces created later. */
 int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
 /* Tuning and test options of a context (set before the first evaluation; never read from the environment).  Names:
- * "cluster" (1: molecule rows for water-like systems on the force-only path, 0: per-atom rows everywhere), "hybrid" (1: molecule
+ * "cluster" (1: molecule rows for three-site molecules on the force-only path, 0: per-atom rows everywhere), "hybrid" (1: molecule
  * rows also for waters that share the box with other atoms, the rest through per-atom rows), "small_group" (1: interaction-group
  * forces with a set of <= 128 atoms are evaluated without a neighbour list), "tab" (tabulated
  * force-only kernels), "site_trips", "lanes_per_row", "build_parts", "unroll", "dual_unroll", "tab_block", "tab_dual_block",
@@ -292,7 +292,7 @@ typedef struct {
     int32_t n_cells;
     double rlist;
     int32_t shares_list;    /* 1 if this force traverses another force's list */
-    int32_t list_kind;      /* rows walked by the last evaluation: 0 one per atom, 1 one per molecule (water-like systems,
+    int32_t list_kind;      /* rows walked by the last evaluation: 0 one per atom, 1 one per molecule (three-site molecules only,
                                force-only evaluations: n_list_pairs then counts nine atom pairs per entry, capacity and
                                max_neighbors are molecule partners per row, lanes_per_atom is lanes per row), 2 hybrid: one per
                                three-site molecule for the pairs of two molecules + one per atom, filtered to the pairs with an
