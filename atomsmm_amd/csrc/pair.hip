@@ -1613,7 +1613,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
         if (ctx->world > 1) pf->active_cap = (int)ns;      // a slice can come to hold any share of the rows with entries
         // the per-atom part of a hybrid list: how many molecule atoms have a partner outside the molecules follows the solute's shape
         // (a chain that unfolds): four times the first build's rows, and never an error short of every row
-        if (pf->hybrid_rest) pf->active_cap = (int)std::min<size_t>(ns, (size_t)4 * f16[8] + 1024);
+        if (pf->hybrid_rest && ctx->world == 1) pf->active_cap = (int)std::min<size_t>(ns, (size_t)4 * f16[8] + 1024);
     }
     pf->built = true;
     return 0;
