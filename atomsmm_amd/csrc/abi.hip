@@ -149,6 +149,11 @@ int amm_check(amm_ctx *ctx) {
                 return 2;
             }
         }
+        if (pf && pf->small && amm_small_group_failed(pf->small) != 0) {
+            amm_set_error("interaction-group pair force " + std::to_string(id) + ": a force on an atom of the small set exceeds the range of "
+                          "the fixed-point sums (1e6 kJ/mol/nm per wavefront: overlapping atoms, or NaN positions)");
+            return 2;
+        }
         if (!pf || !pf->built) continue;
         // (a hidden child is reported under its parent's id: the caller never saw the child's)
         const std::string who = pf->hybrid_rest ? std::to_string(pf->profile_id) + " (per-atom part of its hybrid list)" : std::to_string(id);

@@ -356,6 +356,7 @@ int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> 
 int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy,
                               BondedSet *carry_terms = nullptr);
 int amm_small_group_free(SmallGroup *sg);
+int amm_small_group_failed(SmallGroup *sg);
 // implemented in pair.hip / cells.hip / bonded.hip / integrate.hip
 int amm_pair_build_consts(const amm_pair_desc &d, PairConsts &pc);
 int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate,

@@ -36,6 +36,7 @@
 #define AMM_SG_EXP 0        // measurement variants (scripts/build_variant.sh group ...): wrong forces
 #endif
 #define AMM_FIX_SCALE 1099511627776.0        // 2^40
+#define AMM_FIX_MAX 1.0e6                    // a wavefront's share of a reaction force beyond this (kJ/mol/nm) is reported: the sums hold +-8.4e6
 
 
 struct SmallArgs {
@@ -51,6 +52,7 @@ struct SmallArgs {
     int small_accumulate;          // rows of the small set (written by the last block): += or =
     Box box;
     unsigned long long *acc;       // [ns][3] fixed-point sums of the reaction forces (zero between launches)
+    int *overflow;                 // set when a wavefront's contribution leaves the fixed-point range (overlapping atoms): amm_check reports it
     int *ticket;
     double *epart;                 // [nblocks] energies (EN)
 };
@@ -183,8 +185,10 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
                     const bool hit = (m & (0x1111111111111111ull << sub)) != 0ull;
                     mine = mine || (u == ku && hit);
                 }
-                if (lane < 48 && mine && ksum < A.ns)
+                if (lane < 48 && mine && ksum < A.ns) {
+                    if (!(fabs(part) < AMM_FIX_MAX)) A.overflow[0] = 1;           // (NaN too)
                     atomicAdd(&A.acc[3 * ksum + kd], (unsigned long long)__double2ll_rn(part * AMM_FIX_SCALE));
+                }
             }
         }
         // the four lanes' shares of the force on j
@@ -237,14 +241,14 @@ struct SmallGroup {
     float code = 0.f;
     int *d_small = nullptr;
     unsigned long long *d_acc = nullptr;
-    int *d_ticket = nullptr;
+    int *d_ticket = nullptr, *d_overflow = nullptr;
     double *d_epart = nullptr;
     int nblocks = 0;
 };
 
 int amm_small_group_free(SmallGroup *sg) {
     if (!sg) return 0;
-    void *ptrs[] = {sg->d_small, sg->d_acc, sg->d_ticket, sg->d_epart};
+    void *ptrs[] = {sg->d_small, sg->d_acc, sg->d_ticket, sg->d_epart, sg->d_overflow};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete sg;
@@ -284,6 +288,8 @@ int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> 
     AMM_HIP(hipMalloc(&sg->d_ticket, sizeof(int) * AMM_TICKET_INTS));
     AMM_HIP(hipMemset(sg->d_ticket, 0, sizeof(int) * AMM_TICKET_INTS));
     AMM_HIP(hipMalloc(&sg->d_epart, sizeof(double) * sg->nblocks));
+    AMM_HIP(hipMalloc(&sg->d_overflow, sizeof(int)));
+    AMM_HIP(hipMemset(sg->d_overflow, 0, sizeof(int)));
     pf->small = sg;
     return 0;
 }
@@ -331,6 +337,7 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     }
     A.box = ctx->box;
     A.acc = sg->d_acc;
+    A.overflow = sg->d_overflow;
     A.ticket = sg->d_ticket;
     A.epart = sg->d_epart;
     // AMM_SG_BPC blocks per CU at most (grid stride in the kernel)
@@ -372,4 +379,12 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     pf->n_evals++;
     pf->last_kind = 3;
     return 0;
+}
+
+// pending device-side error of a list-free group force (amm_check; the caller has synchronised): 1 = a reaction force left the
+// fixed-point range of the accumulators
+int amm_small_group_failed(SmallGroup *sg) {
+    int flag = 0;
+    if (hipMemcpy(&flag, sg->d_overflow, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return flag;
 }

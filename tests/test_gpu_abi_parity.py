@@ -1226,3 +1226,28 @@ def test_c3_full_size_one_slice_of_eight_with_the_products_lanes():
         assert mine.sum() == n // 8 and (mine.reshape(-1, 3).all(axis=1) == mine.reshape(-1, 3).any(axis=1)).all()      # whole molecules
         assert np.abs(got[mine] - f_ref[mine]).max() <= 1e-9 * np.abs(f_ref).max()
     ctx.close()
+
+
+def test_list_free_group_force_reports_overflow(heaq):
+    """The list-free interaction-group path (csrc/group.hip) sums the forces on the small set in 64-bit fixed point (+-8.4e6 kJ/mol/nm at
+    2^-40): a solute atom pushed INTO a solvent atom (r = 0.005 nm, Lennard-Jones force ~1e20) must be reported by amm_check, not
+    wrapped around silently."""
+    B = _backend()
+    h = heaq
+    n = len(h['positions'])
+    codes = np.where(h['resname'] == 'aaa', 1.0, 2.0)
+    ctx = B.HipContext(n, h['box'])
+    fid = ctx.pair_create(B.pair_desc(B.NEAR_FSWITCH, 0.7, rc0=0.7, rs0=0.5, flags=B.GROUP_LJ | B.NO_SHIFT, Kc=1.0), codes, h['sigma'],
+                          h['epsilon'], h['exc_pairs'])
+    f = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+    ctx.force_eval(fid, dev(h['positions']), f)
+    ctx.check()
+    assert ctx.pair_stats(fid)['list_kind'] == 3
+    x = h['positions'].copy()
+    solute = np.where((codes == 1.0) & (h['epsilon'] > 0))[0][0]          # two Lennard-Jones sites
+    solvent = np.where((codes == 2.0) & (h['epsilon'] > 0))[0][0]
+    x[solute] = x[solvent] + np.array([0.005, 0.0, 0.0])
+    ctx.force_eval(fid, dev(x), f)
+    with pytest.raises(B.HipError, match='fixed-point'):
+        ctx.check()
+    ctx.close()
