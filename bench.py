@@ -610,7 +610,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.outer == 'damped':
             result['cpu_baseline'] = cpu_baseline_in_child(args.nside, eng.x.cpu().numpy(), eng.v.cpu().numpy())
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
