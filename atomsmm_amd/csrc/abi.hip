@@ -310,7 +310,9 @@ int amm_pair_create(amm_ctx *ctx, const amm_pair_desc *desc, const double *h_q, 
         // the child: same particles, parameters, exclusions and Verlet buffer; its list keeps the pairs with a rest atom (code 2)
         int32_t child_id = -1;
         ctx->creating_rest = true;
-        const int rc = amm_pair_create(ctx, desc, h_q, h_sigma, h_eps, h_excl, n_excl, skin, &child_id);
+        // (twice the Verlet buffer of the molecule rows: walking the per-atom part costs a tenth of walking the molecule rows, rebuilding
+        // it half as much as rebuilding them -- at config C5 its optimum lies at a larger buffer; the two lists are independent)
+        const int rc = amm_pair_create(ctx, desc, h_q, h_sigma, h_eps, h_excl, n_excl, pf->skin * ctx->opt_rest_skin_factor, &child_id);
         ctx->creating_rest = false;
         if (rc) return 1;
         PairForce *child = ctx->forces[child_id].pair;
@@ -1480,6 +1482,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "hybrid") ctx->opt_hybrid = v;
     else if (k == "small_group") ctx->opt_small_group = v;
     else if (k == "mixed_terms") ctx->opt_mixed_terms = v;
+    else if (k == "rest_skin_factor") ctx->opt_rest_skin_factor = value;
     else if (k == "tab") ctx->opt_tab = v;
     else if (k == "site_trips") ctx->site_trips = v != 0;
     else if (k == "lanes_per_row") ctx->opt_lpa = v;

@@ -276,6 +276,7 @@ struct amm_ctx {
     // order of summation of a production run
     int opt_cluster = 1;           // molecule rows for qualifying forces (0: per-atom rows everywhere)
     int opt_hybrid = 1;            // ... also when the three-site molecules share the box with other atoms (hybrid lists)
+    double opt_rest_skin_factor = 2.0;   // Verlet buffer of a hybrid list's per-atom part relative to its molecule rows
     int opt_mixed_terms = 1;       // mixed bond-list sets: small components four lanes each on the fused EVAL + kicks path (bonded.hip)
     int opt_small_group = 1;       // interaction-group forces with a small set (a solute) without a neighbour list (group.hip)
     bool creating_rest = false;    // amm_pair_create is making the hidden child of a hybrid list

@@ -108,14 +108,36 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
     // sixteen atoms per wavefront instead of sixty-four cuts it four times (30 small atoms: 2 trips of pair arithmetic per
     // wavefront instead of 8; measured 31 -> see DESIGN.md).  A block walks its share of the atoms with a grid stride.
     const int sub = lane & 3;
-    for (int jb = A.j0 + blockIdx.x * 64; jb < A.j1; jb += gridDim.x * 64) {
+    // the next atom's record is fetched while this one is tested (all loads at once, whatever the atom's set): the kernel is a chain
+    // of dependent round trips at four wavefronts per SIMD, and a trip of the loop below is shorter than one of them
+    struct Rec {
+        float code;
+        double px, py, pz, q;
+        double2 lj;
+    };
+    auto fetch = [&](int jb) {
+        const int j = jb + (int)(threadIdx.x >> 2);
+        const int jl = min(max(j, A.j0), A.j1 - 1);
+        Rec r;
+        r.code = A.member[jl];
+        r.px = A.pos[3 * jl];
+        r.py = A.pos[3 * jl + 1];
+        r.pz = A.pos[3 * jl + 2];
+        r.q = A.q[jl];
+        r.lj = make_double2(A.hsig[jl], A.seps2[jl]);
+        return r;
+    };
+    const int jstride = (int)gridDim.x * 64;
+    Rec nxt = fetch(A.j0 + (int)blockIdx.x * 64);
+    for (int jb = A.j0 + blockIdx.x * 64; jb < A.j1; jb += jstride) {
+        const Rec cur = nxt;
+        if (jb + jstride < A.j1) nxt = fetch(jb + jstride);
         const int j = jb + (threadIdx.x >> 2);
         const bool in = j < A.j1;
-        const int jl = in ? j : A.j1 - 1;             // (all loads at once, whatever the atom's set: one round trip, not two)
-        const float code = in ? A.member[jl] : 0.f;
-        const double px = A.pos[3 * jl], py = A.pos[3 * jl + 1], pz = A.pos[3 * jl + 2];
-        const double qj = c.Kc * A.q[jl];
-        const double2 lj = make_double2(A.hsig[jl], A.seps2[jl]);
+        const float code = in ? cur.code : 0.f;
+        const double px = cur.px, py = cur.py, pz = cur.pz;
+        const double qj = c.Kc * cur.q;
+        const double2 lj = cur.lj;
         const bool partner = in && code != 0.f && code != A.small_code;       // an atom of the other (large) set
         double fx = 0.0, fy = 0.0, fz = 0.0;
         // (a wavefront without an atom of the large set has nothing to do: wave-uniform)

@@ -270,7 +270,8 @@ int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
 /* Tuning and test options of a context (set before the first evaluation; never read from the environment).  Names:
  * "cluster" (1: molecule rows for three-site molecules on the force-only path, 0: per-atom rows everywhere), "hybrid" (1: molecule
  * rows also for waters that share the box with other atoms, the rest through per-atom rows), "small_group" (1: interaction-group
- * forces with a set of <= 128 atoms are evaluated without a neighbour list), "tab" (tabulated
+ * forces with a set of <= 128 atoms are evaluated without a neighbour list), "rest_skin_factor" (Verlet buffer of a hybrid list's
+ * per-atom part as a multiple of its molecule rows' buffer, default 2; set before amm_pair_create), "mixed_terms", "tab" (tabulated
  * force-only kernels), "site_trips", "lanes_per_row", "build_parts", "unroll", "dual_unroll", "tab_block", "tab_dual_block",
  * "no_dual", "no_defer", "terms_from", "no_term_lanes".  Unknown names are an error. */
 int amm_set_option(amm_ctx *ctx, const char *name, double value);
