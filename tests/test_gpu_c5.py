@@ -129,3 +129,26 @@ def test_c5_fused_inner_iterations_bit_identical():
     assert b1 == b0 and b1 >= 2
     assert np.array_equal(x1, x0) and np.array_equal(v1, v0)
     assert np.isfinite(x1).all()
+
+
+def test_c5_full_size_fused_inner_iterations_bit_identical():
+    """The same comparison at the full 249 075 atoms (82 015 four-lane components + 3 030 atoms of big components, 258 000 terms of
+    which 12 000 are parked; the softcore force without a list): 3 RESPA [4,2,1] steps, fused == unfused bit for bit."""
+    case = solvated_chain()
+
+    def run(fuse):
+        respa = build_c5_system(case)
+        integrator = atomsmm.RespaPropagator([4, 2, 1]).integrator(2 * unit.femtoseconds)
+        context = openmm.Context(respa, integrator)
+        context._engine.ctx.set_fuse_inner(fuse)
+        context.setPositions(case['positions'] * unit.nanometers)
+        context.setVelocities(case['velocities'])
+        context.setParameter('lambda_vdw', 0.7)
+        integrator.step(3)
+        st = context.getState(getPositions=True, getVelocities=True)
+        return st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value
+
+    x1, v1 = run(True)
+    x0, v0 = run(False)
+    assert np.array_equal(x1, x0) and np.array_equal(v1, v0)
+    assert np.isfinite(x1).all() and np.abs(x1 - case['positions']).max() > 1e-4
