@@ -1493,6 +1493,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "tab_dual_block") ctx->opt_tab_dual_bs = v;
     else if (k == "no_dual") ctx->opt_no_dual = v;
     else if (k == "fuse_rows") ctx->opt_fuse_rows = v;
+    else if (k == "row_phases") ctx->opt_row_phases = v;
     else if (k == "site_tab") ctx->opt_site_tab = v;
     else if (k == "no_defer") ctx->opt_no_defer = v;
     else if (k == "terms_from") ctx->opt_terms_from = v;

@@ -283,6 +283,7 @@ struct amm_ctx {
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
     int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
     int opt_site_tab = 1;               // molecule rows: site-site radial tables instead of Lennard-Jones arithmetic where a force has one
+    int opt_row_phases = 1;             // molecule rows: the remainder of the rows after whole rounds of tasks goes out in smaller tasks (cpair_plan)
     int opt_fuse_rows = 1;              // molecule rows: host + guest force of a shared list in ONE launch when a fused kernel exists
     int opt_no_dual = 0, opt_no_defer = 0, opt_terms_from = 8192, opt_no_term_lanes = 0;
     ListWatch watched[AMM_MAX_WATCH];

@@ -528,6 +528,7 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
 }
 
 // ------------------------------------------------------------------------------------------------ traversal
+#define AMM_CPHASES 6
 struct CPairArgs {
     int c_begin, nrows, lpa_shift, cap;
     const int *aperm;
@@ -542,6 +543,10 @@ struct CPairArgs {
     double margin;
     int ntask;
     int per_pair_image;
+    // the rows of an XCD (rpx consecutive rows each) are walked in phases: phase p covers the XCD's rows from ph_off[p] on as
+    // ph_ntask[p] wavefront tasks of 64 >> ph_shift[p] rows (cpair_plan: whole rounds of big tasks, the remainder in smaller ones)
+    int rpx, nphase;
+    int ph_off[AMM_CPHASES], ph_shift[AMM_CPHASES], ph_ntask[AMM_CPHASES];
     // site-site tables (pair_tab.h: SiteTable; kernels with SS): LDS byte offset FROM THE FORCE'S COULOMB TABLE to the place
     // interval 0 of its site-site table would have, the bytes it really holds, and the site class for the analytic fallback
     const double *host_tab_ss;
@@ -785,20 +790,21 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
 
     constexpr int WPB = BS / 64;
     const int lane = threadIdx.x & 63;
-    const int lpa = 1 << A.lpa_shift;
-    const int sub = lane & (lpa - 1);
-    const int rpw = 64 >> A.lpa_shift;
     const double sign = c.sign;
     PairConsts c1 = c, g1 = g;
     c1.sign = 1.0;          // the sign travels with the row atoms' charges and epsilons (every family is linear in both)
     g1.sign = 1.0;
-    // one contiguous eighth of the tasks per XCD (blockIdx & 7): consecutive cell-sorted rows = one slab of the box per L2
+    // one contiguous eighth of the rows per XCD (blockIdx & 7): consecutive cell-sorted rows = one slab of the box per L2
     const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
-    const int per = (A.ntask + 7) >> 3;
-    const int t0 = min(xcd * per, A.ntask), t1 = min(t0 + per, A.ntask);
-    for (int task = t0 + (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); task < t1; task += nwx) {
-        const int a = task * rpw + (lane >> A.lpa_shift);
-        const bool valid = a < A.nrows;
+    const int row_end = min((xcd + 1) * A.rpx, A.nrows);
+    for (int phase = 0; phase < A.nphase; ++phase) {
+    const int shift = A.ph_shift[phase], row0 = xcd * A.rpx + A.ph_off[phase], ntask = A.ph_ntask[phase];
+    const int lpa = 1 << shift;
+    const int sub = lane & (lpa - 1);
+    const int rpw = 64 >> shift;
+    for (int task = (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); task < ntask; task += nwx) {
+        const int a = row0 + task * rpw + (lane >> shift);
+        const bool valid = a < row_end;
         const int cs = A.c_begin + (valid ? a : 0);
         double4 pi[3];
         int i_sites = 0;
@@ -860,6 +866,60 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
             }
         }
     }
+    }
+}
+
+// How the rows of one XCD are shared out among its `waves` resident wavefronts.  A task of 64 >> s rows costs a wavefront about
+// AMM_PHASE_COST[s] (relative to 16 rows at 4 lanes each: more lanes per row = shorter rows, but the row's prologue and the
+// reduction weigh more; from the per-rank table of profiles/, launch and table staging taken off).  With one task size the
+// slowest wavefront walks ceil(tasks / waves) of them -- 3 where the mean is 2.5 at 82 015 rows: a sixth of the chip idle.
+// Here: whole rounds of the biggest tasks, then the remainder in whole rounds of a smaller size ..., at every level the cheaper
+// of "finish with this size" and "a smaller size for what is left".  (The order in which a row's entries are summed depends on
+// its lanes per row, i.e. on the phase the row falls in; the plan is a function of (rows, waves, first size) alone, so a system
+// gets the same sums on every evaluation and every run.)  At most 5 sizes (4 ... 64 lanes per row) < AMM_CPHASES phases.
+static const double AMM_PHASE_COST[7] = {0, 0, 1.0, 0.55, 0.32, 0.18, 0.11};
+static double cpair_plan_rec(int rows, int waves, int s, int off, CPairArgs *P) {
+    const int rpw = 64 >> s, per_round = waves * rpw;
+    const int full = rows / per_round, left = rows - full * per_round;
+    const double finish = (double)((rows + per_round - 1) / per_round) * AMM_PHASE_COST[s];
+    auto put = [&](int ntask) {
+        if (P && ntask > 0) {
+            P->ph_off[P->nphase] = off;
+            P->ph_shift[P->nphase] = s;
+            P->ph_ntask[P->nphase] = ntask;
+            ++P->nphase;
+        }
+    };
+    int s2 = 6;
+    double split = 1e300;
+    for (int t = s + 1; t <= 6 && left > 0; ++t) {           // the next size: the one that finishes the remainder cheapest
+        const double v = cpair_plan_rec(left, waves, t, 0, nullptr);
+        if (v < split) {
+            split = v;
+            s2 = t;
+        }
+    }
+    split += full * AMM_PHASE_COST[s];
+    if (left == 0 || s == 6 || finish <= split) {
+        put((rows + rpw - 1) / rpw);
+        return finish;
+    }
+    put(full * waves);
+    cpair_plan_rec(left, waves, s2, off + full * per_round, P);
+    return split;
+}
+static void cpair_plan(CPairArgs &P, int waves, int enabled) {
+    P.rpx = (P.nrows + 7) / 8;
+    P.nphase = 0;
+    if (enabled) {
+        cpair_plan_rec(P.rpx, waves, P.lpa_shift, 0, &P);
+    } else {
+        const int rpw = 64 >> P.lpa_shift;
+        P.ph_off[0] = 0;
+        P.ph_shift[0] = P.lpa_shift;
+        P.ph_ntask[0] = (P.rpx + rpw - 1) / rpw;
+        P.nphase = 1;
+    }
 }
 
 // per (device, kernel) launch configuration: dynamic LDS attribute + blocks per CU from the occupancy query
@@ -900,7 +960,9 @@ static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c,
     constexpr int WPB = BS / 64;
     long nblk = std::min((long)ncu * k.bpc, ((long)A.ntask + WPB - 1) / WPB);
     nblk = std::max(8L, (nblk + 7) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, A, c, g);
+    CPairArgs P = A;
+    cpair_plan(P, (int)(nblk >> 3) * WPB, ctx->opt_row_phases);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, P, c, g);
     return 0;
 }
 
