@@ -1178,8 +1178,10 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     const bool moves = !more_kicks && j < n_ops && ops[j].op == AMM_OP_MOVE;
                     if (bound && K.n >= 1) {
                         // (the pair force's launch evaluates the bond-list terms too: group.hip, TermsWork)
-                        if (ps && amm_small_group_eval_impl(ctx, ps, ctx->d_x, buf, 0, nullptr, bs) != 0) return 1;
-                        if (amm_bonded_eval_kicks_impl(ctx, bs, ctx->d_x, buf, ps ? 1 : 0, K, moves ? 1 : 0, moves ? ops[j].coef : 0.0, ps ? 1 : 0)) return 1;
+                        const double *pair_rows = nullptr;         // (the pair force's rows: in `buf`, or in a buffer of its own)
+                        const bool own = bs->mixed_ok && ctx->opt_mixed_terms;       // (k_mixed_eval_kicks takes them from anywhere)
+                        if (ps && amm_small_group_eval_impl(ctx, ps, ctx->d_x, buf, 0, nullptr, bs, own ? &pair_rows : nullptr) != 0) return 1;
+                        if (amm_bonded_eval_kicks_impl(ctx, bs, ctx->d_x, buf, ps ? 1 : 0, K, moves ? 1 : 0, moves ? ops[j].coef : 0.0, ps ? 1 : 0, pair_rows)) return 1;
                         if (moves) {
                             ctx->pos_epoch++;
                             amm_watch_moved(ctx);
@@ -1393,6 +1395,12 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     out->has_site_table = (ctx->opt_site_tab && pf->d_tab_ss && pf->pc.tab.ss_first >= 0) ? 1 : 0;
     out->site_tab_error = pf->ss_error;
     out->n_rest_atoms = L->hybrid ? L->n_rest : 0;
+    if (pf->small) {
+        int cs[2];
+        if (amm_small_group_stats(pf->small, cs)) return 1;
+        out->n_candidates = cs[0];
+        out->n_candidate_walks = cs[1];
+    }
     if (L->last_kind >= 1 && L->cl && L->cl->built) {
         ClusterList *cl = L->cl;
         int flags[8];
@@ -1494,6 +1502,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "no_dual") ctx->opt_no_dual = v;
     else if (k == "fuse_rows") ctx->opt_fuse_rows = v;
     else if (k == "row_phases") ctx->opt_row_phases = v;
+    else if (k == "group_candidates") ctx->opt_group_candidates = v;
     else if (k == "site_tab") ctx->opt_site_tab = v;
     else if (k == "no_defer") ctx->opt_no_defer = v;
     else if (k == "terms_from") ctx->opt_terms_from = v;

@@ -283,6 +283,7 @@ struct amm_ctx {
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
     int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
     int opt_site_tab = 1;               // molecule rows: site-site radial tables instead of Lennard-Jones arithmetic where a force has one
+    int opt_group_candidates = 1;       // list-free group forces on the fused inner loop: walk the atoms near the small set only while a companion list vouches for them
     int opt_row_phases = 1;             // molecule rows: the remainder of the rows after whole rounds of tasks goes out in smaller tasks (cpair_plan)
     int opt_fuse_rows = 1;              // molecule rows: host + guest force of a shared list in ONE launch when a fused kernel exists
     int opt_no_dual = 0, opt_no_defer = 0, opt_terms_from = 8192, opt_no_term_lanes = 0;
@@ -355,10 +356,13 @@ int amm_exchange_finish_impl(amm_ctx *ctx);
 // group.hip
 int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> &member);
 // carry_terms: the launch also evaluates the terms of this (finalized, term-parallel) bond-list set into its parked-force buffer
+// own_rows: the caller can take the force's rows from a buffer of the force's own (returned here; nullptr: they are in d_force
+// as usual) -- then the launch may walk the candidate atoms only (group.hip: SmallArgs)
 int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy,
-                              BondedSet *carry_terms = nullptr);
+                              BondedSet *carry_terms = nullptr, const double **own_rows = nullptr);
 int amm_small_group_free(SmallGroup *sg);
 int amm_small_group_failed(SmallGroup *sg);
+int amm_small_group_stats(SmallGroup *sg, int out[2]);
 // implemented in pair.hip / cells.hip / bonded.hip / integrate.hip
 int amm_pair_build_consts(const amm_pair_desc &d, PairConsts &pc);
 int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate,
@@ -375,7 +379,7 @@ int amm_bonded_eval_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, doubl
 int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs);
 // EVAL of a term-parallel set followed by kicks (and a move): the gather launch applies them (bit-identical to the separate ops)
 int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate, const KickList &K,
-                               int with_move, double dcoef, int terms_done = 0);
+                               int with_move, double dcoef, int terms_done = 0, const double *pair_rows = nullptr);
 int amm_bonded_free(BondedSet *bs);
 // (with_move: the launch also evaluates the displacement triggers of the context's lists; the caller bumps pos_epoch and calls
 // amm_watch_moved)

@@ -195,7 +195,7 @@ struct MixedArgs {
 __global__ void __launch_bounds__(256) k_mixed_eval_kicks(BondedArgs A, MixedArgs M, const int *__restrict__ rec_src,
                                                           const double *__restrict__ tf, KickList K, double *__restrict__ x,
                                                           double *__restrict__ v, const double *__restrict__ mass, int with_move, double dcoef,
-                                                          WatchArgs W) {
+                                                          WatchArgs W, const double *__restrict__ pair_rows) {
 #pragma clang fp contract(off)
     __shared__ double s_x[3][256];
     __shared__ double s_out[12][256];
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) k_mixed_eval_kicks(BondedArgs A, MixedArg
     const double m = mass[ah];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        if (A.accumulate) f_row[c] = A.force[3 * ah + c];
+        if (A.accumulate) f_row[c] = pair_rows ? pair_rows[3 * ah + c] : A.force[3 * ah + c];
         v_in[c] = v[3 * ah + c];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -992,7 +992,7 @@ int amm_bonded_terms_work(amm_ctx *ctx, BondedSet *bs, const double *d_pos, Bond
 }
 
 int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos, double *d_force, int accumulate, const KickList &K,
-                               int with_move, double dcoef, int terms_done) {
+                               int with_move, double dcoef, int terms_done, const double *pair_rows) {
     BondedArgs A;
     if (terms_args(ctx, bs, d_pos, d_force, accumulate, A)) return 1;
     const int n = ctx->n;
@@ -1013,9 +1013,13 @@ int amm_bonded_eval_kicks_impl(amm_ctx *ctx, BondedSet *bs, const double *d_pos,
         M.sc_recs = bs->d_sc_recs;
         M.big_atoms = bs->d_big_atoms;
         hipLaunchKernelGGL(k_mixed_eval_kicks, dim3(M.sc_blocks + (bs->n_big + 255) / 256), dim3(256), 0, ctx->stream, A, M, bs->d_rec_src,
-                           bs->d_tf, K, ctx->d_x, ctx->d_v, ctx->d_mass, with_move, dcoef, W);
+                           bs->d_tf, K, ctx->d_x, ctx->d_v, ctx->d_mass, with_move, dcoef, W, pair_rows);
         AMM_HIP(hipGetLastError());
         return 0;
+    }
+    if (pair_rows) {
+        amm_set_error("fused evaluation + kicks: pair rows in a buffer of their own need the mixed kernel");
+        return 1;
     }
     if (!terms_done)
         hipLaunchKernelGGL(k_terms_eval, dim3((bs->n_gterms + 255) / 256), dim3(256), 0, ctx->stream, A, bs->n_gterms, bs->d_gt_a, bs->d_gt_q,

@@ -41,10 +41,24 @@ __device__ __forceinline__ bool amm_last_block(int *ticket) {
     __syncthreads();
     return s_last != 0;
 }
+// the same with `count` (< 1024, the same in every block that calls) participants out of the grid: ticket[0] alone
+__device__ __forceinline__ bool amm_last_of(int *ticket, int count) {
+    __shared__ int s_last_of;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(ticket, 1);
+        s_last_of = (t == count - 1);
+        if (s_last_of) *ticket = 0;
+    }
+    __syncthreads();
+    return s_last_of != 0;
+}
 __device__ __forceinline__ int amm_ld_l2(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long amm_ld_l2(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void amm_st_l2(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void amm_st_l2(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

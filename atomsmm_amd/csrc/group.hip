@@ -20,11 +20,13 @@
 // arguments as the list-based kernel k_pair_nlist.
 // HBM traffic: positions + parameters + force rows once (~56 B per atom), 7.5 M distance tests at 249 075 atoms x 30.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "amm_ctx.h"
 #include "bonded_terms.h"
+#include "cluster.h"
 #include "device_utils.h"
 #include "pair_math.h"
 
@@ -36,7 +38,7 @@
 #define AMM_SG_EXP 0        // measurement variants (scripts/build_variant.sh group ...): wrong forces
 #endif
 #define AMM_FIX_SCALE 1099511627776.0        // 2^40
-#define AMM_FIX_MAX 1.0e6                    // a wavefront's share of a reaction force beyond this (kJ/mol/nm) is reported: the sums hold +-8.4e6
+#define AMM_FIX_MAX 1.0e6                    // a wavefront's share of a reaction force stays below this (a pair's beyond 1/16 of it, kJ/mol/nm, is reported): the sums hold +-8.4e6
 
 
 struct SmallArgs {
@@ -55,13 +57,29 @@ struct SmallArgs {
     int *overflow;                 // set when a wavefront's contribution leaves the fixed-point range (overlapping atoms): amm_check reports it
     int *ticket;
     double *epart;                 // [nblocks] energies (EN)
+    // ---- candidate rows (inner loops: the force is evaluated far more often than atoms change neighbourhoods) ----
+    // A companion neighbour list of the context keeps, for every atom, its position at the list's last build (xref) and a flag
+    // that the kernels which move the atoms raise as soon as one of them is farther than skin / 2 from it.  While the flag is down
+    // a pair inside this force's cutoff was closer than rc + skin in the xref positions: the launch that follows a build of the
+    // companion (its build counter changed) walks every atom as usual and also lists the atoms within rc + skin of a small atom
+    // (`cand`, any order: no sum depends on it, see the fixed-point remark above); later launches walk that list only -- 1 700
+    // atoms instead of 249 075 at config C5 -- and leave the other rows of `force` alone: they are zero and stay zero
+    // (`force` is then a buffer of this force's own: SmallGroup::d_fpair).
+    int cand_on;                   // 0: plain launch (every atom, no list kept)
+    int cand_trust;                // host: the companion's flag was evaluated for THESE positions
+    const double *xref;            // companion: [n][3]
+    const int *lflags;             // companion: [0] rebuild wanted
+    const unsigned long long *lcounters;     // companion: [0] builds
+    double r2cand;                 // (rc + skin)^2
+    int *cand;                     // [n]
+    int *cstate;                   // [0] candidates [1] companion build they belong to [2] append cursor (zero between launches)
 };
 
 // Term evaluation of a bond-list set that shares the force group with this pair force (amm_run_ops: the group of the innermost RESPA
 // loop at config C5 = bond lists + softcore force): the blocks of this launch evaluate the terms too, with a grid stride -- the
 // work of bonded.hip's k_terms_eval (same function, same parked forces), without a launch of its own.  nterms == 0: none.
 struct TermsWork {
-    int nterms;
+    int nterms, nblocks;      // nblocks: the first blocks of the grid, which do nothing else
     const int *list;          // the terms to evaluate (indices into gt_a / gt_q / tf); nullptr: all of 0 .. nterms - 1
     const int4 *gt_a;
     const double4 *gt_q;
@@ -73,33 +91,51 @@ template <int FAM, bool GUARD, bool EN, bool GROUPED>
 __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, TermsWork T) {
     __shared__ double4 s_pos[AMM_SMALL_MAX];          // x, y, z, Kc q
     __shared__ double2 s_lj[AMM_SMALL_MAX];
-    __shared__ double s_tr[4][12][65];                // per wavefront: the twelve reaction components of a trip, [value][lane]
+    __shared__ long long s_tr[4][12][65];             // per wavefront: the twelve reaction components of a trip, [value][lane], fixed point
+    __shared__ double s_ref[AMM_SMALL_MAX][3];        // the small atoms in the companion list's reference positions (candidate builds)
     static_assert(FAM == AMM_SOFTCORE || FAM == AMM_NEAR_FSWITCH || FAM == AMM_NONBONDED, "families of the reference's interaction groups");
     const double *s_tab = nullptr;          // (none of them evaluates erfc: NONBONDED here is the plain-Coulomb instantiation, CMODE 0)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int k = threadIdx.x; k < A.ns; k += 256) {
-        const int i = A.small[k];
-        s_pos[k] = make_double4(A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2], A.q[i]);
-        s_lj[k] = make_double2(A.hsig[i], A.seps2[i]);
+    // Block roles: the first T.nblocks blocks evaluate the bond-list terms (nothing else), the others walk atoms -- two chains of
+    // dependent round trips side by side instead of one behind the other.
+    const int pb = (int)blockIdx.x - T.nblocks, npb = (int)gridDim.x - T.nblocks;        // this block among the atom walkers
+    // (a candidate slot read before anyone knows whether the candidates are walked: one round trip less on that chain)
+    const int spec = (A.cand_on && pb >= 0) ? A.cand[min(pb * 64 + (int)(threadIdx.x >> 2), A.n - 1)] : 0;
+    // walk every atom (and, `listing`, keep the candidates), or the candidates only: the same decision in every block -- the state
+    // changes in the LAST block's tail only, when every other block has read it
+    bool full = true, listing = false;
+    int ncand = 0;
+    if (A.cand_on && A.cand_trust && A.lflags[0] == 0) {
+        if ((int)A.lcounters[0] == A.cstate[1]) {
+            full = false;
+            ncand = A.cstate[0];
+        } else {
+            listing = true;
+        }
     }
-    __syncthreads();
-    // (the bond-list terms first: independent of everything below, and their loads overlap the staging above)
-    for (int kt = blockIdx.x * 256 + threadIdx.x; kt < T.nterms; kt += gridDim.x * 256) {
-        const int t = T.list ? T.list[kt] : kt;
-        const int4 at = T.gt_a[t];
-        const double4 q = T.gt_q[t];
-        const long long code = __double_as_longlong(q.w);
-        const int kind = (int)(code & 7), periodic = (int)((code >> 5) & 1);
-        const int ix[4] = {at.x, at.y, at.z, at.w};
-        const double p[3] = {q.x, q.y, q.z};
-        double fo[4][3], e;
-        PosPlain pos{T.A.pos};
-        bonded_term_forces(T.A, pos, ix, p, kind, periodic, fo, e);
-        double *out = T.tf + (size_t)t * 12;
+    // a candidate walk needs few of the blocks; the others leave at once and the ticket counts the rest
+    const int walkers = full ? npb : max(1, min(npb, (ncand + 63) >> 6));
+    if (pb >= walkers) return;
+    const int ticket_n = full ? (int)gridDim.x : T.nblocks + walkers;
+    if (pb < 0) {
+        for (int kt = blockIdx.x * 256 + threadIdx.x; kt < T.nterms; kt += T.nblocks * 256) {
+            const int t = T.list ? T.list[kt] : kt;
+            const int4 at = T.gt_a[t];
+            const double4 q = T.gt_q[t];
+            const long long code = __double_as_longlong(q.w);
+            const int kind = (int)(code & 7), periodic = (int)((code >> 5) & 1);
+            const int ix[4] = {at.x, at.y, at.z, at.w};
+            const double p[3] = {q.x, q.y, q.z};
+            double fo[4][3], e;
+            PosPlain pos{T.A.pos};
+            bonded_term_forces(T.A, pos, ix, p, kind, periodic, fo, e);
+            double *out = T.tf + (size_t)t * 12;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int x = 0; x < 3; ++x) out[3 * r + x] = fo[r][x];
+                for (int x = 0; x < 3; ++x) out[3 * r + x] = fo[r][x];
+        }
+        if (EN && threadIdx.x == 0) A.epart[blockIdx.x] = 0.0;
     }
     const double guard2 = GUARD ? c.rc0 * c.rc0 : 0.0;
     double esum = 0.0;
@@ -111,14 +147,20 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
     // the next atom's record is fetched while this one is tested (all loads at once, whatever the atom's set): the kernel is a chain
     // of dependent round trips at four wavefronts per SIMD, and a trip of the loop below is shorter than one of them
     struct Rec {
+        int j;
         float code;
         double px, py, pz, q;
         double2 lj;
     };
-    auto fetch = [&](int jb) {
-        const int j = jb + (int)(threadIdx.x >> 2);
-        const int jl = min(max(j, A.j0), A.j1 - 1);
+    // (it: position in the walk -- an atom of this rank's block, or a slot of the candidate list)
+    const int walk_n = full ? A.j1 - A.j0 : ncand;
+    auto atom_of = [&](int it) {
+        const int t = min(max(it, 0), max(walk_n - 1, 0));
+        return full ? A.j0 + t : A.cand[t];
+    };
+    auto fetch_atom = [&](int jl) {
         Rec r;
+        r.j = jl;
         r.code = A.member[jl];
         r.px = A.pos[3 * jl];
         r.py = A.pos[3 * jl + 1];
@@ -127,19 +169,53 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
         r.lj = make_double2(A.hsig[jl], A.seps2[jl]);
         return r;
     };
-    const int jstride = (int)gridDim.x * 64;
-    Rec nxt = fetch(A.j0 + (int)blockIdx.x * 64);
-    for (int jb = A.j0 + blockIdx.x * 64; jb < A.j1; jb += jstride) {
+    auto fetch = [&](int itb) {
+        const int jl = walk_n > 0 ? atom_of(itb + (int)(threadIdx.x >> 2)) : 0;
+        return fetch_atom(jl);
+    };
+    const int jstride = npb * 64;
+    // the first records are on their way (the candidate slot came with the flags) while the small set is staged
+    Rec nxt;
+    if (pb >= 0) {
+        const int it0 = pb * 64 + (int)(threadIdx.x >> 2);
+        nxt = fetch_atom(full ? min(A.j0 + it0, A.j1 - 1) : spec);       // (every slot of `cand` holds an atom, also beyond the list)
+        for (int k = threadIdx.x; k < A.ns; k += 256) {
+            const int i = A.small[k];
+            s_pos[k] = make_double4(A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2], A.q[i]);
+            s_lj[k] = make_double2(A.hsig[i], A.seps2[i]);
+            if (listing) {
+                s_ref[k][0] = A.xref[3 * i];
+                s_ref[k][1] = A.xref[3 * i + 1];
+                s_ref[k][2] = A.xref[3 * i + 2];
+            }
+        }
+        __syncthreads();
+    }
+    for (int itb = pb * 64; pb >= 0 && itb < walk_n; itb += jstride) {
         const Rec cur = nxt;
-        if (jb + jstride < A.j1) nxt = fetch(jb + jstride);
-        const int j = jb + (threadIdx.x >> 2);
-        const bool in = j < A.j1;
+        if (itb + jstride < walk_n) nxt = fetch(itb + jstride);
+        const bool in = itb + (int)(threadIdx.x >> 2) < walk_n;
+        const int j = cur.j;
         const float code = in ? cur.code : 0.f;
         const double px = cur.px, py = cur.py, pz = cur.pz;
         const double qj = c.Kc * cur.q;
         const double2 lj = cur.lj;
         const bool partner = in && code != 0.f && code != A.small_code;       // an atom of the other (large) set
         double fx = 0.0, fy = 0.0, fz = 0.0;
+        if (listing) {
+            // candidate test in the companion's reference positions (lane `sub` takes every fourth small atom, as below)
+            const double rx = A.xref[3 * j], ry = A.xref[3 * j + 1], rz = A.xref[3 * j + 2];
+            bool near = false;
+            for (int kk = sub; kk < A.ns; kk += 4) {
+                const double ddx = amm_min_image(rx - s_ref[kk][0], A.box.L[0], A.box.invL[0]);
+                const double ddy = amm_min_image(ry - s_ref[kk][1], A.box.L[1], A.box.invL[1]);
+                const double ddz = amm_min_image(rz - s_ref[kk][2], A.box.L[2], A.box.invL[2]);
+                near = near || (ddx * ddx + ddy * ddy + ddz * ddz < A.r2cand);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(near && partner);
+            const unsigned int four = (unsigned int)(m >> (lane & ~3)) & 15u;          // the four lanes of this atom
+            if (sub == 0 && four != 0u) A.cand[atomicAdd(&A.cstate[2], 1)] = j;
+        }
         // (a wavefront without an atom of the large set has nothing to do: wave-uniform)
         if (AMM_SG_EXP != 3 && __builtin_amdgcn_ballot_w64(partner) != 0ull) {
             for (int k0 = 0; k0 < A.ns; k0 += 16) {
@@ -184,17 +260,24 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
                 // sub = s.  Through LDS: every lane parks its twelve values ([value][lane], rows padded against bank conflicts),
                 // lane 4 v + s adds value v of the lanes s, s + 4, ... in lane order -- a fixed order, and a tenth of the
                 // cross-lane traffic of the six-round butterflies that stood here first (17 us of this kernel then)
-                double(*tr)[65] = s_tr[w];
+                long long(*tr)[65] = s_tr[w];
                 __builtin_amdgcn_wave_barrier();                  // the previous trip's reads are done
+                bool big = false;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) tr[3 * u + d][lane] = rr[u][d];
+                    for (int d = 0; d < 3; ++d) {
+                        // fixed point BEFORE the lanes are added: integers commute, so the sum does not depend on which atoms
+                        // share a wavefront (the candidate walk groups them differently from the walk over every atom)
+                        big = big || !(fabs(rr[u][d]) < AMM_FIX_MAX / 16);     // (NaN too; sixteen lanes add up below)
+                        tr[3 * u + d][lane] = __double2ll_rn(rr[u][d] * AMM_FIX_SCALE);
+                    }
+                if (big) A.overflow[0] = 1;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int v = min(lane >> 2, 11);
-                double part = 0.0;
+                long long part = 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) part += tr[v][sub + 4 * i];
                 // (small atom of this sum: k0 + 4 (v / 3) + sub, component v % 3; skipped when no lane holds a pair with it)
@@ -207,10 +290,7 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
                     const bool hit = (m & (0x1111111111111111ull << sub)) != 0ull;
                     mine = mine || (u == ku && hit);
                 }
-                if (lane < 48 && mine && ksum < A.ns) {
-                    if (!(fabs(part) < AMM_FIX_MAX)) A.overflow[0] = 1;           // (NaN too)
-                    atomicAdd(&A.acc[3 * ksum + kd], (unsigned long long)__double2ll_rn(part * AMM_FIX_SCALE));
-                }
+                if (lane < 48 && mine && ksum < A.ns) atomicAdd(&A.acc[3 * ksum + kd], (unsigned long long)part);
             }
         }
         // the four lanes' shares of the force on j
@@ -236,7 +316,7 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
             }
         }
     }
-    if (EN) {
+    if (EN && pb >= 0) {
         __shared__ double red[4];
         for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off);
         if (lane == 0) red[w] = esum;
@@ -246,7 +326,13 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
 #if AMM_SG_EXP == 2            // measurement only: no ticket, no tail
     return;
 #endif
-    if (!amm_last_block(A.ticket)) return;
+    if (!(full ? amm_last_block(A.ticket) : amm_last_of(A.ticket, ticket_n))) return;
+    if (!full && threadIdx.x == 0) A.cstate[3] += 1;
+    if (listing && threadIdx.x == 0) {         // the list this launch made serves from the next launch on
+        A.cstate[0] = amm_ld_l2(&A.cstate[2]);
+        A.cstate[1] = (int)A.lcounters[0];
+        amm_st_l2(&A.cstate[2], 0);
+    }
     // ---- last block: accumulators -> force rows of the small set; the accumulators are cleared for the next launch ----
     for (int t = threadIdx.x; t < A.ns * 3; t += 256) {
         const long long fixed = (long long)amm_ld_l2(&A.acc[t]);
@@ -266,11 +352,14 @@ struct SmallGroup {
     int *d_ticket = nullptr, *d_overflow = nullptr;
     double *d_epart = nullptr;
     int nblocks = 0;
+    // candidate rows (SmallArgs): the force's own rows, the list and its state
+    double *d_fpair = nullptr;
+    int *d_cand = nullptr, *d_cstate = nullptr;
 };
 
 int amm_small_group_free(SmallGroup *sg) {
     if (!sg) return 0;
-    void *ptrs[] = {sg->d_small, sg->d_acc, sg->d_ticket, sg->d_epart, sg->d_overflow};
+    void *ptrs[] = {sg->d_small, sg->d_acc, sg->d_ticket, sg->d_epart, sg->d_overflow, sg->d_fpair, sg->d_cand, sg->d_cstate};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete sg;
@@ -309,7 +398,7 @@ int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> 
     AMM_HIP(hipMemset(sg->d_acc, 0, sizeof(unsigned long long) * sg->ns * 3));
     AMM_HIP(hipMalloc(&sg->d_ticket, sizeof(int) * AMM_TICKET_INTS));
     AMM_HIP(hipMemset(sg->d_ticket, 0, sizeof(int) * AMM_TICKET_INTS));
-    AMM_HIP(hipMalloc(&sg->d_epart, sizeof(double) * sg->nblocks));
+    AMM_HIP(hipMalloc(&sg->d_epart, sizeof(double) * (sg->nblocks + 64)));
     AMM_HIP(hipMalloc(&sg->d_overflow, sizeof(int)));
     AMM_HIP(hipMemset(sg->d_overflow, 0, sizeof(int)));
     pf->small = sg;
@@ -330,8 +419,9 @@ static void launch_small(hipStream_t st, int nblocks, bool guard, bool en, const
 
 // same contract as amm_pair_eval_impl (no guest, no exchange); returns -1 when the force's family has no instantiation here
 int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy,
-                              BondedSet *carry_terms) {
+                              BondedSet *carry_terms, const double **own_rows) {
     SmallGroup *sg = pf->small;
+    if (own_rows) *own_rows = nullptr;
     hipStream_t st = ctx->stream;
     const int fam = pf->desc.family;
     const bool grouped = (pf->pc.flags & (AMM_GROUP_LJ | AMM_GROUP_Q)) != 0;
@@ -362,6 +452,44 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     A.overflow = sg->d_overflow;
     A.ticket = sg->d_ticket;
     A.epart = sg->d_epart;
+    A.cand_on = A.cand_trust = 0;
+    A.xref = nullptr;
+    A.lflags = nullptr;
+    A.lcounters = nullptr;
+    A.r2cand = 0.0;
+    A.cand = nullptr;
+    A.cstate = nullptr;
+    if (own_rows && ctx->opt_group_candidates && ctx->world == 1 && !accumulate && !d_energy) {
+        // the companion: a molecule-row list of the context (its reference positions and its flag cover EVERY atom, the atoms
+        // outside the molecules too); the caller reads this force's rows from the force's own buffer
+        const ClusterList *cl = nullptr;
+        for (auto &fo : ctx->forces)
+            if (fo.type == 1 && fo.pair->cl && fo.pair->cl->built && fo.pair->last_kind >= 1 && !fo.pair->host) {
+                cl = fo.pair->cl;
+                break;
+            }
+        if (cl) {
+            if (!sg->d_fpair) {
+                AMM_HIP(hipMalloc(&sg->d_fpair, sizeof(double) * 3 * (size_t)n));
+                AMM_HIP(hipMalloc(&sg->d_cand, sizeof(int) * (size_t)n));
+                AMM_HIP(hipMemset(sg->d_cand, 0, sizeof(int) * (size_t)n));
+                AMM_HIP(hipMalloc(&sg->d_cstate, sizeof(int) * 4));
+                const int init[4] = {0, -1, 0, 0};
+                AMM_HIP(hipMemcpy(sg->d_cstate, init, sizeof(init), hipMemcpyHostToDevice));
+            }
+            A.cand_on = 1;
+            A.cand_trust = ((cl->pre_epoch == ctx->pos_epoch && cl->pre_pos == d_pos) || (cl->checked_epoch == ctx->pos_epoch && cl->checked_pos == d_pos)) ? 1 : 0;
+            A.xref = cl->d_xref;
+            A.lflags = cl->d_flags;
+            A.lcounters = cl->d_counters;
+            const double reach = std::sqrt(pf->pc.rc2) + cl->skin;
+            A.r2cand = reach * reach;
+            A.cand = sg->d_cand;
+            A.cstate = sg->d_cstate;
+            A.force = sg->d_fpair;
+            *own_rows = sg->d_fpair;
+        }
+    }
     // AMM_SG_BPC blocks per CU at most (grid stride in the kernel)
     static int ncu_dev[64] = {0};
     int &ncu = ncu_dev[ctx->device & 63];
@@ -382,6 +510,7 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
         AMM_HIP(hipEventRecord(e0, st));
     }
     TermsWork T;
+    T.nblocks = 0;
     T.nterms = 0;
     T.list = nullptr;
     T.gt_a = nullptr;
@@ -392,14 +521,27 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     } else {
         std::memset(&T.A, 0, sizeof(T.A));
     }
-    if (fam == AMM_SOFTCORE) launch_small<AMM_SOFTCORE, false>(st, nblocks, false, en, A, pf->pc, T);
-    else if (fam == AMM_NEAR_FSWITCH) launch_small<AMM_NEAR_FSWITCH, true>(st, nblocks, guard, en, A, pf->pc, T);
-    else launch_small<AMM_NONBONDED, true>(st, nblocks, false, en, A, pf->pc, T);
+    T.nblocks = std::min(64, (T.nterms + 255) / 256);
+    const int grid = nblocks + T.nblocks;
+    if (fam == AMM_SOFTCORE) launch_small<AMM_SOFTCORE, false>(st, grid, false, en, A, pf->pc, T);
+    else if (fam == AMM_NEAR_FSWITCH) launch_small<AMM_NEAR_FSWITCH, true>(st, grid, guard, en, A, pf->pc, T);
+    else launch_small<AMM_NONBONDED, true>(st, grid, false, en, A, pf->pc, T);
     if (timed) AMM_HIP(hipEventRecord(e1, st));
     AMM_HIP(hipGetLastError());
-    if (en && amm_reduce_add(ctx, sg->d_epart, nblocks, 1.0, d_energy)) return 1;
+    if (en && amm_reduce_add(ctx, sg->d_epart, grid, 1.0, d_energy)) return 1;
     pf->n_evals++;
     pf->last_kind = 3;
+    return 0;
+}
+
+// out[0] = candidates of the current list, out[1] = evaluations that walked candidates only (the caller has synchronised)
+int amm_small_group_stats(SmallGroup *sg, int out[2]) {
+    out[0] = out[1] = 0;
+    if (!sg->d_cstate) return 0;
+    int st[4];
+    if (hipMemcpy(st, sg->d_cstate, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    out[0] = st[0];
+    out[1] = st[3];
     return 0;
 }
 

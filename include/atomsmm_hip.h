@@ -311,6 +311,9 @@ typedef struct {
                                force's sites share one sigma, eps and charge: water) instead of Lennard-Jones arithmetic */
     int32_t n_rest_atoms;   /* hybrid lists: atoms outside the three-site molecules (0: none, or the force keeps per-atom rows) */
     double site_tab_error;  /* its largest relative interpolation error (bound 3e-13: the r^-14 wall) */
+    int32_t n_candidates;   /* list_kind 3 on a fused inner loop: atoms within cutoff + buffer of the small set at the companion
+                               list's last build (the later evaluations walk these only); 0: every evaluation walks every atom */
+    int32_t n_candidate_walks;  /* evaluations that walked the candidates only */
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
 /* Measurement helper (bench.py): the number of directed list entries of this force with r < r_within at d_pos, counted in

@@ -122,13 +122,54 @@ def test_c5_fused_inner_iterations_bit_identical():
         integrator.step(12)
         st = context.getState(getPositions=True, getVelocities=True)
         builds = context._engine.ctx.pair_stats(context._engine.pair_force_ids(2)[0])['n_builds']
-        return st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value, builds
+        soft = [context._engine.ctx.pair_stats(pid) for pid in context._engine.pair_force_ids(0)]
+        soft = [s_ for s_ in soft if s_['list_kind'] == 3]
+        assert len(soft) == 1
+        return st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value, builds, soft[0]
 
-    x1, v1, b1 = run(True)
-    x0, v0, b0 = run(False)
+    x1, v1, b1, s1 = run(True)
+    x0, v0, b0, s0 = run(False)
     assert b1 == b0 and b1 >= 2
     assert np.array_equal(x1, x0) and np.array_equal(v1, v0)
     assert np.isfinite(x1).all()
+    # the fused iterations walked the atoms near the solute only (all but the evaluation after each build of the companion
+    # list); one launch per op walks every atom every time
+    n_eval = 12 * 8
+    assert s1['n_candidate_walks'] >= n_eval - 3 * b1 - 4 and 30 < s1['n_candidates'] < len(x1) // 2, s1
+    assert s0['n_candidate_walks'] == 0 and s0['n_candidates'] == 0, s0
+
+
+def test_c5_candidate_walks_bit_identical():
+    """Fused inner iterations with and without the candidate walk of the list-free softcore force (option group_candidates):
+    the same trajectory bit for bit, through list rebuilds, after a jump of the positions set from the host, and with the
+    buffer of the companion list nearly used up (a small skin: many rebuilds)."""
+    case = solvated_chain(nside=12, n_chain=300, n_solute=30)
+
+    def run(cand, skin):
+        respa = build_c5_system(case)
+        integrator = atomsmm.RespaPropagator([4, 2, 1]).integrator(2 * unit.femtoseconds)
+        context = openmm.Context(respa, integrator, None, {'Skin': str(skin)})
+        context._engine.ctx.set_option('group_candidates', cand)
+        context._engine.ctx.set_option('terms_from', 1)
+        context.setPositions(case['positions'] * unit.nanometers)
+        context.setVelocities(case['velocities'])
+        context.setParameter('lambda_vdw', 0.7)
+        integrator.step(6)
+        x = context.getState(getPositions=True).getPositions(asNumpy=True)._value
+        shifted = x.copy()
+        shifted[case['solute']] += np.array([0.31, -0.17, 0.23])        # the solute jumps: other waters are its neighbours now
+        context.setPositions(shifted * unit.nanometers)
+        integrator.step(6)
+        st = context.getState(getPositions=True, getVelocities=True)
+        soft = [s_ for s_ in (context._engine.ctx.pair_stats(pid) for pid in context._engine.pair_force_ids(0)) if s_['list_kind'] == 3]
+        return st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value, soft[0]
+
+    for skin in (0.1, 0.03):
+        x1, v1, s1 = run(1, skin)
+        x0, v0, s0 = run(0, skin)
+        assert s1['n_candidate_walks'] > 20 and s0['n_candidate_walks'] == 0, (s1, s0)
+        assert np.array_equal(x1, x0) and np.array_equal(v1, v0)
+        assert np.isfinite(x1).all()
 
 
 def test_c5_full_size_fused_inner_iterations_bit_identical():
