@@ -215,19 +215,23 @@ struct CBoxF {
 // One wavefront per (cell, part); a batch of CB_BATCH row molecules lives in scalar registers.  Two passes over the candidates:
 //   1. the stencil's molecules are walked as ONE concatenated stream (lane = candidate; piece table + binary search as in
 //      pair.hip's build) and tested by their FIRST atoms against a sphere that is guaranteed to contain every partner
-//      (|x0_i - x0_j| < rlist + ext_i + ext_j): 10 instructions per 64 candidates and row molecule; the survivors (a sixth of
-//      the stream) are queued in LDS, per row molecule (a ring of 256);
-//   2. as soon as a ring holds 64 it is drained with ALL 64 lanes busy: three records per candidate, the nine atom-pair distances, the smallest
-//      decides (< rlist: listed; < rnear: front part), ordered ballot compaction into the row.
+//      (|x0_i - x0_j| < rlist + ext_i + ext_j), two chunks of 64 side by side in packed fp32 (v_pk_*_f32): 9 instructions per 128
+//      candidates and row molecule + the filing of the hits; the survivors (a fifth of the stream) are queued in LDS, per row
+//      molecule (a ring of 256);
+//   2. as soon as a ring holds 128 it is drained with ALL 64 lanes busy, two survivors per lane (packed again): three records per
+//      candidate, the nine atom-pair distances, the smallest decides (< rlist: listed; < rnear: front part), ordered ballot
+//      compaction into the row.
+// A candidate's piece of the stream (which stencil cell, hence which periodic shift) comes from a coarse table (piece of every
+// 8th stream position, built once per wavefront) + a short walk, not from a binary search per candidate.
 // The old per-atom build spent 42 instructions per 64 ATOM-pair tests, mostly compaction; here the compaction is paid per
 // MOLECULE pair and only for a stream that is already 80 % hits.
 #ifndef CB_BATCH
 #define CB_BATCH 5
 #endif
-#ifndef CB_QCAP
-#define CB_QCAP 192         // ring of survivors per row molecule: >= 63 + 128 (a drain leaves at most 63 behind, a chunk pair adds 128)
-#endif
-__device__ __forceinline__ int cq_wrap(int i) { return i >= CB_QCAP ? i - CB_QCAP : i; }      // i < 2 CB_QCAP
+#define CB_COARSE 256       // entries of the coarse piece table
+#define CB_QCAP 256         // ring of survivors per row molecule: >= 127 + 128 (a drain leaves at most 127 behind, a chunk pair adds 128)
+__device__ __forceinline__ int cq_wrap(int i) { return i & (CB_QCAP - 1); }
+typedef float v2f __attribute__((ext_vector_type(2)));        // two fp32 per lane: v_pk_add / v_pk_mul / v_pk_fma_f32 at the rate of one
 
 __device__ void cfinish_build_block(int *flags, unsigned long long *counters, const unsigned long long *blockstats, int nblocks, int count_only) {
     __shared__ unsigned long long sh_part[4][3];
@@ -270,8 +274,13 @@ __device__ void cfinish_build_block(int *flags, unsigned long long *counters, co
     }
 }
 
+// (the packed drain wants 104 registers = 4 wavefronts per SIMD; at 96 = 5 the rebuild of the 98 304-atom box is 10 us shorter)
+#ifndef CB_WAVES
+#define CB_WAVES 5
+#endif
+#define CB_OCC __attribute__((amdgpu_waves_per_eu(CB_WAVES)))
 template <bool COUNT_ONLY, bool RINT>
-__global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int parts, const int *__restrict__ cell_start,
+__global__ void __launch_bounds__(256) CB_OCC k_cbuild(int c_begin, int c_end, int parts, const int *__restrict__ cell_start,
                                                 const float4 *__restrict__ pos4f, CBoxF box, CellGrid g, float rlist, float rnear2, int cap,
                                                 int *nl, int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
                                                 unsigned long long *counters, int *ticket, int force) {
@@ -280,6 +289,7 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
     __shared__ int s_rpref[4][128];
     __shared__ float s_rshift[4][3][128];
     __shared__ int s_q[4][CB_BATCH][CB_QCAP];        // per row molecule: ring of survivors of the sphere test (sorted slots)
+    __shared__ unsigned char s_coarse[4][CB_COARSE]; // piece of stream position e << cshift
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int c = wave / parts, part = wave - c * parts;
@@ -341,6 +351,21 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        // coarse table: the piece of every (1 << cshift)-th stream position (the last piece that starts at or before it)
+        int cshift = 3;
+        while (((total + 127) >> cshift) > CB_COARSE) ++cshift;
+#pragma unroll
+        for (int q = 0; q < CB_COARSE / 64; ++q) {
+            const int idx = (lane + 64 * q) << cshift;
+            int r = 0;
+#pragma unroll
+            for (int step = 64; step > 0; step >>= 1)
+                if (s_rpref[w][r + step] <= idx) r += step;
+            s_coarse[w][lane + 64 * q] = (unsigned char)r;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int tb = a_begin; tb < a_end; tb += CB_BATCH) {
             const int nt = min(CB_BATCH, a_end - tb);
             // the batch's atoms: lane 3 t + a holds atom a of row molecule t; the loops over t below are REAL loops (t is a scalar
@@ -351,17 +376,24 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
             int row_cnt = 0;          // lane t: entries of row t so far (front | back << 16)
             int q_head = 0, q_cnt = 0;    // lane t: ring of row t (head index, entries waiting)
             auto rl = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-            // ---- pass 2: 64 queued survivors of row t (n of them valid): nine distances, the smallest decides ----
+            // ---- pass 2: 128 queued survivors of row t (n of them valid), two per lane (lane, lane + 64) so that the arithmetic runs
+            // on packed fp32: nine distances each, the smallest decides; the two halves are filed one after the other (ring order) ----
             auto drain = [&](int t, int n) {
                 const int head = __builtin_amdgcn_readlane(q_head, t);
-                const bool v0 = lane < n;
-                const int slot = v0 ? s_q[w][t][cq_wrap(head + lane)] : tb + t;
-                const bool v = v0 && slot != tb + t;          // (a molecule is not its own partner)
-                float4 A[3];
-                A[0] = pos4f[3 * slot];
-                A[1] = pos4f[3 * slot + 1];
-                A[2] = pos4f[3 * slot + 2];
-                const int sites = __float_as_int(A[1].w);
+                int slot[2];
+                bool v[2];
+                float4 A[2][3];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bool v0 = lane + 64 * u < n;
+                    slot[u] = v0 ? s_q[w][t][cq_wrap(head + lane + 64 * u)] : tb + t;
+                    v[u] = v0 && slot[u] != tb + t;          // (a molecule is not its own partner)
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) A[u][b] = pos4f[3 * slot[u] + b];
+                const int sites[2] = {__float_as_int(A[0][1].w), __float_as_int(A[1][1].w)};
                 float px[3], py[3], pz[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
@@ -369,47 +401,62 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
                     py[a] = rl(my.y, 3 * t + a);
                     pz[a] = rl(my.z, 3 * t + a);
                 }
+                v2f ax[3], ay[3], az[3];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    ax[b] = v2f{A[0][b].x, A[1][b].x};
+                    ay[b] = v2f{A[0][b].y, A[1][b].y};
+                    az[b] = v2f{A[0][b].z, A[1][b].z};
+                }
                 if (!RINT) {          // one periodic image per molecule pair, from the first atoms
-                    const float sx = box.L[0] * rintf((A[0].x - px[0]) * box.invL[0]);
-                    const float sy = box.L[1] * rintf((A[0].y - py[0]) * box.invL[1]);
-                    const float sz = box.L[2] * rintf((A[0].z - pz[0]) * box.invL[2]);
+                    const v2f sx = box.L[0] * __builtin_elementwise_rint((ax[0] - px[0]) * box.invL[0]);
+                    const v2f sy = box.L[1] * __builtin_elementwise_rint((ay[0] - py[0]) * box.invL[1]);
+                    const v2f sz = box.L[2] * __builtin_elementwise_rint((az[0] - pz[0]) * box.invL[2]);
 #pragma unroll
                     for (int b = 0; b < 3; ++b) {
-                        A[b].x -= sx;
-                        A[b].y -= sy;
-                        A[b].z -= sz;
+                        ax[b] -= sx;
+                        ay[b] -= sy;
+                        az[b] -= sz;
                     }
                 }
-                float m2 = 3.0e38f;
+                v2f m2 = v2f{3.0e38f, 3.0e38f};
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
                     for (int b = 0; b < 3; ++b) {
-                        float dx = px[a] - A[b].x, dy = py[a] - A[b].y, dz = pz[a] - A[b].z;
+                        v2f dx = px[a] - ax[b], dy = py[a] - ay[b], dz = pz[a] - az[b];
                         if (RINT) {
-                            dx -= box.L[0] * rintf(dx * box.invL[0]);
-                            dy -= box.L[1] * rintf(dy * box.invL[1]);
-                            dz -= box.L[2] * rintf(dz * box.invL[2]);
+                            dx -= box.L[0] * __builtin_elementwise_rint(dx * box.invL[0]);
+                            dy -= box.L[1] * __builtin_elementwise_rint(dy * box.invL[1]);
+                            dz -= box.L[2] * __builtin_elementwise_rint(dz * box.invL[2]);
                         }
-                        m2 = fminf(m2, dx * dx + dy * dy + dz * dz);
+                        v2f r2 = dx * dx;
+                        r2 = __builtin_elementwise_fma(dy, dy, r2);
+                        r2 = __builtin_elementwise_fma(dz, dz, r2);
+                        m2 = __builtin_elementwise_min(m2, r2);
                     }
-                const unsigned long long m_pass = __builtin_amdgcn_ballot_w64(v && m2 < rlist2);
-                if (m_pass != 0ull) {
-                    const unsigned long long m_near = m_pass & __builtin_amdgcn_ballot_w64(m2 < rnear2);
-                    const int np_ = __popcll(m_pass), nn_ = __popcll(m_near);
-                    const int c2 = __builtin_amdgcn_readlane(row_cnt, t);
-                    const int cnt = c2 & 0xffff, cntf = (int)((unsigned)c2 >> 16);
-                    if (!COUNT_ONLY) {
-                        const int mp = __builtin_amdgcn_mbcnt_hi((unsigned)(m_pass >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_pass, 0u));
-                        const int mn = __builtin_amdgcn_mbcnt_hi((unsigned)(m_near >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_near, 0u));
-                        const int pos_near = cnt + mn, pos_far = (cap - 1 - cntf) - (mp - mn);
-                        const bool is_near = (m_near >> lane) & 1ull;
-                        if (cnt + cntf + np_ <= cap) {
-                            int *row_out = nl + (size_t)(tb + t - c_begin) * cap;
-                            if ((m_pass >> lane) & 1ull) row_out[is_near ? pos_near : pos_far] = slot | (sites << 29);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float m2u = u ? m2.y : m2.x;
+                    const bool pass = v[u] && m2u < rlist2;
+                    const unsigned long long m_pass = __builtin_amdgcn_ballot_w64(pass);
+                    if (m_pass != 0ull) {
+                        const bool is_near = pass && m2u < rnear2;
+                        const unsigned long long m_near = __builtin_amdgcn_ballot_w64(is_near);
+                        const int np_ = __popcll(m_pass), nn_ = __popcll(m_near);
+                        const int c2 = __builtin_amdgcn_readlane(row_cnt, t);
+                        const int cnt = c2 & 0xffff, cntf = (int)((unsigned)c2 >> 16);
+                        if (!COUNT_ONLY) {
+                            const int mp = __builtin_amdgcn_mbcnt_hi((unsigned)(m_pass >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_pass, 0u));
+                            const int mn = __builtin_amdgcn_mbcnt_hi((unsigned)(m_near >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_near, 0u));
+                            const int pos_near = cnt + mn, pos_far = (cap - 1 - cntf) - (mp - mn);
+                            if (cnt + cntf + np_ <= cap) {
+                                int *row_out = nl + (size_t)(tb + t - c_begin) * cap;
+                                if (pass) row_out[is_near ? pos_near : pos_far] = slot[u] | (sites[u] << 29);
+                            }
                         }
+                        row_cnt = lane == t ? c2 + nn_ + ((np_ - nn_) << 16) : row_cnt;
                     }
-                    row_cnt = lane == t ? c2 + nn_ + ((np_ - nn_) << 16) : row_cnt;
                 }
                 q_head = lane == t ? cq_wrap(head + n) : q_head;
                 q_cnt = lane == t ? q_cnt - n : q_cnt;
@@ -421,10 +468,9 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
                 for (int u = 0; u < 2; ++u) {
                     const int idx = cb + u * 64 + lane;
                     const bool in = idx < total;
-                    int r = 0;
-#pragma unroll
-                    for (int step = 64; step > 0; step >>= 1)
-                        if (s_rpref[w][r + step] <= idx) r += step;
+                    // (idx < total + 128 <= CB_COARSE << cshift; beyond the stream every piece "starts" at `total`: the walk stops)
+                    int r = s_coarse[w][idx >> cshift];
+                    while (r < 127 && s_rpref[w][r + 1] <= idx) ++r;
                     const int slot = in ? s_rstart[w][r] + idx - s_rpref[w][r] : 0;
                     float4 q = pos4f[3 * slot];
                     if (!RINT) {
@@ -442,38 +488,44 @@ __global__ void __launch_bounds__(256) k_cbuild(int c_begin, int c_end, int part
             float4 cand[2], cand_n[2];
             int js[2], js_n[2];
             fetch(0, cand, js);
+            // (lane 3 t: the radius of row t's sphere without the candidate's own extent)
+            const float plim_l = my.w + rlist;
             for (int cb = 0; cb < total; cb += 128) {
                 if (cb + 128 < total) fetch(cb + 128, cand_n, js_n);
+                // the two chunks side by side in packed registers (a chunk beyond the stream holds far-away / never-reached candidates)
+                const v2f cx = v2f{cand[0].x, cand[1].x}, cy = v2f{cand[0].y, cand[1].y}, cz = v2f{cand[0].z, cand[1].z};
+                const v2f cw = v2f{cand[0].w, cand[1].w};
                 for (int t = 0; t < nt; ++t) {
-                    const float p0x = rl(my.x, 3 * t), p0y = rl(my.y, 3 * t), p0z = rl(my.z, 3 * t), plim = rlist + rl(my.w, 3 * t);
+                    const float p0x = rl(my.x, 3 * t), p0y = rl(my.y, 3 * t), p0z = rl(my.z, 3 * t), plim = rl(plim_l, 3 * t);
                     int qn = __builtin_amdgcn_readlane(q_cnt, t);
                     const int head = __builtin_amdgcn_readlane(q_head, t);
+                    v2f dx = p0x - cx, dy = p0y - cy, dz = p0z - cz;
+                    if (RINT) {
+                        dx -= box.L[0] * __builtin_elementwise_rint(dx * box.invL[0]);
+                        dy -= box.L[1] * __builtin_elementwise_rint(dy * box.invL[1]);
+                        dz -= box.L[2] * __builtin_elementwise_rint(dz * box.invL[2]);
+                    }
+                    v2f r2 = dx * dx;
+                    r2 = __builtin_elementwise_fma(dy, dy, r2);
+                    r2 = __builtin_elementwise_fma(dz, dz, r2);
+                    const v2f lim = plim + cw;
+                    const v2f lim2 = lim * lim;
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        if (cb + u * 64 >= total) continue;
-                        float dx = p0x - cand[u].x, dy = p0y - cand[u].y, dz = p0z - cand[u].z;
-                        if (RINT) {
-                            dx -= box.L[0] * rintf(dx * box.invL[0]);
-                            dy -= box.L[1] * rintf(dy * box.invL[1]);
-                            dz -= box.L[2] * rintf(dz * box.invL[2]);
-                        }
-                        const float r2 = dx * dx + dy * dy + dz * dz;
-                        const float lim = plim + cand[u].w;
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(r2 < lim * lim && lim > 0.f);
+                        // (!RINT: a candidate beyond the stream sits 1e9 away; RINT: its extent is -1e9, lim < 0)
+                        const bool pass = (u ? r2.y < lim2.y : r2.x < lim2.x) && (!RINT || (u ? lim.y : lim.x) > 0.f);
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
                         if (m == 0ull) continue;
                         const int at = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        if ((m >> lane) & 1ull) s_q[w][t][cq_wrap(head + at)] = js[u];
+                        if (pass) s_q[w][t][cq_wrap(head + at)] = js[u];
                         qn += __popcll(m);
                     }
                     q_cnt = lane == t ? qn : q_cnt;
-                    if (qn >= 64) {
+                    if (qn >= 128) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        while (qn >= 64) {
-                            drain(t, 64);
-                            qn -= 64;
-                        }
+                        drain(t, 128);
                     }
                 }
 #pragma unroll
