@@ -1971,7 +1971,14 @@ class Engine:
             env.update(zip(integ._gnames, integ._gvalues))
             env['dt'] = integ._dt
 
+            # After a blocking read the GPU has nothing queued: the next ops go out in small batches (at the first moves, i.e. at
+            # the end of a kick ... move pattern that amm_run_ops fuses) instead of waiting for the host to walk the whole block
+            # -- at config C5 the GPU sat idle for 0.26 ms per AFED step behind the read of deriv(energy, lambda)
+            eager = [0]
+
             def settle():
+                if self._pending is not None and self._pending[1] > 0:
+                    eager[0] = 3
                 self._settle([env, integ._gvalues])
 
             def deferred_in(text):
@@ -2013,7 +2020,7 @@ class Engine:
                     # copies) emits the same ops whenever the globals it names, the valid force groups and the mirrored buffers
                     # are the same: remembered as ONE unit (the host was slower than the GPU at config C5 walking it step by step)
                     pc_end = self._run_end(steps, pc)
-                    if pc_end - pc >= 4 and self._replay_segment(pc, pc_end, steps, env, ops, valid):
+                    if pc_end - pc >= 4 and not eager[0] and self._replay_segment(pc, pc_end, steps, env, ops, valid):
                         pc = pc_end
                         continue
                 if kind == C.ComputeGlobal:
@@ -2047,6 +2054,9 @@ class Engine:
                         except (NotImplementedError, NameError, SyntaxError, TypeError):
                             done = False
                         self._record_segment(pc, done, ops, valid)
+                        if done and eager[0] and target == 'x':
+                            eager[0] -= 1
+                            flush()
                     if not done:
                         prog = X.compile_per_dof(expr, resolve)
                         flush()                                   # EVALs emitted by resolve() run first

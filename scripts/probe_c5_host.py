@@ -18,7 +18,7 @@ def main():
     args = ap.parse_args()
     import torch
     import bench
-    sim, case = bench.build_simulation_c5((2, 2, 1), 1.0)
+    sim, case = bench.build_simulation_c5((4, 2, 1), 2.0)
     sim.step(5)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
