@@ -37,7 +37,7 @@ EXPORTS = [
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read', 'amm_pair_count_within', 'amm_pair_row_padding', 'amm_kernel_revision',
     'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_bath_define_nhl', 'amm_bath_define_sin', 'amm_iso_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
     'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_destroy', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
-    'amm_set_option', 'amm_exchange_per',
+    'amm_set_option', 'amm_positions_changed', 'amm_exchange_per',
 ]
 
 
@@ -183,6 +183,7 @@ def lib():
         L.amm_bath_define_sin.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, ip]
         L.amm_iso_define.argtypes = [vp, C.c_int32, C.c_double, C.c_double, C.c_int32]
         L.amm_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+        L.amm_positions_changed.argtypes = [vp]
         L.amm_exchange_per.argtypes = [vp, ip]
         L.amm_expr_eval.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_uint64, C.c_uint64, vp, vp]
         for name in EXPORTS:
@@ -445,6 +446,10 @@ class HipContext:
     def set_option(self, name, value):
         """Tuning / test option of the context (include/atomsmm_hip.h: amm_set_option); set before the first evaluation."""
         _chk(lib().amm_set_option(self.h, name.encode(), float(value)))
+
+    def positions_changed(self):
+        """The bound position buffer was written outside the library (option 'positions_private')."""
+        _chk(lib().amm_positions_changed(self.h))
 
     def exchange_per(self):
         """Slots of the cell-sorted order per rank (whole molecules of three): chunk geometry of the exchange buffer."""

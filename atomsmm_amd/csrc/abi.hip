@@ -696,6 +696,12 @@ int amm_force_eval(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *
     return force_eval_dispatch(ctx, force_id, d_pos, d_force, accumulate, d_energy);
 }
 
+int amm_positions_changed(amm_ctx *ctx) {
+    if (!ctx) return 1;
+    ctx->pos_epoch++;
+    return 0;
+}
+
 int amm_kick(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int32_t plus, const double *d_mass, double coef) {
     return amm_kick_impl(ctx, d_v, d_f, d_f2, plus, d_mass, coef);
 }
@@ -715,6 +721,7 @@ int amm_expr_eval(amm_ctx *ctx, const int32_t *code, int32_t n_code, const doubl
         amm_set_error("amm_expr_eval: bad arguments");
         return 1;
     }
+    if (d_dst) ctx->pos_epoch++;          // (the destination may be the position buffer, or alias it)
     return amm_expr_eval_impl(ctx, code, n_code, consts, n_consts, globals, n_globals, seed, counter, d_dst, d_sum);
 }
 
@@ -925,7 +932,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
     }
     // user-visible buffers; the fused inner iteration ping-pongs between them and library-owned partners
     double *const user_x = ctx->d_x, *const user_v = ctx->d_v;
-    ctx->pos_epoch++;                 // the caller may have written the bound position buffer
+    if (!ctx->opt_positions_private) ctx->pos_epoch++;                 // the caller may have written the bound position buffer
     int f0_slot = -1;
     double *user_f0 = nullptr;
     bool swapped = false;
@@ -1503,6 +1510,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "fuse_rows") ctx->opt_fuse_rows = v;
     else if (k == "row_phases") ctx->opt_row_phases = v;
     else if (k == "group_candidates") ctx->opt_group_candidates = v;
+    else if (k == "positions_private") ctx->opt_positions_private = v;
     else if (k == "site_tab") ctx->opt_site_tab = v;
     else if (k == "no_defer") ctx->opt_no_defer = v;
     else if (k == "terms_from") ctx->opt_terms_from = v;

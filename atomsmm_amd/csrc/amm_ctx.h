@@ -283,6 +283,7 @@ struct amm_ctx {
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
     int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
     int opt_site_tab = 1;               // molecule rows: site-site radial tables instead of Lennard-Jones arithmetic where a force has one
+    int opt_positions_private = 0;      // amm_run_ops does not assume the caller moved the atoms between calls (amm_positions_changed says so)
     int opt_group_candidates = 1;       // list-free group forces on the fused inner loop: walk the atoms near the small set only while a companion list vouches for them
     int opt_row_phases = 1;             // molecule rows: the remainder of the rows after whole rounds of tasks goes out in smaller tasks (cpair_plan)
     int opt_fuse_rows = 1;              // molecule rows: host + guest force of a shared list in ONE launch when a fused kernel exists

@@ -796,6 +796,9 @@ __device__ __forceinline__ void cwalk_rows(const CPairArgs &A, const PairConsts 
 #ifndef AMM_CBS_SINGLE
 #define AMM_CBS_SINGLE 512
 #endif
+#ifndef AMM_CBS_NEAR          // one force per pass (the fused pass keeps AMM_CBS_SINGLE)
+#define AMM_CBS_NEAR 512
+#endif
 #ifndef AMM_CTAB_WAVES_PER_EU
 #define AMM_CTAB_WAVES_PER_EU 1
 #endif
@@ -984,8 +987,8 @@ static int g_num_cu_c[64] = {0};
 // every wavefront at 98 304 atoms (768 threads: 1.33 -- a third of the chip idles in the tail)
 template <int FAM, int CMODE, int GFAM, int SMASK>
 static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g) {
-    constexpr int BS = AMM_CBS_SINGLE;
     constexpr bool DUAL = GFAM >= 0;
+    constexpr int BS = DUAL ? AMM_CBS_SINGLE : AMM_CBS_NEAR;
     constexpr bool SS = SMASK != 0;
     static CLaunchCfg cfg[64];
     CLaunchCfg &k = cfg[ctx->device & 63];

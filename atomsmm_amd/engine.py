@@ -233,6 +233,10 @@ class Engine:
         self.parameters = {}
         self.entries = []
         self.skin = float(properties.get('Skin', -1.0))
+        # The engine is the only writer of the bound position buffer outside the library (set_positions): amm_run_ops may trust
+        # the displacement checks its own launches made at the end of the previous call
+        if hasattr(self.ctx, 'positions_changed'):
+            self.ctx.set_option('positions_private', 1)
         # 'Option.<name>': tuning / test options of the library context (include/atomsmm_hip.h: amm_set_option)
         for key, value in properties.items():
             if key.startswith('Option.') and hasattr(self.ctx, 'set_option'):
@@ -871,6 +875,8 @@ class Engine:
 
     def set_positions(self, arr):
         self.x.copy_(self.torch.as_tensor(arr, device=self.x.device))
+        if hasattr(self.ctx, 'positions_changed'):
+            self.ctx.positions_changed()
         self._invalidate_forces()
 
     def set_velocities(self, arr):

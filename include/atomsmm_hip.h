@@ -273,8 +273,14 @@ int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
  * forces with a set of <= 128 atoms are evaluated without a neighbour list), "rest_skin_factor" (Verlet buffer of a hybrid list's
  * per-atom part as a multiple of its molecule rows' buffer, default 2; set before amm_pair_create), "mixed_terms", "tab" (tabulated
  * force-only kernels), "site_trips", "lanes_per_row", "build_parts", "unroll", "dual_unroll", "tab_block", "tab_dual_block",
- * "no_dual", "no_defer", "terms_from", "no_term_lanes".  Unknown names are an error. */
+ * "no_dual", "no_defer", "terms_from", "no_term_lanes", "row_phases" (1: the rows a molecule-row traversal cannot deal out in whole
+ * rounds of wavefront tasks go out in smaller tasks), "group_candidates" (1: a list-free group force on a fused inner loop walks only
+ * the atoms near its small set while a neighbour list of the context vouches for them), "positions_private" (1: the caller promises
+ * to call amm_positions_changed after writing the bound position buffer itself; amm_run_ops then trusts the displacement checks its
+ * own launches made at the end of the previous call instead of assuming that anything may have moved).  Unknown names are an error. */
 int amm_set_option(amm_ctx *ctx, const char *name, double value);
+/* The bound position buffer was written by the caller (needed only with option "positions_private"; harmless otherwise). */
+int amm_positions_changed(amm_ctx *ctx);
 /* slots of the cell-sorted order per rank (whole molecules of three: 3 ceil(ceil(n/3) / world)): the exchange buffer holds
  * world x 2 x per x 3 doubles and a chunk of a single / dual evaluation is [1 or 2][per][3] */
 int amm_exchange_per(amm_ctx *ctx, int32_t *per);

@@ -1158,6 +1158,53 @@ def test_c3_full_size_tip3p_respa():
     ctx.close()
 
 
+@pytest.mark.parametrize('nside', [24, 27])
+def test_row_phases_walk_every_row_once(nside):
+    """Molecule rows whose number is no multiple of what the resident wavefronts take per round (csrc/cluster.hip: cpair_plan --
+    whole rounds of the biggest tasks, the remainder in tasks of more lanes per row): nside 24 = 1 728 rows per XCD = one round
+    of 4-row tasks + one of 2-row tasks + 192 single rows; 27 = 2 461 rows per XCD.  Forces of the near force, the outer force
+    and the fused pass against the oracle, and against the same launch with one task size (option row_phases = 0): the same rows,
+    a different order of summation inside a row (lanes per row) -- agreement to rounding, not bit for bit."""
+    B = _backend()
+    from atomsmm_amd.testing import tip3p_box
+    c = tip3p_box(nside)
+    c['positions'] = c['positions'] + np.random.default_rng(nside).normal(0.0, 0.02, c['positions'].shape)
+    n = len(c['positions'])
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+    ref = {key: O.pair_eval(d, c['positions'], c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'], use_cells=True)[1]
+           for key, d in (('near', dn), ('far', dd))}
+    out = {}
+    for phases in (1, 0):
+        ctx = B.HipContext(n, c['box'])
+        ctx.set_option('row_phases', phases)
+        fn = hip_pair(B, ctx, dn, c)
+        ff = hip_pair(B, ctx, dd, c)
+        ctx.pair_share_list(fn, ff)
+        x, v, m = dev(c['positions']), dev(np.zeros((n, 3))), dev(c['mass'])
+        f = [torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda') for _ in range(3)]
+        ctx.bind_state(x, v, m)
+        for slot, buf in enumerate(f):
+            ctx.bind_buffer(slot, buf)
+        ctx.group_define(1, 1, [fn])
+        ctx.group_define(2, 2, [ff])
+        ctx.run_ops([B.Op(B.OP_EVAL, 1, 0, 0, 0.0), B.Op(B.OP_EVAL, 2, 0, 0, 0.0)], 1)        # the fused pass
+        ctx.check()
+        fused = (f[1].cpu().numpy().copy(), f[2].cpu().numpy().copy())
+        assert ctx.pair_stats(fn)['rode_along'] == 1 and ctx.pair_stats(ff)['list_kind'] == 1
+        alone = torch.full((n, 3), float('nan'), dtype=torch.float64, device='cuda')
+        ctx.force_eval(fn, x, alone)                                                         # the near force's own launch
+        ctx.check()
+        out[phases] = fused + (alone.cpu().numpy().copy(),)
+        ctx.close()
+    for phases in (1, 0):
+        for got, key in zip(out[phases], ('near', 'far', 'near')):
+            assert np.isfinite(got).all()
+            assert np.abs(got - ref[key]).max() <= 1e-9 * np.abs(ref[key]).max()
+    for a, b, key in zip(out[1], out[0], ('near', 'far', 'near')):
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(ref[key]).max()
+
+
 def test_c3_full_size_ewald_direct_fused_pass():
     """The step-boundary pass of the PME variant that bench.py times under detail.pme_outer -- Ewald direct space (erfc) as list
     owner, force-switched near force as guest, ONE walk of the molecule rows -- at the full 98 304 atoms against the oracle
