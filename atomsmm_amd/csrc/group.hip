@@ -7,18 +7,19 @@
 // launches per evaluation, and RESPASystem leaves these forces in group 0, i.e. on the INNERMOST loop -- config C5 paid them
 // 32 times per AFED step): every atom of the large set tests the small set's atoms directly.
 //
-// Work decomposition: one thread per atom j (grid stride); the small set's positions and parameters sit in LDS; thread j walks
-// them in order (a fixed order of summation) and keeps the force on j.  The reaction forces on the small set's atoms are reduced
-// over the wavefront in a fixed order (through LDS, four small atoms at a time) -- only for the few (wavefront, small atoms)
-// combinations that hold a pair inside the cutoff -- and added to 64-bit FIXED-POINT accumulators (2^-40 kJ/mol/nm) with
-// device-scope integer atomics: integer additions commute, so the sums -- and every bit of the forces -- are the same on every
-// launch whatever the order the wavefronts arrive in (the PME spread of pme.hip does the same); the LAST block (ticket) turns the
-// accumulators into force rows and clears them.
+// Work decomposition: four lanes per atom j of the large set (grid stride over the atoms); the small set's positions and parameters
+// sit in LDS; the four lanes split its atoms between them (a fixed order of summation) and keep the force on j.  The reaction
+// forces on the small set's atoms are turned to 64-bit FIXED POINT (2^-40 kJ/mol/nm) lane by lane, summed over the wavefront
+// through LDS (four small atoms at a time) -- only for the few (wavefront, small atoms) combinations that hold a pair inside the
+// cutoff -- and added to accumulators with device-scope integer atomics: integer additions commute, so the sums -- and every bit
+// of the forces -- are the same on every launch whatever the order the wavefronts arrive in and whichever atoms share a wavefront
+// (the PME spread of pme.hip does the same); the LAST block (ticket) turns the accumulators into force rows and clears them.
 // (A first version staged per-block floating-point partial sums for the last block to add in block order: the ~100 blocks'
 // partials sit behind loads that bypass the XCD's L2 -- 17 us of a 38 us kernel at 249 075 atoms.)  Resolution 9e-13 against forces
 // of 1e2..1e4: at the level of the fp64 rounding of the sums themselves.  Same pair arithmetic (amm_pair_math) and the same
 // arguments as the list-based kernel k_pair_nlist.
-// HBM traffic: positions + parameters + force rows once (~56 B per atom), 7.5 M distance tests at 249 075 atoms x 30.
+// HBM traffic: positions + parameters + force rows once (~56 B per atom), 7.5 M distance tests at 249 075 atoms x 30 -- unless the
+// launch walks CANDIDATES only (SmallArgs: the fused inner loop of amm_run_ops; ~1 700 atoms at config C5).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
