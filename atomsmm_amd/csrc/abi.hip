@@ -357,9 +357,12 @@ int amm_pair_energy_derivative(amm_ctx *ctx, int32_t force_id, const double *d_p
         return 1;
     }
     if (!ctx->d_fscratch) AMM_HIP(hipMalloc(&ctx->d_fscratch, sizeof(double) * 3 * (size_t)ctx->n));
-    ctx->pos_epoch++;
+    if (!(ctx->opt_positions_private && d_pos == ctx->d_x)) ctx->pos_epoch++;     // (the bound buffer under the caller's promise: unchanged)
     pf->pc.flags |= AMM_DERIV_LAMBDA;
-    const int rc = amm_pair_eval_impl(ctx, pf, d_pos, ctx->d_fscratch, 0, d_out);
+    int rc = -1;
+    // (a list-free group force: only the atoms near its small set when a neighbour list vouches for them -- the rows are scratch)
+    if (pf->small && ctx->opt_small_group && !pf->built) rc = amm_small_group_eval_impl(ctx, pf, d_pos, ctx->d_fscratch, 0, d_out, nullptr, nullptr, 1);
+    if (rc < 0) rc = amm_pair_eval_impl(ctx, pf, d_pos, ctx->d_fscratch, 0, d_out);
     pf->pc.flags &= ~AMM_DERIV_LAMBDA;
     return rc;
 }
@@ -692,7 +695,7 @@ int amm_force_eval(amm_ctx *ctx, int32_t force_id, const double *d_pos, double *
         amm_set_error("amm_force_eval: bad arguments");
         return 1;
     }
-    ctx->pos_epoch++;                 // a caller's positions may have changed in any way since the last call
+    if (!(ctx->opt_positions_private && d_pos == ctx->d_x)) ctx->pos_epoch++;     // a caller's positions may have changed in any way since the last call
     return force_eval_dispatch(ctx, force_id, d_pos, d_force, accumulate, d_energy);
 }
 

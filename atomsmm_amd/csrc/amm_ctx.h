@@ -336,6 +336,10 @@ struct KickList {
 
 // the neighbour lists whose displacement trigger a kernel that MOVES the atoms evaluates for the positions it writes (their own
 // check launch is then skipped: amm_watch_moved).  Passed to kernels by value.
+// a list's flag array: [0] "an atom is farther than skin / 2 from where it was at the last build" (rebuild wanted) and, raised by the
+// same checks, [AMM_FLAG_FAR] "... farther than the whole skin" (who trusted the list's reference positions with a doubled margin --
+// group.hip's candidate walk -- must stop); both cleared by the rebuild
+#define AMM_FLAG_FAR 12
 struct WatchArgs {
     int n;
     const double *xref[AMM_MAX_WATCH];
@@ -358,9 +362,10 @@ int amm_exchange_finish_impl(amm_ctx *ctx);
 int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> &member);
 // carry_terms: the launch also evaluates the terms of this (finalized, term-parallel) bond-list set into its parked-force buffer
 // own_rows: the caller can take the force's rows from a buffer of the force's own (returned here; nullptr: they are in d_force
-// as usual) -- then the launch may walk the candidate atoms only (group.hip: SmallArgs)
+// as usual) -- then the launch may walk the candidate atoms only (group.hip: SmallArgs); rows_unused: the caller wants the energy
+// alone and d_force is scratch -- candidates again
 int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy,
-                              BondedSet *carry_terms = nullptr, const double **own_rows = nullptr);
+                              BondedSet *carry_terms = nullptr, const double **own_rows = nullptr, int rows_unused = 0);
 int amm_small_group_free(SmallGroup *sg);
 int amm_small_group_failed(SmallGroup *sg);
 int amm_small_group_stats(SmallGroup *sg, int out[2]);

@@ -638,7 +638,11 @@ __global__ void __launch_bounds__(256) k_inner_lanes(BondedArgs A, CompArgs C) {
         }
         for (int q = 0; q < C.nwatch; ++q) {
             const double dx = x[0] - C.wref[q][3 * a], dy = x[1] - C.wref[q][3 * a + 1], dz = x[2] - C.wref[q][3 * a + 2];
-            if (!(dx * dx + dy * dy + dz * dz <= C.wthr2[q])) C.wflags[q][0] = 1;   // benign race (NaN also triggers)
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (!(d2 <= C.wthr2[q])) {                                               // benign race (NaN also triggers)
+                C.wflags[q][0] = 1;
+                if (!(d2 <= 4.0 * C.wthr2[q])) C.wflags[q][AMM_FLAG_FAR] = 1;
+            }
         }
     }
 }

@@ -50,7 +50,11 @@ struct PosAdvanced {
 __device__ __forceinline__ void amm_watch_atom(const WatchArgs &W, int a, const double *xn) {
     for (int q = 0; q < W.n; ++q) {
         const double dx = xn[0] - W.xref[q][3 * a], dy = xn[1] - W.xref[q][3 * a + 1], dz = xn[2] - W.xref[q][3 * a + 2];
-        if (!(dx * dx + dy * dy + dz * dz <= W.thr2[q])) W.flags[q][0] = 1;   // benign race (NaN also triggers)
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        if (!(d2 <= W.thr2[q])) {                                              // benign race (NaN also triggers)
+            W.flags[q][0] = 1;
+            if (!(d2 <= 4.0 * W.thr2[q])) W.flags[q][AMM_FLAG_FAR] = 1;
+        }
     }
 }
 

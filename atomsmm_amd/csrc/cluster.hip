@@ -74,7 +74,11 @@ __global__ void k_ccheck_displacement(int n, const double *__restrict__ pos, con
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double dx = pos[3 * i] - xref[3 * i], dy = pos[3 * i + 1] - xref[3 * i + 1], dz = pos[3 * i + 2] - xref[3 * i + 2];
-    if (!(dx * dx + dy * dy + dz * dz <= thr2)) flags[0] = 1;        // benign race; NaN also triggers
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    if (!(d2 <= thr2)) {                                             // benign race; NaN also triggers
+        flags[0] = 1;
+        if (!(d2 <= 4.0 * thr2)) flags[AMM_FLAG_FAR] = 1;
+    }
 }
 
 // cell of every molecule (by its first atom) + per-cell counts; the arrival rank places the molecule in the cell's member table;
@@ -269,6 +273,7 @@ __device__ void cfinish_build_block(int *flags, unsigned long long *counters, co
         counters[2] = sh_part[0][2] + sh_part[1][2] + sh_part[2][2] + sh_part[3][2];
         if (!count_only) {
             flags[0] = 0;
+            flags[AMM_FLAG_FAR] = 0;
             counters[0] += 1;
         }
     }

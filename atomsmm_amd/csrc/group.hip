@@ -59,19 +59,23 @@ struct SmallArgs {
     int *ticket;
     double *epart;                 // [nblocks] energies (EN)
     // ---- candidate rows (inner loops: the force is evaluated far more often than atoms change neighbourhoods) ----
-    // A companion neighbour list of the context keeps, for every atom, its position at the list's last build (xref) and a flag
-    // that the kernels which move the atoms raise as soon as one of them is farther than skin / 2 from it.  While the flag is down
-    // a pair inside this force's cutoff was closer than rc + skin in the xref positions: the launch that follows a build of the
-    // companion (its build counter changed) walks every atom as usual and also lists the atoms within rc + skin of a small atom
-    // (`cand`, any order: no sum depends on it, see the fixed-point remark above); later launches walk that list only -- 1 700
-    // atoms instead of 249 075 at config C5 -- and leave the other rows of `force` alone: they are zero and stay zero
-    // (`force` is then a buffer of this force's own: SmallGroup::d_fpair).
+    // A companion neighbour list of the context keeps, for every atom, its position at the list's last build (xref) and two flags
+    // that the kernels which move the atoms raise as soon as one of them is farther than skin / 2 (the list wants a rebuild) or
+    // than the whole skin (AMM_FLAG_FAR) from it.  While the second flag is down a pair inside this force's cutoff was closer than
+    // rc + 2 skin in the xref positions: the launch that follows a build of the companion (its build counter changed) walks every
+    // atom as usual and also lists the atoms within rc + 2 skin of a small atom (`cand`, any order: no sum depends on it, see the
+    // fixed-point remark above); later launches walk that list only -- 2 000 atoms instead of 249 075 at config C5 -- and leave
+    // the other rows of `force` alone: they are zero and stay zero (`force` is then a buffer of this force's own:
+    // SmallGroup::d_fpair).  (The doubled margin: the companion is rebuilt at its next evaluation, a few inner iterations AFTER the
+    // first flag went up; with a margin of one skin those iterations would have to walk every atom.)
     int cand_on;                   // 0: plain launch (every atom, no list kept)
     int cand_trust;                // host: the companion's flag was evaluated for THESE positions
+    int cand_may_list;             // this launch writes every row of the force's own buffer, so it may replace the list (a launch whose
+                                   // rows go elsewhere must not: rows of atoms that drop out of the list would keep their last values)
     const double *xref;            // companion: [n][3]
-    const int *lflags;             // companion: [0] rebuild wanted
+    const int *lflags;             // companion: [AMM_FLAG_FAR] an atom left the doubled margin
     const unsigned long long *lcounters;     // companion: [0] builds
-    double r2cand;                 // (rc + skin)^2
+    double r2cand;                 // (rc + 2 skin)^2
     int *cand;                     // [n]
     int *cstate;                   // [0] candidates [1] companion build they belong to [2] append cursor (zero between launches)
 };
@@ -106,17 +110,20 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, 
     // changes in the LAST block's tail only, when every other block has read it
     bool full = true, listing = false;
     int ncand = 0;
-    if (A.cand_on && A.cand_trust && A.lflags[0] == 0) {
+    if (A.cand_on && A.cand_trust && A.lflags[AMM_FLAG_FAR] == 0) {
         if ((int)A.lcounters[0] == A.cstate[1]) {
             full = false;
             ncand = A.cstate[0];
         } else {
-            listing = true;
+            listing = A.cand_may_list != 0;
         }
     }
     // a candidate walk needs few of the blocks; the others leave at once and the ticket counts the rest
     const int walkers = full ? npb : max(1, min(npb, (ncand + 63) >> 6));
-    if (pb >= walkers) return;
+    if (pb >= walkers) {
+        if (EN && threadIdx.x == 0) A.epart[blockIdx.x] = 0.0;
+        return;
+    }
     const int ticket_n = full ? (int)gridDim.x : T.nblocks + walkers;
     if (pb < 0) {
         for (int kt = blockIdx.x * 256 + threadIdx.x; kt < T.nterms; kt += T.nblocks * 256) {
@@ -420,7 +427,7 @@ static void launch_small(hipStream_t st, int nblocks, bool guard, bool en, const
 
 // same contract as amm_pair_eval_impl (no guest, no exchange); returns -1 when the force's family has no instantiation here
 int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy,
-                              BondedSet *carry_terms, const double **own_rows) {
+                              BondedSet *carry_terms, const double **own_rows, int rows_unused) {
     SmallGroup *sg = pf->small;
     if (own_rows) *own_rows = nullptr;
     hipStream_t st = ctx->stream;
@@ -453,14 +460,16 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     A.overflow = sg->d_overflow;
     A.ticket = sg->d_ticket;
     A.epart = sg->d_epart;
-    A.cand_on = A.cand_trust = 0;
+    A.cand_on = A.cand_trust = A.cand_may_list = 0;
     A.xref = nullptr;
     A.lflags = nullptr;
     A.lcounters = nullptr;
     A.r2cand = 0.0;
     A.cand = nullptr;
     A.cstate = nullptr;
-    if (own_rows && ctx->opt_group_candidates && ctx->world == 1 && !accumulate && !d_energy) {
+    // candidates: when the caller takes the rows from the force's own buffer (the fused inner loop), or when it wants the energy
+    // alone (rows_unused: deriv(energy, lambda) -- d_force is scratch, only the candidates' rows are written)
+    if ((own_rows ? !d_energy : (rows_unused && d_energy)) && ctx->opt_group_candidates && ctx->world == 1 && !accumulate) {
         // the companion: a molecule-row list of the context (its reference positions and its flag cover EVERY atom, the atoms
         // outside the molecules too); the caller reads this force's rows from the force's own buffer
         const ClusterList *cl = nullptr;
@@ -479,16 +488,19 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
                 AMM_HIP(hipMemcpy(sg->d_cstate, init, sizeof(init), hipMemcpyHostToDevice));
             }
             A.cand_on = 1;
+            A.cand_may_list = own_rows ? 1 : 0;
             A.cand_trust = ((cl->pre_epoch == ctx->pos_epoch && cl->pre_pos == d_pos) || (cl->checked_epoch == ctx->pos_epoch && cl->checked_pos == d_pos)) ? 1 : 0;
             A.xref = cl->d_xref;
             A.lflags = cl->d_flags;
             A.lcounters = cl->d_counters;
-            const double reach = std::sqrt(pf->pc.rc2) + cl->skin;
+            const double reach = std::sqrt(pf->pc.rc2) + 2.0 * cl->skin;
             A.r2cand = reach * reach;
             A.cand = sg->d_cand;
             A.cstate = sg->d_cstate;
-            A.force = sg->d_fpair;
-            *own_rows = sg->d_fpair;
+            if (own_rows) {
+                A.force = sg->d_fpair;
+                *own_rows = sg->d_fpair;
+            }
         }
     }
     // AMM_SG_BPC blocks per CU at most (grid stride in the kernel)

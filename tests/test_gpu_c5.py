@@ -161,15 +161,28 @@ def test_c5_candidate_walks_bit_identical():
         context.setPositions(shifted * unit.nanometers)
         integrator.step(6)
         st = context.getState(getPositions=True, getVelocities=True)
-        soft = [s_ for s_ in (context._engine.ctx.pair_stats(pid) for pid in context._engine.pair_force_ids(0)) if s_['list_kind'] == 3]
-        return st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value, soft[0]
+        # deriv(energy, lambda) after each of a few more steps: the energy-only launch walks the candidates too (its rows are
+        # scratch) unless the step's last pair evaluation has just rebuilt the companion list (the list of candidates is then
+        # renewed by the next launch that owns its rows, not by this one)
+        def soft_stats():
+            return [s_ for s_ in (context._engine.ctx.pair_stats(pid) for pid in context._engine.pair_force_ids(0)) if s_['list_kind'] == 3][0]
+        derivs, walks = [], 0
+        for _ in range(5):
+            before = soft_stats()['n_candidate_walks']
+            derivs.append(context._engine.energy_derivative('lambda_vdw'))
+            walks += soft_stats()['n_candidate_walks'] - before
+            integrator.step(1)
+        st = context.getState(getPositions=True, getVelocities=True)
+        return st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value, soft_stats(), derivs, walks
 
     for skin in (0.1, 0.03):
-        x1, v1, s1 = run(1, skin)
-        x0, v0, s0 = run(0, skin)
+        x1, v1, s1, d1, w1 = run(1, skin)
+        x0, v0, s0, d0, w0 = run(0, skin)
         assert s1['n_candidate_walks'] > 20 and s0['n_candidate_walks'] == 0, (s1, s0)
         assert np.array_equal(x1, x0) and np.array_equal(v1, v0)
         assert np.isfinite(x1).all()
+        assert w0 == 0 and (w1 >= 2 or skin < 0.1)      # derivative launches walked candidates (0.03 nm: every step ends in a rebuild)
+        assert d1 == pytest.approx(d0, rel=1e-11)       # (block partial sums of the energy: other groupings, same pairs)
 
 
 def test_c5_full_size_fused_inner_iterations_bit_identical():
