@@ -363,6 +363,7 @@ struct SmallGroup {
     // candidate rows (SmallArgs): the force's own rows, the list and its state
     double *d_fpair = nullptr;
     int *d_cand = nullptr, *d_cstate = nullptr;
+    const void *companion = nullptr;       // the list the candidates were made against (another one: the list starts over)
 };
 
 int amm_small_group_free(SmallGroup *sg) {
@@ -486,6 +487,12 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
                 AMM_HIP(hipMalloc(&sg->d_cstate, sizeof(int) * 4));
                 const int init[4] = {0, -1, 0, 0};
                 AMM_HIP(hipMemcpy(sg->d_cstate, init, sizeof(init), hipMemcpyHostToDevice));
+            }
+            if (sg->companion != (const void *)cl) {
+                // (build counters of two lists are not comparable: forget the candidates; ordered on the stream)
+                static const int fresh[4] = {0, -1, 0, 0};
+                AMM_HIP(hipMemcpyAsync(sg->d_cstate, fresh, sizeof(int) * 3, hipMemcpyHostToDevice, st));
+                sg->companion = cl;
             }
             A.cand_on = 1;
             A.cand_may_list = own_rows ? 1 : 0;
