@@ -138,6 +138,7 @@ struct PairForce {
     int *d_nnb_lj = nullptr;       // per row: how many of its entries are partners with a Lennard-Jones site (front | back << 16): they come first on either side
     int *d_cell_sets = nullptr;    // interaction-group forces: per cell, which of the two sets have atoms in it (bit 0 / bit 1)
     int active_cap = 0;            // rows the pair kernels' grid covers when d_active is walked
+    int active_size = 0;           // slots of d_active (long rows are filed from its front, short ones from its back)
     int *d_active = nullptr;       // filtered lists: slice-relative rows that hold entries (their number: flags[8])
     float *d_member = nullptr;     // interaction-group forces: set code of each atom (0 none, 1, 2); the list keeps only (1, 2) pairs
     int *d_row_order = nullptr;    // traversal order of the slice's rows: rows with a Lennard-Jones site first (wave-uniform LJ skip)

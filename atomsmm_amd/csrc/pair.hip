@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
     }
     const int gi0 = s_begin - ga0;
     if (row_order && wave == 0 && lane == 0) n_lj_out[0] = ga1 - ga0;
-    if (wave == 0 && lane == 0) n_lj_out[5] = 0;      // flags[8]: rows with entries of a filtered list, counted by the build that follows
+    if (wave == 0 && lane == 0) n_lj_out[5] = n_lj_out[6] = n_lj_out[7] = 0;      // flags[8..10]: rows with entries of a filtered list (all / long / short), counted by the build that follows
     int sets_here = 0;                                // interaction-group force: which of the two sets have atoms in this cell
     for (int a0 = 0; a0 < cnt; a0 += 64) {
         const int a = a0 + lane;
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
                               const float4 *__restrict__ pos4f_s, BoxF box, CellGrid g, float rlist2, float rnear2,
                               const int *__restrict__ excl_ptr, const int *__restrict__ excl_idx, int cap, int *nl,
                               int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
-                              unsigned long long *counters, int *ticket, int which, int force, int filtered, int *active, int active_cap, const int *__restrict__ cell_sets,
+                              unsigned long long *counters, int *ticket, int which, int force, int filtered, int *active, int active_cap, int active_size, const int *__restrict__ cell_sets,
                               const int *__restrict__ cell_start_lj, int *nnb_lj) {
     if (!force && !flags[which]) return;
     __shared__ int s_rstart[4][128];
@@ -608,15 +608,31 @@ __global__ void __launch_bounds__(256) k_build_nlist(int s_begin, int s_end, int
             }
             // filtered lists (interaction groups): most rows are empty -- the rows that hold entries are collected (any order:
             // a row has one producer whatever its place in the walk) so that the pair kernels visit only those; flags[8] counts
+            // Two kinds of rows in the rest part of a hybrid list (filtered == 2): LONG ones (an atom outside the molecules against
+            // everything around it: hundreds of entries) are filed from the front of `active`, SHORT ones (a molecule atom and its
+            // few partners outside the molecules) from the back -- the traversal gives a long row a whole wavefront and packs eight
+            // short ones into one (amm_active_row, k_pair_tab).  flags[9] / flags[10] count them; an interaction group's rows are all long.
             if (!COUNT_ONLY && active) {
                 const bool holds = lane < nt && count + countf > 0 && count + countf <= cap;
+                const bool is_long = holds && (filtered != 2 || my.w == 2.0f);
                 const unsigned long long m_act = __builtin_amdgcn_ballot_w64(holds);
                 if (m_act != 0ull) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&flags[8], __popcll(m_act));
+                    const unsigned long long m_long = __builtin_amdgcn_ballot_w64(is_long), m_short = m_act & ~m_long;
+                    int base = 0, base_l = 0, base_s = 0;
+                    if (lane == 0) {
+                        base = atomicAdd(&flags[8], __popcll(m_act));
+                        if (m_long != 0ull) base_l = atomicAdd(&flags[9], __popcll(m_long));
+                        if (m_short != 0ull) base_s = atomicAdd(&flags[10], __popcll(m_short));
+                    }
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (lane == 0 && base + __popcll(m_act) > active_cap) flags[1] = 1;   // more rows than the pair kernels' grid covers
-                    if (holds) active[base + __popcll(m_act & below)] = tb + lane - s_begin;
+                    base_l = __builtin_amdgcn_readfirstlane(base_l);
+                    base_s = __builtin_amdgcn_readfirstlane(base_s);
+                    const bool fits = base + __popcll(m_act) <= active_cap;
+                    if (lane == 0 && !fits) flags[1] = 1;   // more rows than the pair kernels' grid covers
+                    if (holds && fits) {
+                        if (is_long) active[base_l + __popcll(m_long & below)] = tb + lane - s_begin;
+                        else active[active_size - 1 - (base_s + __popcll(m_short & below))] = tb + lane - s_begin;
+                    }
                 }
             }
         }
@@ -765,8 +781,17 @@ struct PairArgs {
     int gsame;         // the guest accumulates into the SAME rows as the host (fused FarNonbondedForce): one store of the sum
     const int *active;     // filtered lists: the rows that hold entries (slice-relative) ...
     const int *n_active;   // ... and their number (device); null: every row of the slice is walked
+    const int *n_long;     // ... of which this many, filed from the front of `active`, are long rows; the others sit at the back
+    int active_size;       //     of its active_size slots (amm_active_row)
+    int long_shift;        // > 0: the long rows are walked with 1 << long_shift lanes each, before the others (k_pair_tab)
 };
 
+
+// row a (0 <= a < *n_active) of a filtered list's walk: the long rows from the front of `active`, the short ones from the back
+__device__ __forceinline__ int amm_active_row(const PairArgs &A, int a) {
+    const int nl = A.n_long ? *A.n_long : 0x7fffffff;
+    return a < nl ? A.active[a] : A.active[A.active_size - 1 - (a - nl)];
+}
 
 __device__ double amm_erfcx_table_dev[AMM_ERFCX_NI * AMM_ERFCX_NC];
 static bool g_erfcx_uploaded[64] = {false};   // per device: the table is a __device__ symbol of each device's code object
@@ -783,7 +808,7 @@ __global__ void __launch_bounds__(256) k_pair_nlist(PairArgs A, PairConsts c, Pa
     bool listed = true;
     if (A.active) {        // only the rows that hold entries; the caller has zeroed the others' outputs
         listed = a < *A.n_active;
-        a = listed ? A.active[a] : 0;
+        a = listed ? amm_active_row(A, a) : 0;
     }
     const int s = A.s_begin + a;
     const bool valid = listed && s < A.s_end;
@@ -1151,15 +1176,23 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
 
     constexpr int WPB = BS / 64;
     const int lane = threadIdx.x & 63;
-    const int lpa = 1 << A.lpa_shift;
+    // The rest part of a hybrid list is walked in two phases: its long rows (A.long_shift: a whole wavefront each), then its short
+    // ones (A.lpa_shift) -- with one task size a wavefront that drew eight long rows walked 35 trips while most walked 6.
+    const int nphase = (A.active && A.n_long && A.long_shift > 0) ? 2 : 1;
+    const int nrows_all = A.active ? min(*A.n_active, T.nslice) : T.nslice;
+    const int nlong_all = nphase == 2 ? min(*A.n_long, nrows_all) : 0;
+    for (int phase = 0; phase < nphase; ++phase) {
+    const int lpa_shift = (nphase == 2 && phase == 0) ? A.long_shift : A.lpa_shift;
+    const int row0 = (nphase == 2 && phase == 1) ? nlong_all : 0;
+    const int lpa = 1 << lpa_shift;
     const int sub = lane & (lpa - 1);
     // Tasks: one wavefront's worth of rows (rpw = 64 >> lpa_shift), drawn from two pools -- rows with a Lennard-Jones site
     // (the first n_lj entries of row_order; about twice the arithmetic per pair) and rows without.  Each XCD
     // (blockIdx & 7) owns one contiguous eighth of either pool.
     const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
-    const int rpw = 64 >> A.lpa_shift;
+    const int rpw = 64 >> lpa_shift;
     // filtered lists (the rest part of a hybrid list): only the rows that hold entries, in the order the build collected them
-    const int nrows = A.active ? min(*A.n_active, T.nslice) : T.nslice;
+    const int nrows = nphase == 2 ? (phase == 0 ? nlong_all : nrows_all - nlong_all) : nrows_all;
     const int n_lj = T.n_lj ? min(*T.n_lj, nrows) : nrows;
     const int t_lj = (n_lj + rpw - 1) / rpw, t_h = (nrows - n_lj + rpw - 1) / rpw;
     // one contiguous eighth of either pool per XCD: consecutive cell-sorted rows, i.e. a slab of the box, whose gathers (the
@@ -1178,7 +1211,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
         const int before = (int)(((long long)p * nlj_x) / ntask_x), upto = (int)(((long long)(p + 1) * nlj_x) / ntask_x);
         const bool lj_pool = upto > before;
         const int task = lj_pool ? before : nlj_x + (p - upto);
-        const int a = lj_pool ? (lj0 + task) * rpw + (lane >> A.lpa_shift) : n_lj + (h0 + task - nlj_x) * rpw + (lane >> A.lpa_shift);
+        const int a = lj_pool ? (lj0 + task) * rpw + (lane >> lpa_shift) : n_lj + (h0 + task - nlj_x) * rpw + (lane >> lpa_shift);
         const bool valid = lj_pool ? a < n_lj : a < nrows;
         int s = A.s_begin;
         double4 pi = make_double4(0.0, 0.0, 0.0, 0.0);
@@ -1186,7 +1219,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
         int nfront = 0, nn = 0, ntot = 0, sites_front = 0x7fffffff, sites_back = 0x7fffffff;
         const int *row = A.nl;
         if (valid) {
-            s = A.active ? A.s_begin + A.active[a] : (T.row_order ? T.row_order[a] : A.s_begin + a);
+            s = A.active ? A.s_begin + amm_active_row(A, row0 + a) : (T.row_order ? T.row_order[a] : A.s_begin + a);
             const int ra = s - A.s_begin;
             pi = A.posq_s[s];
             li = A.lj_s[s];
@@ -1224,7 +1257,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
             lj_end = all;
             pl_end = 0;
         } else if (any_lj) {
-            const int trip_len = 2 << A.lpa_shift;
+            const int trip_len = 2 << lpa_shift;
             const bool mine = valid && li.y != 0.0;
             // (from the row's full length even when only its front part is walked: the near force alone and as the guest of the
             // outer force's pass then add up a row in the same order -- bit for bit)
@@ -1294,6 +1327,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
                 A.force[3 * i + 2] = fz;
             }
         }
+    }
     }
 }
 
@@ -1460,7 +1494,7 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
     hipLaunchKernelGGL((k_build_nlist<CO, RI>), grid, dim3(256), 0, st, pf->s_begin, pf->s_end, pf->parts, pf->d_perm,  \
                        pf->d_inv_perm, pf->d_cell_start, pf->d_pos4f_s, bf, pf->grid, rl2, rn2, pf->d_excl_ptr,         \
                        pf->d_excl_idx, cap, nl, nnb, nnb_near, pf->d_flags, pf->d_blockstats, pf->d_counters,      \
-                       pf->d_ticket + AMM_TICKET_INTS, which, force, pf->d_member ? (pf->hybrid_rest ? 2 : 1) : 0, direct ? pf->d_active : (int *)nullptr, pf->active_cap, pf->d_cell_sets,        \
+                       pf->d_ticket + AMM_TICKET_INTS, which, force, pf->d_member ? (pf->hybrid_rest ? 2 : 1) : 0, direct ? pf->d_active : (int *)nullptr, pf->active_cap, pf->active_size, pf->d_cell_sets,        \
                        pf->d_cell_start_lj, direct ? pf->d_nnb_lj : (int *)nullptr)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_BUILD(true, true);
@@ -1523,6 +1557,7 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     AMM_HIP(hipMemset(pf->d_nnb_lj, 0, sizeof(int) * ns));
     if (pf->d_member && !(pf->skin_out > pf->skin * (1 + 1e-9))) AMM_HIP(hipMalloc(&pf->d_active, sizeof(int) * ns));
     pf->active_cap = (int)ns;
+    pf->active_size = (int)ns;
     // lanes per atom: aim at >= 8 wavefronts per SIMD (1024 SIMDs) for latency hiding, but not beyond 16 lanes: longer
     // strides waste the tail of every row (measured on 1/8 slices of C3, scripts/probe_slices.py: dual pass 63.6 us
     // with 16 lanes, 71.9 us with 64)
@@ -1794,6 +1829,9 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         A.sorted_out = exchange ? 1 : 0;
         A.active = nullptr;
         A.n_active = nullptr;
+        A.n_long = nullptr;
+        A.active_size = 0;
+        A.long_shift = 0;
         int rows = nslice;
         if (L->d_active && !exchange && (!guest || L->hybrid_rest)) {
             // interaction-group force: walk the rows that hold entries, the others' forces are zero.  Those rows are few and
@@ -1802,6 +1840,9 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             // few partners outside the molecules) is walked the same way with 8 lanes per row; it always adds to its parent's rows
             A.active = L->d_active;
             A.n_active = L->d_flags + 8;
+            A.n_long = L->d_flags + 9;
+            A.active_size = L->active_size;
+            A.long_shift = (L->hybrid_rest && ctx->opt_row_phases) ? 6 : 0;
             if (!accumulate && ctx->world == 1) AMM_HIP(hipMemsetAsync(d_force, 0, sizeof(double) * 3 * (size_t)n, st));
             if (guest && !g_accumulate && g_force != d_force && ctx->world == 1) AMM_HIP(hipMemsetAsync(g_force, 0, sizeof(double) * 3 * (size_t)n, st));
             A.accumulate = 1;
