@@ -49,6 +49,13 @@ struct Box {
     double L[3], invL[3];
 };
 
+// force rows to clear (hybrid lists: the atoms outside the molecules), served by the molecule-row chain's sort / gather launch
+struct CZeroRows {
+    int n;
+    const int *idx;
+    double *f0, *f1;
+};
+
 struct CellGrid {
     int nc[3];
     int nstencil[3];   // number of unique neighbour cells visited per axis (2h+1, or all nc cells)
@@ -284,6 +291,7 @@ struct amm_ctx {
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
     int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
     int opt_site_tab = 1;               // molecule rows: site-site radial tables instead of Lennard-Jones arithmetic where a force has one
+    CZeroRows zero_rows = CZeroRows{0, nullptr, nullptr, nullptr};      // pending request (pair.hip -> cluster.hip, one evaluation)
     int opt_positions_private = 0;      // amm_run_ops does not assume the caller moved the atoms between calls (amm_positions_changed says so)
     int opt_group_candidates = 1;       // list-free group forces on the fused inner loop: walk the atoms near the small set only while a companion list vouches for them
     int opt_row_phases = 1;             // molecule rows: the remainder of the rows after whole rounds of tasks goes out in smaller tasks (cpair_plan)

@@ -151,8 +151,15 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
                                                       float4 *pos4f, const int *flags, int *wflags, int force, const double *__restrict__ q,
                                                       const double *__restrict__ hsig, const double *__restrict__ seps2, double4 *posq_s,
                                                       double2 *lj_s, float rext, const double *__restrict__ site_eps,
-                                                      const int *__restrict__ first) {
+                                                      const int *__restrict__ first, CZeroRows Z) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    // (hybrid lists: the force rows of the atoms outside the molecules start from zero; the molecule-row kernel writes the others
+    // and the per-atom part adds to all of them -- a launch of its own before)
+    if (gid < Z.n) {
+        const int i = Z.idx[gid];
+        if (Z.f0) Z.f0[3 * i] = Z.f0[3 * i + 1] = Z.f0[3 * i + 2] = 0.0;
+        if (Z.f1) Z.f1[3 * i] = Z.f1[3 * i + 1] = Z.f1[3 * i + 2] = 0.0;
+    }
     if (!force && !flags[0]) {
         if (posq_s && gid < nc) cgather_one(gid, cfirst(first, cperm[gid]), pos, box, q, hsig, seps2, posq_s, lj_s);
         return;
@@ -1101,7 +1108,8 @@ static int cluster_setup_grid(amm_ctx *ctx, ClusterList *cl, double rc) {
     return 0;
 }
 
-static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const double *d_pos, int force, bool count_only, PairForce *gather_for) {
+static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const double *d_pos, int force, bool count_only, PairForce *gather_for,
+                         CZeroRows Z = CZeroRows{0, nullptr, nullptr, nullptr}) {
     hipStream_t st = ctx->stream;
     const int nc = cl->nc;
     hipLaunchKernelGGL(k_cassign, dim3((nc + cl->nrest + 255) / 256), dim3(256), 0, st, nc, d_pos, ctx->box, cl->grid, cl->d_cell_count, cl->d_cell_start,
@@ -1109,11 +1117,11 @@ static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const doub
                        cl->d_rest, cl->nrest);
     if (!cl->d_cell_members) return 0;
     PairForce *gf = gather_for;
-    const long sort_threads = std::max((long)cl->grid.ncell * 64, gf ? (long)nc : 0L);
+    const long sort_threads = std::max(std::max((long)cl->grid.ncell * 64, gf ? (long)nc : 0L), (long)Z.n);
     hipLaunchKernelGGL(k_csort_gather, dim3((unsigned)((sort_threads + 255) / 256)), dim3(256), 0, st, cl->grid.ncell, nc, cl->d_cell_start,
                        cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags, cl->d_flags, force,
                        gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr, gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr,
-                       gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2, cl->d_first);
+                       gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2, cl->d_first, Z);
     const long threads = (long)cl->grid.ncell * cl->parts * 64;
     dim3 grid((unsigned)((threads + 255) / 256));
     CBoxF bf;
@@ -1274,6 +1282,9 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
     }
     PairForce *L = pf->host ? pf->host : pf;
     bool gathered = false;
+    // (a hybrid list's request to clear the rows of the atoms outside the molecules: served by the first sort / gather launch below)
+    const CZeroRows Z = ctx->zero_rows;
+    ctx->zero_rows = CZeroRows{0, nullptr, nullptr, nullptr};
     if (!L->cl || !L->cl->built) {
         if (L->cl) {
             amm_set_error("molecule-row list: an earlier first build failed");
@@ -1290,15 +1301,15 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
                                cl->d_flags);
         const int forced = L->force_rebuild_c ? 1 : 0;
         L->force_rebuild_c = false;
-        if (cluster_chain(ctx, L, cl, d_pos, forced, false, pf)) return 1;
+        if (cluster_chain(ctx, L, cl, d_pos, forced, false, pf, Z)) return 1;
         gathered = true;
     }
     cl->checked_epoch = ctx->pos_epoch;
     cl->checked_pos = d_pos;
     if (!gathered)
-        hipLaunchKernelGGL(k_csort_gather, dim3((cl->nc + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start,
+        hipLaunchKernelGGL(k_csort_gather, dim3((std::max(cl->nc, Z.n) + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start,
                            cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0,
-                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first);     // flags[8] stays 0: copies only
+                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, Z);     // flags[8] stays 0: copies only
     const int nrows = cl->c_end - cl->c_begin;
     const int per_c = (cl->nc + ctx->world - 1) / ctx->world, per = 3 * per_c, nf = guest ? 2 : 1;
     double *out = d_force, *gout = g_force;
@@ -1487,7 +1498,7 @@ int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_p
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(k_csort_gather, dim3((cl->nc + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start, cl->d_cell_members,
                        cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0, pf->d_q, pf->d_hsig,
-                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first);
+                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, CZeroRows{0, nullptr, nullptr, nullptr});
     CPairArgs A;
     std::memset(&A, 0, sizeof(A));
     A.c_begin = cl->c_begin;

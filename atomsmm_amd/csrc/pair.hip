@@ -1654,15 +1654,6 @@ static int first_build(amm_ctx *ctx, PairForce *pf, const double *d_pos) {
     return 0;
 }
 
-// hybrid lists: the force rows of the atoms outside the molecules start from zero (the molecule-row kernel writes the others)
-__global__ void k_zero_rows(int nrest, const int *__restrict__ rest, double *f0, double *f1) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nrest) return;
-    const int i = rest[t];
-    if (f0) f0[3 * i] = f0[3 * i + 1] = f0[3 * i + 2] = 0.0;
-    if (f1) f1[3 * i] = f1[3 * i + 1] = f1[3 * i + 2] = 0.0;
-}
-
 // guest != nullptr: `pf` owns the list `guest` traverses, both forces act on the same particles (checked by
 // amm_pair_can_eval_dual) and only forces are wanted: one pass writes pf's force to d_force and the guest's to g_force.
 __global__ void k_unsort(int n, int per, int nf, const int *__restrict__ perm, const double *__restrict__ xchg, double *force,
@@ -1744,10 +1735,12 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             if (ctx->world == 1 && L->n_rest > 0) {     // (world > 1: the molecule-row evaluation clears whole buffers)
                 double *z0 = accumulate ? nullptr : d_force;
                 double *z1 = (guest && !g_accumulate && g_force != d_force) ? g_force : nullptr;
-                if (z0 || z1)
-                    hipLaunchKernelGGL(k_zero_rows, dim3((L->n_rest + 255) / 256), dim3(256), 0, st, L->n_rest, L->d_rest_idx, z0, z1);
+                // (cleared by the molecule-row chain's sort / gather launch, which always runs: no launch of its own)
+                if (z0 || z1) ctx->zero_rows = CZeroRows{L->n_rest, L->d_rest_idx, z0, z1};
             }
-            if (amm_cluster_eval_impl(ctx, pf, d_pos, d_force, accumulate, guest, g_force, g_accumulate, 0)) return 1;
+            const int rc_rows = amm_cluster_eval_impl(ctx, pf, d_pos, d_force, accumulate, guest, g_force, g_accumulate, 0);
+            ctx->zero_rows = CZeroRows{0, nullptr, nullptr, nullptr};          // (consumed; cleared here too for the error paths)
+            if (rc_rows) return 1;
             return amm_pair_eval_impl(ctx, pf->rest, d_pos, d_force, 1, nullptr, guest ? guest->rest : nullptr, g_force, 1, 0);
         }
         if (cluster) {
