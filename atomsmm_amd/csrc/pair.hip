@@ -1158,7 +1158,9 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
 #ifndef AMM_TAB_WAVES_PER_EU
 #define AMM_TAB_WAVES_PER_EU 1
 #endif
-template <int FAM, int CMODE, int GFAM, int BS>
+// PH: the two-phase walk of a hybrid list's rest part (long rows, then short ones).  A compile-time switch: as a run-time one it cost
+// the common kernels two registers -- 130 instead of 128, three wavefronts per SIMD instead of four (C2: 21 -> 27 us).
+template <int FAM, int CMODE, int GFAM, int BS, bool PH = false>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_TAB_WAVES_PER_EU)))
 k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
     extern __shared__ __align__(16) char s_lds[];
@@ -1178,12 +1180,12 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
     const int lane = threadIdx.x & 63;
     // The rest part of a hybrid list is walked in two phases: its long rows (A.long_shift: a whole wavefront each), then its short
     // ones (A.lpa_shift) -- with one task size a wavefront that drew eight long rows walked 35 trips while most walked 6.
-    const int nphase = (A.active && A.n_long && A.long_shift > 0) ? 2 : 1;
+    constexpr int nphase = PH ? 2 : 1;
     const int nrows_all = A.active ? min(*A.n_active, T.nslice) : T.nslice;
-    const int nlong_all = nphase == 2 ? min(*A.n_long, nrows_all) : 0;
+    const int nlong_all = PH ? min(*A.n_long, nrows_all) : 0;
     for (int phase = 0; phase < nphase; ++phase) {
-    const int lpa_shift = (nphase == 2 && phase == 0) ? A.long_shift : A.lpa_shift;
-    const int row0 = (nphase == 2 && phase == 1) ? nlong_all : 0;
+    const int lpa_shift = (PH && phase == 0) ? A.long_shift : A.lpa_shift;
+    const int row0 = (PH && phase == 1) ? nlong_all : 0;
     const int lpa = 1 << lpa_shift;
     const int sub = lane & (lpa - 1);
     // Tasks: one wavefront's worth of rows (rpw = 64 >> lpa_shift), drawn from two pools -- rows with a Lennard-Jones site
@@ -1192,7 +1194,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
     const int xcd = blockIdx.x & 7, nwx = (gridDim.x >> 3) * WPB;
     const int rpw = 64 >> lpa_shift;
     // filtered lists (the rest part of a hybrid list): only the rows that hold entries, in the order the build collected them
-    const int nrows = nphase == 2 ? (phase == 0 ? nlong_all : nrows_all - nlong_all) : nrows_all;
+    const int nrows = PH ? (phase == 0 ? nlong_all : nrows_all - nlong_all) : nrows_all;
     const int n_lj = T.n_lj ? min(*T.n_lj, nrows) : nrows;
     const int t_lj = (n_lj + rpw - 1) / rpw, t_h = (nrows - n_lj + rpw - 1) / rpw;
     // one contiguous eighth of either pool per XCD: consecutive cell-sorted rows, i.e. a slab of the box, whose gathers (the
@@ -1219,7 +1221,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
         int nfront = 0, nn = 0, ntot = 0, sites_front = 0x7fffffff, sites_back = 0x7fffffff;
         const int *row = A.nl;
         if (valid) {
-            s = A.active ? A.s_begin + amm_active_row(A, row0 + a) : (T.row_order ? T.row_order[a] : A.s_begin + a);
+            s = A.active ? A.s_begin + (PH ? amm_active_row(A, row0 + a) : A.active[a]) : (T.row_order ? T.row_order[a] : A.s_begin + a);
             const int ra = s - A.s_begin;
             pi = A.posq_s[s];
             li = A.lj_s[s];
@@ -1333,7 +1335,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
 
 
 // one instantiation: dynamic LDS attribute + blocks per CU (cached), persistent grid (a multiple of 8 blocks)
-template <int FAM, int CMODE, int GFAM, int BS>
+template <int FAM, int CMODE, int GFAM, int BS, bool PH = false>
 static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts &c, const PairConsts &gc, TabArgs &T) {
     // (the LDS attribute and the occupancy answer belong to a device: one slot per device, like the erfcx upload flags)
     static int bpc_dev[64], lds_set_dev[64], cu_dev[64];
@@ -1354,7 +1356,7 @@ static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts
         amm_set_error("tabulated pair kernel: the radial tables of the two forces do not fit LDS together");
         return 1;
     }
-    auto kern = k_pair_tab<FAM, CMODE, GFAM, BS>;
+    auto kern = k_pair_tab<FAM, CMODE, GFAM, BS, PH>;
     if (lds > lds_set) {
         AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         lds_set = lds;
@@ -1387,6 +1389,8 @@ static int tab_block_size(bool dual) {
 template <int FAM, int CMODE, int GFAM>
 static int launch_pair_tab_g(hipStream_t st, const PairArgs &A, const PairConsts &c, const PairConsts &gc, TabArgs &T) {
     const int bs = tab_block_size(GFAM >= 0);
+    // (the rest part of a hybrid list, walked in two phases: the default block sizes only)
+    if (A.active && A.n_long && A.long_shift > 0) return launch_pair_tab_i<FAM, CMODE, GFAM, (GFAM >= 0 ? 768 : 512), true>(st, A, c, gc, T);
     if (bs == 1024) return launch_pair_tab_i<FAM, CMODE, GFAM, 1024>(st, A, c, gc, T);
     if (bs == 768) return launch_pair_tab_i<FAM, CMODE, GFAM, 768>(st, A, c, gc, T);
     return launch_pair_tab_i<FAM, CMODE, GFAM, 512>(st, A, c, gc, T);
