@@ -608,6 +608,60 @@ def test_neighbour_list_rebuild_and_reuse(spcfw, outer_skin):
     ctx.close()
 
 
+def test_positions_private_contract(spcfw):
+    """Option positions_private: amm_run_ops no longer assumes that the caller moved the atoms between two calls -- it keeps the
+    displacement checks its own launches made -- and the caller says amm_positions_changed when it did write the bound position
+    buffer.  Checked: (a) evaluations through amm_run_ops after the caller rewrote the positions + amm_positions_changed meet the
+    oracle (a jump far beyond the Verlet buffer: the list must be rebuilt); (b) moves made by the library's own ops are followed
+    without any notice (a MOVE of 0.3 nm); (c) the default (option off) needs no notice at all."""
+    B = _backend()
+    c = spcfw
+    n = len(c['positions'])
+    d = near('force-switch', 0.7, 0.5)
+    for private in (1, 0):
+        ctx = B.HipContext(n, c['box'])
+        ctx.set_option('positions_private', private)
+        fid = hip_pair(B, ctx, d, c, skin=0.1)
+        x, v, m = dev(c['positions']), dev(np.zeros((n, 3))), dev(c['mass'])
+        f = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+        ctx.bind_state(x, v, m)
+        ctx.bind_buffer(1, f)
+        ctx.group_define(1, 1, [fid])
+        ev = [B.Op(B.OP_EVAL, 1, 0, 0, 0.0)]
+
+        def check(pos):
+            f_ref = O.pair_eval(d, pos, c['box'], c['charge'], c['sigma'], c['epsilon'], c['exc_pairs'])[1]
+            assert np.abs(f.cpu().numpy() - f_ref).max() <= 1e-9 * np.abs(f_ref).max()
+
+        ctx.run_ops(ev, 1)
+        ctx.check()
+        check(c['positions'])
+        builds0 = ctx.pair_stats(fid)['n_builds']
+        # (a) the caller rewrites the bound buffer
+        rng = np.random.default_rng(5)
+        pos = c['positions'] + np.repeat(rng.normal(scale=0.2, size=(n // 3, 3)), 3, axis=0)       # (whole molecules)
+        x.copy_(dev(pos))
+        if private:
+            ctx.positions_changed()
+        ctx.run_ops(ev, 1)
+        ctx.check()
+        check(pos)
+        assert ctx.pair_stats(fid)['n_builds'] > builds0
+        # (b) the library moves the atoms itself: v = const, MOVE by 0.3 nm, then the evaluation -- in ONE call and in two
+        v.copy_(dev(np.tile(np.array([1.0, -0.5, 0.25]), (n, 1))))
+        step = 0.3 / np.sqrt(1.0 + 0.25 + 0.0625)
+        ctx.run_ops([B.Op(B.OP_MOVE, 0, 0, 0, step)] + ev, 1)
+        ctx.check()
+        pos = pos + step * np.array([1.0, -0.5, 0.25])
+        check(pos)
+        ctx.run_ops([B.Op(B.OP_MOVE, 0, 0, 0, step)], 1)
+        ctx.run_ops(ev, 1)
+        ctx.check()
+        pos = pos + step * np.array([1.0, -0.5, 0.25])
+        check(pos)
+        ctx.close()
+
+
 @pytest.mark.parametrize('seed', [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_random_molecule_boxes_vs_oracle(seed):
     random_molecule_case(seed, seed - 1)
