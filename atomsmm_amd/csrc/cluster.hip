@@ -611,6 +611,9 @@ struct CPairArgs {
     // ph_ntask[p] wavefront tasks of 64 >> ph_shift[p] rows (cpair_plan: whole rounds of big tasks, the remainder in smaller ones)
     int rpx, nphase;
     int ph_off[AMM_CPHASES], ph_shift[AMM_CPHASES], ph_ntask[AMM_CPHASES];
+#ifdef AMM_CPAIR_TIMING           // measurement builds (scripts/build_variant.sh): wall clock of every wavefront
+    unsigned long long *wave_times;      // [wavefront][4]: kernel entry, tables staged, tasks done, flags (interior tasks << 8 | tasks)
+#endif
     // site-site tables (pair_tab.h: SiteTable; kernels with SS): LDS byte offset FROM THE FORCE'S COULOMB TABLE to the place
     // interval 0 of its site-site table would have, the bytes it really holds, and the site class for the analytic fallback
     const double *host_tab_ss;
@@ -808,6 +811,7 @@ __device__ __forceinline__ void cwalk_rows(const CPairArgs &A, const PairConsts 
 #ifndef AMM_CBS_SINGLE
 #define AMM_CBS_SINGLE 512
 #endif
+
 #ifndef AMM_CBS_NEAR          // one force per pass (the fused pass keeps AMM_CBS_SINGLE)
 #define AMM_CBS_NEAR 512
 #endif
@@ -822,6 +826,11 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
     constexpr bool DUAL = GFAM >= 0;
     constexpr bool SS = SMASK != 0;
     extern __shared__ __align__(16) char s_lds[];
+#ifdef AMM_CPAIR_TIMING
+    const unsigned long long t_entry = wall_clock64();
+    unsigned long long t_staged = 0;
+    int n_tasks_done = 0, n_interior = 0;
+#endif
     auto stage = [&](int at, const double *src, int bytes) {
         for (int o = threadIdx.x * 16; o < bytes; o += BS * 16)
             *reinterpret_cast<double2 *>(s_lds + at + o) = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(src) + o);
@@ -854,6 +863,9 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
         s_li = reinterpret_cast<double2 *>(s_erfcx + AMM_ERFCX_NI * AMM_ERFCX_NC) + (threadIdx.x >> 6) * 192;
     }
     __syncthreads();
+#ifdef AMM_CPAIR_TIMING
+    t_staged = wall_clock64();
+#endif
 
     constexpr int WPB = BS / 64;
     const int lane = threadIdx.x & 63;
@@ -869,7 +881,11 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
     const int lpa = 1 << shift;
     const int sub = lane & (lpa - 1);
     const int rpw = 64 >> shift;
+#ifdef AMM_CPAIR_SWAP          // measurement: which tasks the last four wavefronts of a block take (is their lag theirs or their rows'?)
+    for (int task = (int)(blockIdx.x >> 3) * WPB + ((int)(threadIdx.x >> 6) ^ 4); task < ntask; task += nwx) {
+#else
     for (int task = (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); task < ntask; task += nwx) {
+#endif
         const int a = row0 + task * rpw + (lane >> shift);
         const bool valid = a < row_end;
         const int cs = A.c_begin + (valid ? a : 0);
@@ -903,6 +919,10 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
         const bool edge = valid && !(pi[0].x >= A.margin && pi[0].x <= A.box.L[0] - A.margin && pi[0].y >= A.margin &&
                                      pi[0].y <= A.box.L[1] - A.margin && pi[0].z >= A.margin && pi[0].z <= A.box.L[2] - A.margin);
         const bool interior = __builtin_amdgcn_ballot_w64(edge) == 0ull;
+#ifdef AMM_CPAIR_TIMING
+        ++n_tasks_done;
+        n_interior += interior ? 1 : 0;
+#endif
         double f[9], fg[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) f[k] = fg[k] = 0.0;
@@ -934,6 +954,15 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
         }
     }
     }
+#ifdef AMM_CPAIR_TIMING
+    if (A.wave_times && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = A.wave_times + 4 * ((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6));
+        o[0] = t_entry;
+        o[1] = t_staged;
+        o[2] = wall_clock64();
+        o[3] = ((unsigned long long)n_interior << 8) | (unsigned long long)n_tasks_done;
+    }
+#endif
 }
 
 // How the rows of one XCD are shared out among its `waves` resident wavefronts.  A task of 64 >> s rows costs a wavefront about
@@ -1029,6 +1058,27 @@ static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c,
     nblk = std::max(8L, (nblk + 7) / 8 * 8);
     CPairArgs P = A;
     cpair_plan(P, (int)(nblk >> 3) * WPB, ctx->opt_row_phases);
+#ifdef AMM_CPAIR_TIMING
+    // the AMM_WAVE_TIMES-th launch of this kernel writes its wavefronts' clocks to $AMM_WAVE_TIMES_OUT.<fused|single> (measurement builds)
+    static int launches = 0;
+    static unsigned long long *d_times = nullptr;
+    const char *which = std::getenv("AMM_WAVE_TIMES");
+    P.wave_times = nullptr;
+    if (which && ++launches == std::atoi(which)) {
+        const size_t nw = (size_t)nblk * WPB;
+        AMM_HIP(hipMalloc(&d_times, sizeof(unsigned long long) * 4 * nw));
+        P.wave_times = d_times;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, P, c, g);
+        std::vector<unsigned long long> h(4 * nw);
+        AMM_HIP(hipMemcpy(h.data(), d_times, sizeof(unsigned long long) * 4 * nw, hipMemcpyDeviceToHost));
+        std::string path = std::string(std::getenv("AMM_WAVE_TIMES_OUT") ? std::getenv("AMM_WAVE_TIMES_OUT") : "/tmp/wave_times") + (DUAL ? ".fused" : ".single");
+        if (FILE *fp = std::fopen(path.c_str(), "wb")) {
+            std::fwrite(h.data(), sizeof(unsigned long long), h.size(), fp);
+            std::fclose(fp);
+        }
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, P, c, g);
     return 0;
 }
