@@ -340,7 +340,13 @@ __device__ __forceinline__ TabLookup amm_tab_fetch(const char *lds_tab, const Pa
     const double2 *cf = reinterpret_cast<const double2 *>(lds_tab + (__umul24(idx, AMM_TAB_STRIDE) + extra));
     L.c01 = cf[0];
     L.c23 = cf[1];
+#if defined(AMM_EXP_TAB_BYTES) && AMM_EXP_TAB_BYTES == 40          // measurement only (wrong forces): what fewer LDS bytes per pair would buy
+    L.c45 = make_double2(*reinterpret_cast<const double *>(cf + 2), 0.0);
+#elif defined(AMM_EXP_TAB_BYTES) && AMM_EXP_TAB_BYTES == 32
+    L.c45 = make_double2(0.0, 0.0);
+#else
     L.c45 = cf[2];
+#endif
     return L;
 }
 __device__ __forceinline__ double amm_tab_horner(const TabLookup &L) {
