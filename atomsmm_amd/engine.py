@@ -1983,8 +1983,8 @@ class Engine:
             eager = [0]
 
             def settle():
-                if self._pending is not None and self._pending[1] > 0:
-                    eager[0] = 3
+                if self._pending is not None and self._pending[1] > 0 and not self._has_constraints:
+                    eager[0] = 3          # (constraint ops stay in one batch with the move they follow)
                 self._settle([env, integ._gvalues])
 
             def deferred_in(text):
