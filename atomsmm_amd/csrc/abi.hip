@@ -1075,7 +1075,15 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                         }
                     }
                 }
-                if (!deferred.empty() && flush_deferred()) return 1;      // no fused launch to ride on
+                if (!deferred.empty()) {
+                    // no component launch to ride on: the deferred kicks can still lead the launch of the run of plain kicks (+ move)
+                    // that opens this repetition (the block further down) -- a velocity-Verlet step is then KICK + KICK + MOVE in one
+                    int run = 0;
+                    for (int j = k; j < n_ops && ops[j].op == AMM_OP_KICK; ++j) ++run;
+                    if (ctx->iso.on || (int)deferred.size() + run > 4) {
+                        if (flush_deferred()) return 1;
+                    }
+                }
             }
             // fused inner RESPA iteration: KICK(c1, fg) ; MOVE(d) ; EVAL(g) ; KICK(c2, fg) with g = one bond-list set
             if (ctx->fuse_inner && !ctx->iso.on && op.op == AMM_OP_KICK && op.b < 0 && k + 3 < n_ops && ops[k + 1].op == AMM_OP_MOVE &&
@@ -1206,6 +1214,28 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 const double *fa[4], *fb[4];
                 int plus[4], nk = 0;
                 double coef[4];
+                // (kicks deferred from the end of the previous repetition come first: the order they were written in)
+                const int ndef = (int)deferred.size();
+                bool def_ok = ndef <= 4;
+                for (int q = 0; q < ndef && def_ok; ++q) {
+                    const amm_op &kick = deferred[q];
+                    const double *a_ = (kick.a >= 0 && kick.a < AMM_MAX_SLOTS) ? ctx->slots[kick.a] : nullptr;
+                    const double *b_ = (kick.b >= 0 && kick.b < AMM_MAX_SLOTS) ? ctx->slots[kick.b] : nullptr;
+                    if (!a_ || (kick.b >= 0 && !b_)) {
+                        def_ok = false;
+                        break;
+                    }
+                    fa[nk] = a_;
+                    fb[nk] = b_;
+                    plus[nk] = kick.c;
+                    coef[nk] = kick.coef;
+                    ++nk;
+                }
+                if (ndef > 0 && !def_ok) {
+                    if (flush_deferred()) return 1;         // (reports the unbound buffer)
+                    nk = 0;
+                }
+                const int nlead = nk;
                 int j = k;
                 while (j < n_ops && nk < 4 && ops[j].op == AMM_OP_KICK) {
                     const amm_op &kick = ops[j];
@@ -1220,8 +1250,10 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     ++j;
                 }
                 const bool moves = j < n_ops && ops[j].op == AMM_OP_MOVE;
-                if (nk == j - k && (nk >= 2 || (nk == 1 && moves))) {
+                const bool whole_run = !(j < n_ops && ops[j].op == AMM_OP_KICK);       // (a fifth kick: the run goes on)
+                if (nk - nlead == j - k && (nlead == 0 || whole_run) && (nk >= 2 || (nk == 1 && moves))) {
                     if (amm_kicks_move_impl(ctx, fa, fb, plus, coef, nk, moves ? 1 : 0, moves ? ops[j].coef : 0.0)) return 1;
+                    deferred.clear();
                     if (moves) {
                         ctx->pos_epoch++;
                         amm_watch_moved(ctx);
@@ -1229,6 +1261,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     k = j - (moves ? 0 : 1);
                     continue;
                 }
+                if (!deferred.empty() && flush_deferred()) return 1;       // (not taken along: before anything else, in their order)
             }
             switch (op.op) {
             case AMM_OP_EVAL: {
