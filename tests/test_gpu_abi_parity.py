@@ -973,6 +973,51 @@ def test_lj_fluid_vs_oracle_cells(adj):
     ctx.close()
 
 
+def test_velocity_verlet_steps_deferred_kick_is_bit_identical():
+    """A velocity-Verlet step KICK ; MOVE ; EVAL(pair force) ; KICK repeated by amm_run_ops: the kick that closes a repetition is
+    deferred into the kick + move launch that opens the next (one launch less per step, config C2).  Same bits as the same steps
+    issued one amm_run_ops call each (nothing to defer into), as every fusion off, and with a program of two kicks per half step
+    (three leading kicks in one launch); list rebuilds on the way."""
+    B = _backend()
+    pos, box, q, s, e = lj_fluid(12)
+    n = len(pos)
+    rng = np.random.default_rng(4)
+    mass = np.full(n, 39.9)
+    v0 = rng.normal(size=(n, 3)) * np.sqrt(2.494 / mass)[:, None]
+    d = near('force-switch', 0.85, 0.765)
+    dt = 0.004
+
+    def run(fuse, split, double_kick):
+        ctx = B.HipContext(n, box)
+        ctx.set_fuse_inner(fuse)
+        fid = ctx.pair_create(B.pair_desc(d.family, d.rc, rc0=d.rc0, rs0=d.rs0), q, s, e, None)
+        x, v, m = dev(pos), dev(v0), dev(mass)
+        f = torch.zeros((n, 3), dtype=torch.float64, device='cuda')
+        ctx.bind_state(x, v, m)
+        ctx.bind_buffer(1, f)
+        ctx.group_define(1, 1, [fid])
+        K, M, E = B.OP_KICK, B.OP_MOVE, B.OP_EVAL
+        half = [B.Op(K, 1, -1, 0, 0.25 * dt), B.Op(K, 1, -1, 0, 0.25 * dt)] if double_kick else [B.Op(K, 1, -1, 0, 0.5 * dt)]
+        step = half + [B.Op(M, 0, 0, 0, dt), B.Op(E, 1, 0, 0, 0.0)] + half
+        ctx.run_ops([B.Op(E, 1, 0, 0, 0.0)], 1)
+        if split:
+            for _ in range(40):
+                ctx.run_ops(step, 1)
+        else:
+            ctx.run_ops(step, 40)
+        ctx.check()
+        out = x.cpu().numpy().copy(), v.cpu().numpy().copy(), ctx.pair_stats(fid)['n_builds']
+        ctx.close()
+        return out
+
+    for double_kick in (False, True):
+        ref = run(False, True, double_kick)
+        assert ref[2] >= 2 and np.abs(ref[0] - pos).max() > 1e-3
+        for fuse, split in ((True, False), (True, True), (False, False)):
+            got = run(fuse, split, double_kick)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+
+
 def test_fused_inner_iteration_is_bit_identical(spcfw):
     """amm_run_ops fuses KICK;MOVE;EVAL(bond lists);KICK into one launch: same bits as the four separate launches,
     for an even and an odd number of fused iterations (the odd case copies the ping-pong state back)."""
