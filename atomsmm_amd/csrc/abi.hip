@@ -346,6 +346,8 @@ int amm_pair_set_scale(amm_ctx *ctx, int32_t force_id, double scale) {
     pf->dual_ok = pf->fuse_ok = -1;
     for (auto &fo : ctx->forces)
         if (fo.type == 1 && fo.pair->host == pf) fo.pair->dual_ok = fo.pair->fuse_ok = -1;
+    // (a hybrid list's per-atom part is a force of its own with its own constants: same scale)
+    if (pf->rest) return amm_pair_set_scale(ctx, pf->rest->id, scale);
     return 0;
 }
 
@@ -1086,6 +1088,10 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 }
             }
             // fused inner RESPA iteration: KICK(c1, fg) ; MOVE(d) ; EVAL(g) ; KICK(c2, fg) with g = one bond-list set
+            // (kicks deferred from the previous repetition must not be overtaken by this block's move: deferral requires
+            // f0_slot < 0, i.e. that this block never matched -- flushed here all the same, so that the order does not rest on that)
+            if (!deferred.empty() && ctx->fuse_inner && !ctx->iso.on && op.op == AMM_OP_KICK && op.b < 0 && k + 3 < n_ops &&
+                ops[k + 1].op == AMM_OP_MOVE && ops[k + 2].op == AMM_OP_EVAL && flush_deferred()) return 1;
             if (ctx->fuse_inner && !ctx->iso.on && op.op == AMM_OP_KICK && op.b < 0 && k + 3 < n_ops && ops[k + 1].op == AMM_OP_MOVE &&
                 ops[k + 2].op == AMM_OP_EVAL && ops[k + 3].op == AMM_OP_KICK && ops[k + 3].b < 0 && ops[k + 3].a == op.a &&
                 ops[k + 2].a >= 0 && ops[k + 2].a < AMM_MAX_GROUPS) {
@@ -1163,7 +1169,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 for (int fid : g.forces) {
                     ForceObj &fo = ctx->forces[fid];
                     if (fo.type == 2 && !bs) bs = fo.bonded;
-                    else if (fo.type == 1 && !ps && fo.pair->small && ctx->opt_small_group && !fo.pair->built) ps = fo.pair;
+                    else if (fo.type == 1 && !ps && fo.pair->small && ctx->opt_small_group && !fo.pair->built && amm_small_group_supported(fo.pair)) ps = fo.pair;
                     else plain = false;
                 }
                 double *buf = ctx->slots[g.slot];

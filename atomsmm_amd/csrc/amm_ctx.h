@@ -375,6 +375,7 @@ int amm_small_group_setup(amm_ctx *ctx, PairForce *pf, const std::vector<float> 
 // alone and d_force is scratch -- candidates again
 int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy,
                               BondedSet *carry_terms = nullptr, const double **own_rows = nullptr, int rows_unused = 0);
+bool amm_small_group_supported(const PairForce *pf);      // k_small_group has an instantiation for the force's family
 int amm_small_group_free(SmallGroup *sg);
 int amm_small_group_failed(SmallGroup *sg);
 int amm_small_group_stats(SmallGroup *sg, int out[2]);

@@ -427,6 +427,14 @@ static void launch_small(hipStream_t st, int nblocks, bool guard, bool en, const
 }
 
 // same contract as amm_pair_eval_impl (no guest, no exchange); returns -1 when the force's family has no instantiation here
+// the families k_small_group is instantiated for (every caller that cannot fall back to the list path asks first)
+bool amm_small_group_supported(const PairForce *pf) {
+    if (!pf || !pf->small) return false;
+    const int fam = pf->desc.family;
+    const bool grouped = (pf->pc.flags & (AMM_GROUP_LJ | AMM_GROUP_Q)) != 0;
+    return (fam == AMM_SOFTCORE && !grouped) || (grouped && (fam == AMM_NEAR_FSWITCH || (fam == AMM_NONBONDED && pf->pc.cmode == 0)));
+}
+
 int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double *d_force, int accumulate, double *d_energy,
                               BondedSet *carry_terms, const double **own_rows, int rows_unused) {
     SmallGroup *sg = pf->small;
@@ -434,7 +442,7 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     hipStream_t st = ctx->stream;
     const int fam = pf->desc.family;
     const bool grouped = (pf->pc.flags & (AMM_GROUP_LJ | AMM_GROUP_Q)) != 0;
-    if (!((fam == AMM_SOFTCORE && !grouped) || (grouped && (fam == AMM_NEAR_FSWITCH || (fam == AMM_NONBONDED && pf->pc.cmode == 0))))) return -1;
+    if (!amm_small_group_supported(pf)) return -1;
     const int n = pf->n;
     const int per = (n + ctx->world - 1) / ctx->world;
     SmallArgs A;

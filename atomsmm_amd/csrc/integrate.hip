@@ -6,6 +6,7 @@
 // (#pragma clang fp contract(off) below), so a kick/move here is BIT-IDENTICAL to the oracle's.
 // Pure streaming: 3N doubles, 16-byte accesses where the layout allows.
 #include "amm_ctx.h"
+#include "bonded_terms.h"
 
 // hipcc contracts a*b+c into FMA by default (and __dmul_rn/__dadd_rn are plain * and + in HIP):
 // switch contraction off for this file so that mul and add round separately, as in OpenMM's VM.
@@ -83,10 +84,7 @@ __global__ void k_kicks_move_atoms(int n, double *__restrict__ x, double *__rest
         xn[c] = x[t] + dx;
         x[t] = xn[c];
     }
-    for (int q = 0; q < W.n; ++q) {
-        const double dx = xn[0] - W.xref[q][3 * i], dy = xn[1] - W.xref[q][3 * i + 1], dz = xn[2] - W.xref[q][3 * i + 2];
-        if (!(dx * dx + dy * dy + dz * dz <= W.thr2[q])) W.flags[q][0] = 1;   // benign race (NaN also triggers)
-    }
+    amm_watch_atom(W, i, xn);      // (both flags: "rebuild wanted" and AMM_FLAG_FAR -- group.hip's candidate walk trusts the second)
 }
 
 int amm_kicks_move_impl(amm_ctx *ctx, const double *const *fa, const double *const *fb, const int *plus, const double *coef, int nk,

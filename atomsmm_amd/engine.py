@@ -1999,6 +1999,8 @@ class Engine:
             ops = [B.Op(B.OP_SAVE_REF, 0, 0, 0, 0.0)] if self._has_constraints else []
 
             def flush():
+                # (a run of per-DOF steps that is being recorded as one unit is no unit any more: the ops before the flush are gone)
+                self._segment_open = None
                 if ops:
                     # a RESPA block between two host-evaluated steps is a static run of ops: pair the near and the outer
                     # evaluation of one list into a single traversal, as the compiled path does
@@ -2026,7 +2028,11 @@ class Engine:
                     # copies) emits the same ops whenever the globals it names, the valid force groups and the mirrored buffers
                     # are the same: remembered as ONE unit (the host was slower than the GPU at config C5 walking it step by step)
                     pc_end = self._run_end(steps, pc)
-                    if pc_end - pc >= 4 and not eager[0] and self._replay_segment(pc, pc_end, steps, env, ops, valid):
+                    # (while THIS run is being recorded its later steps must not ask again: _replay_segment would drop the record
+                    # and open one for the remainder -- only the last four steps of a run were ever remembered as a unit)
+                    rec = self._segment_open
+                    recording = rec is not None and rec[1] == pc_end and not eager[0]
+                    if not recording and pc_end - pc >= 4 and not eager[0] and self._replay_segment(pc, pc_end, steps, env, ops, valid):
                         pc = pc_end
                         continue
                 if kind == C.ComputeGlobal:
