@@ -37,7 +37,7 @@ EXPORTS = [
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read', 'amm_pair_count_within', 'amm_pair_row_padding', 'amm_kernel_revision',
     'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_bath_define_nhl', 'amm_bath_define_sin', 'amm_iso_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
     'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_destroy', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
-    'amm_set_option', 'amm_positions_changed', 'amm_exchange_per',
+    'amm_set_option', 'amm_positions_changed', 'amm_exchange_per', 'amm_run_stats',
 ]
 
 
@@ -139,6 +139,7 @@ def lib():
         L.amm_comm_allreduce.argtypes = [vp, vp, C.c_int64]
         L.amm_comm_destroy.argtypes = [vp]
         L.amm_comm_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.amm_run_stats.argtypes = [vp, C.POINTER(C.c_int64)]
         L.amm_group_set_exchange.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_bind_exchange.argtypes = [vp, vp, C.c_int64]
         L.amm_exchange_finish.argtypes = [vp]
@@ -366,6 +367,12 @@ class HipContext:
         out = (C.c_int64 * 2)()
         _chk(lib().amm_comm_stats(self.h, out))
         return dict(calls=out[0], doubles=out[1])
+
+    def run_stats(self):
+        """What amm_run_ops fused so far: launches that carried the inner RESPA loop as an epilogue, evaluations without a gather launch."""
+        out = (C.c_int64 * 4)()
+        _chk(lib().amm_run_stats(self.h, out))
+        return dict(epilogues=out[0], copies_current=out[1])
 
     def bath_define(self, z, kT):
         bid = C.c_int32(-1)

@@ -986,8 +986,94 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
         return 0;
     };
     const bool no_defer = ctx->opt_no_defer != 0;      // tuning option (A/B)
-    for (int rep = 0; rep < repeat; ++rep)
-        for (int k = 0; k < n_ops; ++k) {
+    // ---- epilogue plans (cluster.hip: cepi_rows) ----
+    // The ops that follow a force-only pair evaluation at op index `after` -- [KICK ...] ; n x { KICK(f0) ; MOVE ; EVAL(g0) ; KICK(f0) }
+    // with g0 = one bond-list set of three-site molecules -- as a plan the evaluation's launch can carry.  When the program ENDS
+    // with the kicks (the closing half kicks of an outer step) and another repetition follows, the plan goes on with the kicks and
+    // the inner loop that open that repetition (`wraps`; what the deferred kicks do for the stand-alone inner-loop launch).
+    // q_resume: the first op not covered (in the next repetition when wraps).
+    auto slot_of = [&](int a) -> double * { return (a >= 0 && a < AMM_MAX_SLOTS) ? ctx->slots[a] : nullptr; };
+    auto plan_epilogue = [&](int after, int rep, EpiPlan &P, int &q_resume, bool &wraps) -> bool {
+        if (!ctx->fuse_inner || !ctx->opt_fuse_epilogue || ctx->iso.on || ctx->world != 1 || swapped || f0_slot >= 0) return false;
+        std::vector<amm_op> kicks;
+        int j = after;
+        wraps = false;
+        while (true) {
+            while (j < n_ops && ops[j].op == AMM_OP_KICK && (int)kicks.size() <= AMM_MAX_PRE) kicks.push_back(ops[j++]);
+            if (j == n_ops && !wraps && rep + 1 < repeat && !no_defer && !kicks.empty() && ops[0].op == AMM_OP_KICK) {
+                wraps = true;
+                j = 0;
+                continue;
+            }
+            break;
+        }
+        // the last kick of the run opens the first inner iteration
+        if (kicks.empty() || j < 1 || j + 2 >= n_ops) return false;
+        const int start = j - 1;
+        const amm_op &k1 = ops[start];
+        if (!(k1.op == AMM_OP_KICK && k1.b < 0 && ops[start + 1].op == AMM_OP_MOVE && ops[start + 2].op == AMM_OP_EVAL &&
+              ops[start + 3 < n_ops ? start + 3 : start].op == AMM_OP_KICK && start + 3 < n_ops)) return false;
+        const int g0 = ops[start + 2].a;
+        if (g0 < 0 || g0 >= AMM_MAX_GROUPS) return false;
+        GroupDef &g = ctx->groups[g0];
+        if (!(g.slot == k1.a && g.forces.size() == 1 && ctx->forces[g.forces[0]].type == 2 && !g.exchange)) return false;
+        BondedSet *bs = ctx->forces[g.forces[0]].bonded;
+        if (!bs->mol3_ok || bs->sliced) return false;
+        auto is_iter = [&](int q) {
+            return q + 3 < n_ops && ops[q].op == AMM_OP_KICK && ops[q].b < 0 && ops[q].a == k1.a && ops[q].coef == k1.coef &&
+                   ops[q + 1].op == AMM_OP_MOVE && ops[q + 1].coef == ops[start + 1].coef && ops[q + 2].op == AMM_OP_EVAL &&
+                   ops[q + 2].a == g0 && ops[q + 3].op == AMM_OP_KICK && ops[q + 3].b < 0 && ops[q + 3].a == k1.a &&
+                   ops[q + 3].coef == ops[start + 3].coef;
+        };
+        int niter = 0, q = start;
+        while (is_iter(q)) { ++niter; q += 4; }
+        const int npre = (int)kicks.size() - 1;
+        if (niter < 1 || npre > AMM_MAX_PRE) return false;
+        P = EpiPlan();
+        P.bs = bs;
+        P.f0 = ctx->slots[g.slot];
+        P.npre = npre;
+        P.niter = niter;
+        for (int p = 0; p < npre; ++p) {
+            P.pre_a[p] = slot_of(kicks[p].a);
+            P.pre_b[p] = kicks[p].b >= 0 ? slot_of(kicks[p].b) : nullptr;
+            if (!P.pre_a[p] || (kicks[p].b >= 0 && !P.pre_b[p])) return false;
+            P.pre_coef[p] = kicks[p].coef;
+            P.pre_plus[p] = kicks[p].c;
+        }
+        P.c1 = k1.coef;
+        P.d = ops[start + 1].coef;
+        P.c2 = ops[start + 3].coef;
+        if (!P.f0) return false;
+        // the force whose sorted copies the next pair evaluation reads: the next EVAL in program order (the list owner when it is
+        // one of a pair that is evaluated in one pass)
+        P.next = nullptr;
+        for (int t = q, seen = 0; seen < n_ops; ++seen, ++t) {
+            if (t >= n_ops) {
+                if (rep + (wraps ? 2 : 1) >= repeat) break;
+                t = 0;
+            }
+            if (ops[t].op != AMM_OP_EVAL) continue;
+            const int ga = ops[t].a;
+            if (ga < 0 || ga >= AMM_MAX_GROUPS || ctx->groups[ga].forces.empty() || ctx->forces[ctx->groups[ga].forces[0]].type != 1) break;
+            PairForce *pa = ctx->forces[ctx->groups[ga].forces[0]].pair;
+            P.next = pa;
+            if (t + 1 < n_ops && ops[t + 1].op == AMM_OP_EVAL && ops[t + 1].a >= 0 && ops[t + 1].a < AMM_MAX_GROUPS &&
+                !ctx->groups[ops[t + 1].a].forces.empty() && ctx->forces[ctx->groups[ops[t + 1].a].forces[0]].type == 1) {
+                PairForce *pb = ctx->forces[ctx->groups[ops[t + 1].a].forces[0]].pair;
+                if (pa->host == pb) P.next = pb;
+                else if (pb->host == pa) P.next = pa;
+            }
+            break;
+        }
+        q_resume = q;
+        return true;
+    };
+    int k_start = 0;
+    for (int rep = 0; rep < repeat; ++rep) {
+        const int k_first = k_start;
+        k_start = 0;
+        for (int k = k_first; k < n_ops; ++k) {
             const amm_op &op = ops[k];
             if (!deferred.empty() && !(k == 0 && op.op == AMM_OP_KICK) && flush_deferred()) return 1;
             // trailing block of the program = only KICKs and COPYs, and the program opens with KICKs: defer the kicks
@@ -1145,7 +1231,26 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                         PairForce *host = guest->host;
                         double *fg = ctx->slots[guest == pa ? g1.slot : g2.slot], *fh = ctx->slots[guest == pa ? g2.slot : g1.slot];
                         if (g1.exchange == g2.exchange && amm_pair_can_eval_dual(ctx, guest, host)) {
-                            if (amm_pair_eval_impl(ctx, host, ctx->d_x, fh, 0, nullptr, guest, fg, 0, g1.exchange)) return 1;
+                            // the kicks and the inner loop that follow as the launch's epilogue, when both groups are the pair forces alone
+                            EpiPlan plan;
+                            int q_resume = 0;
+                            bool wraps = false;
+                            const bool planned = !g1.exchange && g1.forces.size() == 1 && g2.forces.size() == 1 &&
+                                                 plan_epilogue(k + 2, rep, plan, q_resume, wraps);
+                            ctx->epi_request = planned ? &plan : nullptr;
+                            ctx->epi_done = false;
+                            const int rc_dual = amm_pair_eval_impl(ctx, host, ctx->d_x, fh, 0, nullptr, guest, fg, 0, g1.exchange);
+                            ctx->epi_request = nullptr;
+                            if (rc_dual) return 1;
+                            if (ctx->epi_done) {
+                                ctx->epi_done = false;
+                                if (wraps) {
+                                    k_start = q_resume;
+                                    break;
+                                }
+                                k = q_resume - 1;
+                                continue;
+                            }
                             if (exchange_left_to_host(ctx, rep == repeat - 1 && k + 1 == n_ops - 1)) return 1;
                             for (const GroupDef *g : {&g1, &g2})
                                 for (size_t j = 1; j < g->forces.size(); ++j)
@@ -1282,6 +1387,29 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     return 1;
                 }
                 if (g.forces.empty()) AMM_HIP(hipMemsetAsync(buf, 0, sizeof(double) * 3 * (size_t)ctx->n, ctx->stream));
+                if (!g.exchange && g.forces.size() == 1 && ctx->forces[g.forces[0]].type == 1) {
+                    // one pair force: the kicks and the inner loop that follow can ride on its launch (molecule rows: cepi_rows)
+                    EpiPlan plan;
+                    int q_resume = 0;
+                    bool wraps = false;
+                    if (plan_epilogue(k + 1, rep, plan, q_resume, wraps)) {
+                        ctx->epi_request = &plan;
+                        ctx->epi_done = false;
+                        const int rc_one = amm_pair_eval_impl(ctx, ctx->forces[g.forces[0]].pair, ctx->d_x, buf, 0, nullptr);
+                        ctx->epi_request = nullptr;
+                        if (rc_one) return 1;
+                        if (ctx->epi_done) {
+                            ctx->epi_done = false;
+                            if (wraps) {
+                                k_start = q_resume;
+                                k = n_ops;          // (leaves the loop over this repetition's ops)
+                            } else {
+                                k = q_resume - 1;
+                            }
+                        }
+                        break;
+                    }
+                }
                 if (g.exchange) {
                     if (g.forces.size() != 1 || ctx->forces[g.forces[0]].type != 1) {
                         amm_set_error("amm_run_ops: an exchanged group must hold exactly one pair force");
@@ -1413,6 +1541,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
             default: amm_set_error("amm_run_ops: unknown op"); return 1;
             }
         }
+    }
     if (flush_deferred()) return 1;
     if (swapped) {   // odd number of fused iterations: bring the state back into the caller's buffers
         const size_t bytes = sizeof(double) * 3 * (size_t)ctx->n;
@@ -1557,10 +1686,19 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "no_defer") ctx->opt_no_defer = v;
     else if (k == "terms_from") ctx->opt_terms_from = v;
     else if (k == "no_term_lanes") ctx->opt_no_term_lanes = v;
+    else if (k == "fuse_epilogue") ctx->opt_fuse_epilogue = v;
     else {
         amm_set_error("amm_set_option: unknown option '" + k + "'");
         return 1;
     }
+    return 0;
+}
+
+int amm_run_stats(amm_ctx *ctx, int64_t out[4]) {
+    if (!ctx || !out) return 1;
+    out[0] = ctx->n_epilogues;
+    out[1] = ctx->n_copies_current;
+    out[2] = out[3] = 0;
     return 0;
 }
 

@@ -110,6 +110,7 @@ struct PairForce {
     int *d_perm = nullptr, *d_inv_perm = nullptr;
     double4 *d_posq_s = nullptr;   // sorted: wrapped x,y,z and charge
     double2 *d_lj_s = nullptr;     // sorted: sigma/2, 2*sqrt(eps)
+    double4 *d_posq_alt = nullptr; // molecule rows: second copy of d_posq_s, for an epilogue that writes the sorted positions of the NEXT evaluation of this same force
     float4 *d_pos4f_s = nullptr;   // sorted fp32 positions at the last list build
     double *d_xref = nullptr;      // positions at the last prune (original order)
     double *d_xref_out = nullptr;  // positions at the last outer (cell-based) build
@@ -182,6 +183,10 @@ struct BondedSet {
     int ncomp = 0, max_comp = 0;
     // term-parallel inner loop: every component has at most G terms (G lanes per component) -> lane l evaluates term l
     bool terms_ok = false;
+    // ... and, further, every component is one three-site molecule {3 c, 3 c + 1, 3 c + 2} (slot = atom order) with at most four terms,
+    // all of them harmonic bonds / angles (a box of flexible three-site water): the row owner of a molecule-row pair kernel can then
+    // run the inner RESPA loop of its molecules as the kernel's epilogue (cluster.hip: cepi_rows)
+    bool mol3_ok = false;
     int4 *d_term_l = nullptr;                 // [ncomp*G] atoms of the term as component slots (x < 0: no term)
     double4 *d_term_q = nullptr;              // [ncomp*G] parameters + kind/periodic code
     unsigned long long *d_atom_recs = nullptr; // [n] the atom's records as (term slot | role << 3) in 5-bit fields, count in bits 60..63
@@ -278,8 +283,28 @@ static inline int amm_slice_per(int n, int world) {
     return 3 * ((nc + world - 1) / world);
 }
 
+// What follows a force-only pair evaluation in the step program when it is `[KICK ...] ; n x { KICK(f0) ; MOVE ; EVAL(group of f0) ; KICK(f0) }`
+// with the innermost group one bond-list set of three-site molecules (BondedSet::mol3_ok): amm_run_ops hands it to the evaluation, and a
+// molecule-row kernel runs it as its epilogue -- the wavefront that has just summed a molecule's rows kicks, moves and re-evaluates that
+// molecule (no other atom enters) and writes the sorted copies of the next pair evaluation (cluster.hip: cepi_rows).
+struct EpiPlan {
+    BondedSet *bs = nullptr;
+    double *f0 = nullptr;              // the innermost group's force buffer
+    int npre = 0, niter = 0;
+    const double *pre_a[AMM_MAX_PRE] = {nullptr}, *pre_b[AMM_MAX_PRE] = {nullptr};
+    double pre_coef[AMM_MAX_PRE] = {0};
+    int pre_plus[AMM_MAX_PRE] = {0};
+    double c1 = 0, d = 0, c2 = 0;
+    PairForce *next = nullptr;         // the force whose sorted copies the next pair evaluation reads (nullptr: not known)
+};
+
 struct amm_ctx {
     int n = 0;
+    int opt_fuse_epilogue = 1;         // molecule rows: the inner RESPA loop of a box of three-site molecules as the pair kernel's epilogue
+    const EpiPlan *epi_request = nullptr;   // amm_run_ops -> amm_cluster_eval_impl (one evaluation)
+    bool epi_done = false;             // ... which says here whether its launch carried the plan (it then bumped pos_epoch itself)
+    long long n_epilogues = 0;         // launches that did (statistics)
+    long long n_copies_current = 0;    // evaluations that found their sorted copies in place (no gather launch)
     // tuning / test options (amm_set_option): never read from the environment, so that a stray variable cannot change the
     // order of summation of a production run
     int opt_cluster = 1;           // molecule rows for qualifying forces (0: per-atom rows everywhere)

@@ -369,17 +369,6 @@ struct PreKick {
     int plus;
 };
 
-// num / m, correctly rounded, from a precomputed r = RN(1/m) (Markstein 1990): q = RN(num r), e = num - q m exactly
-// (fma), result RN(q + e r) -- identical to the IEEE quotient unless m's significand is all ones, where RN(1/m) is
-// not within half an ulp; those masses (never seen in a force field) take the hardware division.  3 instructions
-// instead of the ~30 of the fp64 division sequence; the inner loop does 18 of them per iteration.
-__device__ __forceinline__ double amm_div_mass(double num, double m, double r, bool exact_r) {
-    const double q = num * r;
-    const double e = fma(-q, m, num);
-    const double fast = fma(e, r, q);
-    return exact_r ? fast : num / m;
-}
-
 struct CompArgs {
     const int *comp_ptr, *comp_atoms;
     const int4 *term_l;             // term-parallel variant (TERMS): one term per lane, see BondedSet
@@ -779,6 +768,14 @@ int amm_bonded_finalize_impl(amm_ctx *ctx, BondedSet *bs) {
                 }
             }
         if (bs->terms_ok) {
+            // one component per three-site molecule, slots in atom order, harmonic bonds / angles only?  (cluster.hip's epilogue)
+            bool mol3 = G == 4 && 3 * (long)ncomp == (long)n;
+            for (int c2 = 0; c2 < ncomp && mol3; ++c2)
+                mol3 = csize[c2] == 3 && comp_atoms[comp_ptr[c2]] == 3 * c2 && comp_atoms[comp_ptr[c2] + 1] == 3 * c2 + 1 &&
+                       comp_atoms[comp_ptr[c2] + 2] == 3 * c2 + 2;
+            for (int kd = 2; kd < 8; ++kd) mol3 = mol3 && bs->n_terms[kd] == 0;
+            for (int i = 0; i < n && mol3; ++i) mol3 = nrec_of[i] <= 4;
+            bs->mol3_ok = mol3;
             for (int i = 0; i < n; ++i) atom_recs[i] |= (unsigned long long)nrec_of[i] << 60;
             AMM_HIP(hipMalloc(&bs->d_term_l, sizeof(int4) * term_l.size()));
             AMM_HIP(hipMalloc(&bs->d_term_q, sizeof(double4) * term_q.size()));

@@ -58,6 +58,17 @@ __device__ __forceinline__ void amm_watch_atom(const WatchArgs &W, int a, const 
     }
 }
 
+// num / m, correctly rounded, from a precomputed r = RN(1/m) (Markstein 1990): q = RN(num r), e = num - q m exactly
+// (fma), result RN(q + e r) -- identical to the IEEE quotient unless m's significand is all ones, where RN(1/m) is
+// not within half an ulp; those masses (never seen in a force field) take the hardware division.  3 instructions
+// instead of the ~30 of the fp64 division sequence; the inner loop does 18 of them per iteration.
+__device__ __forceinline__ double amm_div_mass(double num, double m, double r, bool exact_r) {
+    const double q = num * r;
+    const double e = fma(-q, m, num);
+    const double fast = fma(e, r, q);
+    return exact_r ? fast : num / m;
+}
+
 // positions of a component's atoms in a wavefront-private LDS strip, indexed by the atom's slot in its component
 struct PosLds {
     const double *sx, *sy, *sz;     // strip of this lane's group

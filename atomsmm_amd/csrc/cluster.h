@@ -44,6 +44,11 @@ struct ClusterList {
     int *d_ticket = nullptr;
     long checked_epoch = -1, pre_epoch = -1;
     const double *checked_pos = nullptr, *pre_pos = nullptr;
+    // sorted fp64 copies written ahead of time by the launch that moved the atoms (cluster.hip: cepi_rows): for which force, and for
+    // which positions (epoch / buffer) -- the next evaluation of that force then skips the gather
+    PairForce *sorted_for = nullptr;
+    long sorted_epoch = -1;
+    const double *sorted_pos = nullptr;
     bool per_pair_image = false;   // small box: the periodic image is chosen per atom pair, not per molecule pair
 };
 

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "amm_ctx.h"
+#include "bonded_terms.h"
 #include "cluster.h"
 #include "device_utils.h"
 #include "pair_math.h"
@@ -122,6 +123,14 @@ __global__ void __launch_bounds__(256) k_cassign(int nc, const double *__restric
     if (threadIdx.x == 0) flags[6] = fullest;
 }
 
+// coordinate of an atom in its molecule's sorted copy: the image of the molecule's first atom (x0; sh = wrapped(x0) - x0).  An atom
+// that was wrapped into the box on its own comes back to its molecule: the rint is 0 for a whole molecule and the sum then has the
+// bits of x + sh.  ONE function for every writer of the sorted copies (the gather launch, the rebuild, the pair kernels' epilogue):
+// they must agree bit for bit
+__device__ __forceinline__ double csorted_image(double x, double x0, double sh, double L, double invL) {
+    return x + (sh - L * rint((x - x0) * invL));
+}
+
 // sorted fp64 copies of one molecule (kept whole: every atom takes the image of the first)
 __device__ __forceinline__ void cgather_one(int c, int i0, const double *__restrict__ pos, Box box, const double *__restrict__ q,
                                             const double *__restrict__ hsig, const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s) {
@@ -132,11 +141,9 @@ __device__ __forceinline__ void cgather_one(int c, int i0, const double *__restr
     for (int a = 0; a < 3; ++a) {
         const int i = i0 + a;
         double4 p;
-        // (the image of the first atom's; an atom that was wrapped into the box on its own comes back to its molecule: the
-        // rint is 0 for a whole molecule and the sum below then has the bits of pos + sh)
-        p.x = pos[3 * i] + (sh[0] - box.L[0] * rint((pos[3 * i] - pos[3 * i0]) * box.invL[0]));
-        p.y = pos[3 * i + 1] + (sh[1] - box.L[1] * rint((pos[3 * i + 1] - pos[3 * i0 + 1]) * box.invL[1]));
-        p.z = pos[3 * i + 2] + (sh[2] - box.L[2] * rint((pos[3 * i + 2] - pos[3 * i0 + 2]) * box.invL[2]));
+        p.x = csorted_image(pos[3 * i], pos[3 * i0], sh[0], box.L[0], box.invL[0]);
+        p.y = csorted_image(pos[3 * i + 1], pos[3 * i0 + 1], sh[1], box.L[1], box.invL[1]);
+        p.z = csorted_image(pos[3 * i + 2], pos[3 * i0 + 2], sh[2], box.L[2], box.invL[2]);
         p.w = q[i];
         posq_s[3 * c + a] = p;
         lj_s[3 * c + a] = make_double2(hsig[i], seps2[i]);
@@ -151,7 +158,7 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
                                                       float4 *pos4f, const int *flags, int *wflags, int force, const double *__restrict__ q,
                                                       const double *__restrict__ hsig, const double *__restrict__ seps2, double4 *posq_s,
                                                       double2 *lj_s, float rext, const double *__restrict__ site_eps,
-                                                      const int *__restrict__ first, CZeroRows Z) {
+                                                      const int *__restrict__ first, CZeroRows Z, int copies_current) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     // (hybrid lists: the force rows of the atoms outside the molecules start from zero; the molecule-row kernel writes the others
     // and the per-atom part adds to all of them -- a launch of its own before)
@@ -161,7 +168,8 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
         if (Z.f1) Z.f1[3 * i] = Z.f1[3 * i + 1] = Z.f1[3 * i + 2] = 0.0;
     }
     if (!force && !flags[0]) {
-        if (posq_s && gid < nc) cgather_one(gid, cfirst(first, cperm[gid]), pos, box, q, hsig, seps2, posq_s, lj_s);
+        // (copies_current: the launch that moved the atoms wrote the copies of these positions already -- cepi_rows)
+        if (!copies_current && posq_s && gid < nc) cgather_one(gid, cfirst(first, cperm[gid]), pos, box, q, hsig, seps2, posq_s, lj_s);
         return;
     }
     const int wave = gid >> 6, lane = threadIdx.x & 63;
@@ -196,9 +204,9 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
         for (int t = 0; t < 3; ++t) {
             const int i = i0 + t;
             aperm[3 * sl + t] = i;
-            const double x = pos[3 * i] + (sh[0] - box.L[0] * rint((pos[3 * i] - p0[0]) * box.invL[0]));
-            const double y = pos[3 * i + 1] + (sh[1] - box.L[1] * rint((pos[3 * i + 1] - p0[1]) * box.invL[1]));
-            const double z = pos[3 * i + 2] + (sh[2] - box.L[2] * rint((pos[3 * i + 2] - p0[2]) * box.invL[2]));
+            const double x = csorted_image(pos[3 * i], p0[0], sh[0], box.L[0], box.invL[0]);
+            const double y = csorted_image(pos[3 * i + 1], p0[1], sh[1], box.L[1], box.invL[1]);
+            const double z = csorted_image(pos[3 * i + 2], p0[2], sh[2], box.L[2], box.invL[2]);
             pf[t] = make_float4((float)x, (float)y, (float)z, 0.f);
             const float dx = pf[t].x - pf[0].x, dy = pf[t].y - pf[0].y, dz = pf[t].z - pf[0].z;
             ext2 = fmaxf(ext2, dx * dx + dy * dy + dz * dz);
@@ -808,6 +816,182 @@ __device__ __forceinline__ void cwalk_rows(const CPairArgs &A, const PairConsts 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ epilogue: the inner RESPA loop
+// A box of flexible three-site molecules (BondedSet::mol3_ok: the innermost force group is one bond-list set whose components are the
+// molecules) couples nothing between molecules inside the inner RESPA loop
+//     [kicks with the forces of this launch / of earlier ones]  n0 x { v += c1 f0/m ; x += d v ; f0 = bonded(x) ; v += c2 f0/m }
+// (propagators.py:933-973 unrolled; bonded.hip: k_inner_lanes runs it as a launch of its own).  The wavefront that has just summed
+// the rows of its molecules holds everything the loop needs that this launch produced, so it runs the loop right there: the first
+// four lanes of a row's lanes take atom l / term l of the molecule (k_inner_lanes' TERMS scheme: lane l evaluates term l once, every
+// atom adds up its records in record order -- the same numbers in the same order, bit-identical), positions and term forces travel
+// between the four lanes by wavefront shuffles (no LDS: the fused pass uses 155 of the CU's 160 KB), and the launch also writes what
+// the NEXT pair evaluation reads -- the sorted fp64 copies of the new positions, through the current permutation -- and evaluates the
+// lists' displacement triggers.  Per outer step of RESPA [4, 2, 1] that is two launches of k_inner_lanes and two gather launches
+// less, and the work runs where the pair kernel leaves the chip half empty (the older wavefront of every SIMD finishes a quarter
+// of the kernel's time before the younger one: profiles/r04_wave_times.txt).  The pair kernel never reads x, v or the force
+// buffers of other groups (only the sorted copies, which this launch does not write: the next evaluation's are another buffer).
+struct CEpiPre {
+    const double *a, *b;       // v += coef (a -/+ b) / m ; b may be null (the buffers may be those this launch writes)
+    double coef;
+    int plus;
+};
+struct CEpiArgs {
+    int niter, npre;
+    double *x, *v, *f0;
+    const double *mass;
+    double c1, d, c2;
+    CEpiPre pre[AMM_MAX_PRE];
+    const int *cperm;                          // sorted cluster -> molecule = component of the bond-list set
+    const int4 *term_l;                        // [molecule * 4 + lane] BondedSet::d_term_l / d_term_q / d_atom_recs
+    const double4 *term_q;
+    const unsigned long long *atom_recs;
+    double4 *posq_next;                        // sorted copies of the next pair evaluation (null: none)
+    double2 *lj_next;                          // (null: that force's are in place already)
+    const double *q_next, *hsig_next, *seps2_next;
+    WatchArgs W;
+};
+
+#ifndef CEPI_INLINE
+#define CEPI_INLINE __forceinline__
+#endif
+// positions of the (up to three) atoms of the lane's term, fetched from their lanes before the term code runs (the term code
+// branches on the kind of term per lane, and a shuffle reads nothing from a lane that is not executing it)
+struct PosTermRegs {
+    double p[3][3];
+    __device__ __forceinline__ double get(int r, int k) const { return p[r][k]; }
+};
+
+// NOT inlined, and called when the wavefront has walked ALL of its rows (a second loop over its tasks): inlined behind a task's
+// walk, its arguments and temporaries entered the register allocation of the pair loop (the near kernel went from no scratch to 63
+// scratch accesses inside the loop, the fused pass from 4 to 223), and as a call behind every task the values the pair loop keeps
+// across tasks competed for the callee-saved registers (19 scratch accesses in the fused pass's loop).  Here nothing of the pair loop
+// is live any more.  This launch's forces on the molecule are read back from the buffers the row's first lane stored them to
+// (the caller orders those stores before these loads: same wavefront, same L1).
+// (the box BY VALUE: a reference into the kernel's CPairArgs makes the compiler keep a private copy of the whole argument block in
+// scratch, and the pair loop then reads A.box, A.margin ... from there on every trip)
+__device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, bool valid, int sub) {
+    const int lane = threadIdx.x & 63;
+    const int l = sub & 3;
+    const int qb = lane - sub;                 // first lane of the row's lanes (a multiple of 4)
+    const bool has = valid && sub < 3;         // this lane owns atom l of the row's molecule ...
+    const bool tlane = valid && sub < 4;       // ... and evaluates its term l
+    const int mol = E.cperm[cs];               // (rows beyond the slice alias a valid molecule and never store)
+    const int a = 3 * mol + (l < 3 ? l : 0);
+    const double m = E.mass[a];
+    double x[3], v[3], f[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        x[j] = E.x[3 * a + j];
+        v[j] = E.v[3 * a + j];
+        f[j] = E.f0[3 * a + j];
+    }
+    int4 my_tl = make_int4(-1, -1, -1, -1);
+    double4 my_tq = make_double4(0.0, 0.0, 0.0, 0.0);
+    unsigned long long my_recs = 0ull;
+    if (tlane) {
+        my_tl = E.term_l[4 * mol + l];
+        my_tq = E.term_q[4 * mol + l];
+    }
+    if (has) my_recs = E.atom_recs[a];
+    const double rm = 1.0 / m;
+    const bool rok = (__double_as_longlong(m) & 0xFFFFFFFFFFFFFll) != 0xFFFFFFFFFFFFFll && m > 1e-200 && m < 1e200;
+    {
+#pragma clang fp contract(off)
+        for (int p = 0; p < E.npre; ++p) {
+            const CEpiPre pk = E.pre[p];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double ff = pk.a[3 * a + j];
+                if (pk.b) ff = pk.plus ? ff + pk.b[3 * a + j] : ff - pk.b[3 * a + j];
+                const double num = pk.coef * ff;
+                const double dv = amm_div_mass(num, m, rm, rok);
+                v[j] = v[j] + dv;
+            }
+        }
+    }
+    BondedArgs BA;                             // (harmonic bonds and angles read its box alone)
+    BA.box = box;
+    const int rec_n = (int)(my_recs >> 60);
+    const long long code = __double_as_longlong(my_tq.w);
+    const int kind = (int)(code & 1), periodic = (int)((code >> 5) & 1);
+    const int ix[4] = {0, 1, 2, 3};
+    const double par[3] = {my_tq.x, my_tq.y, my_tq.z};
+    // lanes the term's atoms live in (a lane without a term reads its own row's first lane: any executing lane will do)
+    const int s0 = qb + (my_tl.x & 3), s1 = qb + (my_tl.y & 3), s2 = qb + (my_tl.z & 3);
+    for (int it = 0; it < E.niter; ++it) {
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double num = E.c1 * f[j];
+                const double dv = amm_div_mass(num, m, rm, rok);
+                v[j] = v[j] + dv;
+                const double dx = E.d * v[j];
+                x[j] = x[j] + dx;
+            }
+        }
+        PosTermRegs pos;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pos.p[0][k] = __shfl(x[k], s0);
+            pos.p[1][k] = __shfl(x[k], s1);
+            pos.p[2][k] = __shfl(x[k], s2);
+        }
+        double fo[4][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        if (my_tl.x >= 0) {
+            double e;
+            bonded_term_forces(BA, pos, ix, par, kind, periodic, fo, e);
+        }
+        f[0] = f[1] = f[2] = 0.0;
+        // the atom's records in order: (term slot, role) -> that term's force on that role, from the term's lane.  Every lane
+        // executes every shuffle (the source lanes must); a lane with fewer records keeps its sum
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int rcode = (int)((my_recs >> (5 * t)) & 31ull);
+            const int src = qb + (rcode & 3), role = rcode >> 3;
+#pragma unroll
+            for (int xx = 0; xx < 3; ++xx) {
+                const double r0 = __shfl(fo[0][xx], src), r1 = __shfl(fo[1][xx], src), r2 = __shfl(fo[2][xx], src);
+                const double add = role == 0 ? r0 : (role == 1 ? r1 : r2);
+                f[xx] = t < rec_n ? f[xx] + add : f[xx];
+            }
+        }
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double num = E.c2 * f[j];
+                const double dv = amm_div_mass(num, m, rm, rok);
+                v[j] = v[j] + dv;
+            }
+        }
+    }
+    // the molecule's first atom decides the image of the sorted copy
+    double x0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x0[k] = __shfl(x[k], qb);
+    if (has) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            E.x[3 * a + j] = x[j];
+            E.v[3 * a + j] = v[j];
+            E.f0[3 * a + j] = f[j];
+        }
+        if (E.niter > 0) {
+            amm_watch_atom(E.W, a, x);
+            if (E.posq_next) {
+                double4 pq;
+                pq.x = csorted_image(x[0], x0[0], cwrap1(x0[0], box.L[0], box.invL[0]) - x0[0], box.L[0], box.invL[0]);
+                pq.y = csorted_image(x[1], x0[1], cwrap1(x0[1], box.L[1], box.invL[1]) - x0[1], box.L[1], box.invL[1]);
+                pq.z = csorted_image(x[2], x0[2], cwrap1(x0[2], box.L[2], box.invL[2]) - x0[2], box.L[2], box.invL[2]);
+                pq.w = E.q_next[a];
+                E.posq_next[3 * cs + l] = pq;
+                if (E.lj_next) E.lj_next[3 * cs + l] = make_double2(E.hsig_next[a], E.seps2_next[a]);
+            }
+        }
+    }
+}
+
 #ifndef AMM_CBS_SINGLE
 #define AMM_CBS_SINGLE 512
 #endif
@@ -820,9 +1004,9 @@ __device__ __forceinline__ void cwalk_rows(const CPairArgs &A, const PairConsts 
 #endif
 // LDS: [host Coulomb table][guest Coulomb table][host site-site table][guest site-site table][erfcx table][parameter strips];
 // kernels with site-site tables need neither strips nor -- in LDS -- the erfcx table (their rare analytic path reads it from HBM)
-template <int FAM, int CMODE, int GFAM, int BS, int SMASK>
+template <int FAM, int CMODE, int GFAM, int BS, int SMASK, bool EPI = false>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_CTAB_WAVES_PER_EU)))
-k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
+k_cpair(CPairArgs A, PairConsts c, PairConsts g, CEpiArgs E) {
     constexpr bool DUAL = GFAM >= 0;
     constexpr bool SS = SMASK != 0;
     extern __shared__ __align__(16) char s_lds[];
@@ -952,7 +1136,24 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g) {
                 }
             }
         }
+        // the inner RESPA loop of the rows' molecules (cepi_rows): the row's sums are in f / fg on all of its lanes
     }
+    }
+    if (EPI) {
+        // the inner RESPA loop of the molecules whose rows this wavefront has just summed (cepi_rows): the same tasks again.  The
+        // forces were stored by the first lane of each row; the molecule's lanes read them back (wavefront-scope ordering: the
+        // stores have left the wavefront before the loads are issued; one L1 serves both)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int phase = 0; phase < A.nphase; ++phase) {
+            const int shift = A.ph_shift[phase], row0 = xcd * A.rpx + A.ph_off[phase], ntask = A.ph_ntask[phase];
+            const int rpw = 64 >> shift;
+            for (int task = (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); task < ntask; task += nwx) {
+                const int a = row0 + task * rpw + (lane >> shift);
+                const bool valid = a < row_end;
+                cepi_rows(E, A.box, A.c_begin + (valid ? a : 0), valid, lane & ((1 << shift) - 1));
+            }
+        }
     }
 #ifdef AMM_CPAIR_TIMING
     if (A.wave_times && (threadIdx.x & 63) == 0) {
@@ -1026,8 +1227,8 @@ static int g_num_cu_c[64] = {0};
 
 // 2 wavefronts per SIMD (187 registers one force, 240 fused): one block of 512 per CU; 8 rows per wavefront then deal 2 tasks to
 // every wavefront at 98 304 atoms (768 threads: 1.33 -- a third of the chip idles in the tail)
-template <int FAM, int CMODE, int GFAM, int SMASK>
-static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g) {
+template <int FAM, int CMODE, int GFAM, int SMASK, bool EPI = false>
+static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g, const CEpiArgs &E = CEpiArgs()) {
     constexpr bool DUAL = GFAM >= 0;
     constexpr int BS = DUAL ? AMM_CBS_SINGLE : AMM_CBS_NEAR;
     constexpr bool SS = SMASK != 0;
@@ -1036,7 +1237,7 @@ static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c,
     int lds = A.host_bytes + (DUAL ? A.guest_bytes : 0);
     if (SS) lds += A.host_ss_bytes + (DUAL ? A.guest_ss_bytes : 0);
     else lds += AMM_ERFCX_NI * AMM_ERFCX_NC * 8 + (BS / 64) * 192 * 16;
-    auto kern = k_cpair<FAM, CMODE, GFAM, BS, SMASK>;
+    auto kern = k_cpair<FAM, CMODE, GFAM, BS, SMASK, EPI>;
     if (lds > k.lds_set) {
         AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         k.lds_set = lds;
@@ -1068,7 +1269,7 @@ static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c,
         const size_t nw = (size_t)nblk * WPB;
         AMM_HIP(hipMalloc(&d_times, sizeof(unsigned long long) * 4 * nw));
         P.wave_times = d_times;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, P, c, g);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, P, c, g, E);
         std::vector<unsigned long long> h(4 * nw);
         AMM_HIP(hipMemcpy(h.data(), d_times, sizeof(unsigned long long) * 4 * nw, hipMemcpyDeviceToHost));
         std::string path = std::string(std::getenv("AMM_WAVE_TIMES_OUT") ? std::getenv("AMM_WAVE_TIMES_OUT") : "/tmp/wave_times") + (DUAL ? ".fused" : ".single");
@@ -1079,17 +1280,25 @@ static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c,
         return 0;
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, P, c, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, P, c, g, E);
     return 0;
 }
 
 #define AMM_CPAIR_LDS_LIMIT (160 * 1024)
 // site-site tables are used when the force has one (A.host_ss_bytes > 0; for a fused pass: both forces) and everything fits LDS
+// E: the inner RESPA loop to run as the kernel's epilogue (cepi_rows; kernels with site-site tables only -- without one the caller
+// is told, *epi_done stays false, and runs the loop as launches of its own)
 template <int FAM, int CMODE, int GFAM>
-static int launch_cpair_s(amm_ctx *ctx, CPairArgs A, const PairConsts &c, const PairConsts &g) {
+static int launch_cpair_s(amm_ctx *ctx, CPairArgs A, const PairConsts &c, const PairConsts &g, const CEpiArgs *E = nullptr, bool *epi_done = nullptr) {
     constexpr bool DUAL = GFAM >= 0;
     bool ss = ctx->opt_site_tab && A.host_ss_bytes > 0 && (!DUAL || A.guest_ss_bytes > 0);
     if (ss && A.host_bytes + A.host_ss_bytes + (DUAL ? A.guest_bytes + A.guest_ss_bytes : 0) > AMM_CPAIR_LDS_LIMIT) ss = false;
+#ifndef AMM_CLUSTER_TUNE
+    if (ss && E) {
+        if (epi_done) *epi_done = true;
+        return A.site_atoms == 1 ? launch_cpair_t<FAM, CMODE, GFAM, 1, true>(ctx, A, c, g, *E) : launch_cpair_t<FAM, CMODE, GFAM, 7, true>(ctx, A, c, g, *E);
+    }
+#endif
     // (A.site_atoms: the row atoms that are sites in some molecule -- 1 for three-site water: only the first)
     if (ss) return A.site_atoms == 1 ? launch_cpair_t<FAM, CMODE, GFAM, 1>(ctx, A, c, g) : launch_cpair_t<FAM, CMODE, GFAM, 7>(ctx, A, c, g);
     PairConsts c0 = c, g0 = g;
@@ -1100,21 +1309,21 @@ static int launch_cpair_s(amm_ctx *ctx, CPairArgs A, const PairConsts &c, const 
 
 // fused pass: which (host, guest) pairs have a kernel.  Returns -1 when there is none (the caller launches the two forces one
 // after the other), 0 / 1 as the launch functions
-static int launch_cdual(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g) {
+static int launch_cdual(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const PairConsts &g, const CEpiArgs *E = nullptr, bool *epi_done = nullptr) {
     if (g.family != AMM_NEAR_FSWITCH) return -1;
-    if (c.family == AMM_DAMPED && c.degree == 1) return launch_cpair_s<AMM_DAMPED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+    if (c.family == AMM_DAMPED && c.degree == 1) return launch_cpair_s<AMM_DAMPED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g, E, epi_done);
 #ifndef AMM_CLUSTER_TUNE
-    if (c.family == AMM_DAMPED) return launch_cpair_s<AMM_DAMPED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+    if (c.family == AMM_DAMPED) return launch_cpair_s<AMM_DAMPED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g, E, epi_done);
     if (c.family == AMM_NONBONDED) {
-        if (c.cmode == 1) return launch_cpair_s<AMM_NONBONDED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g);
-        if (c.cmode == 2) return launch_cpair_s<AMM_NONBONDED, 2, AMM_NEAR_FSWITCH>(ctx, A, c, g);
-        return launch_cpair_s<AMM_NONBONDED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g);
+        if (c.cmode == 1) return launch_cpair_s<AMM_NONBONDED, 1, AMM_NEAR_FSWITCH>(ctx, A, c, g, E, epi_done);
+        if (c.cmode == 2) return launch_cpair_s<AMM_NONBONDED, 2, AMM_NEAR_FSWITCH>(ctx, A, c, g, E, epi_done);
+        return launch_cpair_s<AMM_NONBONDED, 0, AMM_NEAR_FSWITCH>(ctx, A, c, g, E, epi_done);
     }
 #endif
     return -1;
 }
 
-static int launch_cpair(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c) {
+static int launch_cpair(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, const CEpiArgs *E = nullptr, bool *epi_done = nullptr) {
 #ifdef AMM_CLUSTER_TUNE      // kernel tuning builds (scripts/build_variant.sh cluster ...): the two instantiations of the bench only
     if (c.family == AMM_NEAR_FSWITCH) return launch_cpair_s<AMM_NEAR_FSWITCH, 0, -1>(ctx, A, c, c);
     if (c.family == AMM_DAMPED && c.degree == 1) return launch_cpair_s<AMM_DAMPED, 1, -1>(ctx, A, c, c);
@@ -1122,16 +1331,16 @@ static int launch_cpair(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c) {
     return 1;
 #else
     switch (c.family) {
-    case AMM_NEAR_NONE: return launch_cpair_s<AMM_NEAR_NONE, 0, -1>(ctx, A, c, c);
-    case AMM_NEAR_SHIFT: return launch_cpair_s<AMM_NEAR_SHIFT, 0, -1>(ctx, A, c, c);
-    case AMM_NEAR_FSWITCH: return launch_cpair_s<AMM_NEAR_FSWITCH, 0, -1>(ctx, A, c, c);
+    case AMM_NEAR_NONE: return launch_cpair_s<AMM_NEAR_NONE, 0, -1>(ctx, A, c, c, E, epi_done);
+    case AMM_NEAR_SHIFT: return launch_cpair_s<AMM_NEAR_SHIFT, 0, -1>(ctx, A, c, c, E, epi_done);
+    case AMM_NEAR_FSWITCH: return launch_cpair_s<AMM_NEAR_FSWITCH, 0, -1>(ctx, A, c, c, E, epi_done);
     case AMM_DAMPED:
-        if (c.degree == 1) return launch_cpair_s<AMM_DAMPED, 1, -1>(ctx, A, c, c);
-        return launch_cpair_s<AMM_DAMPED, 0, -1>(ctx, A, c, c);
+        if (c.degree == 1) return launch_cpair_s<AMM_DAMPED, 1, -1>(ctx, A, c, c, E, epi_done);
+        return launch_cpair_s<AMM_DAMPED, 0, -1>(ctx, A, c, c, E, epi_done);
     default:
-        if (c.cmode == 1) return launch_cpair_s<AMM_NONBONDED, 1, -1>(ctx, A, c, c);
-        if (c.cmode == 2) return launch_cpair_s<AMM_NONBONDED, 2, -1>(ctx, A, c, c);
-        return launch_cpair_s<AMM_NONBONDED, 0, -1>(ctx, A, c, c);
+        if (c.cmode == 1) return launch_cpair_s<AMM_NONBONDED, 1, -1>(ctx, A, c, c, E, epi_done);
+        if (c.cmode == 2) return launch_cpair_s<AMM_NONBONDED, 2, -1>(ctx, A, c, c, E, epi_done);
+        return launch_cpair_s<AMM_NONBONDED, 0, -1>(ctx, A, c, c, E, epi_done);
     }
 #endif
 }
@@ -1159,7 +1368,7 @@ static int cluster_setup_grid(amm_ctx *ctx, ClusterList *cl, double rc) {
 }
 
 static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const double *d_pos, int force, bool count_only, PairForce *gather_for,
-                         CZeroRows Z = CZeroRows{0, nullptr, nullptr, nullptr}) {
+                         CZeroRows Z = CZeroRows{0, nullptr, nullptr, nullptr}, int copies_current = 0) {
     hipStream_t st = ctx->stream;
     const int nc = cl->nc;
     hipLaunchKernelGGL(k_cassign, dim3((nc + cl->nrest + 255) / 256), dim3(256), 0, st, nc, d_pos, ctx->box, cl->grid, cl->d_cell_count, cl->d_cell_start,
@@ -1171,7 +1380,7 @@ static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const doub
     hipLaunchKernelGGL(k_csort_gather, dim3((unsigned)((sort_threads + 255) / 256)), dim3(256), 0, st, cl->grid.ncell, nc, cl->d_cell_start,
                        cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags, cl->d_flags, force,
                        gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr, gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr,
-                       gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2, cl->d_first, Z);
+                       gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2, cl->d_first, Z, copies_current);
     const long threads = (long)cl->grid.ncell * cl->parts * 64;
     dim3 grid((unsigned)((threads + 255) / 256));
     CBoxF bf;
@@ -1343,6 +1552,13 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         if (cluster_first_build(ctx, L, d_pos)) return 1;
     }
     ClusterList *cl = L->cl;
+    // the plan of an epilogue (cepi_rows) that amm_run_ops attached to this evaluation; consumed here whatever happens to it
+    const EpiPlan *plan = ctx->epi_request;
+    ctx->epi_request = nullptr;
+    ctx->epi_done = false;
+    // the launch that moved the atoms to these positions wrote this force's sorted copies already (an earlier epilogue)?
+    const int copies_current = (cl->sorted_for == pf && cl->sorted_epoch == ctx->pos_epoch && cl->sorted_pos == d_pos && Z.n == 0) ? 1 : 0;
+    if (copies_current) ctx->n_copies_current++;
     if (cl->checked_epoch == ctx->pos_epoch && cl->checked_pos == d_pos && !L->force_rebuild_c) {
         // positions unchanged since this list was last checked
     } else {
@@ -1351,15 +1567,19 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
                                cl->d_flags);
         const int forced = L->force_rebuild_c ? 1 : 0;
         L->force_rebuild_c = false;
-        if (cluster_chain(ctx, L, cl, d_pos, forced, false, pf, Z)) return 1;
+        if (cluster_chain(ctx, L, cl, d_pos, forced, false, pf, Z, copies_current)) return 1;
         gathered = true;
     }
     cl->checked_epoch = ctx->pos_epoch;
     cl->checked_pos = d_pos;
-    if (!gathered)
+    if (!gathered && !copies_current)
         hipLaunchKernelGGL(k_csort_gather, dim3((std::max(cl->nc, Z.n) + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start,
                            cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0,
-                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, Z);     // flags[8] stays 0: copies only
+                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, Z, 0);     // flags[8] stays 0: copies only
+    // (the copies in place are this force's at these positions from here on, whoever wrote them)
+    cl->sorted_for = pf;
+    cl->sorted_epoch = ctx->pos_epoch;
+    cl->sorted_pos = d_pos;
     const int nrows = cl->c_end - cl->c_begin;
     const int per_c = (cl->nc + ctx->world - 1) / ctx->world, per = 3 * per_c, nf = guest ? 2 : 1;
     double *out = d_force, *gout = g_force;
@@ -1438,6 +1658,56 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         int rc_ = 0;
         bool fused = false;
         if (guest) guest->last_fused = 0;
+        // ---- epilogue: the inner RESPA loop of the rows' molecules on this launch (cepi_rows) ----
+        CEpiArgs E;
+        const CEpiArgs *Ep = nullptr;
+        bool epi_launched = false;
+        PairForce *enext = nullptr;
+        bool enext_alias = false;
+        if (plan && ctx->opt_fuse_epilogue && ctx->world == 1 && !exchange && !accumulate && !cl->d_first && cl->nrest == 0 && plan->bs &&
+            plan->bs->mol3_ok && plan->bs->finalized && plan->bs->ncomp == cl->nc && plan->f0 && plan->npre <= AMM_MAX_PRE &&
+            (!guest || (!g_accumulate && g_force != d_force && ctx->opt_fuse_rows && A.nnb_total)) && ctx->d_x == d_pos && ctx->d_v) {
+            E.niter = plan->niter;
+            E.npre = plan->npre;
+            E.x = ctx->d_x;
+            E.v = ctx->d_v;
+            E.f0 = plan->f0;
+            E.mass = ctx->d_mass;
+            E.c1 = plan->c1;
+            E.d = plan->d;
+            E.c2 = plan->c2;
+            bool ok = plan->f0 != d_force && plan->f0 != g_force;
+            for (int p = 0; p < AMM_MAX_PRE; ++p) {
+                CEpiPre &k = E.pre[p];
+                k.a = p < plan->npre ? plan->pre_a[p] : nullptr;
+                k.b = p < plan->npre ? plan->pre_b[p] : nullptr;
+                k.coef = p < plan->npre ? plan->pre_coef[p] : 0.0;
+                k.plus = p < plan->npre ? plan->pre_plus[p] : 0;
+                if (p < plan->npre && !k.a) ok = false;
+            }
+            E.cperm = cl->d_cperm;
+            E.term_l = plan->bs->d_term_l;
+            E.term_q = plan->bs->d_term_q;
+            E.atom_recs = plan->bs->d_atom_recs;
+            E.posq_next = nullptr;
+            E.lj_next = nullptr;
+            E.q_next = E.hsig_next = E.seps2_next = nullptr;
+            // the sorted copies the next pair evaluation reads: written through the permutation this launch walks (should the
+            // triggers ask for a rebuild, that evaluation's chain writes them again in the new order)
+            PairForce *nx = plan->niter > 0 ? plan->next : nullptr;
+            if (nx && nx->cluster_ok && (nx == L || nx->host == L) && nx->n == n) {
+                enext = nx;
+                enext_alias = nx->d_posq_s == pf->d_posq_s;
+                if (enext_alias && !nx->d_posq_alt) AMM_HIP(hipMalloc(&nx->d_posq_alt, sizeof(double4) * (size_t)n));
+                E.posq_next = enext_alias ? nx->d_posq_alt : nx->d_posq_s;
+                E.lj_next = enext_alias ? nullptr : nx->d_lj_s;      // (the same force: its parameter records are in place)
+                E.q_next = nx->d_q;
+                E.hsig_next = nx->d_hsig;
+                E.seps2_next = nx->d_seps2;
+            }
+            amm_collect_watches(ctx, E.W);
+            if (ok) Ep = &E;
+        }
         if (guest && ctx->opt_fuse_rows && A.nnb_total) {
             // host and guest in ONE walk of the rows when a fused kernel exists for the two families
             CPairArgs D = A;
@@ -1453,12 +1723,13 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             D.gsr = guest->pc.sign / pf->pc.sign;
             PairConsts gpc = guest->pc;
             if (guest->desc.flags & AMM_GUARD_RC0) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);      // step(rc0 - r)
-            const int r = launch_cdual(ctx, D, pf->pc, gpc);
+            const int r = launch_cdual(ctx, D, pf->pc, gpc, Ep, &epi_launched);
             if (r > 0) return 1;
             fused = r == 0;
             if (fused) guest->last_fused = 1;
+            else epi_launched = false;
         }
-        if (!fused) rc_ = launch_cpair(ctx, A, pf->pc);
+        if (!fused) rc_ = launch_cpair(ctx, A, pf->pc, guest ? nullptr : Ep, &epi_launched);
         if (timed) AMM_HIP(hipEventRecord(e1, st));          // (the guest's launch below is timed under the guest's own id)
         if (!rc_ && guest && !fused) {
             // the guest force of the shared list (same particles, bitwise equal parameters: the host's sorted copies serve): a
@@ -1498,6 +1769,22 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         if (rc_) return 1;
         AMM_HIP(hipGetLastError());
         if (guest) guest->n_evals++;
+        if (epi_launched) {
+            // the launch moved the atoms: new positions epoch, their displacement triggers are evaluated, and (when the next force
+            // was known) its sorted copies are those of the new positions
+            ctx->epi_done = true;
+            ctx->n_epilogues++;
+            if (plan->niter > 0) {
+                ctx->pos_epoch++;
+                amm_watch_moved(ctx);
+                if (enext) {
+                    if (enext_alias) std::swap(enext->d_posq_s, enext->d_posq_alt);
+                    cl->sorted_for = enext;
+                    cl->sorted_epoch = ctx->pos_epoch;
+                    cl->sorted_pos = ctx->d_x;
+                }
+            }
+        }
     }
     pf->n_evals++;
     if (exchange) {
@@ -1548,7 +1835,11 @@ int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_p
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(k_csort_gather, dim3((cl->nc + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start, cl->d_cell_members,
                        cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0, pf->d_q, pf->d_hsig,
-                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, CZeroRows{0, nullptr, nullptr, nullptr});
+                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, CZeroRows{0, nullptr, nullptr, nullptr}, 0);
+    if (cl->sorted_for == pf) {        // (this force's copies in place are those of d_pos now)
+        cl->sorted_epoch = ctx->pos_epoch;
+        cl->sorted_pos = d_pos;
+    }
     CPairArgs A;
     std::memset(&A, 0, sizeof(A));
     A.c_begin = cl->c_begin;

@@ -277,8 +277,14 @@ int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
  * rounds of wavefront tasks go out in smaller tasks), "group_candidates" (1: a list-free group force on a fused inner loop walks only
  * the atoms near its small set while a neighbour list of the context vouches for them), "positions_private" (1: the caller promises
  * to call amm_positions_changed after writing the bound position buffer itself; amm_run_ops then trusts the displacement checks its
- * own launches made at the end of the previous call instead of assuming that anything may have moved).  Unknown names are an error. */
+ * own launches made at the end of the previous call instead of assuming that anything may have moved), "fuse_epilogue" (1: a molecule-row
+ * pair kernel runs the kicks and the inner RESPA loop that follow its EVAL in the step program as its epilogue when the innermost group
+ * is one bond-list set of three-site molecules -- propagators.py:933-973 unrolled; 0: launches of their own).  Unknown names are an error. */
 int amm_set_option(amm_ctx *ctx, const char *name, double value);
+/* What amm_run_ops fused so far (statistics for tests and bench.py): out[0] = pair-kernel launches that carried the inner RESPA loop
+ * of their molecules as an epilogue (the reference runs it as CustomIntegrator steps, propagators.py:933-973), out[1] = pair
+ * evaluations that found their sorted copies written by the launch that moved the atoms (no gather launch), out[2..3] = 0. */
+int amm_run_stats(amm_ctx *ctx, int64_t out[4]);
 /* The bound position buffer was written by the caller (needed only with option "positions_private"; harmless otherwise). */
 int amm_positions_changed(amm_ctx *ctx);
 /* slots of the cell-sorted order per rank (whole molecules of three: 3 ceil(ceil(n/3) / world)): the exchange buffer holds
