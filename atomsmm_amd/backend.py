@@ -345,15 +345,16 @@ class HipContext:
         return path.encode() if os.path.exists(path) else None
 
     @classmethod
-    def comm_unique_id(cls):
+    def comm_unique_id(cls, library=None):
+        """library: path of the RCCL to bind (default: the one torch carries; the error-path tests pass a stand-in)."""
         buf = C.create_string_buffer(COMM_ID_BYTES)
-        _chk(lib().amm_comm_unique_id(cls.rccl_path(), buf))
+        _chk(lib().amm_comm_unique_id(library.encode() if library else cls.rccl_path(), buf))
         return buf.raw
 
-    def comm_init(self, id_bytes):
+    def comm_init(self, id_bytes, library=None):
         if len(id_bytes) != COMM_ID_BYTES:
             raise ValueError('communicator id must be %d bytes' % COMM_ID_BYTES)
-        _chk(lib().amm_comm_init(self.h, self.rccl_path(), bytes(id_bytes), self.rank, self.world))
+        _chk(lib().amm_comm_init(self.h, library.encode() if library else self.rccl_path(), bytes(id_bytes), self.rank, self.world))
         self.has_comm = True
 
     def comm_destroy(self):

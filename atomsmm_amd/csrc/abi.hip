@@ -77,8 +77,9 @@ int amm_create(int32_t n_atoms, const double h_box[3], int32_t device, void *str
 
 int amm_destroy(amm_ctx *ctx) {
     if (!ctx) return 0;
-    (void)hipStreamSynchronize(ctx->stream);
+    // (with a communicator the wait is bounded and a stuck collective is aborted: comm.hip; then the stream drains)
     amm_comm_destroy_impl(ctx);
+    (void)hipStreamSynchronize(ctx->stream);
     for (auto &f : ctx->forces) {
         if (f.pair) {
             amm_pair_free(f.pair);
@@ -122,12 +123,11 @@ int amm_set_slice(amm_ctx *ctx, int32_t rank, int32_t world) {
 }
 
 int amm_synchronize(amm_ctx *ctx) {
-    AMM_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return amm_comm_wait_impl(ctx, "amm_synchronize");         // (hipStreamSynchronize when the context has no communicator)
 }
 
 int amm_check(amm_ctx *ctx) {
-    AMM_HIP(hipStreamSynchronize(ctx->stream));
+    if (amm_comm_wait_impl(ctx, "amm_check")) return 1;
     if (ctx->constraints && amm_constraints_failed(ctx, ctx->constraints)) {
         amm_set_error("constraint solver did not converge (SHAKE / RATTLE, 500 iterations): time step too large or bad geometry");
         return 2;
@@ -1687,6 +1687,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "terms_from") ctx->opt_terms_from = v;
     else if (k == "no_term_lanes") ctx->opt_no_term_lanes = v;
     else if (k == "fuse_epilogue") ctx->opt_fuse_epilogue = v;
+    else if (k == "comm_timeout") ctx->opt_comm_timeout = value;
     else {
         amm_set_error("amm_set_option: unknown option '" + k + "'");
         return 1;

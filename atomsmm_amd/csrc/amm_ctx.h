@@ -353,6 +353,8 @@ struct amm_ctx {
     long pos_epoch = 0;            // bumped whenever the positions may have changed (see amm_pair_eval_impl)
     double skin_out = -1.0;        // outer Verlet buffer for pair forces created afterwards (<= 0: default)
     void *comm = nullptr;          // ncclComm_t of the library's own communicator (comm.hip), or none
+    bool comm_failed = false;      // ... it was aborted after an asynchronous error / a wait that timed out
+    double opt_comm_timeout = 120; // seconds a wait for the stream may last while a communicator exists (comm.hip: amm_comm_wait_impl)
     double *d_xchg = nullptr;      // caller-owned exchange buffer (amm_bind_exchange): world chunks of 2 x ceil(n/world) x 3 doubles
     long long xchg_doubles = 0;
     PendingExchange pending;
@@ -388,6 +390,8 @@ void amm_watch_moved(amm_ctx *ctx);
 int amm_comm_unique_id_impl(const char *rccl_path, unsigned char *out);
 int amm_comm_init_impl(amm_ctx *ctx, const char *rccl_path, const unsigned char *id_bytes, int rank, int world);
 int amm_comm_destroy_impl(amm_ctx *ctx);
+int amm_comm_poll_impl(amm_ctx *ctx);                     // asynchronous error of the communicator -> non-zero + message
+int amm_comm_wait_impl(amm_ctx *ctx, const char *who);    // bounded hipStreamSynchronize while a communicator exists
 int amm_comm_allreduce_impl(amm_ctx *ctx, double *d_buf, size_t count);
 int amm_comm_allgather_impl(amm_ctx *ctx, double *d_buf, size_t count_per_rank);
 int amm_exchange_finish_impl(amm_ctx *ctx);

@@ -1,11 +1,18 @@
 // atomsmm_amd/csrc/comm.hip -- RCCL collectives issued by the library itself (host code only).
 //
-// Atom decomposition: every rank evaluates the pair forces of its slice of the cell-sorted atoms into a
-// full-size buffer (zeros elsewhere) and the ranks all-reduce that buffer after each evaluation of a sliced group.
-// When the host drives this through torch.distributed, every outer step costs ~10 python -> C round trips
-// (measured: 480 us of host time per step, more than the GPU time of a step on 8 ranks).  With a communicator of its
-// own the library runs whole step programs (AMM_OP_ALLREDUCE inside amm_run_ops) without returning to the host:
-// ncclAllReduce is enqueued on the context's stream like any kernel.
+// Atom decomposition: every rank evaluates the pair-force rows of its slice of the cell-sorted order; groups that
+// hold one pair force exchange by ALL-GATHER of the owner-computed slices (the kernel leaves its rows in chunk `rank` of the
+// caller's exchange buffer, amm_comm_allgather_impl brings the other chunks, k_unsort spreads them in atom order); groups that
+// also hold sliced bond-list or reciprocal-space terms all-reduce(sum) their 3 N-double buffer.  When the host drives the
+// exchange through torch.distributed, every outer step costs ~10 python -> C round trips (measured: 480 us of host time per step,
+// more than the GPU time of a step on 8 ranks).  With a communicator of its own the library runs whole step programs
+// (collectives inside amm_run_ops) without returning to the host: they are enqueued on the context's stream like any kernel.
+//
+// Errors (failure detection): an enqueue that fails returns at once; what fails LATER -- a peer that died, a
+// link error -- is an asynchronous error of the communicator: polled (ncclCommGetAsyncError) after every enqueue and wherever the
+// library waits for the stream (amm_check, amm_synchronize, amm_comm_destroy), and those waits are bounded: a stream that does not
+// drain within `comm_timeout` seconds (amm_set_option, default 120) has the communicator aborted (ncclCommAbort) and the call
+// returns non-zero with the reason in amm_last_error -- the caller raises instead of sitting in hipStreamSynchronize for ever.
 //
 // RCCL is bound at run time (dlopen) rather than at link time: a torch process already carries one librccl, and two
 // copies of the library in one process must not be mixed; the caller names the file (or NULL: the loader's default).
@@ -14,8 +21,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 
 namespace {
 struct RcclApi {
@@ -26,6 +35,8 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;      // (optional: older libraries lack them)
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 } g_rccl;
 
 int rccl_load(const char *path) {
@@ -51,6 +62,8 @@ int rccl_load(const char *path) {
     api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
     api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
+    api.CommAbort = (decltype(api.CommAbort))dlsym(h, "ncclCommAbort");
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather || !api.GetErrorString) {
         amm_set_error("amm_comm: the RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce");
         dlclose(h);
@@ -96,18 +109,96 @@ int amm_comm_init_impl(amm_ctx *ctx, const char *rccl_path, const unsigned char 
     return 0;
 }
 
-int amm_comm_destroy_impl(amm_ctx *ctx) {
-    if (ctx->comm) {
-        (void)hipStreamSynchronize(ctx->stream);
-        g_rccl.CommDestroy((ncclComm_t)ctx->comm);
-        ctx->comm = nullptr;
+// asynchronous error of the communicator, if any: non-zero + message (the communicator is aborted: nothing more can run on it)
+static void comm_abort(amm_ctx *ctx) {
+    if (!ctx->comm) return;
+    if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)ctx->comm);
+    else g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_failed = true;
+}
+
+int amm_comm_poll_impl(amm_ctx *ctx) {
+    if (!ctx->comm) {
+        if (ctx->comm_failed) {
+            amm_set_error("the context's RCCL communicator was aborted after an error; create a new context");
+            return 1;
+        }
+        return 0;
     }
-    return 0;
+    if (!g_rccl.CommGetAsyncError) return 0;
+    ncclResult_t err = ncclSuccess;
+    const ncclResult_t r = g_rccl.CommGetAsyncError((ncclComm_t)ctx->comm, &err);
+    if (r != ncclSuccess) err = r;
+    if (err == ncclSuccess || err == ncclInProgress) return 0;
+    const std::string why = g_rccl.GetErrorString(err);
+    comm_abort(ctx);
+    amm_set_error("RCCL asynchronous error (a peer rank died or a link failed): " + why + "; the communicator was aborted");
+    return 1;
+}
+
+// wait for the context's stream, but not for ever when collectives may be stuck in it: event + query loop with the asynchronous
+// error polled on the way; on a time-out the communicator is aborted (which releases its kernels) and the call fails
+int amm_comm_wait_impl(amm_ctx *ctx, const char *who) {
+    if (!ctx->comm) {
+        AMM_HIP(hipStreamSynchronize(ctx->stream));
+        return amm_comm_poll_impl(ctx);
+    }
+    hipEvent_t ev;
+    AMM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipEventDestroy(ev);
+        amm_set_error(std::string("hipEventRecord: ") + hipGetErrorString(e));
+        return 1;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = 0;
+    for (long spins = 0;; ++spins) {
+        e = hipEventQuery(ev);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) {
+            amm_set_error(std::string("hipEventQuery: ") + hipGetErrorString(e));
+            rc = 1;
+            break;
+        }
+        if ((spins & 63) == 63) {
+            if (amm_comm_poll_impl(ctx)) {
+                rc = 1;
+                break;
+            }
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > ctx->opt_comm_timeout) {
+                comm_abort(ctx);
+                amm_set_error(std::string(who) + ": the stream did not drain within " + std::to_string((int)ctx->opt_comm_timeout) +
+                              " s with collectives in flight (a peer rank that died or never arrived?); the RCCL communicator was aborted");
+                rc = 1;
+                break;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    (void)hipEventDestroy(ev);
+    if (rc) return rc;
+    return amm_comm_poll_impl(ctx);
+}
+
+int amm_comm_destroy_impl(amm_ctx *ctx) {
+    int rc = 0;
+    if (ctx->comm) {
+        rc = amm_comm_wait_impl(ctx, "amm_comm_destroy");      // (aborts the communicator itself when the wait fails)
+        if (ctx->comm) {
+            g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+            ctx->comm = nullptr;
+        }
+    }
+    return rc;
 }
 
 // in-place sum over ranks of `count` doubles, enqueued on the context's stream
 int amm_comm_allreduce_impl(amm_ctx *ctx, double *d_buf, size_t count) {
     if (!ctx->comm) {
+        if (ctx->comm_failed) return amm_comm_poll_impl(ctx);
         amm_set_error("all-reduce without a communicator (amm_comm_init)");
         return 1;
     }
@@ -115,12 +206,13 @@ int amm_comm_allreduce_impl(amm_ctx *ctx, double *d_buf, size_t count) {
     if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
     ctx->comm_calls++;
     ctx->comm_doubles += (long long)count;
-    return 0;
+    return amm_comm_poll_impl(ctx);
 }
 
 // in-place all-gather: chunk `rank` of d_buf (count_per_rank doubles) goes to every rank's d_buf, on the context's stream
 int amm_comm_allgather_impl(amm_ctx *ctx, double *d_buf, size_t count_per_rank) {
     if (!ctx->comm) {
+        if (ctx->comm_failed) return amm_comm_poll_impl(ctx);
         amm_set_error("all-gather without a communicator (amm_comm_init)");
         return 1;
     }
@@ -129,5 +221,5 @@ int amm_comm_allgather_impl(amm_ctx *ctx, double *d_buf, size_t count_per_rank) 
     if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
     ctx->comm_calls++;
     ctx->comm_doubles += (long long)count_per_rank;
-    return 0;
+    return amm_comm_poll_impl(ctx);
 }

@@ -141,7 +141,8 @@ def bench_c2(args, torch):
     achieved = alg / max(t_k, 1e-12) / 1e9
     tf = FLOP_PER_PAIR_NEAR * pairs / max(t_k, 1e-12) / 1e12
     result = {
-        'metric': 'ns/day on 100k-atom TIP3P RESPA box; near-nonbonded HBM GB/s vs 8 TB/s peak',
+        # (NOT the headline metric of BASELINE.json -- that is the default run's, config C3; this is its config C2)
+        'metric': 'ns/day on the 32k-atom Lennard-Jones fluid of BASELINE config C2 (NearNonbondedForce only); near-nonbonded HBM GB/s vs 8 TB/s peak',
         'value': round(dt_fs * 1e-6 * 86400.0 / (elapsed / args.steps), 3), 'unit': 'ns/day', 'n_gpus': 1, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -178,6 +179,32 @@ def bench_c2(args, torch):
         except Exception as exc:
             result['cpu_baseline'] = {'value': None, 'unit': 'ns/day', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
     print(json.dumps(result), flush=True)
+
+
+def run_leg(config, steps, warmup, timeout_s=280):
+    """Another BASELINE config (c2 / c5) as a short timed region of its own, in a child process (`bench.py --config ...`: a fresh
+    interpreter and context; the parent's GPU work is over and it only waits), condensed for the default line's `detail`: ns/day,
+    ms/step, the dominant kernel's roofline entry, the CPU leg where the config has one.  A failure costs the leg, not the line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', config, '--steps', str(steps), '--warmup', str(warmup), '--no-legs']
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {'failed': 'no result after %d s' % timeout_s}
+    lines = [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith('{')]
+    if out.returncode != 0 or not lines:
+        return {'failed': 'exit code %s: %s' % (out.returncode, out.stderr.strip()[-300:])}
+    line = json.loads(lines[-1])
+    leg = {'ns_day': line['value'], 'ms_per_step': line['ms_per_step'], 'steps': line['steps'], 'warmup': line['warmup'],
+           'workload': line['config']['workload'], 'roofline': line.get('roofline')}
+    if line.get('roofline_dominant'):
+        leg['roofline_dominant'] = line['roofline_dominant']
+    if line.get('cpu_baseline'):
+        leg['cpu_baseline'] = line['cpu_baseline']
+    for key in ('list_kind', 'rows', 'kernel_revision', 'step_boundary_pass_us', 'near_kernel_us'):
+        if key in line.get('detail', {}):
+            leg[key] = line['detail'][key]
+    return leg
 
 
 def temperature(engine, torch):
@@ -363,6 +390,9 @@ def main():
     ap.add_argument('--pme-steps', type=int, default=100,
                     help='also time this many steps with the PME NonbondedForce as the outer force (what RESPASystem leaves in group 2 for a '
                          'PME source, systems.py:74-75) and report them under detail.pme_outer; 0 skips it')
+    ap.add_argument('--no-legs', action='store_true',
+                    help='the default line also times BASELINE configs 2 and 5 (short regions, child processes) under detail.c2 / detail.c5; this skips them')
+    ap.add_argument('--leg-steps', type=int, nargs=2, default=[2000, 60], metavar=('C2', 'C5'), help='timed steps of the two legs')
     ap.add_argument('--cpu-baseline-child', default=None, help=argparse.SUPPRESS)      # internal: cpu_baseline_in_child
     args = ap.parse_args()
     EXTRA_OPTIONS.extend(tuple(item.split('=', 1)) for item in args.option)
@@ -609,6 +639,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.outer == 'damped':
             result['cpu_baseline'] = cpu_baseline_in_child(args.nside, eng.x.cpu().numpy(), eng.v.cpu().numpy())
+        if world == 1 and args.config == 'c3' and args.outer == 'damped' and args.nside == 32 and not args.no_legs:
+            # BASELINE configs 2 and 5 on the same line: short timed regions after the headline's, each in a child
+            # process; configs[1] = the 32k-atom Lennard-Jones fluid, configs[4] = the ~250k-atom solvated chain under AFED
+            result['detail']['c2'] = run_leg('c2', args.leg_steps[0], 200)
+            result['detail']['c5'] = run_leg('c5', args.leg_steps[1], 20)
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.barrier()

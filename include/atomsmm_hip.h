@@ -139,7 +139,11 @@ int amm_set_slice(amm_ctx *ctx, int32_t rank, int32_t world);
 #define AMM_COMM_ID_BYTES 128
 int amm_comm_unique_id(const char *rccl_path, uint8_t id[AMM_COMM_ID_BYTES]);
 int amm_comm_init(amm_ctx *ctx, const char *rccl_path, const uint8_t id[AMM_COMM_ID_BYTES], int32_t rank, int32_t world);
-/* releases the communicator (amm_destroy does it too); collective, like ncclCommDestroy */
+/* releases the communicator (amm_destroy does it too); collective, like ncclCommDestroy.  Errors of the communicator: an enqueue that
+ * fails returns non-zero at once; an ASYNCHRONOUS error (a peer rank died, a link failed: ncclCommGetAsyncError) is polled after every
+ * collective the library enqueues and by amm_check / amm_synchronize / amm_comm_destroy, whose waits for the stream are bounded by the
+ * option "comm_timeout" -- in either case the communicator is aborted (ncclCommAbort), the call returns non-zero with the reason in
+ * amm_last_error, and every later collective of the context fails the same way (failure detection). */
 int amm_comm_destroy(amm_ctx *ctx);
 /* in-place sum over ranks of count doubles in device memory, on the context's stream */
 int amm_comm_allreduce(amm_ctx *ctx, double *d_buf, int64_t count);
@@ -279,7 +283,9 @@ int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
  * to call amm_positions_changed after writing the bound position buffer itself; amm_run_ops then trusts the displacement checks its
  * own launches made at the end of the previous call instead of assuming that anything may have moved), "fuse_epilogue" (1: a molecule-row
  * pair kernel runs the kicks and the inner RESPA loop that follow its EVAL in the step program as its epilogue when the innermost group
- * is one bond-list set of three-site molecules -- propagators.py:933-973 unrolled; 0: launches of their own).  Unknown names are an error. */
+ * is one bond-list set of three-site molecules -- propagators.py:933-973 unrolled; 0: launches of their own), "comm_timeout" (seconds
+ * amm_check / amm_synchronize / amm_comm_destroy wait for the stream while the context owns an RCCL communicator before they abort it and
+ * fail, default 120).  Unknown names are an error. */
 int amm_set_option(amm_ctx *ctx, const char *name, double value);
 /* What amm_run_ops fused so far (statistics for tests and bench.py): out[0] = pair-kernel launches that carried the inner RESPA loop
  * of their molecules as an epilogue (the reference runs it as CustomIntegrator steps, propagators.py:933-973), out[1] = pair

@@ -50,6 +50,7 @@ class AfedCPU:
         self.rc, self.rs = rc, rs
         self.cells = min(c['box']) / rc >= 3.0
         self.F = {}
+        self._lrc_memo = {}
 
     def softcore(self, lam, want_forces=True):
         c = self.c
@@ -57,10 +58,17 @@ class AfedCPU:
         return O.pair_eval(d, self.x, c['box'], self.codes, c['sigma'], c['epsilon'], want_forces=want_forces, use_cells=self.cells,
                            csr=self.csr)
 
-    def dE_dlambda(self, h=1e-5):
+    def _lrc(self, lam):
+        # (a function of lambda alone -- not of the positions -- and a slow quadrature: remembered per value; a step asks 2 n times
+        # for the same two values)
         c = self.c
-        e = [self.softcore(self.lam + s * h, want_forces=False)[0] +
-             O.softcore_lrc(c['sigma'], c['epsilon'], self.codes, c['box'], self.rc, self.rs, self.lam + s * h) for s in (1, -1)]
+        key = float(lam)
+        if key not in self._lrc_memo:
+            self._lrc_memo[key] = O.softcore_lrc(c['sigma'], c['epsilon'], self.codes, c['box'], self.rc, self.rs, lam)
+        return self._lrc_memo[key]
+
+    def dE_dlambda(self, h=1e-5):
+        e = [self.softcore(self.lam + s * h, want_forces=False)[0] + self._lrc(self.lam + s * h) for s in (1, -1)]
         return (e[0] - e[1]) / (2 * h)
 
     def group_energy_forces(self, g):

@@ -206,3 +206,115 @@ def test_c5_full_size_fused_inner_iterations_bit_identical():
     x0, v0 = run(False)
     assert np.array_equal(x1, x0) and np.array_equal(v1, v0)
     assert np.isfinite(x1).all() and np.abs(x1 - case['positions']).max() > 1e-4
+
+
+def test_c5_full_size_afed_step_vs_oracle():
+    """ONE AFED step of the program `bench.py --config c5` times -- 4 RESPA [4,2,1] steps of 2 fs around the lambda block -- at the full
+    249 075 atoms against oracle/afed_cpu.py (the C oracle's OpenMP cell traversals driven by numpy): positions to 1e-9 nm, lambda and
+    its velocity.  On the way the molecule rows of the hybrid list are rebuilt, the inner iterations are the two-launch form and the
+    list-free softcore force walks its candidates: asserted, so that a silent fall-back cannot pass."""
+    case = solvated_chain()
+    respa = build_c5_system(case)
+    inner = atomsmm.RespaPropagator([4, 2, 1]).integrator(2 * unit.femtoseconds)
+    var = atomsmm.ExtendedSystemVariable('lambda_vdw', 50, 2.5, 20 * unit.femtoseconds)
+    integrator = atomsmm.AdiabaticDynamicsIntegrator(inner, 2, [var])
+    context = openmm.Context(respa, integrator)
+    context.setPositions(case['positions'] * unit.nanometers)
+    context.setVelocities(case['velocities'])
+    context.setParameter('lambda_vdw', 0.6)
+    integrator.step(0)                                              # the (random) initialisation hook ...
+    integrator.setGlobalVariableByName('_v_lambda_vdw', 0.05)       # ... replaced by known starting values
+    integrator.setGlobalVariableByName('_v_eta_lambda_vdw', 0.0)
+    ref = AfedCPU(case, loops=(4, 2, 1), dt=0.002, nsteps=2, mass=50.0, kT=2.5, tau=0.02, lam=0.6, v_lam=0.05)
+    integrator.step(1)
+    ref.step(1)
+    x = context.getState(getPositions=True).getPositions(asNumpy=True)._value
+    assert np.abs(x - ref.x).max() < 1e-9
+    assert np.abs(ref.x - case['positions']).max() > 1e-3                     # (the atoms did move)
+    assert context.getParameter('lambda_vdw') == pytest.approx(ref.lam, abs=1e-9)
+    assert integrator.getGlobalVariableByName('_v_lambda_vdw') == pytest.approx(ref.v_lam, rel=1e-6, abs=1e-9)
+    eng = context._engine
+    eng.ctx.check()
+    for g in (1, 2):
+        for pid in eng.pair_force_ids(g):
+            st = eng.ctx.pair_stats(pid)
+            assert st['list_kind'] == 2, st
+    assert eng.ctx.pair_stats(eng.pair_force_ids(2)[0])['n_builds'] >= 2       # first build + at least one rebuild inside the step
+    soft = [s_ for s_ in (eng.ctx.pair_stats(pid) for pid in eng.pair_force_ids(0)) if s_['list_kind'] == 3]
+    assert len(soft) == 1 and soft[0]['n_candidate_walks'] > 0 and 30 < soft[0]['n_candidates'] < 20000, soft
+
+
+def test_c5_full_size_candidate_walks_bit_identical():
+    """scripts/check_c5_candidates.py as a test (shorter): the full-size AFED program with the candidate walk of the list-free softcore
+    force against the run that walks every atom every time -- positions, velocities and lambda bit for bit over 6 AFED steps."""
+    import bench
+
+    def run(cand):
+        sim, _case = bench.build_simulation_c5((4, 2, 1), 2.0)
+        eng = sim.context._engine
+        eng.ctx.set_option('group_candidates', cand)
+        sim.step(6)
+        eng._check()
+        st = sim.context.getState(getPositions=True, getVelocities=True)
+        soft = [s_ for s_ in (eng.ctx.pair_stats(p) for p in eng.pair_force_ids(0)) if s_['list_kind'] == 3][0]
+        return st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value, sim.context.getParameter('lambda_vdw'), soft
+
+    x1, v1, l1, s1 = run(1)
+    x0, v0, l0, s0 = run(0)
+    assert s1['n_candidate_walks'] > 100 and s0['n_candidate_walks'] == 0, (s1, s0)
+    assert np.array_equal(x1, x0) and np.array_equal(v1, v0) and l1 == l0
+
+
+def test_far_flag_raised_by_the_kicks_and_move_launch():
+    """ADVICE r4: the launch of plain kicks + move (csrc/integrate.hip: k_kicks_move_atoms) evaluates the lists' displacement triggers;
+    it must raise BOTH flags -- "rebuild wanted" and "farther than the whole buffer" (AMM_FLAG_FAR) -- or the candidate walk of a
+    list-free group force goes on trusting reference positions an atom has left.  A step program whose only move IS that launch
+    (kick f0 ; kick f1 ; kick f2 + move), on the small C5 system; one water is shot 0.8 nm -- from beyond cutoff + twice the buffer of
+    every solute atom to well inside the cutoff -- in a single step.  With and without the candidate walk: bit for bit."""
+    case = solvated_chain(nside=12, n_chain=300, n_solute=30)
+    box = np.asarray(case['box'])
+    results = []
+    for cand in (1, 0):
+        respa = build_c5_system(case)
+        integrator = openmm.CustomIntegrator(0.001)
+        integrator.addComputePerDof('v', 'v+0.5*dt*f0/m')
+        integrator.addComputePerDof('v', 'v+0.5*dt*f1/m')
+        integrator.addComputePerDof('v', 'v+0.5*dt*f2/m')
+        integrator.addComputePerDof('x', 'x+dt*v')
+        context = openmm.Context(respa, integrator)
+        eng = context._engine
+        eng.ctx.set_option('group_candidates', cand)
+        eng.ctx.set_option('terms_from', 1)
+        context.setPositions(case['positions'] * unit.nanometers)
+        context.setVelocities(case['velocities'])
+        context.setParameter('lambda_vdw', 0.7)
+        integrator.step(3)
+        st = context.getState(getPositions=True, getVelocities=True)
+        x, v = st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value.copy()
+        sol = x[case['solute']]
+        oxy = 3 * np.arange(case['n_waters'])
+        d = x[oxy][:, None, :] - sol[None, :, :]
+        d -= box * np.rint(d / box)
+        dist = np.linalg.norm(d, axis=2)
+        nearest = dist.min(1)
+        pick = int(np.argmin(np.abs(nearest - 1.5)))
+        assert 1.3 < nearest[pick] < 1.7                      # outside cutoff (1.0) + twice the buffer (0.2) of every solute atom
+        towards = -d[pick, int(np.argmin(dist[pick]))]
+        towards /= np.linalg.norm(towards)
+        v[oxy[pick]:oxy[pick] + 3] = 800.0 * towards          # 0.8 nm in the next 1 fs move
+        context.setVelocities(v)
+        integrator.step(1)                                     # the flight: the step's only move is the kicks + move launch
+        # the next list-free evaluation is deriv(energy, lambda): it walks the candidates only while BOTH flags vouch for them
+        # (no more steps: the water has landed on top of others)
+        deriv = eng.energy_derivative('lambda_vdw')
+        st = context.getState(getPositions=True, getVelocities=True)
+        x1 = st.getPositions(asNumpy=True)._value
+        d1 = x1[oxy[pick]][None, :] - x1[case['solute']]
+        d1 -= box * np.rint(d1 / box)
+        assert np.linalg.norm(d1, axis=1).min() < 0.95          # it did land inside the cutoff of a solute atom
+        soft = [s_ for s_ in (eng.ctx.pair_stats(pid) for pid in eng.pair_force_ids(0)) if s_['list_kind'] == 3][0]
+        results.append((x1, st.getVelocities(asNumpy=True)._value, soft, deriv))
+    assert results[0][2]['n_candidate_walks'] > 0 and results[1][2]['n_candidate_walks'] == 0
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    assert np.isfinite(results[0][0]).all()
+    assert results[0][3] == pytest.approx(results[1][3], rel=1e-10) and results[0][3] != 0.0
