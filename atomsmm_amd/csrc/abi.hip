@@ -1688,6 +1688,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "no_term_lanes") ctx->opt_no_term_lanes = v;
     else if (k == "fuse_epilogue") ctx->opt_fuse_epilogue = v;
     else if (k == "comm_timeout") ctx->opt_comm_timeout = value;
+    else if (k == "spec_assign") ctx->opt_spec_assign = v;
     else {
         amm_set_error("amm_set_option: unknown option '" + k + "'");
         return 1;

@@ -300,6 +300,7 @@ struct EpiPlan {
 
 struct amm_ctx {
     int n = 0;
+    int opt_spec_assign = 1;           // ... which also files the moved molecules in their cells ahead of a possible rebuild (no assign launch)
     int opt_fuse_epilogue = 1;         // molecule rows: the inner RESPA loop of a box of three-site molecules as the pair kernel's epilogue
     const EpiPlan *epi_request = nullptr;   // amm_run_ops -> amm_cluster_eval_impl (one evaluation)
     bool epi_done = false;             // ... which says here whether its launch carried the plan (it then bumped pos_epoch itself)

@@ -49,6 +49,14 @@ struct ClusterList {
     PairForce *sorted_for = nullptr;
     long sorted_epoch = -1;
     const double *sorted_pos = nullptr;
+    // cells assigned ahead of time by the launch that moved the atoms (cluster.hip: cepi_rows files every molecule it has moved in
+    // its new cell; should the triggers ask for a rebuild, the kernel's last block turns the counts into cell_start and the next
+    // evaluation's chain starts at the sort): two count arrays in turn (a launch clears the one the NEXT launch counts in)
+    int *d_spec_count[2] = {nullptr, nullptr};
+    int *d_spec_ticket = nullptr;
+    int spec_parity = 0;
+    long assigned_epoch = -1;
+    const double *assigned_pos = nullptr;
     bool per_pair_image = false;   // small box: the periodic image is chosen per atom pair, not per molecule pair
 };
 

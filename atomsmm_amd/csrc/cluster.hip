@@ -107,10 +107,7 @@ __global__ void __launch_bounds__(256) k_cassign(int nc, const double *__restric
             const int ck = (w == w) ? (int)(w * g.inv_cw[k]) : 0;          // NaN-safe
             cidx[k] = ck >= g.nc[k] ? g.nc[k] - 1 : (ck < 0 ? 0 : ck);
         }
-        if (xref) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) xref[3 * i0 + k] = pos[3 * i0 + k];
-        }
+        // (the molecules' reference positions are written by the sort launch of the rebuild: k_csort_gather)
         const int cell = (cidx[2] * g.nc[1] + cidx[1]) * g.nc[0] + cidx[0];
         const int rank = atomicAdd(&count[cell], 1);
         if (members) {
@@ -158,7 +155,7 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
                                                       float4 *pos4f, const int *flags, int *wflags, int force, const double *__restrict__ q,
                                                       const double *__restrict__ hsig, const double *__restrict__ seps2, double4 *posq_s,
                                                       double2 *lj_s, float rext, const double *__restrict__ site_eps,
-                                                      const int *__restrict__ first, CZeroRows Z, int copies_current) {
+                                                      const int *__restrict__ first, CZeroRows Z, int copies_current, double *xref) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     // (hybrid lists: the force rows of the atoms outside the molecules start from zero; the molecule-row kernel writes the others
     // and the per-atom part adds to all of them -- a launch of its own before)
@@ -207,6 +204,11 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
             const double x = csorted_image(pos[3 * i], p0[0], sh[0], box.L[0], box.invL[0]);
             const double y = csorted_image(pos[3 * i + 1], p0[1], sh[1], box.L[1], box.invL[1]);
             const double z = csorted_image(pos[3 * i + 2], p0[2], sh[2], box.L[2], box.invL[2]);
+            if (xref) {        // the displacement triggers' reference: the positions of this build
+                xref[3 * i] = pos[3 * i];
+                xref[3 * i + 1] = pos[3 * i + 1];
+                xref[3 * i + 2] = pos[3 * i + 2];
+            }
             pf[t] = make_float4((float)x, (float)y, (float)z, 0.f);
             const float dx = pf[t].x - pf[0].x, dy = pf[t].y - pf[0].y, dz = pf[t].z - pf[0].z;
             ext2 = fmaxf(ext2, dx * dx + dy * dy + dz * dz);
@@ -845,6 +847,11 @@ struct CEpiArgs {
     const int4 *term_l;                        // [molecule * 4 + lane] BondedSet::d_term_l / d_term_q / d_atom_recs
     const double4 *term_q;
     const unsigned long long *atom_recs;
+    // cells of the moved molecules, filed ahead of a possible rebuild (ClusterList::d_spec_count): count / members / start as
+    // k_cassign's, the array to clear for the next launch, the list's flags, a ticket for the last block; null: not this launch
+    int *spec_count, *spec_clear, *spec_members, *spec_start, *spec_flags, *spec_ticket;
+    int spec_capc;
+    CellGrid grid;
     double4 *posq_next;                        // sorted copies of the next pair evaluation (null: none)
     double2 *lj_next;                          // (null: that force's are in place already)
     const double *q_next, *hsig_next, *seps2_next;
@@ -854,6 +861,17 @@ struct CEpiArgs {
 #ifndef CEPI_INLINE
 #define CEPI_INLINE __forceinline__
 #endif
+// value of lane (quad base + Q) of the caller's quad, for all four lanes of the quad: a DPP move (VALU rate, no LDS round trip -- the
+// ds_bpermute form of the epilogue spent a dozen serialized LDS latencies per inner iteration on its shuffles)
+template <int Q>
+__device__ __forceinline__ double cquad_bcast(double v) {
+    constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);       // quad_perm: [Q, Q, Q, Q]
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), ctrl, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // positions of the (up to three) atoms of the lane's term, fetched from their lanes before the term code runs (the term code
 // branches on the kind of term per lane, and a shuffle reads nothing from a lane that is not executing it)
 struct PosTermRegs {
@@ -916,8 +934,8 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
     const int kind = (int)(code & 1), periodic = (int)((code >> 5) & 1);
     const int ix[4] = {0, 1, 2, 3};
     const double par[3] = {my_tq.x, my_tq.y, my_tq.z};
-    // lanes the term's atoms live in (a lane without a term reads its own row's first lane: any executing lane will do)
-    const int s0 = qb + (my_tl.x & 3), s1 = qb + (my_tl.y & 3), s2 = qb + (my_tl.z & 3);
+    // slots (lanes of the quad) the term's atoms live in; a molecule has three atoms: slots 0 .. 2
+    const int s0 = my_tl.x & 3, s1 = my_tl.y & 3, s2 = my_tl.z & 3;
     for (int it = 0; it < E.niter; ++it) {
         {
 #pragma clang fp contract(off)
@@ -930,12 +948,14 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
                 x[j] = x[j] + dx;
             }
         }
+        // the three atoms' new positions on all four lanes of the quad (DPP broadcasts), each term picks its own
         PosTermRegs pos;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            pos.p[0][k] = __shfl(x[k], s0);
-            pos.p[1][k] = __shfl(x[k], s1);
-            pos.p[2][k] = __shfl(x[k], s2);
+            const double a0 = cquad_bcast<0>(x[k]), a1 = cquad_bcast<1>(x[k]), a2 = cquad_bcast<2>(x[k]);
+            pos.p[0][k] = s0 == 0 ? a0 : (s0 == 1 ? a1 : a2);
+            pos.p[1][k] = s1 == 0 ? a0 : (s1 == 1 ? a1 : a2);
+            pos.p[2][k] = s2 == 0 ? a0 : (s2 == 1 ? a1 : a2);
         }
         double fo[4][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
         if (my_tl.x >= 0) {
@@ -943,18 +963,29 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
             bonded_term_forces(BA, pos, ix, par, kind, periodic, fo, e);
         }
         f[0] = f[1] = f[2] = 0.0;
-        // the atom's records in order: (term slot, role) -> that term's force on that role, from the term's lane.  Every lane
-        // executes every shuffle (the source lanes must); a lane with fewer records keeps its sum
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int rcode = (int)((my_recs >> (5 * t)) & 31ull);
-            const int src = qb + (rcode & 3), role = rcode >> 3;
-#pragma unroll
-            for (int xx = 0; xx < 3; ++xx) {
-                const double r0 = __shfl(fo[0][xx], src), r1 = __shfl(fo[1][xx], src), r2 = __shfl(fo[2][xx], src);
-                const double add = role == 0 ? r0 : (role == 1 ? r1 : r2);
-                f[xx] = t < rec_n ? f[xx] + add : f[xx];
+        // the atom's records in order: (term slot, role) -> that term's force on that role.  An atom's records name the terms in
+        // ascending slot order (BondedSet: terms and records are laid down in one sweep), a term at most once: so the four terms'
+        // forces are broadcast over the quad one after the other (DPP) and an atom adds the role its next record names when the
+        // record's term is the one on the air -- the sums of k_inner_lanes, in its order
+        {
+            int t_next = 0;                           // the atom's next record
+#define AMM_CEPI_TERM(TL)                                                                                           \
+            {                                                                                                       \
+                const int rcode = (int)((my_recs >> (5 * t_next)) & 31ull);                                         \
+                const bool mine = t_next < rec_n && (rcode & 7) == TL;                                               \
+                const int role = rcode >> 3;                                                                        \
+                _Pragma("unroll") for (int xx = 0; xx < 3; ++xx) {                                                  \
+                    const double r0 = cquad_bcast<TL>(fo[0][xx]), r1 = cquad_bcast<TL>(fo[1][xx]), r2 = cquad_bcast<TL>(fo[2][xx]); \
+                    const double add = role == 0 ? r0 : (role == 1 ? r1 : r2);                                       \
+                    f[xx] = mine ? f[xx] + add : f[xx];                                                              \
+                }                                                                                                   \
+                t_next += mine ? 1 : 0;                                                                             \
             }
+            AMM_CEPI_TERM(0)
+            AMM_CEPI_TERM(1)
+            AMM_CEPI_TERM(2)
+            AMM_CEPI_TERM(3)
+#undef AMM_CEPI_TERM
         }
         {
 #pragma clang fp contract(off)
@@ -969,7 +1000,7 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
     // the molecule's first atom decides the image of the sorted copy
     double x0[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) x0[k] = __shfl(x[k], qb);
+    for (int k = 0; k < 3; ++k) x0[k] = cquad_bcast<0>(x[k]);
     if (has) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -978,7 +1009,30 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
             E.f0[3 * a + j] = f[j];
         }
         if (E.niter > 0) {
-            amm_watch_atom(E.W, a, x);
+            if (l == 0 && E.spec_count) {
+                // the molecule's cell at its new position, as k_cassign would find it (same wrap, same clamps)
+                int cidx[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double w = cwrap1(x[k], box.L[k], box.invL[k]);
+                    const int ck = (w == w) ? (int)(w * E.grid.inv_cw[k]) : 0;
+                    cidx[k] = ck >= E.grid.nc[k] ? E.grid.nc[k] - 1 : (ck < 0 ? 0 : ck);
+                }
+                const int cell = (cidx[2] * E.grid.nc[1] + cidx[1]) * E.grid.nc[0] + cidx[0];
+                const int rank = atomicAdd(&E.spec_count[cell], 1);
+                if (rank < E.spec_capc) E.spec_members[(size_t)cell * E.spec_capc + rank] = mol;
+                else E.spec_flags[7] = 1;
+            }
+            // the lists' displacement triggers (amm_watch_atom), the flags stored past this XCD's L2: the kernel's last block -- on
+            // another XCD, perhaps -- decides on them whether the cells' counts become a cell table
+            for (int q = 0; q < E.W.n; ++q) {
+                const double dx = x[0] - E.W.xref[q][3 * a], dy = x[1] - E.W.xref[q][3 * a + 1], dz = x[2] - E.W.xref[q][3 * a + 2];
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (!(d2 <= E.W.thr2[q])) {
+                    amm_st_l2(&E.W.flags[q][0], 1);
+                    if (!(d2 <= 4.0 * E.W.thr2[q])) amm_st_l2(&E.W.flags[q][AMM_FLAG_FAR], 1);
+                }
+            }
             if (E.posq_next) {
                 double4 pq;
                 pq.x = csorted_image(x[0], x0[0], cwrap1(x0[0], box.L[0], box.invL[0]) - x0[0], box.L[0], box.invL[0]);
@@ -990,6 +1044,46 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
             }
         }
     }
+}
+
+// exclusive scan of count[0 .. ncell) -> start[0 .. ncell] by ONE block of BS threads (wavefront shuffles: 64 bytes of LDS -- the
+// fused pass has 5 KB to spare); the counts are left as they are (the next launch clears them); returns the largest count
+template <int BS>
+__device__ __forceinline__ int cscan_counts(int ncell, const int *count, int *start) {
+    __shared__ int s_part[BS / 64], s_most[BS / 64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int per = (ncell + BS - 1) / BS;
+    const int c0 = min(t * per, ncell), c1 = min(c0 + per, ncell);
+    int sum = 0, most = 0;
+    for (int c = c0; c < c1; ++c) {
+        const int v = amm_ld_l2(&count[c]);
+        sum += v;
+        most = max(most, v);
+    }
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+        most = max(most, __shfl_xor(most, off));
+    }
+    if (lane == 63) {
+        s_part[w] = incl;
+        s_most[w] = most;
+    }
+    __syncthreads();
+    int base = 0, all_most = 0;
+#pragma unroll
+    for (int k = 0; k < BS / 64; ++k) {
+        if (k < w) base += s_part[k];
+        all_most = max(all_most, s_most[k]);
+    }
+    int run = base + incl - sum;
+    for (int c = c0; c < c1; ++c) {
+        start[c] = run;
+        run += amm_ld_l2(&count[c]);
+    }
+    if (t == BS - 1) start[ncell] = run;
+    return all_most;
 }
 
 #ifndef AMM_CBS_SINGLE
@@ -1010,6 +1104,9 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g, CEpiArgs E) {
     constexpr bool DUAL = GFAM >= 0;
     constexpr bool SS = SMASK != 0;
     extern __shared__ __align__(16) char s_lds[];
+    if (EPI && E.spec_clear) {      // the cell counts the NEXT launch's epilogue files its molecules in: cleared here, a launch ahead
+        for (int cidx = blockIdx.x * BS + threadIdx.x; cidx <= E.grid.ncell; cidx += gridDim.x * BS) E.spec_clear[cidx] = 0;
+    }
 #ifdef AMM_CPAIR_TIMING
     const unsigned long long t_entry = wall_clock64();
     unsigned long long t_staged = 0;
@@ -1139,6 +1236,9 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g, CEpiArgs E) {
         // the inner RESPA loop of the rows' molecules (cepi_rows): the row's sums are in f / fg on all of its lanes
     }
     }
+#ifdef AMM_CPAIR_TIMING
+    if (EPI) t_staged = wall_clock64();        // (measurement builds, kernels with the epilogue: the second clock = rows walked)
+#endif
     if (EPI) {
         // the inner RESPA loop of the molecules whose rows this wavefront has just summed (cepi_rows): the same tasks again.  The
         // forces were stored by the first lane of each row; the molecule's lanes read them back (wavefront-scope ordering: the
@@ -1152,6 +1252,14 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g, CEpiArgs E) {
                 const int a = row0 + task * rpw + (lane >> shift);
                 const bool valid = a < row_end;
                 cepi_rows(E, A.box, A.c_begin + (valid ? a : 0), valid, lane & ((1 << shift) - 1));
+            }
+        }
+        // the molecules are filed in their new cells (cepi_rows).  If some trigger now asks for a rebuild, the last block to get here
+        // turns the counts into the cells' start offsets: the next evaluation's chain begins at the sort, no assign launch
+        if (E.spec_count && amm_last_block(E.spec_ticket)) {
+            if (amm_ld_l2(&E.spec_flags[0])) {
+                const int fullest = cscan_counts<BS>(E.grid.ncell, E.spec_count, E.spec_start);
+                if (threadIdx.x == 0) E.spec_flags[6] = fullest;
             }
         }
     }
@@ -1272,7 +1380,7 @@ static int launch_cpair_t(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c,
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, ctx->stream, P, c, g, E);
         std::vector<unsigned long long> h(4 * nw);
         AMM_HIP(hipMemcpy(h.data(), d_times, sizeof(unsigned long long) * 4 * nw, hipMemcpyDeviceToHost));
-        std::string path = std::string(std::getenv("AMM_WAVE_TIMES_OUT") ? std::getenv("AMM_WAVE_TIMES_OUT") : "/tmp/wave_times") + (DUAL ? ".fused" : ".single");
+        std::string path = std::string(std::getenv("AMM_WAVE_TIMES_OUT") ? std::getenv("AMM_WAVE_TIMES_OUT") : "/tmp/wave_times") + (DUAL ? ".fused" : ".single") + (EPI ? "_epi" : "");
         if (FILE *fp = std::fopen(path.c_str(), "wb")) {
             std::fwrite(h.data(), sizeof(unsigned long long), h.size(), fp);
             std::fclose(fp);
@@ -1368,19 +1476,22 @@ static int cluster_setup_grid(amm_ctx *ctx, ClusterList *cl, double rc) {
 }
 
 static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const double *d_pos, int force, bool count_only, PairForce *gather_for,
-                         CZeroRows Z = CZeroRows{0, nullptr, nullptr, nullptr}, int copies_current = 0) {
+                         CZeroRows Z = CZeroRows{0, nullptr, nullptr, nullptr}, int copies_current = 0, bool skip_assign = false) {
     hipStream_t st = ctx->stream;
     const int nc = cl->nc;
-    hipLaunchKernelGGL(k_cassign, dim3((nc + cl->nrest + 255) / 256), dim3(256), 0, st, nc, d_pos, ctx->box, cl->grid, cl->d_cell_count, cl->d_cell_start,
-                       cl->d_cell_members, cl->capc, count_only ? (double *)nullptr : cl->d_xref, cl->d_flags, cl->d_ticket, force, cl->d_first,
-                       cl->d_rest, cl->nrest);
+    // (skip_assign: the launch that moved the atoms filed every molecule in its cell and, if a rebuild is due, scanned the counts)
+    if (!skip_assign)
+        hipLaunchKernelGGL(k_cassign, dim3((nc + cl->nrest + 255) / 256), dim3(256), 0, st, nc, d_pos, ctx->box, cl->grid, cl->d_cell_count, cl->d_cell_start,
+                           cl->d_cell_members, cl->capc, count_only ? (double *)nullptr : cl->d_xref, cl->d_flags, cl->d_ticket, force, cl->d_first,
+                           cl->d_rest, cl->nrest);
     if (!cl->d_cell_members) return 0;
     PairForce *gf = gather_for;
     const long sort_threads = std::max(std::max((long)cl->grid.ncell * 64, gf ? (long)nc : 0L), (long)Z.n);
     hipLaunchKernelGGL(k_csort_gather, dim3((unsigned)((sort_threads + 255) / 256)), dim3(256), 0, st, cl->grid.ncell, nc, cl->d_cell_start,
                        cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags, cl->d_flags, force,
                        gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr, gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr,
-                       gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2, cl->d_first, Z, copies_current);
+                       gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2, cl->d_first, Z, copies_current,
+                       count_only ? (double *)nullptr : cl->d_xref);
     const long threads = (long)cl->grid.ncell * cl->parts * 64;
     dim3 grid((unsigned)((threads + 255) / 256));
     CBoxF bf;
@@ -1567,7 +1678,8 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
                                cl->d_flags);
         const int forced = L->force_rebuild_c ? 1 : 0;
         L->force_rebuild_c = false;
-        if (cluster_chain(ctx, L, cl, d_pos, forced, false, pf, Z, copies_current)) return 1;
+        const bool assigned = !forced && cl->assigned_epoch == ctx->pos_epoch && cl->assigned_pos == d_pos;
+        if (cluster_chain(ctx, L, cl, d_pos, forced, false, pf, Z, copies_current, assigned)) return 1;
         gathered = true;
     }
     cl->checked_epoch = ctx->pos_epoch;
@@ -1575,7 +1687,7 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
     if (!gathered && !copies_current)
         hipLaunchKernelGGL(k_csort_gather, dim3((std::max(cl->nc, Z.n) + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start,
                            cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0,
-                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, Z, 0);     // flags[8] stays 0: copies only
+                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, Z, 0, (double *)nullptr);     // flags[8] stays 0: copies only
     // (the copies in place are this force's at these positions from here on, whoever wrote them)
     cl->sorted_for = pf;
     cl->sorted_epoch = ctx->pos_epoch;
@@ -1706,6 +1818,27 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
                 E.seps2_next = nx->d_seps2;
             }
             amm_collect_watches(ctx, E.W);
+            // the moved molecules' cells, ahead of a possible rebuild (needs this list's own trigger among the watched ones: it is)
+            E.spec_count = E.spec_clear = E.spec_members = E.spec_start = E.spec_flags = E.spec_ticket = nullptr;
+            E.spec_capc = 0;
+            E.grid = cl->grid;
+            if (plan->niter > 0 && ctx->opt_spec_assign) {
+                if (!cl->d_spec_count[0]) {
+                    for (int k = 0; k < 2; ++k) {
+                        AMM_HIP(hipMalloc(&cl->d_spec_count[k], sizeof(int) * (cl->grid.ncell + 1)));
+                        AMM_HIP(hipMemsetAsync(cl->d_spec_count[k], 0, sizeof(int) * (cl->grid.ncell + 1), st));
+                    }
+                    AMM_HIP(hipMalloc(&cl->d_spec_ticket, sizeof(int) * AMM_TICKET_INTS));
+                    AMM_HIP(hipMemsetAsync(cl->d_spec_ticket, 0, sizeof(int) * AMM_TICKET_INTS, st));
+                }
+                E.spec_count = cl->d_spec_count[cl->spec_parity];
+                E.spec_clear = cl->d_spec_count[cl->spec_parity ^ 1];
+                E.spec_members = cl->d_cell_members;
+                E.spec_start = cl->d_cell_start;
+                E.spec_flags = cl->d_flags;
+                E.spec_ticket = cl->d_spec_ticket;
+                E.spec_capc = cl->capc;
+            }
             if (ok) Ep = &E;
         }
         if (guest && ctx->opt_fuse_rows && A.nnb_total) {
@@ -1777,6 +1910,11 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             if (plan->niter > 0) {
                 ctx->pos_epoch++;
                 amm_watch_moved(ctx);
+                if (E.spec_count) {
+                    cl->spec_parity ^= 1;
+                    cl->assigned_epoch = ctx->pos_epoch;
+                    cl->assigned_pos = ctx->d_x;
+                }
                 if (enext) {
                     if (enext_alias) std::swap(enext->d_posq_s, enext->d_posq_alt);
                     cl->sorted_for = enext;
@@ -1835,7 +1973,7 @@ int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_p
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(k_csort_gather, dim3((cl->nc + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start, cl->d_cell_members,
                        cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0, pf->d_q, pf->d_hsig,
-                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, CZeroRows{0, nullptr, nullptr, nullptr}, 0);
+                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, CZeroRows{0, nullptr, nullptr, nullptr}, 0, (double *)nullptr);
     if (cl->sorted_for == pf) {        // (this force's copies in place are those of d_pos now)
         cl->sorted_epoch = ctx->pos_epoch;
         cl->sorted_pos = d_pos;
@@ -1911,6 +2049,8 @@ int amm_cluster_row_padding_impl(amm_ctx *ctx, PairForce *pf, long long out[2]) 
 }
 
 int amm_cluster_free(ClusterList *cl) {
+    for (void *q : {(void *)cl->d_spec_count[0], (void *)cl->d_spec_count[1], (void *)cl->d_spec_ticket})
+        if (q) (void)hipFree(q);
     void *ptrs[] = {cl->d_cell_count, cl->d_cell_start, cl->d_cell_members, cl->d_cperm, cl->d_aperm, cl->d_pos4f, cl->d_xref, cl->d_nl,
                     cl->d_nnb, cl->d_nnb_near, cl->d_flags, cl->d_counters, cl->d_blockstats, cl->d_ticket};
     for (void *p : ptrs)

@@ -3,7 +3,8 @@
 "-DAMM_CLUSTER_TUNE -DAMM_CPAIR_TIMING"; run e.g. scripts/probe_pair.py with AMM_ALLOW_TUNE=1 AMM_LIB=.../lib_wt.so
 AMM_WAVE_TIMES=20 AMM_WAVE_TIMES_OUT=gpurun_out/wt/times: the 20th launch of each kernel writes [wavefront][4] u64 =
 kernel entry, tables staged, tasks done (wall_clock64, 100 MHz), interior tasks << 8 | tasks).
-    python scripts/wave_times.py gpurun_out/wt/times.fused"""
+    python scripts/wave_times.py gpurun_out/wt/times.fused
+Files named *_epi come from the kernels that carry the inner RESPA loop as their epilogue: their second clock is "rows walked"."""
 import sys
 
 import numpy as np
@@ -19,4 +20,10 @@ for path in sys.argv[1:]:
     print('   mean wavefront lifetime / kernel time %.3f; wavefronts 0-3 of a block: median %.1f us, wavefronts 4-7: %.1f us' % (
         (end - entry).mean() / end.max(), np.median(work[slot < 4]), np.median(work[slot >= 4])))
     blk = np.arange(len(a)) // 8
+    if path.endswith('_epi'):
+        epi = end - staged
+        print('   epilogue (inner RESPA loop of the rows\' molecules) per wavefront p10 / median / p90 / max = %.1f / %.1f / %.1f / %.1f us; '
+              'rows walked: wavefronts 0-3 median %.1f us, 4-7 %.1f us, last %.1f us' % (
+                  np.percentile(epi, 10), np.median(epi), np.percentile(epi, 90), epi.max(), np.median((staged - entry)[slot < 4]),
+                  np.median((staged - entry)[slot >= 4]), staged.max()))
     print('   per XCD (block & 7), slowest wavefront: ' + ' '.join('%.1f' % end[(blk & 7) == x].max() for x in range(8)))
