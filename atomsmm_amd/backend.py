@@ -37,7 +37,7 @@ EXPORTS = [
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read', 'amm_pair_count_within', 'amm_pair_row_padding', 'amm_kernel_revision',
     'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_bath_define_nhl', 'amm_bath_define_sin', 'amm_iso_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
     'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_destroy', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
-    'amm_set_option', 'amm_positions_changed', 'amm_exchange_per', 'amm_run_stats',
+    'amm_set_option', 'amm_positions_changed', 'amm_exchange_per', 'amm_run_stats', 'amm_run_ops_from', 'amm_exchange_pending',
 ]
 
 
@@ -60,7 +60,7 @@ class PairStats(C.Structure):
                 ('n_outer_pairs', C.c_int64), ('rlist_outer', C.c_double), ('tab_error', C.c_double),
                 ('has_table', C.c_int32), ('rode_along', C.c_int32),
                 ('has_site_table', C.c_int32), ('n_rest_atoms', C.c_int32), ('site_tab_error', C.c_double),
-                ('n_candidates', C.c_int32), ('n_candidate_walks', C.c_int32)]
+                ('n_candidates', C.c_int32), ('n_candidate_walks', C.c_int32), ('chargeless', C.c_int32), ('reserved_', C.c_int32)]
 
 
 def slice_per(n, world):
@@ -143,6 +143,7 @@ def lib():
         L.amm_group_set_exchange.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_bind_exchange.argtypes = [vp, vp, C.c_int64]
         L.amm_exchange_finish.argtypes = [vp]
+        L.amm_exchange_pending.argtypes = [vp, C.POINTER(C.c_int32)]
         L.amm_check.argtypes = [vp]
         L.amm_pair_create.argtypes = [vp, C.POINTER(PairDesc), dp, dp, dp, ip, C.c_int32, C.c_double, ip]
         L.amm_pair_set_params.argtypes = [vp, C.c_int32, dp, dp, dp]
@@ -161,6 +162,7 @@ def lib():
         L.amm_bind_buffer.argtypes = [vp, C.c_int32, vp]
         L.amm_group_define.argtypes = [vp, C.c_int32, C.c_int32, ip, C.c_int32]
         L.amm_run_ops.argtypes = [vp, C.POINTER(Op), C.c_int32, C.c_int32]
+        L.amm_run_ops_from.argtypes = [vp, C.POINTER(Op), C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
         L.amm_set_fuse_inner.argtypes = [vp, C.c_int32]
         L.amm_set_outer_skin.argtypes = [vp, C.c_double]
         L.amm_pair_get_stats.argtypes = [vp, C.c_int32, C.POINTER(PairStats)]
@@ -373,7 +375,7 @@ class HipContext:
         """What amm_run_ops fused so far: launches that carried the inner RESPA loop as an epilogue, evaluations without a gather launch."""
         out = (C.c_int64 * 4)()
         _chk(lib().amm_run_stats(self.h, out))
-        return dict(epilogues=out[0], copies_current=out[1])
+        return dict(epilogues=out[0], copies_current=out[1], state_exchanges=out[2])
 
     def bath_define(self, z, kT):
         bid = C.c_int32(-1)
@@ -447,6 +449,22 @@ class HipContext:
     def run_ops(self, ops, repeat=1):
         arr = (Op * len(ops))(*ops)
         _chk(lib().amm_run_ops(self.h, arr, len(ops), int(repeat)))
+
+    def run_ops_host_exchanges(self, ops, repeat, exchange):
+        """amm_run_ops for several ranks whose collectives the HOST makes: runs the program to its end, calling `exchange()` -- which
+        must all-gather the chunks of the exchange buffer and call exchange_finish -- whenever an exchanged evaluation waits for it
+        (include/atomsmm_hip.h: amm_run_ops_from)."""
+        arr = (Op * len(ops))(*ops)
+        cursor = C.c_int64(0)
+        total = len(ops) * int(repeat)
+        while True:
+            _chk(lib().amm_run_ops_from(self.h, arr, len(ops), int(repeat), C.byref(cursor)))
+            nf = C.c_int32(0)
+            _chk(lib().amm_exchange_pending(self.h, C.byref(nf)))
+            if nf.value:
+                exchange(nf.value)          # (also the exchange of the program's last op: one more call winds the program up)
+            elif cursor.value >= total:
+                return
 
     def set_outer_skin(self, skin_out):
         _chk(lib().amm_set_outer_skin(self.h, float(skin_out)))

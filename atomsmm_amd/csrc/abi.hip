@@ -448,6 +448,8 @@ int amm_pair_set_params(amm_ctx *ctx, int32_t force_id, const double *h_q, const
         hs[i] = 0.5 * h_sigma[i];          // sigma = 0.5*(sigma1+sigma2)       forces.py:256
         se[i] = 2.0 * std::sqrt(h_eps[i]); // 4*epsilon = 4*sqrt(eps1*eps2)     forces.py:257
     }
+    pf->all_q_zero = true;
+    for (int i = 0; i < n && pf->all_q_zero; ++i) pf->all_q_zero = h_q[i] == 0.0;
     // ordered after any kernels already queued on the stream
     AMM_HIP(hipStreamSynchronize(ctx->stream));
     AMM_HIP(hipMemcpy(pf->d_q, h_q, sizeof(double) * n, hipMemcpyHostToDevice));
@@ -925,14 +927,35 @@ int amm_bind_exchange(amm_ctx *ctx, double *d_buf, int64_t n_doubles) {
     ctx->xchg_doubles = n_doubles;
     return 0;
 }
+int amm_exchange_pending(amm_ctx *ctx, int32_t *nf) {
+    if (!ctx || !nf) return 1;
+    *nf = ctx->pending.active ? ctx->pending.nf : 0;
+    return 0;
+}
 int amm_exchange_finish(amm_ctx *ctx) {
     if (!ctx) return 1;
     return amm_exchange_finish_impl(ctx);
 }
 
-int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) {
+int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) { return amm_run_ops_from(ctx, ops, n_ops, repeat, nullptr); }
+
+// cursor != nullptr: resumable.  Starts at op *cursor of the unrolled program (repetition * n_ops + index) and runs to its end --
+// or to the first exchanged evaluation whose exchange is the HOST's to make (no communicator of the library's own): then it returns 0
+// with *cursor at the op to go on from and the exchange pending (the host all-gathers the chunks, calls amm_exchange_finish and
+// calls again).  *cursor == repeat * n_ops on return: the program is through.
+int amm_run_ops_from(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat, int64_t *cursor) {
     if (!ctx->d_x || !ctx->d_v || !ctx->d_mass) {
         amm_set_error("amm_run_ops: state not bound (amm_bind_state)");
+        return 1;
+    }
+    const long total_ops = (long)repeat * n_ops;
+    if (cursor && (*cursor < 0 || *cursor > total_ops)) {
+        amm_set_error("amm_run_ops_from: cursor out of range");
+        return 1;
+    }
+    // (*cursor == total_ops: nothing left to run -- the call winds the program up: force buffers that hold this rank's rows only)
+    if (ctx->pending.active) {
+        amm_set_error("amm_run_ops: an exchanged evaluation still waits for amm_exchange_finish");
         return 1;
     }
     // user-visible buffers; the fused inner iteration ping-pongs between them and library-owned partners
@@ -980,6 +1003,13 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 amm_set_error("amm_run_ops: KICK buffer not bound");
                 return 1;
             }
+            if (!ctx->own_only.empty()) {
+                const auto has = [&](const double *b) { return b && std::find(ctx->own_only.begin(), ctx->own_only.end(), b) != ctx->own_only.end(); };
+                if (has(fa) || has(fb)) {
+                    amm_set_error("amm_run_ops: a deferred kick reads a force buffer that holds this rank's rows only (state exchange)");
+                    return 1;
+                }
+            }
             if (amm_kick_impl(ctx, ctx->d_v, fa, fb, ko.c, ctx->d_mass, ko.coef)) return 1;
         }
         deferred.clear();
@@ -993,8 +1023,34 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
     // the inner loop that open that repetition (`wraps`; what the deferred kicks do for the stand-alone inner-loop launch).
     // q_resume: the first op not covered (in the next repetition when wraps).
     auto slot_of = [&](int a) -> double * { return (a >= 0 && a < AMM_MAX_SLOTS) ? ctx->slots[a] : nullptr; };
+    // Buffers that hold this rank's rows only (state exchange, cluster.hip).  complete(buf): before an op reads `buf` for ALL atoms --
+    // a bond-list group's buffer is evaluated again (every rank can: positions are whole after every exchange; the same numbers the
+    // owners hold), anything else is an error: a pair group must be evaluated again before its forces are read.
+    auto forget_own_only = [&](const double *buf) {
+        auto it = std::find(ctx->own_only.begin(), ctx->own_only.end(), buf);
+        if (it != ctx->own_only.end()) ctx->own_only.erase(it);
+    };
+    auto complete = [&](const double *buf) -> int {
+        if (!buf || ctx->own_only.empty() || std::find(ctx->own_only.begin(), ctx->own_only.end(), buf) == ctx->own_only.end()) return 0;
+        for (int gi = 0; gi < AMM_MAX_GROUPS; ++gi) {
+            GroupDef &g = ctx->groups[gi];
+            if (g.slot < 0 || ctx->slots[g.slot] != buf || g.forces.empty()) continue;
+            bool bonded_only = true;
+            for (int fid : g.forces) bonded_only = bonded_only && ctx->forces[fid].type == 2 && !ctx->forces[fid].bonded->sliced;
+            if (!bonded_only) break;
+            bool first = true;
+            for (int fid : g.forces) {
+                if (amm_bonded_eval_impl(ctx, ctx->forces[fid].bonded, ctx->d_x, ctx->slots[g.slot], first ? 0 : 1, nullptr)) return 1;
+                first = false;
+            }
+            forget_own_only(buf);
+            return 0;
+        }
+        amm_set_error("amm_run_ops: an op reads a force buffer that holds this rank's rows only (state exchange) before its group was evaluated again");
+        return 1;
+    };
     auto plan_epilogue = [&](int after, int rep, EpiPlan &P, int &q_resume, bool &wraps) -> bool {
-        if (!ctx->fuse_inner || !ctx->opt_fuse_epilogue || ctx->iso.on || ctx->world != 1 || swapped || f0_slot >= 0) return false;
+        if (!ctx->fuse_inner || !ctx->opt_fuse_epilogue || ctx->iso.on || swapped || f0_slot >= 0) return false;
         std::vector<amm_op> kicks;
         int j = after;
         wraps = false;
@@ -1069,11 +1125,24 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
         q_resume = q;
         return true;
     };
-    int k_start = 0;
-    for (int rep = 0; rep < repeat; ++rep) {
+    // leave to the host what only it can do: an exchange pending without a communicator of the library's own.  0: go on, 1: error,
+    // 2: *cursor is set -- wind up and return
+    auto leave_to_host = [&](long next_pos) -> int {
+        if (!ctx->pending.active) return 0;
+        if (cursor) {
+            *cursor = next_pos;
+            return 2;
+        }
+        if (next_pos == total_ops) return 0;       // (the plain entry point: the caller finishes the exchange of the program's last op)
+        amm_set_error("amm_run_ops: without a communicator (amm_comm_init) an exchanged EVAL must be the last op of the call (or use amm_run_ops_from)");
+        return 1;
+    };
+    bool yielded = false;
+    int k_start = cursor ? (int)(*cursor % n_ops) : 0;
+    for (int rep = cursor ? (int)(*cursor / n_ops) : 0; rep < repeat && !yielded; ++rep) {
         const int k_first = k_start;
         k_start = 0;
-        for (int k = k_first; k < n_ops; ++k) {
+        for (int k = k_first; k < n_ops && !yielded; ++k) {
             const amm_op &op = ops[k];
             if (!deferred.empty() && !(k == 0 && op.op == AMM_OP_KICK) && flush_deferred()) return 1;
             // trailing block of the program = only KICKs and COPYs, and the program opens with KICKs: defer the kicks
@@ -1151,6 +1220,9 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                         }
                         double *f0 = ctx->slots[g.slot];
                         if (ok && f0) {
+                            if (complete(f0)) return 1;
+                            for (int j = 0; j < ndef + npre; ++j)
+                                if (complete(pa[j]) || complete(pb[j])) return 1;
                             deferred.clear();
                             if (amm_inner_components_impl(ctx, bs, ctx->d_x, ctx->d_v, f0, ndef + npre, pa, pb, pc, pp, ops[start].coef,
                                                           ops[start + 1].coef, ops[start + eo + 1].coef, niter,
@@ -1235,8 +1307,10 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                             EpiPlan plan;
                             int q_resume = 0;
                             bool wraps = false;
-                            const bool planned = !g1.exchange && g1.forces.size() == 1 && g2.forces.size() == 1 &&
-                                                 plan_epilogue(k + 2, rep, plan, q_resume, wraps);
+                            // (several ranks: only groups whose exchange is the all-gather of slices -- the launch then integrates
+                            // this rank's molecules and the ranks exchange positions and velocities: cluster.hip, state exchange)
+                            const bool planned = (ctx->world == 1 ? !g1.exchange : g1.exchange == AMM_EXCHANGE_GATHER) &&
+                                                 g1.forces.size() == 1 && g2.forces.size() == 1 && plan_epilogue(k + 2, rep, plan, q_resume, wraps);
                             ctx->epi_request = planned ? &plan : nullptr;
                             ctx->epi_done = false;
                             const int rc_dual = amm_pair_eval_impl(ctx, host, ctx->d_x, fh, 0, nullptr, guest, fg, 0, g1.exchange);
@@ -1244,6 +1318,12 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                             if (rc_dual) return 1;
                             if (ctx->epi_done) {
                                 ctx->epi_done = false;
+                                const int lv = leave_to_host(wraps ? (long)(rep + 1) * n_ops + q_resume : (long)rep * n_ops + q_resume);
+                                if (lv == 1) return 1;
+                                if (lv == 2) {
+                                    yielded = true;
+                                    break;
+                                }
                                 if (wraps) {
                                     k_start = q_resume;
                                     break;
@@ -1251,7 +1331,18 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                                 k = q_resume - 1;
                                 continue;
                             }
-                            if (exchange_left_to_host(ctx, rep == repeat - 1 && k + 1 == n_ops - 1)) return 1;
+                            forget_own_only(fh);           // (both buffers are written in full: by the kernel, or by the exchange's unsort)
+                            forget_own_only(fg);
+                            {
+                                const int lv = leave_to_host((long)rep * n_ops + k + 2);
+                                if (lv == 1) return 1;
+                                if (lv == 2) {
+                                    // (further members of the two groups are added after the exchange: only pair-only groups get here --
+                                    // an exchanged group holds exactly one pair force)
+                                    yielded = true;
+                                    break;
+                                }
+                            }
                             for (const GroupDef *g : {&g1, &g2})
                                 for (size_t j = 1; j < g->forces.size(); ++j)
                                     if (force_eval_dispatch(ctx, g->forces[j], ctx->d_x, ctx->slots[g->slot], 1, nullptr)) return 1;
@@ -1363,6 +1454,8 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                 const bool moves = j < n_ops && ops[j].op == AMM_OP_MOVE;
                 const bool whole_run = !(j < n_ops && ops[j].op == AMM_OP_KICK);       // (a fifth kick: the run goes on)
                 if (nk - nlead == j - k && (nlead == 0 || whole_run) && (nk >= 2 || (nk == 1 && moves))) {
+                    for (int q = 0; q < nk; ++q)
+                        if (complete(fa[q]) || complete(fb[q])) return 1;
                     if (amm_kicks_move_impl(ctx, fa, fb, plus, coef, nk, moves ? 1 : 0, moves ? ops[j].coef : 0.0)) return 1;
                     deferred.clear();
                     if (moves) {
@@ -1387,36 +1480,49 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     return 1;
                 }
                 if (g.forces.empty()) AMM_HIP(hipMemsetAsync(buf, 0, sizeof(double) * 3 * (size_t)ctx->n, ctx->stream));
-                if (!g.exchange && g.forces.size() == 1 && ctx->forces[g.forces[0]].type == 1) {
-                    // one pair force: the kicks and the inner loop that follow can ride on its launch (molecule rows: cepi_rows)
+                if ((ctx->world == 1 ? !g.exchange : g.exchange == AMM_EXCHANGE_GATHER) && g.forces.size() == 1 &&
+                    ctx->forces[g.forces[0]].type == 1) {
+                    // one pair force: the kicks and the inner loop that follow can ride on its launch (molecule rows: cepi_rows; several
+                    // ranks: followed by an exchange of positions and velocities instead of forces)
                     EpiPlan plan;
                     int q_resume = 0;
                     bool wraps = false;
                     if (plan_epilogue(k + 1, rep, plan, q_resume, wraps)) {
                         ctx->epi_request = &plan;
                         ctx->epi_done = false;
-                        const int rc_one = amm_pair_eval_impl(ctx, ctx->forces[g.forces[0]].pair, ctx->d_x, buf, 0, nullptr);
+                        const int rc_one = amm_pair_eval_impl(ctx, ctx->forces[g.forces[0]].pair, ctx->d_x, buf, 0, nullptr, nullptr, nullptr, 0, g.exchange);
                         ctx->epi_request = nullptr;
                         if (rc_one) return 1;
                         if (ctx->epi_done) {
                             ctx->epi_done = false;
-                            if (wraps) {
+                            const int lv = leave_to_host(wraps ? (long)(rep + 1) * n_ops + q_resume : (long)rep * n_ops + q_resume);
+                            if (lv == 1) return 1;
+                            if (lv == 2) yielded = true;
+                            else if (wraps) {
                                 k_start = q_resume;
                                 k = n_ops;          // (leaves the loop over this repetition's ops)
                             } else {
                                 k = q_resume - 1;
                             }
+                        } else {
+                            forget_own_only(buf);
+                            const int lv = leave_to_host((long)rep * n_ops + k + 1);
+                            if (lv == 1) return 1;
+                            if (lv == 2) yielded = true;
                         }
                         break;
                     }
                 }
+                forget_own_only(buf);           // (every path below writes the group's buffer in full)
                 if (g.exchange) {
                     if (g.forces.size() != 1 || ctx->forces[g.forces[0]].type != 1) {
                         amm_set_error("amm_run_ops: an exchanged group must hold exactly one pair force");
                         return 1;
                     }
                     if (amm_pair_eval_impl(ctx, ctx->forces[g.forces[0]].pair, ctx->d_x, buf, 0, nullptr, nullptr, nullptr, 0, 1)) return 1;
-                    if (exchange_left_to_host(ctx, rep == repeat - 1 && k == n_ops - 1)) return 1;
+                    const int lv = leave_to_host((long)rep * n_ops + k + 1);
+                    if (lv == 1) return 1;
+                    if (lv == 2) yielded = true;
                     break;
                 }
                 // FarNonbondedForce (forces.py:710-724) = total + discount, two forces of one group: when the discount
@@ -1461,6 +1567,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     amm_set_error("amm_run_ops: KICK buffer not bound");
                     return 1;
                 }
+                if (complete(fa) || complete(fb)) return 1;
                 if (amm_kick_impl(ctx, ctx->d_v, fa, fb, op.c, ctx->d_mass, op.coef)) return 1;
             } break;
             case AMM_OP_MOVE:
@@ -1474,6 +1581,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     amm_set_error("amm_run_ops: COPY buffer not bound");
                     return 1;
                 }
+                if (complete(src)) return 1;
                 if (amm_copy_impl(ctx, dst, src)) return 1;
                 if (dst == ctx->d_x) ctx->pos_epoch++;
             } break;
@@ -1485,6 +1593,7 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
                     amm_set_error("amm_run_ops: COMBINE buffer not bound");
                     return 1;
                 }
+                if (complete(sa) || complete(sb)) return 1;
                 if (amm_combine_impl(ctx, dst, sa, sb, op.coef)) return 1;
                 if (dst == ctx->d_x) ctx->pos_epoch++;
             } break;
@@ -1543,6 +1652,14 @@ int amm_run_ops(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat) 
         }
     }
     if (flush_deferred()) return 1;
+    if (cursor && !yielded) *cursor = total_ops;
+    if (!yielded && !ctx->own_only.empty()) {
+        // the program is through: the caller may read any force buffer now (the engine serves cached forces): bond-list groups are
+        // evaluated again in full, a pair group left with this rank's rows only is an error (a RESPA program ends on a whole evaluation)
+        const std::vector<const double *> left = ctx->own_only;
+        for (const double *b : left)
+            if (complete(b)) return 1;
+    }
     if (swapped) {   // odd number of fused iterations: bring the state back into the caller's buffers
         const size_t bytes = sizeof(double) * 3 * (size_t)ctx->n;
         AMM_HIP(hipMemcpyAsync(user_x, ctx->d_x, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1570,6 +1687,7 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     out->tab_error = pf->tab_error;
     out->has_table = (pf->pc.tab.nint > 0 && pf->d_tab) ? 1 : 0;
     out->rode_along = pf->last_fused;
+    out->chargeless = pf->last_chargeless;
     out->has_site_table = (ctx->opt_site_tab && pf->d_tab_ss && pf->pc.tab.ss_first >= 0) ? 1 : 0;
     out->site_tab_error = pf->ss_error;
     out->n_rest_atoms = L->hybrid ? L->n_rest : 0;
@@ -1689,6 +1807,8 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "fuse_epilogue") ctx->opt_fuse_epilogue = v;
     else if (k == "comm_timeout") ctx->opt_comm_timeout = value;
     else if (k == "spec_assign") ctx->opt_spec_assign = v;
+    else if (k == "chargeless") ctx->opt_chargeless = v;
+    else if (k == "state_exchange") ctx->opt_state_exchange = v;
     else {
         amm_set_error("amm_set_option: unknown option '" + k + "'");
         return 1;
@@ -1700,7 +1820,8 @@ int amm_run_stats(amm_ctx *ctx, int64_t out[4]) {
     if (!ctx || !out) return 1;
     out[0] = ctx->n_epilogues;
     out[1] = ctx->n_copies_current;
-    out[2] = out[3] = 0;
+    out[2] = ctx->n_state_exchanges;
+    out[3] = 0;
     return 0;
 }
 

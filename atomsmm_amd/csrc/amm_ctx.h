@@ -91,6 +91,8 @@ struct PairForce {
     double *d_tab_ss = nullptr;    // site-site table [nint - ss_first][6] (molecule-row kernels); null: none
     double ss_error = 0;           // its largest relative interpolation error
     double ss_built_for[3] = {0, 0, 0};     // (sigma/2, 2 sqrt(eps), q) the tables were last built for
+    bool all_q_zero = false;       // every charge is zero (set_params): the per-atom-row kernel has an instantiation without the Coulomb table
+    int last_chargeless = 0;       // ... and the last force-only evaluation ran it (statistics)
     int last_fused = 0;            // 1: the last force-only evaluation rode on the list owner's launch (molecule rows, fused pass)
     int last_kind = 0;             // list walked by the last evaluation: 0 per-atom rows, 1 molecule rows, 2 hybrid (statistics)
     PairConsts pc;
@@ -265,6 +267,13 @@ struct PendingExchange {
     int per = 0, nf = 0;           // slots per rank; forces per chunk (2 after a dual evaluation)
     const int *perm = nullptr;
     double *force = nullptr, *gforce = nullptr;
+    // kind 1: the chunks hold the STATE of the ranks' molecules -- [x: per x 3][v: per x 3] in cell-sorted order -- after an
+    // evaluation whose launch integrated them (cluster.hip: cepi_rows on a rank's slice); finishing it spreads the other ranks'
+    // positions and velocities to the atom-order arrays, evaluates the lists' displacement triggers for them and writes the next
+    // evaluation's sorted copies of their molecules (k_state_scatter)
+    int kind = 0;
+    ClusterList *cl = nullptr;
+    PairForce *next = nullptr;     // the force whose sorted copies the next pair evaluation reads (or none)
 };
 
 // a neighbour list whose displacement trigger the kernel that moves the atoms evaluates (saves the check launch)
@@ -301,10 +310,17 @@ struct EpiPlan {
 struct amm_ctx {
     int n = 0;
     int opt_spec_assign = 1;           // ... which also files the moved molecules in their cells ahead of a possible rebuild (no assign launch)
+    int opt_state_exchange = 1;        // multi-rank: launches that integrate their rows' molecules exchange positions and velocities, not forces
+    int opt_chargeless = 1;            // per-atom rows: the chargeless instantiation of the tabulated kernel for forces whose charges are all zero
     int opt_fuse_epilogue = 1;         // molecule rows: the inner RESPA loop of a box of three-site molecules as the pair kernel's epilogue
     const EpiPlan *epi_request = nullptr;   // amm_run_ops -> amm_cluster_eval_impl (one evaluation)
     bool epi_done = false;             // ... which says here whether its launch carried the plan (it then bumped pos_epoch itself)
     long long n_epilogues = 0;         // launches that did (statistics)
+    long long n_state_exchanges = 0;   // ... on a rank's slice, followed by an exchange of positions and velocities instead of forces
+    // force buffers that hold THIS RANK'S rows only (written by such launches: the kicks they feed ran on this rank's molecules,
+    // nobody else needs them) until their group is evaluated again in full: amm_run_ops refuses -- or, for bond-list groups,
+    // re-evaluates -- before an op reads one for all atoms
+    std::vector<const double *> own_only;
     long long n_copies_current = 0;    // evaluations that found their sorted copies in place (no gather launch)
     // tuning / test options (amm_set_option): never read from the environment, so that a stray variable cannot change the
     // order of summation of a production run

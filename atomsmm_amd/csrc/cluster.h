@@ -68,4 +68,5 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
                           double *g_force, int g_accumulate, int exchange);
 int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double r_within, long long *count);
 int amm_cluster_row_padding_impl(amm_ctx *ctx, PairForce *pf, long long out[2]);
+int amm_cluster_state_finish_impl(amm_ctx *ctx);       // second half of a state exchange: k_state_scatter
 int amm_cluster_free(ClusterList *cl);

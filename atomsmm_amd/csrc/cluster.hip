@@ -839,6 +839,7 @@ struct CEpiPre {
 };
 struct CEpiArgs {
     int niter, npre;
+    int recompute_f0;                          // the innermost forces at the start are evaluated here, not taken from f0
     double *x, *v, *f0;
     const double *mass;
     double c1, d, c2;
@@ -852,6 +853,10 @@ struct CEpiArgs {
     int *spec_count, *spec_clear, *spec_members, *spec_start, *spec_flags, *spec_ticket;
     int spec_capc;
     CellGrid grid;
+    // multi-rank: this rank's chunk of the exchange buffer takes the new state of its molecules, [x: per x 3][v: per x 3] by sorted
+    // slot relative to the slice (null: single rank)
+    double *xchg_x, *xchg_v;
+    int c_first;                               // first sorted cluster of the slice
     double4 *posq_next;                        // sorted copies of the next pair evaluation (null: none)
     double2 *lj_next;                          // (null: that force's are in place already)
     const double *q_next, *hsig_next, *seps2_next;
@@ -936,8 +941,10 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
     const double par[3] = {my_tq.x, my_tq.y, my_tq.z};
     // slots (lanes of the quad) the term's atoms live in; a molecule has three atoms: slots 0 .. 2
     const int s0 = my_tl.x & 3, s1 = my_tl.y & 3, s2 = my_tl.z & 3;
-    for (int it = 0; it < E.niter; ++it) {
-        {
+    // (recompute_f0: pass -1 evaluates the terms at the positions as they are -- several ranks: a rebuild may have made this rank the
+    // owner of molecules whose innermost forces another rank held; bonded(x) is the same number whoever computes it)
+    for (int it = E.recompute_f0 ? -1 : 0; it < E.niter; ++it) {
+        if (it >= 0) {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -987,7 +994,7 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
             AMM_CEPI_TERM(3)
 #undef AMM_CEPI_TERM
         }
-        {
+        if (it >= 0) {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -1007,6 +1014,14 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
             E.x[3 * a + j] = x[j];
             E.v[3 * a + j] = v[j];
             E.f0[3 * a + j] = f[j];
+        }
+        if (E.xchg_x) {                        // the other ranks take the molecule's state from here (k_state_scatter)
+            const size_t sl = 3 * (size_t)(cs - E.c_first) + l;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                E.xchg_x[3 * sl + j] = x[j];
+                E.xchg_v[3 * sl + j] = v[j];
+            }
         }
         if (E.niter > 0) {
             if (l == 0 && E.spec_count) {
@@ -1453,6 +1468,70 @@ static int launch_cpair(amm_ctx *ctx, const CPairArgs &A, const PairConsts &c, c
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ exchange of the molecules' state
+// Multi-rank, owner-integrates: the rank that walks a molecule's rows also runs its inner RESPA loop (cepi_rows)
+// and leaves the molecule's new positions and velocities in its chunk of the exchange buffer; the chunks are all-gathered and this
+// kernel -- one thread per molecule of the OTHER ranks -- spreads them to the atom-order arrays, evaluates the lists' displacement
+// triggers for them (every rank then holds the same flags: its own molecules' from the epilogue, the others' from here) and writes
+// their records of the next pair evaluation's sorted copies, as the epilogue did for the rank's own.  Replaces, per evaluation, the
+// unsort of the gathered forces, the redundant inner loop over all atoms and the gather of the sorted copies.
+__global__ void __launch_bounds__(256) k_state_scatter(int nc, int per_c, int c_begin, int c_end, const int *__restrict__ aperm,
+                                                       const double *__restrict__ xchg, double *x, double *v, Box box, WatchArgs W,
+                                                       double4 *posq_next, double2 *lj_next, const double *__restrict__ q_next,
+                                                       const double *__restrict__ hsig_next, const double *__restrict__ seps2_next) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc || (c >= c_begin && c < c_end)) return;
+    const int r = c / per_c, loc = c - r * per_c;
+    const size_t per = 3 * (size_t)per_c;
+    const double *sx = xchg + ((size_t)r * 2 * per + 3 * (size_t)loc) * 3, *sv = sx + per * 3;
+    double p[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int i = aperm[3 * c + a];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p[a][k] = sx[3 * a + k];
+            x[3 * i + k] = p[a][k];
+            v[3 * i + k] = sv[3 * a + k];
+        }
+        amm_watch_atom(W, i, p[a]);
+    }
+    if (posq_next) {
+        double sh[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sh[k] = cwrap1(p[0][k], box.L[k], box.invL[k]) - p[0][k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int i = aperm[3 * c + a];
+            posq_next[3 * c + a] = make_double4(csorted_image(p[a][0], p[0][0], sh[0], box.L[0], box.invL[0]),
+                                                csorted_image(p[a][1], p[0][1], sh[1], box.L[1], box.invL[1]),
+                                                csorted_image(p[a][2], p[0][2], sh[2], box.L[2], box.invL[2]), q_next[i]);
+            if (lj_next) lj_next[3 * c + a] = make_double2(hsig_next[i], seps2_next[i]);
+        }
+    }
+}
+
+int amm_cluster_state_finish_impl(amm_ctx *ctx) {
+    PendingExchange &pe = ctx->pending;
+    ClusterList *cl = pe.cl;
+    WatchArgs W;
+    amm_collect_watches(ctx, W);
+    PairForce *nx = pe.next;
+    hipLaunchKernelGGL(k_state_scatter, dim3((cl->nc + 255) / 256), dim3(256), 0, ctx->stream, cl->nc, pe.per / 3, cl->c_begin, cl->c_end,
+                       cl->d_aperm, ctx->d_xchg, ctx->d_x, ctx->d_v, ctx->box, W, nx ? nx->d_posq_s : (double4 *)nullptr,
+                       nx ? nx->d_lj_s : (double2 *)nullptr, nx ? nx->d_q : nullptr, nx ? nx->d_hsig : nullptr, nx ? nx->d_seps2 : nullptr);
+    AMM_HIP(hipGetLastError());
+    amm_watch_moved(ctx);              // (the triggers of these positions are evaluated now: the owners' in the epilogue, the others' here)
+    if (nx) {
+        cl->sorted_for = nx;
+        cl->sorted_epoch = ctx->pos_epoch;
+        cl->sorted_pos = ctx->d_x;
+    }
+    pe.active = false;
+    pe.kind = 0;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ host orchestration
 static int cluster_setup_grid(amm_ctx *ctx, ClusterList *cl, double rc) {
     CellGrid &g = cl->grid;
@@ -1695,7 +1774,37 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
     const int nrows = cl->c_end - cl->c_begin;
     const int per_c = (cl->nc + ctx->world - 1) / ctx->world, per = 3 * per_c, nf = guest ? 2 : 1;
     double *out = d_force, *gout = g_force;
-    if (exchange) {
+    // Multi-rank with a plan for the launch's epilogue: STATE exchange -- this rank's launch integrates the molecules whose rows it
+    // walks and the ranks all-gather positions and velocities instead of forces (k_state_scatter).  Decided from quantities every
+    // rank holds alike (the plan, the families, the sizes): all ranks take the same path.
+    auto ss_bytes_of = [](const PairForce *p) { return (p->d_tab_ss && p->pc.tab.ss_first >= 0) ? (p->pc.tab.nint - p->pc.tab.ss_first) * AMM_TAB_STRIDE : 0; };
+    auto plan_fits = [&]() {
+        if (!(plan && ctx->opt_fuse_epilogue && !accumulate && !cl->d_first && cl->nrest == 0 && plan->bs && plan->bs->mol3_ok &&
+              plan->bs->finalized && plan->bs->ncomp == cl->nc && plan->f0 && plan->npre <= AMM_MAX_PRE && ctx->d_x == d_pos && ctx->d_v &&
+              plan->f0 != d_force && plan->f0 != g_force)) return false;
+        if (guest && !(!g_accumulate && g_force != d_force && ctx->opt_fuse_rows && pf == L && cl->rnear_build > 0)) return false;
+        return true;
+    };
+    bool state_mode = false;
+    if (exchange && ctx->world > 1 && ctx->opt_state_exchange && plan_fits() && cl->nc - per_c * (ctx->world - 1) > 0) {
+        // (the kernels that carry an epilogue: site-site tables, and for two forces the fused pass of launch_cdual)
+        bool kernel = ctx->opt_site_tab && ss_bytes_of(pf) > 0 && (!guest || ss_bytes_of(guest) > 0);
+        const int lds = pf->pc.tab.nint * AMM_TAB_STRIDE + ss_bytes_of(pf) + (guest ? guest->pc.tab.nint * AMM_TAB_STRIDE + ss_bytes_of(guest) : 0);
+        kernel = kernel && lds <= AMM_CPAIR_LDS_LIMIT;
+        if (guest) kernel = kernel && guest->pc.family == AMM_NEAR_FSWITCH && (pf->pc.family == AMM_DAMPED || pf->pc.family == AMM_NONBONDED);
+        state_mode = kernel;
+    }
+    if (state_mode) {
+        if (ctx->pending.active) {
+            amm_set_error("exchanged evaluation while the previous one still waits for amm_exchange_finish");
+            return 1;
+        }
+        if (!ctx->d_xchg || ctx->xchg_doubles < (long long)ctx->world * 2 * per * 3) {
+            amm_set_error("exchanged evaluation: bind an exchange buffer of world * 2 * per * 3 doubles, per = amm_exchange_per()");
+            return 1;
+        }
+        // (the forces of this rank's rows go straight to the groups' buffers, in atom order: only this rank's epilogue reads them)
+    } else if (exchange) {
         if (accumulate || g_accumulate) {
             amm_set_error("exchanged evaluation: forces only, no accumulation");
             return 1;
@@ -1734,7 +1843,7 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         A.lj = pf->d_lj_s;
         A.force = out;
         A.accumulate = accumulate;
-        A.sorted_out = exchange ? 1 : 0;
+        A.sorted_out = (exchange && !state_mode) ? 1 : 0;
         A.box = ctx->box;
         A.host_tab = pf->d_tab;
         A.host_bytes = pf->pc.tab.nint * AMM_TAB_STRIDE;
@@ -1776,11 +1885,10 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         bool epi_launched = false;
         PairForce *enext = nullptr;
         bool enext_alias = false;
-        if (plan && ctx->opt_fuse_epilogue && ctx->world == 1 && !exchange && !accumulate && !cl->d_first && cl->nrest == 0 && plan->bs &&
-            plan->bs->mol3_ok && plan->bs->finalized && plan->bs->ncomp == cl->nc && plan->f0 && plan->npre <= AMM_MAX_PRE &&
-            (!guest || (!g_accumulate && g_force != d_force && ctx->opt_fuse_rows && A.nnb_total)) && ctx->d_x == d_pos && ctx->d_v) {
+        if (((ctx->world == 1 && !exchange) || state_mode) && plan_fits()) {
             E.niter = plan->niter;
             E.npre = plan->npre;
+            E.recompute_f0 = (state_mode && plan->niter > 0) ? 1 : 0;
             E.x = ctx->d_x;
             E.v = ctx->d_v;
             E.f0 = plan->f0;
@@ -1788,7 +1896,10 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             E.c1 = plan->c1;
             E.d = plan->d;
             E.c2 = plan->c2;
-            bool ok = plan->f0 != d_force && plan->f0 != g_force;
+            bool ok = true;
+            E.xchg_x = state_mode ? ctx->d_xchg + (size_t)ctx->rank * 2 * per * 3 : nullptr;
+            E.xchg_v = state_mode ? E.xchg_x + (size_t)per * 3 : nullptr;
+            E.c_first = cl->c_begin;
             for (int p = 0; p < AMM_MAX_PRE; ++p) {
                 CEpiPre &k = E.pre[p];
                 k.a = p < plan->npre ? plan->pre_a[p] : nullptr;
@@ -1822,7 +1933,7 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             E.spec_count = E.spec_clear = E.spec_members = E.spec_start = E.spec_flags = E.spec_ticket = nullptr;
             E.spec_capc = 0;
             E.grid = cl->grid;
-            if (plan->niter > 0 && ctx->opt_spec_assign) {
+            if (plan->niter > 0 && ctx->opt_spec_assign && ctx->world == 1) {
                 if (!cl->d_spec_count[0]) {
                     for (int k = 0; k < 2; ++k) {
                         AMM_HIP(hipMalloc(&cl->d_spec_count[k], sizeof(int) * (cl->grid.ncell + 1)));
@@ -1851,7 +1962,7 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
             D.host_ss_off = D.host_bytes + D.guest_bytes - pf->pc.tab.ss_first * AMM_TAB_STRIDE;
             D.guest_ss_off = D.guest_bytes + D.host_ss_bytes - guest->pc.tab.ss_first * AMM_TAB_STRIDE;
             D.gforce = gout;
-            D.g_accumulate = (g_force == d_force && !exchange) ? 1 : g_accumulate;
+            D.g_accumulate = (g_force == d_force && !(exchange && !state_mode)) ? 1 : g_accumulate;
             D.gfac = (guest->pc.Kc * guest->pc.sign) / (pf->pc.Kc * pf->pc.sign);
             D.gsr = guest->pc.sign / pf->pc.sign;
             PairConsts gpc = guest->pc;
@@ -1902,7 +2013,34 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         if (rc_) return 1;
         AMM_HIP(hipGetLastError());
         if (guest) guest->n_evals++;
-        if (epi_launched) {
+        if (state_mode && !epi_launched) {
+            amm_set_error("internal: state exchange planned but the launch carried no epilogue");
+            return 1;
+        }
+        if (epi_launched && state_mode) {
+            // this rank's molecules are integrated; the others' state comes with the exchange (k_state_scatter), which also evaluates
+            // their displacement triggers and writes their part of the next evaluation's sorted copies
+            ctx->epi_done = true;
+            ctx->n_epilogues++;
+            ctx->n_state_exchanges++;
+            if (plan->niter > 0) ctx->pos_epoch++;
+            if (enext && enext_alias) std::swap(enext->d_posq_s, enext->d_posq_alt);
+            for (const double *b : {(const double *)d_force, (const double *)(guest ? g_force : nullptr), (const double *)plan->f0})
+                if (b && std::find(ctx->own_only.begin(), ctx->own_only.end(), b) == ctx->own_only.end()) ctx->own_only.push_back(b);
+            PendingExchange &pe = ctx->pending;
+            pe.active = true;
+            pe.kind = 1;
+            pe.per = per;
+            pe.nf = 2;
+            pe.cl = cl;
+            pe.next = plan->niter > 0 ? enext : nullptr;
+            pe.perm = cl->d_aperm;
+            pe.force = pe.gforce = nullptr;
+            if (ctx->comm) {
+                if (amm_comm_allgather_impl(ctx, ctx->d_xchg, (size_t)2 * per * 3)) return 1;
+                if (amm_exchange_finish_impl(ctx)) return 1;
+            }
+        } else if (epi_launched) {
             // the launch moved the atoms: new positions epoch, their displacement triggers are evaluated, and (when the next force
             // was known) its sorted copies are those of the new positions
             ctx->epi_done = true;
@@ -1925,9 +2063,10 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
         }
     }
     pf->n_evals++;
-    if (exchange) {
+    if (exchange && !state_mode) {
         PendingExchange &pe = ctx->pending;
         pe.active = true;
+        pe.kind = 0;
         pe.per = per;
         pe.nf = nf;
         pe.perm = cl->d_aperm;

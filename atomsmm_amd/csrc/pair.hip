@@ -1009,7 +1009,10 @@ struct TabArgs {
     const int *nnb_all;                   // per row: total length (also when only the front part is walked: the stretches are cut the same way)
 };
 
-template <int FAM, int CMODE, int GFAM, bool INTERIOR, bool LJ>
+// NOQ: every charge of the force is zero (a Lennard-Jones fluid: config C2 of BASELINE.json): no Coulomb table -- no index
+// arithmetic, no LDS look-up, no Horner chain, no charge product; the Lennard-Jones part is analytic as before and no pair is ever
+// "below the table"
+template <int FAM, int CMODE, int GFAM, bool INTERIOR, bool LJ, bool NOQ = false>
 __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairConsts &c, const PairConsts &gc,
                                                  const char *tabh, const char *tabg, const double *s_erfcx, const double4 pi,
                                                  const double2 li, const int *row, int nfront, int nn, int sub, int lpa, int s,
@@ -1059,8 +1062,8 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
             double dx, dy, dz;
             const double r2 = geometry(pj[u], dx, dy, dz);
             const bool pass = ok && (r2 < c.rc2);
-            const double qq = qi * pj[u].w;
-            double fr = qq * amm_tab_eval(tabh, c.tab, r2);
+            const double qq = NOQ ? 0.0 : qi * pj[u].w;
+            double fr = NOQ ? 0.0 : qq * amm_tab_eval(tabh, c.tab, r2);
             double frg = 0.0;
             if (GFAM >= 0) {
                 if (guest_trip) frg = qq * amm_tab_eval(tabg, gc.tab, r2);
@@ -1074,7 +1077,7 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
                 }
             }
             const bool gpass = GFAM >= 0 && pass && (r2 < gc.rc2);
-            const bool low = pass && (r2 < c.tab.r2min), glow = gpass && (r2 < gc.tab.r2min);
+            const bool low = !NOQ && pass && (r2 < c.tab.r2min), glow = gpass && (r2 < gc.tab.r2min);
             any_low = any_low || low || glow;
             fr = (pass && !low) ? fr : 0.0;
             fx += fr * dx;
@@ -1090,7 +1093,7 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
             }
         }
 #ifndef AMM_EXP_NOFALLBACK
-        if (__builtin_amdgcn_ballot_w64(any_low) != 0ull) {     // closer than a table reaches: analytic (never in a liquid)
+        if (!NOQ && __builtin_amdgcn_ballot_w64(any_low) != 0ull) {     // closer than a table reaches: analytic (never in a liquid)
             for (int u = 0; u < UNR; ++u) {
                 double dx, dy, dz;
                 const double r2 = geometry(pj[u], dx, dy, dz);
@@ -1160,7 +1163,7 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
 #endif
 // PH: the two-phase walk of a hybrid list's rest part (long rows, then short ones).  A compile-time switch: as a run-time one it cost
 // the common kernels two registers -- 130 instead of 128, three wavefronts per SIMD instead of four (C2: 21 -> 27 us).
-template <int FAM, int CMODE, int GFAM, int BS, bool PH = false>
+template <int FAM, int CMODE, int GFAM, int BS, bool PH = false, bool NOQ = false>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_TAB_WAVES_PER_EU)))
 k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
     extern __shared__ __align__(16) char s_lds[];
@@ -1240,7 +1243,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
         const bool interior = __builtin_amdgcn_ballot_w64(edge) == 0ull;
         const bool any_lj = __builtin_amdgcn_ballot_w64(valid && li.y != 0.0) != 0ull;
         double fx = 0.0, fy = 0.0, fz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-#define AMM_WALK(IN, LJF, KS, KE, KC, KG) amm_walk_row_tab<FAM, CMODE, GFAM, IN, LJF>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz, KS, KE, KC, KG)
+#define AMM_WALK(IN, LJF, KS, KE, KC, KG) amm_walk_row_tab<FAM, CMODE, GFAM, IN, LJF, NOQ>(A, c, gc, tabh, tabg, s_erfcx, pi, li, row, nfront, nn, sub, lpa, s, fx, fy, fz, gx, gy, gz, KS, KE, KC, KG)
 #define AMM_STRETCHES(LJF, KS, KE, KC, KG)                                                        \
         do {                                                                                      \
             if ((KE) > (KS) && __builtin_amdgcn_ballot_w64(valid && nn > (KS)) != 0ull) {         \
@@ -1335,7 +1338,7 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
 
 
 // one instantiation: dynamic LDS attribute + blocks per CU (cached), persistent grid (a multiple of 8 blocks)
-template <int FAM, int CMODE, int GFAM, int BS, bool PH = false>
+template <int FAM, int CMODE, int GFAM, int BS, bool PH = false, bool NOQ = false>
 static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts &c, const PairConsts &gc, TabArgs &T) {
     // (the LDS attribute and the occupancy answer belong to a device: one slot per device, like the erfcx upload flags)
     static int bpc_dev[64], lds_set_dev[64], cu_dev[64];
@@ -1356,7 +1359,7 @@ static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts
         amm_set_error("tabulated pair kernel: the radial tables of the two forces do not fit LDS together");
         return 1;
     }
-    auto kern = k_pair_tab<FAM, CMODE, GFAM, BS, PH>;
+    auto kern = k_pair_tab<FAM, CMODE, GFAM, BS, PH, NOQ>;
     if (lds > lds_set) {
         AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         lds_set = lds;
@@ -1685,6 +1688,7 @@ int amm_exchange_finish_impl(amm_ctx *ctx) {
         amm_set_error("amm_exchange_finish: no evaluation is waiting for its exchange");
         return 1;
     }
+    if (pe.kind == 1) return amm_cluster_state_finish_impl(ctx);      // the chunks hold positions and velocities (cluster.hip)
     hipLaunchKernelGGL(k_unsort, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream, ctx->n, pe.per, pe.nf, pe.perm, ctx->d_xchg,
                        pe.force, pe.gforce);
     AMM_HIP(hipGetLastError());
@@ -1901,6 +1905,17 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             PairConsts gpc = guest ? guest->pc : pf->pc;
             if (guest && (guest->desc.flags & AMM_GUARD_RC0)) gpc.rc2 = std::min(gpc.rc2, gpc.rc0 * gpc.rc0);   // step(rc0 - r)
             int rc_ = 0;
+            // a force without charges (all q = 0: a Lennard-Jones fluid) on its own: the instantiation without the Coulomb table
+            const bool noq = pf->all_q_zero && !guest && !A.active && tab_block_size(false) == 512 && ctx->opt_chargeless &&
+                             pf->desc.family >= AMM_NEAR_NONE && pf->desc.family <= AMM_NEAR_FSWITCH;
+            pf->last_chargeless = noq ? 1 : 0;
+            if (noq) {
+                T.host_bytes = 0;           // (nothing staged, no erfcx table needed: the analytic erfc families are not these)
+                T.need_erfcx = 0;
+                if (pf->desc.family == AMM_NEAR_NONE) rc_ = launch_pair_tab_i<AMM_NEAR_NONE, 0, -1, 512, false, true>(st, A, pf->pc, gpc, T);
+                else if (pf->desc.family == AMM_NEAR_SHIFT) rc_ = launch_pair_tab_i<AMM_NEAR_SHIFT, 0, -1, 512, false, true>(st, A, pf->pc, gpc, T);
+                else rc_ = launch_pair_tab_i<AMM_NEAR_FSWITCH, 0, -1, 512, false, true>(st, A, pf->pc, gpc, T);
+            } else
             switch (pf->desc.family) {
             case AMM_NEAR_NONE: rc_ = launch_pair_tab<AMM_NEAR_NONE, 0>(st, gfam, A, pf->pc, gpc, T); break;
             case AMM_NEAR_SHIFT: rc_ = launch_pair_tab<AMM_NEAR_SHIFT, 0>(st, gfam, A, pf->pc, gpc, T); break;

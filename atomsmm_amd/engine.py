@@ -1774,24 +1774,25 @@ class Engine:
                     current = []
                 else:
                     current.append(op)
-                    if op.op == B.OP_EVAL and op.a in self._gather_groups:
-                        segments.append((current, ('gather', None)))
-                        current = []
             plan = (ops, segments, current)
             if cache:
                 self._native_ops[id(ops)] = plan
         _, segments, tail = plan
         inv = {slot: name for name, slot in self._slots.items()}
+        # the all-gather exchanges INSIDE a run of ops are the library's to ask for: it runs up to an exchanged evaluation, hands back,
+        # the chunks are gathered here, and it goes on where it stopped (amm_run_ops_from) -- so that the launches which integrate
+        # their rows' molecules and exchange positions and velocities (state exchange) see the ops that follow their EVAL
+        if not segments:            # no all-reduce markers (groups of one pair force each: the bench): whole repetitions in one go
+            if tail:
+                self.ctx.run_ops_host_exchanges(tail, repeat, self._host_gather)
+            return
         for _ in range(repeat):
             for seg, (kind, slot) in segments:
                 if seg:
-                    self.ctx.run_ops(seg, 1)
-                if kind == 'reduce':
-                    self.torch.distributed.all_reduce(self._buffers[inv[slot]])
-                else:
-                    self._host_gather(1)
+                    self.ctx.run_ops_host_exchanges(seg, 1, self._host_gather)
+                self.torch.distributed.all_reduce(self._buffers[inv[slot]])
             if tail:
-                self.ctx.run_ops(tail, 1)
+                self.ctx.run_ops_host_exchanges(tail, 1, self._host_gather)
 
     def _host_gather(self, nf):
         """All-gather of the exchange chunks by torch.distributed (no library-owned communicator), then the unsort."""

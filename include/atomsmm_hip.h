@@ -158,6 +158,9 @@ enum { AMM_EXCHANGE_REDUCE = 0, AMM_EXCHANGE_GATHER = 1 };
 int amm_group_set_exchange(amm_ctx *ctx, int32_t group, int32_t mode);
 int amm_bind_exchange(amm_ctx *ctx, double *d_buf, int64_t n_doubles);
 int amm_exchange_finish(amm_ctx *ctx);
+/* *nf = 0: no exchange is waiting; else every rank's chunk of the exchange buffer holds nf x amm_exchange_per() x 3 doubles to all-gather
+ * (1: one force; 2: the two forces of a dual evaluation, or positions + velocities of a state exchange -- see amm_run_stats) */
+int amm_exchange_pending(amm_ctx *ctx, int32_t *nf);
 /* out[0] = collectives issued so far, out[1] = doubles per rank they carried (AMM_OP_ALLREDUCE ops on buffers that are
  * neighbours in memory are merged into one message) */
 int amm_comm_stats(amm_ctx *ctx, int64_t out[2]);
@@ -289,8 +292,15 @@ int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
 int amm_set_option(amm_ctx *ctx, const char *name, double value);
 /* What amm_run_ops fused so far (statistics for tests and bench.py): out[0] = pair-kernel launches that carried the inner RESPA loop
  * of their molecules as an epilogue (the reference runs it as CustomIntegrator steps, propagators.py:933-973), out[1] = pair
- * evaluations that found their sorted copies written by the launch that moved the atoms (no gather launch), out[2..3] = 0. */
+ * evaluations that found their sorted copies written by the launch that moved the atoms (no gather launch), out[2] = of out[0], the
+ * launches on a rank's slice that were followed by an exchange of positions and velocities instead of forces, out[3] = 0. */
 int amm_run_stats(amm_ctx *ctx, int64_t out[4]);
+/* amm_run_ops, resumable (several ranks whose collectives the HOST makes -- torch.distributed over gloo, or RCCL outside the library):
+ * starts at op *cursor of the unrolled program (repetition * n_ops + index; 0 at first) and runs to the end (*cursor = repeat * n_ops)
+ * or to the first exchanged evaluation that now waits for its exchange: the caller all-gathers the chunks of the exchange buffer,
+ * calls amm_exchange_finish and calls again with the cursor it was given.  With a communicator of the library's own nothing is left
+ * to the host and one call runs everything, as amm_run_ops does. */
+int amm_run_ops_from(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t repeat, int64_t *cursor);
 /* The bound position buffer was written by the caller (needed only with option "positions_private"; harmless otherwise). */
 int amm_positions_changed(amm_ctx *ctx);
 /* slots of the cell-sorted order per rank (whole molecules of three: 3 ceil(ceil(n/3) / world)): the exchange buffer holds
@@ -332,6 +342,9 @@ typedef struct {
     int32_t n_candidates;   /* list_kind 3 on a fused inner loop: atoms within cutoff + buffer of the small set at the companion
                                list's last build (the later evaluations walk these only); 0: every evaluation walks every atom */
     int32_t n_candidate_walks;  /* evaluations that walked the candidates only */
+    int32_t chargeless;         /* 1: the last force-only evaluation ran the per-atom-row kernel's instantiation without the Coulomb
+                                   table (every charge of the force is zero: the Lennard-Jones fluid of BASELINE config C2) */
+    int32_t reserved_;
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
 /* Measurement helper (bench.py): the number of directed list entries of this force with r < r_within at d_pos, counted in

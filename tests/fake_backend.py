@@ -116,6 +116,10 @@ class RecordingContext:
     def run_ops(self, ops, repeat=1):
         self.runs.append(([(o.op, o.a, o.b, o.c, o.coef) for o in ops], repeat))
 
+    def run_ops_host_exchanges(self, ops, repeat, exchange):
+        """The resumable form (several ranks, collectives made by the host): nothing is exchanged by this recorder."""
+        self.run_ops(ops, repeat)
+
     def force_eval(self, fid, pos, force, accumulate=False, energy=None):
         self.calls.append(('force_eval', fid, accumulate))
 

@@ -30,7 +30,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(B.PairDesc) == 4 * 4 + 9 * 8
     assert C.sizeof(B.Op) == 4 * 4 + 8
-    assert C.sizeof(B.PairStats) == 4 * 8 + 4 * 4 + 8 + 2 * 4 + 3 * 8 + 8 + 2 * 4 + 2 * 4 + 8 + 2 * 4
+    assert C.sizeof(B.PairStats) == 4 * 8 + 4 * 4 + 8 + 2 * 4 + 3 * 8 + 8 + 2 * 4 + 2 * 4 + 8 + 2 * 4 + 2 * 4
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -132,7 +132,7 @@ def test_engine_collectives_under_gloo():
 
 def _engine_gather_job(rank, world):
     """As _engine_job, with a recording backend that offers the exchange buffer: groups of one pair force exchange
-    their slices by all-gather (host-driven here: the op list is cut after each of their EVALs, the engine gathers the
+    their slices by all-gather (host-driven here: the library hands back at each of their EVALs, the engine gathers the
     chunks over gloo and calls exchange_finish); nothing is all-reduced for them."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -157,15 +157,19 @@ def _engine_gather_job(rank, world):
             assert mode == B.EXCHANGE_GATHER
             self.gather_groups.add(group)
 
-        def run_ops(self, ops, repeat=1):
+        def run_ops_host_exchanges(self, ops, repeat, exchange):
+            # (the library runs up to an exchanged EVAL, hands back, the engine gathers the chunks and calls exchange_finish, the
+            # library goes on: include/atomsmm_hip.h, amm_run_ops_from)
             super().run_ops(ops, repeat)
-            assert not self.pending, 'a new segment although the previous exchange was not finished'
-            evals = [k for k, o in enumerate(ops) if o.op == B.OP_EVAL and o.a in self.gather_groups]
-            assert evals in ([], [len(ops) - 1]) and (repeat == 1 or not evals)   # an exchanged EVAL ends its segment
-            if evals:          # the pair kernel's part: this rank's chunk of the exchange buffer
-                per = (self.n + self.world - 1) // self.world
-                self.exchange[self.rank * per * 3:(self.rank + 1) * per * 3] = float(self.rank + 1)
-                self.pending = True
+            per = (self.n + self.world - 1) // self.world
+            for _ in range(repeat):
+                for o in ops:
+                    if o.op == B.OP_EVAL and o.a in self.gather_groups:
+                        assert not self.pending, 'an exchanged EVAL although the previous exchange was not finished'
+                        # the pair kernel's part: this rank's chunk of the exchange buffer
+                        self.exchange[self.rank * per * 3:(self.rank + 1) * per * 3] = float(self.rank + 1)
+                        self.pending = True
+                        exchange(1)
 
         def exchange_finish(self):
             assert self.pending

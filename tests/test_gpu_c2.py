@@ -57,5 +57,6 @@ def test_c2_full_size_velocity_verlet_vs_oracle():
     assert np.abs(x - case['positions']).max() > 1e-3
     eng = simulation.context._engine
     st = eng.ctx.pair_stats(eng.pair_force_ids(0)[0])
-    assert st['list_kind'] == 0 and st['has_table'] == 1          # per-atom rows, tabulated force-only kernel
+    assert st['list_kind'] == 0 and st['has_table'] == 1          # per-atom rows, tabulated force-only kernel ...
+    assert st['chargeless'] == 1                                   # ... in its instantiation without the Coulomb table (all q = 0)
     eng.ctx.check()

@@ -26,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _simulate(nsteps, pme=False):
+def _simulate(nsteps, pme=False, state=1, chunks=1):
     import atomsmm_amd as atomsmm
     from atomsmm_amd import openmm, unit
     from atomsmm_amd.openmm import app
@@ -42,14 +42,17 @@ def _simulate(nsteps, pme=False):
     integrator = atomsmm.RespaPropagator([4, 2, 1]).integrator(2 * unit.femtoseconds)
     # equal Verlet buffers on both sides of the comparison: the default grows with the number of ranks, and another buffer means
     # other (masked) entries between the same pairs in a row, i.e. another order of the partial sums
-    sim = app.Simulation(app.Topology(), respa, integrator, openmm.Platform.getPlatformByName('HIP'), {'Skin': '0.1'})
+    sim = app.Simulation(app.Topology(), respa, integrator, openmm.Platform.getPlatformByName('HIP'),
+                         {'Skin': '0.1', 'Option.state_exchange': str(state)})
     sim.context.setPositions(c['positions'] * unit.nanometers)
     sim.context.setVelocities(c['velocities'])
     e0 = sim.context.getState(getEnergy=True).getPotentialEnergy()._value
     eng = sim.context._engine
     before = eng.ctx.comm_stats() if eng._native_comm else None
-    sim.step(nsteps)
+    for _ in range(chunks):
+        sim.step(nsteps)
     after = eng.ctx.comm_stats() if eng._native_comm else None
+    run_stats = eng.ctx.run_stats()
     st = sim.context.getState(getPositions=True, getVelocities=True, getEnergy=True, getForces=True, groups={0, 1, 2})
     stats = eng.ctx.pair_stats(eng.pair_force_ids(2)[0])
     native = eng._native_comm
@@ -57,11 +60,11 @@ def _simulate(nsteps, pme=False):
     eng.ctx.close()      # deterministic teardown: stream drained, ncclCommDestroy of the library's communicator, context freed -- now
     return dict(x=st.getPositions(asNumpy=True)._value, v=st.getVelocities(asNumpy=True)._value,
                 f=st.getForces(asNumpy=True)._value, e=st.getPotentialEnergy()._value, e0=e0,
-                slice_atoms=stats['n_slice_atoms'], world=world, native_comm=native,
+                slice_atoms=stats['n_slice_atoms'], world=world, native_comm=native, run_stats=run_stats, builds=stats['n_builds'],
                 comm=None if before is None else {k: after[k] - before[k] for k in after})
 
 
-def _worker(rank, world, port, ret, pme=False):
+def _worker(rank, world, port, ret, pme=False, state=1, nsteps=3, chunks=1):
     import faulthandler
     import sys
     faulthandler.dump_traceback_later(100, exit=True, file=sys.stderr)      # a stall names its stack instead of being 'did not finish'
@@ -72,7 +75,7 @@ def _worker(rank, world, port, ret, pme=False):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        ret[rank] = _simulate(3, pme)
+        ret[rank] = _simulate(nsteps, pme, state, chunks)
     finally:
         dist.destroy_process_group()
 
@@ -113,6 +116,41 @@ def test_two_ranks_match_single_rank_bit_for_bit(pme):
             assert np.array_equal(out[r]['f'], single['f'])
         assert out[r]['e0'] == pytest.approx(single['e0'], rel=1e-13)
         assert out[r]['e'] == pytest.approx(single['e'], rel=1e-13)
+
+
+@pytest.mark.parametrize('world,state', [(2, 1), (2, 0), (4, 1)])
+def test_ranks_that_integrate_their_own_molecules_match_single_rank(world, state):
+    """Owner-integrates: with several ranks the launch that walks a molecule's rows also runs its inner RESPA
+    loop (csrc/cluster.hip: cepi_rows on the rank's slice) and the ranks all-gather positions and velocities -- not forces -- which
+    k_state_scatter spreads to the atom-order arrays together with the next evaluation's sorted copies; the redundant inner loop over
+    all atoms, the unsort and the gather are gone.  15 + 15 RESPA steps in two calls (rebuilds on the way, the calls' first and last
+    evaluations take the force exchange) on 2 and 4 ranks sharing the card over gloo: the single rank's positions, velocities and
+    forces bit for bit; option state_exchange = 0 is the force exchange of rounds 2-4, with the same bits."""
+    import torch.multiprocessing as mp
+    single = _simulate(15, chunks=2)
+    assert single['world'] == 1 and single['run_stats']['state_exchanges'] == 0 and single['run_stats']['epilogues'] > 0
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as manager:
+        ret = manager.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, ret, False, state, 15, 2)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(150)
+        stuck = [p for p in procs if p.is_alive()]
+        for p in stuck:          # never leave a rank behind on the GPU box
+            p.kill()
+        assert not stuck, 'a rank did not finish within 150 s'
+        assert all(p.exitcode == 0 for p in procs)
+        out = dict(ret)
+    for r in range(world):
+        assert out[r]['world'] == world and out[r]['builds'] == single['builds'] and single['builds'] >= 2
+        # every evaluation of a call but its last step boundary: 2 x (15 x 2 - 1), one less when the engine runs the first step alone
+        assert out[r]['run_stats']['state_exchanges'] in ((57, 58) if state else (0,)), out[r]['run_stats']
+        assert np.array_equal(out[r]['x'], single['x'])
+        assert np.array_equal(out[r]['v'], single['v'])
+        assert np.array_equal(out[r]['f'], single['f'])
 
 
 def _phase(name):
