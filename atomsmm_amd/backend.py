@@ -194,8 +194,29 @@ def lib():
                 getattr(L, name).restype = C.c_int
         L.amm_last_error.restype = C.c_char_p
         L.amm_kernel_revision.restype = C.c_char_p
-        _LIB = L
+        _LIB = _Serialised(L)
     return _LIB
+
+
+class _Serialised:
+    """The loaded library with ONE caller at a time: ctypes releases the GIL during a call, and the library's host code (launch
+    caches, upload flags) is not written for two threads inside it at once.  Matters only for engine.LocalWorld -- ranks as threads of
+    one process -- and costs a quarter of a microsecond per call otherwise."""
+
+    def __init__(self, library):
+        import threading
+        self._library = library
+        self._lock = threading.RLock()
+
+    def __getattr__(self, name):
+        fn = getattr(self._library, name)          # (AttributeError for a missing symbol, as ctypes raises it)
+        lock = self._lock
+
+        def call(*args):
+            with lock:
+                return fn(*args)
+        self.__dict__[name] = call
+        return call
 
 
 def _chk(rc):

@@ -18,6 +18,7 @@ Design (MI355X-first, not OpenMM's):
 There is no CPU path: creating a Context without the built HIP library or without a GPU raises.
 """
 import os
+import threading
 import math
 import re
 
@@ -152,6 +153,75 @@ def dispersion_correction(sigma, eps, box, rc, rswitch=None):
     return 2 * math.pi * n * n * total / (box[0] * box[1] * box[2])
 
 
+class LocalWorld:
+    """W ranks inside ONE process, one thread each, all on the same GPU and the same stream: the multi-rank code path -- slices, exchange
+    chunks, amm_exchange_finish, the launches that integrate a rank's own molecules -- with the collectives made by device-to-device
+    copies between the ranks' buffers.  For tests at world sizes a one-GPU box cannot host as processes (8 ranks) and for the per-rank
+    budgets of DESIGN.md section 5 (scripts/per_rank_step.py): a rank's kernels are the real ones, the exchange costs nothing.
+
+        world = LocalWorld(8)
+        results = world.run(lambda rank: job(rank))        # job builds its own Context; Engine finds the world it runs in
+    """
+    _tls = threading.local()
+
+    def __init__(self, world):
+        self.world = int(world)
+        self._barrier = threading.Barrier(self.world)
+        self._slots = [None] * self.world
+
+    @classmethod
+    def current(cls):
+        return getattr(cls._tls, 'membership', None)
+
+    def run(self, job):
+        results, errors = [None] * self.world, [None] * self.world
+
+        def body(rank):
+            LocalWorld._tls.membership = (self, rank)
+            try:
+                results[rank] = job(rank)
+            except BaseException as exc:      # noqa: BLE001 -- reported below; the others must not wait for this rank for ever
+                errors[rank] = exc
+                self._barrier.abort()
+            finally:
+                LocalWorld._tls.membership = None
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        first = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)] or [e for e in errors if e is not None]
+        if first:
+            raise first[0]
+        return results
+
+    def all_gather(self, rank, buf, count):
+        """chunk r of every rank's `buf` (count elements each) <- rank r's chunk r."""
+        self._slots[rank] = buf
+        self._barrier.wait()
+        for r in range(self.world):
+            if r != rank:
+                buf[r * count:(r + 1) * count].copy_(self._slots[r][r * count:(r + 1) * count])
+        self._barrier.wait()
+
+    def all_reduce(self, rank, tensor, op='sum'):
+        self._slots[rank] = tensor.clone()
+        self._barrier.wait()
+        total = self._slots[0].clone()
+        for r in range(1, self.world):
+            total = total + self._slots[r] if op == 'sum' else total.maximum(self._slots[r])
+        self._barrier.wait()
+        tensor.copy_(total)
+
+    def broadcast(self, rank, value):
+        if rank == 0:
+            self._slots[0] = value
+        self._barrier.wait()
+        out = self._slots[0]
+        self._barrier.wait()
+        return out
+
+
 class _Entry:
     """One System force translated to backend objects."""
 
@@ -202,7 +272,13 @@ class Engine:
         self.box = np.array([vecs[0][0], vecs[1][1], vecs[2][2]], dtype=np.float64)
         self.rank, self.world = 0, 1
         dist = torch.distributed
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # (ranks as threads of this process: LocalWorld above)
+        self._local = None
+        member = LocalWorld.current()
+        if member is not None and member[0].world > 1:
+            self._local, self.rank = member
+            self.world = self._local.world
+        elif dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             self.rank, self.world = dist.get_rank(), dist.get_world_size()
         # AMM_FORCE_COLLECTIVES=1: a 1-rank job takes the multi-rank code path (collectives over a 1-rank group), to
         # measure its host-side cost on a single GPU
@@ -213,7 +289,7 @@ class Engine:
         self.n = n
         self._native_comm = False
         self._native_ops = {}
-        if self._coll and hasattr(self.ctx, 'comm_init') and dist.get_backend() == 'nccl' \
+        if self._coll and self._local is None and hasattr(self.ctx, 'comm_init') and dist.get_backend() == 'nccl' \
                 and os.environ.get('AMM_NATIVE_COMM', '1') != '0':
             self._init_native_comm(dist)
         dev = self.ctx.torch_device
@@ -999,6 +1075,14 @@ class Engine:
             self.ctx.check()
         except Exception as exc:       # noqa: BLE001 -- re-raised below, on every rank
             err = exc
+        if self._local is not None:
+            flag = self.torch.tensor([1 if err is not None else 0], dtype=self.torch.int32)
+            self._local.all_reduce(self.rank, flag, op='max')
+            if err is not None:
+                raise err
+            if int(flag.item()):
+                raise B.HipError('another rank reported a failed check (neighbour-row overflow or constraint failure)')
+            return
         dist = self.torch.distributed
         flag = self.torch.tensor([1 if err is not None else 0], dtype=self.torch.int32,
                                  device=self.x.device if dist.get_backend() == 'nccl' else 'cpu')
@@ -1012,6 +1096,8 @@ class Engine:
         """A host array every rank must hold bit for bit (e.g. randomly drawn velocities): rank 0's copy wins."""
         if not self._coll:
             return array
+        if self._local is not None:
+            return np.array(self._local.broadcast(self.rank, np.ascontiguousarray(array, dtype=np.float64)))
         dist = self.torch.distributed
         t = self.torch.as_tensor(np.ascontiguousarray(array, dtype=np.float64),
                                  device=self.x.device if dist.get_backend() == 'nccl' else 'cpu')
@@ -1020,7 +1106,9 @@ class Engine:
 
     def _allreduce(self, tensor):
         if self._coll:
-            if self._native_comm:
+            if self._local is not None:
+                self._local.all_reduce(self.rank, tensor)
+            elif self._native_comm:
                 self.ctx.comm_allreduce(tensor)
             else:
                 self.torch.distributed.all_reduce(tensor)
@@ -1790,7 +1878,7 @@ class Engine:
             for seg, (kind, slot) in segments:
                 if seg:
                     self.ctx.run_ops_host_exchanges(seg, 1, self._host_gather)
-                self.torch.distributed.all_reduce(self._buffers[inv[slot]])
+                self._allreduce(self._buffers[inv[slot]])
             if tail:
                 self.ctx.run_ops_host_exchanges(tail, 1, self._host_gather)
 
@@ -1798,6 +1886,10 @@ class Engine:
         """All-gather of the exchange chunks by torch.distributed (no library-owned communicator), then the unsort."""
         dist = self.torch.distributed
         count = nf * self._per * 3
+        if self._local is not None:
+            self._local.all_gather(self.rank, self._xchg, count)
+            self.ctx.exchange_finish()
+            return
         chunks = [self._xchg[r * count:(r + 1) * count] for r in range(self.world)]
         if dist.get_backend() == 'nccl':
             dist.all_gather_into_tensor(self._xchg[:self.world * count], chunks[self.rank].clone())

@@ -153,6 +153,21 @@ def test_ranks_that_integrate_their_own_molecules_match_single_rank(world, state
         assert np.array_equal(out[r]['f'], single['f'])
 
 
+def test_eight_ranks_as_threads_match_single_rank():
+    """World 8 on one card: the ranks are threads of this process (atomsmm_amd.engine.LocalWorld -- the real slices, chunks and launches;
+    the all-gathers are device-to-device copies).  Owner-integrates with the state exchange, 12 + 12 RESPA steps: every rank ends with
+    the single rank's positions, velocities and forces, bit for bit."""
+    from atomsmm_amd.engine import LocalWorld
+    single = _simulate(12, chunks=2)
+    out = LocalWorld(8).run(lambda rank: _simulate(12, chunks=2))
+    for r in range(8):
+        assert out[r]['world'] == 8 and out[r]['run_stats']['state_exchanges'] >= 45
+        assert out[r]['builds'] == single['builds']
+        assert np.array_equal(out[r]['x'], single['x'])
+        assert np.array_equal(out[r]['v'], single['v'])
+        assert np.array_equal(out[r]['f'], single['f'])
+
+
 def _phase(name):
     """One line per phase of a spawned rank on its stderr (the parent shows it when the rank fails or stalls)."""
     import sys
