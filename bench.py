@@ -39,7 +39,7 @@ BYTES_PER_ATOM_DUAL = 96       # dual pass: the same read set, two force arrays 
 FLOP_PER_PAIR_NEAR = 60        # force-switch near, force only
 FLOP_PER_PAIR_FAR = 80         # DampedSmoothedForce (erfc + exp), force only
 FP64_SUSTAINED_TF = 60.7       # measured: v_fma_f64, 8 wavefronts per SIMD, 2.16 ns per wave-instruction per SIMD (DVFS clock)
-TRAFFIC_FILE = 'r04_traffic.json'
+TRAFFIC_FILE = 'r05_traffic.json'
 KB = 0.0083144626181532
 
 
@@ -140,6 +140,7 @@ def bench_c2(args, torch):
     alg = BYTES_PER_ATOM * n
     achieved = alg / max(t_k, 1e-12) / 1e9
     tf = FLOP_PER_PAIR_NEAR * pairs / max(t_k, 1e-12) / 1e12
+    stored = stored_traffic(backend)
     result = {
         # (NOT the headline metric of BASELINE.json -- that is the default run's, config C3; this is its config C2)
         'metric': 'ns/day on the 32k-atom Lennard-Jones fluid of BASELINE config C2 (NearNonbondedForce only); near-nonbonded HBM GB/s vs 8 TB/s peak',
@@ -151,8 +152,11 @@ def bench_c2(args, torch):
                    'atoms': n, 'step_fs': dt_fs, 'relax_steps': relaxed, 'parallelism': 'single GPU',
                    'temperature_K_end': round(temperature(eng, torch), 1)},
         'roofline': {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': None,
-                     'kernel': 'k_pair_tab<NEAR_FSWITCH> (per-atom rows, force only)', 'avg_launch_us': round(t_k * 1e6, 2),
+                     'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': stored.get('c2_near', {}).get('hbm_bytes_per_launch'),
+                     'traffic_raw': (int((stored['c2_near']['fetch_size_kb_avg'] + stored['c2_near']['write_size_kb_avg']) * 1024)
+                                     if 'c2_near' in stored else None),
+                     'kernel': 'k_pair_tab<NEAR_FSWITCH%s> (per-atom rows, force only)' % (', no Coulomb table: all charges zero' if st1.get('chargeless') else ''),
+                     'avg_launch_us': round(t_k * 1e6, 2),
                      'launches': launches, 'algorithmic_bytes_per_launch': alg, 'fp64_tflops': round(tf, 3),
                      'fp64_frac_of_vector_peak': round(tf / FP64_VECTOR_PEAK_TF, 4),
                      'note': 'FP64-VALU / latency bound, not HBM bound (SURVEY.md 8d)'},
@@ -164,6 +168,11 @@ def bench_c2(args, torch):
         # CPU leg: the oracle's OpenMP cell-list traversal of the same force at the final configuration (one evaluation = one step's
         # force work; kicks and moves are negligible next to it), all host threads OpenMP gives it
         try:
+            # (the box shows all of the host's logical CPUs under a cgroup quota: as many OpenMP threads as the quota grants)
+            from oracle import cpu_port
+            quota = cpu_port.cpu_quota()
+            threads = max(1, int(min(os.cpu_count() or 1, quota if quota else (os.cpu_count() or 1))))
+            os.environ['OMP_NUM_THREADS'] = str(threads)
             from oracle import oracle as O
             d = O.desc(O.ADJ['force-switch'], rc=rc, rc0=rc, rs0=rs)
             x = eng.x.cpu().numpy()
@@ -173,12 +182,23 @@ def bench_c2(args, torch):
             for _ in range(reps):
                 O.pair_eval(d, x, case['box'], case['charge'], case['sigma'], case['epsilon'], None, use_cells=True)
             sec = (time.perf_counter() - t0) / reps
-            result['cpu_baseline'] = {'value': round(dt_fs * 1e-6 * 86400.0 / sec, 4), 'unit': 'ns/day', 'cores': os.cpu_count(), 'kind': 'port',
+            result['cpu_baseline'] = {'value': round(dt_fs * 1e-6 * 86400.0 / sec, 4), 'unit': 'ns/day', 'cores': threads, 'kind': 'port',
                                       'sample': '%d force evaluations of the same %d-atom configuration by the oracle (oracle/amm_oracle.c, OpenMP '
                                                 'cell traversal, every pair twice), %.1f ms each' % (reps, n, sec * 1e3)}
         except Exception as exc:
             result['cpu_baseline'] = {'value': None, 'unit': 'ns/day', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
     print(json.dumps(result), flush=True)
+
+
+def stored_traffic(backend):
+    """HBM bytes per launch from the PMC passes of scripts/measure_round.sh (rocprofv3 cannot run inside this process), kept in
+    profiles/ and quoted only while the kernels are the ones they were measured on."""
+    path = os.path.join(ROOT, 'profiles', TRAFFIC_FILE)
+    try:
+        stored = json.load(open(path))
+        return stored if stored.get('kernel_revision') == backend.kernel_revision() else {}
+    except Exception:
+        return {}
 
 
 def run_leg(config, steps, warmup, timeout_s=280):
@@ -559,6 +579,17 @@ def main():
                     traffic = stored
             except Exception:
                 pass
+        if world == 1 and args.config == 'c5':
+            # a hybrid list's evaluation is two launches (molecule rows + per-atom part): their traffic added up
+            stored = stored_traffic(backend)
+            for tag in ('near', 'dual'):
+                a_, b_ = stored.get('c5_' + tag), stored.get('c5_%s_rest' % tag)
+                if a_ and b_:
+                    traffic[tag] = {'hbm_bytes_per_launch': a_['hbm_bytes_per_launch'] + b_['hbm_bytes_per_launch'],
+                                    'fetch_size_kb_avg': a_['fetch_size_kb_avg'] + b_['fetch_size_kb_avg'],
+                                    'write_size_kb_avg': a_['write_size_kb_avg'] + b_['write_size_kb_avg']}
+            if traffic:
+                traffic['kernel_revision'] = stored.get('kernel_revision')
 
         molecule_rows = bool(near_stats.get('list_kind'))
         # molecule rows with a fused kernel for the two families: the near force of the step boundary rides on the outer force's launch

@@ -19,6 +19,10 @@ def main():
     if args and args[0] == '--traffic-json':
         args.pop(0)
         tj = args.pop(0)
+    prefix = ''            # --prefix c2_ : the passes are of another config of bench.py; its tags are ADDED to an existing json
+    if args and args[0] == '--prefix':
+        args.pop(0)
+        prefix = args.pop(0)
     acc = collections.defaultdict(list)
     for d in args:
         for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
@@ -31,10 +35,20 @@ def main():
     print('\n'.join(lines))
     if tj:
         res = {}
+        if prefix:
+            try:
+                res = json.load(open(tj))
+            except Exception:
+                res = {}
         for tag, pats in (('near', ('k_cpair<2, 0, -1', 'k_cpair_tab<2, 0', 'k_pair_tab<2, 0, -1', 'k_pair_nlist<2')),
                           ('outer', ('k_cpair<3, 1, -1', 'k_cpair<4, 1, -1', 'k_cpair_tab<3, 1', 'k_cpair_tab<4, 1')),
                           ('dual', ('k_cpair<3, 1, 2', 'k_cpair<4, 1, 2', 'k_cpair_dual<3, 1, 2', 'k_cpair_dual<4, 1, 2', 'k_pair_tab<3, 1, 2', 'k_pair_nlist<3')),
+                          # (C5: the per-atom part of the hybrid list -- k_pair_tab walks the rows that involve an atom outside the molecules)
+                          ('near_rest', ('k_pair_tab<2, 0, -1',) if prefix == 'c5_' else ()),
+                          ('dual_rest', ('k_pair_tab<3, 1, 2',) if prefix == 'c5_' else ()),
                           ('build', ('k_cbuild<false', 'k_build_nlist<false'))):
+            if prefix == 'c5_' and tag in ('near', 'dual'):       # (the molecule rows only: the per-atom part is listed apart)
+                pats = tuple(q for q in pats if q.startswith('k_cpair'))
             fe = [x for (cn, kn), v in acc.items() if cn == 'FETCH_SIZE' and any(p in kn for p in pats) for x in v]
             wr = [x for (cn, kn), v in acc.items() if cn == 'WRITE_SIZE' and any(p in kn for p in pats) for x in v]
             iv = [x for (cn, kn), v in acc.items() if cn == 'SQ_INSTS_VALU' and any(p in kn for p in pats) for x in v]
@@ -45,11 +59,11 @@ def main():
                 iv = [x for x in iv if x > 1.0e5]
             if fe and wr:
                 f_kb, w_kb = sum(fe) / len(fe), sum(wr) / len(wr)
-                res[tag] = {'kernel': names[0].split('(')[0] if names else None, 'fetch_size_kb_avg': round(f_kb, 1),
+                res[prefix + tag] = {'kernel': names[0].split('(')[0] if names else None, 'fetch_size_kb_avg': round(f_kb, 1),
                             'write_size_kb_avg': round(w_kb, 1), 'launches': len(fe),
                             'hbm_bytes_per_launch': int((2 * f_kb + w_kb) * 1024)}
                 if iv:
-                    res[tag]['valu_insts_per_launch'] = int(sum(iv) / len(iv))
+                    res[prefix + tag]['valu_insts_per_launch'] = int(sum(iv) / len(iv))
         res['note'] = ('rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_INSTS_VALU in separate passes of bench.py; '
                        'hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of MI355X_MICROARCH.md, stated for wide '
                        'streaming reads: these kernels gather 32-byte records, so the truth lies between raw and corrected); '
