@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 FP64_VECTOR_PEAK_TF = 78.6     # public datasheet value; not in the container's guide
 BYTES_PER_ATOM = 72            # fp64: read x,y,z + q,sigma,eps, write Fx,Fy,Fz
 BYTES_PER_ATOM_DUAL = 96       # dual pass: the same read set, two force arrays written
+EPILOGUE_BYTES_PER_ATOM = 200  # inner RESPA loop inside the launch: x, v, f0 read + written (144), mass (8), next sorted copy (48)
 FLOP_PER_PAIR_NEAR = 60        # force-switch near, force only
 FLOP_PER_PAIR_FAR = 80         # DampedSmoothedForce (erfc + exp), force only
 FP64_SUSTAINED_TF = 60.7       # measured: v_fma_f64, 8 wavefronts per SIMD, 2.16 ns per wave-instruction per SIMD (DVFS clock)
@@ -493,6 +494,7 @@ def main():
     # metric names) under the near force's id, the dual pass (outer + near force in one traversal: the dominant kernel)
     # under the outer force's id
     eng.ctx.profile_enable(True)
+    rs0 = eng.ctx.run_stats() if hasattr(eng.ctx, 'run_stats') else {}
     fence()
     t0 = time.perf_counter()
     simulation.step(args.steps)
@@ -599,6 +601,10 @@ def main():
         kname = 'k_cpair' if molecule_rows else 'k_pair_tab'
         outer_name = 'DAMPED' if args.outer == 'damped' else 'NONBONDED/Ewald'
 
+        rs = eng.ctx.run_stats() if hasattr(eng.ctx, 'run_stats') else {}
+        fused_share = (rs.get('epilogues', 0) - rs0.get('epilogues', 0)) / max(n_near + n_dual, 1)
+        epilogues_per_launch = {'near': fused_share, 'dual': fused_share} if fused_share > 0 else {}
+
         def roofline(kernel, seconds, launches, alg_bytes, flops, tag, npairs, listed):
             achieved = alg_bytes / max(seconds, 1e-12) / 1e9
             tf = flops / max(seconds, 1e-12) / 1e12
@@ -610,6 +616,17 @@ def main():
                      'note': 'FP64-VALU / latency bound, not HBM bound (SURVEY.md 8d); fp64 fraction against the %.1f TF datasheet peak '
                              '(a bare v_fma_f64 loop sustains %.1f TF on this chip: scripts/micro/fp64_rate.hip)'
                              % (FP64_VECTOR_PEAK_TF, FP64_SUSTAINED_TF)}
+            if epilogues_per_launch.get(tag):
+                # the launch also ran the inner RESPA loop of its molecules (csrc/cluster.hip: cepi_rows): the kicks, moves and bond-list
+                # evaluations that were launches of their own until round 4.  `frac` keeps SURVEY 8d's bytes of the PAIR evaluation (what
+                # earlier rounds quoted) over the whole launch; with the loop's compulsory traffic -- read + write x, v, f0 (144 B), mass
+                # (8 B), the next evaluation's sorted copy (48 B) per atom -- the launch moves this many algorithmic bytes:
+                with_epi = alg_bytes + EPILOGUE_BYTES_PER_ATOM * atoms_per_launch
+                entry['epilogue'] = {'share_of_launches': round(epilogues_per_launch[tag], 3), 'algorithmic_bytes_per_launch': with_epi,
+                                     'achieved': round(with_epi / max(seconds, 1e-12) / 1e9, 3),
+                                     'frac': round(with_epi / max(seconds, 1e-12) / 1e9 / HBM_PEAK_GBS, 6),
+                                     'note': 'inner RESPA loop of the rows\' molecules (4 x {kick, move, bonds + angle, kick} + the '
+                                             'preceding kicks) inside this launch: ~12 us of its duration'}
             if entry['traffic'] is not None:
                 t_ = traffic.get(tag, {})
                 # FETCH_SIZE halves WIDE streaming reads on gfx950 (MI355X_MICROARCH.md); this kernel's reads are 32-byte gathers,
@@ -638,7 +655,7 @@ def main():
                        % (n, case['box'][0], 'DampedSmoothedForce(2.9/nm, 1.0, 0.9)' if args.outer == 'damped'
                           else 'PME NonbondedForce (rc 1.0, switch 0.9, tol 5e-4: direct + reciprocal space)'),
                        'atoms': n, 'loops': list(loops), 'outer_step_fs': dt_fs, 'relax_steps': relaxed,
-                       'parallelism': ('atom decomposition x%d, %s' % (world, 'all-gather of owner-computed force slices (RCCL, library-owned communicator)'
+                       'parallelism': ('atom decomposition x%d, %s' % (world, 'owner-integrates: all-gather of positions + velocities of the molecules a rank walked (force slices at the first and last evaluation of a call); RCCL, library-owned communicator'
                                                                      if getattr(eng, '_native_comm', False) else 'collectives through torch.distributed')) if world > 1 else 'single GPU',
                        'temperature_K_end': round(T_end, 1)},
             # the kernel the metric names: the near-force traversal (group 1, force only).  Molecule rows: the same kernel serves the
@@ -666,7 +683,8 @@ def main():
                                 2: 'hybrid: one per three-site molecule for the pairs of two molecules + per-atom rows for every pair with one of the '
                                    '%d other atoms (kernel times: both launches of an evaluation)' % near_stats.get('n_rest_atoms', 0),
                                 3: 'none'}.get(near_stats.get('list_kind'), '?'),
-                       'row_padding': padding or None, 'pme_outer': pme_outer},
+                       'row_padding': padding or None, 'pme_outer': pme_outer,
+                       'run_stats': {k: rs.get(k, 0) - rs0.get(k, 0) for k in rs} or None},
         }
         if world == 1 and not args.no_cpu_baseline and args.outer == 'damped':
             result['cpu_baseline'] = cpu_baseline_in_child(args.nside, eng.x.cpu().numpy(), eng.v.cpu().numpy())
