@@ -1125,6 +1125,53 @@ int amm_run_ops_from(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t rep
         q_resume = q;
         return true;
     };
+    // ... and for per-atom rows (pair.hip: AtomEpiArgs): `[KICK ...] [; MOVE]` behind the EVAL of a group that is one pair force -- a
+    // velocity-Verlet step's closing half kick and, across the end of the repetition, the opening half kick + move of the next
+    auto plan_atoms = [&](int after, int rep, EpiPlan &P, int &q_resume, bool &wraps) -> bool {
+        if (!ctx->fuse_inner || !ctx->opt_fuse_epilogue || ctx->iso.on || ctx->world != 1 || swapped || f0_slot >= 0) return false;
+        std::vector<amm_op> kicks;
+        int j = after;
+        wraps = false;
+        while (true) {
+            while (j < n_ops && ops[j].op == AMM_OP_KICK && (int)kicks.size() < 4) kicks.push_back(ops[j++]);
+            if (j == n_ops && !wraps && rep + 1 < repeat && !no_defer && !kicks.empty() && ops[0].op == AMM_OP_KICK) {
+                wraps = true;
+                j = 0;
+                continue;
+            }
+            break;
+        }
+        if (kicks.empty() || (j < n_ops && ops[j].op == AMM_OP_KICK)) return false;        // (a fifth kick: left to the plain path)
+        const bool moves = j < n_ops && ops[j].op == AMM_OP_MOVE;
+        if (!moves && !wraps && j == n_ops) return false;                                  // (closing kicks of the call's last step: as before)
+        P = EpiPlan();
+        P.kind = 1;
+        P.npre = (int)kicks.size();
+        for (int p = 0; p < P.npre; ++p) {
+            P.pre_a[p] = slot_of(kicks[p].a);
+            P.pre_b[p] = kicks[p].b >= 0 ? slot_of(kicks[p].b) : nullptr;
+            if (!P.pre_a[p] || (kicks[p].b >= 0 && !P.pre_b[p])) return false;
+            P.pre_coef[p] = kicks[p].coef;
+            P.pre_plus[p] = kicks[p].c;
+        }
+        P.with_move = moves ? 1 : 0;
+        P.dcoef = moves ? ops[j].coef : 0.0;
+        q_resume = moves ? j + 1 : j;
+        // the next pair evaluation's force: the next EVAL in program order
+        P.next = nullptr;
+        for (int t = q_resume, seen = 0; seen < n_ops; ++seen, ++t) {
+            if (t >= n_ops) {
+                if (rep + (wraps ? 2 : 1) >= repeat) break;
+                t = 0;
+            }
+            if (ops[t].op != AMM_OP_EVAL) continue;
+            const int ga = ops[t].a;
+            if (ga >= 0 && ga < AMM_MAX_GROUPS && ctx->groups[ga].forces.size() == 1 && ctx->forces[ctx->groups[ga].forces[0]].type == 1)
+                P.next = ctx->forces[ctx->groups[ga].forces[0]].pair;
+            break;
+        }
+        return q_resume < n_ops || !wraps;        // (a wrapped plan that swallowed the whole next repetition: not a step program)
+    };
     // leave to the host what only it can do: an exchange pending without a communicator of the library's own.  0: go on, 1: error,
     // 2: *cursor is set -- wind up and return
     auto leave_to_host = [&](long next_pos) -> int {
@@ -1487,7 +1534,9 @@ int amm_run_ops_from(amm_ctx *ctx, const amm_op *ops, int32_t n_ops, int32_t rep
                     EpiPlan plan;
                     int q_resume = 0;
                     bool wraps = false;
-                    if (plan_epilogue(k + 1, rep, plan, q_resume, wraps)) {
+                    if (plan_epilogue(k + 1, rep, plan, q_resume, wraps) ||
+                        (ctx->forces[g.forces[0]].pair->all_q_zero && !ctx->forces[g.forces[0]].pair->cluster_ok &&
+                         plan_atoms(k + 1, rep, plan, q_resume, wraps))) {
                         ctx->epi_request = &plan;
                         ctx->epi_done = false;
                         const int rc_one = amm_pair_eval_impl(ctx, ctx->forces[g.forces[0]].pair, ctx->d_x, buf, 0, nullptr, nullptr, nullptr, 0, g.exchange);

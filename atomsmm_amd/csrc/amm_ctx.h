@@ -112,6 +112,10 @@ struct PairForce {
     int *d_perm = nullptr, *d_inv_perm = nullptr;
     double4 *d_posq_s = nullptr;   // sorted: wrapped x,y,z and charge
     double2 *d_lj_s = nullptr;     // sorted: sigma/2, 2*sqrt(eps)
+    // per-atom rows: sorted copies written ahead of time by the launch that moved the atoms (pair.hip: the kernel's epilogue)
+    PairForce *a_sorted_for = nullptr;
+    long a_sorted_epoch = -1;
+    const double *a_sorted_pos = nullptr;
     double4 *d_posq_alt = nullptr; // molecule rows: second copy of d_posq_s, for an epilogue that writes the sorted positions of the NEXT evaluation of this same force
     float4 *d_pos4f_s = nullptr;   // sorted fp32 positions at the last list build
     double *d_xref = nullptr;      // positions at the last prune (original order)
@@ -305,6 +309,11 @@ struct EpiPlan {
     int pre_plus[AMM_MAX_PRE] = {0};
     double c1 = 0, d = 0, c2 = 0;
     PairForce *next = nullptr;         // the force whose sorted copies the next pair evaluation reads (nullptr: not known)
+    // kind 1: per-atom rows (pair.hip, AtomEpiArgs) -- the ops behind the EVAL are plain kicks and, maybe, a move (velocity Verlet):
+    // the kicks are pre_*[0 .. npre), niter = 0
+    int kind = 0;
+    int with_move = 0;
+    double dcoef = 0;
 };
 
 struct amm_ctx {

@@ -66,6 +66,9 @@ __device__ __forceinline__ double amm_div_mass(double num, double m, double r, b
     const double q = num * r;
     const double e = fma(-q, m, num);
     const double fast = fma(e, r, q);
+    // (the IEEE division only when some lane of the wavefront needs it: as a select both were computed -- 3 x ~30 instructions per
+    // kick in a loop that is a chain of dependent latencies; the branch is wave-uniform, the result the same)
+    if (__builtin_amdgcn_ballot_w64(!exact_r) == 0ull) return fast;
     return exact_r ? fast : num / m;
 }
 

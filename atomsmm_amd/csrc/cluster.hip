@@ -866,6 +866,8 @@ struct CEpiArgs {
 #ifndef CEPI_INLINE
 #define CEPI_INLINE __forceinline__
 #endif
+
+struct CEpiArgs;
 // value of lane (quad base + Q) of the caller's quad, for all four lanes of the quad: a DPP move (VALU rate, no LDS round trip -- the
 // ds_bpermute form of the epilogue spent a dozen serialized LDS latencies per inner iteration on its shuffles)
 template <int Q>
@@ -883,6 +885,55 @@ struct PosTermRegs {
     double p[3][3];
     __device__ __forceinline__ double get(int r, int k) const { return p[r][k]; }
 };
+
+// the part of the epilogue that depends on the final positions alone (all lanes call: the quad broadcast of the first atom)
+__device__ __forceinline__ void cepi_positions_final(const CEpiArgs &E, const Box &box, int cs, int a, int l, int mol, bool has, const double (&x)[3],
+                                                     double q_nx, double hs_nx, double se_nx) {
+    double x0[3];          // the molecule's first atom decides the image of the sorted copy
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x0[k] = cquad_bcast<0>(x[k]);
+    if (!has) return;
+    if (l == 0 && E.spec_count) {
+        // the molecule's cell at its new position, as k_cassign would find it (same wrap, same clamps)
+        int cidx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double w = cwrap1(x[k], box.L[k], box.invL[k]);
+            const int ck = (w == w) ? (int)(w * E.grid.inv_cw[k]) : 0;
+            cidx[k] = ck >= E.grid.nc[k] ? E.grid.nc[k] - 1 : (ck < 0 ? 0 : ck);
+        }
+        const int cell = (cidx[2] * E.grid.nc[1] + cidx[1]) * E.grid.nc[0] + cidx[0];
+        const int rank = atomicAdd(&E.spec_count[cell], 1);
+        if (rank < E.spec_capc) E.spec_members[(size_t)cell * E.spec_capc + rank] = mol;
+        else E.spec_flags[7] = 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) E.x[3 * a + j] = x[j];
+    if (E.xchg_x) {
+        const size_t sl = 3 * (size_t)(cs - E.c_first) + l;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) E.xchg_x[3 * sl + j] = x[j];
+    }
+    // the lists' displacement triggers (amm_watch_atom), the flags stored past this XCD's L2: the kernel's last block -- on another
+    // XCD, perhaps -- decides on them whether the cells' counts become a cell table
+    for (int q = 0; q < E.W.n; ++q) {
+        const double dx = x[0] - E.W.xref[q][3 * a], dy = x[1] - E.W.xref[q][3 * a + 1], dz = x[2] - E.W.xref[q][3 * a + 2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        if (!(d2 <= E.W.thr2[q])) {
+            amm_st_l2(&E.W.flags[q][0], 1);
+            if (!(d2 <= 4.0 * E.W.thr2[q])) amm_st_l2(&E.W.flags[q][AMM_FLAG_FAR], 1);
+        }
+    }
+    if (E.posq_next) {
+        double4 pq;
+        pq.x = csorted_image(x[0], x0[0], cwrap1(x0[0], box.L[0], box.invL[0]) - x0[0], box.L[0], box.invL[0]);
+        pq.y = csorted_image(x[1], x0[1], cwrap1(x0[1], box.L[1], box.invL[1]) - x0[1], box.L[1], box.invL[1]);
+        pq.z = csorted_image(x[2], x0[2], cwrap1(x0[2], box.L[2], box.invL[2]) - x0[2], box.L[2], box.invL[2]);
+        pq.w = q_nx;
+        E.posq_next[3 * cs + l] = pq;
+        if (E.lj_next) E.lj_next[3 * cs + l] = make_double2(hs_nx, se_nx);
+    }
+}
 
 // NOT inlined, and called when the wavefront has walked ALL of its rows (a second loop over its tasks): inlined behind a task's
 // walk, its arguments and temporaries entered the register allocation of the pair loop (the near kernel went from no scratch to 63
@@ -916,8 +967,21 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
         my_tq = E.term_q[4 * mol + l];
     }
     if (has) my_recs = E.atom_recs[a];
+    // what the END of the loop needs from memory is fetched now: the records of the next sorted copy (charge; sigma/2, 2 sqrt(eps))
+    double q_nx = 0.0, hs_nx = 0.0, se_nx = 0.0;
+    if (has && E.posq_next && E.niter > 0) {
+        q_nx = E.q_next[a];
+        if (E.lj_next) {
+            hs_nx = E.hsig_next[a];
+            se_nx = E.seps2_next[a];
+        }
+    }
     const double rm = 1.0 / m;
     const bool rok = (__double_as_longlong(m) & 0xFFFFFFFFFFFFFll) != 0xFFFFFFFFFFFFFll && m > 1e-200 && m < 1e200;
+    // the forces this launch stored (by the first lane of each row) are read back by the molecule's lanes from here on: the stores
+    // have left the wavefront before these loads are issued, one L1 serves both.  (Behind the loads above, which do not wait for them.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     {
 #pragma clang fp contract(off)
         for (int p = 0; p < E.npre; ++p) {
@@ -955,6 +1019,10 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
                 x[j] = x[j] + dx;
             }
         }
+        // the positions are final after the last move: everything that depends on them alone -- the stores, the molecule's cell, the
+        // triggers, the next sorted copy -- is issued here, behind the last evaluation of the terms and the last kick (an atomic with
+        // a return value and a dozen stores: their latency was the tail of the kernel)
+        if (it == E.niter - 1) cepi_positions_final(E, box, cs, a, l, mol, has, x, q_nx, hs_nx, se_nx);
         // the three atoms' new positions on all four lanes of the quad (DPP broadcasts), each term picks its own
         PosTermRegs pos;
 #pragma unroll
@@ -1004,14 +1072,10 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
             }
         }
     }
-    // the molecule's first atom decides the image of the sorted copy
-    double x0[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) x0[k] = cquad_bcast<0>(x[k]);
     if (has) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            E.x[3 * a + j] = x[j];
+            if (E.niter == 0) E.x[3 * a + j] = x[j];
             E.v[3 * a + j] = v[j];
             E.f0[3 * a + j] = f[j];
         }
@@ -1019,43 +1083,8 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
             const size_t sl = 3 * (size_t)(cs - E.c_first) + l;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                E.xchg_x[3 * sl + j] = x[j];
+                if (E.niter == 0) E.xchg_x[3 * sl + j] = x[j];
                 E.xchg_v[3 * sl + j] = v[j];
-            }
-        }
-        if (E.niter > 0) {
-            if (l == 0 && E.spec_count) {
-                // the molecule's cell at its new position, as k_cassign would find it (same wrap, same clamps)
-                int cidx[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double w = cwrap1(x[k], box.L[k], box.invL[k]);
-                    const int ck = (w == w) ? (int)(w * E.grid.inv_cw[k]) : 0;
-                    cidx[k] = ck >= E.grid.nc[k] ? E.grid.nc[k] - 1 : (ck < 0 ? 0 : ck);
-                }
-                const int cell = (cidx[2] * E.grid.nc[1] + cidx[1]) * E.grid.nc[0] + cidx[0];
-                const int rank = atomicAdd(&E.spec_count[cell], 1);
-                if (rank < E.spec_capc) E.spec_members[(size_t)cell * E.spec_capc + rank] = mol;
-                else E.spec_flags[7] = 1;
-            }
-            // the lists' displacement triggers (amm_watch_atom), the flags stored past this XCD's L2: the kernel's last block -- on
-            // another XCD, perhaps -- decides on them whether the cells' counts become a cell table
-            for (int q = 0; q < E.W.n; ++q) {
-                const double dx = x[0] - E.W.xref[q][3 * a], dy = x[1] - E.W.xref[q][3 * a + 1], dz = x[2] - E.W.xref[q][3 * a + 2];
-                const double d2 = dx * dx + dy * dy + dz * dz;
-                if (!(d2 <= E.W.thr2[q])) {
-                    amm_st_l2(&E.W.flags[q][0], 1);
-                    if (!(d2 <= 4.0 * E.W.thr2[q])) amm_st_l2(&E.W.flags[q][AMM_FLAG_FAR], 1);
-                }
-            }
-            if (E.posq_next) {
-                double4 pq;
-                pq.x = csorted_image(x[0], x0[0], cwrap1(x0[0], box.L[0], box.invL[0]) - x0[0], box.L[0], box.invL[0]);
-                pq.y = csorted_image(x[1], x0[1], cwrap1(x0[1], box.L[1], box.invL[1]) - x0[1], box.L[1], box.invL[1]);
-                pq.z = csorted_image(x[2], x0[2], cwrap1(x0[2], box.L[2], box.invL[2]) - x0[2], box.L[2], box.invL[2]);
-                pq.w = E.q_next[a];
-                E.posq_next[3 * cs + l] = pq;
-                if (E.lj_next) E.lj_next[3 * cs + l] = make_double2(E.hsig_next[a], E.seps2_next[a]);
             }
         }
     }
@@ -1258,8 +1287,7 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g, CEpiArgs E) {
         // the inner RESPA loop of the molecules whose rows this wavefront has just summed (cepi_rows): the same tasks again.  The
         // forces were stored by the first lane of each row; the molecule's lanes read them back (wavefront-scope ordering: the
         // stores have left the wavefront before the loads are issued; one L1 serves both)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // (the ordering fence sits inside cepi_rows, behind the loads that do not depend on this launch's forces)
         for (int phase = 0; phase < A.nphase; ++phase) {
             const int shift = A.ph_shift[phase], row0 = xcd * A.rpx + A.ph_off[phase], ntask = A.ph_ntask[phase];
             const int rpw = 64 >> shift;
@@ -1773,7 +1801,7 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
     // rank holds alike (the plan, the families, the sizes): all ranks take the same path.
     auto ss_bytes_of = [](const PairForce *p) { return (p->d_tab_ss && p->pc.tab.ss_first >= 0) ? (p->pc.tab.nint - p->pc.tab.ss_first) * AMM_TAB_STRIDE : 0; };
     auto plan_fits = [&]() {
-        if (!(plan && ctx->opt_fuse_epilogue && !accumulate && !cl->d_first && cl->nrest == 0 && plan->bs && plan->bs->mol3_ok &&
+        if (!(plan && plan->kind == 0 && ctx->opt_fuse_epilogue && !accumulate && !cl->d_first && cl->nrest == 0 && plan->bs && plan->bs->mol3_ok &&
               plan->bs->finalized && plan->bs->ncomp == cl->nc && plan->f0 && plan->npre <= AMM_MAX_PRE && ctx->d_x == d_pos && ctx->d_v &&
               plan->f0 != d_force && plan->f0 != g_force)) return false;
         if (guest && !(!g_accumulate && g_force != d_force && ctx->opt_fuse_rows && pf == L && cl->rnear_build > 0)) return false;

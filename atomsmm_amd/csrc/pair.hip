@@ -18,6 +18,7 @@
 #include <cstring>
 
 #include "amm_ctx.h"
+#include "bonded_terms.h"
 #include "cluster.h"
 #include "device_utils.h"
 #include "pair_math.h"
@@ -139,10 +140,11 @@ __global__ void __launch_bounds__(256) k_cell_sort_gather(int ncell, int n, cons
                                                           const double *__restrict__ seps2, double4 *posq_s, double2 *lj_s,
                                                           const int *__restrict__ cls, const int *__restrict__ start_lj,
                                                           int *row_order, int s_begin, int s_end, int *n_lj_out, const float *__restrict__ member,
-                                                          int *cell_sets, int filter_mode) {
+                                                          int *cell_sets, int filter_mode, int copies_current) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (!force && !flags[which]) {
-        if (posq_s && gid < n) {
+        // (copies_current: the launch that moved the atoms wrote the copies of these positions already -- k_pair_tab's epilogue)
+        if (!copies_current && posq_s && gid < n) {
             const int i = perm[gid];
             double4 p;
             p.x = wrap1(pos[3 * i], box.L[0], box.invL[0]);
@@ -1158,14 +1160,30 @@ __device__ __forceinline__ void amm_walk_row_tab(const PairArgs &A, const PairCo
     }
 }
 
+// Epilogue of the per-atom-row kernel (AEPI; the chargeless instantiations: config C2): the lane that has just stored the force on a
+// row's atom applies the kicks and the move that follow the EVAL in the step program -- velocity Verlet: the closing half kick of
+// this step and the opening half kick + move of the next (propagators.py:1136-1153 unrolled; k_kicks_move_atoms' arithmetic, per
+// degree of freedom, FP contraction off: bit-identical) -- evaluates the lists' displacement triggers for the new position and
+// writes the atom's record of the NEXT evaluation's sorted copy (a second buffer: other wavefronts still read this one).  A
+// second loop over the wavefront's tasks, as cluster.hip's: nothing of the pair loop is live in it.
+struct AtomEpiArgs {
+    double *x, *v;
+    const double *mass, *q;
+    KickList K;
+    int with_move;
+    double dcoef;
+    WatchArgs W;
+    double4 *posq_next;
+};
+
 #ifndef AMM_TAB_WAVES_PER_EU
 #define AMM_TAB_WAVES_PER_EU 1
 #endif
 // PH: the two-phase walk of a hybrid list's rest part (long rows, then short ones).  A compile-time switch: as a run-time one it cost
 // the common kernels two registers -- 130 instead of 128, three wavefronts per SIMD instead of four (C2: 21 -> 27 us).
-template <int FAM, int CMODE, int GFAM, int BS, bool PH = false, bool NOQ = false>
+template <int FAM, int CMODE, int GFAM, int BS, bool PH = false, bool NOQ = false, bool AEPI = false>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(AMM_TAB_WAVES_PER_EU)))
-k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
+k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T, AtomEpiArgs E) {
     extern __shared__ __align__(16) char s_lds[];
     // stage the table(s): 16-byte pieces, coalesced
     for (int o = threadIdx.x * 16; o < T.host_bytes; o += BS * 16)
@@ -1236,6 +1254,16 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
                 sites_front = sites & 0xffff;
                 sites_back = (int)((unsigned)sites >> 16);
                 ntot = T.nnb_all[ra];
+            }
+        }
+        double ev[3] = {0.0, 0.0, 0.0}, ex[3] = {0.0, 0.0, 0.0}, em = 1.0;       // AEPI: the row atom's state, fetched ahead of the walk
+        if (AEPI && !PH && GFAM < 0 && valid && sub == 0) {
+            const int ia = A.perm[s];
+            em = E.mass[ia];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                ev[d] = E.v[3 * ia + d];
+                ex[d] = E.x[3 * ia + d];
             }
         }
         const bool edge = valid && !(pi.x >= T.margin && pi.x <= A.box.L[0] - T.margin && pi.y >= T.margin && pi.y <= A.box.L[1] - T.margin &&
@@ -1331,6 +1359,45 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
                 A.force[3 * i + 1] = fy;
                 A.force[3 * i + 2] = fz;
             }
+            if (AEPI && !PH && GFAM < 0) {
+                // the kicks (+ move) that follow the EVAL, for this row's atom: its velocity, position and mass were fetched before
+                // the walk (a dependent load chain behind the walk cost more than the launch it replaced: 29.7 against 19.9 + 4.6 us)
+                const double fnow[3] = {fx, fy, fz};
+                double xn[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+#pragma clang fp contract(off)
+                    const int t = 3 * i + d;
+                    double vt = ev[d];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (k < E.K.n) {
+                            // (a kick with THIS launch's force takes it from the register; other buffers are read)
+                            double ff = E.K.f[k] == A.force ? fnow[d] : E.K.f[k][t];
+                            if (E.K.f2[k]) {
+                                const double f2 = E.K.f2[k] == A.force ? fnow[d] : E.K.f2[k][t];
+                                ff = E.K.plus[k] ? ff + f2 : ff - f2;
+                            }
+                            const double num = E.K.coef[k] * ff;
+                            const double dv = num / em;
+                            vt = vt + dv;
+                        }
+                    }
+                    E.v[t] = vt;
+                    xn[d] = ex[d];
+                    if (E.with_move) {
+                        const double dx = E.dcoef * vt;
+                        xn[d] = xn[d] + dx;
+                        E.x[t] = xn[d];
+                    }
+                }
+                if (E.with_move) {
+                    amm_watch_atom(E.W, i, xn);
+                    if (E.posq_next)
+                        E.posq_next[s] = make_double4(wrap1(xn[0], A.box.L[0], A.box.invL[0]), wrap1(xn[1], A.box.L[1], A.box.invL[1]),
+                                                      wrap1(xn[2], A.box.L[2], A.box.invL[2]), E.q[i]);
+                }
+            }
         }
     }
     }
@@ -1338,8 +1405,9 @@ k_pair_tab(PairArgs A, PairConsts c, PairConsts gc, TabArgs T) {
 
 
 // one instantiation: dynamic LDS attribute + blocks per CU (cached), persistent grid (a multiple of 8 blocks)
-template <int FAM, int CMODE, int GFAM, int BS, bool PH = false, bool NOQ = false>
-static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts &c, const PairConsts &gc, TabArgs &T) {
+template <int FAM, int CMODE, int GFAM, int BS, bool PH = false, bool NOQ = false, bool AEPI = false>
+static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts &c, const PairConsts &gc, TabArgs &T,
+                             const AtomEpiArgs &E = AtomEpiArgs()) {
     // (the LDS attribute and the occupancy answer belong to a device: one slot per device, like the erfcx upload flags)
     static int bpc_dev[64], lds_set_dev[64], cu_dev[64];
     static bool init_dev[64];
@@ -1359,7 +1427,7 @@ static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts
         amm_set_error("tabulated pair kernel: the radial tables of the two forces do not fit LDS together");
         return 1;
     }
-    auto kern = k_pair_tab<FAM, CMODE, GFAM, BS, PH, NOQ>;
+    auto kern = k_pair_tab<FAM, CMODE, GFAM, BS, PH, NOQ, AEPI>;
     if (lds > lds_set) {
         AMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         lds_set = lds;
@@ -1377,7 +1445,7 @@ static int launch_pair_tab_i(hipStream_t st, const PairArgs &A, const PairConsts
     constexpr int WPB = BS / 64;
     long nblk = std::min((long)g_num_cu * bpc, ((long)T.ntask + WPB - 1) / WPB);
     nblk = std::max(8L, (nblk + 7) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, st, A, c, gc, T);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BS), (size_t)lds, st, A, c, gc, T, E);
     return 0;
 }
 
@@ -1465,7 +1533,7 @@ static int setup_grid(amm_ctx *ctx, PairForce *pf) {
 // cell list -> candidate sweep.  direct = false: OUTER list (radius rc + skin_out, conditional on flags[4]);
 // direct = true (single-list mode, skin_out <= skin): straight into the traversed inner list (flags[0]).
 static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, int force, bool count_only, bool direct,
-                            PairForce *gather_for = nullptr) {
+                            PairForce *gather_for = nullptr, int copies_current = 0) {
     hipStream_t st = ctx->stream;
     const int n = pf->n;
     const int nb = (n + 255) / 256;
@@ -1482,7 +1550,7 @@ static int cell_build_chain(amm_ctx *ctx, PairForce *pf, const double *d_pos, in
                        pf->d_inv_perm, pf->d_flags, which, force, gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr,
                        gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr, gf ? gf->d_lj_s : (double2 *)nullptr,
                        pf->d_cls, pf->d_cell_start_lj, pf->d_row_order, pf->s_begin, pf->s_end, pf->d_flags + 3, pf->d_member,
-                       pf->d_cell_sets, pf->hybrid_rest ? 2 : 1);
+                       pf->d_cell_sets, pf->hybrid_rest ? 2 : 1, copies_current);
     const long threads = (long)pf->grid.ncell * pf->parts * 64;   // one wavefront per (cell, part)
     dim3 grid((unsigned)((threads + 255) / 256));
     BoxF bf;
@@ -1757,6 +1825,13 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
         }
         L->last_kind = 0;
     }
+    // the plan of an epilogue that amm_run_ops attached to this evaluation (kind 1: kicks + move of the rows' atoms); consumed here
+    const EpiPlan *aplan = ctx->epi_request;
+    ctx->epi_request = nullptr;
+    ctx->epi_done = false;
+    // the launch that moved the atoms to these positions wrote this force's sorted copies already?
+    const int copies_current = (L->a_sorted_for == pf && L->a_sorted_epoch == ctx->pos_epoch && L->a_sorted_pos == d_pos && !L->dual) ? 1 : 0;
+    if (copies_current) ctx->n_copies_current++;
     bool gathered = false;
     if (!L->built) {
         if (first_build(ctx, L, d_pos)) return 1;
@@ -1774,13 +1849,13 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             if (cell_build_chain(ctx, L, d_pos, forced, false, false)) return 1;
             if (prune_chain(ctx, L, d_pos, forced, false)) return 1;
         } else {
-            if (cell_build_chain(ctx, L, d_pos, forced, false, true, pf)) return 1;
+            if (cell_build_chain(ctx, L, d_pos, forced, false, true, pf, copies_current)) return 1;
             gathered = true;
         }
     }
     L->checked_epoch = ctx->pos_epoch;
     L->checked_pos = d_pos;
-    if (!gathered)
+    if (!gathered && !copies_current)
         hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, n, L->d_perm, d_pos, pf->d_q, pf->d_hsig,
                            pf->d_seps2, ctx->box, pf->d_posq_s, pf->d_lj_s);
     pf->s_begin = L->s_begin;
@@ -1909,10 +1984,57 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             const bool noq = pf->all_q_zero && !guest && !A.active && tab_block_size(false) == 512 && ctx->opt_chargeless &&
                              pf->desc.family >= AMM_NEAR_NONE && pf->desc.family <= AMM_NEAR_FSWITCH;
             pf->last_chargeless = noq ? 1 : 0;
+            // ... and the kicks (+ move) that follow the EVAL in the step program as the launch's epilogue (AtomEpiArgs), one rank
+            bool aepi = false;
+            AtomEpiArgs AE;
+            if (noq && aplan && aplan->kind == 1 && ctx->opt_fuse_epilogue && ctx->world == 1 && !exchange && !accumulate && pf == L &&
+                !L->dual && aplan->npre >= 1 && aplan->npre <= 4 && ctx->d_x == d_pos && ctx->d_v) {
+                AE.x = ctx->d_x;
+                AE.v = ctx->d_v;
+                AE.mass = ctx->d_mass;
+                AE.q = pf->d_q;
+                AE.K.n = aplan->npre;
+                aepi = true;
+                for (int k = 0; k < 4; ++k) {
+                    AE.K.f[k] = k < aplan->npre ? aplan->pre_a[k] : nullptr;
+                    AE.K.f2[k] = k < aplan->npre ? aplan->pre_b[k] : nullptr;
+                    AE.K.plus[k] = k < aplan->npre ? aplan->pre_plus[k] : 0;
+                    AE.K.coef[k] = k < aplan->npre ? aplan->pre_coef[k] : 0.0;
+                    if (k < aplan->npre && !AE.K.f[k]) aepi = false;
+                }
+                AE.with_move = aplan->with_move;
+                AE.dcoef = aplan->dcoef;
+                amm_collect_watches(ctx, AE.W);
+                AE.posq_next = nullptr;
+                if (aplan->with_move && aplan->next == pf) {
+                    // (the next evaluation is this force's again: its positions go to the second copy, swapped in below; the
+                    // parameter records stay -- the order of the rows does not change without a rebuild)
+                    if (!pf->d_posq_alt) AMM_HIP(hipMalloc(&pf->d_posq_alt, sizeof(double4) * (size_t)n));
+                    AE.posq_next = pf->d_posq_alt;
+                }
+            }
             if (noq) {
                 T.host_bytes = 0;           // (nothing staged, no erfcx table needed: the analytic erfc families are not these)
                 T.need_erfcx = 0;
-                if (pf->desc.family == AMM_NEAR_NONE) rc_ = launch_pair_tab_i<AMM_NEAR_NONE, 0, -1, 512, false, true>(st, A, pf->pc, gpc, T);
+                if (aepi) {
+                    if (pf->desc.family == AMM_NEAR_NONE) rc_ = launch_pair_tab_i<AMM_NEAR_NONE, 0, -1, 512, false, true, true>(st, A, pf->pc, gpc, T, AE);
+                    else if (pf->desc.family == AMM_NEAR_SHIFT) rc_ = launch_pair_tab_i<AMM_NEAR_SHIFT, 0, -1, 512, false, true, true>(st, A, pf->pc, gpc, T, AE);
+                    else rc_ = launch_pair_tab_i<AMM_NEAR_FSWITCH, 0, -1, 512, false, true, true>(st, A, pf->pc, gpc, T, AE);
+                    if (!rc_) {
+                        ctx->epi_done = true;
+                        ctx->n_epilogues++;
+                        if (aplan->with_move) {
+                            ctx->pos_epoch++;
+                            amm_watch_moved(ctx);
+                            if (AE.posq_next) {
+                                std::swap(pf->d_posq_s, pf->d_posq_alt);
+                                L->a_sorted_for = pf;
+                                L->a_sorted_epoch = ctx->pos_epoch;
+                                L->a_sorted_pos = ctx->d_x;
+                            }
+                        }
+                    }
+                } else if (pf->desc.family == AMM_NEAR_NONE) rc_ = launch_pair_tab_i<AMM_NEAR_NONE, 0, -1, 512, false, true>(st, A, pf->pc, gpc, T);
                 else if (pf->desc.family == AMM_NEAR_SHIFT) rc_ = launch_pair_tab_i<AMM_NEAR_SHIFT, 0, -1, 512, false, true>(st, A, pf->pc, gpc, T);
                 else rc_ = launch_pair_tab_i<AMM_NEAR_FSWITCH, 0, -1, 512, false, true>(st, A, pf->pc, gpc, T);
             } else
@@ -2095,9 +2217,9 @@ int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos,
 extern "C" __attribute__((weak)) const char *amm_variant_tag(void);
 const char *amm_kernel_revision_impl() {
 #ifdef AMM_CLUSTER_TUNE
-    return "r05-epi2-tune";
+    return "r05-epi3-tune";
 #else
-    return amm_variant_tag ? "r05-epi2-tune" : "r05-epi2";
+    return amm_variant_tag ? "r05-epi3-tune" : "r05-epi3";
 #endif
 }
 

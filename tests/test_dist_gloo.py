@@ -310,3 +310,65 @@ def test_slices_are_whole_molecules_and_cover_every_atom():
             assert per % 3 == 0 and world * per >= n
             assert (world - 1) * per < n + 3 * world            # no more than a molecule of slack per rank
             assert per == 3 * -(-(-(-n // 3)) // world)
+
+
+def test_local_world_runs_ranks_as_threads():
+    """engine.LocalWorld: W ranks as threads of one process (what the 8-rank GPU test and scripts/per_rank_step.py run on) -- the
+    collectives' semantics on host tensors, an engine that finds the world it runs in, and a rank that raises does not leave the others
+    waiting."""
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    import atomsmm_amd as atomsmm
+    from atomsmm_amd import engine as E
+    from atomsmm_amd import openmm, unit
+    from atomsmm_amd.testing import system_from_arrays
+    from fake_backend import RecordingContext
+
+    world = E.LocalWorld(4)
+
+    def collectives(rank):
+        buf = torch.full((4 * 3,), -1.0, dtype=torch.float64)
+        buf[rank * 3:(rank + 1) * 3] = float(rank + 1)
+        world.all_gather(rank, buf, 3)
+        total = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        world.all_reduce(rank, total)
+        flag = torch.tensor([1 if rank == 2 else 0], dtype=torch.int32)
+        world.all_reduce(rank, flag, op='max')
+        return buf.tolist(), float(total), int(flag), world.broadcast(rank, 'from rank %d' % rank)
+
+    out = world.run(collectives)
+    for r in range(4):
+        assert out[r][0] == [1.0] * 3 + [2.0] * 3 + [3.0] * 3 + [4.0] * 3
+        assert out[r][1:] == (10.0, 1, 'from rank 0')
+
+    made = []
+    saved = E._context_factory
+    E._context_factory = lambda *a, **k: made.append(RecordingContext(*a, **k)) or made[-1]
+    try:
+        d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'q-SPC-FW.npz'))
+        case = {k: d[k] for k in d.files}
+
+        def job(rank):
+            system = system_from_arrays(case, nonbondedMethod='CutoffPeriodic')
+            respa = atomsmm.RESPASystem(system, 0.7 * unit.nanometers, 0.5 * unit.nanometers)
+            integ = atomsmm.RespaPropagator([2, 2, 1]).integrator(2 * unit.femtoseconds)
+            ctx = openmm.Context(respa, integ)
+            ctx.setPositions(case['positions'])
+            integ.step(2)
+            eng = ctx._engine
+            return eng.rank, eng.world, eng._local is not None
+
+        assert E.LocalWorld(2).run(job) == [(0, 2, True), (1, 2, True)]
+        assert sorted((c.rank, c.world) for c in made) == [(0, 2), (1, 2)]
+    finally:
+        E._context_factory = saved
+
+    def failing(rank):
+        if rank == 1:
+            raise ValueError('rank 1 fails')
+        world.all_reduce(rank, torch.zeros(1))
+
+    with pytest.raises(ValueError, match='rank 1 fails'):
+        world.run(failing)
