@@ -380,7 +380,8 @@ struct amm_ctx {
     double skin_out = -1.0;        // outer Verlet buffer for pair forces created afterwards (<= 0: default)
     void *comm = nullptr;          // ncclComm_t of the library's own communicator (comm.hip), or none
     bool comm_failed = false;      // ... it was aborted after an asynchronous error / a wait that timed out
-    double opt_comm_timeout = 120; // seconds a wait for the stream may last while a communicator exists (comm.hip: amm_comm_wait_impl)
+    double opt_comm_timeout = 0;   // > 0: seconds a wait for the stream may last while a communicator exists before it is aborted (comm.hip:
+                                   // amm_comm_wait_impl); 0: no deadline -- the asynchronous error is polled, the work queued may take any time
     double *d_xchg = nullptr;      // caller-owned exchange buffer (amm_bind_exchange): world chunks of 2 x ceil(n/world) x 3 doubles
     long long xchg_doubles = 0;
     PendingExchange pending;

@@ -10,9 +10,10 @@
 //
 // Errors (failure detection): an enqueue that fails returns at once; what fails LATER -- a peer that died, a
 // link error -- is an asynchronous error of the communicator: polled (ncclCommGetAsyncError) after every enqueue and wherever the
-// library waits for the stream (amm_check, amm_synchronize, amm_comm_destroy), and those waits are bounded: a stream that does not
-// drain within `comm_timeout` seconds (amm_set_option, default 120) has the communicator aborted (ncclCommAbort) and the call
-// returns non-zero with the reason in amm_last_error -- the caller raises instead of sitting in hipStreamSynchronize for ever.
+// library waits for the stream (amm_check, amm_synchronize, amm_comm_destroy) -- an event-query loop, not hipStreamSynchronize, so
+// that the error is seen while the stream is stuck -- and those waits can be bounded: with the option `comm_timeout` > 0 (seconds;
+// default 0 = no deadline: a stream may legitimately hold minutes of queued steps) a stream that does not drain in time has the
+// communicator aborted (ncclCommAbort) and the call returns non-zero with the reason in amm_last_error.
 //
 // RCCL is bound at run time (dlopen) rather than at link time: a torch process already carries one librccl, and two
 // copies of the library in one process must not be mixed; the caller names the file (or NULL: the loader's default).
@@ -168,7 +169,7 @@ int amm_comm_wait_impl(amm_ctx *ctx, const char *who) {
                 break;
             }
             const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (waited > ctx->opt_comm_timeout) {
+            if (ctx->opt_comm_timeout > 0 && waited > ctx->opt_comm_timeout) {
                 comm_abort(ctx);
                 amm_set_error(std::string(who) + ": the stream did not drain within " + std::to_string((int)ctx->opt_comm_timeout) +
                               " s with collectives in flight (a peer rank that died or never arrived?); the RCCL communicator was aborted");

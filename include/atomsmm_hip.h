@@ -288,7 +288,7 @@ int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
  * pair kernel runs the kicks and the inner RESPA loop that follow its EVAL in the step program as its epilogue when the innermost group
  * is one bond-list set of three-site molecules -- propagators.py:933-973 unrolled; 0: launches of their own), "comm_timeout" (seconds
  * amm_check / amm_synchronize / amm_comm_destroy wait for the stream while the context owns an RCCL communicator before they abort it and
- * fail, default 120).  Unknown names are an error. */
+ * fail; default 0 = no deadline, the asynchronous error alone is polled).  Unknown names are an error. */
 int amm_set_option(amm_ctx *ctx, const char *name, double value);
 /* What amm_run_ops fused so far (statistics for tests and bench.py): out[0] = pair-kernel launches that carried the inner RESPA loop
  * of their molecules as an epilogue (the reference runs it as CustomIntegrator steps, propagators.py:933-973), out[1] = pair

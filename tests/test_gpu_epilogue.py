@@ -103,3 +103,31 @@ def test_epilogue_off_without_site_tables():
     new = _run(c, [4, 2, 1], 4, 'epilogue', options=(('site_tab', 0),))
     assert new['stats']['epilogues'] == 0
     assert np.array_equal(new['x'], ref['x']) and np.array_equal(new['v'], ref['v'])
+
+
+@pytest.mark.parametrize('loops,kwargs', [([1, 1, 1], {}), ([2, 2, 2], {}), ([4, 2, 1], {'has_memory': True}), ([3, 2], {}), ([4, 2, 1], {'blitz': True})])
+def test_epilogue_other_step_programs(loops, kwargs):
+    """Other shapes of the RESPA program (propagators.py:897-973): one iteration per level, an outermost loop of two, force memory,
+    two levels only (group 2 is never integrated), `blitz` -- whatever the planner makes of them (fused where the ops behind an EVAL are
+    kicks + the inner loop, declined elsewhere), the trajectory equals the plain op sequence bit for bit, in two calls of odd length."""
+    c = tip3p_box(8)
+
+    def run(mode):
+        respa = _respa_system(c)
+        integrator = atomsmm.RespaPropagator(loops, **kwargs).integrator(0.5 * float(np.prod(loops)) * unit.femtoseconds)      # (0.5 fs innermost)
+        context = openmm.Context(respa, integrator, openmm.Platform.getPlatformByName('HIP'))
+        ctx = context._engine.ctx
+        ctx.set_fuse_inner(mode != 'plain')
+        context.setPositions(c['positions'] * unit.nanometers)
+        context.setVelocities(c['velocities'])
+        integrator.step(5)
+        integrator.step(4)
+        st = context.getState(getPositions=True, getVelocities=True)
+        ctx.check()
+        return st.getPositions(asNumpy=True)._value, st.getVelocities(asNumpy=True)._value, ctx.run_stats()
+
+    x1, v1, s1 = run('epilogue')
+    x0, v0, s0 = run('plain')
+    assert s0['epilogues'] == 0
+    assert np.array_equal(x1, x0) and np.array_equal(v1, v0)
+    assert np.isfinite(x1).all()
