@@ -943,7 +943,13 @@ __device__ __forceinline__ void cepi_positions_final(const CEpiArgs &E, const Bo
 // (the caller orders those stores before these loads: same wavefront, same L1).
 // (the box BY VALUE: a reference into the kernel's CPairArgs makes the compiler keep a private copy of the whole argument block in
 // scratch, and the pair loop then reads A.box, A.margin ... from there on every trip)
+#ifdef AMM_CPAIR_TIMING
+#define CEPI_STAMP(k) (tstamp[k] = wall_clock64())
+__device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, bool valid, int sub, unsigned long long (&tstamp)[3]) {
+#else
+#define CEPI_STAMP(k)
 __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, bool valid, int sub) {
+#endif
     const int lane = threadIdx.x & 63;
     const int l = sub & 3;
     const int qb = lane - sub;                 // first lane of the row's lanes (a multiple of 4)
@@ -982,9 +988,36 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
     // have left the wavefront before these loads are issued, one L1 serves both.  (Behind the loads above, which do not wait for them.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    CEPI_STAMP(0);
     {
 #pragma clang fp contract(off)
-        for (int p = 0; p < E.npre; ++p) {
+        // the forces the first four kicks read are fetched in one go (a RESPA boundary has four: as loads inside the loop each kick
+        // waited for its own: 0.6 us a kick for a wavefront that runs alone)
+        double pa[4][3], pb[4][3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool on = p < E.npre;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                pa[p][j] = on ? E.pre[p].a[3 * a + j] : 0.0;
+                pb[p][j] = (on && E.pre[p].b) ? E.pre[p].b[3 * a + j] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (p < E.npre) {
+                const CEpiPre pk = E.pre[p];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double ff = pa[p][j];
+                    if (pk.b) ff = pk.plus ? ff + pb[p][j] : ff - pb[p][j];
+                    const double num = pk.coef * ff;
+                    const double dv = amm_div_mass(num, m, rm, rok);
+                    v[j] = v[j] + dv;
+                }
+            }
+        }
+        for (int p = 4; p < E.npre; ++p) {
             const CEpiPre pk = E.pre[p];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -996,6 +1029,7 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
             }
         }
     }
+    CEPI_STAMP(1);
     BondedArgs BA;                             // (harmonic bonds and angles read its box alone)
     BA.box = box;
     const int rec_n = (int)(my_recs >> 60);
@@ -1072,6 +1106,7 @@ __device__ CEPI_INLINE void cepi_rows(const CEpiArgs &E, const Box box, int cs, 
             }
         }
     }
+    CEPI_STAMP(2);
     if (has) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -1155,6 +1190,7 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g, CEpiArgs E) {
     const unsigned long long t_entry = wall_clock64();
     unsigned long long t_staged = 0;
     int n_tasks_done = 0, n_interior = 0;
+    unsigned long long t_epi[3] = {0, 0, 0};      // epilogue: forces visible / preceding kicks done / loop done (last task)
 #endif
     auto stage = [&](int at, const double *src, int bytes) {
         for (int o = threadIdx.x * 16; o < bytes; o += BS * 16)
@@ -1294,7 +1330,11 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g, CEpiArgs E) {
             for (int task = (int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6); task < ntask; task += nwx) {
                 const int a = row0 + task * rpw + (lane >> shift);
                 const bool valid = a < row_end;
+#ifdef AMM_CPAIR_TIMING
+                cepi_rows(E, A.box, A.c_begin + (valid ? a : 0), valid, lane & ((1 << shift) - 1), t_epi);
+#else
                 cepi_rows(E, A.box, A.c_begin + (valid ? a : 0), valid, lane & ((1 << shift) - 1));
+#endif
             }
         }
         // the molecules are filed in their new cells (cepi_rows).  If some trigger now asks for a rebuild, the last block to get here
@@ -1312,7 +1352,9 @@ k_cpair(CPairArgs A, PairConsts c, PairConsts g, CEpiArgs E) {
         o[0] = t_entry;
         o[1] = t_staged;
         o[2] = wall_clock64();
-        o[3] = ((unsigned long long)n_interior << 8) | (unsigned long long)n_tasks_done;
+        // (kernels with the epilogue: the fourth word holds three 20-bit offsets from "rows walked", in clock ticks of 10 ns)
+        o[3] = EPI ? (((t_epi[0] - t_staged) & 0xfffffull) | (((t_epi[1] - t_staged) & 0xfffffull) << 20) | (((t_epi[2] - t_staged) & 0xfffffull) << 40))
+                   : (((unsigned long long)n_interior << 8) | (unsigned long long)n_tasks_done);
     }
 #endif
 }

@@ -21,6 +21,12 @@ for path in sys.argv[1:]:
         (end - entry).mean() / end.max(), np.median(work[slot < 4]), np.median(work[slot >= 4])))
     blk = np.arange(len(a)) // 8
     if path.endswith('_epi'):
+        w3 = a[:, 3]
+        parts = [((w3 >> np.uint64(sh)) & np.uint64(0xfffff)).astype(float) / 100.0 for sh in (0, 20, 40)]
+        young = slot >= 4
+        print('   epilogue of the wavefronts that run it alone (4-7), medians from "rows walked": own loads + this launch\'s forces visible %.1f us, '
+              'preceding kicks done %.1f us, loop done %.1f us, stores issued / wavefront ends %.1f us' % (
+                  np.median(parts[0][young]), np.median(parts[1][young]), np.median(parts[2][young]), np.median((end - staged)[young])))
         epi = end - staged
         print('   epilogue (inner RESPA loop of the rows\' molecules) per wavefront p10 / median / p90 / max = %.1f / %.1f / %.1f / %.1f us; '
               'rows walked: wavefronts 0-3 median %.1f us, 4-7 %.1f us, last %.1f us' % (
