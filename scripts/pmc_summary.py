@@ -49,10 +49,14 @@ def main():
                           ('build', ('k_cbuild<false', 'k_build_nlist<false'))):
             if prefix == 'c5_' and tag in ('near', 'dual'):       # (the molecule rows only: the per-atom part is listed apart)
                 pats = tuple(q for q in pats if q.startswith('k_cpair'))
-            fe = [x for (cn, kn), v in acc.items() if cn == 'FETCH_SIZE' and any(p in kn for p in pats) for x in v]
-            wr = [x for (cn, kn), v in acc.items() if cn == 'WRITE_SIZE' and any(p in kn for p in pats) for x in v]
-            iv = [x for (cn, kn), v in acc.items() if cn == 'SQ_INSTS_VALU' and any(p in kn for p in pats) for x in v]
-            names = sorted(set(kn for (cn, kn) in acc if cn == 'FETCH_SIZE' and any(p in kn for p in pats)))
+            # several instantiations may match (with / without the inner-loop epilogue): the figures are those of the one launched most
+            names = sorted(set(kn for (cn, kn) in acc if cn == 'FETCH_SIZE' and any(p in kn for p in pats)),
+                           key=lambda kn: -len(acc[('FETCH_SIZE', kn)]))
+            if tag != 'build':
+                names = names[:1]
+            fe = [x for (cn, kn), v in acc.items() if cn == 'FETCH_SIZE' and kn in names for x in v]
+            wr = [x for (cn, kn), v in acc.items() if cn == 'WRITE_SIZE' and kn in names for x in v]
+            iv = [x for (cn, kn), v in acc.items() if cn == 'SQ_INSTS_VALU' and kn in names for x in v]
             if tag == 'build':      # only the launches that actually rebuilt (the others return at once)
                 fe = [x for x in fe if x > 100.0]
                 wr = [x for x in wr if x > 100.0]
