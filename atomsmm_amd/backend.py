@@ -60,7 +60,7 @@ class PairStats(C.Structure):
                 ('n_outer_pairs', C.c_int64), ('rlist_outer', C.c_double), ('tab_error', C.c_double),
                 ('has_table', C.c_int32), ('rode_along', C.c_int32),
                 ('has_site_table', C.c_int32), ('n_rest_atoms', C.c_int32), ('site_tab_error', C.c_double),
-                ('n_candidates', C.c_int32), ('n_candidate_walks', C.c_int32), ('chargeless', C.c_int32), ('reserved_', C.c_int32)]
+                ('n_candidates', C.c_int32), ('n_candidate_walks', C.c_int32), ('chargeless', C.c_int32), ('build_split', C.c_int32)]
 
 
 def slice_per(n, world):

@@ -1737,6 +1737,7 @@ int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out) {
     out->has_table = (pf->pc.tab.nint > 0 && pf->d_tab) ? 1 : 0;
     out->rode_along = pf->last_fused;
     out->chargeless = pf->last_chargeless;
+    out->build_split = (L->cl && L->last_kind != 0) ? L->cl->split_parts : 0;
     out->has_site_table = (ctx->opt_site_tab && pf->d_tab_ss && pf->pc.tab.ss_first >= 0) ? 1 : 0;
     out->site_tab_error = pf->ss_error;
     out->n_rest_atoms = L->hybrid ? L->n_rest : 0;
@@ -1840,6 +1841,7 @@ int amm_set_option(amm_ctx *ctx, const char *name, double value) {
     else if (k == "site_trips") ctx->site_trips = v != 0;
     else if (k == "lanes_per_row") ctx->opt_lpa = v;
     else if (k == "build_parts") ctx->opt_parts = v;
+    else if (k == "build_split") ctx->opt_build_split = v;
     else if (k == "unroll") ctx->opt_unroll = v;
     else if (k == "dual_unroll") ctx->opt_dual_unroll = v;
     else if (k == "tab_block") ctx->opt_tab_bs = v;

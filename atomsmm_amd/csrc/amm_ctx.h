@@ -340,6 +340,7 @@ struct amm_ctx {
     int opt_small_group = 1;       // interaction-group forces with a small set (a solute) without a neighbour list (group.hip)
     bool creating_rest = false;    // amm_pair_create is making the hidden child of a hybrid list
     int opt_tab = 1;               // tabulated force-only kernels (0: the analytic kernels)
+    int opt_build_split = 0;       // split-stream list build (k_cbuild_split): 0 = off, -1 = for slices (world > 1) with the library's choice of blocks per cell, k > 0 = k blocks per cell
     int opt_lpa = 0, opt_parts = 0, opt_unroll = 2, opt_dual_unroll = 2, opt_tab_bs = 0, opt_tab_dual_bs = 0;
     int opt_site_tab = 1;               // molecule rows: site-site radial tables instead of Lennard-Jones arithmetic where a force has one
     CZeroRows zero_rows = CZeroRows{0, nullptr, nullptr, nullptr};      // pending request (pair.hip -> cluster.hip, one evaluation)

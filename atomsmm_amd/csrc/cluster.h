@@ -27,6 +27,8 @@ struct ClusterList {
     CellGrid grid;
     int capc = 0;                  // members per cell in the cell tables
     int parts = 1;                 // wavefronts per cell in the build
+    int *d_slice_cells = nullptr;  // [2]: the cells that hold the first / the last row of this rank's slice (k_csort_gather)
+    int split_parts = 0;           // > 0: blocks per cell of the split-stream build (slices; k_cbuild<.., SPLIT>)
     double rext = 0;               // bound on the distance of a molecule's atoms from its first atom (cells, interior margin)
     double rlist_build = 0, rnear_build = 0, skin = 0;
     int *d_cell_count = nullptr, *d_cell_start = nullptr, *d_cell_members = nullptr;

@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
                                                       float4 *pos4f, const int *flags, int *wflags, int force, const double *__restrict__ q,
                                                       const double *__restrict__ hsig, const double *__restrict__ seps2, double4 *posq_s,
                                                       double2 *lj_s, float rext, const double *__restrict__ site_eps,
-                                                      const int *__restrict__ first, CZeroRows Z, int copies_current, double *xref) {
+                                                      const int *__restrict__ first, CZeroRows Z, int copies_current, double *xref,
+                                                      int c_begin, int c_end, int *slice_cells) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     // (hybrid lists: the force rows of the atoms outside the molecules start from zero; the molecule-row kernel writes the others
     // and the per-atom part adds to all of them -- a launch of its own before)
@@ -173,6 +174,11 @@ __global__ void __launch_bounds__(256) k_csort_gather(int ncell, int nc, const i
     if (wave >= ncell) return;
     const int b = start[wave];
     const int cnt = min(start[wave + 1] - b, capc);
+    // the cells that hold the first and the last row of this rank's slice: the build launches blocks for those cells only
+    if (lane == 0 && c_begin < c_end) {
+        if (b <= c_begin && c_begin < start[wave + 1]) slice_cells[0] = wave;
+        if (b <= c_end - 1 && c_end - 1 < start[wave + 1]) slice_cells[1] = wave;
+    }
     const int *mem = members + (size_t)wave * capc;
     for (int a0 = 0; a0 < cnt; a0 += 64) {
         const int a = a0 + lane;
@@ -301,11 +307,20 @@ __device__ void cfinish_build_block(int *flags, unsigned long long *counters, co
 #define CB_WAVES 5
 #endif
 #define CB_OCC __attribute__((amdgpu_waves_per_eu(CB_WAVES)))
-template <bool COUNT_ONLY, bool RINT>
-__global__ void __launch_bounds__(256) CB_OCC k_cbuild(int c_begin, int c_end, int parts, const int *__restrict__ cell_start,
+#ifdef AMM_CBS_TIMING          // measurement builds: clock sums of the phases over the first wavefronts of the busy blocks
+__device__ unsigned long long g_cbs_t[8];
+#define CBS_STAMP(i) do { const unsigned long long now_ = wall_clock64(); if (w == 0 && lane == 0) atomicAdd(&g_cbs_t[i], now_ - t_last); t_last = now_; } while (0)
+#else
+#define CBS_STAMP(i) do { } while (0)
+#endif
+// SLICE (a rank's slice of the rows): the grid covers the cells of the slice only -- k_csort_gather recorded the first and the last
+// (slice_cells) -- with a stride over the (cell, part) units in case the slice spans more cells than the host allowed for; a grid
+// over every cell of the box spent a third of the slice's build on dispatching blocks that return at once.
+template <bool COUNT_ONLY, bool RINT, bool SLICE = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SLICE ? 3 : CB_WAVES))) k_cbuild(int c_begin, int c_end, int parts, const int *__restrict__ cell_start,
                                                 const float4 *__restrict__ pos4f, CBoxF box, CellGrid g, float rlist, float rnear2, int cap,
                                                 int *nl, int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
-                                                unsigned long long *counters, int *ticket, int force) {
+                                                unsigned long long *counters, int *ticket, int force, const int *slice_cells) {
     if (!force && !flags[0]) return;
     __shared__ int s_rstart[4][128];
     __shared__ int s_rpref[4][128];
@@ -314,11 +329,18 @@ __global__ void __launch_bounds__(256) CB_OCC k_cbuild(int c_begin, int c_end, i
     __shared__ unsigned char s_coarse[4][CB_COARSE]; // piece of stream position e << cshift
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    const int c = wave / parts, part = wave - c * parts;
     const float FAR = 1.0e9f;
     const float rlist2 = rlist * rlist;
     unsigned long long wsum = 0, wnear = 0;
     int wmax = 0;
+    const int first_cell = SLICE ? __builtin_amdgcn_readfirstlane(slice_cells[0]) : 0;
+    const int nunits = SLICE ? (__builtin_amdgcn_readfirstlane(slice_cells[1]) - first_cell + 1) * parts : g.ncell * parts;
+    int unit = wave;
+#ifdef AMM_CBS_TIMING
+    unsigned long long t_last = wall_clock64(), t_drain = 0, n_drain = 0;
+#endif
+    do {
+    const int c = unit < nunits ? first_cell + unit / parts : g.ncell, part = unit % parts;
     int a_begin = 0, a_end = 0;
     if (c < g.ncell) {
         const int cb0 = __builtin_amdgcn_readfirstlane(cell_start[c]), cb1 = __builtin_amdgcn_readfirstlane(cell_start[c + 1]);
@@ -388,6 +410,9 @@ __global__ void __launch_bounds__(256) CB_OCC k_cbuild(int c_begin, int c_end, i
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef AMM_CBS_TIMING
+        if (SLICE && lane == 0) { atomicAdd(&g_cbs_t[7], 1ull); atomicAdd(&g_cbs_t[0], wall_clock64() - t_last); }
+#endif
         for (int tb = a_begin; tb < a_end; tb += CB_BATCH) {
             const int nt = min(CB_BATCH, a_end - tb);
             // the batch's atoms: lane 3 t + a holds atom a of row molecule t; the loops over t below are REAL loops (t is a scalar
@@ -401,6 +426,10 @@ __global__ void __launch_bounds__(256) CB_OCC k_cbuild(int c_begin, int c_end, i
             // ---- pass 2: 128 queued survivors of row t (n of them valid), two per lane (lane, lane + 64) so that the arithmetic runs
             // on packed fp32: nine distances each, the smallest decides; the two halves are filed one after the other (ring order) ----
             auto drain = [&](int t, int n) {
+#ifdef AMM_CBS_TIMING
+                const unsigned long long t_d0 = wall_clock64();
+                n_drain++;
+#endif
                 const int head = __builtin_amdgcn_readlane(q_head, t);
                 int slot[2];
                 bool v[2];
@@ -482,6 +511,9 @@ __global__ void __launch_bounds__(256) CB_OCC k_cbuild(int c_begin, int c_end, i
                 }
                 q_head = lane == t ? cq_wrap(head + n) : q_head;
                 q_cnt = lane == t ? q_cnt - n : q_cnt;
+#ifdef AMM_CBS_TIMING
+                t_drain += wall_clock64() - t_d0;
+#endif
             };
             // ---- pass 1: the candidate stream, first atoms only; a row's ring is drained in FULL chunks as soon as it holds 64 ----
             // (the candidates of chunk pair i + 1 -- piece search in LDS, then a gather -- are fetched while pair i is tested)
@@ -580,6 +612,11 @@ __global__ void __launch_bounds__(256) CB_OCC k_cbuild(int c_begin, int c_end, i
             }
         }
     }
+#ifdef AMM_CBS_TIMING
+    if (SLICE && lane == 0 && a_begin < a_end) { atomicAdd(&g_cbs_t[1], wall_clock64() - t_last); atomicAdd(&g_cbs_t[2], t_drain); atomicAdd(&g_cbs_t[3], n_drain); }
+#endif
+    unit += (int)(gridDim.x * (blockDim.x >> 6));
+    } while (SLICE && unit < nunits);
     for (int off = 32; off > 0; off >>= 1) {
         wsum += __shfl_xor(wsum, off);
         wnear += __shfl_xor(wnear, off);
@@ -599,6 +636,344 @@ __global__ void __launch_bounds__(256) CB_OCC k_cbuild(int c_begin, int c_end, i
         amm_st_l2(&blockstats[3 * blockIdx.x + 2], s_near[0] + s_near[1] + s_near[2] + s_near[3]);
     }
     if (amm_last_block(ticket)) cfinish_build_block(flags, counters, blockstats, (int)gridDim.x, COUNT_ONLY ? 1 : 0);
+}
+
+// ---- split-stream build: a rank's slice of the rows ----
+// A slice gives too few (cell, part) units to fill the chip, and a wavefront's time in k_cbuild is its own chain of dependent reads
+// over the cell's WHOLE candidate stream (~12 chunk pairs) plus ~3 drains per row, whatever its share of the rows.  Here a BLOCK takes
+// the unit and both passes are shared out over its four wavefronts:
+//   1. the stream goes in rounds of 4 x CBS_SEG candidates, wavefront w takes the w-th CBS_SEG of the round (whole chunk pairs) for
+//      every row molecule of the batch and queues its survivors in a ring of its own (no drains: the ring holds a whole segment);
+//   2. block barrier; the survivors of a row -- the four rings one behind the other, i.e. in stream order -- are cut into chunks of
+//      128 and the chunks of all rows are dealt out to the wavefronts round robin (splitting the stream alone leaves the drains on
+//      the two wavefronts whose segments cross the middle of the stencil: measured slower than the unsplit build); a chunk's hits
+//      are filed in a chunk row in LDS (front part from the left, back part from the right, like the row itself);
+//   3. block barrier; the chunk rows are copied into the row one behind the other, in chunk order = stream order.
+// The rows are those of k_cbuild entry for entry (tests/test_gpu_abi_parity.py), so a rank's forces do not depend on the variant.
+#ifndef CBS_BATCH
+#define CBS_BATCH 3
+#endif
+#ifndef CBS_SEG
+#define CBS_SEG 384             // candidates per wavefront and round (a multiple of 128)
+#endif
+#define CBS_MAXCH (4 * CBS_SEG / 128)       // chunks of 128 survivors a row can have in one round
+template <bool RINT>
+__global__ void __launch_bounds__(256) k_cbuild_split(int c_begin, int c_end, int parts, const int *__restrict__ cell_start,
+                                                      const float4 *__restrict__ pos4f, CBoxF box, CellGrid g, float rlist, float rnear2, int cap,
+                                                      int *nl, int *nnb, int *nnb_near, int *flags, unsigned long long *blockstats,
+                                                      unsigned long long *counters, int *ticket, int force, const int *slice_cells) {
+    if (!force && !flags[0]) return;
+    __shared__ int s_rstart[128];
+    __shared__ int s_rpref[128];
+    __shared__ float s_rshift[3][128];
+    __shared__ unsigned char s_coarse[CB_COARSE];
+    __shared__ int s_total;
+    __shared__ int s_ring[4][CBS_BATCH][CBS_SEG];           // survivors of the sphere test, per wavefront and row molecule
+    __shared__ int s_cnt[4][CBS_BATCH];
+    __shared__ int s_stage[CBS_BATCH * CBS_MAXCH][128];     // chunk rows
+    __shared__ int s_ccnt[CBS_BATCH * CBS_MAXCH];           // their entries (front | back << 16)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float FAR = 1.0e9f;
+    const float rlist2 = rlist * rlist;
+    unsigned long long wsum = 0, wnear = 0;
+    int wmax = 0;
+    // the (cell, part) units of the slice's cells (k_csort_gather recorded the first and the last), a block each
+    const int first_cell = __builtin_amdgcn_readfirstlane(slice_cells[0]);
+    const int nunits = (__builtin_amdgcn_readfirstlane(slice_cells[1]) - first_cell + 1) * parts;
+    for (int unit = (int)blockIdx.x; unit < nunits; unit += (int)gridDim.x) {
+    const int c = first_cell + unit / parts, part = unit % parts;
+    int a_begin = 0, a_end = 0;
+    if (c < g.ncell) {
+        const int cb0 = __builtin_amdgcn_readfirstlane(cell_start[c]), cb1 = __builtin_amdgcn_readfirstlane(cell_start[c + 1]);
+        const int per = (cb1 - cb0 + parts - 1) / parts;
+        a_begin = max(cb0 + part * per, c_begin);
+        a_end = min(min(cb0 + (part + 1) * per, cb1), c_end);
+    }
+    if (a_begin < a_end) {          // (the same in every wavefront of the block: the barriers below are met by all four)
+#ifdef AMM_CBS_TIMING
+        unsigned long long t_last = wall_clock64();
+        if (w == 0 && lane == 0) atomicAdd(&g_cbs_t[7], 1ull);
+#endif
+        const int ncx = g.nc[0], ncy = g.nc[1], ncz = g.nc[2];
+        const int cx = c % ncx, cy = (c / ncx) % ncy, cz = c / (ncx * ncy);
+        // ---- piece table of the block (first wavefront): a lane describes the stencil cells e = lane and lane + 64, x fastest ----
+        if (w == 0) {
+            const int nsx = g.nstencil[0], nsy = g.nstencil[1], ne = nsx * nsy * g.nstencil[2];
+            int ecs[2] = {0, 0}, len[2] = {0, 0}, inc[2];
+            float esx[2] = {0.f, 0.f}, esy[2] = {0.f, 0.f}, esz[2] = {0.f, 0.f};
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int e = lane + 64 * hh;
+                if (e < ne) {
+                    const int ox = e % nsx, oy = (e / nsx) % nsy, oz = e / (nsx * nsy);
+                    int nz = ncz < 2 * g.h[2] + 1 ? oz : cz - g.h[2] + oz;
+                    esz[hh] = nz < 0 ? -box.L[2] : (nz >= ncz ? box.L[2] : 0.f);
+                    nz = nz < 0 ? nz + ncz : (nz >= ncz ? nz - ncz : nz);
+                    int ny = ncy < 2 * g.h[1] + 1 ? oy : cy - g.h[1] + oy;
+                    esy[hh] = ny < 0 ? -box.L[1] : (ny >= ncy ? box.L[1] : 0.f);
+                    ny = ny < 0 ? ny + ncy : (ny >= ncy ? ny - ncy : ny);
+                    int nx = ncx < 2 * g.h[0] + 1 ? ox : cx - g.h[0] + ox;
+                    esx[hh] = nx < 0 ? -box.L[0] : (nx >= ncx ? box.L[0] : 0.f);
+                    nx = nx < 0 ? nx + ncx : (nx >= ncx ? nx - ncx : nx);
+                    const int cc = (nz * ncy + ny) * ncx + nx;
+                    ecs[hh] = cell_start[cc];
+                    len[hh] = cell_start[cc + 1] - ecs[hh];
+                }
+                inc[hh] = len[hh];
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(inc[hh], off);
+                    if (lane >= off) inc[hh] += v;
+                }
+            }
+            const int lower = __builtin_amdgcn_readlane(inc[0], 63);
+            if (lane == 0) s_total = lower + __builtin_amdgcn_readlane(inc[1], 63);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                s_rstart[lane + 64 * hh] = ecs[hh];
+                s_rpref[lane + 64 * hh] = (hh ? lower : 0) + inc[hh] - len[hh];       // exclusive prefix; beyond the stencil: the total
+                s_rshift[0][lane + 64 * hh] = esx[hh];
+                s_rshift[1][lane + 64 * hh] = esy[hh];
+                s_rshift[2][lane + 64 * hh] = esz[hh];
+            }
+        }
+        __syncthreads();
+        const int total = s_total;
+        int cshift = 3;
+        while (((total + 127) >> cshift) > CB_COARSE) ++cshift;
+        {       // coarse table: the piece of every (1 << cshift)-th stream position, one entry per thread
+            const int idx = (int)threadIdx.x << cshift;
+            int r = 0;
+#pragma unroll
+            for (int step = 64; step > 0; step >>= 1)
+                if (s_rpref[r + step] <= idx) r += step;
+            s_coarse[threadIdx.x] = (unsigned char)r;
+        }
+        __syncthreads();
+        CBS_STAMP(0);
+        // rounds of equal length: a wavefront's segment is the round's quarter in whole chunk pairs (<= CBS_SEG)
+        const int rounds = (total + 4 * CBS_SEG - 1) / (4 * CBS_SEG);
+        const int seg = (((total + rounds - 1) / rounds + 511) >> 9) << 7;
+        auto rl = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        for (int tb = a_begin; tb < a_end; tb += CBS_BATCH) {
+            const int nt = min(CBS_BATCH, a_end - tb);
+            float4 my = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < 3 * nt) my = pos4f[3 * tb + lane];
+            const float plim_l = my.w + rlist;
+            int row_cnt = 0;          // lane t: entries of row t so far (front | back << 16) -- the same in every wavefront
+            for (int r0 = 0; r0 < total; r0 += 4 * seg) {
+                // ---- pass 1: this wavefront's segment of the round, first atoms only ----
+                const int lo = min(r0 + w * seg, total), hi = min(lo + seg, total);
+                int q_cnt = 0;        // lane t: survivors of row t in this wavefront's ring
+                auto fetch = [&](int cb, float4 (&cand)[2], int (&js)[2]) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int idx = cb + u * 64 + lane;
+                        const bool in = idx < hi;
+                        int r = s_coarse[idx >> cshift];
+                        while (r < 127 && s_rpref[r + 1] <= idx) ++r;
+                        const int slot = in ? s_rstart[r] + idx - s_rpref[r] : 0;
+                        float4 q = pos4f[3 * slot];
+                        if (!RINT) {
+                            const float sx = s_rshift[0][r], sy = s_rshift[1][r], sz = s_rshift[2][r];
+                            q.x = in ? q.x + sx : FAR;
+                            q.y = in ? q.y + sy : FAR;
+                            q.z = in ? q.z + sz : FAR;
+                        } else if (!in) {
+                            q.w = -1.0e9f;            // beyond the segment: no sphere reaches it
+                        }
+                        cand[u] = q;
+                        js[u] = slot;
+                    }
+                };
+                if (lo < hi) {
+                    // (the whole segment -- at most CBS_SEG / 128 chunk pairs -- is in flight before the first is tested)
+                    float4 pc[CBS_SEG / 128][2];
+                    int pj[CBS_SEG / 128][2];
+#pragma unroll
+                    for (int st = 0; st < CBS_SEG / 128; ++st)
+                        if (lo + 128 * st < hi) fetch(lo + 128 * st, pc[st], pj[st]);
+#pragma unroll
+                    for (int st = 0; st < CBS_SEG / 128; ++st) {
+                        if (lo + 128 * st >= hi) break;
+                        const float4 (&cand)[2] = pc[st];
+                        const int (&js)[2] = pj[st];
+                        const v2f cx2 = v2f{cand[0].x, cand[1].x}, cy2 = v2f{cand[0].y, cand[1].y}, cz2 = v2f{cand[0].z, cand[1].z};
+                        const v2f cw = v2f{cand[0].w, cand[1].w};
+                        for (int t = 0; t < nt; ++t) {
+                            const float p0x = rl(my.x, 3 * t), p0y = rl(my.y, 3 * t), p0z = rl(my.z, 3 * t), plim = rl(plim_l, 3 * t);
+                            int qn = __builtin_amdgcn_readlane(q_cnt, t);
+                            v2f dx = p0x - cx2, dy = p0y - cy2, dz = p0z - cz2;
+                            if (RINT) {
+                                dx -= box.L[0] * __builtin_elementwise_rint(dx * box.invL[0]);
+                                dy -= box.L[1] * __builtin_elementwise_rint(dy * box.invL[1]);
+                                dz -= box.L[2] * __builtin_elementwise_rint(dz * box.invL[2]);
+                            }
+                            v2f r2 = dx * dx;
+                            r2 = __builtin_elementwise_fma(dy, dy, r2);
+                            r2 = __builtin_elementwise_fma(dz, dz, r2);
+                            const v2f lim = plim + cw;
+                            const v2f lim2 = lim * lim;
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const bool pass = (u ? r2.y < lim2.y : r2.x < lim2.x) && (!RINT || (u ? lim.y : lim.x) > 0.f);
+                                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                                if (m == 0ull) continue;
+                                const int at = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                if (pass) s_ring[w][t][at] = js[u];          // (at < CBS_SEG: a segment has no more candidates)
+                                qn += __popcll(m);
+                            }
+                            q_cnt = lane == t ? qn : q_cnt;
+                        }
+                    }
+                }
+                CBS_STAMP(1);
+                if (lane < CBS_BATCH) s_cnt[w][lane] = q_cnt;
+                __syncthreads();
+                CBS_STAMP(2);
+                // ---- pass 2: the rows' survivors in chunks of 128, dealt out round robin; two per lane, packed fp32 (as k_cbuild's drain) ----
+                int j0 = 0;       // number of the row's first chunk
+                for (int t = 0; t < nt; ++t) {
+                    const int c0 = __builtin_amdgcn_readfirstlane(s_cnt[0][t]), c1 = c0 + __builtin_amdgcn_readfirstlane(s_cnt[1][t]);
+                    const int c2 = c1 + __builtin_amdgcn_readfirstlane(s_cnt[2][t]), T = c2 + __builtin_amdgcn_readfirstlane(s_cnt[3][t]);
+                    const int nch = (T + 127) >> 7;
+                    for (int k = 0; k < nch; ++k) {
+                        const int j = j0 + k;
+                        if ((j & 3) != w) continue;
+                        const int n = min(128, T - 128 * k);
+                        int slot[2];
+                        bool v[2];
+                        float4 A[2][3];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int gi = 128 * k + lane + 64 * u;
+                            const bool v0 = lane + 64 * u < n;
+                            const int ww = (gi >= c0 ? 1 : 0) + (gi >= c1 ? 1 : 0) + (gi >= c2 ? 1 : 0);
+                            const int off = gi - (ww == 0 ? 0 : (ww == 1 ? c0 : (ww == 2 ? c1 : c2)));
+                            slot[u] = v0 ? s_ring[ww][t][off] : tb + t;
+                            v[u] = v0 && slot[u] != tb + t;          // (a molecule is not its own partner)
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) A[u][b] = pos4f[3 * slot[u] + b];
+                        const int sites[2] = {__float_as_int(A[0][1].w), __float_as_int(A[1][1].w)};
+                        float px[3], py[3], pz[3];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            px[a] = rl(my.x, 3 * t + a);
+                            py[a] = rl(my.y, 3 * t + a);
+                            pz[a] = rl(my.z, 3 * t + a);
+                        }
+                        v2f ax[3], ay[3], az[3];
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) {
+                            ax[b] = v2f{A[0][b].x, A[1][b].x};
+                            ay[b] = v2f{A[0][b].y, A[1][b].y};
+                            az[b] = v2f{A[0][b].z, A[1][b].z};
+                        }
+                        if (!RINT) {          // one periodic image per molecule pair, from the first atoms
+                            const v2f sx = box.L[0] * __builtin_elementwise_rint((ax[0] - px[0]) * box.invL[0]);
+                            const v2f sy = box.L[1] * __builtin_elementwise_rint((ay[0] - py[0]) * box.invL[1]);
+                            const v2f sz = box.L[2] * __builtin_elementwise_rint((az[0] - pz[0]) * box.invL[2]);
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) {
+                                ax[b] -= sx;
+                                ay[b] -= sy;
+                                az[b] -= sz;
+                            }
+                        }
+                        v2f m2 = v2f{3.0e38f, 3.0e38f};
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) {
+                                v2f dx = px[a] - ax[b], dy = py[a] - ay[b], dz = pz[a] - az[b];
+                                if (RINT) {
+                                    dx -= box.L[0] * __builtin_elementwise_rint(dx * box.invL[0]);
+                                    dy -= box.L[1] * __builtin_elementwise_rint(dy * box.invL[1]);
+                                    dz -= box.L[2] * __builtin_elementwise_rint(dz * box.invL[2]);
+                                }
+                                v2f r2 = dx * dx;
+                                r2 = __builtin_elementwise_fma(dy, dy, r2);
+                                r2 = __builtin_elementwise_fma(dz, dz, r2);
+                                m2 = __builtin_elementwise_min(m2, r2);
+                            }
+                        int cnt = 0, cntf = 0;        // the chunk row so far
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const float m2u = u ? m2.y : m2.x;
+                            const bool pass = v[u] && m2u < rlist2;
+                            const unsigned long long m_pass = __builtin_amdgcn_ballot_w64(pass);
+                            if (m_pass != 0ull) {
+                                const bool is_near = pass && m2u < rnear2;
+                                const unsigned long long m_near = __builtin_amdgcn_ballot_w64(is_near);
+                                const int np_ = __popcll(m_pass), nn_ = __popcll(m_near);
+                                const int mp = __builtin_amdgcn_mbcnt_hi((unsigned)(m_pass >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_pass, 0u));
+                                const int mn = __builtin_amdgcn_mbcnt_hi((unsigned)(m_near >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_near, 0u));
+                                if (pass) s_stage[j][is_near ? cnt + mn : 127 - cntf - (mp - mn)] = slot[u] | (sites[u] << 29);
+                                cnt += nn_;
+                                cntf += np_ - nn_;
+                            }
+                        }
+                        if (lane == 0) s_ccnt[j] = cnt | (cntf << 16);
+                    }
+                    j0 += nch;
+                }
+                CBS_STAMP(3);
+                __syncthreads();
+                CBS_STAMP(4);
+                // ---- the chunk rows into the rows, one behind the other (every wavefront walks the counts, the one that made a chunk copies it) ----
+                j0 = 0;
+                for (int t = 0; t < nt; ++t) {
+                    const int T = __builtin_amdgcn_readfirstlane(s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t]);
+                    const int nch = (T + 127) >> 7;
+                    const int have = __builtin_amdgcn_readlane(row_cnt, t);
+                    int nf = have & 0xffff, nb_ = (int)((unsigned)have >> 16);
+                    int *row_out = nl + (size_t)(tb + t - c_begin) * cap;
+                    for (int k = 0; k < nch; ++k) {
+                        const int j = j0 + k;
+                        const int cc = __builtin_amdgcn_readfirstlane(s_ccnt[j]);
+                        const int cn = cc & 0xffff, cf = (int)((unsigned)cc >> 16);
+                        if ((j & 3) == w && nf + nb_ + cn + cf <= cap) {
+                            for (int i = lane; i < cn; i += 64) row_out[nf + i] = s_stage[j][i];
+                            for (int i = lane; i < cf; i += 64) row_out[cap - 1 - nb_ - i] = s_stage[j][127 - i];
+                        }
+                        nf = min(nf + cn, 0xffff);        // (a row that overflows is reported below; the counters must not wrap)
+                        nb_ = min(nb_ + cf, 0xffff);
+                    }
+                    row_cnt = lane == t ? (nf | (nb_ << 16)) : row_cnt;
+                    j0 += nch;
+                }
+                CBS_STAMP(5);
+                __syncthreads();          // rings, counts and chunk rows are free for the next round
+                CBS_STAMP(6);
+            }
+            if (w == 0 && lane < nt) {
+                const int count = row_cnt & 0xffff, countf = (int)((unsigned)row_cnt >> 16);
+                const int total_nb = count + countf;
+                const bool over = total_nb > cap;
+                nnb[tb + lane - c_begin] = over ? 0 : total_nb;
+                nnb_near[tb + lane - c_begin] = over ? 0 : count;
+                if (over) flags[1] = 1;
+                wsum += (unsigned long long)total_nb;
+                wnear += (unsigned long long)count;
+                wmax = max(wmax, total_nb);
+            }
+        }
+    }
+    __syncthreads();          // (a second unit of this block rebuilds the piece table)
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        wsum += __shfl_xor(wsum, off);
+        wnear += __shfl_xor(wnear, off);
+        wmax = max(wmax, __shfl_xor(wmax, off));
+    }
+    if (w == 0 && lane == 0) {
+        amm_st_l2(&blockstats[3 * blockIdx.x], wsum);
+        amm_st_l2(&blockstats[3 * blockIdx.x + 1], (unsigned long long)wmax);
+        amm_st_l2(&blockstats[3 * blockIdx.x + 2], wnear);
+    }
+    if (amm_last_block(ticket)) cfinish_build_block(flags, counters, blockstats, (int)gridDim.x, 0);
 }
 
 // ------------------------------------------------------------------------------------------------ traversal
@@ -1634,9 +2009,15 @@ static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const doub
                        cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags, cl->d_flags, force,
                        gf ? gf->d_q : nullptr, gf ? gf->d_hsig : nullptr, gf ? gf->d_seps2 : nullptr, gf ? gf->d_posq_s : (double4 *)nullptr,
                        gf ? gf->d_lj_s : (double2 *)nullptr, (float)cl->rext, L->d_seps2, cl->d_first, Z, copies_current,
-                       count_only ? (double *)nullptr : cl->d_xref);
-    const long threads = (long)cl->grid.ncell * cl->parts * 64;
-    dim3 grid((unsigned)((threads + 255) / 256));
+                       count_only ? (double *)nullptr : cl->d_xref, cl->c_begin, cl->c_end, cl->d_slice_cells);
+    // A rank's slice (rows c_begin .. c_end of the sorted order): blocks for the cells of the slice only (a quarter more than its
+    // share of the cells + 4; the kernels stride over the units should the slice span more), and -- k_cbuild_split -- a block per
+    // (cell, part) with both passes shared out over its wavefronts
+    const bool slice = cl->c_end - cl->c_begin < cl->nc;
+    const bool split = cl->split_parts > 0 && !count_only;
+    const int ncell_grid = slice ? (int)std::min<long>(cl->grid.ncell, (5L * cl->grid.ncell) / (4L * std::max(1, ctx->world)) + 4) : cl->grid.ncell;
+    const long threads = (long)ncell_grid * cl->parts * 64;
+    dim3 grid(split ? (unsigned)(ncell_grid * cl->split_parts) : (unsigned)((threads + 255) / 256));
     CBoxF bf;
     for (int k = 0; k < 3; ++k) {
         bf.L[k] = (float)ctx->box.L[k];
@@ -1646,17 +2027,32 @@ static int cluster_chain(amm_ctx *ctx, PairForce *L, ClusterList *cl, const doub
     const float rn2 = cl->rnear_build > 0 ? (float)(cl->rnear_build * cl->rnear_build) : 3.0e38f;
     const bool use_rint = cl->grid.nc[0] < 5 || cl->grid.nc[1] < 5 || cl->grid.nc[2] < 5;
 #define AMM_LAUNCH_CBUILD(CO, RI)                                                                                                   \
-    hipLaunchKernelGGL((k_cbuild<CO, RI>), grid, dim3(256), 0, st, cl->c_begin, cl->c_end, cl->parts, cl->d_cell_start, cl->d_pos4f, bf, \
-                       cl->grid, rl, rn2, cl->cap, cl->d_nl, cl->d_nnb, cl->d_nnb_near, cl->d_flags, cl->d_blockstats, cl->d_counters,   \
-                       cl->d_ticket + AMM_TICKET_INTS, force)
+    do {                                                                                                                            \
+        if (slice)                                                                                                                  \
+            hipLaunchKernelGGL((k_cbuild<CO, RI, true>), grid, dim3(256), 0, st, cl->c_begin, cl->c_end, cl->parts, cl->d_cell_start,    \
+                               cl->d_pos4f, bf, cl->grid, rl, rn2, cl->cap, cl->d_nl, cl->d_nnb, cl->d_nnb_near, cl->d_flags,            \
+                               cl->d_blockstats, cl->d_counters, cl->d_ticket + AMM_TICKET_INTS, force, cl->d_slice_cells);              \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((k_cbuild<CO, RI, false>), grid, dim3(256), 0, st, cl->c_begin, cl->c_end, cl->parts, cl->d_cell_start,   \
+                               cl->d_pos4f, bf, cl->grid, rl, rn2, cl->cap, cl->d_nl, cl->d_nnb, cl->d_nnb_near, cl->d_flags,            \
+                               cl->d_blockstats, cl->d_counters, cl->d_ticket + AMM_TICKET_INTS, force, cl->d_slice_cells);              \
+    } while (0)
+#define AMM_LAUNCH_CBUILD_SPLIT(RI)                                                                                                  \
+    hipLaunchKernelGGL((k_cbuild_split<RI>), grid, dim3(256), 0, st, cl->c_begin, cl->c_end, cl->split_parts, cl->d_cell_start,     \
+                       cl->d_pos4f, bf, cl->grid, rl, rn2, cl->cap, cl->d_nl, cl->d_nnb, cl->d_nnb_near, cl->d_flags, cl->d_blockstats,  \
+                       cl->d_counters, cl->d_ticket + AMM_TICKET_INTS, force, cl->d_slice_cells)
     if (count_only) {
         if (use_rint) AMM_LAUNCH_CBUILD(true, true);
         else AMM_LAUNCH_CBUILD(true, false);
+    } else if (split) {
+        if (use_rint) AMM_LAUNCH_CBUILD_SPLIT(true);
+        else AMM_LAUNCH_CBUILD_SPLIT(false);
     } else {
         if (use_rint) AMM_LAUNCH_CBUILD(false, true);
         else AMM_LAUNCH_CBUILD(false, false);
     }
 #undef AMM_LAUNCH_CBUILD
+#undef AMM_LAUNCH_CBUILD_SPLIT
     AMM_HIP(hipGetLastError());
     return 0;
 }
@@ -1723,6 +2119,8 @@ static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) 
     AMM_HIP(hipMemset(cl->d_ticket, 0, sizeof(int) * 4 * AMM_TICKET_INTS));
     AMM_HIP(hipMalloc(&cl->d_counters, sizeof(unsigned long long) * 8));
     AMM_HIP(hipMemset(cl->d_counters, 0, sizeof(unsigned long long) * 8));
+    AMM_HIP(hipMalloc(&cl->d_slice_cells, sizeof(int) * 2));
+    AMM_HIP(hipMemset(cl->d_slice_cells, 0, sizeof(int) * 2));
     // lanes per row: 16 rows per wavefront on a whole box; a rank's slice has fewer rows than the persistent grid has wavefronts
     // (256 CUs x 8), so rows are shared out over more lanes until every wavefront has one task (measured on slices of the
     // 98 304-atom box, dual pass: 2 ranks 113 us with 8 lanes; 4 ranks 68 with 16 (107 with 8); 8 ranks 44 with 32 (105 with 8))
@@ -1753,9 +2151,22 @@ static int cluster_first_build(amm_ctx *ctx, PairForce *L, const double *d_pos) 
         cl->parts = std::max(cl->parts, std::min(want, std::min(most, 6)));      // (1/8 slice, us: 3 parts 87, 4 73, 5 67, 6 68, 8 79, 12 83)
     }
     if (ctx->opt_parts > 0) cl->parts = std::max(1, std::min(16, ctx->opt_parts));
+    // split-stream build of a slice (k_cbuild_split; option build_split: -1 = this choice, k = k blocks per cell; default 0 = off -- on
+    // the 1/8 slice of the 98 304-atom box it takes 67 us for the whole chain against 65 of k_cbuild<.., SLICE>):
+    // blocks per cell so that the slice's cells give about one round of resident blocks (four per CU: 40 KB of LDS each), and no
+    // more than give every block a full batch
+    cl->split_parts = 0;
+    if (ctx->world > 1 && ctx->opt_build_split < 0) {
+        const int active_cells = std::max(1, ncell / ctx->world);
+        const int most = std::max(1, (int)std::ceil((double)nc / ncell / CBS_BATCH));
+        cl->split_parts = std::max(1, std::min(std::min(16, most), (1024 + active_cells / 2) / active_cells));
+    }
+    if (ctx->opt_build_split == 0) cl->split_parts = 0;
+    if (ctx->opt_build_split > 0) cl->split_parts = std::min(16, ctx->opt_build_split);
     {
         const long t1 = (long)ncell * cl->parts * 64;
-        AMM_HIP(hipMalloc(&cl->d_blockstats, sizeof(unsigned long long) * 3 * (size_t)((t1 + 255) / 256)));
+        const size_t nblocks = std::max((size_t)((t1 + 255) / 256), (size_t)ncell * (size_t)cl->split_parts);
+        AMM_HIP(hipMalloc(&cl->d_blockstats, sizeof(unsigned long long) * 3 * nblocks));
     }
     // row capacity from the longest row of the whole box (a later rebuild can bring any row into this rank's slice)
     cl->cap = 0;
@@ -1830,7 +2241,7 @@ int amm_cluster_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, doub
     if (!gathered && !copies_current)
         hipLaunchKernelGGL(k_csort_gather, dim3((std::max(cl->nc, Z.n) + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start,
                            cl->d_cell_members, cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0,
-                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, Z, 0, (double *)nullptr);     // flags[8] stays 0: copies only
+                           pf->d_q, pf->d_hsig, pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, Z, 0, (double *)nullptr, 0, 0, (int *)nullptr);     // flags[8] stays 0: copies only
     // (the copies in place are this force's at these positions from here on, whoever wrote them)
     cl->sorted_for = pf;
     cl->sorted_epoch = ctx->pos_epoch;
@@ -2176,7 +2587,7 @@ int amm_cluster_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_p
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(k_csort_gather, dim3((cl->nc + 255) / 256), dim3(256), 0, st, cl->grid.ncell, cl->nc, cl->d_cell_start, cl->d_cell_members,
                        cl->capc, cl->d_cperm, cl->d_aperm, d_pos, ctx->box, cl->d_pos4f, cl->d_flags + 8, cl->d_flags, 0, pf->d_q, pf->d_hsig,
-                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, CZeroRows{0, nullptr, nullptr, nullptr}, 0, (double *)nullptr);
+                       pf->d_seps2, pf->d_posq_s, pf->d_lj_s, (float)cl->rext, L->d_seps2, cl->d_first, CZeroRows{0, nullptr, nullptr, nullptr}, 0, (double *)nullptr, 0, 0, (int *)nullptr);
     if (cl->sorted_for == pf) {        // (this force's copies in place are those of d_pos now)
         cl->sorted_epoch = ctx->pos_epoch;
         cl->sorted_pos = d_pos;
@@ -2252,8 +2663,20 @@ int amm_cluster_row_padding_impl(amm_ctx *ctx, PairForce *pf, long long out[2]) 
 }
 
 int amm_cluster_free(ClusterList *cl) {
+#ifdef AMM_CBS_TIMING
+    {
+        unsigned long long t[8];
+        if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_cbs_t), sizeof(t)) == hipSuccess && t[7])
+            fprintf(stderr, "k_cbuild<SLICE>: %llu busy wavefronts, mean: prologue %.2f us, whole %.2f us, in drains %.2f us (%.2f drains)\n", t[7], t[0] / 100.0 / t[7],
+                    t[1] / 100.0 / t[7], t[2] / 100.0 / t[7], (double)t[3] / t[7]);
+        if (0)
+            fprintf(stderr, "k_cbuild_split, first wavefront of %llu busy blocks, mean clocks (100 MHz): prologue %.2f | pass 1 %.2f wait %.2f | pass 2 %.2f wait %.2f | copy %.2f wait %.2f us\n",
+                    t[7], t[0] / 100.0 / t[7], t[1] / 100.0 / t[7], t[2] / 100.0 / t[7], t[3] / 100.0 / t[7], t[4] / 100.0 / t[7], t[5] / 100.0 / t[7], t[6] / 100.0 / t[7]);
+    }
+#endif
     for (void *q : {(void *)cl->d_spec_count[0], (void *)cl->d_spec_count[1], (void *)cl->d_spec_ticket})
         if (q) (void)hipFree(q);
+    if (cl->d_slice_cells) (void)hipFree(cl->d_slice_cells);
     void *ptrs[] = {cl->d_cell_count, cl->d_cell_start, cl->d_cell_members, cl->d_cperm, cl->d_aperm, cl->d_pos4f, cl->d_xref, cl->d_nl,
                     cl->d_nnb, cl->d_nnb_near, cl->d_flags, cl->d_counters, cl->d_blockstats, cl->d_ticket};
     for (void *p : ptrs)

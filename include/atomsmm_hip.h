@@ -279,7 +279,9 @@ int amm_set_outer_skin(amm_ctx *ctx, double skin_out);
  * rows also for waters that share the box with other atoms, the rest through per-atom rows), "small_group" (1: interaction-group
  * forces with a set of <= 128 atoms are evaluated without a neighbour list), "rest_skin_factor" (Verlet buffer of a hybrid list's
  * per-atom part as a multiple of its molecule rows' buffer, default 2; set before amm_pair_create), "mixed_terms", "tab" (tabulated
- * force-only kernels), "site_trips", "lanes_per_row", "build_parts", "unroll", "dual_unroll", "tab_block", "tab_dual_block",
+ * force-only kernels), "site_trips", "lanes_per_row", "build_parts", "build_split" (molecule rows: the split-stream
+ * list build -- a block per (cell, part), both passes shared out over its four wavefronts; 0 = off (default: not faster than the
+ * one-wavefront build on the slices measured), -1 = for a rank's slice of the rows, k = k blocks per cell; the rows are the same), "unroll", "dual_unroll", "tab_block", "tab_dual_block",
  * "no_dual", "no_defer", "terms_from", "no_term_lanes", "row_phases" (1: the rows a molecule-row traversal cannot deal out in whole
  * rounds of wavefront tasks go out in smaller tasks), "group_candidates" (1: a list-free group force on a fused inner loop walks only
  * the atoms near its small set while a neighbour list of the context vouches for them), "positions_private" (1: the caller promises
@@ -344,7 +346,8 @@ typedef struct {
     int32_t n_candidate_walks;  /* evaluations that walked the candidates only */
     int32_t chargeless;         /* 1: the last force-only evaluation ran the per-atom-row kernel's instantiation without the Coulomb
                                    table (every charge of the force is zero: the Lennard-Jones fluid of BASELINE config C2) */
-    int32_t reserved_;
+    int32_t build_split;        /* molecule rows: blocks per cell of the split-stream list build (a rank's slice of the rows: the four
+                                   wavefronts of a block share one cell's candidate stream); 0: one wavefront per (cell, part) */
 } amm_pair_stats;
 int amm_pair_get_stats(amm_ctx *ctx, int32_t force_id, amm_pair_stats *out);   /* synchronises */
 /* Measurement helper (bench.py): the number of directed list entries of this force with r < r_within at d_pos, counted in

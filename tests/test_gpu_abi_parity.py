@@ -1374,6 +1374,47 @@ def test_c3_full_size_one_slice_of_eight_with_the_products_lanes():
     ctx.close()
 
 
+@pytest.mark.parametrize('nside,world,rank', [(32, 8, 3), (16, 4, 1), (8, 2, 1)])
+def test_split_stream_slice_build_writes_the_same_rows(nside, world, rank):
+    """The list build of a rank's slice (k_cbuild<.., SPLIT>: a block per (cell, part), the cell's candidate stream split over the block's
+    four wavefronts, partial rows joined in wavefront order = stream order) must write the rows of the one-wavefront build entry for
+    entry: the forces of the slice -- sums in row order -- agree BIT FOR BIT with option build_split = 0, at the first build and after a
+    rebuild at moved positions; nside 8 is a box of fewer than five cells per edge (the per-pair-image variant of the kernel)."""
+    B = _backend()
+    from atomsmm_amd.testing import tip3p_box
+    c = tip3p_box(nside)
+    n = len(c['positions'])
+    dn = near('force-switch', 0.7, 0.5)
+    dd = O.desc(O.DAMPED, rc=1.0, rswitch=0.9, alpha=2.9, degree=1)
+    rng = np.random.default_rng(5)
+    moved = c['positions'] + rng.normal(0.0, 0.05, (n // 3, 3)).repeat(3, axis=0)          # (whole molecules, beyond half the Verlet buffer: a rebuild)
+    results = {}
+    for split in (0, -1, 2):
+        ctx = B.HipContext(n, c['box'], rank=rank, world=world)
+        ctx.set_option('build_split', split)
+        fn, fd = hip_pair(B, ctx, dn, c), hip_pair(B, ctx, dd, c)
+        ctx.pair_share_list(fn, fd)
+        out = []
+        for pos in (c['positions'], moved):
+            x = dev(pos)
+            fa = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+            fb = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+            ctx.force_eval(fd, x, fa)
+            ctx.force_eval(fn, x, fb)
+            out += [fa.cpu().numpy().copy(), fb.cpu().numpy().copy()]
+        ctx.check()
+        st = ctx.pair_stats(fd)
+        assert st['list_kind'] == 1 and st['n_builds'] == 2
+        assert (st['build_split'] > 0) == (split != 0) and (split <= 0 or st['build_split'] == split)
+        results[split] = (out, st['n_list_pairs'])
+        ctx.close()
+    for split in (-1, 2):
+        assert results[split][1] == results[0][1]
+        for a, b in zip(results[split][0], results[0][0]):
+            assert np.array_equal(a, b)
+    assert np.abs(results[0][0][0]).max() > 1.0
+
+
 def test_list_free_group_force_reports_overflow(heaq):
     """The list-free interaction-group path (csrc/group.hip) sums the forces on the small set in 64-bit fixed point (+-8.4e6 kJ/mol/nm at
     2^-40): a solute atom pushed INTO a solvent atom (r = 0.005 nm, Lennard-Jones force ~1e20) must be reported by amm_check, not
