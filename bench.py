@@ -97,6 +97,9 @@ def build_simulation_c5(loops, dt_fs, afed_substeps=2, skin=None):
     return simulation, case
 
 
+C2_SKIN_NM = 0.2
+
+
 def bench_c2(args, torch):
     """Config C2 of BASELINE.json: 32 768-atom Lennard-Jones fluid (atomsmm_amd.testing.lj_fluid, rho sigma^3 = 0.8), the ONLY force a
     NearNonbondedForce(2.5 sigma, 0.9 x that, 'force-switch') imported from the NonbondedForce (forces.py:655-670), fp64, one GPU;
@@ -118,8 +121,11 @@ def bench_c2(args, torch):
     near = atomsmm.NearNonbondedForce(rc * unit.nanometers, rs * unit.nanometers, 'force-switch').importFrom(nb)
     near.addTo(system)
     integrator = atomsmm.UnconstrainedVelocityVerletPropagator().integrator(dt_fs * unit.femtoseconds)
-    simulation = app.Simulation(app.Topology(n), system, integrator, openmm.Platform.getPlatformByName('HIP'),
-                                dict([('Skin', str(args.skin))] if args.skin is not None else []) or None)
+    # Verlet buffer: the slow atoms of a 100 K Lennard-Jones fluid want a wider one than the library's default of 0.1 nm (made for
+    # water's hydrogens at 4 fs): 0.2 nm -- 40 instead of 16 steps between list builds -- measured on the scan 0.06 ... 0.30 nm
+    # (profiles/r05_c2_skin_scan.txt: 6690 / 7490 at 0.1 / 8110 at 0.18-0.26 / 7890 ns/day); `--skin` overrides
+    skin = args.skin if args.skin is not None else C2_SKIN_NM
+    simulation = app.Simulation(app.Topology(n), system, integrator, openmm.Platform.getPlatformByName('HIP'), {'Skin': str(skin)})
     simulation.context.setPositions(case['positions'] * unit.nanometers)
     simulation.context.setVelocities(case['velocities'])
     eng = simulation.context._engine
@@ -149,8 +155,8 @@ def bench_c2(args, torch):
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'C2: %d-atom Lennard-Jones fluid (L = %.3f nm, rho sigma^3 = 0.8), NearNonbondedForce(%.3f, %.3f, force-switch) '
-                               'only, velocity Verlet at %.0f fs' % (n, case['box'][0], rc, rs, dt_fs),
-                   'atoms': n, 'step_fs': dt_fs, 'relax_steps': relaxed, 'parallelism': 'single GPU',
+                               'only, velocity Verlet at %.0f fs; Verlet buffer %.2f nm' % (n, case['box'][0], rc, rs, dt_fs, skin),
+                   'atoms': n, 'step_fs': dt_fs, 'verlet_buffer_nm': skin, 'relax_steps': relaxed, 'parallelism': 'single GPU',
                    'temperature_K_end': round(temperature(eng, torch), 1)},
         'roofline': {'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': stored.get('c2_near', {}).get('hbm_bytes_per_launch'),

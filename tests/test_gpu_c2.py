@@ -39,7 +39,7 @@ def test_c2_full_size_velocity_verlet_vs_oracle():
     rc, rs, dt = 2.5 * sigma, 0.9 * 2.5 * sigma, 0.004
     rng = np.random.default_rng(7)
     case['velocities'] = rng.normal(size=(n, 3)) * np.sqrt(KB * 100.0 / case['mass'])[:, None]
-    simulation = _c2_simulation(case, rc, rs, 4.0)
+    simulation = _c2_simulation(case, rc, rs, 4.0, {'Skin': '0.2'})          # (the Verlet buffer bench.py's C2 leg runs with: C2_SKIN_NM)
     d = O.desc(O.ADJ['force-switch'], rc=rc, rc0=rc, rs0=rs)
     force = lambda p: O.pair_eval(d, p, case['box'], case['charge'], case['sigma'], case['epsilon'], None, use_cells=True)[1]
     x, v, m = case['positions'].copy(), case['velocities'].copy(), case['mass']
