@@ -35,7 +35,7 @@ EXPORTS = [
     'amm_move', 'amm_copy', 'amm_mvv', 'amm_bind_state', 'amm_bind_buffer', 'amm_group_define', 'amm_run_ops',
     'amm_set_fuse_inner', 'amm_set_outer_skin',
     'amm_pair_get_stats', 'amm_profile_enable', 'amm_profile_read', 'amm_pair_count_within', 'amm_pair_row_padding', 'amm_kernel_revision',
-    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_expr_eval', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_bath_define_nhl', 'amm_bath_define_sin', 'amm_iso_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
+    'amm_pme_create', 'amm_pme_set_charges', 'amm_pme_set_sliced', 'amm_pair_set_lambda', 'amm_pair_set_lambda_dev', 'amm_expr_eval', 'amm_expr_eval_scalar', 'amm_expr_define', 'amm_expr_seed', 'amm_bath_define', 'amm_bath_define_nhl', 'amm_bath_define_sin', 'amm_iso_define', 'amm_pair_energy_derivative', 'amm_constraints_create', 'amm_pair_set_scale',
     'amm_comm_unique_id', 'amm_comm_init', 'amm_comm_destroy', 'amm_comm_allreduce', 'amm_comm_stats', 'amm_group_set_exchange', 'amm_bind_exchange', 'amm_exchange_finish',
     'amm_set_option', 'amm_positions_changed', 'amm_exchange_per', 'amm_run_stats', 'amm_run_ops_from', 'amm_exchange_pending',
 ]
@@ -176,6 +176,8 @@ def lib():
         L.amm_pme_set_charges.argtypes = [vp, C.c_int32, dp]
         L.amm_pme_set_sliced.argtypes = [vp, C.c_int32, C.c_int32]
         L.amm_pair_set_lambda.argtypes = [vp, C.c_int32, C.c_double]
+        L.amm_pair_set_lambda_dev.argtypes = [vp, C.c_int32, vp]
+        L.amm_expr_eval_scalar.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, vp, C.c_int32]
         L.amm_pair_set_scale.argtypes = [vp, C.c_int32, C.c_double]
         L.amm_expr_define.argtypes = [vp, ip, C.c_int32, dp, C.c_int32, dp, C.c_int32, ip]
         L.amm_expr_seed.argtypes = [vp, C.c_uint64]
@@ -309,6 +311,19 @@ class HipContext:
 
     def pair_set_lambda(self, fid, value):
         _chk(lib().amm_pair_set_lambda(self.h, fid, float(value)))
+
+    def pair_set_lambda_dev(self, fid, scalars, index):
+        """lambda of a softcore force = scalars[index] (device tensor of doubles) at every later launch; scalars = None: back to the
+        number of the last pair_set_lambda."""
+        ptr = None if scalars is None else C.c_void_p(scalars.data_ptr() + 8 * int(index))
+        _chk(lib().amm_pair_set_lambda_dev(self.h, fid, ptr))
+
+    def expr_eval_scalar(self, code, consts, scalars):
+        """Run a scalar program (atomsmm_amd.expr.compile_scalar pieces, each closed by OUT dst): scalars[dst] <- value, in order; DEVG
+        operands are entries of `scalars`."""
+        c_, cp = _hi(code)
+        k_, kp = _hd(consts if len(consts) else [0.0])
+        _chk(lib().amm_expr_eval_scalar(self.h, cp, len(c_), kp, len(consts), _ptr(scalars), int(scalars.numel())))
 
     def bonded_create(self):
         fid = C.c_int32(-1)

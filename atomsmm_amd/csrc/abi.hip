@@ -334,7 +334,23 @@ int amm_pair_set_lambda(amm_ctx *ctx, int32_t force_id, double value) {
         return 1;
     }
     pf->desc.alpha = value;
+    pf->d_lambda_dev = nullptr;        // (a number from the host replaces a device-resident lambda)
     return amm_pair_build_consts(pf->desc, pf->pc);
+}
+
+int amm_pair_set_lambda_dev(amm_ctx *ctx, int32_t force_id, const double *d_lambda) {
+    PairForce *pf = get_pair(ctx, force_id);
+    if (!pf) return 1;
+    if (pf->desc.family != AMM_SOFTCORE) {
+        amm_set_error("amm_pair_set_lambda_dev: not a softcore pair force");
+        return 1;
+    }
+    if (d_lambda && !(pf->small && ctx->opt_small_group && amm_small_group_supported(pf))) {
+        amm_set_error("amm_pair_set_lambda_dev: only the list-free evaluation of a softcore force with a small set reads lambda from the device");
+        return 1;
+    }
+    pf->d_lambda_dev = d_lambda;
+    return 0;
 }
 
 int amm_pair_set_scale(amm_ctx *ctx, int32_t force_id, double scale) {
@@ -730,6 +746,15 @@ int amm_expr_eval(amm_ctx *ctx, const int32_t *code, int32_t n_code, const doubl
     }
     if (d_dst) ctx->pos_epoch++;          // (the destination may be the position buffer, or alias it)
     return amm_expr_eval_impl(ctx, code, n_code, consts, n_consts, globals, n_globals, seed, counter, d_dst, d_sum);
+}
+
+int amm_expr_eval_scalar(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts, double *d_scalars,
+                         int32_t n_scalars) {
+    if (!ctx || !code || (n_consts > 0 && !consts) || !d_scalars) {
+        amm_set_error("amm_expr_eval_scalar: bad arguments");
+        return 1;
+    }
+    return amm_expr_eval_scalar_impl(ctx, code, n_code, consts, n_consts, d_scalars, n_scalars);
 }
 
 int amm_constraints_create(amm_ctx *ctx, const int32_t *h_pairs, const double *h_dist, int32_t n_constraints, double tolerance) {

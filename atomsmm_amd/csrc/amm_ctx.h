@@ -91,6 +91,7 @@ struct PairForce {
     double *d_tab_ss = nullptr;    // site-site table [nint - ss_first][6] (molecule-row kernels); null: none
     double ss_error = 0;           // its largest relative interpolation error
     double ss_built_for[3] = {0, 0, 0};     // (sigma/2, 2 sqrt(eps), q) the tables were last built for
+    const double *d_lambda_dev = nullptr;      // softcore family: lambda is read from this device scalar at launch time (amm_pair_set_lambda_dev)
     bool all_q_zero = false;       // every charge is zero (set_params): the per-atom-row kernel has an instantiation without the Coulomb table
     int last_chargeless = 0;       // ... and the last force-only evaluation ran it (statistics)
     int last_fused = 0;            // 1: the last force-only evaluation rode on the list owner's launch (molecule rows, fused pass)
@@ -477,6 +478,8 @@ int amm_pme_set_charges_impl(amm_ctx *ctx, PmeForce *pm, const double *h_q);
 int amm_pme_eval_impl(amm_ctx *ctx, PmeForce *pm, const double *d_pos, double *d_force, int accumulate, double *d_energy);
 int amm_pme_set_sliced_impl(PmeForce *pm, int on);
 int amm_pme_free(PmeForce *pm);
+int amm_expr_eval_scalar_impl(amm_ctx *ctx, const int32_t *code, int n_code, const double *consts, int n_consts, double *d_scalars,
+                              int n_scalars);
 int amm_expr_eval_impl(amm_ctx *ctx, const int32_t *code, int n_code, const double *consts, int n_consts, const double *globals,
                        int n_globals, unsigned long long seed, unsigned long long counter, double *d_dst, double *d_sum);
 int amm_kick_impl(amm_ctx *ctx, double *d_v, const double *d_f, const double *d_f2, int plus, const double *d_mass, double coef);

@@ -34,13 +34,145 @@ __global__ void __launch_bounds__(256) k_expr(int n3, ExprProg P, double *dst, d
 
 int amm_reduce_add(amm_ctx *ctx, const double *d_part, int n, double scale, double *d_out);
 
+// Scalars of a host-walked program: scalars[dst] <- expression for a sequence of assignments (X_OUT closes each), whose X_DEVG
+// operands are other entries of `scalars` (device memory).  CustomIntegrator.addComputeGlobal steps whose operands wait on device
+// results -- the extended variable's block of AdiabaticDynamicsIntegrator (integrators.py:701-737): lambda moves, reflects at the
+// walls, its Nose-Hoover thermostat acts, all on numbers that depend on deriv(energy, lambda) sums still in flight.  One thread
+// interprets; the block's threads stage the program in LDS first.
+__global__ void __launch_bounds__(64) k_expr_scalar(ScalarProg P, double *scalars) {
+    __shared__ int s_code[AMM_SCALAR_MAXCODE];
+    __shared__ double s_const[AMM_SCALAR_MAXCONST];
+    __shared__ double st[AMM_EXPR_STACK], loc[AMM_EXPR_LOCALS];
+    for (int k = threadIdx.x; k < P.ncode; k += 64) s_code[k] = P.code[k];
+    for (int k = threadIdx.x; k < P.nconst; k += 64) s_const[k] = P.consts[k];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int sp = 0;
+    for (int pc = 0; pc < P.ncode; ++pc) {
+        const int word = s_code[pc], op = word & 0xff, arg = word >> 8;
+        switch (op) {
+        case X_CONST: st[sp++] = s_const[arg]; break;
+        case X_DEVG: st[sp++] = scalars[arg]; break;
+        case X_OUT: scalars[arg] = st[--sp]; break;
+        case X_LOAD: st[sp++] = loc[arg]; break;
+        case X_STORE: loc[arg] = st[--sp]; break;
+        case X_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+        case X_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+        case X_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+        case X_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+        case X_NEG: st[sp - 1] = -st[sp - 1]; break;
+        case X_POW: sp--; st[sp - 1] = pow(st[sp - 1], st[sp]); break;
+        case X_POWI: {
+            const double b = st[sp - 1];
+            int e = arg < 0 ? -arg : arg;
+            double r = 1.0, q = b;
+            while (e) {
+                if (e & 1) r *= q;
+                q *= q;
+                e >>= 1;
+            }
+            st[sp - 1] = arg < 0 ? 1.0 / r : r;
+        } break;
+        case X_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
+        case X_EXP: st[sp - 1] = exp(st[sp - 1]); break;
+        case X_LOG: st[sp - 1] = log(st[sp - 1]); break;
+        case X_SIN: st[sp - 1] = sin(st[sp - 1]); break;
+        case X_COS: st[sp - 1] = cos(st[sp - 1]); break;
+        case X_TAN: st[sp - 1] = tan(st[sp - 1]); break;
+        case X_ASIN: st[sp - 1] = asin(st[sp - 1]); break;
+        case X_ACOS: st[sp - 1] = acos(st[sp - 1]); break;
+        case X_ATAN: st[sp - 1] = atan(st[sp - 1]); break;
+        case X_SINH: st[sp - 1] = sinh(st[sp - 1]); break;
+        case X_COSH: st[sp - 1] = cosh(st[sp - 1]); break;
+        case X_TANH: st[sp - 1] = tanh(st[sp - 1]); break;
+        case X_ERF: st[sp - 1] = erf(st[sp - 1]); break;
+        case X_ERFC: st[sp - 1] = erfc(st[sp - 1]); break;
+        case X_ABS: st[sp - 1] = fabs(st[sp - 1]); break;
+        case X_FLOOR: st[sp - 1] = floor(st[sp - 1]); break;
+        case X_CEIL: st[sp - 1] = ceil(st[sp - 1]); break;
+        case X_STEP: st[sp - 1] = st[sp - 1] >= 0.0 ? 1.0 : 0.0; break;
+        case X_DELTA: st[sp - 1] = st[sp - 1] == 0.0 ? 1.0 : 0.0; break;
+        case X_MIN: sp--; st[sp - 1] = fmin(st[sp - 1], st[sp]); break;
+        case X_MAX: sp--; st[sp - 1] = fmax(st[sp - 1], st[sp]); break;
+        case X_SELECT: sp -= 2; st[sp - 1] = st[sp - 1] != 0.0 ? st[sp] : st[sp + 1]; break;
+        case X_ATAN2: sp--; st[sp - 1] = atan2(st[sp - 1], st[sp]); break;
+        default: break;
+        }
+    }
+}
+
+static int expr_fill(amm_ctx *ctx, ExprProg &P, const int32_t *code, int n_code, const double *consts, int n_consts, const double *globals,
+                     int n_globals, bool per_dof);
+
+int amm_expr_eval_scalar_impl(amm_ctx *ctx, const int32_t *code, int n_code, const double *consts, int n_consts, double *d_scalars,
+                              int n_scalars) {
+    if (n_code < 1 || n_code > AMM_SCALAR_MAXCODE || n_consts > AMM_SCALAR_MAXCONST) {
+        amm_set_error("amm_expr_eval_scalar: program too long (code <= 640, constants <= 96)");
+        return 1;
+    }
+    // validate on the host: the kernel indexes without checks
+    ScalarProg P;
+    P.ncode = n_code;
+    P.nconst = n_consts;
+    int depth = 0, max_depth = 0, outs = 0;
+    for (int k = 0; k < n_code && depth >= 0; ++k) {
+        P.code[k] = code[k];
+        const int op = code[k] & 0xff, arg = code[k] >> 8;
+        int push = 0, pop = 0;
+        switch (op) {
+        case X_CONST: push = 1; if (arg < 0 || arg >= n_consts) depth = -1000; break;
+        case X_DEVG: push = 1; if (arg < 0 || arg >= n_scalars) depth = -1000; break;
+        case X_OUT: pop = 1; outs++; if (arg < 0 || arg >= n_scalars || depth != 1) depth = -1000; break;
+        case X_LOAD: push = 1; if (arg < 0 || arg >= AMM_EXPR_LOCALS) depth = -1000; break;
+        case X_STORE: pop = 1; if (arg < 0 || arg >= AMM_EXPR_LOCALS) depth = -1000; break;
+        case X_ADD: case X_SUB: case X_MUL: case X_DIV: case X_POW: case X_MIN: case X_MAX: case X_ATAN2: pop = 2; push = 1; break;
+        case X_SELECT: pop = 3; push = 1; break;
+        case X_NEG: case X_POWI: case X_SQRT: case X_EXP: case X_LOG: case X_SIN: case X_COS: case X_TAN: case X_ASIN: case X_ACOS:
+        case X_ATAN: case X_SINH: case X_COSH: case X_TANH: case X_ERF: case X_ERFC: case X_ABS: case X_FLOOR: case X_CEIL:
+        case X_STEP: case X_DELTA: pop = 1; push = 1; break;
+        default: depth = -1000; break;        // (no per-DOF operands, no random draws: the host makes those)
+        }
+        depth -= pop;
+        if (depth < 0) break;
+        depth += push;
+        max_depth = std::max(max_depth, depth);
+    }
+    if (depth != 0 || outs == 0 || max_depth > AMM_EXPR_STACK) {
+        amm_set_error("amm_expr_eval_scalar: malformed program (bad operand, stack discipline, or an assignment left open)");
+        return 1;
+    }
+    for (int k = 0; k < n_consts; ++k) P.consts[k] = consts[k];
+    hipLaunchKernelGGL(k_expr_scalar, dim3(1), dim3(64), 0, ctx->stream, P, d_scalars);
+    AMM_HIP(hipGetLastError());
+    return 0;
+}
+
 int amm_expr_eval_impl(amm_ctx *ctx, const int32_t *code, int n_code, const double *consts, int n_consts, const double *globals,
                        int n_globals, unsigned long long seed, unsigned long long counter, double *d_dst, double *d_sum) {
+    ExprProg P;
+    if (expr_fill(ctx, P, code, n_code, consts, n_consts, globals, n_globals, true)) return 1;
+    P.mass = ctx->d_mass;
+    P.seed = seed;
+    P.counter = counter;
+    const int n3 = 3 * ctx->n, nblk = (n3 + 255) / 256;
+    if (d_sum && !ctx->d_expr_part) AMM_HIP(hipMalloc(&ctx->d_expr_part, sizeof(double) * nblk));
+    hipLaunchKernelGGL(k_expr, dim3(nblk), dim3(256), 0, ctx->stream, n3, P, d_dst, d_sum ? ctx->d_expr_part : (double *)nullptr);
+    AMM_HIP(hipGetLastError());
+    if (d_sum) {
+        AMM_HIP(hipMemsetAsync(d_sum, 0, sizeof(double), ctx->stream));
+        if (amm_reduce_add(ctx, ctx->d_expr_part, nblk, 1.0, d_sum)) return 1;
+    }
+    if (d_dst == ctx->d_x) ctx->pos_epoch++;
+    return 0;
+}
+
+// validate a postfix program on the host (the kernels index without checks) and copy it into the launch argument
+static int expr_fill(amm_ctx *ctx, ExprProg &P, const int32_t *code, int n_code, const double *consts, int n_consts, const double *globals,
+                     int n_globals, bool per_dof) {
     if (n_code < 1 || n_code > AMM_EXPR_MAXCODE || n_consts > AMM_EXPR_MAXCONST || n_globals > AMM_EXPR_MAXGLOBAL) {
         amm_set_error("amm_expr_eval: program too long (code <= 256, constants <= 48, globals <= 48)");
         return 1;
     }
-    ExprProg P;
     P.ncode = n_code;
     int depth = 0, max_depth = 0;
     for (int k = 0; k < n_code; ++k) {
@@ -51,9 +183,9 @@ int amm_expr_eval_impl(amm_ctx *ctx, const int32_t *code, int n_code, const doub
         switch (op) {
         case X_CONST: push = 1; if (arg < 0 || arg >= n_consts) depth = -1000; break;
         case X_GLOBAL: push = 1; if (arg < 0 || arg >= n_globals) depth = -1000; break;
-        case X_BUF: push = 1; if (arg < 0 || arg >= AMM_MAX_SLOTS || !ctx->slots[arg]) depth = -1000; break;
-        case X_MASS: push = 1; if (!ctx->d_mass) depth = -1000; break;
-        case X_GAUSS: case X_UNIFORM: push = 1; break;
+        case X_BUF: push = 1; if (!per_dof || arg < 0 || arg >= AMM_MAX_SLOTS || !ctx->slots[arg]) depth = -1000; break;
+        case X_MASS: push = 1; if (!per_dof || !ctx->d_mass) depth = -1000; break;
+        case X_GAUSS: case X_UNIFORM: push = 1; if (!per_dof) depth = -1000; break;      // (a scalar's random draws are made by the host)
         case X_LOAD: push = 1; if (arg < 0 || arg >= AMM_EXPR_LOCALS) depth = -1000; break;
         case X_STORE: pop = 1; if (arg < 0 || arg >= AMM_EXPR_LOCALS) depth = -1000; break;
         case X_ADD: case X_SUB: case X_MUL: case X_DIV: case X_POW: case X_MIN: case X_MAX: case X_ATAN2: pop = 2; push = 1; break;
@@ -75,18 +207,6 @@ int amm_expr_eval_impl(amm_ctx *ctx, const int32_t *code, int n_code, const doub
     for (int k = 0; k < n_consts; ++k) P.consts[k] = consts[k];
     for (int k = 0; k < n_globals; ++k) P.globals[k] = globals[k];
     for (int k = 0; k < AMM_MAX_SLOTS; ++k) P.bufs[k] = ctx->slots[k];
-    P.mass = ctx->d_mass;
-    P.seed = seed;
-    P.counter = counter;
-    const int n3 = 3 * ctx->n, nblk = (n3 + 255) / 256;
-    if (d_sum && !ctx->d_expr_part) AMM_HIP(hipMalloc(&ctx->d_expr_part, sizeof(double) * nblk));
-    hipLaunchKernelGGL(k_expr, dim3(nblk), dim3(256), 0, ctx->stream, n3, P, d_dst, d_sum ? ctx->d_expr_part : (double *)nullptr);
-    AMM_HIP(hipGetLastError());
-    if (d_sum) {
-        AMM_HIP(hipMemsetAsync(d_sum, 0, sizeof(double), ctx->stream));
-        if (amm_reduce_add(ctx, ctx->d_expr_part, nblk, 1.0, d_sum)) return 1;
-    }
-    if (d_dst == ctx->d_x) ctx->pos_epoch++;
     return 0;
 }
 

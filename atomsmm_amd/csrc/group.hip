@@ -78,6 +78,7 @@ struct SmallArgs {
     double r2cand;                 // (rc + 2 skin)^2
     int *cand;                     // [n]
     int *cstate;                   // [0] candidates [1] companion build they belong to [2] append cursor (zero between launches)
+    const double *lambda_dev;      // softcore family: lambda (PairConsts::alpha) is this device scalar, not the launch argument's (or nullptr)
 };
 
 // Term evaluation of a bond-list set that shares the force group with this pair force (amm_run_ops: the group of the innermost RESPA
@@ -93,7 +94,9 @@ struct TermsWork {
 };
 
 template <int FAM, bool GUARD, bool EN, bool GROUPED>
-__global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c, TermsWork T) {
+__global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c_launch, TermsWork T) {
+    PairConsts c = c_launch;
+    if (FAM == AMM_SOFTCORE && A.lambda_dev) c.alpha = A.lambda_dev[0];       // (amm_pair_set_lambda_dev: an AFED step left it on the device)
     __shared__ double4 s_pos[AMM_SMALL_MAX];          // x, y, z, Kc q
     __shared__ double2 s_lj[AMM_SMALL_MAX];
     __shared__ long long s_tr[4][12][65];             // per wavefront: the twelve reaction components of a trip, [value][lane], fixed point
@@ -476,6 +479,7 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     A.r2cand = 0.0;
     A.cand = nullptr;
     A.cstate = nullptr;
+    A.lambda_dev = pf->d_lambda_dev;
     // candidates: when the caller takes the rows from the force's own buffer (the fused inner loop), or when it wants the energy
     // alone (rows_unused: deriv(energy, lambda) -- d_force is scratch, only the candidates' rows are written)
     if ((own_rows ? !d_energy : (rows_unused && d_energy)) && ctx->opt_group_candidates && ctx->world == 1 && !accumulate) {

@@ -2094,7 +2094,13 @@ int amm_pair_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, double 
             if (pf->pc.degree == 1) launch_pair<AMM_DAMPED, 1>(grid, block, st, false, en, A, pf->pc);
             else launch_pair<AMM_DAMPED, 0>(grid, block, st, false, en, A, pf->pc);
             break;
-        case AMM_SOFTCORE: launch_pair<AMM_SOFTCORE, 0>(grid, block, st, false, en, A, pf->pc); break;
+        case AMM_SOFTCORE:
+            if (pf->d_lambda_dev) {       // (amm_pair_set_lambda_dev: only the list-free kernel reads lambda from the device)
+                amm_set_error("softcore force with lambda on the device evaluated through its neighbour list: call amm_pair_set_lambda first");
+                return 1;
+            }
+            launch_pair<AMM_SOFTCORE, 0>(grid, block, st, false, en, A, pf->pc);
+            break;
         case AMM_LJ_VIRIAL: launch_pair<AMM_LJ_VIRIAL, 0>(grid, block, st, false, en, A, pf->pc); break;
         case AMM_NONBONDED:
             if (pf->pc.cmode == 1) launch_pair<AMM_NONBONDED, 1>(grid, block, st, false, en, A, pf->pc);

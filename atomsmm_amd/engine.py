@@ -40,6 +40,7 @@ _AUX_FORCE = re.compile(r'_f[0-9]*_')      # auxiliary buffers of multi-force ex
 _NO_ALIAS = os.environ.get('AMM_NO_ALIAS') is not None      # tuning knob (A/B)
 # host-walked step programs evaluate the same few dozen texts every step: compiled code, split conditions, symbol lists
 _CODE_CACHE, _CONDITION_CACHE, _PER_DOF_SYMBOLS = {}, {}, {}
+_SCALARS = 2048        # device scalars of a host-walked program: deriv(energy, p) sums in flight and the globals computed from them
 _COMPARE = {'<': lambda a, b: a < b, '>': lambda a, b: a > b, '<=': lambda a, b: a <= b, '>=': lambda a, b: a >= b,
             '=': lambda a, b: a == b, '!=': lambda a, b: a != b}
 _context_factory = B.HipContext   # the only backend; tests of the host logic substitute a call recorder
@@ -333,6 +334,11 @@ class Engine:
         self._emit_memo = {}        # what the per-DOF steps of a host-walked program emit (_emit_per_dof_memo)
         self._segment_memo, self._segment_ends, self._segment_symbols, self._segment_open = {}, {}, {}, None      # ... and whole runs of them
         self._pending = None        # device scalars that deferred globals wait for: (buffer, number in use)
+        self._device_params = {}    # Context parameters whose number is a device scalar for now (name -> [pair force ids]): AFED's lambda
+        self._scalar_code, self._scalar_consts = [], []      # assignments to device scalars not yet launched (one launch per batch)
+        self._lrc_on_device = {}    # (pair force, lambda's scalar) -> the correction's lambda-derivative there
+        self.n_scalar_evals = self.n_scalar_launches = self.n_settles = 0     # (tests / bench: global expressions evaluated on the device, blocking reads of the scalars)
+        self.device_globals = True  # nonlinear uses of deferred globals are evaluated on the device (amm_expr_eval_scalar) instead of waited for
         self._valid = {}
         self._interpreted = None    # None: undecided; True: general (host-walked) step programs
         self._static_exprs = False
@@ -869,9 +875,21 @@ class Engine:
                 value = (quadrature(parameters, lam_value + h)[1] - quadrature(parameters, lam_value - h)[1]) / (2 * h)
             return value * (parameters[scale_name] if scale_name else 1.0)
 
+        def derivative_polynomial(parameters):
+            """d(correction)/d(lambda) on [0, 1] as monomial coefficients in u = 2 lambda - 1 (lowest first), for the evaluation on
+            the device while lambda lives there (amm_expr_eval_scalar: Horner) -- the interpolant's derivative, as constant_derivative."""
+            if not use_lrc:
+                return []
+            record = classes_of(parameters)
+            if len(record) < 5:          # (made once per set of offset parameters, like the interpolant)
+                record.append([float(c) for c in np.polynomial.chebyshev.cheb2poly(on_unit_interval(parameters)[1].coef)])
+            scale = parameters[scale_name] if scale_name else 1.0
+            return record[4] if scale == 1.0 else [c * scale for c in record[4]]
+
         entry.constant = constant(self.parameters)
         lam = set(names) | {lam_name} | ({scale_name} if scale_name else set())
-        entry.softcore = dict(pid=pid, lambda_name=lam_name, constant=constant, constant_derivative=constant_derivative, depends=lam)
+        entry.softcore = dict(pid=pid, lambda_name=lam_name, constant=constant, constant_derivative=constant_derivative, depends=lam,
+                              use_lrc=bool(use_lrc), derivative_polynomial=derivative_polynomial)
 
         def update(parameters, changed):
             if not (lam & changed):
@@ -2001,34 +2019,134 @@ class Engine:
             value = self.energy_derivative(name)
         else:
             if self._pending is None:
-                self._pending = [self.torch.zeros(64, dtype=self.torch.float64, device=self.x.device), 0]
+                self._pending = [self.torch.zeros(_SCALARS, dtype=self.torch.float64, device=self.x.device), 0]
             value = 0.0
             for entry in self.entries:
                 sc = entry.softcore
                 if sc is not None and sc['lambda_name'] == name:
-                    if self._pending[1] >= 64:
+                    if self._pending[1] >= _SCALARS:
                         settle()
                     slot = self._pending[1]
                     self._pending[1] += 1
+                    self._flush_scalars()                 # (lambda itself may be an assignment still queued)
                     self.ctx.pair_energy_derivative(sc['pid'], self.x, self._pending[0][slot:slot + 1])
-                    value = value + X.Deferred(sc['constant_derivative'](self.parameters), {slot: 1.0})
+                    lam = self.parameters[sc['lambda_name']]
+                    if isinstance(lam, X.Deferred):       # lambda is a device scalar: so is the correction's derivative at it
+                        coef = sc['derivative_polynomial'](self.parameters)
+                        if coef:
+                            key = (sc['pid'], tuple(sorted(lam.terms.items())), lam.const)
+                            if key not in self._lrc_on_device:
+                                text = repr(coef[-1])
+                                for c in reversed(coef[:-1]):
+                                    text = '(%s)*u+%r' % (text, c)
+                                self._lrc_on_device = {key: self._eval_global_on_device(text + '; u = 2*lam-1', {'lam': lam}, None, settle)}
+                            value = value + self._lrc_on_device[key]
+                        value = value + X.Deferred(0.0, {slot: 1.0})
+                    else:
+                        value = value + X.Deferred(sc['constant_derivative'](self.parameters), {slot: 1.0})
         self._deriv_cache[name] = value
         return value
+
+    def _device_scalars_ok(self):
+        """Deferred globals may be worked on where they are: single rank (the ranks' partial sums are added up at a settle), a
+        backend with the scalar kernel."""
+        return self.device_globals and not self._coll and hasattr(self.ctx, 'expr_eval_scalar')
+
+    def _scalar_slot(self, settle):
+        if self._pending is None:
+            self._pending = [self.torch.zeros(_SCALARS, dtype=self.torch.float64, device=self.x.device), 0]
+        if self._pending[1] >= _SCALARS:
+            settle()
+        slot = self._pending[1]
+        self._pending[1] += 1
+        return slot
+
+    def _eval_global_on_device(self, expr, env, rng, settle, predicate=None, keep=None):
+        """A global expression whose operands wait on device results, evaluated by one thread on the stream (amm_expr_eval_scalar):
+        its value is a new device scalar, the host goes on without it (AFED: integrators.py:701-737, the extended variable's move,
+        walls and thermostat).  Returns the Deferred that names the scalar."""
+        prog = X.compile_scalar(expr, env, rng, predicate, keep)
+        self.n_scalar_evals += 1
+        slot = self._scalar_slot(settle)
+        # queued: consecutive assignments go out as ONE launch (_flush_scalars: before anything that reads a scalar is enqueued)
+        if len(self._scalar_code) + len(prog.code) + 1 > 640 or len(self._scalar_consts) + len(prog.consts) > 96:
+            self._flush_scalars()
+        base = len(self._scalar_consts)
+        const_op = X.OPCODES['CONST']
+        self._scalar_code += [w + (base << 8) if (w & 0xff) == const_op else w for w in prog.code]
+        self._scalar_code.append(X.OPCODES['OUT'] | (slot << 8))
+        self._scalar_consts += prog.consts
+        return X.Deferred(0.0, {slot: 1.0})
+
+    def _flush_scalars(self):
+        if self._scalar_code:
+            self.ctx.expr_eval_scalar(self._scalar_code, self._scalar_consts, self._pending[0])
+            self.n_scalar_launches += 1
+            self._scalar_code, self._scalar_consts = [], []
+
+    def _parameter_to_device(self, name, value, settle):
+        """context.setParameter(name, <a device scalar>): possible when every force that depends on the parameter is a softcore
+        pair force with this lambda and the list-free kernel (its long-range correction's derivative follows as a polynomial) -- the
+        solute-solvent force of SolvationSystem under AFED.  Returns False when the number is needed after all."""
+        pids = []
+        for entry in self.entries:
+            sc = entry.softcore
+            if sc is not None and name in sc['depends']:
+                if sc['lambda_name'] != name:
+                    return False
+                pids.append(sc['pid'])
+            elif name in getattr(entry, 'depends', ()):
+                return False
+        if not pids:
+            return False
+        if len(value.terms) != 1 or value.const != 0.0 or list(value.terms.values()) != [1.0]:
+            value = self._eval_global_on_device('__v', {'__v': value}, None, settle)         # (a linear form: one scalar of its own)
+        slot = next(iter(value.terms))
+        try:
+            for pid in pids:
+                self.ctx.pair_set_lambda_dev(pid, self._pending[0], slot)
+        except B.HipError:
+            for pid in pids:
+                self.ctx.pair_set_lambda_dev(pid, None, 0)
+            return False
+        self.parameters[name] = value
+        self._device_params[name] = pids
+        groups = {e.group for e in self.entries if e.softcore is not None and e.softcore['pid'] in pids}
+        for g in self._valid:
+            if g in groups or g == 'all':
+                self._valid[g] = False
+        self._deriv_cache.clear()
+        self._programs.clear()
+        return True
 
     def _settle(self, containers):
         """Read the pending device scalars (one synchronising copy; summed over the ranks first) and turn every deferred
         global in `containers` (dicts / lists) into its number."""
         if self._pending is None or self._pending[1] == 0:
             return
+        self._flush_scalars()
+        self._lrc_on_device = {}
         buf, used = self._pending
         if self._coll:
             self._allreduce(buf)
         values = buf[:used].cpu().numpy()
+        self.n_settles += 1
         for box in containers + [self._deriv_cache]:
             keys = range(len(box)) if isinstance(box, list) else list(box)
             for k in keys:
                 if isinstance(box[k], X.Deferred):
                     box[k] = box[k].resolve(values)
+        # Context parameters that lived on the device (an extended variable between two reads): the host has their numbers again, and
+        # the library its launch argument -- the same value its kernels read from the scalar until now: no force becomes stale
+        for name, pids in self._device_params.items():
+            value = self.parameters[name].resolve(values)
+            self.parameters[name] = value
+            for pid in pids:
+                self.ctx.pair_set_lambda(pid, value)
+            for entry in self.entries:
+                if entry.softcore is not None and entry.softcore['pid'] in pids:
+                    entry.constant = entry.softcore['constant'](self.parameters)
+        self._device_params = {}
         buf.zero_()
         self._pending[1] = 0
 
@@ -2075,16 +2193,25 @@ class Engine:
             # -- at config C5 the GPU sat idle for 0.26 ms per AFED step behind the read of deriv(energy, lambda)
             eager = [0]
 
+            preds = []          # if-blocks whose condition waits on the device: [end pc, predicate] (their steps are evaluated there, predicated)
+
             def settle():
                 if self._pending is not None and self._pending[1] > 0 and not self._has_constraints:
                     eager[0] = 3          # (constraint ops stay in one batch with the move they follow)
-                self._settle([env, integ._gvalues])
+                if self._device_params:
+                    flush()               # (launches recorded so far read the parameter where it is now)
+                held = [p[1] for p in preds]
+                self._settle([env, integ._gvalues, held])
+                for p, value in zip(preds, held):
+                    p[1] = value
 
             def deferred_in(text):
                 """Does the expression name a global whose number is still on the device?"""
                 if self._pending is None or self._pending[1] == 0:
                     return False
-                return any(isinstance(env.get(name), X.Deferred) for name in X.symbols(text))
+                m = re.match(r'^(.*?)(<=|>=|!=|=|<|>)(.*)$', text) if re.search(r'[<>=]', text) else None      # (a block's condition)
+                names = X.symbols(m.group(1)) | X.symbols(m.group(3)) if m else X.symbols(text)
+                return any(isinstance(env.get(name), X.Deferred) for name in names)
 
             env['__deriv__'] = lambda what, name: self._deriv_deferred(what, name, settle)
             valid = self._valid
@@ -2094,6 +2221,7 @@ class Engine:
             def flush():
                 # (a run of per-DOF steps that is being recorded as one unit is no unit any more: the ops before the flush are gone)
                 self._segment_open = None
+                self._flush_scalars()         # (assignments to device scalars queued so far: the launches below may read them)
                 if ops:
                     # a RESPA block between two host-evaluated steps is a static run of ops: pair the near and the outer
                     # evaluation of one list into a single traversal, as the compiled path does
@@ -2116,6 +2244,8 @@ class Engine:
                 if guard > 2_000_000:
                     raise RuntimeError('step program does not terminate')
                 kind, target, expr = steps[pc]
+                if self._pending is not None and self._pending[1] > _SCALARS - 64:
+                    settle()            # (room for the scalars a step may ask for; what was deferred is a number from here on)
                 if kind == C.ComputePerDof:
                     # a straight run of per-DOF steps (a RESPA block of the atoms inside an AFED step: ~60 kicks, moves and
                     # copies) emits the same ops whenever the globals it names, the valid force groups and the mirrored buffers
@@ -2132,19 +2262,45 @@ class Engine:
                     if 'deriv(' in expr:
                         flush()                                   # the derivative is taken at the current positions
                     rng_state = self._host_rng.bit_generator.state
-                    try:
-                        value = X.eval_global(expr, env, self._host_rng)
-                    except X.NeedsValue:                          # more than sums and multiples of a deferred global
-                        self._host_rng.bit_generator.state = rng_state
-                        settle()
-                        value = X.eval_global(expr, env, self._host_rng)
+                    pred = preds[-1][1] if preds else None
+                    if isinstance(pred, X.Deferred):
+                        # inside an if-block whose condition is still on the device: target <- select(condition, expression, target)
+                        value = self._eval_global_on_device(expr, env, self._host_rng, settle, pred, env[target])
+                    elif pred is not None and not pred:
+                        pc += 1                                   # (the condition was read after all, and is false)
+                        continue
+                    else:
+                        try:
+                            value = X.eval_global(expr, env, self._host_rng)
+                        except X.NeedsValue:                      # more than sums and multiples of a deferred global
+                            self._host_rng.bit_generator.state = rng_state
+                            value = None
+                            if self._device_scalars_ok():
+                                try:
+                                    value = self._eval_global_on_device(expr, env, self._host_rng, settle)
+                                except (X.NeedsValue, X.ExpressionError):
+                                    self._host_rng.bit_generator.state = rng_state
+                                    value = None
+                            if value is None:
+                                settle()
+                                value = X.eval_global(expr, env, self._host_rng)
                     if target in self.parameters and target not in integ._gnames:
-                        if isinstance(value, X.Deferred):         # a Context parameter needs its number
-                            env[target] = value
-                            settle()
-                            value = env[target]
-                        if value != self.parameters[target]:
+                        done = False
+                        if isinstance(value, X.Deferred):         # a Context parameter: on the device if its forces can read it there
+                            if self._device_scalars_ok():
+                                flush()
+                                done = self._parameter_to_device(target, value, settle)
+                                if done:
+                                    value = self.parameters[target]
+                                    valid = self._valid
+                            if not done:
+                                env[target] = value
+                                settle()
+                                value = env[target]
+                        if not done and (isinstance(self.parameters[target], X.Deferred) or value != self.parameters[target]):
                             flush()
+                            if isinstance(self.parameters[target], X.Deferred):
+                                settle()
                             self.set_parameter(target, value)     # an extended-system variable (AFED): forces change
                             valid = self._valid
                     env[target] = value
@@ -2189,10 +2345,24 @@ class Engine:
                     pass
                 elif kind in (C.IfBlock, C.WhileBlock):
                     if deferred_in(expr):
+                        body = steps[pc + 1:match[pc]]
+                        if (kind == C.IfBlock and self._device_scalars_ok() and body and all(b[0] == C.ComputeGlobal for b in body)
+                                and not any('deriv(' in b[2] for b in body)):
+                            # the condition stays on the device (1 or 0) and the block's steps are evaluated there, predicated --
+                            # the reflecting walls of an extended variable (integrators.py:701-714)
+                            lhs, op, rhs = re.match(r'^(.*?)(<=|>=|!=|=|<|>)(.*)$', expr).groups()
+                            diff = '((%s)-(%s))' % (lhs, rhs)
+                            text = {'=': 'delta(%s)', '!=': '1-delta(%s)', '>=': 'step(%s)', '<': '1-step(%s)',
+                                    '<=': 'step(-%s)', '>': '1-step(-%s)'}[op] % diff
+                            preds.append([match[pc], self._eval_global_on_device(text, env, None, settle)])
+                            pc += 1
+                            continue
                         settle()
                     if not self._condition(expr, env):
                         pc = match[pc]
                 elif kind == C.EndBlock:
+                    if preds and preds[-1][0] == pc:
+                        preds.pop()
                     if steps[match[pc]][0] == C.WhileBlock:
                         pc = match[pc] - 1
                 pc += 1

@@ -14,7 +14,7 @@ import math
 import re
 
 OPCODES = dict(
-    CONST=0, GLOBAL=1, BUF=2, MASS=3, GAUSS=4, UNIFORM=5, LOAD=6, STORE=7,
+    CONST=0, GLOBAL=1, BUF=2, MASS=3, GAUSS=4, UNIFORM=5, LOAD=6, STORE=7, DEVG=8, OUT=9,
     ADD=10, SUB=11, MUL=12, DIV=13, NEG=14, POW=15, POWI=16,
     sqrt=20, exp=21, log=22, sin=23, cos=24, tan=25, asin=26, acos=27, atan=28, sinh=29, cosh=30, tanh=31, erf=32,
     erfc=33, abs=34, floor=35, ceil=36, step=37, delta=38, min=39, max=40, select=41, atan2=42)
@@ -216,6 +216,96 @@ def compile_per_dof(text, resolve):
             raise ExpressionError('unsupported syntax in expression: ' + ast.dump(node))
 
     gen(_parse(main))
+    return prog
+
+
+def compile_scalar(text, env, rng=None, predicate=None, keep=None):
+    """Compile a GLOBAL expression (addComputeGlobal) whose operands include deferred values (Deferred: const + sum coef * scalar[k],
+    the scalars living in a device buffer) into a postfix program for amm_expr_eval_scalar: numbers become constants, a Deferred its
+    linear form over DEVG operands, `deriv(energy, p)` what env['__deriv__'] returns, `gaussian` / `uniform` one host draw each.
+    `predicate` / `keep` (values as in env): the program's value is select(predicate, expression, keep) -- a step inside an
+    if-block whose condition waits on the device."""
+    main, defs = split_definitions(text)
+    prog = Program()
+    local_of, in_progress, draws = {}, set(), {}
+
+    def value(v):
+        if isinstance(v, Deferred):
+            prog.emit('CONST', prog.const(v.const))
+            for k, coef in sorted(v.terms.items()):
+                prog.emit('DEVG', k)
+                if coef != 1.0:
+                    prog.emit('CONST', prog.const(coef))
+                    prog.emit('MUL')
+                prog.emit('ADD')
+        else:
+            prog.emit('CONST', prog.const(float(v)))
+
+    def gen(node):
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)):
+            prog.emit('CONST', prog.const(node.value))
+        elif isinstance(node, ast.Name):
+            name = node.id
+            if name in defs:
+                if name not in local_of:
+                    if name in in_progress:
+                        raise ExpressionError('circular auxiliary definition: ' + name)
+                    if len(local_of) + len(in_progress) >= MAX_LOCALS:
+                        raise ExpressionError('too many auxiliary definitions')
+                    in_progress.add(name)
+                    gen(_parse(defs[name]))
+                    in_progress.discard(name)
+                    local_of[name] = len(local_of)
+                    prog.emit('STORE', local_of[name])
+                prog.emit('LOAD', local_of[name])
+            elif name in ('gaussian', 'uniform', 'random'):
+                key = 'gaussian' if name == 'gaussian' else 'uniform'
+                if key not in draws:
+                    if rng is None:
+                        raise ExpressionError('random numbers in a global expression need a generator')
+                    draws[key] = float(rng.standard_normal()) if key == 'gaussian' else float(rng.random())
+                prog.emit('CONST', prog.const(draws[key]))
+            elif name in env and not callable(env[name]):
+                value(env[name])
+            else:
+                raise ExpressionError('unknown symbol in global expression: ' + name)
+        elif isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            gen(node.operand)
+            if isinstance(node.op, ast.USub):
+                prog.emit('NEG')
+        elif isinstance(node, ast.BinOp) and isinstance(node.op, (ast.Add, ast.Sub, ast.Mult, ast.Div, ast.Pow)):
+            if isinstance(node.op, ast.Pow):
+                e = node.right
+                neg = isinstance(e, ast.UnaryOp) and isinstance(e.op, ast.USub)
+                ev = e.operand if neg else e
+                if isinstance(ev, ast.Constant) and float(ev.value) == int(ev.value) and abs(int(ev.value)) < 1 << 20:
+                    gen(node.left)
+                    prog.emit('POWI', -int(ev.value) if neg else int(ev.value))
+                    return
+            gen(node.left)
+            gen(node.right)
+            prog.emit({ast.Add: 'ADD', ast.Sub: 'SUB', ast.Mult: 'MUL', ast.Div: 'DIV', ast.Pow: 'POW'}[type(node.op)])
+        elif isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == 'deriv' and len(node.args) == 2 \
+                and all(isinstance(a, ast.Name) for a in node.args):
+            if '__deriv__' not in env:
+                raise ExpressionError('deriv() is not available in this context')
+            value(env['__deriv__'](node.args[0].id, node.args[1].id))
+        elif isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and not node.keywords:
+            fn = node.func.id
+            if fn not in OPCODES or fn.isupper() or len(node.args) != _ARITY.get(fn, 1):
+                raise ExpressionError('unsupported function call: %s/%d' % (fn, len(node.args)))
+            for a in node.args:
+                gen(a)
+            prog.emit(fn)
+        else:
+            raise ExpressionError('unsupported syntax in expression: ' + ast.dump(node))
+
+    if predicate is not None:
+        value(predicate)
+    gen(_parse(main))
+    if predicate is not None:
+        value(keep)
+        prog.emit('select')
     return prog
 
 

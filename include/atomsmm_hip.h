@@ -186,6 +186,10 @@ int amm_pair_share_list(amm_ctx *ctx, int32_t force_id, int32_t host_id);
 /* CustomBondForce / HarmonicBondForce / HarmonicAngleForce term lists of one force group. */
 /* context.setParameter('lambda_vdw', value) for a softcore pair force (systems.py:267: global parameter). */
 int amm_pair_set_lambda(amm_ctx *ctx, int32_t force_id, double value);
+/* The same with lambda left on the device (an AFED step moves it with amm_expr_eval_scalar): the force's kernels read *d_lambda at
+ * launch time from now on; NULL, or a later amm_pair_set_lambda, returns to the host's number.  Only the list-free evaluation of a
+ * softcore force with a small set (csrc/group.hip: what SolvationSystem's solute gets) supports it; others return an error. */
+int amm_pair_set_lambda_dev(amm_ctx *ctx, int32_t force_id, const double *d_lambda);
 /* Overall factor of a pair force (desc.sign): a global parameter that multiplies the whole energy -- `respa_switch`, or
  * the coupling function of a CustomCVForce over this force (systems.py:738-772) -- changed by setParameter. */
 int amm_pair_set_scale(amm_ctx *ctx, int32_t force_id, double scale);
@@ -237,6 +241,15 @@ int amm_mvv(amm_ctx *ctx, const double *d_v, const double *d_m, double *d_out); 
  * may be one of the bound buffers) receives the per-DOF values, *d_sum (device) their sum; either may be NULL. */
 int amm_expr_eval(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
                   const double *globals, int32_t n_globals, uint64_t seed, uint64_t counter, double *d_dst, double *d_sum);
+
+/* CustomIntegrator.addComputeGlobal(variable, expression) whose operands wait on device results -- the extended variable's scalar
+ * block of AdiabaticDynamicsIntegrator (integrators.py:701-737: lambda moves, reflects, is thermostatted, all on sums of
+ * deriv(energy, lambda) that kernels already enqueued will leave in device memory).  The postfix program is a sequence of
+ * assignments, each closed by X_OUT dst: d_scalars[dst] <- the value on the stack; X_DEVG operands are other entries of d_scalars
+ * (n_scalars doubles, device; later assignments see earlier ones); constants as in amm_expr_eval, no per-DOF operands, no random
+ * draws (the host makes those); <= 640 words, <= 96 constants.  One thread on the context's stream; the host never waits. */
+int amm_expr_eval_scalar(amm_ctx *ctx, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts, double *d_scalars,
+                         int32_t n_scalars);
 
 /* System.addConstraint(i, j, distance) x n (forcefield.createSystem(constraints=HBonds, rigidWater=True) in the
  * reference's tests, tests/test_propagators.py:11-18).  Clusters of coupled constraints (<= 8 atoms, <= 16 constraints)

@@ -318,3 +318,51 @@ def test_far_flag_raised_by_the_kicks_and_move_launch():
     assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
     assert np.isfinite(results[0][0]).all()
     assert results[0][3] == pytest.approx(results[1][3], rel=1e-10) and results[0][3] != 0.0
+
+
+def _afed_context(case, lam, v_lam, device_globals):
+    respa = build_c5_system(case)
+    inner = atomsmm.RespaPropagator([2, 2, 1]).integrator(1 * unit.femtoseconds)
+    var = atomsmm.ExtendedSystemVariable('lambda_vdw', 50, 2.5, 20 * unit.femtoseconds)
+    integrator = atomsmm.AdiabaticDynamicsIntegrator(inner, 2, [var])
+    context = openmm.Context(respa, integrator)
+    context._engine.device_globals = device_globals
+    context.setPositions(case['positions'] * unit.nanometers)
+    context.setVelocities(case['velocities'])
+    context.setParameter('lambda_vdw', lam)
+    integrator.step(0)
+    integrator.setGlobalVariableByName('_v_lambda_vdw', v_lam)
+    integrator.setGlobalVariableByName('_v_eta_lambda_vdw', 0.0)
+    return context, integrator
+
+
+@pytest.mark.parametrize('lam,v_lam', [(0.8, 0.05), (0.9985, 2.0)])
+def test_afed_scalar_block_on_the_device(lam, v_lam):
+    """AdiabaticDynamicsIntegrator's extended-variable block (integrators.py:701-737: lambda moves, reflects at the walls, its
+    Nose-Hoover thermostat acts) runs on the device while its operands -- sums of deriv(energy, lambda) -- are still in flight
+    (amm_expr_eval_scalar), the softcore kernels read lambda where it is (amm_pair_set_lambda_dev), and the host reads the scalars once
+    per step() CALL instead of once per AFED step.  Six steps in one call against the waiting path (engine.device_globals = False) and
+    against the CPU oracle; (0.9985, 2.0): lambda crosses 1 in the first step, the reflection (an if-block) is evaluated predicated."""
+    case = solvated_chain(nside=12, n_chain=300, n_solute=30)
+    ref = AfedCPU(case, loops=(2, 2, 1), dt=0.001, nsteps=2, mass=50.0, kT=2.5, tau=0.02, lam=lam, v_lam=v_lam)
+    ref.step(6)
+    out = {}
+    for mode in (True, False):
+        context, integrator = _afed_context(case, lam, v_lam, mode)
+        eng = context._engine
+        integrator.step(6)
+        out[mode] = (context.getState(getPositions=True).getPositions(asNumpy=True)._value, context.getParameter('lambda_vdw'),
+                     integrator.getGlobalVariableByName('_v_lambda_vdw'), integrator.getGlobalVariableByName('_v_eta_lambda_vdw'),
+                     eng.n_scalar_evals, eng.n_settles, eng.n_scalar_launches)
+        eng.ctx.check()
+    dev, host = out[True], out[False]
+    assert dev[4] >= 6 * 5 and host[4] == 0                 # the block's nonlinear steps (and the walls' test) ran on the device ...
+    assert 6 <= dev[6] <= 6 * 6                              # ... as a few launches per AFED step (consecutive assignments share one) ...
+    assert dev[5] <= 2 and host[5] >= 6                      # ... and the scalars were read once, at the end of the call
+    assert np.abs(dev[0] - host[0]).max() < 1e-10
+    for k in (1, 2, 3):
+        assert dev[k] == pytest.approx(host[k], rel=1e-10, abs=1e-12)
+    assert np.abs(dev[0] - ref.x).max() < 1e-9
+    assert dev[1] == pytest.approx(ref.lam, abs=1e-9) and dev[2] == pytest.approx(ref.v_lam, rel=1e-6, abs=1e-9)
+    if lam > 0.99:
+        assert 0.9 < dev[1] < 1.0 and dev[2] < 1.0           # it bounced off the wall at 1 in the first half move (0.9985 + 0.002 x 2.0 > 1)
