@@ -78,6 +78,7 @@ struct SmallArgs {
     double r2cand;                 // (rc + 2 skin)^2
     int *cand;                     // [n]
     int *cstate;                   // [0] candidates [1] companion build they belong to [2] append cursor (zero between launches)
+    double *eout;                  // EN: the last block adds the blocks' energies to *eout (the order of k_reduce_add: no launch of its own)
     const double *lambda_dev;      // softcore family: lambda (PairConsts::alpha) is this device scalar, not the launch argument's (or nullptr)
 };
 
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c_l
     // a candidate walk needs few of the blocks; the others leave at once and the ticket counts the rest
     const int walkers = full ? npb : max(1, min(npb, (ncand + 63) >> 6));
     if (pb >= walkers) {
-        if (EN && threadIdx.x == 0) A.epart[blockIdx.x] = 0.0;
+        if (EN && threadIdx.x == 0) amm_st_l2((unsigned long long *)&A.epart[blockIdx.x], 0ull);
         return;
     }
     const int ticket_n = full ? (int)gridDim.x : T.nblocks + walkers;
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c_l
 #pragma unroll
                 for (int x = 0; x < 3; ++x) out[3 * r + x] = fo[r][x];
         }
-        if (EN && threadIdx.x == 0) A.epart[blockIdx.x] = 0.0;
+        if (EN && threadIdx.x == 0) amm_st_l2((unsigned long long *)&A.epart[blockIdx.x], 0ull);
     }
     const double guard2 = GUARD ? c.rc0 * c.rc0 : 0.0;
     double esum = 0.0;
@@ -332,12 +333,27 @@ __global__ void __launch_bounds__(256) k_small_group(SmallArgs A, PairConsts c_l
         for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off);
         if (lane == 0) red[w] = esum;
         __syncthreads();
-        if (threadIdx.x == 0) A.epart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];       // every pair once: no factor 1/2
+        // (through L2: the last block reads it)
+        if (threadIdx.x == 0) amm_st_l2((unsigned long long *)&A.epart[blockIdx.x], (unsigned long long)__double_as_longlong(((red[0] + red[1]) + red[2]) + red[3]));       // every pair once: no factor 1/2
     }
 #if AMM_SG_EXP == 2            // measurement only: no ticket, no tail
     return;
 #endif
     if (!(full ? amm_last_block(A.ticket) : amm_last_of(A.ticket, ticket_n))) return;
+    if (EN && A.eout) {
+        // the blocks' energies, added up as k_reduce_add does (256 strided partial sums, then a tree): blocks that did not walk hold 0
+        __shared__ double sh[256];
+        double s = 0.0;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+            s += i < ticket_n ? __longlong_as_double((long long)amm_ld_l2((const unsigned long long *)&A.epart[i])) : 0.0;
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) A.eout[0] += sh[0];
+    }
     if (!full && threadIdx.x == 0) A.cstate[3] += 1;
     if (listing && threadIdx.x == 0) {         // the list this launch made serves from the next launch on
         A.cstate[0] = amm_ld_l2(&A.cstate[2]);
@@ -480,6 +496,7 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     A.cand = nullptr;
     A.cstate = nullptr;
     A.lambda_dev = pf->d_lambda_dev;
+    A.eout = d_energy;
     // candidates: when the caller takes the rows from the force's own buffer (the fused inner loop), or when it wants the energy
     // alone (rows_unused: deriv(energy, lambda) -- d_force is scratch, only the candidates' rows are written)
     if ((own_rows ? !d_energy : (rows_unused && d_energy)) && ctx->opt_group_candidates && ctx->world == 1 && !accumulate) {
@@ -560,7 +577,6 @@ int amm_small_group_eval_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos, 
     else launch_small<AMM_NONBONDED, true>(st, grid, false, en, A, pf->pc, T);
     if (timed) AMM_HIP(hipEventRecord(e1, st));
     AMM_HIP(hipGetLastError());
-    if (en && amm_reduce_add(ctx, sg->d_epart, grid, 1.0, d_energy)) return 1;
     pf->n_evals++;
     pf->last_kind = 3;
     return 0;
