@@ -11,6 +11,7 @@
 // `gaussian`/`uniform` within the expression, launch counter): reproducible whatever the launch geometry, and the
 // same stream on every rank (ranks integrate all atoms redundantly and must stay in lock-step).
 #include "amm_ctx.h"
+#include "device_utils.h"
 
 #include "expr_vm.h"
 
@@ -37,68 +38,108 @@ int amm_reduce_add(amm_ctx *ctx, const double *d_part, int n, double scale, doub
 // Scalars of a host-walked program: scalars[dst] <- expression for a sequence of assignments (X_OUT closes each), whose X_DEVG
 // operands are other entries of `scalars` (device memory).  CustomIntegrator.addComputeGlobal steps whose operands wait on device
 // results -- the extended variable's block of AdiabaticDynamicsIntegrator (integrators.py:701-737): lambda moves, reflects at the
-// walls, its Nose-Hoover thermostat acts, all on numbers that depend on deriv(energy, lambda) sums still in flight.  One thread
-// interprets; the block's threads stage the program in LDS first.
+// walls, its Nose-Hoover thermostat acts, all on numbers that depend on deriv(energy, lambda) sums still in flight.
+// One wavefront, every lane doing the same: the program word comes by v_readlane from a register that holds 64 words of the code
+// (refilled from LDS every 64 words), constants, stack and locals live one per LANE in registers (push = a select on the lane index,
+// pop = v_readlane with a scalar index): no memory access on the interpreter's critical path but the scalars themselves.  (Stack and
+// code in LDS took 0.25 us per word, in private memory and the launch argument 0.6.)
 __global__ void __launch_bounds__(64) k_expr_scalar(ScalarProg P, double *scalars) {
     __shared__ int s_code[AMM_SCALAR_MAXCODE];
-    __shared__ double s_const[AMM_SCALAR_MAXCONST];
-    __shared__ double st[AMM_EXPR_STACK], loc[AMM_EXPR_LOCALS];
-    for (int k = threadIdx.x; k < P.ncode; k += 64) s_code[k] = P.code[k];
-    for (int k = threadIdx.x; k < P.nconst; k += 64) s_const[k] = P.consts[k];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < P.ncode; k += 64) s_code[k] = P.code[k];
+    const double c_lo = lane < P.nconst ? P.consts[lane] : 0.0, c_hi = 64 + lane < P.nconst ? P.consts[64 + lane] : 0.0;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    int sp = 0;
+    auto lane_of = [&](double v, int l) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+        return __hiloint2double(hi, lo);
+    };
+    double stk = 0.0, locals = 0.0;       // lane k: stack slot k / local k
+    int sp = 0, chunk = 0;
+#define X_PUSH(x) do { const double x_ = (x); stk = lane == sp ? x_ : stk; ++sp; } while (0)
+#define X_POP() (--sp, lane_of(stk, sp))
+#define X_UN(expr) do { const double a = X_POP(); X_PUSH(expr); } while (0)
+#define X_BIN(expr) do { const double b = X_POP(); const double a = X_POP(); X_PUSH(expr); } while (0)
     for (int pc = 0; pc < P.ncode; ++pc) {
-        const int word = s_code[pc], op = word & 0xff, arg = word >> 8;
+        if ((pc & 63) == 0) chunk = s_code[min(pc + lane, AMM_SCALAR_MAXCODE - 1)];
+        const int word = __builtin_amdgcn_readlane(chunk, pc & 63), op = word & 0xff, arg = word >> 8;
+        // the frequent words first, one test each (a lone wavefront pays ~40 cycles per TAKEN branch: the compiler's decision tree
+        // over all 40 opcodes cost six of them per word)
+        if (op == X_CONST) { X_PUSH(arg < 64 ? lane_of(c_lo, arg) : lane_of(c_hi, arg - 64)); continue; }
+        if (op == X_MUL) { X_BIN(a * b); continue; }
+        if (op == X_ADD) { X_BIN(a + b); continue; }
+        if (op == X_LOAD) { X_PUSH(lane_of(locals, arg)); continue; }
+        if (op == X_DEVG) { X_PUSH(__longlong_as_double((long long)amm_ld_l2((const unsigned long long *)&scalars[arg]))); continue; }
+        if (op == X_SUB) { X_BIN(a - b); continue; }
+        if (op == X_HORNER) {        // top <- top * local 0 + constant: one step of a polynomial in the first auxiliary definition
+            const double a = X_POP();
+            X_PUSH(fma(a, lane_of(locals, 0), arg < 64 ? lane_of(c_lo, arg) : lane_of(c_hi, arg - 64)));
+            continue;
+        }
         switch (op) {
-        case X_CONST: st[sp++] = s_const[arg]; break;
-        case X_DEVG: st[sp++] = scalars[arg]; break;
-        case X_OUT: scalars[arg] = st[--sp]; break;
-        case X_LOAD: st[sp++] = loc[arg]; break;
-        case X_STORE: loc[arg] = st[--sp]; break;
-        case X_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
-        case X_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
-        case X_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
-        case X_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
-        case X_NEG: st[sp - 1] = -st[sp - 1]; break;
-        case X_POW: sp--; st[sp - 1] = pow(st[sp - 1], st[sp]); break;
+        case X_CONST: X_PUSH(arg < 64 ? lane_of(c_lo, arg) : lane_of(c_hi, arg - 64)); break;
+        case X_DEVG: X_PUSH(__longlong_as_double((long long)amm_ld_l2((const unsigned long long *)&scalars[arg]))); break;      // (through L2: an X_OUT of this program may have written it)
+        case X_OUT: {
+            const double a = X_POP();
+            if (lane == 0) amm_st_l2((unsigned long long *)&scalars[arg], (unsigned long long)__double_as_longlong(a));
+            __builtin_amdgcn_s_waitcnt(0);        // (a later X_DEVG of this program may read it)
+        } break;
+        case X_LOAD: X_PUSH(lane_of(locals, arg)); break;
+        case X_STORE: {
+            const double a = X_POP();
+            locals = lane == arg ? a : locals;
+        } break;
+        case X_ADD: X_BIN(a + b); break;
+        case X_SUB: X_BIN(a - b); break;
+        case X_MUL: X_BIN(a * b); break;
+        case X_DIV: X_BIN(a / b); break;
+        case X_NEG: X_UN(-a); break;
+        case X_POW: X_BIN(pow(a, b)); break;
         case X_POWI: {
-            const double b = st[sp - 1];
+            const double base = X_POP();
             int e = arg < 0 ? -arg : arg;
-            double r = 1.0, q = b;
+            double r = 1.0, q = base;
             while (e) {
                 if (e & 1) r *= q;
                 q *= q;
                 e >>= 1;
             }
-            st[sp - 1] = arg < 0 ? 1.0 / r : r;
+            X_PUSH(arg < 0 ? 1.0 / r : r);
         } break;
-        case X_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
-        case X_EXP: st[sp - 1] = exp(st[sp - 1]); break;
-        case X_LOG: st[sp - 1] = log(st[sp - 1]); break;
-        case X_SIN: st[sp - 1] = sin(st[sp - 1]); break;
-        case X_COS: st[sp - 1] = cos(st[sp - 1]); break;
-        case X_TAN: st[sp - 1] = tan(st[sp - 1]); break;
-        case X_ASIN: st[sp - 1] = asin(st[sp - 1]); break;
-        case X_ACOS: st[sp - 1] = acos(st[sp - 1]); break;
-        case X_ATAN: st[sp - 1] = atan(st[sp - 1]); break;
-        case X_SINH: st[sp - 1] = sinh(st[sp - 1]); break;
-        case X_COSH: st[sp - 1] = cosh(st[sp - 1]); break;
-        case X_TANH: st[sp - 1] = tanh(st[sp - 1]); break;
-        case X_ERF: st[sp - 1] = erf(st[sp - 1]); break;
-        case X_ERFC: st[sp - 1] = erfc(st[sp - 1]); break;
-        case X_ABS: st[sp - 1] = fabs(st[sp - 1]); break;
-        case X_FLOOR: st[sp - 1] = floor(st[sp - 1]); break;
-        case X_CEIL: st[sp - 1] = ceil(st[sp - 1]); break;
-        case X_STEP: st[sp - 1] = st[sp - 1] >= 0.0 ? 1.0 : 0.0; break;
-        case X_DELTA: st[sp - 1] = st[sp - 1] == 0.0 ? 1.0 : 0.0; break;
-        case X_MIN: sp--; st[sp - 1] = fmin(st[sp - 1], st[sp]); break;
-        case X_MAX: sp--; st[sp - 1] = fmax(st[sp - 1], st[sp]); break;
-        case X_SELECT: sp -= 2; st[sp - 1] = st[sp - 1] != 0.0 ? st[sp] : st[sp + 1]; break;
-        case X_ATAN2: sp--; st[sp - 1] = atan2(st[sp - 1], st[sp]); break;
+        case X_SQRT: X_UN(sqrt(a)); break;
+        case X_EXP: X_UN(exp(a)); break;
+        case X_LOG: X_UN(log(a)); break;
+        case X_SIN: X_UN(sin(a)); break;
+        case X_COS: X_UN(cos(a)); break;
+        case X_TAN: X_UN(tan(a)); break;
+        case X_ASIN: X_UN(asin(a)); break;
+        case X_ACOS: X_UN(acos(a)); break;
+        case X_ATAN: X_UN(atan(a)); break;
+        case X_SINH: X_UN(sinh(a)); break;
+        case X_COSH: X_UN(cosh(a)); break;
+        case X_TANH: X_UN(tanh(a)); break;
+        case X_ERF: X_UN(erf(a)); break;
+        case X_ERFC: X_UN(erfc(a)); break;
+        case X_ABS: X_UN(fabs(a)); break;
+        case X_FLOOR: X_UN(floor(a)); break;
+        case X_CEIL: X_UN(ceil(a)); break;
+        case X_STEP: X_UN(a >= 0.0 ? 1.0 : 0.0); break;
+        case X_DELTA: X_UN(a == 0.0 ? 1.0 : 0.0); break;
+        case X_MIN: X_BIN(fmin(a, b)); break;
+        case X_MAX: X_BIN(fmax(a, b)); break;
+        case X_ATAN2: X_BIN(atan2(a, b)); break;
+        case X_SELECT: {
+            const double no = X_POP();
+            const double yes = X_POP();
+            const double cond = X_POP();
+            X_PUSH(cond != 0.0 ? yes : no);
+        } break;
         default: break;
         }
     }
+#undef X_PUSH
+#undef X_POP
+#undef X_UN
+#undef X_BIN
 }
 
 static int expr_fill(amm_ctx *ctx, ExprProg &P, const int32_t *code, int n_code, const double *consts, int n_consts, const double *globals,
@@ -122,6 +163,7 @@ int amm_expr_eval_scalar_impl(amm_ctx *ctx, const int32_t *code, int n_code, con
         switch (op) {
         case X_CONST: push = 1; if (arg < 0 || arg >= n_consts) depth = -1000; break;
         case X_DEVG: push = 1; if (arg < 0 || arg >= n_scalars) depth = -1000; break;
+        case X_HORNER: pop = 1; push = 1; if (arg < 0 || arg >= n_consts) depth = -1000; break;
         case X_OUT: pop = 1; outs++; if (arg < 0 || arg >= n_scalars || depth != 1) depth = -1000; break;
         case X_LOAD: push = 1; if (arg < 0 || arg >= AMM_EXPR_LOCALS) depth = -1000; break;
         case X_STORE: pop = 1; if (arg < 0 || arg >= AMM_EXPR_LOCALS) depth = -1000; break;

@@ -10,7 +10,7 @@
 #define AMM_EXPR_LOCALS 16
 
 enum {
-    X_CONST = 0, X_GLOBAL = 1, X_BUF = 2, X_MASS = 3, X_GAUSS = 4, X_UNIFORM = 5, X_LOAD = 6, X_STORE = 7, X_DEVG = 8, X_OUT = 9,
+    X_CONST = 0, X_GLOBAL = 1, X_BUF = 2, X_MASS = 3, X_GAUSS = 4, X_UNIFORM = 5, X_LOAD = 6, X_STORE = 7, X_DEVG = 8, X_OUT = 9, X_HORNER = 43,
     X_ADD = 10, X_SUB = 11, X_MUL = 12, X_DIV = 13, X_NEG = 14, X_POW = 15, X_POWI = 16,
     X_SQRT = 20, X_EXP = 21, X_LOG = 22, X_SIN = 23, X_COS = 24, X_TAN = 25, X_ASIN = 26, X_ACOS = 27, X_ATAN = 28,
     X_SINH = 29, X_COSH = 30, X_TANH = 31, X_ERF = 32, X_ERFC = 33, X_ABS = 34, X_FLOOR = 35, X_CEIL = 36,

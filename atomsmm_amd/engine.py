@@ -882,7 +882,12 @@ class Engine:
                 return []
             record = classes_of(parameters)
             if len(record) < 5:          # (made once per set of offset parameters, like the interpolant)
-                record.append([float(c) for c in np.polynomial.chebyshev.cheb2poly(on_unit_interval(parameters)[1].coef)])
+                cheb = np.array(on_unit_interval(parameters)[1].coef, dtype=np.float64)
+                # (the trailing Chebyshev terms of an analytic function are below rounding: |T_k| <= 1 bounds what is dropped)
+                keep = len(cheb)
+                while keep > 1 and np.abs(cheb[keep - 1:]).sum() < 1e-15 * np.abs(cheb).max():
+                    keep -= 1
+                record.append([float(c) for c in np.polynomial.chebyshev.cheb2poly(cheb[:keep])])
             scale = parameters[scale_name] if scale_name else 1.0
             return record[4] if scale == 1.0 else [c * scale for c in record[4]]
 
@@ -2028,19 +2033,14 @@ class Engine:
                         settle()
                     slot = self._pending[1]
                     self._pending[1] += 1
+                    lam = self.parameters[sc['lambda_name']]
+                    # (lambda is a device scalar: so is the correction's derivative at it -- queued first: one launch with the block that moved lambda)
+                    correction = self._lrc_derivative_on_device(sc, lam, settle) if isinstance(lam, X.Deferred) else None
                     self._flush_scalars()                 # (lambda itself may be an assignment still queued)
                     self.ctx.pair_energy_derivative(sc['pid'], self.x, self._pending[0][slot:slot + 1])
-                    lam = self.parameters[sc['lambda_name']]
-                    if isinstance(lam, X.Deferred):       # lambda is a device scalar: so is the correction's derivative at it
-                        coef = sc['derivative_polynomial'](self.parameters)
-                        if coef:
-                            key = (sc['pid'], tuple(sorted(lam.terms.items())), lam.const)
-                            if key not in self._lrc_on_device:
-                                text = repr(coef[-1])
-                                for c in reversed(coef[:-1]):
-                                    text = '(%s)*u+%r' % (text, c)
-                                self._lrc_on_device = {key: self._eval_global_on_device(text + '; u = 2*lam-1', {'lam': lam}, None, settle)}
-                            value = value + self._lrc_on_device[key]
+                    if isinstance(lam, X.Deferred):
+                        if correction is not None:
+                            value = value + correction
                         value = value + X.Deferred(0.0, {slot: 1.0})
                     else:
                         value = value + X.Deferred(sc['constant_derivative'](self.parameters), {slot: 1.0})
@@ -2065,15 +2065,17 @@ class Engine:
         """A global expression whose operands wait on device results, evaluated by one thread on the stream (amm_expr_eval_scalar):
         its value is a new device scalar, the host goes on without it (AFED: integrators.py:701-737, the extended variable's move,
         walls and thermostat).  Returns the Deferred that names the scalar."""
-        prog = X.compile_scalar(expr, env, rng, predicate, keep)
+        return self._queue_scalar(X.compile_scalar(expr, env, rng, predicate, keep), settle)
+
+    def _queue_scalar(self, prog, settle):
         self.n_scalar_evals += 1
         slot = self._scalar_slot(settle)
         # queued: consecutive assignments go out as ONE launch (_flush_scalars: before anything that reads a scalar is enqueued)
         if len(self._scalar_code) + len(prog.code) + 1 > 640 or len(self._scalar_consts) + len(prog.consts) > 96:
             self._flush_scalars()
         base = len(self._scalar_consts)
-        const_op = X.OPCODES['CONST']
-        self._scalar_code += [w + (base << 8) if (w & 0xff) == const_op else w for w in prog.code]
+        const_ops = (X.OPCODES['CONST'], X.OPCODES['HORNER'])      # (words whose argument is a constant's index)
+        self._scalar_code += [w + (base << 8) if (w & 0xff) in const_ops else w for w in prog.code]
         self._scalar_code.append(X.OPCODES['OUT'] | (slot << 8))
         self._scalar_consts += prog.consts
         return X.Deferred(0.0, {slot: 1.0})
@@ -2083,6 +2085,17 @@ class Engine:
             self.ctx.expr_eval_scalar(self._scalar_code, self._scalar_consts, self._pending[0])
             self.n_scalar_launches += 1
             self._scalar_code, self._scalar_consts = [], []
+
+    def _lrc_derivative_on_device(self, sc, lam, settle):
+        """d(long-range correction)/d(lambda) of a softcore force at a lambda that is a device scalar: the interpolant's monomial form
+        in u = 2 lambda - 1, Horner, as one more assignment (queued with the block that moved lambda: no launch of its own)."""
+        coef = sc['derivative_polynomial'](self.parameters)
+        if not coef:
+            return None
+        key = (sc['pid'], tuple(sorted(lam.terms.items())), lam.const)
+        if key not in self._lrc_on_device:
+            self._lrc_on_device[key] = self._queue_scalar(X.compile_polynomial(coef, 2.0, -1.0, lam), settle)
+        return self._lrc_on_device[key]
 
     def _parameter_to_device(self, name, value, settle):
         """context.setParameter(name, <a device scalar>): possible when every force that depends on the parameter is a softcore
@@ -2221,8 +2234,8 @@ class Engine:
             def flush():
                 # (a run of per-DOF steps that is being recorded as one unit is no unit any more: the ops before the flush are gone)
                 self._segment_open = None
-                self._flush_scalars()         # (assignments to device scalars queued so far: the launches below may read them)
                 if ops:
+                    self._flush_scalars()     # (assignments to device scalars queued so far: the launches below may read them)
                     # a RESPA block between two host-evaluated steps is a static run of ops: pair the near and the outer
                     # evaluation of one list into a single traversal, as the compiled path does
                     self._run(self._pair_up_evals(list(ops)), 1, cache=False)

@@ -17,7 +17,7 @@ OPCODES = dict(
     CONST=0, GLOBAL=1, BUF=2, MASS=3, GAUSS=4, UNIFORM=5, LOAD=6, STORE=7, DEVG=8, OUT=9,
     ADD=10, SUB=11, MUL=12, DIV=13, NEG=14, POW=15, POWI=16,
     sqrt=20, exp=21, log=22, sin=23, cos=24, tan=25, asin=26, acos=27, atan=28, sinh=29, cosh=30, tanh=31, erf=32,
-    erfc=33, abs=34, floor=35, ceil=36, step=37, delta=38, min=39, max=40, select=41, atan2=42)
+    erfc=33, abs=34, floor=35, ceil=36, step=37, delta=38, min=39, max=40, select=41, atan2=42, HORNER=43)
 _ARITY = {'min': 2, 'max': 2, 'select': 3, 'atan2': 2}
 MAX_LOCALS = 16
 
@@ -216,6 +216,32 @@ def compile_per_dof(text, resolve):
             raise ExpressionError('unsupported syntax in expression: ' + ast.dump(node))
 
     gen(_parse(main))
+    return prog
+
+
+def compile_polynomial(coefficients, scale, shift, operand):
+    """Scalar program (amm_expr_eval_scalar) for sum_k coefficients[k] * u^k with u = scale * operand + shift: the first local holds u,
+    one HORNER word per coefficient (top <- top * u + c)."""
+    prog = Program()
+    if isinstance(operand, Deferred):
+        prog.emit('CONST', prog.const(operand.const))
+        for k, coef in sorted(operand.terms.items()):
+            prog.emit('DEVG', k)
+            if coef != 1.0:
+                prog.emit('CONST', prog.const(coef))
+                prog.emit('MUL')
+            prog.emit('ADD')
+    else:
+        prog.emit('CONST', prog.const(float(operand)))
+    prog.emit('CONST', prog.const(scale))
+    prog.emit('MUL')
+    prog.emit('CONST', prog.const(shift))
+    prog.emit('ADD')
+    prog.emit('STORE', 0)
+    prog.emit('CONST', prog.const(coefficients[-1]))
+    for c in reversed(coefficients[:-1]):
+        prog.consts.append(float(c))          # (no search for equal constants: their order is the polynomial's)
+        prog.emit('HORNER', len(prog.consts) - 1)
     return prog
 
 
