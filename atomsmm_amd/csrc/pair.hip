@@ -2223,9 +2223,9 @@ int amm_pair_count_within_impl(amm_ctx *ctx, PairForce *pf, const double *d_pos,
 extern "C" __attribute__((weak)) const char *amm_variant_tag(void);
 const char *amm_kernel_revision_impl() {
 #ifdef AMM_CLUSTER_TUNE
-    return "r05-epi4-tune";
+    return "r05-epi5-tune";
 #else
-    return amm_variant_tag ? "r05-epi4-tune" : "r05-epi4";
+    return amm_variant_tag ? "r05-epi5-tune" : "r05-epi5";
 #endif
 }
 
