@@ -366,3 +366,24 @@ def test_afed_scalar_block_on_the_device(lam, v_lam):
     assert dev[1] == pytest.approx(ref.lam, abs=1e-9) and dev[2] == pytest.approx(ref.v_lam, rel=1e-6, abs=1e-9)
     if lam > 0.99:
         assert 0.9 < dev[1] < 1.0 and dev[2] < 1.0           # it bounced off the wall at 1 in the first half move (0.9985 + 0.002 x 2.0 > 1)
+
+
+def test_afed_scalars_survive_a_full_buffer(monkeypatch):
+    """The device scalars of a host-walked program are a finite buffer: when it runs full in the middle of a step() call the engine reads it
+    (one blocking read), hands the library lambda's number back and starts over.  With room for 160 scalars instead of 2 048 that happens
+    every few AFED steps: 20 steps in one call end where the waiting path ends."""
+    from atomsmm_amd import engine as E
+    case = solvated_chain(nside=12, n_chain=300, n_solute=30)
+    out = {}
+    for mode in (True, False):
+        monkeypatch.setattr(E, '_SCALARS', 160 if mode else 2048)
+        context, integrator = _afed_context(case, 0.7, -0.3, mode)
+        eng = context._engine
+        integrator.step(20)
+        out[mode] = (context.getState(getPositions=True).getPositions(asNumpy=True)._value, context.getParameter('lambda_vdw'),
+                     integrator.getGlobalVariableByName('_v_lambda_vdw'), eng.n_settles, eng.n_scalar_evals)
+        eng.ctx.check()
+    dev, host = out[True], out[False]
+    assert dev[4] > 100 and 3 <= dev[3] < host[3]             # several reads forced by the full buffer, still fewer than one per step
+    assert np.abs(dev[0] - host[0]).max() < 1e-9
+    assert dev[1] == pytest.approx(host[1], abs=1e-10) and dev[2] == pytest.approx(host[2], rel=1e-8, abs=1e-10)
