@@ -2666,10 +2666,12 @@ int amm_cluster_free(ClusterList *cl) {
 #ifdef AMM_CBS_TIMING
     {
         unsigned long long t[8];
-        if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_cbs_t), sizeof(t)) == hipSuccess && t[7])
+        // (measurement builds: the clocks of the slice's list build -- the two kernels use the slots differently)
+        const bool got = hipMemcpyFromSymbol(t, HIP_SYMBOL(g_cbs_t), sizeof(t)) == hipSuccess && t[7];
+        if (got && cl->split_parts == 0)
             fprintf(stderr, "k_cbuild<SLICE>: %llu busy wavefronts, mean: prologue %.2f us, whole %.2f us, in drains %.2f us (%.2f drains)\n", t[7], t[0] / 100.0 / t[7],
                     t[1] / 100.0 / t[7], t[2] / 100.0 / t[7], (double)t[3] / t[7]);
-        if (0)
+        if (got && cl->split_parts > 0)
             fprintf(stderr, "k_cbuild_split, first wavefront of %llu busy blocks, mean clocks (100 MHz): prologue %.2f | pass 1 %.2f wait %.2f | pass 2 %.2f wait %.2f | copy %.2f wait %.2f us\n",
                     t[7], t[0] / 100.0 / t[7], t[1] / 100.0 / t[7], t[2] / 100.0 / t[7], t[3] / 100.0 / t[7], t[4] / 100.0 / t[7], t[5] / 100.0 / t[7], t[6] / 100.0 / t[7]);
     }
